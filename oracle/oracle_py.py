@@ -1,0 +1,264 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/liboracle*.so (the CPU restatement of the reference path).  Importable only from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg — never from the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False):
+    """Compile the oracle (and oracle/_ref when /root/reference is present)."""
+    need = force or not all(os.path.exists(os.path.join(_HERE, f)) for f in ("liboracle.so", "liboracle_fast.so"))
+    if need or os.path.exists("/root/reference"):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _pts(a):
+    a = _f32(a)
+    if a.ndim == 1:
+        a = a.reshape(-1, 4)
+    assert a.shape[1] == 4
+    return a
+
+
+class Oracle:
+    def __init__(self, fast: bool = False):
+        path = os.path.join(_HERE, "liboracle_fast.so" if fast else "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = self.L = C.CDLL(path)
+        vp = C.c_void_p
+        L.orc_voxel_grid.restype = C.c_int
+        for name in ("orc_scanreg_create", "orc_odom_create", "orc_map_create"):
+            getattr(L, name).restype = vp
+        for name in ("orc_scanreg_get", "orc_odom_get_cloud", "orc_map_get_cloud", "orc_map_process",
+                     "orc_map_has_fresh_map", "orc_map_residual_pass", "orc_inv6", "orc_degeneracy"):
+            getattr(L, name).restype = C.c_int
+
+    # ---- primitives
+    def voxel_grid(self, pts, leaf):
+        pts = _pts(pts)
+        out = np.zeros((max(len(pts), 1), 4), np.float32)
+        n = self.L.orc_voxel_grid(pts.ctypes.data_as(C.c_void_p), len(pts), C.c_float(leaf),
+                                  out.ctypes.data_as(C.c_void_p), len(out))
+        return out[:n].copy()
+
+    def knn(self, pts, queries, k, brute=False):
+        pts, q = _pts(pts), _pts(queries)
+        idx = np.zeros((len(q), k), np.int32)
+        d2 = np.zeros((len(q), k), np.float32)
+        self.L.orc_knn(pts.ctypes.data_as(C.c_void_p), len(pts), q.ctypes.data_as(C.c_void_p), len(q), k,
+                       idx.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p), 1 if brute else 0)
+        return idx, d2
+
+    def eig(self, A):
+        A = _f32(A)
+        n = A.shape[0]
+        w = np.zeros(n, np.float32)
+        V = np.zeros((n, n), np.float32)
+        fn = self.L.orc_eig3 if n == 3 else self.L.orc_eig6
+        fn(A.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), V.ctypes.data_as(C.c_void_p))
+        return w, V
+
+    def qr_solve(self, A, b):
+        A, b = _f32(A), _f32(b)
+        x = np.zeros(A.shape[1], np.float32)
+        fn = self.L.orc_qr53 if A.shape == (5, 3) else self.L.orc_qr66
+        fn(A.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p))
+        return x
+
+    def inv6(self, A):
+        A = _f32(A)
+        out = np.zeros((6, 6), np.float32)
+        ok = self.L.orc_inv6(A.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out, bool(ok)
+
+    def degeneracy(self, AtA, thr):
+        AtA = _f32(AtA)
+        P = np.zeros((6, 6), np.float32)
+        d = self.L.orc_degeneracy(AtA.ctypes.data_as(C.c_void_p), C.c_float(thr), P.ctypes.data_as(C.c_void_p))
+        return bool(d), P
+
+    def rotate_zxy(self, p, rz, rx, ry):
+        p = _f32(p).copy()
+        self.L.orc_rotate_zxy(p.ctypes.data_as(C.c_void_p), C.c_float(rz), C.c_float(rx), C.c_float(ry))
+        return p
+
+
+def _get_cloud(fn, h, which, cap_hint=0):
+    n = fn(h, which, None, 0)
+    out = np.zeros((max(n, 1), 4), np.float32)
+    fn(h, which, out.ctypes.data_as(C.c_void_p), n)
+    return out[:n].copy()
+
+
+class ScanRegistration:
+    """oracle restatement of BasicScanRegistration (IMU-less)."""
+    NAMES = ("full", "sharp", "less_sharp", "flat", "less_flat")
+
+    def __init__(self, orc: Oracle, **cfg):
+        self.o = orc
+        self.h = C.c_void_p(orc.L.orc_scanreg_create())
+        c = dict(scanPeriod=0.1, nFeatureRegions=6, curvatureRegion=5, maxCornerSharp=2, maxSurfaceFlat=4,
+                 lessFlatFilterSize=0.2, surfaceCurvatureThreshold=0.1)
+        c.update(cfg)
+        orc.L.orc_scanreg_config(self.h, C.c_float(c["scanPeriod"]), c["nFeatureRegions"], c["curvatureRegion"],
+                                 c["maxCornerSharp"], c["maxSurfaceFlat"], C.c_float(c["lessFlatFilterSize"]),
+                                 C.c_float(c["surfaceCurvatureThreshold"]))
+
+    def __del__(self):
+        self.o.L.orc_scanreg_destroy(self.h)
+
+    def process(self, pts, ring_sizes):
+        pts = _pts(pts)
+        rs = np.ascontiguousarray(ring_sizes, np.int32)
+        self.o.L.orc_scanreg_process(self.h, pts.ctypes.data_as(C.c_void_p), rs.ctypes.data_as(C.c_void_p), len(rs))
+        return {n: _get_cloud(self.o.L.orc_scanreg_get, self.h, k) for k, n in enumerate(self.NAMES)}
+
+
+class LaserOdometry:
+    def __init__(self, orc: Oracle, scanPeriod=0.1, maxIterations=25, deltaTAbort=0.1, deltaRAbort=0.1):
+        self.o = orc
+        self.h = C.c_void_p(orc.L.orc_odom_create())
+        orc.L.orc_odom_config(self.h, C.c_float(scanPeriod), maxIterations, C.c_float(deltaTAbort), C.c_float(deltaRAbort))
+
+    def __del__(self):
+        self.o.L.orc_odom_destroy(self.h)
+
+    def set_features(self, f):
+        for k, n in enumerate(ScanRegistration.NAMES):
+            p = _pts(f[n])
+            self.o.L.orc_odom_set_cloud(self.h, k, p.ctypes.data_as(C.c_void_p), len(p))
+
+    def set_transform(self, t6):
+        t6 = _f32(t6)
+        self.o.L.orc_odom_set_transform(self.h, t6.ctypes.data_as(C.c_void_p))
+
+    def process(self):
+        self.o.L.orc_odom_process(self.h)
+
+    def _t(self, fn):
+        t = np.zeros(6, np.float32)
+        fn(self.h, t.ctypes.data_as(C.c_void_p))
+        return t
+
+    @property
+    def transform(self):
+        return self._t(self.o.L.orc_odom_get_transform)
+
+    @property
+    def transform_sum(self):
+        return self._t(self.o.L.orc_odom_get_transform_sum)
+
+    def last_corner(self):
+        return _get_cloud(self.o.L.orc_odom_get_cloud, self.h, 0)
+
+    def last_surf(self):
+        return _get_cloud(self.o.L.orc_odom_get_cloud, self.h, 1)
+
+    def full_to_end(self):
+        self.o.L.orc_odom_transform_full_to_end(self.h)
+        return _get_cloud(self.o.L.orc_odom_get_cloud, self.h, 2)
+
+    def stats(self):
+        s = np.zeros(3, np.int32)
+        self.o.L.orc_odom_stats(self.h, s.ctypes.data_as(C.c_void_p))
+        return dict(iterations=int(s[0]), sel=int(s[1]), frame=int(s[2]))
+
+
+class LaserMapping:
+    CLOUDS = ("full_res", "surround_ds", "corner_from_map", "surf_from_map", "corner_stack_ds", "surf_stack_ds",
+              "corner_cubes", "surf_cubes")
+
+    def __init__(self, orc: Oracle, scanPeriod=0.1, maxIterations=10, deltaTAbort=0.05, deltaRAbort=0.05,
+                 cornerLeaf=0.2, surfLeaf=0.4):
+        self.o = orc
+        self.h = C.c_void_p(orc.L.orc_map_create())
+        orc.L.orc_map_config(self.h, C.c_float(scanPeriod), maxIterations, C.c_float(deltaTAbort),
+                             C.c_float(deltaRAbort), C.c_float(cornerLeaf), C.c_float(surfLeaf))
+
+    def __del__(self):
+        self.o.L.orc_map_destroy(self.h)
+
+    def set_inputs(self, corner_last, surf_last, full_res, transform_sum):
+        for k, p in enumerate((corner_last, surf_last, full_res)):
+            p = _pts(p)
+            self.o.L.orc_map_set_cloud(self.h, k, p.ctypes.data_as(C.c_void_p), len(p))
+        t = _f32(transform_sum)
+        self.o.L.orc_map_update_odometry(self.h, t.ctypes.data_as(C.c_void_p))
+
+    def process(self):
+        return bool(self.o.L.orc_map_process(self.h))
+
+    def transform(self, which="aft"):
+        t = np.zeros(6, np.float32)
+        self.o.L.orc_map_get_transform(self.h, ("aft", "bef", "tobe", "sum").index(which), t.ctypes.data_as(C.c_void_p))
+        return t
+
+    def set_transform(self, which, t6):
+        t6 = _f32(t6)
+        self.o.L.orc_map_set_transform(self.h, ("aft", "bef", "tobe", "sum").index(which), t6.ctypes.data_as(C.c_void_p))
+
+    def cloud(self, name):
+        return _get_cloud(self.o.L.orc_map_get_cloud, self.h, self.CLOUDS.index(name))
+
+    def has_fresh_map(self):
+        return bool(self.o.L.orc_map_has_fresh_map(self.h))
+
+    def load_cubes(self, corner, surf):
+        c, s = _pts(corner), _pts(surf)
+        self.o.L.orc_map_load_cubes(self.h, c.ctypes.data_as(C.c_void_p), len(c), s.ctypes.data_as(C.c_void_p), len(s))
+
+    def set_frozen(self, corner, surf):
+        c, s = _pts(corner), _pts(surf)
+        self.o.L.orc_map_set_frozen(self.h, c.ctypes.data_as(C.c_void_p), len(c), s.ctypes.data_as(C.c_void_p), len(s))
+
+    def register_frozen(self, corner_last, surf_last, guess6):
+        for k, p in enumerate((corner_last, surf_last)):
+            p = _pts(p)
+            self.o.L.orc_map_set_cloud(self.h, k, p.ctypes.data_as(C.c_void_p), len(p))
+        g = _f32(guess6)
+        pose = np.zeros(6, np.float32)
+        self.o.L.orc_map_register_frozen(self.h, g.ctypes.data_as(C.c_void_p), pose.ctypes.data_as(C.c_void_p))
+        return pose
+
+    def residual_pass(self, pose6, cap=200000):
+        p = _f32(pose6)
+        ori = np.zeros((cap, 4), np.float32)
+        co = np.zeros((cap, 4), np.float32)
+        n = self.o.L.orc_map_residual_pass(self.h, p.ctypes.data_as(C.c_void_p), ori.ctypes.data_as(C.c_void_p),
+                                           co.ctypes.data_as(C.c_void_p), cap)
+        return ori[:n].copy(), co[:n].copy()
+
+    def stats(self):
+        s = np.zeros(8, np.int32)
+        self.o.L.orc_map_stats(self.h, s.ctypes.data_as(C.c_void_p))
+        keys = ("iterations", "sel", "corner_ds", "surf_ds", "corner_from_map", "surf_from_map", "degenerate", "optimized")
+        return dict(zip(keys, (int(v) for v in s)))
+
+
+def ref_knn(pts, queries, k):
+    """kNN through the REFERENCE's own nanoflann.hpp (oracle/_ref); None when the shim is not built."""
+    path = os.path.join(_HERE, "_ref", "libref_nanoflann.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    pts, q = _pts(pts), _pts(queries)
+    idx = np.zeros((len(q), k), np.int32)
+    d2 = np.zeros((len(q), k), np.float32)
+    L.ref_knn(pts.ctypes.data_as(C.c_void_p), len(pts), q.ctypes.data_as(C.c_void_p), len(q), k,
+              idx.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p))
+    return idx, d2

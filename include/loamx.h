@@ -1,0 +1,198 @@
+/* loamx — C-ABI of the MI355X-native LOAM registration hot path.
+ *
+ * One opaque handle per reference class on the path; every entry point below is what a binding of that class
+ * would call.  The reference interfaces replaced (all under /root/reference):
+ *
+ *   loamx_scanreg_*  <->  loam::BasicScanRegistration   include/loam_velodyne/BasicScanRegistration.h:135-163
+ *                                                        (processScanlines src/lib/BasicScanRegistration.cpp:28-46,
+ *                                                         extractFeatures :155-254, RegistrationParams .h:34-72)
+ *   loamx_odom_*     <->  loam::BasicLaserOdometry      include/loam_velodyne/BasicLaserOdometry.h:16-48
+ *                                                        (process src/lib/BasicLaserOdometry.cpp:196-666,
+ *                                                         transformToEnd :57-87, updateIMU :181-194)
+ *   loamx_map_*      <->  loam::BasicLaserMapping       include/loam_velodyne/BasicLaserMapping.h:80-111
+ *                                                        (process src/lib/BasicLaserMapping.cpp:266-599,
+ *                                                         optimizeTransformTobeMapped :626-926,
+ *                                                         updateOdometry :607-621)
+ *   loamx_batch_*    new: the batched-sweep mode of BASELINE.json's north_star (independent sweeps against a frozen
+ *                    shared map) — the unit that is sharded across GPUs.
+ *
+ * Conventions
+ *  - Point clouds are caller-owned arrays of records with x,y,z float32 at byte offsets 0/4/8 and intensity float32
+ *    at byte offset `intensity_offset` of each record, `stride` bytes apart.  pcl::PointXYZI is {stride 32,
+ *    intensity_offset 16}; a packed float4 is {16, 12}.  Outputs are written with the same description.
+ *  - Poses are float[6] = rot_x (pitch), rot_y (yaw), rot_z (roll), x, y, z in the LOAM camera frame, rotation order
+ *    R = Ry*Rx*Rz (reference src/lib/math_utils.h:212-238).
+ *  - Return value: 0 = processed, 1 = skipped (mirrors the reference's `false` / silent guards), < 0 = error;
+ *    loamx_last_error() gives the text for the calling thread's last failing call.  No exception or abort crosses
+ *    the ABI.
+ *  - A handle is single-threaded (externally synchronised), owns its device memory and one HIP stream; calls are
+ *    synchronous unless named *_async.  No pointer returned by the library outlives the next call on that handle.
+ *  - The library needs a gfx950 GPU: creating a handle without one fails with LOAMX_E_NOGPU.  There is no CPU
+ *    fallback anywhere in the library.
+ */
+#ifndef LOAMX_H
+#define LOAMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOAMX_OK 0
+#define LOAMX_SKIPPED 1
+#define LOAMX_E_INVALID (-1)
+#define LOAMX_E_CAPACITY (-2)
+#define LOAMX_E_HIP (-3)
+#define LOAMX_E_NOGPU (-4)
+
+/* caller-owned cloud description (input or output) */
+typedef struct loamx_cloud {
+  void* data;                /* first record */
+  uint32_t count;            /* in: number of points (input) / capacity (output); out: points written */
+  uint32_t stride;           /* bytes between records, >= 16 */
+  uint32_t intensity_offset; /* byte offset of the float32 intensity inside a record (12 or 16) */
+  uint32_t reserved;
+} loamx_cloud;
+
+const char* loamx_last_error(void);
+/* number of visible HIP devices (0 if none / HIP unavailable); never fails */
+int loamx_device_count(void);
+/* ABI version of this header */
+#define LOAMX_ABI_VERSION 1
+int loamx_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Feature extraction  (BasicScanRegistration, IMU-less path)
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct loamx_scanreg loamx_scanreg;
+
+/* mirrors loam::RegistrationParams (BasicScanRegistration.h:34-72, defaults .h:37-44) */
+typedef struct loamx_scanreg_config {
+  float scan_period;                 /* 0.1 */
+  int n_feature_regions;             /* 6 */
+  int curvature_region;              /* 5 */
+  int max_corner_sharp;              /* 2  (max_corner_less_sharp = 10x) */
+  int max_surface_flat;              /* 4 */
+  float less_flat_filter_size;       /* 0.2 */
+  float surface_curvature_threshold; /* 0.1 */
+  int device;                        /* HIP device ordinal */
+} loamx_scanreg_config;
+
+void loamx_scanreg_default_config(loamx_scanreg_config* cfg);
+loamx_scanreg* loamx_scanreg_create(const loamx_scanreg_config* cfg);
+void loamx_scanreg_destroy(loamx_scanreg* h);
+/* processScanlines: `cloud` holds the rings concatenated in ring order, ring r occupying ring_size[r] points.
+ * Outputs (any may be NULL): sharp, less_sharp, flat, less_flat; count fields return the sizes. */
+int loamx_scanreg_process(loamx_scanreg* h, const loamx_cloud* cloud, const uint32_t* ring_size, uint32_t n_rings,
+                          loamx_cloud* sharp, loamx_cloud* less_sharp, loamx_cloud* flat, loamx_cloud* less_flat);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Sweep-to-sweep odometry  (BasicLaserOdometry)
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct loamx_odom loamx_odom;
+
+typedef struct loamx_odom_config {
+  float scan_period;  /* 0.1  */
+  int max_iterations; /* 25   */
+  float delta_t_abort; /* 0.1 */
+  float delta_r_abort; /* 0.1 */
+  int device;
+} loamx_odom_config;
+
+void loamx_odom_default_config(loamx_odom_config* cfg);
+loamx_odom* loamx_odom_create(const loamx_odom_config* cfg);
+void loamx_odom_destroy(loamx_odom* h);
+/* updateIMU: 4 x (x,y,z) = pitch/yaw/roll start, pitch/yaw/roll end, shift from start, velocity from start */
+int loamx_odom_update_imu(loamx_odom* h, const float imu_trans[12]);
+/* process(): the four feature clouds of the current sweep.  The first call only initialises (reference
+ * BasicLaserOdometry.cpp:198-211). */
+int loamx_odom_process(loamx_odom* h, const loamx_cloud* sharp, const loamx_cloud* less_sharp, const loamx_cloud* flat,
+                       const loamx_cloud* less_flat);
+int loamx_odom_get_transform(loamx_odom* h, float transform[6]);
+int loamx_odom_get_transform_sum(loamx_odom* h, float transform_sum[6]);
+int loamx_odom_set_transform(loamx_odom* h, const float transform[6]);
+int loamx_odom_set_transform_sum(loamx_odom* h, const float transform_sum[6]);
+/* lastCornerCloud()/lastSurfaceCloud(): the re-projected feature clouds handed on to mapping */
+int loamx_odom_get_last_clouds(loamx_odom* h, loamx_cloud* last_corner, loamx_cloud* last_surf);
+/* transformToEnd(cloud): in place on a caller cloud, with the current transform */
+int loamx_odom_transform_to_end(loamx_odom* h, loamx_cloud* cloud);
+/* diagnostics: iterations entered / rows selected in the last iteration of the last process() */
+int loamx_odom_get_stats(loamx_odom* h, int stats[4]);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Scan-to-map registration  (BasicLaserMapping)
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct loamx_map loamx_map;
+
+typedef struct loamx_map_config {
+  float scan_period;     /* 0.1  */
+  int max_iterations;    /* 10   */
+  float delta_t_abort;   /* 0.05 */
+  float delta_r_abort;   /* 0.05 */
+  float corner_filter_size; /* 0.2 */
+  float surf_filter_size;   /* 0.4 */
+  float map_filter_size;    /* kept for API parity; unused by the reference as well (BasicLaserMapping.cpp:261) */
+  int device;
+} loamx_map_config;
+
+void loamx_map_default_config(loamx_map_config* cfg);
+loamx_map* loamx_map_create(const loamx_map_config* cfg);
+void loamx_map_destroy(loamx_map* h);
+int loamx_map_update_odometry(loamx_map* h, const float transform_sum[6]);
+/* process(): corner_last / surf_last in, full_res registered in place (transformFullResToMap). */
+int loamx_map_process(loamx_map* h, const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res);
+/* which: 0 transformAftMapped, 1 transformBefMapped, 2 transformTobeMapped, 3 transformSum */
+int loamx_map_get_transform(loamx_map* h, int which, float transform[6]);
+int loamx_map_set_transform(loamx_map* h, int which, const float transform[6]);
+int loamx_map_has_fresh_map(loamx_map* h);
+/* laserCloudSurroundDS() */
+int loamx_map_get_surround(loamx_map* h, loamx_cloud* out);
+/* test / warm-start hook: insert map-frame points straight into the rolling cube grid (by coordinate) */
+int loamx_map_load_cubes(loamx_map* h, const loamx_cloud* corner, const loamx_cloud* surf);
+/* dump the whole map: which 0 = corner cubes, 1 = surf cubes */
+int loamx_map_get_cubes(loamx_map* h, int which, loamx_cloud* out);
+/* diagnostics of the last process(): iterations, rows selected, corner queries, surf queries, corner sub-map size,
+ * surf sub-map size, degenerate flag, optimised flag */
+int loamx_map_get_stats(loamx_map* h, int stats[8]);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Batched-sweep mode: B independent sweeps registered against one frozen sub-map.
+ *   set_frozen[_device]  -> upload (or adopt) the sub-map and build its spatial index once per map epoch
+ *   upload               -> stage the B sweeps' corner_last / surf_last (+ optional full-resolution) clouds in HBM
+ *   run                  -> device only: stack round trip, voxel down-sampling, <= max_iterations Gauss-Newton
+ *                           iterations per sweep, registration of the full-resolution clouds
+ *   download             -> poses + per-sweep stats (+ optionally the registered clouds)
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct loamx_batch loamx_batch;
+
+loamx_batch* loamx_batch_create(const loamx_map_config* cfg, uint32_t max_sweeps);
+void loamx_batch_destroy(loamx_batch* h);
+int loamx_batch_set_frozen(loamx_batch* h, const loamx_cloud* corner_map, const loamx_cloud* surf_map);
+/* device-resident packed float4 (x,y,z,intensity) arrays, e.g. the buffers an RCCL broadcast just filled */
+int loamx_batch_set_frozen_device(loamx_batch* h, const void* d_corner_xyzi, uint32_t n_corner, const void* d_surf_xyzi,
+                                  uint32_t n_surf);
+/* sweep s uses corner_last[s], surf_last[s], full_res[s] (full_res may be NULL) and guess[s][6] =
+ * initial transformTobeMapped */
+int loamx_batch_upload(loamx_batch* h, uint32_t n_sweeps, const loamx_cloud* corner_last, const loamx_cloud* surf_last,
+                       const loamx_cloud* full_res, const float* guess6);
+int loamx_batch_run(loamx_batch* h);
+int loamx_batch_run_async(loamx_batch* h);
+int loamx_batch_sync(loamx_batch* h);
+/* poses6: n_sweeps x 6; stats: n_sweeps x 4 ints (iterations, rows selected, corner queries, surf queries);
+ * either may be NULL */
+int loamx_batch_download(loamx_batch* h, float* poses6, int* stats4);
+int loamx_batch_download_full_res(loamx_batch* h, uint32_t sweep, loamx_cloud* out);
+/* kernel-level timing of the last run(): ms[0] = whole run, ms[1] = sum of residual-kernel launches,
+ * counts[0] = residual launches, counts[1] = total query-iterations executed, counts[2] = total DS queries */
+/* record HIP events around every residual launch of the next run()s (off by default) */
+int loamx_batch_set_timing(loamx_batch* h, int on);
+int loamx_batch_get_timing(loamx_batch* h, float ms[4], uint64_t counts[4]);
+/* raw HIP stream of the handle (hipStream_t) so a harness can bracket it with its own events */
+void* loamx_batch_stream(loamx_batch* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOAMX_H */

@@ -1,0 +1,27 @@
+// Process-wide pieces of the C-ABI: last-error slot, device selection, version.
+#include "common.h"
+
+namespace loamx {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+
+void select_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw Error(LOAMX_E_NOGPU, "no HIP device visible: libloamx has no CPU fallback (hipGetDeviceCount: " +
+                                   std::string(e == hipSuccess ? "0 devices" : hipGetErrorString(e)) + ")");
+  if (device < 0 || device >= n) throw Error(LOAMX_E_INVALID, "device ordinal out of range");
+  LX_HIP(hipSetDevice(device));
+}
+}  // namespace loamx
+
+extern "C" {
+const char* loamx_last_error(void) { return loamx::g_last_error.c_str(); }
+int loamx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int loamx_abi_version(void) { return LOAMX_ABI_VERSION; }
+}

@@ -1,0 +1,124 @@
+// Shared host/device definitions of libloamx (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include "../../include/loamx.h"
+
+namespace loamx {
+
+// ---- error plumbing: exceptions never cross the ABI; each extern "C" entry wraps its body in guard() ------------
+void set_last_error(const std::string& s);
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string& s) : std::runtime_error(s), code(c) {}
+};
+#define LX_HIP(expr)                                                                                         \
+  do {                                                                                                       \
+    hipError_t e_ = (expr);                                                                                  \
+    if (e_ != hipSuccess)                                                                                    \
+      throw ::loamx::Error(LOAMX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                                            ":" + std::to_string(__LINE__) + ")");                          \
+  } while (0)
+#define LX_REQUIRE(cond, msg)                                         \
+  do {                                                                \
+    if (!(cond)) throw ::loamx::Error(LOAMX_E_INVALID, (msg));        \
+  } while (0)
+
+template <class F> int guard(F&& f) {
+  try {
+    return f();
+  } catch (const Error& e) {
+    set_last_error(e.what());
+    return e.code;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return LOAMX_E_INVALID;
+  } catch (...) {
+    set_last_error("unknown error");
+    return LOAMX_E_INVALID;
+  }
+}
+
+// ---- device buffer with grow-only capacity ------------------------------------------------------------------------
+template <class T> struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  // grow (contents discarded unless keep)
+  void reserve(size_t n, hipStream_t st = nullptr, bool keep = false) {
+    if (n <= cap) return;
+    size_t ncap = n + n / 4 + 64;
+    T* np = nullptr;
+    LX_HIP(hipMalloc((void**)&np, ncap * sizeof(T)));
+    if (keep && p && cap) {
+      LX_HIP(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st));
+      LX_HIP(hipStreamSynchronize(st));
+    }
+    if (p) (void)hipFree(p);
+    p = np;
+    cap = ncap;
+  }
+};
+
+// pinned host staging buffer
+template <class T> struct PinBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  ~PinBuf() {
+    if (p) (void)hipHostFree(p);
+  }
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (p) (void)hipHostFree(p);
+    cap = n + n / 4 + 64;
+    LX_HIP(hipHostMalloc((void**)&p, cap * sizeof(T), hipHostMallocDefault));
+  }
+};
+
+// ---- packing between caller records and the device float4 layout ------------------------------------------------
+inline void check_cloud(const loamx_cloud* c, bool allow_null_data = true) {
+  LX_REQUIRE(c != nullptr, "cloud descriptor is NULL");
+  LX_REQUIRE(c->stride >= 16 && (c->stride % 4) == 0, "cloud stride must be a multiple of 4 and >= 16");
+  LX_REQUIRE(c->intensity_offset >= 12 && c->intensity_offset + 4 <= c->stride && (c->intensity_offset % 4) == 0,
+             "cloud intensity_offset must be 4-aligned, >= 12 and inside the record");
+  LX_REQUIRE(allow_null_data || c->data != nullptr || c->count == 0, "cloud data is NULL");
+}
+inline void pack_cloud(const loamx_cloud* c, float4* dst) {
+  const char* src = (const char*)c->data;
+  for (uint32_t i = 0; i < c->count; i++) {
+    const float* r = (const float*)(src + (size_t)i * c->stride);
+    dst[i] = make_float4(r[0], r[1], r[2], *(const float*)((const char*)r + c->intensity_offset));
+  }
+}
+// writes min(n, capacity) points; returns LOAMX_E_CAPACITY (after writing what fits) when n > capacity
+inline int unpack_cloud(const float4* src, uint32_t n, loamx_cloud* c) {
+  uint32_t cap = c->count;
+  uint32_t m = n < cap ? n : cap;
+  char* dst = (char*)c->data;
+  for (uint32_t i = 0; i < m; i++) {
+    float* r = (float*)(dst + (size_t)i * c->stride);
+    r[0] = src[i].x; r[1] = src[i].y; r[2] = src[i].z;
+    if (c->stride >= 32 && c->intensity_offset == 16) r[3] = 1.0f;   // PCL's homogeneous w
+    *(float*)((char*)r + c->intensity_offset) = src[i].w;
+  }
+  c->count = n;
+  return n > cap ? LOAMX_E_CAPACITY : LOAMX_OK;
+}
+
+void select_device(int device);   // throws LOAMX_E_NOGPU
+
+}  // namespace loamx

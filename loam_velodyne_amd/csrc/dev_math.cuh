@@ -1,0 +1,332 @@
+// Device-side scalar math of the registration path (gfx950).  float32 with the reference's double promotions;
+// compiled with -ffp-contract=off so a*b+c is two roundings exactly as written in the reference expressions.
+//   Pose / rotations        <-> reference include/loam_velodyne/Angle.h:16-67, src/lib/math_utils.h:129-275
+//   eig3_sym (Jacobi)       <-> Eigen::SelfAdjointEigenSolver<Matrix3f> at BasicLaserMapping.cpp:695-697
+//   qr_solve (col. pivoted) <-> colPivHouseholderQr().solve at BasicLaserMapping.cpp:768, :867, BasicLaserOdometry.cpp:559
+//   eig6 / inverse6 / projector <-> BasicLaserMapping.cpp:869-899, BasicLaserOdometry.cpp:561-591
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+
+namespace loamx {
+
+// A pose with the cached float sin/cos the reference's Angle carries.
+struct Pose {
+  float rx, ry, rz, tx, ty, tz;
+  float srx, crx, sry, cry, srz, crz;
+};
+
+// correctly-rounded float sin/cos through double (matches glibc sinf/cosf on all but a vanishing set of inputs)
+__host__ __device__ inline void pose_set_angles(Pose& p, float rx, float ry, float rz) {
+  p.rx = rx; p.ry = ry; p.rz = rz;
+  p.srx = (float)sin((double)rx); p.crx = (float)cos((double)rx);
+  p.sry = (float)sin((double)ry); p.cry = (float)cos((double)ry);
+  p.srz = (float)sin((double)rz); p.crz = (float)cos((double)rz);
+}
+
+// rotX/rotY/rotZ with explicit (cos, sin) — math_utils.h:129-201
+__host__ __device__ inline void rot_x(float& y, float& z, float c, float s) {
+  float y0 = y;
+  y = c * y0 - s * z;
+  z = s * y0 + c * z;
+}
+__host__ __device__ inline void rot_y(float& x, float& z, float c, float s) {
+  float x0 = x;
+  x = c * x0 + s * z;
+  z = c * z - s * x0;
+}
+__host__ __device__ inline void rot_z(float& x, float& y, float c, float s) {
+  float x0 = x;
+  x = c * x0 - s * y;
+  y = s * x0 + c * y;
+}
+
+// pointAssociateToMap — BasicLaserMapping.cpp:207-219
+__host__ __device__ inline void to_map(const Pose& T, float& x, float& y, float& z) {
+  rot_z(x, y, T.crz, T.srz);
+  rot_x(y, z, T.crx, T.srx);
+  rot_y(x, z, T.cry, T.sry);
+  x += T.tx; y += T.ty; z += T.tz;
+}
+// pointAssociateTobeMapped — BasicLaserMapping.cpp:223-231 (negated angles: sine flips, cosine kept)
+__host__ __device__ inline void to_be_mapped(const Pose& T, float& x, float& y, float& z) {
+  x = x - T.tx; y = y - T.ty; z = z - T.tz;
+  rot_y(x, z, T.cry, -T.sry);
+  rot_x(y, z, T.crx, -T.srx);
+  rot_z(x, y, T.crz, -T.srz);
+}
+
+// ---- symmetric 3x3 eigen-decomposition, cyclic Jacobi.  In: lower triangle a00,a10,a11,a20,a21,a22.
+// Out: eigenvalues ascending w0<=w1<=w2 and the unit eigenvector of the LARGEST one.
+__device__ inline void eig3_sym(float a00, float a10, float a11, float a20, float a21, float a22, float& w0, float& w1,
+                                float& w2, float& vx, float& vy, float& vz) {
+  float A[3][3] = {{a00, a10, a20}, {a10, a11, a21}, {a20, a21, a22}};
+  float Q[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
+  for (int sweep = 0; sweep < 16; sweep++) {
+    float off = A[1][0] * A[1][0] + A[2][0] * A[2][0] + A[2][1] * A[2][1];
+    float diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+    if (off <= 1e-20f * diag || off == 0.f) break;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+      for (int q = p + 1; q < 3; q++) {
+        float apq = A[p][q];
+        if (apq != 0.f) {
+          float theta = (A[q][q] - A[p][p]) / (2.f * apq);
+          float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
+          float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            float akp = A[k][p], akq = A[k][q];
+            A[k][p] = c * akp - s * akq;
+            A[k][q] = s * akp + c * akq;
+          }
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            float apk = A[p][k], aqk = A[q][k];
+            A[p][k] = c * apk - s * aqk;
+            A[q][k] = s * apk + c * aqk;
+          }
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            float qkp = Q[k][p], qkq = Q[k][q];
+            Q[k][p] = c * qkp - s * qkq;
+            Q[k][q] = s * qkp + c * qkq;
+          }
+        }
+      }
+    }
+  }
+  float e0 = A[0][0], e1 = A[1][1], e2 = A[2][2];
+  float c0x = Q[0][0], c0y = Q[1][0], c0z = Q[2][0];
+  float c1x = Q[0][1], c1y = Q[1][1], c1z = Q[2][1];
+  float c2x = Q[0][2], c2y = Q[1][2], c2z = Q[2][2];
+#define LX_CSWAP(ea, eb, ax, ay, az, bx, by, bz) \
+  if (eb < ea) {                                 \
+    float t_;                                    \
+    t_ = ea; ea = eb; eb = t_;                   \
+    t_ = ax; ax = bx; bx = t_;                   \
+    t_ = ay; ay = by; by = t_;                   \
+    t_ = az; az = bz; bz = t_;                   \
+  }
+  LX_CSWAP(e0, e1, c0x, c0y, c0z, c1x, c1y, c1z)
+  LX_CSWAP(e1, e2, c1x, c1y, c1z, c2x, c2y, c2z)
+  LX_CSWAP(e0, e1, c0x, c0y, c0z, c1x, c1y, c1z)
+#undef LX_CSWAP
+  w0 = e0; w1 = e1; w2 = e2;
+  vx = c2x; vy = c2y; vz = c2z;
+}
+
+// ---- column-pivoted Householder QR least squares, fully unrolled so A stays in registers.
+template <int M, int N> __device__ inline void qr_solve(float (&A)[M][N], float (&b)[M], float (&x)[N]) {
+  int perm[N];
+#pragma unroll
+  for (int c = 0; c < N; c++) perm[c] = c;
+  float maxnorm = 0.f;
+#pragma unroll
+  for (int c = 0; c < N; c++) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < M; r++) s += A[r][c] * A[r][c];
+    maxnorm = fmaxf(maxnorm, sqrtf(s));
+  }
+  const float eps = FLT_EPSILON;
+  const float thr_helper = (maxnorm * eps) * (maxnorm * eps) / float(M);
+  int nonzero = N;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    int best = k;
+    float bestn = -1.f;
+#pragma unroll
+    for (int c = k; c < N; c++) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = k; r < M; r++) s += A[r][c] * A[r][c];
+      if (s > bestn) { bestn = s; best = c; }
+    }
+    if (nonzero == N && bestn < thr_helper * float(M - k)) nonzero = k;
+#pragma unroll
+    for (int c = k + 1; c < N; c++) {
+      if (best == c) {
+#pragma unroll
+        for (int r = 0; r < M; r++) { float t = A[r][k]; A[r][k] = A[r][c]; A[r][c] = t; }
+        int t = perm[k]; perm[k] = perm[c]; perm[c] = t;
+      }
+    }
+    float c0 = A[k][k], tail = 0.f;
+#pragma unroll
+    for (int r = k + 1; r < M; r++) tail += A[r][k] * A[r][k];
+    float tau, beta;
+    float v[M];
+    if (tail <= FLT_MIN) {
+      tau = 0.f;
+      beta = c0;
+#pragma unroll
+      for (int r = k + 1; r < M; r++) v[r] = 0.f;
+    } else {
+      beta = sqrtf(c0 * c0 + tail);
+      if (c0 >= 0.f) beta = -beta;
+#pragma unroll
+      for (int r = k + 1; r < M; r++) v[r] = A[r][k] / (c0 - beta);
+      tau = (beta - c0) / beta;
+    }
+    v[k] = 1.f;
+    A[k][k] = beta;
+#pragma unroll
+    for (int r = k + 1; r < M; r++) A[r][k] = 0.f;
+#pragma unroll
+    for (int c = k + 1; c < N; c++) {
+      float dot = 0.f;
+#pragma unroll
+      for (int r = k; r < M; r++) dot += v[r] * A[r][c];
+      dot *= tau;
+#pragma unroll
+      for (int r = k; r < M; r++) A[r][c] -= dot * v[r];
+    }
+    {
+      float dot = 0.f;
+#pragma unroll
+      for (int r = k; r < M; r++) dot += v[r] * b[r];
+      dot *= tau;
+#pragma unroll
+      for (int r = k; r < M; r++) b[r] -= dot * v[r];
+    }
+  }
+  float y[N];
+#pragma unroll
+  for (int c = 0; c < N; c++) y[c] = 0.f;
+#pragma unroll
+  for (int k = N - 1; k >= 0; k--) {
+    if (k < nonzero) {
+      float s = b[k];
+#pragma unroll
+      for (int c = k + 1; c < N; c++)
+        if (c < nonzero) s -= A[k][c] * y[c];
+      y[k] = s / A[k][k];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < N; c++) x[c] = 0.f;
+#pragma unroll
+  for (int c = 0; c < N; c++)
+#pragma unroll
+    for (int j = 0; j < N; j++)
+      if (c < nonzero && perm[c] == j) x[j] = y[c];
+}
+
+// ---- 6x6 helpers for the once-per-iteration solve (one thread; dynamic indexing is fine here) --------------------
+__device__ inline void eig6_sym(const float* Ain, float* w, float* V) {
+  float A[6][6], Q[6][6];
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c <= r; c++) A[r][c] = A[c][r] = Ain[r * 6 + c];
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c < 6; c++) Q[r][c] = (r == c) ? 1.f : 0.f;
+  for (int sweep = 0; sweep < 16; sweep++) {
+    float off = 0.f, diag = 0.f;
+    for (int r = 0; r < 6; r++) {
+      diag += A[r][r] * A[r][r];
+      for (int c = 0; c < r; c++) off += A[r][c] * A[r][c];
+    }
+    if (off <= 1e-20f * diag || off == 0.f) break;
+    for (int p = 0; p < 5; p++)
+      for (int q = p + 1; q < 6; q++) {
+        float apq = A[p][q];
+        if (apq == 0.f) continue;
+        float theta = (A[q][q] - A[p][p]) / (2.f * apq);
+        float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
+        float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
+        for (int k = 0; k < 6; k++) {
+          float akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - s * akq;
+          A[k][q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < 6; k++) {
+          float apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - s * aqk;
+          A[q][k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < 6; k++) {
+          float qkp = Q[k][p], qkq = Q[k][q];
+          Q[k][p] = c * qkp - s * qkq;
+          Q[k][q] = s * qkp + c * qkq;
+        }
+      }
+  }
+  int order[6];
+  for (int k = 0; k < 6; k++) order[k] = k;
+  for (int a = 1; a < 6; a++)
+    for (int b = a; b > 0 && A[order[b]][order[b]] < A[order[b - 1]][order[b - 1]]; b--) {
+      int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t;
+    }
+  for (int k = 0; k < 6; k++) {
+    w[k] = A[order[k]][order[k]];
+    for (int r = 0; r < 6; r++) V[r * 6 + k] = Q[r][order[k]];
+  }
+}
+
+__device__ inline bool inverse6(const float* Ain, float* inv) {
+  float A[6][12];
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c < 6; c++) {
+      A[r][c] = Ain[r * 6 + c];
+      A[r][6 + c] = (r == c) ? 1.f : 0.f;
+    }
+  for (int k = 0; k < 6; k++) {
+    int piv = k;
+    for (int r = k + 1; r < 6; r++)
+      if (fabsf(A[r][k]) > fabsf(A[piv][k])) piv = r;
+    if (A[piv][k] == 0.f) return false;
+    if (piv != k)
+      for (int c = 0; c < 12; c++) { float t = A[k][c]; A[k][c] = A[piv][c]; A[piv][c] = t; }
+    float d = 1.f / A[k][k];
+    for (int c = 0; c < 12; c++) A[k][c] *= d;
+    for (int r = 0; r < 6; r++)
+      if (r != k) {
+        float f = A[r][k];
+        if (f != 0.f)
+          for (int c = 0; c < 12; c++) A[r][c] -= f * A[k][c];
+      }
+  }
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c < 6; c++) inv[r * 6 + c] = A[r][6 + c];
+  return true;
+}
+
+// P = V^-1 * V2, V2 = V with ROW i zeroed while ascending eigenvalue i < thr (BasicLaserMapping.cpp:875-898)
+__device__ inline bool degeneracy_projector(const float* AtA, float thr, float* P) {
+  float w[6], V[36], V2[36], Vi[36];
+  eig6_sym(AtA, w, V);
+  for (int k = 0; k < 36; k++) V2[k] = V[k];
+  bool degenerate = false;
+  for (int i = 0; i < 6; i++) {
+    if (w[i] < thr) {
+      for (int j = 0; j < 6; j++) V2[i * 6 + j] = 0.f;
+      degenerate = true;
+    } else
+      break;
+  }
+  if (!inverse6(V, Vi)) {
+    for (int k = 0; k < 36; k++) P[k] = (k % 7 == 0) ? 1.f : 0.f;
+    return degenerate;
+  }
+  for (int r = 0; r < 6; r++)
+    for (int c = 0; c < 6; c++) {
+      float s = 0.f;
+      for (int k = 0; k < 6; k++) s += Vi[r * 6 + k] * V2[k * 6 + c];
+      P[r * 6 + c] = s;
+    }
+  return degenerate;
+}
+
+// 6x6 column-pivoted QR solve on plain arrays (single thread)
+__device__ inline void qr_solve6(const float* AtA, const float* AtB, float* X) {
+  float A[6][6], b[6], x[6];
+  for (int r = 0; r < 6; r++) {
+    b[r] = AtB[r];
+    for (int c = 0; c < 6; c++) A[r][c] = AtA[r * 6 + c];
+  }
+  qr_solve<6, 6>(A, b, x);
+  for (int r = 0; r < 6; r++) X[r] = x[r];
+}
+
+}  // namespace loamx

@@ -1,0 +1,118 @@
+// Scan-to-map registration engine shared by the batched mode (loamx_batch_*) and the sequential
+// BasicLaserMapping replacement (loamx_map_*).  Host classes; kernels live in registration.hip.
+#pragma once
+#include "common.h"
+#include "dev_math.cuh"
+
+namespace loamx {
+
+// uniform grid over a sub-map: cell edge >= 1.05 m so the 3x3x3 neighbourhood of a query's cell contains every
+// point within the 1 m gate of BasicLaserMapping.cpp:671/:760.
+struct GridDesc {
+  float ox, oy, oz, inv_h;
+  int nx, ny, nz;
+  uint32_t ncell;
+};
+
+constexpr uint32_t LX_MAX_CELLS = 16u * 1024 * 1024 - 2048;   // scan limit (scan.cuh)
+constexpr int LX_RES_THREADS = 256;
+constexpr int LX_NSUM = 28;   // 21 upper-triangular AtA + 6 AtB + row count
+
+class SubMapIndex {
+ public:
+  void init(hipStream_t st);
+  // (re)build over n device points (packed float4; .w ignored).  Asynchronous on the stream.
+  void build(const float4* d_pts, uint32_t n);
+  uint32_t size() const { return n_; }
+  const float4* sorted() const { return sorted_.p; }          // .w = original index (bit pattern)
+  const uint32_t* cell_start() const { return cell_start_.p; }
+  const GridDesc* desc() const { return d_desc_.p; }
+
+ private:
+  hipStream_t st_ = nullptr;
+  uint32_t n_ = 0;
+  DevBuf<float4> sorted_;
+  DevBuf<uint32_t> cell_of_, cell_start_, cursor_, tile_sums_, scratch_;   // scratch_: bbox enc[6], ncell+1, total
+  DevBuf<GridDesc> d_desc_;
+};
+
+struct SweepStats {
+  int iterations, sel, corner_q, surf_q, degenerate, done, pad0, pad1;
+};
+
+struct RegParams {
+  int max_iterations = 10;
+  float delta_t_abort = 0.05f, delta_r_abort = 0.05f;
+  float corner_leaf = 0.2f, surf_leaf = 0.4f;
+};
+
+// Registers up to max_sweeps sweeps' (corner_last, surf_last) against the two indexed sub-maps.
+class Registrar {
+ public:
+  Registrar(int device, uint32_t max_sweeps);
+  ~Registrar();
+  RegParams params;
+  SubMapIndex corner_index, surf_index;
+  hipStream_t stream() const { return st_; }
+
+  // frozen sub-map (host records or device float4)
+  void set_submap_host(const loamx_cloud* corner, const loamx_cloud* surf);
+  void set_submap_device(const float4* d_corner, uint32_t nc, const float4* d_surf, uint32_t ns);
+
+  // stage inputs (H2D, async on the stream)
+  void upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const loamx_cloud* surf_last, const loamx_cloud* full_res,
+              const float* guess6);
+  // device-only: stack round trip + voxel DS + LM iterations (+ full-res registration)
+  void run_async();
+  void sync();
+  void download(float* poses6, int* stats4);
+  void download_stats(SweepStats* out);
+  int download_full_res(uint32_t sweep, loamx_cloud* out);
+  // down-sampled query clouds of a sweep (device pointers valid until the next run); counts need a sync'd download
+  void download_ds(uint32_t sweep, std::vector<float4>& corner_ds, std::vector<float4>& surf_ds);
+  // registered (final-pose) DS clouds, for map insertion: device array + offsets
+  const float4* d_ds_points() const { return ds_pts_.p; }
+  const uint32_t* d_ds_offsets() const { return ds_off_.p; }
+  const Pose* d_poses() const { return poses_.p; }
+
+  void set_timing(bool on) { timing_ = on; }
+  void get_timing(float ms[4], uint64_t counts[4]);
+  uint32_t n_sweeps() const { return n_sweeps_; }
+  bool submap_sufficient() const { return corner_index.size() > 10 && surf_index.size() > 100; }
+
+ private:
+  int device_;
+  uint32_t max_sweeps_, n_sweeps_ = 0;
+  hipStream_t st_ = nullptr;
+  bool timing_ = false;
+
+  // owned copies of a host-provided sub-map
+  DevBuf<float4> own_corner_, own_surf_;
+
+  // inputs: segments 2s (corner), 2s+1 (surf)
+  PinBuf<float4> h_in_, h_full_;
+  std::vector<uint32_t> h_seg_off_, h_full_off_;
+  PinBuf<float> h_guess_;
+  DevBuf<float4> in_, stack_, ds_pts_, full_;
+  DevBuf<uint32_t> seg_off_, full_off_, ds_off_;
+  DevBuf<float> guess_;
+  DevBuf<int> ijk_, seg_minmax_;   // ijk: 3 ints / point; seg_minmax: 6 ints / segment
+  DevBuf<unsigned long long> keys_, keys_sorted_;
+  DevBuf<uint32_t> vals_, vals_sorted_, head_, head_scan_, tile_sums_, scratch_;
+  DevBuf<char> sort_tmp_;
+  size_t sort_tmp_bytes_ = 0;
+  uint32_t n_in_ = 0, n_full_ = 0, max_q_per_sweep_ = 0;
+
+  DevBuf<Pose> poses_;
+  DevBuf<SweepStats> stats_;
+  DevBuf<float> matP_;        // 36 per sweep
+  DevBuf<double> partials_;   // per sweep x blocks x LX_NSUM
+  uint32_t nblk_ = 0;
+
+  std::vector<hipEvent_t> ev_;   // timing events: [0]=run start, [1]=run end, then pairs per residual launch
+  int n_res_launch_ = 0;
+  PinBuf<SweepStats> h_stats_;
+  PinBuf<Pose> h_poses_;
+};
+
+}  // namespace loamx

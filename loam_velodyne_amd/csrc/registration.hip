@@ -1,0 +1,758 @@
+// Scan-to-map registration kernels for gfx950 (MI355X).
+//
+// What runs here, per batch of independent sweeps (reference: src/lib/BasicLaserMapping.cpp):
+//   k_stack          stack round trip  pointAssociateToMap -> pointAssociateTobeMapped        (:282-292, :512-516)
+//   k_keys/sort/k_voxel_reduce   pcl::VoxelGrid on the stack clouds (corner 0.2 m / surf 0.4 m) (:519-527)
+//   SubMapIndex      replaces the two kd-tree rebuilds (:636-637) by a counting-sorted uniform grid
+//   k_residual       per query: pointAssociateToMap, exact 5-NN within the 1 m gate, 3x3 eigen edge fit or 5x3 QR
+//                    plane fit, residual + weight, Jacobian row, block-reduced J^T J / J^T r      (:665-866)
+//   k_solve          6x6 column-pivoted QR, degeneracy projector, pose update, convergence test   (:867-922)
+//   k_transform_full transformFullResToMap                                                         (:235-240)
+// HBM-bound gather work: no MFMA (the only dense contraction is 6x6).  Points are packed float4 so a neighbour is one
+// 16-byte load; queries are processed in voxel order, so the lanes of a wave walk the same few grid cells.
+#include "registration.cuh"
+#include "scan.cuh"
+#include <rocprim/rocprim.hpp>
+
+namespace loamx {
+
+// ----------------------------------------------------------------------------------------------------------------
+// small helpers
+// ----------------------------------------------------------------------------------------------------------------
+__device__ inline uint32_t enc_f32(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float dec_f32(uint32_t u) {
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+#ifdef __HIP_DEVICE_COMPILE__
+  return __uint_as_float(u);
+#else
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+#endif
+}
+
+__global__ void k_fill_u32(uint32_t* p, uint32_t n, uint32_t v) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_init_bbox(uint32_t* scratch) {
+  const uint32_t t = threadIdx.x;
+  if (t < 3) scratch[t] = 0xffffffffu;
+  else if (t < 16) scratch[t] = 0u;
+}
+__global__ void k_init_minmax(int* mm, uint32_t nseg) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 6 * nseg) mm[i] = (i % 6) < 3 ? 2147483647 : (-2147483647 - 1);
+}
+__global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
+__global__ void k_zero_u32_dn(uint32_t* p, const uint32_t* d_n) {
+  const uint32_t n = *d_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// SubMapIndex: bounding box -> grid descriptor -> cell histogram -> exclusive scan -> scatter
+// scratch layout (uint32): [0..5] encoded min xyz / max xyz, [6] ncell+1, [7] scan total, [8] ncell
+// ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bbox(const float4* __restrict__ pts, uint32_t n, uint32_t* __restrict__ enc) {
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float4 p = pts[i];
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], d, 64));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, 64));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&enc[a], enc_f32(mn[a]));
+      atomicMax(&enc[3 + a], enc_f32(mx[a]));
+    }
+  }
+}
+
+__global__ void k_grid_setup(uint32_t* __restrict__ scratch, GridDesc* __restrict__ desc, uint32_t max_cells) {
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; a++) { mn[a] = dec_f32(scratch[a]); mx[a] = dec_f32(scratch[3 + a]); }
+  float h = 1.05f;
+  GridDesc g;
+  for (;;) {
+    g.inv_h = 1.0f / h;
+    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+    g.nx = (int)floorf((mx[0] - mn[0]) * g.inv_h) + 1;
+    g.ny = (int)floorf((mx[1] - mn[1]) * g.inv_h) + 1;
+    g.nz = (int)floorf((mx[2] - mn[2]) * g.inv_h) + 1;
+    unsigned long long nc = (unsigned long long)g.nx * g.ny * g.nz;
+    if (nc <= max_cells) { g.ncell = (uint32_t)nc; break; }
+    h *= 1.25f;   // a coarser grid is still exact (the 27-cell neighbourhood only grows)
+  }
+  *desc = g;
+  scratch[6] = g.ncell + 1;
+  scratch[8] = g.ncell;
+}
+
+__device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ inline void cell_coords(const GridDesc& g, float x, float y, float z, int& cx, int& cy, int& cz) {
+  cx = clampi((int)floorf((x - g.ox) * g.inv_h), 0, g.nx - 1);
+  cy = clampi((int)floorf((y - g.oy) * g.inv_h), 0, g.ny - 1);
+  cz = clampi((int)floorf((z - g.oz) * g.inv_h), 0, g.nz - 1);
+}
+
+__global__ __launch_bounds__(256) void k_cell_count(const float4* __restrict__ pts, uint32_t n, const GridDesc* __restrict__ desc,
+                                                    uint32_t* __restrict__ cell_of, uint32_t* __restrict__ counts) {
+  const GridDesc g = *desc;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  int cx, cy, cz;
+  cell_coords(g, p.x, p.y, p.z, cx, cy, cz);
+  uint32_t c = ((uint32_t)cz * g.ny + cy) * g.nx + cx;
+  cell_of[i] = c;
+  atomicAdd(&counts[c], 1u);
+}
+
+__global__ __launch_bounds__(256) void k_copy_u32_dn(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                     const uint32_t* d_n) {
+  const uint32_t n = *d_n;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void k_cell_scatter(const float4* __restrict__ pts, uint32_t n,
+                                                      const uint32_t* __restrict__ cell_of, uint32_t* __restrict__ cursor,
+                                                      float4* __restrict__ sorted) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float4 p = pts[i];
+  uint32_t pos = atomicAdd(&cursor[cell_of[i]], 1u);
+  p.w = __uint_as_float(i);   // original index: kNN ties are broken on it, so the slot order inside a cell is irrelevant
+  sorted[pos] = p;
+}
+
+void SubMapIndex::init(hipStream_t st) {
+  st_ = st;
+  scratch_.reserve(16);
+  d_desc_.reserve(1);
+  tile_sums_.reserve(8192);
+}
+
+void SubMapIndex::build(const float4* d_pts, uint32_t n) {
+  n_ = n;
+  if (n == 0) return;
+  sorted_.reserve(n);
+  cell_of_.reserve(n);
+  cell_start_.reserve((size_t)LX_MAX_CELLS + 2);
+  cursor_.reserve((size_t)LX_MAX_CELLS + 2);
+  hipLaunchKernelGGL(k_init_bbox, dim3(1), dim3(16), 0, st_, scratch_.p);
+  const uint32_t nb = (n + 255) / 256;
+  hipLaunchKernelGGL(k_bbox, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, st_, d_pts, n, scratch_.p);
+  hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(1), 0, st_, scratch_.p, d_desc_.p, LX_MAX_CELLS);
+  hipLaunchKernelGGL(k_zero_u32_dn, dim3(2048), dim3(256), 0, st_, cursor_.p, scratch_.p + 6);
+  hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st_, d_pts, n, d_desc_.p, cell_of_.p, cursor_.p);
+  exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 8, scratch_.p + 7, LX_MAX_CELLS, st_);
+  hipLaunchKernelGGL(k_copy_u32_dn, dim3(2048), dim3(256), 0, st_, cell_start_.p, cursor_.p, scratch_.p + 6);
+  hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(256), 0, st_, d_pts, n, cell_of_.p, cursor_.p, sorted_.p);
+  LX_HIP(hipGetLastError());
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// stack round trip + voxel keys
+// ----------------------------------------------------------------------------------------------------------------
+__device__ inline uint32_t find_seg(const uint32_t* __restrict__ off, uint32_t nseg, uint32_t i) {
+  uint32_t lo = 0, hi = nseg;   // off[lo] <= i < off[hi]
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// seg_minmax: per segment min ix,iy,iz / max ix,iy,iz
+__global__ __launch_bounds__(256) void k_stack(const float4* __restrict__ in, uint32_t n, const uint32_t* __restrict__ seg_off,
+                                               uint32_t nseg, const Pose* __restrict__ poses, float inv_corner, float inv_surf,
+                                               float4* __restrict__ stack, int* __restrict__ ijk, int* __restrict__ seg_minmax) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t seg = find_seg(seg_off, nseg, i);
+  const Pose T = poses[seg >> 1];
+  float4 p = in[i];
+  float x = p.x, y = p.y, z = p.z;
+  to_map(T, x, y, z);
+  to_be_mapped(T, x, y, z);
+  stack[i] = make_float4(x, y, z, p.w);
+  const float inv = (seg & 1) ? inv_surf : inv_corner;
+  int ix = (int)floorf(x * inv), iy = (int)floorf(y * inv), iz = (int)floorf(z * inv);
+  ijk[3 * i] = ix; ijk[3 * i + 1] = iy; ijk[3 * i + 2] = iz;
+  int* mm = seg_minmax + 6 * seg;
+  atomicMin(&mm[0], ix); atomicMin(&mm[1], iy); atomicMin(&mm[2], iz);
+  atomicMax(&mm[3], ix); atomicMax(&mm[4], iy); atomicMax(&mm[5], iz);
+}
+
+// key = seg << 36 | dz << 24 | dy << 12 | dx  (order == PCL's ix + iy*divx + iz*divx*divy inside a segment).
+// A segment whose box would overflow PCL's int32 voxel index (or our 12-bit fields) is passed through unfiltered,
+// as PCL does ("leaf size is too small"): every point keeps its own key.
+__global__ __launch_bounds__(256) void k_keys(uint32_t n, const uint32_t* __restrict__ seg_off, uint32_t nseg,
+                                              const int* __restrict__ ijk, const int* __restrict__ seg_minmax,
+                                              unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t seg = find_seg(seg_off, nseg, i);
+  const int* mm = seg_minmax + 6 * seg;
+  const long long dx = (long long)mm[3] - mm[0] + 1, dy = (long long)mm[4] - mm[1] + 1, dz = (long long)mm[5] - mm[2] + 1;
+  unsigned long long k;
+  if (dx * dy * dz > 2147483647LL || dx > 4096 || dy > 4096 || dz > 4096) {
+    k = (unsigned long long)(i - seg_off[seg]);
+  } else {
+    k = ((unsigned long long)(ijk[3 * i + 2] - mm[2]) << 24) | ((unsigned long long)(ijk[3 * i + 1] - mm[1]) << 12) |
+        (unsigned long long)(ijk[3 * i] - mm[0]);
+  }
+  keys[i] = ((unsigned long long)seg << 36) | k;
+  vals[i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_heads(const unsigned long long* __restrict__ keys, uint32_t n, uint32_t* __restrict__ head) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// one thread per voxel head: float mean of x,y,z,intensity over the run, accumulated in input order
+__global__ __launch_bounds__(256) void k_voxel_reduce(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                      const uint32_t* __restrict__ head, const uint32_t* __restrict__ head_scan,
+                                                      uint32_t n, const float4* __restrict__ stack, float4* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  const unsigned long long k = keys[i];
+  float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+  uint32_t j = i;
+  do {
+    float4 p = stack[vals[j]];
+    sx += p.x; sy += p.y; sz += p.z; si += p.w;
+    j++;
+  } while (j < n && keys[j] == k);
+  const float cnt = (float)(j - i);
+  out[head_scan[i]] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+}
+
+// ds_off[s] = number of voxels before segment s; ds_off[nseg] = total
+__global__ void k_ds_offsets(const uint32_t* __restrict__ head_scan, const uint32_t* __restrict__ seg_off, uint32_t nseg,
+                             uint32_t n, uint32_t* __restrict__ ds_off) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > nseg) return;
+  ds_off[s] = (s == nseg || seg_off[s] >= n) ? head_scan[n] : head_scan[seg_off[s]];
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Gauss-Newton iteration
+// ----------------------------------------------------------------------------------------------------------------
+__global__ void k_pose_init(const float* __restrict__ guess, uint32_t ns, Pose* __restrict__ poses, SweepStats* __restrict__ stats) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  Pose T;
+  pose_set_angles(T, guess[6 * s], guess[6 * s + 1], guess[6 * s + 2]);
+  T.tx = guess[6 * s + 3]; T.ty = guess[6 * s + 4]; T.tz = guess[6 * s + 5];
+  poses[s] = T;
+  SweepStats z = {0, 0, 0, 0, 0, 0, 0, 0};
+  stats[s] = z;
+}
+
+__device__ inline void knn_insert(float (&bd)[5], uint32_t (&bi)[5], uint32_t (&bp)[5], float d2, uint32_t id, uint32_t pos) {
+  if (!(d2 < bd[4] || (d2 == bd[4] && id < bi[4]))) return;
+  bd[4] = d2; bi[4] = id; bp[4] = pos;
+#pragma unroll
+  for (int j = 4; j > 0; j--) {
+    const bool sw = (bd[j] < bd[j - 1]) || (bd[j] == bd[j - 1] && bi[j] < bi[j - 1]);
+    if (sw) {
+      float td = bd[j]; bd[j] = bd[j - 1]; bd[j - 1] = td;
+      uint32_t ti = bi[j]; bi[j] = bi[j - 1]; bi[j - 1] = ti;
+      uint32_t tp = bp[j]; bp[j] = bp[j - 1]; bp[j - 1] = tp;
+    }
+  }
+}
+
+// exact 5-NN within the 1 m gate; returns true when 5 neighbours with d2 < 1 exist (== pointSearchSqDis[4] < 1.0)
+__device__ inline bool knn5(const GridDesc& g, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start, float qx,
+                            float qy, float qz, uint32_t (&bp)[5]) {
+  float bd[5];
+  uint32_t bi[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) { bd[j] = FLT_MAX; bi[j] = 0xffffffffu; bp[j] = 0u; }
+  // unclamped cell of the query; the searched ranges are clamped, so points binned into border cells are still found
+  const int cx = (int)floorf((qx - g.ox) * g.inv_h), cy = (int)floorf((qy - g.oy) * g.inv_h), cz = (int)floorf((qz - g.oz) * g.inv_h);
+  const int x0 = clampi(cx - 1, 0, g.nx - 1), x1 = clampi(cx + 1, 0, g.nx - 1);
+  const int y0 = clampi(cy - 1, 0, g.ny - 1), y1 = clampi(cy + 1, 0, g.ny - 1);
+  const int z0 = clampi(cz - 1, 0, g.nz - 1), z1 = clampi(cz + 1, 0, g.nz - 1);
+  if (cx + 1 < 0 || cx - 1 > g.nx - 1 || cy + 1 < 0 || cy - 1 > g.ny - 1 || cz + 1 < 0 || cz - 1 > g.nz - 1) return false;
+  for (int z = z0; z <= z1; z++)
+    for (int y = y0; y <= y1; y++) {
+      const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
+      const uint32_t beg = cell_start[row + x0], end = cell_start[row + x1 + 1];   // x is the fastest cell axis: one run
+      for (uint32_t k = beg; k < end; k++) {
+        const float4 p = pts[k];
+        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;   // x -> y -> z accumulation (nanoflann.hpp:372-379)
+        if (d2 < 1.0f) knn_insert(bd, bi, bp, d2, __float_as_uint(p.w), k);
+      }
+    }
+  return bi[4] != 0xffffffffu;
+}
+
+struct Row {
+  float a[6];
+  float b;
+  bool sel;
+};
+
+// corner query: BasicLaserMapping.cpp:667-751
+__device__ inline void corner_row(const Pose& T, const float4 po, const GridDesc& g, const float4* __restrict__ pts,
+                                  const uint32_t* __restrict__ cell_start, float& cx_, float& cy_, float& cz_, float& ci_, bool& sel) {
+  sel = false;
+  float x0 = po.x, y0 = po.y, z0 = po.z;
+  to_map(T, x0, y0, z0);
+  uint32_t bp[5];
+  if (!knn5(g, pts, cell_start, x0, y0, z0, bp)) return;
+  float4 nb[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) nb[j] = pts[bp[j]];
+  float vx = 0.f, vy = 0.f, vz = 0.f;
+#pragma unroll
+  for (int j = 0; j < 5; j++) { vx += nb[j].x; vy += nb[j].y; vz += nb[j].z; }
+  vx /= 5.0f; vy /= 5.0f; vz /= 5.0f;
+  float a00 = 0.f, a10 = 0.f, a20 = 0.f, a11 = 0.f, a21 = 0.f, a22 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const float ax = nb[j].x - vx, ay = nb[j].y - vy, az = nb[j].z - vz;
+    a00 += ax * ax; a10 += ax * ay; a20 += ax * az; a11 += ay * ay; a21 += ay * az; a22 += az * az;
+  }
+  a00 /= 5.0f; a10 /= 5.0f; a20 /= 5.0f; a11 /= 5.0f; a21 /= 5.0f; a22 /= 5.0f;
+  float w0, w1, w2, ex, ey, ez;
+  eig3_sym(a00, a10, a11, a20, a21, a22, w0, w1, w2, ex, ey, ez);
+  if (!(w2 > 3 * w1)) return;
+  const float x1 = (float)(vx + 0.1 * ex), y1 = (float)(vy + 0.1 * ey), z1 = (float)(vz + 0.1 * ez);
+  const float x2 = (float)(vx - 0.1 * ex), y2 = (float)(vy - 0.1 * ey), z2 = (float)(vz - 0.1 * ez);
+  const float a012 = sqrtf(((x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1)) * ((x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1)) +
+                           ((x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1)) * ((x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1)) +
+                           ((y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1)) * ((y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1)));
+  const float l12 = sqrtf((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2) + (z1 - z2) * (z1 - z2));
+  const float la = ((y1 - y2) * ((x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1)) +
+                    (z1 - z2) * ((x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1))) / a012 / l12;
+  const float lb = -((x1 - x2) * ((x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1)) -
+                     (z1 - z2) * ((y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1))) / a012 / l12;
+  const float lc = -((x1 - x2) * ((x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1)) +
+                     (y1 - y2) * ((y0 - y1) * (z0 - z2) - (y0 - y2) * (z0 - z1))) / a012 / l12;
+  const float ld2 = a012 / l12;
+  const float s = 1 - 0.9f * fabsf(ld2);
+  cx_ = s * la; cy_ = s * lb; cz_ = s * lc; ci_ = s * ld2;
+  sel = ((double)s > 0.1);
+}
+
+// surf query: BasicLaserMapping.cpp:756-816
+__device__ inline void surf_row(const Pose& T, const float4 po, const GridDesc& g, const float4* __restrict__ pts,
+                                const uint32_t* __restrict__ cell_start, float& cx_, float& cy_, float& cz_, float& ci_, bool& sel) {
+  sel = false;
+  float x0 = po.x, y0 = po.y, z0 = po.z;
+  to_map(T, x0, y0, z0);
+  uint32_t bp[5];
+  if (!knn5(g, pts, cell_start, x0, y0, z0, bp)) return;
+  float A[5][3], b[5], X[3];
+  float4 nb[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    nb[j] = pts[bp[j]];
+    A[j][0] = nb[j].x; A[j][1] = nb[j].y; A[j][2] = nb[j].z;
+    b[j] = -1.f;
+  }
+  qr_solve<5, 3>(A, b, X);
+  float pa = X[0], pb = X[1], pc = X[2], pd = 1;
+  const float ps = sqrtf(pa * pa + pb * pb + pc * pc);
+  pa /= ps; pb /= ps; pc /= ps; pd /= ps;
+  bool planeValid = true;
+#pragma unroll
+  for (int j = 0; j < 5; j++)
+    if ((double)fabsf(pa * nb[j].x + pb * nb[j].y + pc * nb[j].z + pd) > 0.2) planeValid = false;
+  if (!planeValid) return;
+  const float pd2 = pa * x0 + pb * y0 + pc * z0 + pd;
+  const float s = 1 - 0.9f * fabsf(pd2) / sqrtf(sqrtf(x0 * x0 + y0 * y0 + z0 * z0));
+  cx_ = s * pa; cy_ = s * pb; cz_ = s * pc; ci_ = s * pd2;
+  sel = ((double)s > 0.1);
+}
+
+// grid = (blocks per sweep, sweeps).  partials[(s*nblk + b)*LX_NSUM + k]
+__global__ __launch_bounds__(LX_RES_THREADS) void k_residual(
+    const float4* __restrict__ ds_pts, const uint32_t* __restrict__ ds_off, const Pose* __restrict__ poses,
+    const SweepStats* __restrict__ stats, const GridDesc* __restrict__ cdesc, const float4* __restrict__ cpts,
+    const uint32_t* __restrict__ cstart, const GridDesc* __restrict__ sdesc, const float4* __restrict__ spts,
+    const uint32_t* __restrict__ sstart, double* __restrict__ partials, uint32_t nblk) {
+  const uint32_t s = blockIdx.y;
+  if (stats[s].done) return;
+  const uint32_t q0 = ds_off[2 * s], qm = ds_off[2 * s + 1], q1 = ds_off[2 * s + 2];
+  const uint32_t first = q0 + blockIdx.x * LX_RES_THREADS;
+  if (first >= q1) return;
+  const uint32_t q = first + threadIdx.x;
+  const Pose T = poses[s];
+
+  float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bb = 0.f;
+  bool sel = false;
+  if (q < q1) {
+    const float4 po = ds_pts[q];
+    float cx, cy, cz, ci;
+    if (q < qm) corner_row(T, po, *cdesc, cpts, cstart, cx, cy, cz, ci, sel);
+    else surf_row(T, po, *sdesc, spts, sstart, cx, cy, cz, ci, sel);
+    if (sel) {
+      // Jacobian row, BasicLaserMapping.cpp:842-861
+      const float srx = T.srx, crx = T.crx, sry = T.sry, cry = T.cry, srz = T.srz, crz = T.crz;
+      a[0] = (crx * sry * srz * po.x + crx * crz * sry * po.y - srx * sry * po.z) * cx +
+             (-srx * srz * po.x - crz * srx * po.y - crx * po.z) * cy +
+             (crx * cry * srz * po.x + crx * cry * crz * po.y - cry * srx * po.z) * cz;
+      a[1] = ((cry * srx * srz - crz * sry) * po.x + (sry * srz + cry * crz * srx) * po.y + crx * cry * po.z) * cx +
+             ((-cry * crz - srx * sry * srz) * po.x + (cry * srz - crz * srx * sry) * po.y - crx * sry * po.z) * cz;
+      a[2] = ((crz * srx * sry - cry * srz) * po.x + (-cry * crz - srx * sry * srz) * po.y) * cx +
+             (crx * crz * po.x - crx * srz * po.y) * cy +
+             ((sry * srz + cry * crz * srx) * po.x + (crz * sry - cry * srx * srz) * po.y) * cz;
+      a[3] = cx; a[4] = cy; a[5] = cz;
+      bb = -ci;
+    }
+  }
+  // products in float (as Eigen's float A^T A forms them), accumulated in double
+  double v[LX_NSUM];
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = i; j < 6; j++) v[k++] = (double)(a[i] * a[j]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) v[k++] = (double)(a[i] * bb);
+  v[k] = sel ? 1.0 : 0.0;
+
+  __shared__ double red[LX_RES_THREADS / 64][LX_NSUM];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < LX_NSUM; t++) {
+    double x = v[t];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+    if (lane == 0) red[wid][t] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < LX_NSUM) {
+    double x = 0.0;
+#pragma unroll
+    for (int w = 0; w < LX_RES_THREADS / 64; w++) x += red[w][threadIdx.x];
+    partials[((size_t)s * nblk + blockIdx.x) * LX_NSUM + threadIdx.x] = x;
+  }
+}
+
+// one wave per sweep: fixed-order reduction of the block partials, then lane 0 solves and updates the pose
+__global__ __launch_bounds__(64) void k_solve(const uint32_t* __restrict__ ds_off, Pose* __restrict__ poses, SweepStats* __restrict__ stats,
+                                              float* __restrict__ matP, const double* __restrict__ partials, uint32_t nblk, int iter,
+                                              float delta_t_abort, float delta_r_abort) {
+  const uint32_t s = blockIdx.x;
+  if (stats[s].done) return;
+  const uint32_t nq = ds_off[2 * s + 2] - ds_off[2 * s];
+  const uint32_t nact = (nq + LX_RES_THREADS - 1) / LX_RES_THREADS;
+  __shared__ double sums[LX_NSUM];
+  if (threadIdx.x < LX_NSUM) {
+    double x = 0.0;
+    for (uint32_t b = 0; b < nact; b++) x += partials[((size_t)s * nblk + b) * LX_NSUM + threadIdx.x];
+    sums[threadIdx.x] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  SweepStats st = stats[s];
+  st.iterations = iter + 1;
+  st.sel = (int)sums[27];
+  st.corner_q = (int)(ds_off[2 * s + 1] - ds_off[2 * s]);
+  st.surf_q = (int)(ds_off[2 * s + 2] - ds_off[2 * s + 1]);
+  if (st.sel < 50) {   // BasicLaserMapping.cpp:826-828: the iteration is burnt, pose untouched
+    stats[s] = st;
+    return;
+  }
+  float AtA[36], AtB[6], X[6];
+  int k = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++) {
+      AtA[i * 6 + j] = AtA[j * 6 + i] = (float)sums[k];
+      k++;
+    }
+  for (int i = 0; i < 6; i++) AtB[i] = (float)sums[21 + i];
+  qr_solve6(AtA, AtB, X);
+  float* P = matP + 36 * s;
+  if (iter == 0) st.degenerate = degeneracy_projector(AtA, 100.f, P) ? 1 : 0;
+  if (st.degenerate) {
+    float X2[6];
+    for (int r = 0; r < 6; r++) X2[r] = X[r];
+    for (int r = 0; r < 6; r++) {
+      float acc = 0.f;
+      for (int c = 0; c < 6; c++) acc += P[r * 6 + c] * X2[c];
+      X[r] = acc;
+    }
+  }
+  Pose T = poses[s];
+  pose_set_angles(T, T.rx + X[0], T.ry + X[1], T.rz + X[2]);
+  T.tx += X[3]; T.ty += X[4]; T.tz += X[5];
+  poses[s] = T;
+  const double r2d = 180.0 / M_PI;   // rad2deg(float) goes through double (math_utils.h:30-33)
+  const float d0 = (float)(X[0] * 180.0 / M_PI), d1 = (float)(X[1] * 180.0 / M_PI), d2 = (float)(X[2] * 180.0 / M_PI);
+  (void)r2d;
+  const float deltaR = (float)sqrt((double)d0 * d0 + (double)d1 * d1 + (double)d2 * d2);
+  const float t0 = X[3] * 100, t1 = X[4] * 100, t2 = X[5] * 100;
+  const float deltaT = (float)sqrt((double)t0 * t0 + (double)t1 * t1 + (double)t2 * t2);
+  if (deltaR < delta_r_abort && deltaT < delta_t_abort) st.done = 1;
+  stats[s] = st;
+}
+
+__global__ __launch_bounds__(256) void k_transform_full(float4* __restrict__ full, uint32_t n, const uint32_t* __restrict__ full_off,
+                                                        uint32_t ns, const Pose* __restrict__ poses) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = find_seg(full_off, ns, i);
+  const Pose T = poses[s];
+  float4 p = full[i];
+  to_map(T, p.x, p.y, p.z);
+  full[i] = p;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Registrar (host)
+// ----------------------------------------------------------------------------------------------------------------
+Registrar::Registrar(int device, uint32_t max_sweeps) : device_(device), max_sweeps_(max_sweeps) {
+  select_device(device);
+  LX_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  corner_index.init(st_);
+  surf_index.init(st_);
+  poses_.reserve(max_sweeps);
+  stats_.reserve(max_sweeps);
+  matP_.reserve((size_t)36 * max_sweeps);
+  guess_.reserve((size_t)6 * max_sweeps);
+  h_guess_.reserve((size_t)6 * max_sweeps);
+  seg_off_.reserve(2 * max_sweeps + 2);
+  full_off_.reserve(max_sweeps + 2);
+  ds_off_.reserve(2 * max_sweeps + 2);
+  seg_minmax_.reserve((size_t)12 * max_sweeps);
+  tile_sums_.reserve(8192);
+  scratch_.reserve(16);
+  h_stats_.reserve(max_sweeps);
+  h_poses_.reserve(max_sweeps);
+  ev_.resize(2 + 2 * 64);
+  for (auto& e : ev_) LX_HIP(hipEventCreate(&e));
+}
+
+Registrar::~Registrar() {
+  for (auto& e : ev_) (void)hipEventDestroy(e);
+  if (st_) (void)hipStreamDestroy(st_);
+}
+
+void Registrar::set_submap_host(const loamx_cloud* corner, const loamx_cloud* surf) {
+  check_cloud(corner, false);
+  check_cloud(surf, false);
+  LX_HIP(hipSetDevice(device_));
+  PinBuf<float4> hc, hs;
+  hc.reserve(corner->count);
+  hs.reserve(surf->count);
+  pack_cloud(corner, hc.p);
+  pack_cloud(surf, hs.p);
+  own_corner_.reserve(corner->count);
+  own_surf_.reserve(surf->count);
+  LX_HIP(hipMemcpyAsync(own_corner_.p, hc.p, sizeof(float4) * corner->count, hipMemcpyHostToDevice, st_));
+  LX_HIP(hipMemcpyAsync(own_surf_.p, hs.p, sizeof(float4) * surf->count, hipMemcpyHostToDevice, st_));
+  corner_index.build(own_corner_.p, corner->count);
+  surf_index.build(own_surf_.p, surf->count);
+  LX_HIP(hipStreamSynchronize(st_));
+}
+
+void Registrar::set_submap_device(const float4* d_corner, uint32_t nc, const float4* d_surf, uint32_t ns) {
+  LX_HIP(hipSetDevice(device_));
+  corner_index.build(d_corner, nc);
+  surf_index.build(d_surf, ns);
+  LX_HIP(hipStreamSynchronize(st_));
+}
+
+void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const loamx_cloud* surf_last, const loamx_cloud* full_res,
+                       const float* guess6) {
+  LX_REQUIRE(n_sweeps >= 1 && n_sweeps <= max_sweeps_, "n_sweeps out of range for this handle");
+  LX_REQUIRE(corner_last && surf_last && guess6, "NULL input");
+  LX_HIP(hipSetDevice(device_));
+  n_sweeps_ = n_sweeps;
+  h_seg_off_.assign(2 * n_sweeps + 1, 0);
+  h_full_off_.assign(n_sweeps + 1, 0);
+  max_q_per_sweep_ = 0;
+  for (uint32_t s = 0; s < n_sweeps; s++) {
+    check_cloud(&corner_last[s], false);
+    check_cloud(&surf_last[s], false);
+    h_seg_off_[2 * s + 1] = h_seg_off_[2 * s] + corner_last[s].count;
+    h_seg_off_[2 * s + 2] = h_seg_off_[2 * s + 1] + surf_last[s].count;
+    max_q_per_sweep_ = std::max(max_q_per_sweep_, corner_last[s].count + surf_last[s].count);
+    if (full_res) {
+      check_cloud(&full_res[s], false);
+      h_full_off_[s + 1] = h_full_off_[s] + full_res[s].count;
+    }
+  }
+  n_in_ = h_seg_off_[2 * n_sweeps];
+  n_full_ = h_full_off_[n_sweeps];
+  h_in_.reserve(n_in_ + 1);
+  in_.reserve(n_in_ + 1);
+  stack_.reserve(n_in_ + 1);
+  ds_pts_.reserve(n_in_ + 1);
+  ijk_.reserve((size_t)3 * n_in_ + 3);
+  keys_.reserve(n_in_ + 1);
+  keys_sorted_.reserve(n_in_ + 1);
+  vals_.reserve(n_in_ + 1);
+  vals_sorted_.reserve(n_in_ + 1);
+  head_.reserve(n_in_ + 2);
+  head_scan_.reserve(n_in_ + 2);
+  LX_REQUIRE(n_in_ < SCAN_MAX_N, "too many feature points in one batch");
+  for (uint32_t s = 0; s < n_sweeps; s++) {
+    pack_cloud(&corner_last[s], h_in_.p + h_seg_off_[2 * s]);
+    pack_cloud(&surf_last[s], h_in_.p + h_seg_off_[2 * s + 1]);
+  }
+  LX_HIP(hipMemcpyAsync(in_.p, h_in_.p, sizeof(float4) * n_in_, hipMemcpyHostToDevice, st_));
+  LX_HIP(hipMemcpyAsync(seg_off_.p, h_seg_off_.data(), sizeof(uint32_t) * (2 * n_sweeps + 1), hipMemcpyHostToDevice, st_));
+  if (n_full_) {
+    h_full_.reserve(n_full_);
+    full_.reserve(n_full_);
+    for (uint32_t s = 0; s < n_sweeps; s++) pack_cloud(&full_res[s], h_full_.p + h_full_off_[s]);
+    LX_HIP(hipMemcpyAsync(full_.p, h_full_.p, sizeof(float4) * n_full_, hipMemcpyHostToDevice, st_));
+    LX_HIP(hipMemcpyAsync(full_off_.p, h_full_off_.data(), sizeof(uint32_t) * (n_sweeps + 1), hipMemcpyHostToDevice, st_));
+  }
+  memcpy(h_guess_.p, guess6, sizeof(float) * 6 * n_sweeps);
+  LX_HIP(hipMemcpyAsync(guess_.p, h_guess_.p, sizeof(float) * 6 * n_sweeps, hipMemcpyHostToDevice, st_));
+  // sort scratch
+  size_t need = 0;
+  LX_HIP(rocprim::radix_sort_pairs(nullptr, need, keys_.p, keys_sorted_.p, vals_.p, vals_sorted_.p, (size_t)n_in_, 0, 48, st_));
+  if (need > sort_tmp_bytes_) {
+    sort_tmp_.reserve(need);
+    sort_tmp_bytes_ = need;
+  }
+  nblk_ = (max_q_per_sweep_ + LX_RES_THREADS - 1) / LX_RES_THREADS;
+  if (nblk_ == 0) nblk_ = 1;
+  partials_.reserve((size_t)n_sweeps * nblk_ * LX_NSUM);
+  LX_HIP(hipStreamSynchronize(st_));   // host staging buffers are reused by the caller after return
+}
+
+void Registrar::run_async() {
+  LX_REQUIRE(n_sweeps_ > 0, "run() before upload()");
+  LX_HIP(hipSetDevice(device_));
+  const uint32_t ns = n_sweeps_, nseg = 2 * ns, n = n_in_;
+  if (timing_) LX_HIP(hipEventRecord(ev_[0], st_));
+  n_res_launch_ = 0;
+  hipLaunchKernelGGL(k_pose_init, dim3((ns + 63) / 64), dim3(64), 0, st_, guess_.p, ns, poses_.p, stats_.p);
+  if (n > 0) {
+    // per-segment voxel bounds: min = INT_MAX, max = INT_MIN
+    hipLaunchKernelGGL(k_init_minmax, dim3((6 * nseg + 255) / 256), dim3(256), 0, st_, seg_minmax_.p, nseg);
+    const uint32_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_stack, dim3(nb), dim3(256), 0, st_, in_.p, n, seg_off_.p, nseg, poses_.p, 1.0f / params.corner_leaf,
+                       1.0f / params.surf_leaf, stack_.p, ijk_.p, seg_minmax_.p);
+    hipLaunchKernelGGL(k_keys, dim3(nb), dim3(256), 0, st_, n, seg_off_.p, nseg, ijk_.p, seg_minmax_.p, keys_.p, vals_.p);
+    size_t tmp = sort_tmp_bytes_;
+    LX_HIP(rocprim::radix_sort_pairs(sort_tmp_.p, tmp, keys_.p, keys_sorted_.p, vals_.p, vals_sorted_.p, (size_t)n, 0, 48, st_));
+    hipLaunchKernelGGL(k_heads, dim3(nb), dim3(256), 0, st_, keys_sorted_.p, n, head_.p);
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st_, scratch_.p, n);
+    exclusive_scan_u32(head_.p, head_scan_.p, tile_sums_.p, scratch_.p, scratch_.p + 1, n, st_);
+    hipLaunchKernelGGL(k_voxel_reduce, dim3(nb), dim3(256), 0, st_, keys_sorted_.p, vals_sorted_.p, head_.p, head_scan_.p, n, stack_.p,
+                       ds_pts_.p);
+    hipLaunchKernelGGL(k_ds_offsets, dim3((nseg + 64) / 64), dim3(64), 0, st_, head_scan_.p, seg_off_.p, nseg, n, ds_off_.p);
+  } else {
+    LX_HIP(hipMemsetAsync(ds_off_.p, 0, sizeof(uint32_t) * (nseg + 1), st_));
+  }
+  if (submap_sufficient() && n > 0) {   // BasicLaserMapping.cpp:628-629 guard
+    for (int it = 0; it < params.max_iterations; it++) {
+      const bool tm = timing_ && n_res_launch_ < 64;
+      if (tm) LX_HIP(hipEventRecord(ev_[2 + 2 * n_res_launch_], st_));
+      hipLaunchKernelGGL(k_residual, dim3(nblk_, ns), dim3(LX_RES_THREADS), 0, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p,
+                         corner_index.desc(), corner_index.sorted(), corner_index.cell_start(), surf_index.desc(),
+                         surf_index.sorted(), surf_index.cell_start(), partials_.p, nblk_);
+      if (tm) {
+        LX_HIP(hipEventRecord(ev_[3 + 2 * n_res_launch_], st_));
+        n_res_launch_++;
+      }
+      hipLaunchKernelGGL(k_solve, dim3(ns), dim3(64), 0, st_, ds_off_.p, poses_.p, stats_.p, matP_.p, partials_.p, nblk_, it,
+                         params.delta_t_abort, params.delta_r_abort);
+    }
+  }
+  if (n_full_)
+    hipLaunchKernelGGL(k_transform_full, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, n_full_, full_off_.p, ns, poses_.p);
+  if (timing_) LX_HIP(hipEventRecord(ev_[1], st_));
+  LX_HIP(hipGetLastError());
+}
+
+void Registrar::sync() { LX_HIP(hipStreamSynchronize(st_)); }
+
+void Registrar::download_stats(SweepStats* out) {
+  LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * n_sweeps_, hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipStreamSynchronize(st_));
+  memcpy(out, h_stats_.p, sizeof(SweepStats) * n_sweeps_);
+}
+
+void Registrar::download(float* poses6, int* stats4) {
+  LX_REQUIRE(n_sweeps_ > 0, "download() before run()");
+  LX_HIP(hipMemcpyAsync(h_poses_.p, poses_.p, sizeof(Pose) * n_sweeps_, hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * n_sweeps_, hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipStreamSynchronize(st_));
+  for (uint32_t s = 0; s < n_sweeps_; s++) {
+    if (poses6) {
+      const Pose& T = h_poses_.p[s];
+      float* o = poses6 + 6 * s;
+      o[0] = T.rx; o[1] = T.ry; o[2] = T.rz; o[3] = T.tx; o[4] = T.ty; o[5] = T.tz;
+    }
+    if (stats4) {
+      const SweepStats& st = h_stats_.p[s];
+      int* o = stats4 + 4 * s;
+      o[0] = st.iterations; o[1] = st.sel; o[2] = st.corner_q; o[3] = st.surf_q;
+    }
+  }
+}
+
+int Registrar::download_full_res(uint32_t sweep, loamx_cloud* out) {
+  LX_REQUIRE(sweep < n_sweeps_, "sweep index out of range");
+  check_cloud(out, false);
+  const uint32_t a = h_full_off_[sweep], b = h_full_off_[sweep + 1];
+  std::vector<float4> tmp(b - a);
+  if (b > a) LX_HIP(hipMemcpyAsync(tmp.data(), full_.p + a, sizeof(float4) * (b - a), hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipStreamSynchronize(st_));
+  return unpack_cloud(tmp.data(), b - a, out);
+}
+
+void Registrar::download_ds(uint32_t sweep, std::vector<float4>& corner_ds, std::vector<float4>& surf_ds) {
+  LX_REQUIRE(sweep < n_sweeps_, "sweep index out of range");
+  uint32_t off[3];
+  LX_HIP(hipMemcpyAsync(off, ds_off_.p + 2 * sweep, sizeof(off), hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipStreamSynchronize(st_));
+  corner_ds.resize(off[1] - off[0]);
+  surf_ds.resize(off[2] - off[1]);
+  if (!corner_ds.empty())
+    LX_HIP(hipMemcpyAsync(corner_ds.data(), ds_pts_.p + off[0], sizeof(float4) * corner_ds.size(), hipMemcpyDeviceToHost, st_));
+  if (!surf_ds.empty())
+    LX_HIP(hipMemcpyAsync(surf_ds.data(), ds_pts_.p + off[1], sizeof(float4) * surf_ds.size(), hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipStreamSynchronize(st_));
+}
+
+void Registrar::get_timing(float ms[4], uint64_t counts[4]) {
+  for (int k = 0; k < 4; k++) { ms[k] = 0.f; counts[k] = 0; }
+  if (!timing_) return;
+  LX_HIP(hipEventSynchronize(ev_[1]));
+  LX_HIP(hipEventElapsedTime(&ms[0], ev_[0], ev_[1]));
+  for (int k = 0; k < n_res_launch_; k++) {
+    float t = 0.f;
+    LX_HIP(hipEventElapsedTime(&t, ev_[2 + 2 * k], ev_[3 + 2 * k]));
+    ms[1] += t;
+  }
+  counts[0] = n_res_launch_;
+  std::vector<SweepStats> st(n_sweeps_);
+  download_stats(st.data());
+  for (auto& s : st) {
+    counts[1] += (uint64_t)s.iterations * (uint64_t)(s.corner_q + s.surf_q);
+    counts[2] += (uint64_t)(s.corner_q + s.surf_q);
+  }
+}
+
+}  // namespace loamx

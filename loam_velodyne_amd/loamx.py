@@ -1,0 +1,181 @@
+"""ctypes binding of libloamx.so (the C-ABI of include/loamx.h) for the Python harness (tests/, bench.py, smoke()).
+
+This is plumbing over the C-ABI, not a second implementation: every method is one `loamx_*` call.  There is no CPU
+fallback — if the shared library is missing or no GPU is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libloamx.so")
+
+OK, SKIPPED, E_INVALID, E_CAPACITY, E_HIP, E_NOGPU = 0, 1, -1, -2, -3, -4
+
+
+class Cloud(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("count", C.c_uint32), ("stride", C.c_uint32),
+                ("intensity_offset", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class ScanRegConfig(C.Structure):
+    _fields_ = [("scan_period", C.c_float), ("n_feature_regions", C.c_int), ("curvature_region", C.c_int),
+                ("max_corner_sharp", C.c_int), ("max_surface_flat", C.c_int), ("less_flat_filter_size", C.c_float),
+                ("surface_curvature_threshold", C.c_float), ("device", C.c_int)]
+
+
+class OdomConfig(C.Structure):
+    _fields_ = [("scan_period", C.c_float), ("max_iterations", C.c_int), ("delta_t_abort", C.c_float),
+                ("delta_r_abort", C.c_float), ("device", C.c_int)]
+
+
+class MapConfig(C.Structure):
+    _fields_ = [("scan_period", C.c_float), ("max_iterations", C.c_int), ("delta_t_abort", C.c_float),
+                ("delta_r_abort", C.c_float), ("corner_filter_size", C.c_float), ("surf_filter_size", C.c_float),
+                ("map_filter_size", C.c_float), ("device", C.c_int)]
+
+
+class LoamxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"loamx error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libloamx.so (built in-tree by __graft_entry__.build()).  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "(no CPU fallback exists)")
+        L = C.CDLL(LIB_PATH)
+        L.loamx_last_error.restype = C.c_char_p
+        for n in ("loamx_scanreg_create", "loamx_odom_create", "loamx_map_create", "loamx_batch_create",
+                  "loamx_batch_stream"):
+            if hasattr(L, n):
+                getattr(L, n).restype = C.c_void_p
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise LoamxError(rc, lib().loamx_last_error().decode())
+    return rc
+
+
+def device_count() -> int:
+    return int(lib().loamx_device_count())
+
+
+def as_points(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim == 1:
+        a = a.reshape(-1, 4)
+    assert a.ndim == 2 and a.shape[1] in (4, 8), "points must be (N,4) packed xyzi or (N,8) PCL PointXYZI records"
+    return a
+
+
+def cloud_of(a: np.ndarray) -> Cloud:
+    """Describe a (N,4) packed or (N,8) PCL-layout float32 array."""
+    stride = a.shape[1] * 4
+    return Cloud(a.ctypes.data if a.size else None, a.shape[0], stride, 12 if stride == 16 else 16, 0)
+
+
+def to_pcl_layout(a: np.ndarray) -> np.ndarray:
+    """(N,4) xyzi -> (N,8) pcl::PointXYZI records {x,y,z,1, intensity,0,0,0}."""
+    out = np.zeros((len(a), 8), np.float32)
+    out[:, :3] = a[:, :3]
+    out[:, 3] = 1.0
+    out[:, 4] = a[:, 3]
+    return out
+
+
+def _cfg(struct_t, default_fn, **kw):
+    c = struct_t()
+    getattr(lib(), default_fn)(C.byref(c))
+    for k, v in kw.items():
+        assert hasattr(c, k), k
+        setattr(c, k, v)
+    return c
+
+
+class Batch:
+    """loamx_batch_*: B independent sweeps registered against one frozen sub-map."""
+
+    def __init__(self, max_sweeps: int, **cfg):
+        self._c = _cfg(MapConfig, "loamx_map_default_config", **cfg)
+        self.h = C.c_void_p(lib().loamx_batch_create(C.byref(self._c), max_sweeps))
+        if not self.h:
+            raise LoamxError(E_INVALID, lib().loamx_last_error().decode())
+        self.n = 0
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().loamx_batch_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_frozen(self, corner_map, surf_map):
+        c, s = as_points(corner_map), as_points(surf_map)
+        cc, sc = cloud_of(c), cloud_of(s)
+        _check(lib().loamx_batch_set_frozen(self.h, C.byref(cc), C.byref(sc)))
+
+    def set_frozen_device(self, d_corner_ptr: int, n_corner: int, d_surf_ptr: int, n_surf: int):
+        _check(lib().loamx_batch_set_frozen_device(self.h, C.c_void_p(d_corner_ptr), n_corner, C.c_void_p(d_surf_ptr), n_surf))
+
+    def upload(self, corner_last, surf_last, guesses, full_res=None):
+        n = len(corner_last)
+        assert len(surf_last) == n and len(guesses) == n
+        cl = [as_points(a) for a in corner_last]
+        sl = [as_points(a) for a in surf_last]
+        fr = [as_points(a) for a in full_res] if full_res is not None else None
+        CA = (Cloud * n)(*[cloud_of(a) for a in cl])
+        SA = (Cloud * n)(*[cloud_of(a) for a in sl])
+        FA = (Cloud * n)(*[cloud_of(a) for a in fr]) if fr is not None else None
+        g = np.ascontiguousarray(guesses, np.float32).reshape(n, 6)
+        _check(lib().loamx_batch_upload(self.h, n, CA, SA, FA, g.ctypes.data_as(C.c_void_p)))
+        self.n = n
+        self._full_sizes = [len(a) for a in fr] if fr is not None else None
+
+    def run(self):
+        return _check(lib().loamx_batch_run(self.h))
+
+    def run_async(self):
+        _check(lib().loamx_batch_run_async(self.h))
+
+    def sync(self):
+        _check(lib().loamx_batch_sync(self.h))
+
+    def download(self):
+        poses = np.zeros((self.n, 6), np.float32)
+        stats = np.zeros((self.n, 4), np.int32)
+        _check(lib().loamx_batch_download(self.h, poses.ctypes.data_as(C.c_void_p), stats.ctypes.data_as(C.c_void_p)))
+        return poses, stats
+
+    def download_full_res(self, sweep: int):
+        out = np.zeros((self._full_sizes[sweep], 4), np.float32)
+        c = cloud_of(out)
+        _check(lib().loamx_batch_download_full_res(self.h, sweep, C.byref(c)))
+        return out[:c.count]
+
+    def set_timing(self, on: bool):
+        _check(lib().loamx_batch_set_timing(self.h, 1 if on else 0))
+
+    def timing(self):
+        ms = (C.c_float * 4)()
+        cnt = (C.c_uint64 * 4)()
+        _check(lib().loamx_batch_get_timing(self.h, ms, cnt))
+        return dict(run_ms=ms[0], residual_ms=ms[1], residual_launches=int(cnt[0]), query_iterations=int(cnt[1]),
+                    queries=int(cnt[2]))
+
+    @property
+    def stream(self) -> int:
+        return int(lib().loamx_batch_stream(self.h) or 0)

@@ -1,0 +1,67 @@
+// C-ABI: feature extraction (loamx_scanreg_*) — shim over loamx::FeatureExtractor.
+#include "features.cuh"
+
+using namespace loamx;
+
+struct loamx_scanreg {
+  FeatureExtractor fx;
+  explicit loamx_scanreg(int device) : fx(device) {}
+};
+
+extern "C" {
+
+void loamx_scanreg_default_config(loamx_scanreg_config* cfg) {
+  if (!cfg) return;
+  cfg->scan_period = 0.1f;
+  cfg->n_feature_regions = 6;
+  cfg->curvature_region = 5;
+  cfg->max_corner_sharp = 2;
+  cfg->max_surface_flat = 4;
+  cfg->less_flat_filter_size = 0.2f;
+  cfg->surface_curvature_threshold = 0.1f;
+  cfg->device = 0;
+}
+
+loamx_scanreg* loamx_scanreg_create(const loamx_scanreg_config* cfg) {
+  loamx_scanreg* h = nullptr;
+  guard([&]() {
+    loamx_scanreg_config c;
+    if (cfg) c = *cfg; else loamx_scanreg_default_config(&c);
+    // same validation as the reference's parameter parsing (ScanRegistration.cpp:49-138)
+    LX_REQUIRE(c.scan_period > 0.f, "scan_period must be positive");
+    LX_REQUIRE(c.n_feature_regions >= 1, "n_feature_regions must be >= 1");
+    LX_REQUIRE(c.curvature_region >= 1, "curvature_region must be >= 1");
+    LX_REQUIRE(c.max_corner_sharp >= 1, "max_corner_sharp must be >= 1");
+    LX_REQUIRE(c.max_surface_flat >= 1, "max_surface_flat must be >= 1");
+    LX_REQUIRE(c.less_flat_filter_size >= 0.001f, "less_flat_filter_size must be >= 0.001");
+    LX_REQUIRE(c.surface_curvature_threshold >= 0.001f, "surface_curvature_threshold must be >= 0.001");
+    h = new loamx_scanreg(c.device);
+    FeatParams& p = h->fx.params;
+    p.scan_period = c.scan_period;
+    p.n_regions = c.n_feature_regions;
+    p.curv_region = c.curvature_region;
+    p.max_sharp = c.max_corner_sharp;
+    p.max_less_sharp = 10 * c.max_corner_sharp;   // RegistrationParams ctor, BasicScanRegistration.cpp:22
+    p.max_flat = c.max_surface_flat;
+    p.less_flat_leaf = c.less_flat_filter_size;
+    p.curv_thr = c.surface_curvature_threshold;
+    return LOAMX_OK;
+  });
+  return h;
+}
+
+void loamx_scanreg_destroy(loamx_scanreg* h) { delete h; }
+
+int loamx_scanreg_process(loamx_scanreg* h, const loamx_cloud* cloud, const uint32_t* ring_size, uint32_t n_rings,
+                          loamx_cloud* sharp, loamx_cloud* less_sharp, loamx_cloud* flat, loamx_cloud* less_flat) {
+  return guard([&]() {
+    LX_REQUIRE(h && cloud && ring_size && n_rings > 0, "NULL / empty argument");
+    const uint32_t* rs[1] = {ring_size};
+    h->fx.upload(1, cloud, rs, &n_rings);
+    h->fx.run_async();
+    h->fx.sync();
+    return h->fx.download(0, sharp, less_sharp, flat, less_flat);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+// Per-sweep feature extraction (BasicScanRegistration::extractFeatures, IMU-less) for a batch of sweeps.
+#pragma once
+#include "common.h"
+#include "voxel.cuh"
+
+namespace loamx {
+
+struct FeatParams {
+  float scan_period = 0.1f;
+  int n_regions = 6;
+  int curv_region = 5;
+  int max_sharp = 2;
+  int max_less_sharp = 20;
+  int max_flat = 4;
+  float less_flat_leaf = 0.2f;
+  float curv_thr = 0.1f;
+};
+
+class FeatureExtractor {
+ public:
+  FeatureExtractor(int device, hipStream_t shared_stream = nullptr);
+  ~FeatureExtractor();
+  FeatParams params;
+  hipStream_t stream() const { return st_; }
+
+  // stage nsw sweeps: cloud[s] = rings concatenated, ring_size[s][0..n_rings[s])
+  void upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings);
+  void run_async();
+  void sync();
+  // host copies of one sweep's outputs (after sync); any pointer may be NULL
+  int download(uint32_t sweep, loamx_cloud* sharp, loamx_cloud* less_sharp, loamx_cloud* flat, loamx_cloud* less_flat);
+
+  // device-side results for chaining (valid after run_async on the same stream):
+  //   kind 0 sharp, 1 less_sharp, 2 flat: compact arrays + per-sweep offsets [nsw+1]
+  //   less_flat: voxel-filtered per ring; d_less_flat_ring_off [total_rings+1]; sweep s owns rings [ring_base(s), ring_base(s+1))
+  const float4* d_feat(int kind) const { return out_[kind].p; }
+  const uint32_t* d_feat_off(int kind) const { return out_off_[kind].p; }
+  const float4* d_less_flat() const { return lf_out_.p; }
+  const uint32_t* d_less_flat_ring_off() const { return lf_off_.p; }
+  const float4* d_cloud() const { return cloud_.p; }
+  uint32_t n_points() const { return n_; }
+  uint32_t n_sweeps() const { return nsw_; }
+  uint32_t ring_base(uint32_t s) const { return h_ring_base_[s]; }
+  uint32_t point_base(uint32_t s) const { return h_pt_base_[s]; }
+  uint32_t total_rings() const { return nring_; }
+
+ private:
+  int device_;
+  hipStream_t st_ = nullptr;
+  bool own_stream_ = false;
+  uint32_t nsw_ = 0, n_ = 0, nring_ = 0, max_ring_len_ = 0;
+  std::vector<uint32_t> h_ring_off_, h_ring_base_, h_pt_base_, h_ring_sweep_base_;
+  PinBuf<float4> h_cloud_;
+  DevBuf<float4> cloud_;
+  DevBuf<uint32_t> ring_off_, ring_sweep_base_;   // ring_off_[nring+1] global point offsets; sweep base offset per ring
+  DevBuf<float> curv_;
+  DevBuf<uint8_t> flags_, lf_valid_;
+  DevBuf<float4> slots_[3];       // per-ring fixed-capacity pick slots (sharp / less sharp / flat)
+  DevBuf<uint32_t> slot_cnt_[3];  // per-ring counts
+  DevBuf<float4> out_[3];
+  DevBuf<uint32_t> out_off_[3], sweep_ring_base_;
+  DevBuf<float4> lf_out_;
+  DevBuf<uint32_t> lf_off_;
+  VoxelPipeline vox_;
+  PinBuf<uint32_t> h_off_;
+};
+
+}  // namespace loamx

@@ -1,0 +1,421 @@
+// Feature extraction kernels for gfx950 — reference src/lib/BasicScanRegistration.cpp:155-386.
+//
+//   k_feat_point   per point: curvature stencil (+-curvatureRegion neighbours on the ring, :293-306) and the
+//                  unreliable-point masks of setScanBuffersFor (:321-363).  Streaming, coalesced float4 loads.
+//   k_feat_ring    one wave64 per scan ring.  For each of the ring's feature regions: stable rank sort of the
+//                  curvatures in LDS (:311-317), then the order-dependent greedy picks (:198-235) done
+//                  cooperatively: the 64 lanes test the next 64 candidates in sorted order, a ballot finds the first
+//                  admissible one, and markAsPicked (:367-386) suppresses its neighbours before the next round — the
+//                  sequential semantics are kept exactly, only the skipping of masked candidates is parallel.
+//                  Regions of a ring are processed in order because suppression spills across region borders.
+//   VoxelPipeline  per-ring pcl::VoxelGrid(0.2 m) of the less-flat candidates (:246-252).
+//   k_feat_*       compaction of the per-ring pick slots into the four output clouds (ring order, pick order).
+#include "features.cuh"
+#include "scan.cuh"
+
+namespace loamx {
+
+__device__ inline float sqdiff3(const float4& a, const float4& b) {
+  const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+  return dx * dx + dy * dy + dz * dz;
+}
+__device__ inline float sqdiff3w(const float4& a, const float4& b, float wb) {
+  const float dx = a.x - b.x * wb, dy = a.y - b.y * wb, dz = a.z - b.z * wb;
+  return dx * dx + dy * dy + dz * dz;
+}
+
+// grid = (ceil(max_ring_len/256), nring)
+__global__ __launch_bounds__(256) void k_feat_point(const float4* __restrict__ cloud, const uint32_t* __restrict__ ring_off, int cr,
+                                                    float* __restrict__ curv, uint8_t* __restrict__ flags) {
+  const uint32_t r = blockIdx.y;
+  const uint32_t s0 = ring_off[r], e1 = ring_off[r + 1];
+  const uint32_t len = e1 - s0;
+  if (len <= 2u * cr + 1u) return;
+  const uint32_t e0 = e1 - 1;
+  const uint32_t i = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < s0 + cr || i > e0 - cr) return;
+  const float4 p = cloud[i];
+  // curvature (:293-306): diff = -2*cr*p + sum_j (p[i+j] + p[i-j])
+  const float w = (float)(-2 * cr);
+  float dx = w * p.x, dy = w * p.y, dz = w * p.z;
+  for (int j = 1; j <= cr; j++) {
+    const float4 a = cloud[i + j], b = cloud[i - j];
+    dx += a.x + b.x;
+    dy += a.y + b.y;
+    dz += a.z + b.z;
+  }
+  curv[i] = dx * dx + dy * dy + dz * dz;
+  if (i >= e0 - cr) return;   // the mask loop stops one short (:328)
+  // setScanBuffersFor (:329-361); flags are only ever set to 1, so concurrent writers are benign
+  const float4 prev = cloud[i - 1], next = cloud[i + 1];
+  const float diffNext = sqdiff3(next, p);
+  if ((double)diffNext > 0.1) {
+    const float depth1 = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+    const float depth2 = sqrtf(next.x * next.x + next.y * next.y + next.z * next.z);
+    if (depth1 > depth2) {
+      const float wd = sqrtf(sqdiff3w(next, p, depth2 / depth1)) / depth2;
+      if ((double)wd < 0.1) {
+        for (int k = 0; k <= cr; k++) flags[i - cr + k] = 1;
+        return;   // `continue` in the reference: the parallel-beam test is skipped
+      }
+    } else {
+      const float wd = sqrtf(sqdiff3w(p, next, depth1 / depth2)) / depth1;
+      if ((double)wd < 0.1)
+        for (int k = 0; k <= cr; k++) flags[i + 1 + k] = 1;
+    }
+  }
+  const float diffPrev = sqdiff3(p, prev);
+  const float dis = p.x * p.x + p.y * p.y + p.z * p.z;
+  if ((double)diffNext > 0.0002 * (double)dis && (double)diffPrev > 0.0002 * (double)dis) flags[i] = 1;
+}
+
+struct RingLds {
+  uint8_t* flags;
+  float* c;
+  uint32_t* sorted;
+  int8_t* label;
+};
+
+// suppress the neighbours of a picked point (markAsPicked :367-386); whole wave participates
+__device__ inline void mark_as_picked(const float4* __restrict__ cloud, uint32_t g /* global index */, uint32_t scan_i, int cr,
+                                      uint8_t* flags, int lane) {
+  bool brk = false;
+  if (lane < cr) {
+    const int i = lane + 1;
+    brk = (double)sqdiff3(cloud[g + i], cloud[g + i - 1]) > 0.05;
+  } else if (lane >= 32 && lane < 32 + cr) {
+    const int i = lane - 32 + 1;
+    brk = (double)sqdiff3(cloud[g - i], cloud[g - i + 1]) > 0.05;
+  }
+  const unsigned long long m = __ballot(brk);
+  const uint32_t mf = (uint32_t)(m & 0xffffffffull), mb = (uint32_t)(m >> 32);
+  const int nf = mf ? __builtin_ctz(mf) : cr;
+  const int nb = mb ? __builtin_ctz(mb) : cr;
+  if (lane == 0) flags[scan_i] = 1;
+  if (lane < nf) flags[scan_i + lane + 1] = 1;
+  if (lane >= 32 && lane - 32 < nb) flags[scan_i - (lane - 32) - 1] = 1;
+  __syncthreads();
+}
+
+// one wave per ring; dynamic LDS: flags[flag_bytes] | c[nmax] | sorted[nmax] | label[nmax]
+__global__ __launch_bounds__(64) void k_feat_ring(const float4* __restrict__ cloud, const uint32_t* __restrict__ ring_off,
+                                                  const uint32_t* __restrict__ ring_sweep_base, FeatParams P,
+                                                  const float* __restrict__ curv, const uint8_t* __restrict__ gflags,
+                                                  uint32_t flag_bytes, uint32_t nmax, float4* __restrict__ slotS,
+                                                  float4* __restrict__ slotLS, float4* __restrict__ slotF, uint32_t* __restrict__ cntS,
+                                                  uint32_t* __restrict__ cntLS, uint32_t* __restrict__ cntF, uint8_t* __restrict__ lf_valid) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint8_t* flags = (uint8_t*)smem;
+  float* c = (float*)(smem + flag_bytes);
+  uint32_t* sorted = (uint32_t*)(c + nmax);
+  int8_t* label = (int8_t*)(sorted + nmax);
+
+  const uint32_t r = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint32_t s0g = ring_off[r], len = ring_off[r + 1] - s0g;
+  const int cr = P.curv_region, nreg = P.n_regions;
+  const uint32_t capS = P.max_sharp * nreg, capLS = P.max_less_sharp * nreg, capF = P.max_flat * nreg;
+  uint32_t nS = 0, nLS = 0, nF = 0;
+  if (len > 2u * cr + 1u) {
+    const uint32_t base = ring_sweep_base[r];
+    // indices relative to the sweep's cloud, exactly the values the reference's integer region formula sees (:180-183)
+    const unsigned long long s0 = s0g - base, e0 = s0 + len - 1;
+    for (uint32_t k = lane; k < len; k += 64) flags[k] = gflags[s0g + k];
+    __syncthreads();
+    for (int j = 0; j < nreg; j++) {
+      const unsigned long long sp = ((s0 + cr) * (unsigned long long)(nreg - j) + (e0 - cr) * (unsigned long long)j) / nreg;
+      const unsigned long long ep = ((s0 + cr) * (unsigned long long)(nreg - 1 - j) + (e0 - cr) * (unsigned long long)(j + 1)) / nreg - 1;
+      if (ep <= sp) continue;
+      const uint32_t n = (uint32_t)(ep - sp + 1);
+      const uint32_t gsp = base + (uint32_t)sp;       // global index of the region's first point
+      const uint32_t scan_sp = (uint32_t)(sp - s0);    // ring-relative index of the region's first point
+      for (uint32_t e = lane; e < n; e += 64) {
+        c[e] = curv[gsp + e];
+        label[e] = 0;   // SURFACE_LESS_FLAT
+      }
+      __syncthreads();
+      // stable ascending order (:311-317): rank = #smaller + #equal-before
+      for (uint32_t e = lane; e < n; e += 64) {
+        const float ce = c[e];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < n; q++) {
+          const float cq = c[q];
+          rank += (cq < ce || (cq == ce && q < e)) ? 1u : 0u;
+        }
+        sorted[rank] = e;
+      }
+      __syncthreads();
+      // corner picks from the largest curvature down (:197-217)
+      {
+        int picked = 0;
+        int pos = (int)n;
+        while (pos > 0 && picked < P.max_less_sharp) {
+          const int kk = pos - 1 - lane;
+          const bool in = kk >= 0;
+          const uint32_t e = in ? sorted[kk] : 0u;
+          const float ce = in ? c[e] : 0.f;
+          const bool above = in && (ce > P.curv_thr);
+          const bool ok = above && flags[scan_sp + e] == 0;
+          const unsigned long long mok = __ballot(ok), mstop = __ballot(in && !above);
+          const int fo = mok ? __builtin_ctzll(mok) : 64, fs = mstop ? __builtin_ctzll(mstop) : 64;
+          if (fo < fs) {
+            const uint32_t pe = __shfl(e, fo, 64);
+            picked++;
+            const float4 pt = cloud[gsp + pe];
+            if (lane == 0) {
+              if (picked <= P.max_sharp) {
+                label[pe] = 2;
+                slotS[(size_t)r * capS + nS] = pt;
+              } else {
+                label[pe] = 1;
+              }
+              slotLS[(size_t)r * capLS + nLS] = pt;
+            }
+            if (picked <= P.max_sharp) nS++;
+            nLS++;
+            mark_as_picked(cloud, gsp + pe, scan_sp + pe, cr, flags, lane);
+            pos = pos - 1 - fo;
+          } else if (fs < 64) {
+            break;   // sorted: nothing further exceeds the threshold
+          } else {
+            pos -= 64;
+          }
+        }
+      }
+      // flat picks from the smallest curvature up (:220-235)
+      {
+        int picked = 0;
+        int pos = 0;
+        while (pos < (int)n && picked < P.max_flat) {
+          const int kk = pos + lane;
+          const bool in = kk < (int)n;
+          const uint32_t e = in ? sorted[kk] : 0u;
+          const float ce = in ? c[e] : 0.f;
+          const bool below = in && (ce < P.curv_thr);
+          const bool ok = below && flags[scan_sp + e] == 0;
+          const unsigned long long mok = __ballot(ok), mstop = __ballot(in && !below);
+          const int fo = mok ? __builtin_ctzll(mok) : 64, fs = mstop ? __builtin_ctzll(mstop) : 64;
+          if (fo < fs) {
+            const uint32_t pe = __shfl(e, fo, 64);
+            picked++;
+            if (lane == 0) {
+              label[pe] = -1;
+              slotF[(size_t)r * capF + nF] = cloud[gsp + pe];
+            }
+            nF++;
+            mark_as_picked(cloud, gsp + pe, scan_sp + pe, cr, flags, lane);
+            pos = pos + fo + 1;
+          } else if (fs < 64) {
+            break;
+          } else {
+            pos += 64;
+          }
+        }
+      }
+      __syncthreads();
+      // less-flat candidates: everything in the region that is not a corner (:238-242)
+      for (uint32_t e = lane; e < n; e += 64) lf_valid[gsp + e] = label[e] <= 0 ? 1 : 0;
+      __syncthreads();
+    }
+  }
+  if (lane == 0) {
+    cntS[r] = nS;
+    cntLS[r] = nLS;
+    cntF[r] = nF;
+  }
+}
+
+// exclusive prefix of per-ring counts -> prefix[nring+1]; one block per kind
+__global__ __launch_bounds__(1024) void k_feat_prefix(const uint32_t* __restrict__ c0, const uint32_t* __restrict__ c1,
+                                                      const uint32_t* __restrict__ c2, uint32_t nring, uint32_t* __restrict__ p0,
+                                                      uint32_t* __restrict__ p1, uint32_t* __restrict__ p2) {
+  __shared__ uint32_t lds[17];
+  const uint32_t* cnt = blockIdx.x == 0 ? c0 : (blockIdx.x == 1 ? c1 : c2);
+  uint32_t* pre = blockIdx.x == 0 ? p0 : (blockIdx.x == 1 ? p1 : p2);
+  uint32_t carry = 0;
+  for (uint32_t b = 0; b < nring; b += 1024) {
+    const uint32_t i = b + threadIdx.x;
+    const uint32_t v = i < nring ? cnt[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_excl_scan(v, lds, total);
+    if (i < nring) pre[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) pre[nring] = carry;
+}
+
+// grid = (nring, 3): copy a ring's slots to its compact position
+__global__ __launch_bounds__(64) void k_feat_copy(const float4* __restrict__ s0, const float4* __restrict__ s1,
+                                                  const float4* __restrict__ s2, const uint32_t* __restrict__ c0,
+                                                  const uint32_t* __restrict__ c1, const uint32_t* __restrict__ c2,
+                                                  const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1,
+                                                  const uint32_t* __restrict__ p2, uint32_t cap0, uint32_t cap1, uint32_t cap2,
+                                                  float4* __restrict__ o0, float4* __restrict__ o1, float4* __restrict__ o2) {
+  const uint32_t r = blockIdx.x, kind = blockIdx.y;
+  const float4* s = kind == 0 ? s0 : (kind == 1 ? s1 : s2);
+  const uint32_t* c = kind == 0 ? c0 : (kind == 1 ? c1 : c2);
+  const uint32_t* p = kind == 0 ? p0 : (kind == 1 ? p1 : p2);
+  const uint32_t cap = kind == 0 ? cap0 : (kind == 1 ? cap1 : cap2);
+  float4* o = kind == 0 ? o0 : (kind == 1 ? o1 : o2);
+  const uint32_t n = c[r], dst = p[r];
+  for (uint32_t k = threadIdx.x; k < n; k += 64) o[dst + k] = s[(size_t)r * cap + k];
+}
+
+// per-sweep offsets: off[kind][s] = prefix[kind][ring_base[s]]
+__global__ void k_feat_sweep_off(const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1, const uint32_t* __restrict__ p2,
+                                 const uint32_t* __restrict__ sweep_ring_base, uint32_t nsw, uint32_t* __restrict__ o0,
+                                 uint32_t* __restrict__ o1, uint32_t* __restrict__ o2) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > nsw) return;
+  const uint32_t rb = sweep_ring_base[s];
+  o0[s] = p0[rb];
+  o1[s] = p1[rb];
+  o2[s] = p2[rb];
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+FeatureExtractor::FeatureExtractor(int device, hipStream_t shared_stream) : device_(device) {
+  select_device(device);
+  if (shared_stream) {
+    st_ = shared_stream;
+  } else {
+    LX_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    own_stream_ = true;
+  }
+  vox_.init(st_);
+}
+
+FeatureExtractor::~FeatureExtractor() {
+  if (own_stream_ && st_) (void)hipStreamDestroy(st_);
+}
+
+void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
+  LX_REQUIRE(nsw >= 1 && clouds && ring_size && n_rings, "invalid sweep batch");
+  LX_REQUIRE(params.curv_region >= 1 && params.curv_region <= 16, "curvature_region must be in [1,16]");
+  LX_REQUIRE(params.n_regions >= 1 && params.n_regions <= 64, "n_feature_regions must be in [1,64]");
+  LX_REQUIRE(params.max_sharp >= 0 && params.max_flat >= 0 && params.max_less_sharp >= params.max_sharp, "invalid pick limits");
+  LX_REQUIRE(params.less_flat_leaf > 0.f, "less_flat_filter_size must be positive");
+  LX_HIP(hipSetDevice(device_));
+  nsw_ = nsw;
+  h_ring_off_.assign(1, 0);
+  h_ring_base_.assign(nsw + 1, 0);
+  h_pt_base_.assign(nsw + 1, 0);
+  h_ring_sweep_base_.clear();
+  max_ring_len_ = 0;
+  uint32_t pt = 0;
+  for (uint32_t s = 0; s < nsw; s++) {
+    check_cloud(&clouds[s], false);
+    uint32_t sum = 0;
+    for (uint32_t r = 0; r < n_rings[s]; r++) {
+      sum += ring_size[s][r];
+      h_ring_off_.push_back(pt + sum);
+      h_ring_sweep_base_.push_back(pt);
+      max_ring_len_ = std::max(max_ring_len_, ring_size[s][r]);
+    }
+    LX_REQUIRE(sum == clouds[s].count, "ring sizes do not add up to the cloud size");
+    pt += sum;
+    h_pt_base_[s + 1] = pt;
+    h_ring_base_[s + 1] = h_ring_base_[s] + n_rings[s];
+  }
+  n_ = pt;
+  nring_ = h_ring_base_[nsw];
+  LX_REQUIRE(nring_ >= 1, "no scan rings");
+  h_cloud_.reserve(n_ + 1);
+  for (uint32_t s = 0; s < nsw; s++) pack_cloud(&clouds[s], h_cloud_.p + h_pt_base_[s]);
+  cloud_.reserve(n_ + 1);
+  curv_.reserve(n_ + 1);
+  flags_.reserve(n_ + 1);
+  lf_valid_.reserve(n_ + 1);
+  lf_out_.reserve(n_ + 1);
+  ring_off_.reserve(nring_ + 2);
+  ring_sweep_base_.reserve(nring_ + 2);
+  lf_off_.reserve(nring_ + 2);
+  sweep_ring_base_.reserve(nsw + 2);
+  const uint32_t caps[3] = {(uint32_t)(params.max_sharp * params.n_regions), (uint32_t)(params.max_less_sharp * params.n_regions),
+                            (uint32_t)(params.max_flat * params.n_regions)};
+  for (int k = 0; k < 3; k++) {
+    slots_[k].reserve((size_t)nring_ * caps[k] + 1);
+    out_[k].reserve((size_t)nring_ * caps[k] + 1);
+    slot_cnt_[k].reserve(2 * (size_t)nring_ + 4);   // counts [0,nring) + prefix [nring+1 .. 2nring+2)
+    out_off_[k].reserve(nsw + 2);
+  }
+  vox_.reserve(n_ + 1, nring_);
+  if (n_) LX_HIP(hipMemcpyAsync(cloud_.p, h_cloud_.p, sizeof(float4) * n_, hipMemcpyHostToDevice, st_));
+  LX_HIP(hipMemcpyAsync(ring_off_.p, h_ring_off_.data(), sizeof(uint32_t) * (nring_ + 1), hipMemcpyHostToDevice, st_));
+  LX_HIP(hipMemcpyAsync(ring_sweep_base_.p, h_ring_sweep_base_.data(), sizeof(uint32_t) * nring_, hipMemcpyHostToDevice, st_));
+  LX_HIP(hipMemcpyAsync(sweep_ring_base_.p, h_ring_base_.data(), sizeof(uint32_t) * (nsw + 1), hipMemcpyHostToDevice, st_));
+  LX_HIP(hipStreamSynchronize(st_));
+}
+
+void FeatureExtractor::run_async() {
+  LX_REQUIRE(nsw_ > 0, "run() before upload()");
+  LX_HIP(hipSetDevice(device_));
+  const int cr = params.curv_region;
+  LX_HIP(hipMemsetAsync(flags_.p, 0, n_ + 1, st_));
+  LX_HIP(hipMemsetAsync(lf_valid_.p, 0, n_ + 1, st_));
+  if (n_ && max_ring_len_) {
+    hipLaunchKernelGGL(k_feat_point, dim3((max_ring_len_ + 255) / 256, nring_), dim3(256), 0, st_, cloud_.p, ring_off_.p, cr, curv_.p,
+                       flags_.p);
+  }
+  const uint32_t flag_bytes = (max_ring_len_ + 15u) & ~15u;
+  const uint32_t nmax = (max_ring_len_ / (uint32_t)params.n_regions + 4u + 3u) & ~3u;
+  const size_t lds = (size_t)flag_bytes + (size_t)nmax * (4 + 4 + 1) + 16;
+  LX_REQUIRE(lds <= 160 * 1024, "scan ring too long for the LDS staging of k_feat_ring");
+  const uint32_t caps[3] = {(uint32_t)(params.max_sharp * params.n_regions), (uint32_t)(params.max_less_sharp * params.n_regions),
+                            (uint32_t)(params.max_flat * params.n_regions)};
+  if (lds > 64 * 1024)
+    LX_HIP(hipFuncSetAttribute((const void*)k_feat_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_feat_ring, dim3(nring_), dim3(64), lds, st_, cloud_.p, ring_off_.p, ring_sweep_base_.p, params, curv_.p,
+                     flags_.p, flag_bytes, nmax, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p,
+                     lf_valid_.p);
+  uint32_t* pre[3] = {slot_cnt_[0].p + nring_ + 1, slot_cnt_[1].p + nring_ + 1, slot_cnt_[2].p + nring_ + 1};
+  hipLaunchKernelGGL(k_feat_prefix, dim3(3), dim3(1024), 0, st_, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p, nring_, pre[0], pre[1],
+                     pre[2]);
+  hipLaunchKernelGGL(k_feat_copy, dim3(nring_, 3), dim3(64), 0, st_, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p,
+                     slot_cnt_[1].p, slot_cnt_[2].p, pre[0], pre[1], pre[2], caps[0], caps[1], caps[2], out_[0].p, out_[1].p, out_[2].p);
+  hipLaunchKernelGGL(k_feat_sweep_off, dim3((nsw_ + 64) / 64), dim3(64), 0, st_, pre[0], pre[1], pre[2], sweep_ring_base_.p, nsw_,
+                     out_off_[0].p, out_off_[1].p, out_off_[2].p);
+  // per-ring voxel grid of the less-flat candidates
+  const float inv = 1.0f / params.less_flat_leaf;
+  vox_.compute_ijk(cloud_.p, lf_valid_.p, n_, ring_off_.p, nring_, inv, inv);
+  vox_.sort_reduce(cloud_.p, lf_valid_.p, n_, ring_off_.p, nring_, lf_out_.p, lf_off_.p);
+  LX_HIP(hipGetLastError());
+}
+
+void FeatureExtractor::sync() { LX_HIP(hipStreamSynchronize(st_)); }
+
+int FeatureExtractor::download(uint32_t sweep, loamx_cloud* sharp, loamx_cloud* less_sharp, loamx_cloud* flat, loamx_cloud* less_flat) {
+  LX_REQUIRE(sweep < nsw_, "sweep index out of range");
+  h_off_.reserve(3 * (nsw_ + 1) + nring_ + 2);
+  uint32_t* ho[3] = {h_off_.p, h_off_.p + (nsw_ + 1), h_off_.p + 2 * (nsw_ + 1)};
+  uint32_t* hlf = h_off_.p + 3 * (nsw_ + 1);
+  for (int k = 0; k < 3; k++)
+    LX_HIP(hipMemcpyAsync(ho[k], out_off_[k].p, sizeof(uint32_t) * (nsw_ + 1), hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipMemcpyAsync(hlf, lf_off_.p, sizeof(uint32_t) * (nring_ + 1), hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipStreamSynchronize(st_));
+  int rc = LOAMX_OK;
+  loamx_cloud* outs[3] = {sharp, less_sharp, flat};
+  std::vector<float4> tmp;
+  for (int k = 0; k < 3; k++) {
+    if (!outs[k]) continue;
+    check_cloud(outs[k], false);
+    const uint32_t a = ho[k][sweep], b = ho[k][sweep + 1];
+    tmp.resize(b - a);
+    if (b > a) LX_HIP(hipMemcpyAsync(tmp.data(), out_[k].p + a, sizeof(float4) * (b - a), hipMemcpyDeviceToHost, st_));
+    LX_HIP(hipStreamSynchronize(st_));
+    int r = unpack_cloud(tmp.data(), b - a, outs[k]);
+    if (r != LOAMX_OK) rc = r;
+  }
+  if (less_flat) {
+    check_cloud(less_flat, false);
+    const uint32_t a = hlf[h_ring_base_[sweep]], b = hlf[h_ring_base_[sweep + 1]];
+    tmp.resize(b - a);
+    if (b > a) LX_HIP(hipMemcpyAsync(tmp.data(), lf_out_.p + a, sizeof(float4) * (b - a), hipMemcpyDeviceToHost, st_));
+    LX_HIP(hipStreamSynchronize(st_));
+    int r = unpack_cloud(tmp.data(), b - a, less_flat);
+    if (r != LOAMX_OK) rc = r;
+  }
+  return rc;
+}
+
+}  // namespace loamx

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "dev_math.cuh"
+#include "voxel.cuh"
 
 namespace loamx {
 
@@ -96,11 +97,7 @@ class Registrar {
   DevBuf<float4> in_, stack_, ds_pts_, full_;
   DevBuf<uint32_t> seg_off_, full_off_, ds_off_;
   DevBuf<float> guess_;
-  DevBuf<int> ijk_, seg_minmax_;   // ijk: 3 ints / point; seg_minmax: 6 ints / segment
-  DevBuf<unsigned long long> keys_, keys_sorted_;
-  DevBuf<uint32_t> vals_, vals_sorted_, head_, head_scan_, tile_sums_, scratch_;
-  DevBuf<char> sort_tmp_;
-  size_t sort_tmp_bytes_ = 0;
+  VoxelPipeline vox_;
   uint32_t n_in_ = 0, n_full_ = 0, max_q_per_sweep_ = 0;
 
   DevBuf<Pose> poses_;

@@ -12,7 +12,7 @@
 // 16-byte load; queries are processed in voxel order, so the lanes of a wave walk the same few grid cells.
 #include "registration.cuh"
 #include "scan.cuh"
-#include <rocprim/rocprim.hpp>
+#include "voxel.cuh"
 
 namespace loamx {
 
@@ -43,11 +43,6 @@ __global__ void k_init_bbox(uint32_t* scratch) {
   if (t < 3) scratch[t] = 0xffffffffu;
   else if (t < 16) scratch[t] = 0u;
 }
-__global__ void k_init_minmax(int* mm, uint32_t nseg) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 6 * nseg) mm[i] = (i % 6) < 3 ? 2147483647 : (-2147483647 - 1);
-}
-__global__ void k_set_u32(uint32_t* p, uint32_t v) { *p = v; }
 __global__ void k_zero_u32_dn(uint32_t* p, const uint32_t* d_n) {
   const uint32_t n = *d_n;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
@@ -168,22 +163,13 @@ void SubMapIndex::build(const float4* d_pts, uint32_t n) {
 // ----------------------------------------------------------------------------------------------------------------
 // stack round trip + voxel keys
 // ----------------------------------------------------------------------------------------------------------------
-__device__ inline uint32_t find_seg(const uint32_t* __restrict__ off, uint32_t nseg, uint32_t i) {
-  uint32_t lo = 0, hi = nseg;   // off[lo] <= i < off[hi]
-  while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (off[mid] <= i) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
 // seg_minmax: per segment min ix,iy,iz / max ix,iy,iz
 __global__ __launch_bounds__(256) void k_stack(const float4* __restrict__ in, uint32_t n, const uint32_t* __restrict__ seg_off,
                                                uint32_t nseg, const Pose* __restrict__ poses, float inv_corner, float inv_surf,
                                                float4* __restrict__ stack, int* __restrict__ ijk, int* __restrict__ seg_minmax) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t seg = find_seg(seg_off, nseg, i);
+  const uint32_t seg = vox_find_seg(seg_off, nseg, i);
   const Pose T = poses[seg >> 1];
   float4 p = in[i];
   float x = p.x, y = p.y, z = p.z;
@@ -196,60 +182,6 @@ __global__ __launch_bounds__(256) void k_stack(const float4* __restrict__ in, ui
   int* mm = seg_minmax + 6 * seg;
   atomicMin(&mm[0], ix); atomicMin(&mm[1], iy); atomicMin(&mm[2], iz);
   atomicMax(&mm[3], ix); atomicMax(&mm[4], iy); atomicMax(&mm[5], iz);
-}
-
-// key = seg << 36 | dz << 24 | dy << 12 | dx  (order == PCL's ix + iy*divx + iz*divx*divy inside a segment).
-// A segment whose box would overflow PCL's int32 voxel index (or our 12-bit fields) is passed through unfiltered,
-// as PCL does ("leaf size is too small"): every point keeps its own key.
-__global__ __launch_bounds__(256) void k_keys(uint32_t n, const uint32_t* __restrict__ seg_off, uint32_t nseg,
-                                              const int* __restrict__ ijk, const int* __restrict__ seg_minmax,
-                                              unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t seg = find_seg(seg_off, nseg, i);
-  const int* mm = seg_minmax + 6 * seg;
-  const long long dx = (long long)mm[3] - mm[0] + 1, dy = (long long)mm[4] - mm[1] + 1, dz = (long long)mm[5] - mm[2] + 1;
-  unsigned long long k;
-  if (dx * dy * dz > 2147483647LL || dx > 4096 || dy > 4096 || dz > 4096) {
-    k = (unsigned long long)(i - seg_off[seg]);
-  } else {
-    k = ((unsigned long long)(ijk[3 * i + 2] - mm[2]) << 24) | ((unsigned long long)(ijk[3 * i + 1] - mm[1]) << 12) |
-        (unsigned long long)(ijk[3 * i] - mm[0]);
-  }
-  keys[i] = ((unsigned long long)seg << 36) | k;
-  vals[i] = i;
-}
-
-__global__ __launch_bounds__(256) void k_heads(const unsigned long long* __restrict__ keys, uint32_t n, uint32_t* __restrict__ head) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
-}
-
-// one thread per voxel head: float mean of x,y,z,intensity over the run, accumulated in input order
-__global__ __launch_bounds__(256) void k_voxel_reduce(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                      const uint32_t* __restrict__ head, const uint32_t* __restrict__ head_scan,
-                                                      uint32_t n, const float4* __restrict__ stack, float4* __restrict__ out) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || !head[i]) return;
-  const unsigned long long k = keys[i];
-  float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-  uint32_t j = i;
-  do {
-    float4 p = stack[vals[j]];
-    sx += p.x; sy += p.y; sz += p.z; si += p.w;
-    j++;
-  } while (j < n && keys[j] == k);
-  const float cnt = (float)(j - i);
-  out[head_scan[i]] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
-}
-
-// ds_off[s] = number of voxels before segment s; ds_off[nseg] = total
-__global__ void k_ds_offsets(const uint32_t* __restrict__ head_scan, const uint32_t* __restrict__ seg_off, uint32_t nseg,
-                             uint32_t n, uint32_t* __restrict__ ds_off) {
-  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s > nseg) return;
-  ds_off[s] = (s == nseg || seg_off[s] >= n) ? head_scan[n] : head_scan[seg_off[s]];
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -515,7 +447,7 @@ __global__ __launch_bounds__(256) void k_transform_full(float4* __restrict__ ful
                                                         uint32_t ns, const Pose* __restrict__ poses) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t s = find_seg(full_off, ns, i);
+  const uint32_t s = vox_find_seg(full_off, ns, i);
   const Pose T = poses[s];
   float4 p = full[i];
   to_map(T, p.x, p.y, p.z);
@@ -538,9 +470,7 @@ Registrar::Registrar(int device, uint32_t max_sweeps) : device_(device), max_swe
   seg_off_.reserve(2 * max_sweeps + 2);
   full_off_.reserve(max_sweeps + 2);
   ds_off_.reserve(2 * max_sweeps + 2);
-  seg_minmax_.reserve((size_t)12 * max_sweeps);
-  tile_sums_.reserve(8192);
-  scratch_.reserve(16);
+  vox_.init(st_);
   h_stats_.reserve(max_sweeps);
   h_poses_.reserve(max_sweeps);
   ev_.resize(2 + 2 * 64);
@@ -603,13 +533,7 @@ void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const 
   in_.reserve(n_in_ + 1);
   stack_.reserve(n_in_ + 1);
   ds_pts_.reserve(n_in_ + 1);
-  ijk_.reserve((size_t)3 * n_in_ + 3);
-  keys_.reserve(n_in_ + 1);
-  keys_sorted_.reserve(n_in_ + 1);
-  vals_.reserve(n_in_ + 1);
-  vals_sorted_.reserve(n_in_ + 1);
-  head_.reserve(n_in_ + 2);
-  head_scan_.reserve(n_in_ + 2);
+  vox_.reserve(n_in_ + 1, 2 * n_sweeps);
   LX_REQUIRE(n_in_ < SCAN_MAX_N, "too many feature points in one batch");
   for (uint32_t s = 0; s < n_sweeps; s++) {
     pack_cloud(&corner_last[s], h_in_.p + h_seg_off_[2 * s]);
@@ -626,13 +550,6 @@ void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const 
   }
   memcpy(h_guess_.p, guess6, sizeof(float) * 6 * n_sweeps);
   LX_HIP(hipMemcpyAsync(guess_.p, h_guess_.p, sizeof(float) * 6 * n_sweeps, hipMemcpyHostToDevice, st_));
-  // sort scratch
-  size_t need = 0;
-  LX_HIP(rocprim::radix_sort_pairs(nullptr, need, keys_.p, keys_sorted_.p, vals_.p, vals_sorted_.p, (size_t)n_in_, 0, 48, st_));
-  if (need > sort_tmp_bytes_) {
-    sort_tmp_.reserve(need);
-    sort_tmp_bytes_ = need;
-  }
   nblk_ = (max_q_per_sweep_ + LX_RES_THREADS - 1) / LX_RES_THREADS;
   if (nblk_ == 0) nblk_ = 1;
   partials_.reserve((size_t)n_sweeps * nblk_ * LX_NSUM);
@@ -647,20 +564,11 @@ void Registrar::run_async() {
   n_res_launch_ = 0;
   hipLaunchKernelGGL(k_pose_init, dim3((ns + 63) / 64), dim3(64), 0, st_, guess_.p, ns, poses_.p, stats_.p);
   if (n > 0) {
-    // per-segment voxel bounds: min = INT_MAX, max = INT_MIN
-    hipLaunchKernelGGL(k_init_minmax, dim3((6 * nseg + 255) / 256), dim3(256), 0, st_, seg_minmax_.p, nseg);
     const uint32_t nb = (n + 255) / 256;
+    vox_.reset_minmax(nseg);
     hipLaunchKernelGGL(k_stack, dim3(nb), dim3(256), 0, st_, in_.p, n, seg_off_.p, nseg, poses_.p, 1.0f / params.corner_leaf,
-                       1.0f / params.surf_leaf, stack_.p, ijk_.p, seg_minmax_.p);
-    hipLaunchKernelGGL(k_keys, dim3(nb), dim3(256), 0, st_, n, seg_off_.p, nseg, ijk_.p, seg_minmax_.p, keys_.p, vals_.p);
-    size_t tmp = sort_tmp_bytes_;
-    LX_HIP(rocprim::radix_sort_pairs(sort_tmp_.p, tmp, keys_.p, keys_sorted_.p, vals_.p, vals_sorted_.p, (size_t)n, 0, 48, st_));
-    hipLaunchKernelGGL(k_heads, dim3(nb), dim3(256), 0, st_, keys_sorted_.p, n, head_.p);
-    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st_, scratch_.p, n);
-    exclusive_scan_u32(head_.p, head_scan_.p, tile_sums_.p, scratch_.p, scratch_.p + 1, n, st_);
-    hipLaunchKernelGGL(k_voxel_reduce, dim3(nb), dim3(256), 0, st_, keys_sorted_.p, vals_sorted_.p, head_.p, head_scan_.p, n, stack_.p,
-                       ds_pts_.p);
-    hipLaunchKernelGGL(k_ds_offsets, dim3((nseg + 64) / 64), dim3(64), 0, st_, head_scan_.p, seg_off_.p, nseg, n, ds_off_.p);
+                       1.0f / params.surf_leaf, stack_.p, vox_.ijk(), vox_.seg_minmax());
+    vox_.sort_reduce(stack_.p, nullptr, n, seg_off_.p, nseg, ds_pts_.p, ds_off_.p);
   } else {
     LX_HIP(hipMemsetAsync(ds_off_.p, 0, sizeof(uint32_t) * (nseg + 1), st_));
   }

@@ -1,0 +1,51 @@
+// Segmented voxel-grid down-sampling (pcl::VoxelGrid semantics) on device: keys -> radix sort -> run heads ->
+// exclusive scan -> per-voxel float means in input order.  Used for the mapping stack clouds
+// (reference BasicLaserMapping.cpp:519-527), the per-ring less-flat clouds (BasicScanRegistration.cpp:246-252) and the
+// per-cube map re-filtering (BasicLaserMapping.cpp:580-593).
+//
+// Voxel membership = floor(p * (1/leaf)) per axis (PCL multiplies by the reciprocal leaf); output order inside a
+// segment = ascending (iz, iy, ix) = PCL's ascending voxel index; the mean covers x, y, z and intensity.  PCL's
+// unstable std::sort leaves the summation order inside a voxel unspecified; here it is input order (stable radix sort).
+#pragma once
+#include "common.h"
+#include "scan.cuh"
+
+namespace loamx {
+
+constexpr int VOX_SEG_SHIFT = 36;
+
+__device__ inline uint32_t vox_find_seg(const uint32_t* __restrict__ off, uint32_t nseg, uint32_t i) {
+  uint32_t lo = 0, hi = nseg;   // off[lo] <= i < off[hi]
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+class VoxelPipeline {
+ public:
+  void init(hipStream_t st);
+  void reserve(uint32_t n_slots, uint32_t nseg);
+  int* ijk() { return ijk_.p; }
+  int* seg_minmax() { return seg_minmax_.p; }
+  void reset_minmax(uint32_t nseg);
+  // optional helper: ijk + per-segment bounds from points (valid may be NULL = all valid);
+  // segment s uses inv_even when s is even, inv_odd otherwise
+  void compute_ijk(const float4* pts, const uint8_t* valid, uint32_t n, const uint32_t* d_seg_off, uint32_t nseg, float inv_even,
+                   float inv_odd);
+  // after ijk()/seg_minmax() are filled for the n slots: sort + reduce.  out gets the voxel means, d_out_off[nseg+1]
+  // the per-segment output offsets.  Slots with valid[i]==0 are ignored.
+  void sort_reduce(const float4* pts, const uint8_t* valid, uint32_t n, const uint32_t* d_seg_off, uint32_t nseg, float4* out,
+                   uint32_t* d_out_off);
+
+ private:
+  hipStream_t st_ = nullptr;
+  DevBuf<int> ijk_, seg_minmax_;
+  DevBuf<unsigned long long> keys_, keys_sorted_;
+  DevBuf<uint32_t> vals_, vals_sorted_, head_, head_scan_, tile_sums_, scratch_;
+  DevBuf<char> sort_tmp_;
+  size_t sort_tmp_bytes_ = 0;
+};
+
+}  // namespace loamx

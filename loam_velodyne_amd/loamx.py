@@ -179,3 +179,35 @@ class Batch:
     @property
     def stream(self) -> int:
         return int(lib().loamx_batch_stream(self.h) or 0)
+
+
+class ScanRegistration:
+    """loamx_scanreg_*: BasicScanRegistration::processScanlines / extractFeatures on the GPU."""
+    NAMES = ("sharp", "less_sharp", "flat", "less_flat")
+
+    def __init__(self, **cfg):
+        self._c = _cfg(ScanRegConfig, "loamx_scanreg_default_config", **cfg)
+        self.h = C.c_void_p(lib().loamx_scanreg_create(C.byref(self._c)))
+        if not self.h:
+            raise LoamxError(E_INVALID, lib().loamx_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().loamx_scanreg_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def process(self, points, ring_sizes, pcl_layout=False):
+        pts = as_points(points)
+        rs = np.ascontiguousarray(ring_sizes, np.uint32)
+        n = len(pts)
+        width = 8 if pcl_layout else 4
+        outs = [np.zeros((max(n, 1), width), np.float32) for _ in range(4)]
+        cl = [cloud_of(o) for o in outs]
+        cin = cloud_of(pts)
+        _check(lib().loamx_scanreg_process(self.h, C.byref(cin), rs.ctypes.data_as(C.c_void_p), len(rs), C.byref(cl[0]),
+                                           C.byref(cl[1]), C.byref(cl[2]), C.byref(cl[3])))
+        res = {name: outs[k][:cl[k].count].copy() for k, name in enumerate(self.NAMES)}
+        res["full"] = pts[:, :4].copy() if pts.shape[1] == 4 else pts
+        return res

@@ -1,0 +1,83 @@
+// C-ABI: sweep-to-sweep odometry (loamx_odom_*) — shim over loamx::Odometry.
+#include "odometry.cuh"
+
+using namespace loamx;
+
+struct loamx_odom {
+  Odometry od;
+  explicit loamx_odom(int device) : od(device) {}
+};
+
+extern "C" {
+
+void loamx_odom_default_config(loamx_odom_config* cfg) {
+  if (!cfg) return;
+  cfg->scan_period = 0.1f;
+  cfg->max_iterations = 25;
+  cfg->delta_t_abort = 0.1f;
+  cfg->delta_r_abort = 0.1f;
+  cfg->device = 0;
+}
+
+loamx_odom* loamx_odom_create(const loamx_odom_config* cfg) {
+  loamx_odom* h = nullptr;
+  guard([&]() {
+    loamx_odom_config c;
+    if (cfg) c = *cfg; else loamx_odom_default_config(&c);
+    // same validation as LaserOdometry::setup (LaserOdometry.cpp:70-138)
+    LX_REQUIRE(c.scan_period > 0.f, "scan_period must be positive");
+    LX_REQUIRE(c.max_iterations >= 1, "max_iterations must be >= 1");
+    LX_REQUIRE(c.delta_t_abort > 0.f && c.delta_r_abort > 0.f, "abort thresholds must be positive");
+    h = new loamx_odom(c.device);
+    h->od.params.scan_period = c.scan_period;
+    h->od.params.max_iterations = c.max_iterations;
+    h->od.params.delta_t_abort = c.delta_t_abort;
+    h->od.params.delta_r_abort = c.delta_r_abort;
+    return LOAMX_OK;
+  });
+  return h;
+}
+void loamx_odom_destroy(loamx_odom* h) { delete h; }
+
+int loamx_odom_update_imu(loamx_odom* h, const float imu_trans[12]) {
+  return guard([&]() {
+    LX_REQUIRE(h && imu_trans, "NULL argument");
+    h->od.update_imu(imu_trans);
+    return LOAMX_OK;
+  });
+}
+int loamx_odom_process(loamx_odom* h, const loamx_cloud* sharp, const loamx_cloud* less_sharp, const loamx_cloud* flat,
+                       const loamx_cloud* less_flat) {
+  return guard([&]() {
+    LX_REQUIRE(h && sharp && less_sharp && flat && less_flat, "NULL argument");
+    return h->od.process(sharp, less_sharp, flat, less_flat);
+  });
+}
+int loamx_odom_get_transform(loamx_odom* h, float t[6]) {
+  return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->od.get_transform(t); return LOAMX_OK; });
+}
+int loamx_odom_get_transform_sum(loamx_odom* h, float t[6]) {
+  return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->od.get_transform_sum(t); return LOAMX_OK; });
+}
+int loamx_odom_set_transform(loamx_odom* h, const float t[6]) {
+  return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->od.set_transform(t); return LOAMX_OK; });
+}
+int loamx_odom_set_transform_sum(loamx_odom* h, const float t[6]) {
+  return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->od.set_transform_sum(t); return LOAMX_OK; });
+}
+int loamx_odom_get_last_clouds(loamx_odom* h, loamx_cloud* last_corner, loamx_cloud* last_surf) {
+  return guard([&]() { LX_REQUIRE(h, "NULL handle"); return h->od.get_last_clouds(last_corner, last_surf); });
+}
+int loamx_odom_transform_to_end(loamx_odom* h, loamx_cloud* cloud) {
+  return guard([&]() { LX_REQUIRE(h && cloud, "NULL argument"); return h->od.transform_to_end(cloud); });
+}
+int loamx_odom_get_stats(loamx_odom* h, int stats[4]) {
+  return guard([&]() {
+    LX_REQUIRE(h && stats, "NULL argument");
+    OdomStats s = h->od.stats();
+    stats[0] = s.iterations; stats[1] = s.sel; stats[2] = s.frame; stats[3] = s.degenerate;
+    return LOAMX_OK;
+  });
+}
+
+}  // extern "C"

@@ -211,3 +211,71 @@ class ScanRegistration:
         res = {name: outs[k][:cl[k].count].copy() for k, name in enumerate(self.NAMES)}
         res["full"] = pts[:, :4].copy() if pts.shape[1] == 4 else pts
         return res
+
+
+class LaserOdometry:
+    """loamx_odom_*: BasicLaserOdometry on the GPU."""
+
+    def __init__(self, **cfg):
+        self._c = _cfg(OdomConfig, "loamx_odom_default_config", **cfg)
+        self.h = C.c_void_p(lib().loamx_odom_create(C.byref(self._c)))
+        if not self.h:
+            raise LoamxError(E_INVALID, lib().loamx_last_error().decode())
+        self._sizes = (0, 0)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().loamx_odom_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def update_imu(self, t12):
+        t = np.ascontiguousarray(t12, np.float32)
+        _check(lib().loamx_odom_update_imu(self.h, t.ctypes.data_as(C.c_void_p)))
+
+    def process(self, feats):
+        arrs = [as_points(feats[n]) for n in ("sharp", "less_sharp", "flat", "less_flat")]
+        cl = [cloud_of(a) for a in arrs]
+        rc = _check(lib().loamx_odom_process(self.h, C.byref(cl[0]), C.byref(cl[1]), C.byref(cl[2]), C.byref(cl[3])))
+        self._sizes = (len(arrs[1]), len(arrs[3]))
+        return rc
+
+    def _t(self, fn):
+        t = np.zeros(6, np.float32)
+        _check(fn(self.h, t.ctypes.data_as(C.c_void_p)))
+        return t
+
+    @property
+    def transform(self):
+        return self._t(lib().loamx_odom_get_transform)
+
+    @property
+    def transform_sum(self):
+        return self._t(lib().loamx_odom_get_transform_sum)
+
+    def set_transform(self, t6):
+        t = np.ascontiguousarray(t6, np.float32)
+        _check(lib().loamx_odom_set_transform(self.h, t.ctypes.data_as(C.c_void_p)))
+
+    def set_transform_sum(self, t6):
+        t = np.ascontiguousarray(t6, np.float32)
+        _check(lib().loamx_odom_set_transform_sum(self.h, t.ctypes.data_as(C.c_void_p)))
+
+    def last_clouds(self):
+        c = np.zeros((max(self._sizes[0], 1), 4), np.float32)
+        s = np.zeros((max(self._sizes[1], 1), 4), np.float32)
+        cc, sc = cloud_of(c), cloud_of(s)
+        _check(lib().loamx_odom_get_last_clouds(self.h, C.byref(cc), C.byref(sc)))
+        return c[:cc.count].copy(), s[:sc.count].copy()
+
+    def transform_to_end(self, cloud):
+        a = as_points(cloud).copy()
+        c = cloud_of(a)
+        _check(lib().loamx_odom_transform_to_end(self.h, C.byref(c)))
+        return a
+
+    def stats(self):
+        s = (C.c_int * 4)()
+        _check(lib().loamx_odom_get_stats(self.h, s))
+        return dict(iterations=s[0], sel=s[1], frame=s[2], degenerate=s[3])

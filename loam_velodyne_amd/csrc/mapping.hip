@@ -1,0 +1,626 @@
+// Sequential scan-to-map registration with a live map (BasicLaserMapping::process) for gfx950.
+//
+// Map layout in HBM (per feature type): ONE flat packed-float4 array + a parallel uint32 tag array holding the
+// absolute 50 m-cube coordinates of each point.  The reference's 21x11x21 pointer grid (BasicLaserMapping.cpp:60-95,
+// :311-441) becomes pure bookkeeping: shifting the window only changes (cenW, cenH, cenD); points whose cube leaves
+// the window are dropped at the next partition.  Per sweep (one pass over the map at HBM speed each):
+//   k_map_classify + scans + k_map_partition   sub-map (valid cubes, :503-509) | rest | dropped
+//   Registrar (B = 1)                           stack round trip, voxel DS, grid index, <= 10 GN iterations (:511-533)
+//   k_map_insert                                re-project DS features with the optimised pose, bucket into cubes (:536-577)
+//   VoxelPipeline (segments = valid cubes)      per-cube pcl::VoxelGrid re-filtering (:580-593)
+//   k_map_append / k_map_hist                   next map = rest ++ filtered; per-cube counts for the host directory
+// Host: closed-form pose prediction (:103-167), cube window + field-of-view selection (:300-500), transformUpdate.
+#include "registration.cuh"
+#include "host_math.h"
+#include "scan.cuh"
+
+namespace loamx {
+
+constexpr int MW = 21, MH = 11, MD = 21, MCUBES = MW * MH * MD;
+
+__host__ __device__ inline uint32_t pack_tag(int ia, int ja, int ka) {
+  return (uint32_t)(ia + 512) | ((uint32_t)(ja + 512) << 10) | ((uint32_t)(ka + 512) << 20);
+}
+__host__ __device__ inline void unpack_tag(uint32_t t, int& ia, int& ja, int& ka) {
+  ia = (int)(t & 1023u) - 512;
+  ja = (int)((t >> 10) & 1023u) - 512;
+  ka = (int)((t >> 20) & 1023u) - 512;
+}
+// cube index of a map coordinate relative to the map origin (BasicLaserMapping.cpp:303-309 / :540-546 without the
+// window centre): double arithmetic, truncation, negative fix-up
+__host__ __device__ inline int cube_abs(float v) {
+  const double CUBE_SIZE = 50.0, CUBE_HALF = CUBE_SIZE / 2;
+  int c = (int)(((double)v + CUBE_HALF) / CUBE_SIZE);
+  if ((double)v + CUBE_HALF < 0) c--;
+  return c;
+}
+
+struct MapWindow {
+  int cen[3];
+};
+
+// cls: 0 dropped (outside the window), 1 rest, 2 valid (slot in seg)
+__global__ __launch_bounds__(256) void k_map_classify(const uint32_t* __restrict__ tags, uint32_t n, MapWindow w,
+                                                      const short* __restrict__ slot_lut, uint32_t* __restrict__ fv,
+                                                      uint32_t* __restrict__ fr, uint32_t* __restrict__ seg) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int ia, ja, ka;
+  unpack_tag(tags[i], ia, ja, ka);
+  const int I = ia + w.cen[0], J = ja + w.cen[1], K = ka + w.cen[2];
+  uint32_t v = 0, r = 0, s = 0;
+  if (I >= 0 && I < MW && J >= 0 && J < MH && K >= 0 && K < MD) {
+    const int slot = slot_lut[I + MW * J + MW * MH * K];
+    if (slot >= 0) { v = 1; s = (uint32_t)slot; } else r = 1;
+  }
+  fv[i] = v;
+  fr[i] = r;
+  seg[i] = s;
+}
+
+// order-preserving split: valid -> (sub_pts, sub_seg) ; rest -> (new_pts, new_tags)
+__global__ __launch_bounds__(256) void k_map_partition(const float4* __restrict__ pts, const uint32_t* __restrict__ tags, uint32_t n,
+                                                       const uint32_t* __restrict__ fv, const uint32_t* __restrict__ sv,
+                                                       const uint32_t* __restrict__ fr, const uint32_t* __restrict__ sr,
+                                                       const uint32_t* __restrict__ seg, float4* __restrict__ sub_pts,
+                                                       uint32_t* __restrict__ sub_seg, float4* __restrict__ new_pts,
+                                                       uint32_t* __restrict__ new_tags) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (fv[i]) {
+    const uint32_t d = sv[i];
+    sub_pts[d] = pts[i];
+    sub_seg[d] = seg[i];
+  } else if (fr[i]) {
+    const uint32_t d = sr[i];
+    new_pts[d] = pts[i];
+    new_tags[d] = tags[i];
+  }
+}
+
+// re-project the down-sampled features of one type with the final pose and bucket them (:536-577).
+// Filter-input slot (n_old + j) receives feature j when its cube is valid; features in other in-window cubes are
+// flagged for the rest list; the remainder (outside the window) is dropped as in the reference.
+__global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ ds_pts, const uint32_t* __restrict__ ds_off, int type,
+                                                    uint32_t n_slots, const Pose* __restrict__ pose, MapWindow w,
+                                                    const short* __restrict__ slot_lut, uint32_t n_old, float4* __restrict__ fin_pts,
+                                                    uint32_t* __restrict__ fin_seg, uint8_t* __restrict__ fin_valid,
+                                                    uint32_t* __restrict__ rest_flag, float4* __restrict__ ins_pts,
+                                                    uint32_t* __restrict__ ins_tags) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_slots) return;
+  const uint32_t a = ds_off[type], b = ds_off[type + 1];
+  uint8_t valid = 0;
+  uint32_t rest = 0;
+  if (j < b - a) {
+    const Pose T = *pose;
+    float4 p = ds_pts[a + j];
+    to_map(T, p.x, p.y, p.z);
+    const int ia = cube_abs(p.x), ja = cube_abs(p.y), ka = cube_abs(p.z);
+    const int I = ia + w.cen[0], J = ja + w.cen[1], K = ka + w.cen[2];
+    if (I >= 0 && I < MW && J >= 0 && J < MH && K >= 0 && K < MD) {
+      const int slot = slot_lut[I + MW * J + MW * MH * K];
+      if (slot >= 0) {
+        valid = 1;
+        fin_pts[n_old + j] = p;
+        fin_seg[n_old + j] = (uint32_t)slot;
+      } else {
+        rest = 1;
+        ins_pts[j] = p;
+        ins_tags[j] = pack_tag(ia, ja, ka);
+      }
+    }
+  }
+  fin_valid[n_old + j] = valid;
+  rest_flag[j] = rest;
+}
+
+// cnt[0] = number of rest points carried over (from the partition scan); appends flagged insertions after them
+__global__ __launch_bounds__(256) void k_map_append_rest(const float4* __restrict__ ins_pts, const uint32_t* __restrict__ ins_tags,
+                                                         const uint32_t* __restrict__ flag, const uint32_t* __restrict__ scan,
+                                                         uint32_t n, const uint32_t* __restrict__ d_base, float4* __restrict__ new_pts,
+                                                         uint32_t* __restrict__ new_tags) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n || !flag[j]) return;
+  const uint32_t d = *d_base + scan[j];
+  new_pts[d] = ins_pts[j];
+  new_tags[d] = ins_tags[j];
+}
+
+// filtered voxels (segment-ordered) go behind rest + inserted; base = d_base0 + d_base1
+__global__ __launch_bounds__(256) void k_map_append_filtered(const float4* __restrict__ filt, const uint32_t* __restrict__ out_off,
+                                                             uint32_t nslots, const uint32_t* __restrict__ slot_tag, uint32_t max_n,
+                                                             const uint32_t* __restrict__ d_base0, const uint32_t* __restrict__ d_base1,
+                                                             float4* __restrict__ new_pts, uint32_t* __restrict__ new_tags,
+                                                             uint32_t* __restrict__ d_total) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nf = out_off[nslots];
+  const uint32_t base = *d_base0 + *d_base1;
+  if (v == 0) *d_total = base + nf;
+  if (v >= nf || v >= max_n) return;
+  uint32_t lo = 0, hi = nslots;   // out_off[lo] <= v < out_off[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (out_off[mid] <= v) lo = mid; else hi = mid;
+  }
+  new_pts[base + v] = filt[v];
+  new_tags[base + v] = slot_tag[lo];
+}
+
+__global__ __launch_bounds__(256) void k_map_hist(const uint32_t* __restrict__ tags, const uint32_t* __restrict__ d_n, uint32_t max_n,
+                                                  MapWindow w, uint32_t* __restrict__ hist) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *d_n || i >= max_n) return;
+  int ia, ja, ka;
+  unpack_tag(tags[i], ia, ja, ka);
+  const int I = ia + w.cen[0], J = ja + w.cen[1], K = ka + w.cen[2];
+  if (I >= 0 && I < MW && J >= 0 && J < MH && K >= 0 && K < MD) atomicAdd(&hist[I + MW * J + MW * MH * K], 1u);
+}
+
+// gather flags for the surround cloud (createDownsizedMap :251-257)
+__global__ __launch_bounds__(256) void k_map_surround_flags(const uint32_t* __restrict__ tags, const uint32_t* __restrict__ d_n,
+                                                            uint32_t max_n, MapWindow w, const uint8_t* __restrict__ sur_lut,
+                                                            uint32_t* __restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= max_n) return;
+  uint32_t f = 0;
+  if (i < *d_n) {
+    int ia, ja, ka;
+    unpack_tag(tags[i], ia, ja, ka);
+    const int I = ia + w.cen[0], J = ja + w.cen[1], K = ka + w.cen[2];
+    if (I >= 0 && I < MW && J >= 0 && J < MH && K >= 0 && K < MD) f = sur_lut[I + MW * J + MW * MH * K];
+  }
+  flag[i] = f;
+}
+__global__ __launch_bounds__(256) void k_map_compact(const float4* __restrict__ pts, const uint32_t* __restrict__ flag,
+                                                     const uint32_t* __restrict__ scan, uint32_t n, uint32_t dst_base,
+                                                     const uint32_t* __restrict__ d_dst_base, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flag[i]) return;
+  const uint32_t b = dst_base + (d_dst_base ? *d_dst_base : 0u);
+  out[b + scan[i]] = pts[i];
+}
+__global__ void k_map_valid_ones(uint8_t* v, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = 1;
+}
+__global__ void k_map_surround_valid(uint8_t* v, uint32_t max_n, const uint32_t* __restrict__ d_nc, const uint32_t* __restrict__ d_ns) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < max_n) v[i] = i < (*d_nc + *d_ns) ? 1 : 0;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+struct TypeMap {   // one feature type (corner / surf)
+  DevBuf<float4> pts[2];      // double-buffered map
+  DevBuf<uint32_t> tags[2];
+  int cur = 0;
+  uint32_t n = 0;             // host copy of the point count (exact after every process())
+  std::vector<uint32_t> cube_cnt = std::vector<uint32_t>(MCUBES, 0);   // host directory, window coordinates
+  // per-sweep work buffers
+  DevBuf<uint32_t> fv, fr, sv, sr, seg, sub_seg, fin_seg, rest_flag, rest_scan, ins_tags, out_off, hist;
+  DevBuf<float4> sub, fin, ins, filt;
+  DevBuf<uint8_t> fin_valid;
+  DevBuf<uint32_t> counters;   // [0..1] valid scan n/total, [2..3] rest scan n/total, [4..5] insert-rest scan, [6] new total
+  VoxelPipeline vox;
+  DevBuf<uint32_t> tile_sums;
+  PinBuf<uint32_t> h_hist;
+  PinBuf<uint32_t> h_counters;
+};
+
+class Mapper {
+ public:
+  explicit Mapper(const loamx_map_config& cfg);
+  loamx_map_config cfg;
+  Registrar reg;
+  HTwist sum, incre, tobe, bef, aft;
+  int cen[3] = {10, 5, 10};
+  long frame_count = 0, map_frame_count = 4;
+  bool fresh_map = false;
+  SweepStats last_stats = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool last_optimized = false;
+  uint32_t last_sub[2] = {0, 0};
+  TypeMap tm[2];
+  DevBuf<short> slot_lut;
+  DevBuf<uint8_t> sur_lut;
+  DevBuf<uint32_t> slot_tag;
+  // surround cloud
+  DevBuf<float4> sur_in, sur_out;
+  DevBuf<uint32_t> sur_flag, sur_scan, sur_off, sur_cnt, sur_tiles;
+  DevBuf<uint8_t> sur_valid;
+  VoxelPipeline sur_vox;
+  uint32_t n_surround = 0;
+
+  int process(const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res);
+  void load_cubes(const loamx_cloud* corner, const loamx_cloud* surf);
+  int get_cubes(int which, loamx_cloud* out);
+  int get_surround(loamx_cloud* out);
+
+ private:
+  void shift_counts(int axis, int dir);
+  void ensure(TypeMap& t, uint32_t n_map_max, uint32_t n_in);
+};
+
+Mapper::Mapper(const loamx_map_config& c) : cfg(c), reg(c.device, 1) {
+  reg.params.max_iterations = c.max_iterations;
+  reg.params.delta_t_abort = c.delta_t_abort;
+  reg.params.delta_r_abort = c.delta_r_abort;
+  reg.params.corner_leaf = c.corner_filter_size;
+  reg.params.surf_leaf = c.surf_filter_size;
+  for (int t = 0; t < 2; t++) {
+    tm[t].vox.init(reg.stream());
+    tm[t].counters.reserve(16);
+    tm[t].tile_sums.reserve(8192);
+    tm[t].hist.reserve(MCUBES);
+    tm[t].h_hist.reserve(MCUBES);
+    tm[t].h_counters.reserve(16);
+    tm[t].out_off.reserve(130);
+  }
+  slot_lut.reserve(MCUBES);
+  sur_lut.reserve(MCUBES);
+  slot_tag.reserve(128);
+  sur_vox.init(reg.stream());
+  sur_off.reserve(4);
+  sur_cnt.reserve(16);
+  sur_tiles.reserve(8192);
+}
+
+// the reference's pointer-swap loops (:311-441) applied to the host count directory: contents move by one cube along
+// `axis` (dir=+1 towards higher indices) and the vacated layer is cleared
+void Mapper::shift_counts(int axis, int dir) {
+  const int n[3] = {MW, MH, MD};
+  for (int t = 0; t < 2; t++) {
+    std::vector<uint32_t> nc(MCUBES, 0);
+    for (int k = 0; k < MD; k++)
+      for (int j = 0; j < MH; j++)
+        for (int i = 0; i < MW; i++) {
+          int ijk[3] = {i, j, k};
+          ijk[axis] -= dir;   // source cube
+          if (ijk[axis] < 0 || ijk[axis] >= n[axis]) continue;
+          nc[i + MW * j + MW * MH * k] = tm[t].cube_cnt[ijk[0] + MW * ijk[1] + MW * MH * ijk[2]];
+        }
+    tm[t].cube_cnt.swap(nc);
+  }
+}
+
+void Mapper::ensure(TypeMap& t, uint32_t n_map_max, uint32_t n_in) {
+  hipStream_t st = reg.stream();
+  for (int b = 0; b < 2; b++) {
+    t.pts[b].reserve(n_map_max + 1, st, b == t.cur);
+    t.tags[b].reserve(n_map_max + 1, st, b == t.cur);
+  }
+  t.fv.reserve(n_map_max + 2); t.fr.reserve(n_map_max + 2); t.sv.reserve(n_map_max + 2); t.sr.reserve(n_map_max + 2);
+  t.seg.reserve(n_map_max + 1); t.sub.reserve(n_map_max + 1); t.sub_seg.reserve(n_map_max + 1);
+  t.fin.reserve(n_map_max + 1); t.fin_seg.reserve(n_map_max + 1); t.fin_valid.reserve(n_map_max + 1);
+  t.filt.reserve(n_map_max + 1);
+  t.rest_flag.reserve(n_in + 2); t.rest_scan.reserve(n_in + 2); t.ins.reserve(n_in + 1); t.ins_tags.reserve(n_in + 1);
+  t.vox.reserve(n_map_max + 1, 126);
+}
+
+int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res) {
+  check_cloud(corner_last, false);
+  check_cloud(surf_last, false);
+  if (full_res) check_cloud(full_res, false);
+  LX_HIP(hipSetDevice(cfg.device));
+  hipStream_t st = reg.stream();
+  frame_count++;
+  if (frame_count < 1) return LOAMX_SKIPPED;   // _stackFrameNum = 1 (:269-274)
+  frame_count = 0;
+
+  transform_associate_to_map(sum, bef, aft, incre, tobe);
+  const Pose guess = tobe.pose();
+
+  // pointOnYAxis (:294-298)
+  float py[3] = {0.f, 10.f, 0.f};
+  to_map(guess, py[0], py[1], py[2]);
+
+  int cc[3] = {cube_abs(tobe.pos.x) + cen[0], cube_abs(tobe.pos.y) + cen[1], cube_abs(tobe.pos.z) + cen[2]};
+  const int dims[3] = {MW, MH, MD};
+  for (int a = 0; a < 3; a++) {
+    while (cc[a] < 3) { shift_counts(a, +1); cc[a]++; cen[a]++; }
+    while (cc[a] >= dims[a] - 3) { shift_counts(a, -1); cc[a]--; cen[a]--; }
+  }
+
+  // 5x5x5 neighbourhood, FOV test on the cube corners (:443-500); valid list in the reference's i->j->k order
+  std::vector<short> lut(MCUBES, -1);
+  std::vector<uint8_t> slut(MCUBES, 0);
+  std::vector<uint32_t> stag;
+  int nvalid = 0;
+  for (int i = cc[0] - 2; i <= cc[0] + 2; i++)
+    for (int j = cc[1] - 2; j <= cc[1] + 2; j++)
+      for (int k = cc[2] - 2; k <= cc[2] + 2; k++) {
+        if (i < 0 || i >= MW || j < 0 || j >= MH || k < 0 || k >= MD) continue;
+        const float centerX = 50.0f * (i - cen[0]), centerY = 50.0f * (j - cen[1]), centerZ = 50.0f * (k - cen[2]);
+        bool in_fov = false;
+        for (int ii = -1; ii <= 1; ii += 2)
+          for (int jj = -1; jj <= 1; jj += 2)
+            for (int kk = -1; kk <= 1; kk += 2) {
+              const float cx = centerX + 25.0f * ii, cy = centerY + 25.0f * jj, cz = centerZ + 25.0f * kk;
+              const float ax = tobe.pos.x - cx, ay = tobe.pos.y - cy, az = tobe.pos.z - cz;
+              const float s1 = ax * ax + ay * ay + az * az;
+              const float bx = py[0] - cx, by = py[1] - cy, bz = py[2] - cz;
+              const float s2 = bx * bx + by * by + bz * bz;
+              const float check1 = 100.0f + s1 - s2 - 10.0f * std::sqrt(3.0f) * std::sqrt(s1);
+              const float check2 = 100.0f + s1 - s2 + 10.0f * std::sqrt(3.0f) * std::sqrt(s1);
+              if (check1 < 0 && check2 > 0) in_fov = true;
+            }
+        const int idx = i + MW * j + MW * MH * k;
+        if (in_fov) {
+          lut[idx] = (short)nvalid++;
+          stag.push_back(pack_tag(i - cen[0], j - cen[1], k - cen[2]));
+        }
+        slut[idx] = 1;
+      }
+  if (stag.empty()) stag.push_back(0);
+  uint32_t n_sub[2] = {0, 0};
+  for (int t = 0; t < 2; t++)
+    for (int idx = 0; idx < MCUBES; idx++)
+      if (lut[idx] >= 0) n_sub[t] += tm[t].cube_cnt[idx];
+  last_sub[0] = n_sub[0];
+  last_sub[1] = n_sub[1];
+
+  LX_HIP(hipMemcpyAsync(slot_lut.p, lut.data(), sizeof(short) * MCUBES, hipMemcpyHostToDevice, st));
+  LX_HIP(hipMemcpyAsync(sur_lut.p, slut.data(), MCUBES, hipMemcpyHostToDevice, st));
+  LX_HIP(hipMemcpyAsync(slot_tag.p, stag.data(), sizeof(uint32_t) * stag.size(), hipMemcpyHostToDevice, st));
+  LX_HIP(hipStreamSynchronize(st));   // the host vectors above go out of scope
+
+  MapWindow w;
+  for (int a = 0; a < 3; a++) w.cen[a] = cen[a];
+  const uint32_t n_in[2] = {corner_last->count, surf_last->count};
+
+  // ---- partition the map: sub-map | rest | dropped
+  for (int t = 0; t < 2; t++) {
+    TypeMap& T = tm[t];
+    ensure(T, T.n + n_in[t] + 64, n_in[t]);
+    const int cur = T.cur, nxt = 1 - cur;
+    if (T.n) {
+      const uint32_t nb = (T.n + 255) / 256;
+      hipLaunchKernelGGL(k_map_classify, dim3(nb), dim3(256), 0, st, T.tags[cur].p, T.n, w, slot_lut.p, T.fv.p, T.fr.p, T.seg.p);
+      exclusive_scan_u32_n(T.fv.p, T.sv.p, T.tile_sums.p, T.counters.p + 0, T.n, st);
+      exclusive_scan_u32_n(T.fr.p, T.sr.p, T.tile_sums.p, T.counters.p + 2, T.n, st);
+      hipLaunchKernelGGL(k_map_partition, dim3(nb), dim3(256), 0, st, T.pts[cur].p, T.tags[cur].p, T.n, T.fv.p, T.sv.p, T.fr.p, T.sr.p,
+                         T.seg.p, T.sub.p, T.sub_seg.p, T.pts[nxt].p, T.tags[nxt].p);
+    } else {
+      LX_HIP(hipMemsetAsync(T.counters.p, 0, sizeof(uint32_t) * 4, st));
+    }
+  }
+
+  // ---- registration against the sub-map (guard + iterations inside Registrar::run_async)
+  reg.set_submap_device(tm[0].sub.p, n_sub[0], tm[1].sub.p, n_sub[1], false);
+  float g6[6];
+  tobe.get(g6);
+  reg.upload(1, corner_last, surf_last, full_res, g6);
+  reg.run_async();
+  last_optimized = reg.submap_sufficient();
+
+  // ---- map insertion + per-cube re-filtering
+  for (int t = 0; t < 2; t++) {
+    TypeMap& T = tm[t];
+    const int nxt = 1 - T.cur;
+    const uint32_t n_old = n_sub[t], n_slots = n_in[t], n_fin = n_old + n_slots;
+    if (n_old) {
+      LX_HIP(hipMemcpyAsync(T.fin.p, T.sub.p, sizeof(float4) * n_old, hipMemcpyDeviceToDevice, st));
+      LX_HIP(hipMemcpyAsync(T.fin_seg.p, T.sub_seg.p, sizeof(uint32_t) * n_old, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(k_map_valid_ones, dim3((n_old + 255) / 256), dim3(256), 0, st, T.fin_valid.p, n_old);
+    }
+    if (n_slots) {
+      const uint32_t nb = (n_slots + 255) / 256;
+      hipLaunchKernelGGL(k_map_insert, dim3(nb), dim3(256), 0, st, reg.d_ds_points(), reg.d_ds_offsets(), t, n_slots, reg.d_poses(), w,
+                         slot_lut.p, n_old, T.fin.p, T.fin_seg.p, T.fin_valid.p, T.rest_flag.p, T.ins.p, T.ins_tags.p);
+      exclusive_scan_u32_n(T.rest_flag.p, T.rest_scan.p, T.tile_sums.p, T.counters.p + 4, n_slots, st);
+      hipLaunchKernelGGL(k_map_append_rest, dim3(nb), dim3(256), 0, st, T.ins.p, T.ins_tags.p, T.rest_flag.p, T.rest_scan.p, n_slots,
+                         T.counters.p + 3, T.pts[nxt].p, T.tags[nxt].p);
+    } else {
+      LX_HIP(hipMemsetAsync(T.counters.p + 4, 0, sizeof(uint32_t) * 2, st));
+    }
+    const uint32_t nslots = (uint32_t)std::max(nvalid, 1);
+    const float inv = 1.0f / (t == 0 ? cfg.corner_filter_size : cfg.surf_filter_size);
+    T.vox.compute_ijk(T.fin.p, T.fin_valid.p, n_fin, nullptr, nslots, inv, inv, T.fin_seg.p);
+    T.vox.sort_reduce(T.fin.p, T.fin_valid.p, n_fin, nullptr, nslots, T.filt.p, T.out_off.p, T.fin_seg.p);
+    const uint32_t max_f = n_fin ? n_fin : 1;
+    hipLaunchKernelGGL(k_map_append_filtered, dim3((max_f + 255) / 256), dim3(256), 0, st, T.filt.p, T.out_off.p, nslots, slot_tag.p,
+                       max_f, T.counters.p + 3, T.counters.p + 5, T.pts[nxt].p, T.tags[nxt].p, T.counters.p + 6);
+    LX_HIP(hipMemsetAsync(T.hist.p, 0, sizeof(uint32_t) * MCUBES, st));
+    const uint32_t max_new = T.n + n_slots + 1;
+    hipLaunchKernelGGL(k_map_hist, dim3((max_new + 255) / 256), dim3(256), 0, st, T.tags[nxt].p, T.counters.p + 6, max_new, w, T.hist.p);
+    LX_HIP(hipMemcpyAsync(T.h_hist.p, T.hist.p, sizeof(uint32_t) * MCUBES, hipMemcpyDeviceToHost, st));
+    LX_HIP(hipMemcpyAsync(T.h_counters.p, T.counters.p, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, st));
+  }
+
+  // ---- results
+  float pose6[6];
+  int stats4[4];
+  reg.download(pose6, stats4);   // synchronises the stream
+  LX_HIP(hipGetLastError());
+  for (int t = 0; t < 2; t++) {
+    TypeMap& T = tm[t];
+    LX_REQUIRE(T.n == 0 || T.h_counters.p[1] == n_sub[t], "internal: sub-map size differs from the host cube directory");
+    T.cur = 1 - T.cur;
+    T.n = T.h_counters.p[6];
+    for (int idx = 0; idx < MCUBES; idx++) T.cube_cnt[idx] = T.h_hist.p[idx];
+  }
+  SweepStats ss;
+  reg.download_stats(&ss);
+  last_stats = ss;
+  int rc = LOAMX_OK;
+  if (last_optimized) {
+    // transformUpdate (:171-203, IMU-less): only reached when the optimisation ran (:628-629)
+    tobe.set(pose6);
+    bef = sum;
+    aft = tobe;
+  }
+  if (full_res && full_res->count) {
+    int r = reg.download_full_res(0, full_res);
+    if (r != LOAMX_OK) rc = r;
+  }
+
+  // ---- createDownsizedMap (:242-264): every 5th processed frame
+  map_frame_count++;
+  fresh_map = false;
+  if (map_frame_count >= 5) {
+    map_frame_count = 0;
+    const uint32_t nc = tm[0].n, nsf = tm[1].n, ntot = nc + nsf;
+    sur_in.reserve(ntot + 1);
+    sur_out.reserve(ntot + 1);
+    sur_flag.reserve(std::max(nc, nsf) + 2);
+    sur_scan.reserve(std::max(nc, nsf) + 2);
+    sur_valid.reserve(ntot + 1);
+    sur_vox.reserve(ntot + 1, 2);
+    for (int t = 0; t < 2; t++) {
+      TypeMap& T = tm[t];
+      const uint32_t n = T.n;
+      uint32_t* cnt = sur_cnt.p + 4 * t;   // [n, total]
+      if (n) {
+        const uint32_t nb = (n + 255) / 256;
+        hipLaunchKernelGGL(k_map_surround_flags, dim3(nb), dim3(256), 0, st, T.tags[T.cur].p, T.counters.p + 6, n, w, sur_lut.p, sur_flag.p);
+        exclusive_scan_u32_n(sur_flag.p, sur_scan.p, sur_tiles.p, cnt, n, st);
+        hipLaunchKernelGGL(k_map_compact, dim3(nb), dim3(256), 0, st, T.pts[T.cur].p, sur_flag.p, sur_scan.p, n, 0u,
+                           t == 0 ? (const uint32_t*)nullptr : (const uint32_t*)(sur_cnt.p + 1), sur_in.p);
+      } else {
+        LX_HIP(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2, st));
+      }
+    }
+    if (ntot) {
+      hipLaunchKernelGGL(k_map_surround_valid, dim3((ntot + 255) / 256), dim3(256), 0, st, sur_valid.p, ntot, sur_cnt.p + 1, sur_cnt.p + 5);
+      const float inv = 1.0f / cfg.corner_filter_size;   // the corner filter, not the map filter (:261)
+      uint32_t zero_off[2] = {0, ntot};
+      LX_HIP(hipMemcpyAsync(sur_off.p, zero_off, sizeof(zero_off), hipMemcpyHostToDevice, st));
+      LX_HIP(hipStreamSynchronize(st));
+      sur_vox.compute_ijk(sur_in.p, sur_valid.p, ntot, sur_off.p, 1, inv, inv);
+      sur_vox.sort_reduce(sur_in.p, sur_valid.p, ntot, sur_off.p, 1, sur_out.p, sur_off.p + 2);
+      uint32_t off[2] = {0, 0};
+      LX_HIP(hipMemcpyAsync(off, sur_off.p + 2, sizeof(off), hipMemcpyDeviceToHost, st));
+      LX_HIP(hipStreamSynchronize(st));
+      n_surround = off[1];
+    } else {
+      n_surround = 0;
+    }
+    fresh_map = true;
+  }
+  return rc;
+}
+
+void Mapper::load_cubes(const loamx_cloud* corner, const loamx_cloud* surf) {
+  LX_HIP(hipSetDevice(cfg.device));
+  hipStream_t st = reg.stream();
+  const loamx_cloud* cl[2] = {corner, surf};
+  for (int t = 0; t < 2; t++) {
+    if (!cl[t] || !cl[t]->count) continue;
+    check_cloud(cl[t], false);
+    TypeMap& T = tm[t];
+    std::vector<float4> p(cl[t]->count), keep;
+    std::vector<uint32_t> tags;
+    pack_cloud(cl[t], p.data());
+    for (const float4& q : p) {
+      const int ia = cube_abs(q.x), ja = cube_abs(q.y), ka = cube_abs(q.z);
+      const int I = ia + cen[0], J = ja + cen[1], K = ka + cen[2];
+      if (I < 0 || I >= MW || J < 0 || J >= MH || K < 0 || K >= MD) continue;
+      keep.push_back(q);
+      tags.push_back(pack_tag(ia, ja, ka));
+      T.cube_cnt[I + MW * J + MW * MH * K]++;
+    }
+    const uint32_t add = (uint32_t)keep.size();
+    ensure(T, T.n + add + 64, 0);
+    if (add) {
+      LX_HIP(hipMemcpyAsync(T.pts[T.cur].p + T.n, keep.data(), sizeof(float4) * add, hipMemcpyHostToDevice, st));
+      LX_HIP(hipMemcpyAsync(T.tags[T.cur].p + T.n, tags.data(), sizeof(uint32_t) * add, hipMemcpyHostToDevice, st));
+      LX_HIP(hipStreamSynchronize(st));
+    }
+    T.n += add;
+  }
+}
+
+int Mapper::get_cubes(int which, loamx_cloud* out) {
+  LX_REQUIRE(which == 0 || which == 1, "which must be 0 (corner) or 1 (surf)");
+  check_cloud(out, false);
+  LX_HIP(hipSetDevice(cfg.device));
+  TypeMap& T = tm[which];
+  std::vector<float4> tmp(T.n);
+  if (T.n) LX_HIP(hipMemcpy(tmp.data(), T.pts[T.cur].p, sizeof(float4) * T.n, hipMemcpyDeviceToHost));
+  return unpack_cloud(tmp.data(), T.n, out);
+}
+
+int Mapper::get_surround(loamx_cloud* out) {
+  check_cloud(out, false);
+  LX_HIP(hipSetDevice(cfg.device));
+  std::vector<float4> tmp(n_surround);
+  if (n_surround) LX_HIP(hipMemcpy(tmp.data(), sur_out.p, sizeof(float4) * n_surround, hipMemcpyDeviceToHost));
+  return unpack_cloud(tmp.data(), n_surround, out);
+}
+
+}  // namespace loamx
+
+// ----------------------------------------------------------------------------------------------------------------
+// C-ABI
+// ----------------------------------------------------------------------------------------------------------------
+using namespace loamx;
+
+struct loamx_map {
+  Mapper m;
+  explicit loamx_map(const loamx_map_config& c) : m(c) {}
+};
+
+extern "C" {
+
+loamx_map* loamx_map_create(const loamx_map_config* cfg) {
+  loamx_map* h = nullptr;
+  guard([&]() {
+    loamx_map_config c;
+    if (cfg) c = *cfg; else loamx_map_default_config(&c);
+    // same validation as LaserMapping::setup (LaserMapping.cpp:56-152)
+    LX_REQUIRE(c.scan_period > 0.f, "scan_period must be positive");
+    LX_REQUIRE(c.max_iterations >= 1 && c.max_iterations <= 64, "max_iterations must be in [1, 64]");
+    LX_REQUIRE(c.delta_t_abort > 0.f && c.delta_r_abort > 0.f, "abort thresholds must be positive");
+    LX_REQUIRE(c.corner_filter_size >= 0.001f && c.surf_filter_size >= 0.001f, "filter sizes must be >= 0.001");
+    h = new loamx_map(c);
+    return LOAMX_OK;
+  });
+  return h;
+}
+void loamx_map_destroy(loamx_map* h) { delete h; }
+
+int loamx_map_update_odometry(loamx_map* h, const float t[6]) {
+  return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->m.sum.set(t); return LOAMX_OK; });
+}
+int loamx_map_process(loamx_map* h, const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res) {
+  return guard([&]() {
+    LX_REQUIRE(h && corner_last && surf_last, "NULL argument");
+    return h->m.process(corner_last, surf_last, full_res);
+  });
+}
+int loamx_map_get_transform(loamx_map* h, int which, float t[6]) {
+  return guard([&]() {
+    LX_REQUIRE(h && t && which >= 0 && which < 4, "invalid argument");
+    const HTwist* tw[4] = {&h->m.aft, &h->m.bef, &h->m.tobe, &h->m.sum};
+    tw[which]->get(t);
+    return LOAMX_OK;
+  });
+}
+int loamx_map_set_transform(loamx_map* h, int which, const float t[6]) {
+  return guard([&]() {
+    LX_REQUIRE(h && t && which >= 0 && which < 4, "invalid argument");
+    HTwist* tw[4] = {&h->m.aft, &h->m.bef, &h->m.tobe, &h->m.sum};
+    tw[which]->set(t);
+    return LOAMX_OK;
+  });
+}
+int loamx_map_has_fresh_map(loamx_map* h) { return (h && h->m.fresh_map) ? 1 : 0; }
+int loamx_map_get_surround(loamx_map* h, loamx_cloud* out) {
+  return guard([&]() { LX_REQUIRE(h && out, "NULL argument"); return h->m.get_surround(out); });
+}
+int loamx_map_load_cubes(loamx_map* h, const loamx_cloud* corner, const loamx_cloud* surf) {
+  return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->m.load_cubes(corner, surf); return LOAMX_OK; });
+}
+int loamx_map_get_cubes(loamx_map* h, int which, loamx_cloud* out) {
+  return guard([&]() { LX_REQUIRE(h && out, "NULL argument"); return h->m.get_cubes(which, out); });
+}
+int loamx_map_get_stats(loamx_map* h, int s[8]) {
+  return guard([&]() {
+    LX_REQUIRE(h && s, "NULL argument");
+    const SweepStats& st = h->m.last_stats;
+    s[0] = st.iterations; s[1] = st.sel; s[2] = st.corner_q; s[3] = st.surf_q;
+    s[4] = (int)h->m.last_sub[0]; s[5] = (int)h->m.last_sub[1]; s[6] = st.degenerate; s[7] = h->m.last_optimized ? 1 : 0;
+    return LOAMX_OK;
+  });
+}
+
+}  // extern "C"

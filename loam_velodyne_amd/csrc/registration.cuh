@@ -58,7 +58,7 @@ class Registrar {
 
   // frozen sub-map (host records or device float4)
   void set_submap_host(const loamx_cloud* corner, const loamx_cloud* surf);
-  void set_submap_device(const float4* d_corner, uint32_t nc, const float4* d_surf, uint32_t ns);
+  void set_submap_device(const float4* d_corner, uint32_t nc, const float4* d_surf, uint32_t ns, bool sync = true);
 
   // stage inputs (H2D, async on the stream)
   void upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const loamx_cloud* surf_last, const loamx_cloud* full_res,

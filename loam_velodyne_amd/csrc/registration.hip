@@ -500,11 +500,11 @@ void Registrar::set_submap_host(const loamx_cloud* corner, const loamx_cloud* su
   LX_HIP(hipStreamSynchronize(st_));
 }
 
-void Registrar::set_submap_device(const float4* d_corner, uint32_t nc, const float4* d_surf, uint32_t ns) {
+void Registrar::set_submap_device(const float4* d_corner, uint32_t nc, const float4* d_surf, uint32_t ns, bool sync) {
   LX_HIP(hipSetDevice(device_));
   corner_index.build(d_corner, nc);
   surf_index.build(d_surf, ns);
-  LX_HIP(hipStreamSynchronize(st_));
+  if (sync) LX_HIP(hipStreamSynchronize(st_));
 }
 
 void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const loamx_cloud* surf_last, const loamx_cloud* full_res,

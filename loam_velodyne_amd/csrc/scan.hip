@@ -68,4 +68,11 @@ void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums /
   hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, st, out, tile_sums, d_n, d_total);
 }
 
+__global__ void k_scan_set_n(uint32_t* p, uint32_t v) { *p = v; }
+
+void exclusive_scan_u32_n(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, uint32_t* scratch2, uint32_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_scan_set_n, dim3(1), dim3(1), 0, st, scratch2, n);
+  exclusive_scan_u32(in, out, tile_sums, scratch2, scratch2 + 1, n, st);
+}
+
 }  // namespace loamx

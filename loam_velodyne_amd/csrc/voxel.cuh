@@ -32,12 +32,17 @@ class VoxelPipeline {
   void reset_minmax(uint32_t nseg);
   // optional helper: ijk + per-segment bounds from points (valid may be NULL = all valid);
   // segment s uses inv_even when s is even, inv_odd otherwise
+  // d_seg_ids (optional): explicit segment id per slot instead of the contiguous ranges of d_seg_off
   void compute_ijk(const float4* pts, const uint8_t* valid, uint32_t n, const uint32_t* d_seg_off, uint32_t nseg, float inv_even,
-                   float inv_odd);
+                   float inv_odd, const uint32_t* d_seg_ids = nullptr);
   // after ijk()/seg_minmax() are filled for the n slots: sort + reduce.  out gets the voxel means, d_out_off[nseg+1]
   // the per-segment output offsets.  Slots with valid[i]==0 are ignored.
   void sort_reduce(const float4* pts, const uint8_t* valid, uint32_t n, const uint32_t* d_seg_off, uint32_t nseg, float4* out,
-                   uint32_t* d_out_off);
+                   uint32_t* d_out_off, const uint32_t* d_seg_ids = nullptr);
+  // after sort_reduce: original slot index of the first point of output voxel v is first_slot()[v] (device)
+  const uint32_t* sorted_vals() const { return vals_sorted_.p; }
+  const uint32_t* head_flags() const { return head_.p; }
+  const uint32_t* head_scan() const { return head_scan_.p; }
 
  private:
   hipStream_t st_ = nullptr;

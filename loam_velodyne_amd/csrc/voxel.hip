@@ -11,12 +11,13 @@ __global__ void k_vox_init_minmax(int* mm, uint32_t nseg) {
 __global__ void k_vox_set_u32(uint32_t* p, uint32_t v) { *p = v; }
 
 __global__ __launch_bounds__(256) void k_vox_ijk(const float4* __restrict__ pts, const uint8_t* __restrict__ valid, uint32_t n,
-                                                 const uint32_t* __restrict__ seg_off, uint32_t nseg, float inv_even, float inv_odd,
-                                                 int* __restrict__ ijk, int* __restrict__ seg_minmax) {
+                                                 const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_ids,
+                                                 uint32_t nseg, float inv_even, float inv_odd, int* __restrict__ ijk,
+                                                 int* __restrict__ seg_minmax) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (valid && !valid[i]) return;
-  const uint32_t seg = vox_find_seg(seg_off, nseg, i);
+  const uint32_t seg = seg_ids ? seg_ids[i] : vox_find_seg(seg_off, nseg, i);
   const float inv = (seg & 1) ? inv_odd : inv_even;
   const float4 p = pts[i];
   const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv), iz = (int)floorf(p.z * inv);
@@ -31,7 +32,8 @@ __global__ __launch_bounds__(256) void k_vox_ijk(const float4* __restrict__ pts,
 // PCL does ("leaf size is too small for the input dataset"): every point keeps its own key.  Ignored slots get the
 // pseudo-segment nseg so they sort behind everything.
 __global__ __launch_bounds__(256) void k_vox_keys(uint32_t n, const uint8_t* __restrict__ valid, const uint32_t* __restrict__ seg_off,
-                                                  uint32_t nseg, const int* __restrict__ ijk, const int* __restrict__ seg_minmax,
+                                                  const uint32_t* __restrict__ seg_ids, uint32_t nseg, const int* __restrict__ ijk,
+                                                  const int* __restrict__ seg_minmax,
                                                   unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -40,12 +42,12 @@ __global__ __launch_bounds__(256) void k_vox_keys(uint32_t n, const uint8_t* __r
     keys[i] = (unsigned long long)nseg << VOX_SEG_SHIFT;
     return;
   }
-  const uint32_t seg = vox_find_seg(seg_off, nseg, i);
+  const uint32_t seg = seg_ids ? seg_ids[i] : vox_find_seg(seg_off, nseg, i);
   const int* mm = seg_minmax + 6 * seg;
   const long long dx = (long long)mm[3] - mm[0] + 1, dy = (long long)mm[4] - mm[1] + 1, dz = (long long)mm[5] - mm[2] + 1;
   unsigned long long k;
   if (dx * dy * dz > 2147483647LL || dx > 4096 || dy > 4096 || dz > 4096) {
-    k = (unsigned long long)(i - seg_off[seg]);
+    k = (unsigned long long)(seg_ids ? i : i - seg_off[seg]);
   } else {
     k = ((unsigned long long)(ijk[3 * i + 2] - mm[2]) << 24) | ((unsigned long long)(ijk[3 * i + 1] - mm[1]) << 12) |
         (unsigned long long)(ijk[3 * i] - mm[0]);
@@ -123,21 +125,21 @@ void VoxelPipeline::reset_minmax(uint32_t nseg) {
 }
 
 void VoxelPipeline::compute_ijk(const float4* pts, const uint8_t* valid, uint32_t n, const uint32_t* d_seg_off, uint32_t nseg,
-                                float inv_even, float inv_odd) {
+                                float inv_even, float inv_odd, const uint32_t* d_seg_ids) {
   reset_minmax(nseg);
   if (n == 0) return;
-  hipLaunchKernelGGL(k_vox_ijk, dim3((n + 255) / 256), dim3(256), 0, st_, pts, valid, n, d_seg_off, nseg, inv_even, inv_odd, ijk_.p,
+  hipLaunchKernelGGL(k_vox_ijk, dim3((n + 255) / 256), dim3(256), 0, st_, pts, valid, n, d_seg_off, d_seg_ids, nseg, inv_even, inv_odd, ijk_.p,
                      seg_minmax_.p);
 }
 
 void VoxelPipeline::sort_reduce(const float4* pts, const uint8_t* valid, uint32_t n, const uint32_t* d_seg_off, uint32_t nseg,
-                                float4* out, uint32_t* d_out_off) {
+                                float4* out, uint32_t* d_out_off, const uint32_t* d_seg_ids) {
   if (n == 0) {
     LX_HIP(hipMemsetAsync(d_out_off, 0, sizeof(uint32_t) * (nseg + 1), st_));
     return;
   }
   const uint32_t nb = (n + 255) / 256;
-  hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, st_, n, valid, d_seg_off, nseg, ijk_.p, seg_minmax_.p, keys_.p, vals_.p);
+  hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, st_, n, valid, d_seg_off, d_seg_ids, nseg, ijk_.p, seg_minmax_.p, keys_.p, vals_.p);
   size_t tmp = sort_tmp_bytes_;
   int seg_bits = 1;
   while ((1u << seg_bits) <= nseg) seg_bits++;

@@ -279,3 +279,75 @@ class LaserOdometry:
         s = (C.c_int * 4)()
         _check(lib().loamx_odom_get_stats(self.h, s))
         return dict(iterations=s[0], sel=s[1], frame=s[2], degenerate=s[3])
+
+
+class LaserMapping:
+    """loamx_map_*: BasicLaserMapping (live rolling map) on the GPU."""
+
+    def __init__(self, **cfg):
+        self._c = _cfg(MapConfig, "loamx_map_default_config", **cfg)
+        self.h = C.c_void_p(lib().loamx_map_create(C.byref(self._c)))
+        if not self.h:
+            raise LoamxError(E_INVALID, lib().loamx_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().loamx_map_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def update_odometry(self, t6):
+        t = np.ascontiguousarray(t6, np.float32)
+        _check(lib().loamx_map_update_odometry(self.h, t.ctypes.data_as(C.c_void_p)))
+
+    def process(self, corner_last, surf_last, full_res=None):
+        c, s = as_points(corner_last), as_points(surf_last)
+        cc, sc = cloud_of(c), cloud_of(s)
+        if full_res is not None:
+            f = as_points(full_res).copy()
+            fc = cloud_of(f)
+            rc = _check(lib().loamx_map_process(self.h, C.byref(cc), C.byref(sc), C.byref(fc)))
+            return rc, f
+        rc = _check(lib().loamx_map_process(self.h, C.byref(cc), C.byref(sc), None))
+        return rc, None
+
+    def transform(self, which="aft"):
+        t = np.zeros(6, np.float32)
+        _check(lib().loamx_map_get_transform(self.h, ("aft", "bef", "tobe", "sum").index(which), t.ctypes.data_as(C.c_void_p)))
+        return t
+
+    def set_transform(self, which, t6):
+        t = np.ascontiguousarray(t6, np.float32)
+        _check(lib().loamx_map_set_transform(self.h, ("aft", "bef", "tobe", "sum").index(which), t.ctypes.data_as(C.c_void_p)))
+
+    def has_fresh_map(self):
+        return bool(lib().loamx_map_has_fresh_map(self.h))
+
+    def _get(self, fn, *args, cap=1 << 16):
+        while True:
+            out = np.zeros((cap, 4), np.float32)
+            c = cloud_of(out)
+            rc = fn(self.h, *args, C.byref(c))
+            if rc == E_CAPACITY:
+                cap = int(c.count) + 16
+                continue
+            _check(rc)
+            return out[:c.count].copy()
+
+    def surround(self):
+        return self._get(lib().loamx_map_get_surround)
+
+    def cubes(self, which):
+        return self._get(lib().loamx_map_get_cubes, 0 if which == "corner" else 1)
+
+    def load_cubes(self, corner, surf):
+        c, s = as_points(corner), as_points(surf)
+        cc, sc = cloud_of(c), cloud_of(s)
+        _check(lib().loamx_map_load_cubes(self.h, C.byref(cc), C.byref(sc)))
+
+    def stats(self):
+        s = (C.c_int * 8)()
+        _check(lib().loamx_map_get_stats(self.h, s))
+        keys = ("iterations", "sel", "corner_ds", "surf_ds", "corner_from_map", "surf_from_map", "degenerate", "optimized")
+        return dict(zip(keys, (int(v) for v in s)))

@@ -192,6 +192,40 @@ int loamx_batch_get_timing(loamx_batch* h, float ms[4], uint64_t counts[4]);
 /* raw HIP stream of the handle (hipStream_t) so a harness can bracket it with its own events */
 void* loamx_batch_stream(loamx_batch* h);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Streaming pipeline: n independent streams, each advancing one sweep per step through feature extraction ->
+ * odometry -> registration against the frozen sub-map.  A stream keeps the reference's sequential state (odometry
+ * transform / transformSum / last clouds, mapping transformBefMapped / transformAftMapped); only the map is frozen.
+ * Sweeps are staged in HBM ahead of time, so step() is device work plus a few offset / pose read-backs.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct loamx_pipeline loamx_pipeline;
+
+loamx_pipeline* loamx_pipeline_create(const loamx_scanreg_config* fcfg, const loamx_odom_config* ocfg,
+                                      const loamx_map_config* mcfg, uint32_t n_streams);
+void loamx_pipeline_destroy(loamx_pipeline* h);
+int loamx_pipeline_set_frozen(loamx_pipeline* h, const loamx_cloud* corner_map, const loamx_cloud* surf_map);
+int loamx_pipeline_set_frozen_device(loamx_pipeline* h, const void* d_corner_xyzi, uint32_t n_corner, const void* d_surf_xyzi,
+                                     uint32_t n_surf);
+/* seed a stream's state; any pointer may be NULL (left unchanged) */
+int loamx_pipeline_set_state(loamx_pipeline* h, uint32_t stream, const float* transform, const float* transform_sum,
+                             const float* bef_mapped, const float* aft_mapped);
+/* stage n_steps sweeps per stream: sweep (t, s) = clouds[t * n_streams + s] (rings concatenated) */
+int loamx_pipeline_upload(loamx_pipeline* h, uint32_t n_steps, const loamx_cloud* clouds, const uint32_t* const* ring_size,
+                          const uint32_t* n_rings);
+/* run staged step t for every stream.  LOAMX_SKIPPED when no stream reached the registration stage (first sweeps) */
+int loamx_pipeline_step(loamx_pipeline* h, uint32_t step);
+/* stats8: odometry iterations, odometry rows, mapping iterations, mapping rows, corner queries, surf queries,
+ * degenerate, mapped */
+int loamx_pipeline_get(loamx_pipeline* h, uint32_t stream, float* transform, float* transform_sum, float* aft_mapped,
+                       int* stats8);
+/* registered full-resolution cloud of the k-th stream that was registered in the last step */
+int loamx_pipeline_download_full_res(loamx_pipeline* h, uint32_t slot, loamx_cloud* out);
+int loamx_pipeline_set_timing(loamx_pipeline* h, int on);
+/* stage_ms: features, odometry, registration, whole step (HIP events on the pipeline's stream);
+ * reg_ms / counts as loamx_batch_get_timing */
+int loamx_pipeline_get_timing(loamx_pipeline* h, float stage_ms[4], float reg_ms[4], uint64_t counts[4]);
+void* loamx_pipeline_stream(loamx_pipeline* h);
+
 #ifdef __cplusplus
 }
 #endif

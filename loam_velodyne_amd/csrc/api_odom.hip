@@ -4,8 +4,8 @@
 using namespace loamx;
 
 struct loamx_odom {
-  Odometry od;
-  explicit loamx_odom(int device) : od(device) {}
+  OdometryBatch od;
+  explicit loamx_odom(int device) : od(device, 1) {}
 };
 
 extern "C" {
@@ -42,7 +42,7 @@ void loamx_odom_destroy(loamx_odom* h) { delete h; }
 int loamx_odom_update_imu(loamx_odom* h, const float imu_trans[12]) {
   return guard([&]() {
     LX_REQUIRE(h && imu_trans, "NULL argument");
-    h->od.update_imu(imu_trans);
+    h->od.update_imu(0, imu_trans);
     return LOAMX_OK;
   });
 }
@@ -50,31 +50,31 @@ int loamx_odom_process(loamx_odom* h, const loamx_cloud* sharp, const loamx_clou
                        const loamx_cloud* less_flat) {
   return guard([&]() {
     LX_REQUIRE(h && sharp && less_sharp && flat && less_flat, "NULL argument");
-    return h->od.process(sharp, less_sharp, flat, less_flat);
+    return h->od.process_host(0, sharp, less_sharp, flat, less_flat);
   });
 }
 int loamx_odom_get_transform(loamx_odom* h, float t[6]) {
-  return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->od.get_transform(t); return LOAMX_OK; });
+  return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->od.stream_state(0).transform.get(t); return LOAMX_OK; });
 }
 int loamx_odom_get_transform_sum(loamx_odom* h, float t[6]) {
-  return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->od.get_transform_sum(t); return LOAMX_OK; });
+  return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->od.stream_state(0).transform_sum.get(t); return LOAMX_OK; });
 }
 int loamx_odom_set_transform(loamx_odom* h, const float t[6]) {
-  return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->od.set_transform(t); return LOAMX_OK; });
+  return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->od.stream_state(0).transform.set(t); return LOAMX_OK; });
 }
 int loamx_odom_set_transform_sum(loamx_odom* h, const float t[6]) {
-  return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->od.set_transform_sum(t); return LOAMX_OK; });
+  return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->od.stream_state(0).transform_sum.set(t); return LOAMX_OK; });
 }
 int loamx_odom_get_last_clouds(loamx_odom* h, loamx_cloud* last_corner, loamx_cloud* last_surf) {
-  return guard([&]() { LX_REQUIRE(h, "NULL handle"); return h->od.get_last_clouds(last_corner, last_surf); });
+  return guard([&]() { LX_REQUIRE(h, "NULL handle"); return h->od.get_last_clouds(0, last_corner, last_surf); });
 }
 int loamx_odom_transform_to_end(loamx_odom* h, loamx_cloud* cloud) {
-  return guard([&]() { LX_REQUIRE(h && cloud, "NULL argument"); return h->od.transform_to_end(cloud); });
+  return guard([&]() { LX_REQUIRE(h && cloud, "NULL argument"); return h->od.transform_to_end_host(0, cloud); });
 }
 int loamx_odom_get_stats(loamx_odom* h, int stats[4]) {
   return guard([&]() {
     LX_REQUIRE(h && stats, "NULL argument");
-    OdomStats s = h->od.stats();
+    OdomStats s = h->od.stream_state(0).stats;
     stats[0] = s.iterations; stats[1] = s.sel; stats[2] = s.frame; stats[3] = s.degenerate;
     return LOAMX_OK;
   });

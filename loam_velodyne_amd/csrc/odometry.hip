@@ -1,17 +1,16 @@
 // Sweep-to-sweep odometry for gfx950 — reference src/lib/BasicLaserOdometry.cpp.
 //
 // The problem is small (<= 768 sharp + 1536 flat features against the previous sweep's <= ~60 k feature points) and
-// strictly iterative (<= 25 dependent Gauss-Newton steps), i.e. latency-bound.  One PERSISTENT workgroup per sweep runs
-// the whole loop in a single launch, so there is no kernel boundary (~1.5 us each) between the 25 iterations:
-//   every 5th iteration  (:250-302, :368-435)
-//     phase A  thread per feature: transformToStart + exact 1-NN (5 m gate) in the previous cloud through a uniform grid
-//              searched in expanding shells (replaces the kd-tree of :203-204 / :662-663)
-//     phase B  wave per feature: the +-2.5-ring window scans over the ring-ordered previous cloud, lanes striding the
-//              window, ballot for the loop's break, shuffle arg-min with scan-order tie-break
-//   every iteration      (:304-361, :437-481, :497-559)
-//     phase C  thread per feature: point-to-line / point-to-plane coefficients, Jacobian row with the de-skew chain
-//              rule, J^T J / J^T r reduced with wave shuffles (double accumulators), thread 0: 6x6 pivoted QR solve,
-//              degeneracy projector, update, convergence test.
+// strictly iterative (<= 25 dependent Gauss-Newton steps), i.e. latency-bound.  Per group of 5 iterations, for all
+// streams of a batch at once:
+//   k_odom_nn      (:250-256, :368-372)  thread per feature: transformToStart + exact 1-NN (5 m gate) in the previous
+//                  cloud through a uniform grid searched in expanding shells (replaces the kd-tree of :203-204 / :662-663)
+//   k_odom_window  (:258-302, :374-435)  wave per feature: the +-2.5-ring window scans over the ring-ordered previous
+//                  cloud, lanes striding the window, ballot for the loop's break, shuffle arg-min with scan-order tie-break
+//   k_odom_lm      (:304-361, :437-481, :497-622)  one PERSISTENT workgroup per stream runs the 5 iterations without a
+//                  kernel boundary: thread per feature point-to-line / point-to-plane coefficients and Jacobian row with
+//                  the de-skew chain rule, J^T J / J^T r reduced with wave shuffles (double accumulators), thread 0:
+//                  6x6 pivoted QR solve, degeneracy projector, update, convergence test.
 #include "odometry.cuh"
 
 namespace loamx {
@@ -102,100 +101,113 @@ __device__ inline void wave_argmin(float& d, int& j, int& order) {
   }
 }
 
-__global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict__ probs, OdomParams P) {
+// ---- phase A: nearest neighbour per feature; grid = (ceil(maxFeat/256), streams)
+__global__ __launch_bounds__(256) void k_odom_nn(OdomProblem* __restrict__ probs, OdomParams P) {
+  OdomProblem& pb = probs[blockIdx.y];
+  if (pb.done) return;
+  const int nSharp = (int)pb.n_sharp, nFeat = nSharp + (int)pb.n_flat;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nFeat) return;
+  float T[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) T[k] = pb.transform[k];
+  const bool corner = f < nSharp;
+  const float4 pi = corner ? pb.sharp[f] : pb.flat[f - nSharp];
+  float x, y, z;
+  transform_to_start(T, P.scan_period, pi, x, y, z);
+  const int c = corner ? nn1(*pb.lc_desc, pb.lc_sorted, pb.lc_cell, x, y, z) : nn1(*pb.ls_desc, pb.ls_sorted, pb.ls_cell, x, y, z);
+  pb.ind[5 * f] = c;
+  pb.ind[5 * f + 1] = -1;
+  pb.ind[5 * f + 2] = -1;
+}
+
+// ---- phase B: ring-window scans, one wave per feature; grid = (ceil(maxFeat/4), streams), 256 threads
+__global__ __launch_bounds__(256) void k_odom_window(OdomProblem* __restrict__ probs, OdomParams P) {
+  OdomProblem& pb = probs[blockIdx.y];
+  if (pb.done) return;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nSharp = (int)pb.n_sharp, nFlat = (int)pb.n_flat, nFeat = nSharp + nFlat;
+  const int f = blockIdx.x * 4 + wid;
+  if (f >= nFeat) return;
+  const int closest = pb.ind[5 * f];
+  if (closest < 0) return;   // wave-uniform
+  float T[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) T[k] = pb.transform[k];
+  const bool corner = f < nSharp;
+  const float4 pi = corner ? pb.sharp[f] : pb.flat[f - nSharp];
+  float x, y, z;
+  transform_to_start(T, P.scan_period, pi, x, y, z);
+  const float4* last = corner ? pb.last_corner : pb.last_surf;
+  const int nLast = corner ? (int)pb.n_last_corner : (int)pb.n_last_surf;
+  const int nCur = corner ? nSharp : nFlat;
+  const int bound = nCur < nLast ? nCur : nLast;   // forward scans are bounded by the CURRENT feature count (:262, :378)
+  const int cscan = (int)last[closest].w;
+  float d2 = 25.f, d3 = 25.f;
+  int j2 = -1, j3 = -1, o2 = 0x7fffffff, o3 = 0x7fffffff;
+  for (int base = closest + 1; base < bound; base += 64) {
+    const int j = base + lane;
+    const bool in = j < bound;
+    const float4 q = in ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ring = (int)q.w;
+    const bool brk = in && ((double)ring > (double)cscan + 2.5);
+    const unsigned long long mb = __ballot(brk);
+    const int fb = mb ? __builtin_ctzll(mb) : 64;
+    if (in && lane < fb) {
+      const float d = sqd(q, x, y, z);
+      const int order = j - (closest + 1);
+      if (corner) {
+        if (ring > cscan && d < d2) { d2 = d; j2 = j; o2 = order; }
+      } else {
+        if (ring <= cscan) { if (d < d2) { d2 = d; j2 = j; o2 = order; } }
+        else { if (d < d3) { d3 = d; j3 = j; o3 = order; } }
+      }
+    }
+    if (mb) break;
+  }
+  for (int base = closest - 1; base >= 0; base -= 64) {
+    const int j = base - lane;
+    const bool in = j >= 0;
+    const float4 q = in ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ring = (int)q.w;
+    const bool brk = in && ((double)ring < (double)cscan - 2.5);
+    const unsigned long long mb = __ballot(brk);
+    const int fb = mb ? __builtin_ctzll(mb) : 64;
+    if (in && lane < fb) {
+      const float d = sqd(q, x, y, z);
+      const int order = 0x40000000 + (closest - 1 - j);   // backward candidates come after all forward ones
+      if (corner) {
+        if (ring < cscan && d < d2) { d2 = d; j2 = j; o2 = order; }
+      } else {
+        if (ring >= cscan) { if (d < d2) { d2 = d; j2 = j; o2 = order; } }
+        else { if (d < d3) { d3 = d; j3 = j; o3 = order; } }
+      }
+    }
+    if (mb) break;
+  }
+  wave_argmin(d2, j2, o2);
+  if (!corner) wave_argmin(d3, j3, o3);
+  if (lane == 0) {
+    pb.ind[5 * f + 1] = j2;
+    pb.ind[5 * f + 2] = corner ? -1 : j3;
+  }
+}
+
+// ---- phase C: iterations [iter0, iter0 + n_iters) of one stream in one persistent workgroup
+__global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict__ probs, OdomParams P, int iter0, int n_iters) {
   OdomProblem& pb = probs[blockIdx.x];
+  if (pb.done) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int nSharp = (int)pb.n_sharp, nFlat = (int)pb.n_flat, nFeat = nSharp + nFlat;
-  const int nLC = (int)pb.n_last_corner, nLS = (int)pb.n_last_surf;
   __shared__ float T[6];
   __shared__ float trig[6];
   __shared__ double red[OD_WAVES][LX_NSUM];
-  __shared__ int sh_done, sh_deg;
-  __shared__ float matP[36];
+  __shared__ int sh_done;
   if (tid < 6) T[tid] = pb.transform[tid];
-  if (tid == 0) { sh_done = 0; sh_deg = 0; pb.stats.iterations = 0; pb.stats.sel = 0; pb.stats.degenerate = 0; }
+  if (tid == 0) sh_done = 0;
   __syncthreads();
-  const GridDesc gc = *pb.lc_desc, gs = *pb.ls_desc;
 
-  for (int iter = 0; iter < P.max_iterations; iter++) {
-    if (iter % 5 == 0) {
-      // ---- phase A: nearest neighbour per feature
-      for (int f = tid; f < nFeat; f += OD_THREADS) {
-        const bool corner = f < nSharp;
-        const float4 pi = corner ? pb.sharp[f] : pb.flat[f - nSharp];
-        float x, y, z;
-        transform_to_start(T, P.scan_period, pi, x, y, z);
-        const int c = corner ? nn1(gc, pb.lc_sorted, pb.lc_cell, x, y, z) : nn1(gs, pb.ls_sorted, pb.ls_cell, x, y, z);
-        pb.ind[5 * f] = c;
-        pb.ind[5 * f + 1] = -1;
-        pb.ind[5 * f + 2] = -1;
-      }
-      __syncthreads();
-      // ---- phase B: ring-window scans, one wave per feature
-      for (int f = wid; f < nFeat; f += OD_WAVES) {
-        const int closest = pb.ind[5 * f];
-        if (closest < 0) continue;   // wave-uniform
-        const bool corner = f < nSharp;
-        const float4 pi = corner ? pb.sharp[f] : pb.flat[f - nSharp];
-        float x, y, z;
-        transform_to_start(T, P.scan_period, pi, x, y, z);
-        const float4* last = corner ? pb.last_corner : pb.last_surf;
-        const int nLast = corner ? nLC : nLS;
-        const int nCur = corner ? nSharp : nFlat;
-        const int bound = nCur < nLast ? nCur : nLast;   // forward scans are bounded by the CURRENT feature count (:262, :378)
-        const int cscan = (int)last[closest].w;
-        float d2 = 25.f, d3 = 25.f;
-        int j2 = -1, j3 = -1, o2 = 0x7fffffff, o3 = 0x7fffffff;
-        for (int base = closest + 1; base < bound; base += 64) {
-          const int j = base + lane;
-          const bool in = j < bound;
-          const float4 q = in ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-          const int ring = (int)q.w;
-          const bool brk = in && ((double)ring > (double)cscan + 2.5);
-          const unsigned long long mb = __ballot(brk);
-          const int fb = mb ? __builtin_ctzll(mb) : 64;
-          if (in && lane < fb) {
-            const float d = sqd(q, x, y, z);
-            const int order = j - (closest + 1);
-            if (corner) {
-              if (ring > cscan && d < d2) { d2 = d; j2 = j; o2 = order; }
-            } else {
-              if (ring <= cscan) { if (d < d2) { d2 = d; j2 = j; o2 = order; } }
-              else { if (d < d3) { d3 = d; j3 = j; o3 = order; } }
-            }
-          }
-          if (mb) break;
-        }
-        for (int base = closest - 1; base >= 0; base -= 64) {
-          const int j = base - lane;
-          const bool in = j >= 0;
-          const float4 q = in ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-          const int ring = (int)q.w;
-          const bool brk = in && ((double)ring < (double)cscan - 2.5);
-          const unsigned long long mb = __ballot(brk);
-          const int fb = mb ? __builtin_ctzll(mb) : 64;
-          if (in && lane < fb) {
-            const float d = sqd(q, x, y, z);
-            const int order = 0x40000000 + (closest - 1 - j);   // backward candidates come after all forward ones
-            if (corner) {
-              if (ring < cscan && d < d2) { d2 = d; j2 = j; o2 = order; }
-            } else {
-              if (ring >= cscan) { if (d < d2) { d2 = d; j2 = j; o2 = order; } }
-              else { if (d < d3) { d3 = d; j3 = j; o3 = order; } }
-            }
-          }
-          if (mb) break;
-        }
-        wave_argmin(d2, j2, o2);
-        if (!corner) wave_argmin(d3, j3, o3);
-        if (lane == 0) {
-          pb.ind[5 * f + 1] = j2;
-          pb.ind[5 * f + 2] = corner ? -1 : j3;
-        }
-      }
-      __syncthreads();
-    }
-
+  for (int iter = iter0; iter < iter0 + n_iters; iter++) {
     // ---- phase C: residual rows + normal equations
     if (tid == 0) {
       trig[0] = (float)sin((double)T[0]); trig[1] = (float)cos((double)T[0]);
@@ -305,16 +317,13 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
           for (int j = i; j < 6; j++) { AtA[i * 6 + j] = AtA[j * 6 + i] = (float)sums[k]; k++; }
         for (int i = 0; i < 6; i++) AtB[i] = (float)sums[21 + i];
         qr_solve6(AtA, AtB, X);
-        if (iter == 0) {
-          sh_deg = degeneracy_projector(AtA, 10.f, matP) ? 1 : 0;
-          pb.stats.degenerate = sh_deg;
-        }
-        if (sh_deg) {
+        if (iter == 0) pb.stats.degenerate = degeneracy_projector(AtA, 10.f, pb.matP) ? 1 : 0;
+        if (pb.stats.degenerate) {
           float X2[6];
           for (int r = 0; r < 6; r++) X2[r] = X[r];
           for (int r = 0; r < 6; r++) {
             float acc = 0.f;
-            for (int c = 0; c < 6; c++) acc += matP[r * 6 + c] * X2[c];
+            for (int c = 0; c < 6; c++) acc += pb.matP[r * 6 + c] * X2[c];
             X[r] = acc;
           }
         }
@@ -334,6 +343,7 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
     if (sh_done) break;
   }
   if (tid < 6) pb.transform[tid] = T[tid];
+  if (tid == 0 && sh_done) pb.done = 1;
 }
 
 struct ToEndParams {
@@ -367,159 +377,215 @@ __global__ __launch_bounds__(256) void k_transform_to_end(float4* __restrict__ p
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-Odometry::Odometry(int device) : device_(device) {
+OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_stream) : device_(device) {
   select_device(device);
-  LX_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
-  idx_corner_.init(st_);
-  idx_surf_.init(st_);
-  prob_.reserve(1);
-  h_prob_.reserve(1);
+  LX_REQUIRE(n_streams >= 1 && n_streams <= 1024, "n_streams must be in [1, 1024]");
+  if (shared_stream) {
+    st_ = shared_stream;
+  } else {
+    LX_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    own_stream_ = true;
+  }
+  for (uint32_t s = 0; s < n_streams; s++) {
+    streams_.push_back(new OdomStream());
+    streams_.back()->idx_corner.init(st_);
+    streams_.back()->idx_surf.init(st_);
+  }
+  prob_.reserve(n_streams);
+  h_prob_.reserve(n_streams);
 }
 
-Odometry::~Odometry() {
-  if (st_) (void)hipStreamDestroy(st_);
+OdometryBatch::~OdometryBatch() {
+  for (auto* p : streams_) delete p;
+  if (own_stream_ && st_) (void)hipStreamDestroy(st_);
 }
 
-void Odometry::update_imu(const float* t) {
-  imu_pitch_start_ = HAngle(t[0]); imu_yaw_start_ = HAngle(t[1]); imu_roll_start_ = HAngle(t[2]);
-  imu_pitch_end_ = HAngle(t[3]); imu_yaw_end_ = HAngle(t[4]); imu_roll_end_ = HAngle(t[5]);
-  imu_shift_ = {t[6], t[7], t[8]};
-  imu_velo_ = {t[9], t[10], t[11]};
+void OdometryBatch::update_imu(uint32_t s, const float* t) {
+  OdomStream& S = *streams_[s];
+  S.imu_pitch_start = HAngle(t[0]); S.imu_yaw_start = HAngle(t[1]); S.imu_roll_start = HAngle(t[2]);
+  S.imu_pitch_end = HAngle(t[3]); S.imu_yaw_end = HAngle(t[4]); S.imu_roll_end = HAngle(t[5]);
+  S.imu_shift = {t[6], t[7], t[8]};
+  S.imu_velo = {t[9], t[10], t[11]};
 }
 
-void Odometry::upload_cloud(const loamx_cloud* c, DevBuf<float4>& dst) {
-  check_cloud(c, false);
-  h_stage_.reserve(c->count + 1);
-  dst.reserve(c->count + 1);
-  pack_cloud(c, h_stage_.p);
-  if (c->count) LX_HIP(hipMemcpyAsync(dst.p, h_stage_.p, sizeof(float4) * c->count, hipMemcpyHostToDevice, st_));
-  LX_HIP(hipStreamSynchronize(st_));   // the single staging buffer is reused
-}
-
-void Odometry::to_end_device(float4* pts, uint32_t n) {
+void OdometryBatch::to_end_device(uint32_t s, float4* pts, uint32_t n) {
   if (!n) return;
+  OdomStream& S = *streams_[s];
   ToEndParams P;
-  transform_.get(P.T);
-  const HAngle* ta[3] = {&transform_.rot_x, &transform_.rot_y, &transform_.rot_z};
-  const HAngle* sa[3] = {&imu_pitch_start_, &imu_yaw_start_, &imu_roll_start_};
-  const HAngle* ea[3] = {&imu_pitch_end_, &imu_yaw_end_, &imu_roll_end_};
+  S.transform.get(P.T);
+  const HAngle* ta[3] = {&S.transform.rot_x, &S.transform.rot_y, &S.transform.rot_z};
+  const HAngle* sa[3] = {&S.imu_pitch_start, &S.imu_yaw_start, &S.imu_roll_start};
+  const HAngle* ea[3] = {&S.imu_pitch_end, &S.imu_yaw_end, &S.imu_roll_end};
   for (int k = 0; k < 3; k++) {
     P.sT[k] = ta[k]->s; P.cT[k] = ta[k]->c;
     P.s_start[k] = sa[k]->s; P.c_start[k] = sa[k]->c;
     P.s_end[k] = ea[k]->s; P.c_end[k] = ea[k]->c;
   }
-  P.shift[0] = imu_shift_.x; P.shift[1] = imu_shift_.y; P.shift[2] = imu_shift_.z;
+  P.shift[0] = S.imu_shift.x; P.shift[1] = S.imu_shift.y; P.shift[2] = S.imu_shift.z;
   P.scan_period = params.scan_period;
   hipLaunchKernelGGL(k_transform_to_end, dim3((n + 255) / 256), dim3(256), 0, st_, pts, n, P);
 }
 
-int Odometry::process(const loamx_cloud* sharp, const loamx_cloud* less_sharp, const loamx_cloud* flat, const loamx_cloud* less_flat) {
-  LX_HIP(hipSetDevice(device_));
-  upload_cloud(sharp, sharp_);
-  upload_cloud(less_sharp, less_sharp_);
-  upload_cloud(flat, flat_);
-  upload_cloud(less_flat, less_flat_);
-  const uint32_t nSharp = sharp->count, nLessSharp = less_sharp->count, nFlat = flat->count, nLessFlat = less_flat->count;
-
-  if (!inited_) {   // :198-211
-    std::swap(less_sharp_.p, last_corner_.p); std::swap(less_sharp_.cap, last_corner_.cap);
-    std::swap(less_flat_.p, last_surf_.p); std::swap(less_flat_.cap, last_surf_.cap);
-    n_last_corner_ = nLessSharp;
-    n_last_surf_ = nLessFlat;
-    idx_corner_.build(last_corner_.p, n_last_corner_);
-    idx_surf_.build(last_surf_.p, n_last_surf_);
-    transform_sum_.rot_x = HAngle(transform_sum_.rot_x.r + imu_pitch_start_.r);
-    transform_sum_.rot_z = HAngle(transform_sum_.rot_z.r + imu_roll_start_.r);
-    inited_ = true;
-    LX_HIP(hipStreamSynchronize(st_));
-    return LOAMX_SKIPPED;
-  }
-  frame_++;
-  transform_.pos.x -= imu_velo_.x * params.scan_period;
-  transform_.pos.y -= imu_velo_.y * params.scan_period;
-  transform_.pos.z -= imu_velo_.z * params.scan_period;
-  stats_ = {0, 0, (int)frame_, 0};
-
-  if (n_last_corner_ > 10 && n_last_surf_ > 100) {
-    ind_.reserve((size_t)5 * (nSharp + nFlat) + 5);
-    OdomProblem& pb = *h_prob_.p;
-    pb.sharp = sharp_.p; pb.n_sharp = nSharp;
-    pb.flat = flat_.p; pb.n_flat = nFlat;
-    pb.last_corner = last_corner_.p; pb.n_last_corner = n_last_corner_;
-    pb.last_surf = last_surf_.p; pb.n_last_surf = n_last_surf_;
-    pb.lc_sorted = idx_corner_.sorted(); pb.lc_cell = idx_corner_.cell_start(); pb.lc_desc = idx_corner_.desc();
-    pb.ls_sorted = idx_surf_.sorted(); pb.ls_cell = idx_surf_.cell_start(); pb.ls_desc = idx_surf_.desc();
-    pb.ind = ind_.p;
-    transform_.get(pb.transform);
-    pb.stats = {0, 0, 0, 0};
-    LX_HIP(hipMemcpyAsync(prob_.p, h_prob_.p, sizeof(OdomProblem), hipMemcpyHostToDevice, st_));
-    hipLaunchKernelGGL(k_odom_lm, dim3(1), dim3(OD_THREADS), 0, st_, prob_.p, params);
-    LX_HIP(hipMemcpyAsync(h_prob_.p, prob_.p, sizeof(OdomProblem), hipMemcpyDeviceToHost, st_));
-    LX_HIP(hipStreamSynchronize(st_));
-    // _transform.rot_* = rad + x re-derives the cached sin/cos (:599-601)
-    transform_.set(h_prob_.p->transform);
-    stats_.iterations = h_prob_.p->stats.iterations;
-    stats_.sel = h_prob_.p->stats.sel;
-    stats_.degenerate = h_prob_.p->stats.degenerate;
-  }
-
-  // pose integration (:626-649)
-  HAngle rx, ry, rz;
-  accumulate_rotation(transform_sum_.rot_x, transform_sum_.rot_y, transform_sum_.rot_z, -transform_.rot_x,
-                      HAngle((float)(-transform_.rot_y.r * 1.05)), -transform_.rot_z, rx, ry, rz);
-  HVec3 v{transform_.pos.x - imu_shift_.x, transform_.pos.y - imu_shift_.y, (float)(transform_.pos.z * 1.05 - imu_shift_.z)};
-  h_rot_zxy(v, rz, rx, ry);
-  HVec3 trans{transform_sum_.pos.x - v.x, transform_sum_.pos.y - v.y, transform_sum_.pos.z - v.z};
-  plugin_imu_rotation(rx, ry, rz, imu_pitch_start_, imu_yaw_start_, imu_roll_start_, imu_pitch_end_, imu_yaw_end_, imu_roll_end_, rx, ry, rz);
-  transform_sum_.rot_x = rx; transform_sum_.rot_y = ry; transform_sum_.rot_z = rz;
-  transform_sum_.pos = trans;
-
-  // re-project to the sweep end and hand over as "last" clouds (:651-664)
-  to_end_device(less_sharp_.p, nLessSharp);
-  to_end_device(less_flat_.p, nLessFlat);
-  std::swap(less_sharp_.p, last_corner_.p); std::swap(less_sharp_.cap, last_corner_.cap);
-  std::swap(less_flat_.p, last_surf_.p); std::swap(less_flat_.cap, last_surf_.cap);
-  n_last_corner_ = nLessSharp;
-  n_last_surf_ = nLessFlat;
-  if (n_last_corner_ > 10 && n_last_surf_ > 100) {
-    idx_corner_.build(last_corner_.p, n_last_corner_);
-    idx_surf_.build(last_surf_.p, n_last_surf_);
-  }
-  LX_HIP(hipStreamSynchronize(st_));
-  return LOAMX_OK;
+void OdometryBatch::process(const OdomInput* in, int* rc) {
+  std::vector<uint32_t> all(streams_.size());
+  for (uint32_t s = 0; s < all.size(); s++) all[s] = s;
+  process_subset(all, in, rc);
 }
 
-int Odometry::get_last_clouds(loamx_cloud* corner, loamx_cloud* surf) {
+// `in` and `rc` are indexed by position in `which`
+void OdometryBatch::process_subset(const std::vector<uint32_t>& which, const OdomInput* in, int* rc) {
   LX_HIP(hipSetDevice(device_));
+  const uint32_t nw = (uint32_t)which.size();
+  std::vector<uint32_t> active;   // positions whose stream runs the optimisation
+  uint32_t max_feat = 0;
+  for (uint32_t k = 0; k < nw; k++) {
+    OdomStream& S = *streams_[which[k]];
+    const OdomInput& I = in[k];
+    // the current less-sharp / less-flat clouds are re-projected in place later, so they are copied
+    S.cur_corner.reserve(I.n_less_sharp + 1);
+    S.cur_surf.reserve(I.n_less_flat + 1);
+    if (I.n_less_sharp) LX_HIP(hipMemcpyAsync(S.cur_corner.p, I.less_sharp, sizeof(float4) * I.n_less_sharp, hipMemcpyDeviceToDevice, st_));
+    if (I.n_less_flat) LX_HIP(hipMemcpyAsync(S.cur_surf.p, I.less_flat, sizeof(float4) * I.n_less_flat, hipMemcpyDeviceToDevice, st_));
+    if (!S.inited) {   // :198-211
+      std::swap(S.cur_corner.p, S.last_corner.p); std::swap(S.cur_corner.cap, S.last_corner.cap);
+      std::swap(S.cur_surf.p, S.last_surf.p); std::swap(S.cur_surf.cap, S.last_surf.cap);
+      S.n_last_corner = I.n_less_sharp;
+      S.n_last_surf = I.n_less_flat;
+      S.idx_corner.build(S.last_corner.p, S.n_last_corner);
+      S.idx_surf.build(S.last_surf.p, S.n_last_surf);
+      S.transform_sum.rot_x = HAngle(S.transform_sum.rot_x.r + S.imu_pitch_start.r);
+      S.transform_sum.rot_z = HAngle(S.transform_sum.rot_z.r + S.imu_roll_start.r);
+      S.inited = true;
+      rc[k] = LOAMX_SKIPPED;
+      continue;
+    }
+    rc[k] = LOAMX_OK;
+    S.frame++;
+    S.transform.pos.x -= S.imu_velo.x * params.scan_period;
+    S.transform.pos.y -= S.imu_velo.y * params.scan_period;
+    S.transform.pos.z -= S.imu_velo.z * params.scan_period;
+    S.stats = {0, 0, (int)S.frame, 0};
+    if (S.n_last_corner > 10 && S.n_last_surf > 100) {
+      S.ind.reserve((size_t)5 * (I.n_sharp + I.n_flat) + 5);
+      OdomProblem& pb = h_prob_.p[active.size()];
+      pb.sharp = I.sharp; pb.n_sharp = I.n_sharp;
+      pb.flat = I.flat; pb.n_flat = I.n_flat;
+      pb.last_corner = S.last_corner.p; pb.n_last_corner = S.n_last_corner;
+      pb.last_surf = S.last_surf.p; pb.n_last_surf = S.n_last_surf;
+      pb.lc_sorted = S.idx_corner.sorted(); pb.lc_cell = S.idx_corner.cell_start(); pb.lc_desc = S.idx_corner.desc();
+      pb.ls_sorted = S.idx_surf.sorted(); pb.ls_cell = S.idx_surf.cell_start(); pb.ls_desc = S.idx_surf.desc();
+      pb.ind = S.ind.p;
+      S.transform.get(pb.transform);
+      pb.stats = {0, 0, 0, 0};
+      pb.done = 0;
+      max_feat = std::max(max_feat, I.n_sharp + I.n_flat);
+      active.push_back(k);
+    }
+  }
+  const uint32_t na = (uint32_t)active.size();
+  if (na) {
+    LX_HIP(hipMemcpyAsync(prob_.p, h_prob_.p, sizeof(OdomProblem) * na, hipMemcpyHostToDevice, st_));
+    if (max_feat) {
+      for (int it0 = 0; it0 < params.max_iterations; it0 += 5) {
+        const int nit = std::min(5, params.max_iterations - it0);
+        hipLaunchKernelGGL(k_odom_nn, dim3((max_feat + 255) / 256, na), dim3(256), 0, st_, prob_.p, params);
+        hipLaunchKernelGGL(k_odom_window, dim3((max_feat + 3) / 4, na), dim3(256), 0, st_, prob_.p, params);
+        hipLaunchKernelGGL(k_odom_lm, dim3(na), dim3(OD_THREADS), 0, st_, prob_.p, params, it0, nit);
+      }
+    }
+    LX_HIP(hipMemcpyAsync(h_prob_.p, prob_.p, sizeof(OdomProblem) * na, hipMemcpyDeviceToHost, st_));
+    LX_HIP(hipStreamSynchronize(st_));
+    for (uint32_t a = 0; a < na; a++) {
+      OdomStream& S = *streams_[which[active[a]]];
+      // _transform.rot_* = rad + x re-derives the cached sin/cos (:599-601)
+      S.transform.set(h_prob_.p[a].transform);
+      S.stats.iterations = h_prob_.p[a].stats.iterations;
+      S.stats.sel = h_prob_.p[a].stats.sel;
+      S.stats.degenerate = h_prob_.p[a].stats.degenerate;
+    }
+  }
+  for (uint32_t k = 0; k < nw; k++) {
+    if (rc[k] != LOAMX_OK) continue;
+    OdomStream& S = *streams_[which[k]];
+    const OdomInput& I = in[k];
+    // pose integration (:626-649)
+    HAngle rx, ry, rz;
+    accumulate_rotation(S.transform_sum.rot_x, S.transform_sum.rot_y, S.transform_sum.rot_z, -S.transform.rot_x,
+                        HAngle((float)(-S.transform.rot_y.r * 1.05)), -S.transform.rot_z, rx, ry, rz);
+    HVec3 v{S.transform.pos.x - S.imu_shift.x, S.transform.pos.y - S.imu_shift.y, (float)(S.transform.pos.z * 1.05 - S.imu_shift.z)};
+    h_rot_zxy(v, rz, rx, ry);
+    HVec3 trans{S.transform_sum.pos.x - v.x, S.transform_sum.pos.y - v.y, S.transform_sum.pos.z - v.z};
+    plugin_imu_rotation(rx, ry, rz, S.imu_pitch_start, S.imu_yaw_start, S.imu_roll_start, S.imu_pitch_end, S.imu_yaw_end, S.imu_roll_end,
+                        rx, ry, rz);
+    S.transform_sum.rot_x = rx; S.transform_sum.rot_y = ry; S.transform_sum.rot_z = rz;
+    S.transform_sum.pos = trans;
+    // re-project to the sweep end and hand over as "last" clouds (:651-664)
+    to_end_device(which[k], S.cur_corner.p, I.n_less_sharp);
+    to_end_device(which[k], S.cur_surf.p, I.n_less_flat);
+    std::swap(S.cur_corner.p, S.last_corner.p); std::swap(S.cur_corner.cap, S.last_corner.cap);
+    std::swap(S.cur_surf.p, S.last_surf.p); std::swap(S.cur_surf.cap, S.last_surf.cap);
+    S.n_last_corner = I.n_less_sharp;
+    S.n_last_surf = I.n_less_flat;
+    if (S.n_last_corner > 10 && S.n_last_surf > 100) {
+      S.idx_corner.build(S.last_corner.p, S.n_last_corner);
+      S.idx_surf.build(S.last_surf.p, S.n_last_surf);
+    }
+  }
+  LX_HIP(hipStreamSynchronize(st_));
+}
+
+int OdometryBatch::process_host(uint32_t s, const loamx_cloud* sharp, const loamx_cloud* less_sharp, const loamx_cloud* flat,
+                                const loamx_cloud* less_flat) {
+  LX_HIP(hipSetDevice(device_));
+  const loamx_cloud* cl[4] = {sharp, less_sharp, flat, less_flat};
+  for (int k = 0; k < 4; k++) {
+    check_cloud(cl[k], false);
+    h_stage_.reserve(cl[k]->count + 1);
+    up_[k].reserve(cl[k]->count + 1);
+    pack_cloud(cl[k], h_stage_.p);
+    if (cl[k]->count) LX_HIP(hipMemcpyAsync(up_[k].p, h_stage_.p, sizeof(float4) * cl[k]->count, hipMemcpyHostToDevice, st_));
+    LX_HIP(hipStreamSynchronize(st_));   // single staging buffer
+  }
+  OdomInput in{up_[0].p, sharp->count, up_[1].p, less_sharp->count, up_[2].p, flat->count, up_[3].p, less_flat->count};
+  int rc = LOAMX_OK;
+  process_subset({s}, &in, &rc);
+  return rc;
+}
+
+int OdometryBatch::get_last_clouds(uint32_t s, loamx_cloud* corner, loamx_cloud* surf) {
+  LX_HIP(hipSetDevice(device_));
+  OdomStream& S = *streams_[s];
   int rc = LOAMX_OK;
   std::vector<float4> tmp;
   if (corner) {
     check_cloud(corner, false);
-    tmp.resize(n_last_corner_);
-    if (n_last_corner_) LX_HIP(hipMemcpy(tmp.data(), last_corner_.p, sizeof(float4) * n_last_corner_, hipMemcpyDeviceToHost));
-    int r = unpack_cloud(tmp.data(), n_last_corner_, corner);
+    tmp.resize(S.n_last_corner);
+    if (S.n_last_corner) LX_HIP(hipMemcpy(tmp.data(), S.last_corner.p, sizeof(float4) * S.n_last_corner, hipMemcpyDeviceToHost));
+    int r = unpack_cloud(tmp.data(), S.n_last_corner, corner);
     if (r != LOAMX_OK) rc = r;
   }
   if (surf) {
     check_cloud(surf, false);
-    tmp.resize(n_last_surf_);
-    if (n_last_surf_) LX_HIP(hipMemcpy(tmp.data(), last_surf_.p, sizeof(float4) * n_last_surf_, hipMemcpyDeviceToHost));
-    int r = unpack_cloud(tmp.data(), n_last_surf_, surf);
+    tmp.resize(S.n_last_surf);
+    if (S.n_last_surf) LX_HIP(hipMemcpy(tmp.data(), S.last_surf.p, sizeof(float4) * S.n_last_surf, hipMemcpyDeviceToHost));
+    int r = unpack_cloud(tmp.data(), S.n_last_surf, surf);
     if (r != LOAMX_OK) rc = r;
   }
   return rc;
 }
 
-int Odometry::transform_to_end(loamx_cloud* cloud) {
+int OdometryBatch::transform_to_end_host(uint32_t s, loamx_cloud* cloud) {
   LX_HIP(hipSetDevice(device_));
   check_cloud(cloud, false);
   const uint32_t n = cloud->count;
-  upload_cloud(cloud, tmp_cloud_);
-  to_end_device(tmp_cloud_.p, n);
-  std::vector<float4> tmp(n);
-  if (n) LX_HIP(hipMemcpyAsync(tmp.data(), tmp_cloud_.p, sizeof(float4) * n, hipMemcpyDeviceToHost, st_));
+  h_stage_.reserve(n + 1);
+  tmp_cloud_.reserve(n + 1);
+  pack_cloud(cloud, h_stage_.p);
+  if (n) LX_HIP(hipMemcpyAsync(tmp_cloud_.p, h_stage_.p, sizeof(float4) * n, hipMemcpyHostToDevice, st_));
+  to_end_device(s, tmp_cloud_.p, n);
+  if (n) LX_HIP(hipMemcpyAsync(h_stage_.p, tmp_cloud_.p, sizeof(float4) * n, hipMemcpyDeviceToHost, st_));
   LX_HIP(hipStreamSynchronize(st_));
-  return unpack_cloud(tmp.data(), n, cloud);
+  return unpack_cloud(h_stage_.p, n, cloud);
 }
 
 }  // namespace loamx

@@ -1,0 +1,250 @@
+// Batched streaming pipeline: n independent streams, each advancing one sweep per step through
+//   feature extraction (BasicScanRegistration) -> odometry (BasicLaserOdometry) -> registration against a frozen
+//   sub-map (BasicLaserMapping::optimizeTransformTobeMapped, transformAssociateToMap, transformFullResToMap).
+// This is the batched-sweep mode of BASELINE.json's north_star: the streams are the independent units that are sharded
+// across GPUs; every stream keeps the reference's sequential semantics (its odometry state, its
+// transformBefMapped / transformAftMapped), only the map is frozen for the epoch.  All device work of a step runs on one
+// HIP stream with inputs resident in HBM; the host touches only offsets and 6-float poses between the stages.
+#include "features.cuh"
+#include "odometry.cuh"
+#include "registration.cuh"
+#include <memory>
+
+namespace loamx {
+
+struct PipeStreamState {
+  HTwist bef, aft, tobe, incre;   // mapping-side transforms (transformSum comes from the odometry stream)
+  SweepStats map_stats = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool mapped = false;
+};
+
+class Pipeline {
+ public:
+  Pipeline(const loamx_scanreg_config& fc, const loamx_odom_config& oc, const loamx_map_config& mc, uint32_t n_streams)
+      : reg(mc.device, n_streams), odom(mc.device, n_streams, reg.stream()), fcfg(fc), n_streams_(n_streams), st(n_streams) {
+    reg.params.max_iterations = mc.max_iterations;
+    reg.params.delta_t_abort = mc.delta_t_abort;
+    reg.params.delta_r_abort = mc.delta_r_abort;
+    reg.params.corner_leaf = mc.corner_filter_size;
+    reg.params.surf_leaf = mc.surf_filter_size;
+    odom.params.scan_period = oc.scan_period;
+    odom.params.max_iterations = oc.max_iterations;
+    odom.params.delta_t_abort = oc.delta_t_abort;
+    odom.params.delta_r_abort = oc.delta_r_abort;
+    for (uint32_t s = 0; s < n_streams; s++) full_tmp.push_back(std::make_unique<DevBuf<float4>>());
+    device = mc.device;
+  }
+  Registrar reg;
+  OdometryBatch odom;
+  loamx_scanreg_config fcfg;
+  uint32_t n_streams_;
+  int device;
+  std::vector<PipeStreamState> st;
+  std::vector<std::unique_ptr<FeatureExtractor>> fx;   // one staged batch per step
+  std::vector<std::unique_ptr<DevBuf<float4>>> full_tmp;
+  PinBuf<uint32_t> h_off;
+  float last_ms[4] = {0, 0, 0, 0};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool timing = false;
+
+  void upload(uint32_t n_steps, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
+    LX_REQUIRE(n_steps >= 1 && clouds && ring_size && n_rings, "invalid argument");
+    fx.clear();
+    for (uint32_t t = 0; t < n_steps; t++) {
+      auto f = std::make_unique<FeatureExtractor>(device, reg.stream());
+      FeatParams& p = f->params;
+      p.scan_period = fcfg.scan_period;
+      p.n_regions = fcfg.n_feature_regions;
+      p.curv_region = fcfg.curvature_region;
+      p.max_sharp = fcfg.max_corner_sharp;
+      p.max_less_sharp = 10 * fcfg.max_corner_sharp;
+      p.max_flat = fcfg.max_surface_flat;
+      p.less_flat_leaf = fcfg.less_flat_filter_size;
+      p.curv_thr = fcfg.surface_curvature_threshold;
+      f->upload(n_streams_, clouds + (size_t)t * n_streams_, ring_size + (size_t)t * n_streams_, n_rings + (size_t)t * n_streams_);
+      fx.push_back(std::move(f));
+    }
+  }
+
+  int step(uint32_t t) {
+    LX_REQUIRE(t < fx.size(), "step index beyond the staged sweeps");
+    LX_HIP(hipSetDevice(device));
+    hipStream_t s_ = reg.stream();
+    const uint32_t ns = n_streams_;
+    FeatureExtractor& F = *fx[t];
+    if (timing) {
+      for (auto& e : ev)
+        if (!e) LX_HIP(hipEventCreate(&e));
+      LX_HIP(hipEventRecord(ev[0], s_));
+    }
+    // ---- features
+    F.run_async();
+    const uint32_t nring = F.total_rings();
+    h_off.reserve(3 * (ns + 1) + nring + 2);
+    uint32_t* ho[3] = {h_off.p, h_off.p + (ns + 1), h_off.p + 2 * (ns + 1)};
+    uint32_t* hlf = h_off.p + 3 * (ns + 1);
+    for (int k = 0; k < 3; k++) LX_HIP(hipMemcpyAsync(ho[k], F.d_feat_off(k), sizeof(uint32_t) * (ns + 1), hipMemcpyDeviceToHost, s_));
+    LX_HIP(hipMemcpyAsync(hlf, F.d_less_flat_ring_off(), sizeof(uint32_t) * (nring + 1), hipMemcpyDeviceToHost, s_));
+    if (timing) LX_HIP(hipEventRecord(ev[1], s_));
+    LX_HIP(hipStreamSynchronize(s_));
+    // ---- odometry
+    std::vector<OdomInput> in(ns);
+    std::vector<int> rc(ns, 0);
+    for (uint32_t s = 0; s < ns; s++) {
+      const uint32_t la = hlf[F.ring_base(s)], lb = hlf[F.ring_base(s + 1)];
+      in[s] = OdomInput{F.d_feat(0) + ho[0][s], ho[0][s + 1] - ho[0][s], F.d_feat(1) + ho[1][s], ho[1][s + 1] - ho[1][s],
+                        F.d_feat(2) + ho[2][s], ho[2][s + 1] - ho[2][s], F.d_less_flat() + la, lb - la};
+    }
+    odom.process(in.data(), rc.data());
+    if (timing) LX_HIP(hipEventRecord(ev[2], s_));
+    // ---- registration against the frozen sub-map
+    std::vector<const float4*> cl(ns), sl(ns), fr(ns);
+    std::vector<uint32_t> ncl(ns), nsl(ns), nfr(ns), who;
+    std::vector<float> guess;
+    for (uint32_t s = 0; s < ns; s++) {
+      if (rc[s] != LOAMX_OK) continue;   // a stream's first sweep only initialises the odometry
+      OdomStream& O = odom.stream_state(s);
+      PipeStreamState& P = st[s];
+      transform_associate_to_map(O.transform_sum, P.bef, P.aft, P.incre, P.tobe);
+      float g[6];
+      P.tobe.get(g);
+      guess.insert(guess.end(), g, g + 6);
+      const uint32_t k = (uint32_t)who.size();
+      cl[k] = O.last_corner.p; ncl[k] = O.n_last_corner;
+      sl[k] = O.last_surf.p; nsl[k] = O.n_last_surf;
+      // the full-resolution cloud is re-projected to the sweep end before it is registered (LaserOdometry.cpp:326)
+      const uint32_t np = F.point_base(s + 1) - F.point_base(s);
+      full_tmp[s]->reserve(np + 1);
+      if (np) LX_HIP(hipMemcpyAsync(full_tmp[s]->p, F.d_cloud() + F.point_base(s), sizeof(float4) * np, hipMemcpyDeviceToDevice, s_));
+      odom.to_end_device(s, full_tmp[s]->p, np);
+      fr[k] = full_tmp[s]->p; nfr[k] = np;
+      who.push_back(s);
+    }
+    int ret = LOAMX_SKIPPED;
+    if (!who.empty()) {
+      const uint32_t nw = (uint32_t)who.size();
+      reg.upload_device(nw, cl.data(), ncl.data(), sl.data(), nsl.data(), fr.data(), nfr.data(), guess.data());
+      reg.run_async();
+      if (timing) LX_HIP(hipEventRecord(ev[3], s_));
+      std::vector<float> poses(6 * nw);
+      std::vector<SweepStats> ss(nw);
+      reg.download(poses.data(), nullptr);
+      reg.download_stats(ss.data());
+      for (uint32_t k = 0; k < nw; k++) {
+        PipeStreamState& P = st[who[k]];
+        P.map_stats = ss[k];
+        P.mapped = true;
+        if (reg.submap_sufficient()) {   // transformUpdate (BasicLaserMapping.cpp:171-203, :628-629)
+          P.tobe.set(&poses[6 * k]);
+          P.bef = odom.stream_state(who[k]).transform_sum;
+          P.aft = P.tobe;
+        }
+      }
+      ret = LOAMX_OK;
+    } else if (timing) {
+      LX_HIP(hipEventRecord(ev[3], s_));
+    }
+    if (timing) {
+      LX_HIP(hipEventSynchronize(ev[3]));
+      for (int k = 0; k < 3; k++) LX_HIP(hipEventElapsedTime(&last_ms[k], ev[k], ev[k + 1]));
+      LX_HIP(hipEventElapsedTime(&last_ms[3], ev[0], ev[3]));
+    }
+    return ret;
+  }
+};
+
+}  // namespace loamx
+
+using namespace loamx;
+
+struct loamx_pipeline {
+  Pipeline p;
+  loamx_pipeline(const loamx_scanreg_config& f, const loamx_odom_config& o, const loamx_map_config& m, uint32_t n) : p(f, o, m, n) {}
+};
+
+extern "C" {
+
+loamx_pipeline* loamx_pipeline_create(const loamx_scanreg_config* fcfg, const loamx_odom_config* ocfg, const loamx_map_config* mcfg,
+                                      uint32_t n_streams) {
+  loamx_pipeline* h = nullptr;
+  guard([&]() {
+    loamx_scanreg_config f;
+    loamx_odom_config o;
+    loamx_map_config m;
+    if (fcfg) f = *fcfg; else loamx_scanreg_default_config(&f);
+    if (ocfg) o = *ocfg; else loamx_odom_default_config(&o);
+    if (mcfg) m = *mcfg; else loamx_map_default_config(&m);
+    LX_REQUIRE(n_streams >= 1 && n_streams <= 1024, "n_streams must be in [1, 1024]");
+    LX_REQUIRE(f.device == m.device && o.device == m.device, "all three configurations must name the same device");
+    h = new loamx_pipeline(f, o, m, n_streams);
+    return LOAMX_OK;
+  });
+  return h;
+}
+void loamx_pipeline_destroy(loamx_pipeline* h) { delete h; }
+
+int loamx_pipeline_set_frozen(loamx_pipeline* h, const loamx_cloud* corner_map, const loamx_cloud* surf_map) {
+  return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->p.reg.set_submap_host(corner_map, surf_map); return LOAMX_OK; });
+}
+int loamx_pipeline_set_frozen_device(loamx_pipeline* h, const void* d_corner, uint32_t nc, const void* d_surf, uint32_t ns) {
+  return guard([&]() {
+    LX_REQUIRE(h && (d_corner || !nc) && (d_surf || !ns), "NULL argument");
+    h->p.reg.set_submap_device((const float4*)d_corner, nc, (const float4*)d_surf, ns);
+    return LOAMX_OK;
+  });
+}
+int loamx_pipeline_set_state(loamx_pipeline* h, uint32_t stream, const float* transform, const float* transform_sum, const float* bef,
+                             const float* aft) {
+  return guard([&]() {
+    LX_REQUIRE(h && stream < h->p.n_streams_, "invalid stream");
+    if (transform) h->p.odom.stream_state(stream).transform.set(transform);
+    if (transform_sum) h->p.odom.stream_state(stream).transform_sum.set(transform_sum);
+    if (bef) h->p.st[stream].bef.set(bef);
+    if (aft) h->p.st[stream].aft.set(aft);
+    return LOAMX_OK;
+  });
+}
+int loamx_pipeline_upload(loamx_pipeline* h, uint32_t n_steps, const loamx_cloud* clouds, const uint32_t* const* ring_size,
+                          const uint32_t* n_rings) {
+  return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->p.upload(n_steps, clouds, ring_size, n_rings); return LOAMX_OK; });
+}
+int loamx_pipeline_step(loamx_pipeline* h, uint32_t step) {
+  return guard([&]() { LX_REQUIRE(h, "NULL handle"); return h->p.step(step); });
+}
+int loamx_pipeline_get(loamx_pipeline* h, uint32_t stream, float* transform, float* transform_sum, float* aft, int* stats8) {
+  return guard([&]() {
+    LX_REQUIRE(h && stream < h->p.n_streams_, "invalid stream");
+    OdomStream& O = h->p.odom.stream_state(stream);
+    PipeStreamState& P = h->p.st[stream];
+    if (transform) O.transform.get(transform);
+    if (transform_sum) O.transform_sum.get(transform_sum);
+    if (aft) P.aft.get(aft);
+    if (stats8) {
+      stats8[0] = O.stats.iterations; stats8[1] = O.stats.sel; stats8[2] = P.map_stats.iterations; stats8[3] = P.map_stats.sel;
+      stats8[4] = P.map_stats.corner_q; stats8[5] = P.map_stats.surf_q; stats8[6] = P.map_stats.degenerate; stats8[7] = P.mapped ? 1 : 0;
+    }
+    return LOAMX_OK;
+  });
+}
+int loamx_pipeline_download_full_res(loamx_pipeline* h, uint32_t slot, loamx_cloud* out) {
+  return guard([&]() { LX_REQUIRE(h && out, "NULL argument"); return h->p.reg.download_full_res(slot, out); });
+}
+int loamx_pipeline_set_timing(loamx_pipeline* h, int on) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    h->p.timing = on != 0;
+    h->p.reg.set_timing(on != 0);
+    return LOAMX_OK;
+  });
+}
+int loamx_pipeline_get_timing(loamx_pipeline* h, float stage_ms[4], float reg_ms[4], uint64_t counts[4]) {
+  return guard([&]() {
+    LX_REQUIRE(h && stage_ms && reg_ms && counts, "NULL argument");
+    for (int k = 0; k < 4; k++) stage_ms[k] = h->p.last_ms[k];
+    h->p.reg.get_timing(reg_ms, counts);
+    return LOAMX_OK;
+  });
+}
+void* loamx_pipeline_stream(loamx_pipeline* h) { return h ? (void*)h->p.reg.stream() : nullptr; }
+
+}  // extern "C"

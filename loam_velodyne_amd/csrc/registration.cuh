@@ -63,6 +63,9 @@ class Registrar {
   // stage inputs (H2D, async on the stream)
   void upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const loamx_cloud* surf_last, const loamx_cloud* full_res,
               const float* guess6);
+  // same with device-resident packed float4 inputs (copied device-to-device; async on the stream)
+  void upload_device(uint32_t n_sweeps, const float4* const* corner_last, const uint32_t* n_corner, const float4* const* surf_last,
+                     const uint32_t* n_surf, const float4* const* full_res, const uint32_t* n_full, const float* guess6);
   // device-only: stack round trip + voxel DS + LM iterations (+ full-res registration)
   void run_async();
   void sync();
@@ -75,6 +78,8 @@ class Registrar {
   const float4* d_ds_points() const { return ds_pts_.p; }
   const uint32_t* d_ds_offsets() const { return ds_off_.p; }
   const Pose* d_poses() const { return poses_.p; }
+  const float4* d_full_res() const { return full_.p; }
+  uint32_t full_offset(uint32_t s) const { return h_full_off_[s]; }
 
   void set_timing(bool on) { timing_ = on; }
   void get_timing(float ms[4], uint64_t counts[4]);
@@ -85,7 +90,7 @@ class Registrar {
   int device_;
   uint32_t max_sweeps_, n_sweeps_ = 0;
   hipStream_t st_ = nullptr;
-  bool timing_ = false;
+  bool timing_ = false, timed_run_ = false;
 
   // owned copies of a host-provided sub-map
   DevBuf<float4> own_corner_, own_surf_;

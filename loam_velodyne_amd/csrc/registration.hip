@@ -466,7 +466,7 @@ Registrar::Registrar(int device, uint32_t max_sweeps) : device_(device), max_swe
   stats_.reserve(max_sweeps);
   matP_.reserve((size_t)36 * max_sweeps);
   guess_.reserve((size_t)6 * max_sweeps);
-  h_guess_.reserve((size_t)6 * max_sweeps);
+  h_guess_.reserve((size_t)16 * max_sweeps + 16);
   seg_off_.reserve(2 * max_sweeps + 2);
   full_off_.reserve(max_sweeps + 2);
   ds_off_.reserve(2 * max_sweeps + 2);
@@ -556,6 +556,52 @@ void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const 
   LX_HIP(hipStreamSynchronize(st_));   // host staging buffers are reused by the caller after return
 }
 
+void Registrar::upload_device(uint32_t n_sweeps, const float4* const* corner_last, const uint32_t* n_corner,
+                              const float4* const* surf_last, const uint32_t* n_surf, const float4* const* full_res,
+                              const uint32_t* n_full, const float* guess6) {
+  LX_REQUIRE(n_sweeps >= 1 && n_sweeps <= max_sweeps_, "n_sweeps out of range for this handle");
+  LX_HIP(hipSetDevice(device_));
+  n_sweeps_ = n_sweeps;
+  h_seg_off_.assign(2 * n_sweeps + 1, 0);
+  h_full_off_.assign(n_sweeps + 1, 0);
+  max_q_per_sweep_ = 0;
+  for (uint32_t s = 0; s < n_sweeps; s++) {
+    h_seg_off_[2 * s + 1] = h_seg_off_[2 * s] + n_corner[s];
+    h_seg_off_[2 * s + 2] = h_seg_off_[2 * s + 1] + n_surf[s];
+    max_q_per_sweep_ = std::max(max_q_per_sweep_, n_corner[s] + n_surf[s]);
+    h_full_off_[s + 1] = h_full_off_[s] + (full_res ? n_full[s] : 0u);
+  }
+  n_in_ = h_seg_off_[2 * n_sweeps];
+  n_full_ = h_full_off_[n_sweeps];
+  in_.reserve(n_in_ + 1);
+  stack_.reserve(n_in_ + 1);
+  ds_pts_.reserve(n_in_ + 1);
+  vox_.reserve(n_in_ + 1, 2 * n_sweeps);
+  LX_REQUIRE(n_in_ < SCAN_MAX_N, "too many feature points in one batch");
+  for (uint32_t s = 0; s < n_sweeps; s++) {
+    if (n_corner[s]) LX_HIP(hipMemcpyAsync(in_.p + h_seg_off_[2 * s], corner_last[s], sizeof(float4) * n_corner[s], hipMemcpyDeviceToDevice, st_));
+    if (n_surf[s]) LX_HIP(hipMemcpyAsync(in_.p + h_seg_off_[2 * s + 1], surf_last[s], sizeof(float4) * n_surf[s], hipMemcpyDeviceToDevice, st_));
+  }
+  // offsets / guesses go through the pinned buffers owned by this object (valid until the next upload)
+  h_guess_.reserve((size_t)6 * n_sweeps + 2 * (3 * (size_t)n_sweeps + 2));
+  memcpy(h_guess_.p, guess6, sizeof(float) * 6 * n_sweeps);
+  uint32_t* hoff = (uint32_t*)(h_guess_.p + 6 * n_sweeps);
+  memcpy(hoff, h_seg_off_.data(), sizeof(uint32_t) * (2 * n_sweeps + 1));
+  uint32_t* hfull = hoff + (2 * n_sweeps + 1);
+  memcpy(hfull, h_full_off_.data(), sizeof(uint32_t) * (n_sweeps + 1));
+  LX_HIP(hipMemcpyAsync(guess_.p, h_guess_.p, sizeof(float) * 6 * n_sweeps, hipMemcpyHostToDevice, st_));
+  LX_HIP(hipMemcpyAsync(seg_off_.p, hoff, sizeof(uint32_t) * (2 * n_sweeps + 1), hipMemcpyHostToDevice, st_));
+  if (n_full_) {
+    full_.reserve(n_full_);
+    for (uint32_t s = 0; s < n_sweeps; s++)
+      if (n_full[s]) LX_HIP(hipMemcpyAsync(full_.p + h_full_off_[s], full_res[s], sizeof(float4) * n_full[s], hipMemcpyDeviceToDevice, st_));
+    LX_HIP(hipMemcpyAsync(full_off_.p, hfull, sizeof(uint32_t) * (n_sweeps + 1), hipMemcpyHostToDevice, st_));
+  }
+  nblk_ = (max_q_per_sweep_ + LX_RES_THREADS - 1) / LX_RES_THREADS;
+  if (nblk_ == 0) nblk_ = 1;
+  partials_.reserve((size_t)n_sweeps * nblk_ * LX_NSUM);
+}
+
 void Registrar::run_async() {
   LX_REQUIRE(n_sweeps_ > 0, "run() before upload()");
   LX_HIP(hipSetDevice(device_));
@@ -589,7 +635,7 @@ void Registrar::run_async() {
   }
   if (n_full_)
     hipLaunchKernelGGL(k_transform_full, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, n_full_, full_off_.p, ns, poses_.p);
-  if (timing_) LX_HIP(hipEventRecord(ev_[1], st_));
+  if (timing_) { LX_HIP(hipEventRecord(ev_[1], st_)); timed_run_ = true; }
   LX_HIP(hipGetLastError());
 }
 
@@ -646,7 +692,7 @@ void Registrar::download_ds(uint32_t sweep, std::vector<float4>& corner_ds, std:
 
 void Registrar::get_timing(float ms[4], uint64_t counts[4]) {
   for (int k = 0; k < 4; k++) { ms[k] = 0.f; counts[k] = 0; }
-  if (!timing_) return;
+  if (!timing_ || !timed_run_) return;
   LX_HIP(hipEventSynchronize(ev_[1]));
   LX_HIP(hipEventElapsedTime(&ms[0], ev_[0], ev_[1]));
   for (int k = 0; k < n_res_launch_; k++) {

@@ -351,3 +351,94 @@ class LaserMapping:
         _check(lib().loamx_map_get_stats(self.h, s))
         keys = ("iterations", "sel", "corner_ds", "surf_ds", "corner_from_map", "surf_from_map", "degenerate", "optimized")
         return dict(zip(keys, (int(v) for v in s)))
+
+
+class Pipeline:
+    """loamx_pipeline_*: n independent streams, one sweep per stream per step, features -> odometry -> registration
+    against a frozen sub-map."""
+
+    def __init__(self, n_streams: int, scanreg=None, odom=None, mapping=None):
+        self._f = _cfg(ScanRegConfig, "loamx_scanreg_default_config", **(scanreg or {}))
+        self._o = _cfg(OdomConfig, "loamx_odom_default_config", **(odom or {}))
+        self._m = _cfg(MapConfig, "loamx_map_default_config", **(mapping or {}))
+        L = lib()
+        L.loamx_pipeline_create.restype = C.c_void_p
+        L.loamx_pipeline_stream.restype = C.c_void_p
+        self.h = C.c_void_p(L.loamx_pipeline_create(C.byref(self._f), C.byref(self._o), C.byref(self._m), n_streams))
+        if not self.h:
+            raise LoamxError(E_INVALID, L.loamx_last_error().decode())
+        self.n_streams = n_streams
+        self._sizes = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().loamx_pipeline_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_frozen(self, corner_map, surf_map):
+        c, s = as_points(corner_map), as_points(surf_map)
+        cc, sc = cloud_of(c), cloud_of(s)
+        _check(lib().loamx_pipeline_set_frozen(self.h, C.byref(cc), C.byref(sc)))
+
+    def set_frozen_device(self, d_corner_ptr, n_corner, d_surf_ptr, n_surf):
+        _check(lib().loamx_pipeline_set_frozen_device(self.h, C.c_void_p(d_corner_ptr), n_corner, C.c_void_p(d_surf_ptr), n_surf))
+
+    def set_state(self, stream, transform=None, transform_sum=None, bef=None, aft=None):
+        def p(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, np.float32)
+            keep.append(a)
+            return a.ctypes.data_as(C.c_void_p)
+        keep = []
+        _check(lib().loamx_pipeline_set_state(self.h, stream, p(transform), p(transform_sum), p(bef), p(aft)))
+
+    def upload(self, sweeps):
+        """sweeps[t][s] = (points (N,4), ring_sizes)"""
+        n_steps = len(sweeps)
+        ns = self.n_streams
+        pts, rings = [], []
+        for t in range(n_steps):
+            assert len(sweeps[t]) == ns
+            for s in range(ns):
+                pts.append(as_points(sweeps[t][s][0]))
+                rings.append(np.ascontiguousarray(sweeps[t][s][1], np.uint32))
+        CA = (Cloud * len(pts))(*[cloud_of(a) for a in pts])
+        RP = (C.c_void_p * len(pts))(*[r.ctypes.data for r in rings])
+        NR = (C.c_uint32 * len(pts))(*[len(r) for r in rings])
+        _check(lib().loamx_pipeline_upload(self.h, n_steps, CA, RP, NR))
+        self._sizes = [len(a) for a in pts]
+
+    def step(self, t: int):
+        return _check(lib().loamx_pipeline_step(self.h, t))
+
+    def get(self, stream: int):
+        tr, ts, aft = (np.zeros(6, np.float32) for _ in range(3))
+        st = (C.c_int * 8)()
+        _check(lib().loamx_pipeline_get(self.h, stream, tr.ctypes.data_as(C.c_void_p), ts.ctypes.data_as(C.c_void_p),
+                                        aft.ctypes.data_as(C.c_void_p), st))
+        keys = ("odom_iterations", "odom_sel", "map_iterations", "map_sel", "corner_ds", "surf_ds", "degenerate", "mapped")
+        return tr, ts, aft, dict(zip(keys, (int(v) for v in st)))
+
+    def download_full_res(self, slot: int, n: int):
+        out = np.zeros((n, 4), np.float32)
+        c = cloud_of(out)
+        _check(lib().loamx_pipeline_download_full_res(self.h, slot, C.byref(c)))
+        return out[:c.count]
+
+    def set_timing(self, on: bool):
+        _check(lib().loamx_pipeline_set_timing(self.h, 1 if on else 0))
+
+    def timing(self):
+        ms = (C.c_float * 4)()
+        rms = (C.c_float * 4)()
+        cnt = (C.c_uint64 * 4)()
+        _check(lib().loamx_pipeline_get_timing(self.h, ms, rms, cnt))
+        return dict(features_ms=ms[0], odometry_ms=ms[1], registration_ms=ms[2], step_ms=ms[3], reg_run_ms=rms[0],
+                    residual_ms=rms[1], residual_launches=int(cnt[0]), query_iterations=int(cnt[1]), queries=int(cnt[2]))
+
+    @property
+    def stream(self) -> int:
+        return int(lib().loamx_pipeline_stream(self.h) or 0)

@@ -177,6 +177,12 @@ void orc_map_load_cubes(void* h, const float* corner, int nc, const float* surf,
 void orc_map_set_frozen(void* h, const float* corner, int nc, const float* surf, int ns) {
   ((LaserMapping*)h)->set_frozen_submap(to_cloud(corner, nc), to_cloud(surf, ns));
 }
+// transformAssociateToMap with the current sum/bef/aft; returns the predicted transformTobeMapped
+void orc_map_associate(void* h, float* tobe6) {
+  auto* m = (LaserMapping*)h;
+  m->transform_associate_to_map();
+  twist_to(m->transformTobeMapped, tobe6);
+}
 void orc_map_register_frozen(void* h, const float* guess6, float* pose6) {
   auto* m = (LaserMapping*)h;
   m->register_frozen(guess6);

@@ -235,6 +235,11 @@ class LaserMapping:
         self.o.L.orc_map_register_frozen(self.h, g.ctypes.data_as(C.c_void_p), pose.ctypes.data_as(C.c_void_p))
         return pose
 
+    def associate(self):
+        t = np.zeros(6, np.float32)
+        self.o.L.orc_map_associate(self.h, t.ctypes.data_as(C.c_void_p))
+        return t
+
     def residual_pass(self, pose6, cap=200000):
         p = _f32(pose6)
         ori = np.zeros((cap, 4), np.float32)

@@ -76,7 +76,10 @@ struct RingLds {
   int8_t* label;
 };
 
-// suppress the neighbours of a picked point (markAsPicked :367-386); whole wave participates
+// LDS writes of this wave become visible to its own later LDS reads (one wave works on the pick lists at a time)
+__device__ inline void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+
+// suppress the neighbours of a picked point (markAsPicked :367-386); one whole wave participates
 __device__ inline void mark_as_picked(const float4* __restrict__ cloud, uint32_t g /* global index */, uint32_t scan_i, int cr,
                                       uint8_t* flags, int lane) {
   bool brk = false;
@@ -94,47 +97,55 @@ __device__ inline void mark_as_picked(const float4* __restrict__ cloud, uint32_t
   if (lane == 0) flags[scan_i] = 1;
   if (lane < nf) flags[scan_i + lane + 1] = 1;
   if (lane >= 32 && lane - 32 < nb) flags[scan_i - (lane - 32) - 1] = 1;
-  __syncthreads();
+  wave_lds_sync();
 }
 
-// one wave per ring; dynamic LDS: flags[flag_bytes] | c[nmax] | sorted[nmax] | label[nmax]
-__global__ __launch_bounds__(64) void k_feat_ring(const float4* __restrict__ cloud, const uint32_t* __restrict__ ring_off,
-                                                  const uint32_t* __restrict__ ring_sweep_base, FeatParams P,
-                                                  const float* __restrict__ curv, const uint8_t* __restrict__ gflags,
-                                                  uint32_t flag_bytes, uint32_t nmax, float4* __restrict__ slotS,
-                                                  float4* __restrict__ slotLS, float4* __restrict__ slotF, uint32_t* __restrict__ cntS,
-                                                  uint32_t* __restrict__ cntLS, uint32_t* __restrict__ cntF, uint8_t* __restrict__ lf_valid) {
+constexpr int FEAT_WAVES = 6;   // regions sorted concurrently per ring
+
+// one workgroup of FEAT_WAVES waves per ring.  Dynamic LDS: flags[flag_bytes] | per wave { c[nmax] | sorted[nmax] | label[nmax] }
+__global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
+    const float4* __restrict__ cloud, const uint32_t* __restrict__ ring_off, const uint32_t* __restrict__ ring_sweep_base, FeatParams P,
+    const float* __restrict__ curv, const uint8_t* __restrict__ gflags, uint32_t flag_bytes, uint32_t nmax, float4* __restrict__ slotS,
+    float4* __restrict__ slotLS, float4* __restrict__ slotF, uint32_t* __restrict__ cntS, uint32_t* __restrict__ cntLS,
+    uint32_t* __restrict__ cntF, uint8_t* __restrict__ lf_valid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint8_t* flags = (uint8_t*)smem;
-  float* c = (float*)(smem + flag_bytes);
-  uint32_t* sorted = (uint32_t*)(c + nmax);
-  int8_t* label = (int8_t*)(sorted + nmax);
+  const size_t wave_bytes = (size_t)nmax * 9;
+  __shared__ uint32_t reg_n[FEAT_WAVES], reg_gsp[FEAT_WAVES], reg_scan[FEAT_WAVES];
 
   const uint32_t r = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const uint32_t s0g = ring_off[r], len = ring_off[r + 1] - s0g;
   const int cr = P.curv_region, nreg = P.n_regions;
   const uint32_t capS = P.max_sharp * nreg, capLS = P.max_less_sharp * nreg, capF = P.max_flat * nreg;
-  uint32_t nS = 0, nLS = 0, nF = 0;
-  if (len > 2u * cr + 1u) {
+  uint32_t nS = 0, nLS = 0, nF = 0;   // maintained by wave 0
+  if (len > 2u * cr + 1u) {           // block-uniform
     const uint32_t base = ring_sweep_base[r];
     // indices relative to the sweep's cloud, exactly the values the reference's integer region formula sees (:180-183)
     const unsigned long long s0 = s0g - base, e0 = s0 + len - 1;
-    for (uint32_t k = lane; k < len; k += 64) flags[k] = gflags[s0g + k];
-    __syncthreads();
-    for (int j = 0; j < nreg; j++) {
-      const unsigned long long sp = ((s0 + cr) * (unsigned long long)(nreg - j) + (e0 - cr) * (unsigned long long)j) / nreg;
-      const unsigned long long ep = ((s0 + cr) * (unsigned long long)(nreg - 1 - j) + (e0 - cr) * (unsigned long long)(j + 1)) / nreg - 1;
-      if (ep <= sp) continue;
-      const uint32_t n = (uint32_t)(ep - sp + 1);
-      const uint32_t gsp = base + (uint32_t)sp;       // global index of the region's first point
-      const uint32_t scan_sp = (uint32_t)(sp - s0);    // ring-relative index of the region's first point
+    for (uint32_t k = tid; k < len; k += blockDim.x) flags[k] = gflags[s0g + k];
+    float* c = (float*)(smem + flag_bytes + wid * wave_bytes);
+    uint32_t* sorted = (uint32_t*)(c + nmax);
+    int8_t* label = (int8_t*)(sorted + nmax);
+    for (int jb = 0; jb < nreg; jb += FEAT_WAVES) {
+      const int j = jb + wid;
+      uint32_t n = 0, gsp = 0, scan_sp = 0;
+      if (j < nreg) {
+        const unsigned long long sp = ((s0 + cr) * (unsigned long long)(nreg - j) + (e0 - cr) * (unsigned long long)j) / nreg;
+        const unsigned long long ep = ((s0 + cr) * (unsigned long long)(nreg - 1 - j) + (e0 - cr) * (unsigned long long)(j + 1)) / nreg - 1;
+        if (ep > sp) {
+          n = (uint32_t)(ep - sp + 1);
+          gsp = base + (uint32_t)sp;      // global index of the region's first point
+          scan_sp = (uint32_t)(sp - s0);  // ring-relative index of the region's first point
+        }
+      }
+      if (lane == 0) { reg_n[wid] = n; reg_gsp[wid] = gsp; reg_scan[wid] = scan_sp; }
       for (uint32_t e = lane; e < n; e += 64) {
         c[e] = curv[gsp + e];
         label[e] = 0;   // SURFACE_LESS_FLAT
       }
       __syncthreads();
-      // stable ascending order (:311-317): rank = #smaller + #equal-before
+      // stable ascending order (:311-317): rank = #smaller + #equal-before.  Every wave sorts its own region.
       for (uint32_t e = lane; e < n; e += 64) {
         const float ce = c[e];
         uint32_t rank = 0;
@@ -145,71 +156,83 @@ __global__ __launch_bounds__(64) void k_feat_ring(const float4* __restrict__ clo
         sorted[rank] = e;
       }
       __syncthreads();
-      // corner picks from the largest curvature down (:197-217)
-      {
-        int picked = 0;
-        int pos = (int)n;
-        while (pos > 0 && picked < P.max_less_sharp) {
-          const int kk = pos - 1 - lane;
-          const bool in = kk >= 0;
-          const uint32_t e = in ? sorted[kk] : 0u;
-          const float ce = in ? c[e] : 0.f;
-          const bool above = in && (ce > P.curv_thr);
-          const bool ok = above && flags[scan_sp + e] == 0;
-          const unsigned long long mok = __ballot(ok), mstop = __ballot(in && !above);
-          const int fo = mok ? __builtin_ctzll(mok) : 64, fs = mstop ? __builtin_ctzll(mstop) : 64;
-          if (fo < fs) {
-            const uint32_t pe = __shfl(e, fo, 64);
-            picked++;
-            const float4 pt = cloud[gsp + pe];
-            if (lane == 0) {
-              if (picked <= P.max_sharp) {
-                label[pe] = 2;
-                slotS[(size_t)r * capS + nS] = pt;
+      // the order-dependent greedy picks: wave 0 walks the regions of this group in order
+      if (wid == 0) {
+        for (int w = 0; w < FEAT_WAVES && jb + w < nreg; w++) {
+          const uint32_t rn = reg_n[w];
+          if (rn == 0) continue;
+          const uint32_t rgsp = reg_gsp[w], rscan = reg_scan[w];
+          const float* rc = (const float*)(smem + flag_bytes + w * wave_bytes);
+          const uint32_t* rsorted = (const uint32_t*)(rc + nmax);
+          int8_t* rlabel = (int8_t*)(rsorted + nmax);
+          // corner picks from the largest curvature down (:197-217)
+          {
+            int picked = 0;
+            int pos = (int)rn;
+            while (pos > 0 && picked < P.max_less_sharp) {
+              const int kk = pos - 1 - lane;
+              const bool in = kk >= 0;
+              const uint32_t e = in ? rsorted[kk] : 0u;
+              const float ce = in ? rc[e] : 0.f;
+              const bool above = in && (ce > P.curv_thr);
+              const bool ok = above && flags[rscan + e] == 0;
+              const unsigned long long mok = __ballot(ok), mstop = __ballot(in && !above);
+              const int fo = mok ? __builtin_ctzll(mok) : 64, fs = mstop ? __builtin_ctzll(mstop) : 64;
+              if (fo < fs) {
+                const uint32_t pe = __shfl(e, fo, 64);
+                picked++;
+                const float4 pt = cloud[rgsp + pe];
+                if (lane == 0) {
+                  if (picked <= P.max_sharp) {
+                    rlabel[pe] = 2;
+                    slotS[(size_t)r * capS + nS] = pt;
+                  } else {
+                    rlabel[pe] = 1;
+                  }
+                  slotLS[(size_t)r * capLS + nLS] = pt;
+                }
+                if (picked <= P.max_sharp) nS++;
+                nLS++;
+                mark_as_picked(cloud, rgsp + pe, rscan + pe, cr, flags, lane);
+                pos = pos - 1 - fo;
+              } else if (fs < 64) {
+                break;   // sorted: nothing further exceeds the threshold
               } else {
-                label[pe] = 1;
+                pos -= 64;
               }
-              slotLS[(size_t)r * capLS + nLS] = pt;
             }
-            if (picked <= P.max_sharp) nS++;
-            nLS++;
-            mark_as_picked(cloud, gsp + pe, scan_sp + pe, cr, flags, lane);
-            pos = pos - 1 - fo;
-          } else if (fs < 64) {
-            break;   // sorted: nothing further exceeds the threshold
-          } else {
-            pos -= 64;
           }
-        }
-      }
-      // flat picks from the smallest curvature up (:220-235)
-      {
-        int picked = 0;
-        int pos = 0;
-        while (pos < (int)n && picked < P.max_flat) {
-          const int kk = pos + lane;
-          const bool in = kk < (int)n;
-          const uint32_t e = in ? sorted[kk] : 0u;
-          const float ce = in ? c[e] : 0.f;
-          const bool below = in && (ce < P.curv_thr);
-          const bool ok = below && flags[scan_sp + e] == 0;
-          const unsigned long long mok = __ballot(ok), mstop = __ballot(in && !below);
-          const int fo = mok ? __builtin_ctzll(mok) : 64, fs = mstop ? __builtin_ctzll(mstop) : 64;
-          if (fo < fs) {
-            const uint32_t pe = __shfl(e, fo, 64);
-            picked++;
-            if (lane == 0) {
-              label[pe] = -1;
-              slotF[(size_t)r * capF + nF] = cloud[gsp + pe];
+          // flat picks from the smallest curvature up (:220-235)
+          {
+            int picked = 0;
+            int pos = 0;
+            while (pos < (int)rn && picked < P.max_flat) {
+              const int kk = pos + lane;
+              const bool in = kk < (int)rn;
+              const uint32_t e = in ? rsorted[kk] : 0u;
+              const float ce = in ? rc[e] : 0.f;
+              const bool below = in && (ce < P.curv_thr);
+              const bool ok = below && flags[rscan + e] == 0;
+              const unsigned long long mok = __ballot(ok), mstop = __ballot(in && !below);
+              const int fo = mok ? __builtin_ctzll(mok) : 64, fs = mstop ? __builtin_ctzll(mstop) : 64;
+              if (fo < fs) {
+                const uint32_t pe = __shfl(e, fo, 64);
+                picked++;
+                if (lane == 0) {
+                  rlabel[pe] = -1;
+                  slotF[(size_t)r * capF + nF] = cloud[rgsp + pe];
+                }
+                nF++;
+                mark_as_picked(cloud, rgsp + pe, rscan + pe, cr, flags, lane);
+                pos = pos + fo + 1;
+              } else if (fs < 64) {
+                break;
+              } else {
+                pos += 64;
+              }
             }
-            nF++;
-            mark_as_picked(cloud, gsp + pe, scan_sp + pe, cr, flags, lane);
-            pos = pos + fo + 1;
-          } else if (fs < 64) {
-            break;
-          } else {
-            pos += 64;
           }
+          wave_lds_sync();
         }
       }
       __syncthreads();
@@ -218,7 +241,7 @@ __global__ __launch_bounds__(64) void k_feat_ring(const float4* __restrict__ clo
       __syncthreads();
     }
   }
-  if (lane == 0) {
+  if (tid == 0) {
     cntS[r] = nS;
     cntLS[r] = nLS;
     cntF[r] = nF;
@@ -358,14 +381,14 @@ void FeatureExtractor::run_async() {
                        flags_.p);
   }
   const uint32_t flag_bytes = (max_ring_len_ + 15u) & ~15u;
-  const uint32_t nmax = (max_ring_len_ / (uint32_t)params.n_regions + 4u + 3u) & ~3u;
-  const size_t lds = (size_t)flag_bytes + (size_t)nmax * (4 + 4 + 1) + 16;
+  const uint32_t nmax = (max_ring_len_ / (uint32_t)params.n_regions + 4u + 15u) & ~15u;
+  const size_t lds = (size_t)flag_bytes + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) + 16;
   LX_REQUIRE(lds <= 160 * 1024, "scan ring too long for the LDS staging of k_feat_ring");
   const uint32_t caps[3] = {(uint32_t)(params.max_sharp * params.n_regions), (uint32_t)(params.max_less_sharp * params.n_regions),
                             (uint32_t)(params.max_flat * params.n_regions)};
   if (lds > 64 * 1024)
     LX_HIP(hipFuncSetAttribute((const void*)k_feat_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_feat_ring, dim3(nring_), dim3(64), lds, st_, cloud_.p, ring_off_.p, ring_sweep_base_.p, params, curv_.p,
+  hipLaunchKernelGGL(k_feat_ring, dim3(nring_), dim3(64 * FEAT_WAVES), lds, st_, cloud_.p, ring_off_.p, ring_sweep_base_.p, params, curv_.p,
                      flags_.p, flag_bytes, nmax, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p,
                      lf_valid_.p);
   uint32_t* pre[3] = {slot_cnt_[0].p + nring_ + 1, slot_cnt_[1].p + nring_ + 1, slot_cnt_[2].p + nring_ + 1};

@@ -43,23 +43,34 @@ __device__ inline float sqd(const float4& a, float x, float y, float z) {
   return dx * dx + dy * dy + dz * dz;
 }
 
-// exact nearest neighbour with squared distance < 25 (:253-256); returns the ORIGINAL index or -1
+// exact nearest neighbour with squared distance < 25 (:253-256); returns the ORIGINAL index or -1.
+// Expanding shells of grid cells around the query's cell; a row of cells is skipped when its (y,z) slab is already
+// farther than the best distance found, and the x-run of a row is clipped to the cells the best-distance ball can
+// reach (bounds shrunk by a relative 1e-4 so float rounding can only make the search visit MORE cells, never fewer).
 __device__ inline int nn1(const GridDesc& g, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, float qx,
                           float qy, float qz) {
-  float best = FLT_MAX;
+  float best = 25.0f;   // only candidates with d2 < 25 are admissible
   uint32_t best_id = 0xffffffffu;
   const float h = 1.0f / g.inv_h;
-  const int cx = (int)floorf((qx - g.ox) * g.inv_h), cy = (int)floorf((qy - g.oy) * g.inv_h), cz = (int)floorf((qz - g.oz) * g.inv_h);
+  const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
   for (int L = 0;; L++) {
     for (int dz = -L; dz <= L; dz++) {
       const int z = cz + dz;
       if (z < 0 || z >= g.nz) continue;
+      // distance from the query to the slab of cells z (0 inside)
+      const float gz = dz == 0 ? 0.f : (dz > 0 ? ((float)z - fz) : (fz - (float)(z + 1))) * h;
       for (int dy = -L; dy <= L; dy++) {
         const int y = cy + dy;
         if (y < 0 || y >= g.ny) continue;
+        const float gy = dy == 0 ? 0.f : (dy > 0 ? ((float)y - fy) : (fy - (float)(y + 1))) * h;
+        const float gyz = (gy * gy + gz * gz) * 0.9999f;
+        if (gyz >= best) continue;
         const bool face = (dz == -L || dz == L || dy == -L || dy == L);
+        // reach of the current best ball along x, in cells
+        const float rx = sqrtf(best - gyz) * g.inv_h * 1.0001f + 1e-3f;
+        const int xlo = (int)floorf(fx - rx), xhi = (int)floorf(fx + rx);
         const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
-        // on a face row the whole x-run [cx-L, cx+L] is new; otherwise only its two end cells
         for (int part = 0; part < 2; part++) {
           int xa, xb;
           if (face) {
@@ -69,6 +80,8 @@ __device__ inline int nn1(const GridDesc& g, const float4* __restrict__ sorted, 
             xa = xb = part ? cx + L : cx - L;
             if (L == 0 && part) break;
           }
+          if (xa < xlo) xa = xlo;
+          if (xb > xhi) xb = xhi;
           if (xa < 0) xa = 0;
           if (xb > g.nx - 1) xb = g.nx - 1;
           if (xa > xb) continue;
@@ -78,7 +91,7 @@ __device__ inline int nn1(const GridDesc& g, const float4* __restrict__ sorted, 
             const float dx = qx - p.x, dy2 = qy - p.y, dz2 = qz - p.z;
             const float d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
             const uint32_t id = __float_as_uint(p.w);
-            if (d2 < best || (d2 == best && id < best_id)) { best = d2; best_id = id; }
+            if (d2 < best || (d2 == best && best_id != 0xffffffffu && id < best_id)) { best = d2; best_id = id; }
           }
         }
       }
@@ -87,7 +100,7 @@ __device__ inline int nn1(const GridDesc& g, const float4* __restrict__ sorted, 
     if (best <= cover * cover) break;
     if (cover * cover >= 25.0f) break;
   }
-  return (best < 25.0f && best_id != 0xffffffffu) ? (int)best_id : -1;
+  return best_id != 0xffffffffu ? (int)best_id : -1;
 }
 
 // wave-level arg-min of (d, order); every lane gets the winner

@@ -167,21 +167,23 @@ void SubMapIndex::build(const float4* d_pts, uint32_t n) {
 __global__ __launch_bounds__(256) void k_stack(const float4* __restrict__ in, uint32_t n, const uint32_t* __restrict__ seg_off,
                                                uint32_t nseg, const Pose* __restrict__ poses, float inv_corner, float inv_surf,
                                                float4* __restrict__ stack, int* __restrict__ ijk, int* __restrict__ seg_minmax) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t seg = vox_find_seg(seg_off, nseg, i);
-  const Pose T = poses[seg >> 1];
-  float4 p = in[i];
-  float x = p.x, y = p.y, z = p.z;
-  to_map(T, x, y, z);
-  to_be_mapped(T, x, y, z);
-  stack[i] = make_float4(x, y, z, p.w);
-  const float inv = (seg & 1) ? inv_surf : inv_corner;
-  int ix = (int)floorf(x * inv), iy = (int)floorf(y * inv), iz = (int)floorf(z * inv);
-  ijk[3 * i] = ix; ijk[3 * i + 1] = iy; ijk[3 * i + 2] = iz;
-  int* mm = seg_minmax + 6 * seg;
-  atomicMin(&mm[0], ix); atomicMin(&mm[1], iy); atomicMin(&mm[2], iz);
-  atomicMax(&mm[3], ix); atomicMax(&mm[4], iy); atomicMax(&mm[5], iz);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < n;
+  uint32_t seg = 0;
+  int ix = 0, iy = 0, iz = 0;
+  if (active) {
+    seg = vox_find_seg(seg_off, nseg, i);
+    const Pose T = poses[seg >> 1];
+    const float4 p = in[i];
+    float x = p.x, y = p.y, z = p.z;
+    to_map(T, x, y, z);
+    to_be_mapped(T, x, y, z);
+    stack[i] = make_float4(x, y, z, p.w);
+    const float inv = (seg & 1) ? inv_surf : inv_corner;
+    ix = (int)floorf(x * inv); iy = (int)floorf(y * inv); iz = (int)floorf(z * inv);
+    ijk[3 * i] = ix; ijk[3 * i + 1] = iy; ijk[3 * i + 2] = iz;
+  }
+  seg_minmax_update(seg_minmax, active, seg, ix, iy, iz);
 }
 
 // ----------------------------------------------------------------------------------------------------------------

@@ -23,6 +23,38 @@ __device__ inline uint32_t vox_find_seg(const uint32_t* __restrict__ off, uint32
   return lo;
 }
 
+// per-segment integer bounds.  Must be called by ALL lanes of the wave (no early returns before it); `active` marks
+// the lanes that carry a point.  Lanes sharing the segment of the first active lane are reduced with shuffles and
+// issue one set of atomics; stragglers (a wave straddling a segment border) fall back to their own atomics.
+__device__ inline void seg_minmax_update(int* __restrict__ seg_minmax, bool active, uint32_t seg, int ix, int iy, int iz) {
+  const unsigned long long mact = __ballot(active);
+  if (mact == 0) return;
+  const int leader = __builtin_ctzll(mact);
+  const uint32_t first = __shfl(seg, leader, 64);
+  const bool same = active && seg == first;
+  int v[6] = {same ? ix : 2147483647, same ? iy : 2147483647, same ? iz : 2147483647,
+              same ? ix : (-2147483647 - 1), same ? iy : (-2147483647 - 1), same ? iz : (-2147483647 - 1)};
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int a = __shfl_xor(v[k], d, 64), b = __shfl_xor(v[3 + k], d, 64);
+      v[k] = a < v[k] ? a : v[k];
+      v[3 + k] = b > v[3 + k] ? b : v[3 + k];
+    }
+  }
+  if ((int)__lane_id() == leader) {
+    int* mm = seg_minmax + 6 * first;
+    atomicMin(&mm[0], v[0]); atomicMin(&mm[1], v[1]); atomicMin(&mm[2], v[2]);
+    atomicMax(&mm[3], v[3]); atomicMax(&mm[4], v[4]); atomicMax(&mm[5], v[5]);
+  }
+  if (active && !same) {
+    int* mm = seg_minmax + 6 * seg;
+    atomicMin(&mm[0], ix); atomicMin(&mm[1], iy); atomicMin(&mm[2], iz);
+    atomicMax(&mm[3], ix); atomicMax(&mm[4], iy); atomicMax(&mm[5], iz);
+  }
+}
+
 class VoxelPipeline {
  public:
   void init(hipStream_t st);

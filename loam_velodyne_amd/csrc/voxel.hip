@@ -14,17 +14,18 @@ __global__ __launch_bounds__(256) void k_vox_ijk(const float4* __restrict__ pts,
                                                  const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_ids,
                                                  uint32_t nseg, float inv_even, float inv_odd, int* __restrict__ ijk,
                                                  int* __restrict__ seg_minmax) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (valid && !valid[i]) return;
-  const uint32_t seg = seg_ids ? seg_ids[i] : vox_find_seg(seg_off, nseg, i);
-  const float inv = (seg & 1) ? inv_odd : inv_even;
-  const float4 p = pts[i];
-  const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv), iz = (int)floorf(p.z * inv);
-  ijk[3 * i] = ix; ijk[3 * i + 1] = iy; ijk[3 * i + 2] = iz;
-  int* mm = seg_minmax + 6 * seg;
-  atomicMin(&mm[0], ix); atomicMin(&mm[1], iy); atomicMin(&mm[2], iz);
-  atomicMax(&mm[3], ix); atomicMax(&mm[4], iy); atomicMax(&mm[5], iz);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < n && !(valid && !valid[i]);
+  uint32_t seg = 0;
+  int ix = 0, iy = 0, iz = 0;
+  if (active) {
+    seg = seg_ids ? seg_ids[i] : vox_find_seg(seg_off, nseg, i);
+    const float inv = (seg & 1) ? inv_odd : inv_even;
+    const float4 p = pts[i];
+    ix = (int)floorf(p.x * inv); iy = (int)floorf(p.y * inv); iz = (int)floorf(p.z * inv);
+    ijk[3 * i] = ix; ijk[3 * i + 1] = iy; ijk[3 * i + 2] = iz;
+  }
+  seg_minmax_update(seg_minmax, active, seg, ix, iy, iz);
 }
 
 // key = seg << 36 | dz << 24 | dy << 12 | dx  (order == PCL's ix + iy*divx + iz*divx*divy inside a segment).

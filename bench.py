@@ -59,6 +59,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from loam_velodyne_amd import loamx, synth
+    from loam_velodyne_amd import dist as lxdist
 
     ns, K, W = args.streams, args.steps, args.warmup
     T = 1 + W + K   # first sweep of a stream only initialises the odometry
@@ -66,8 +67,7 @@ def main():
 
     # ---- frozen map: generated on rank 0, broadcast over RCCL, adopted in place by the library
     M = args.map_points
-    n_corner = int(round(M * 0.1))
-    n_surf = M - n_corner
+    n_corner, n_surf = lxdist.split_map(M)
     map_t = torch.empty((M, 4), dtype=torch.float32, device=dev)
     if rank == 0:
         cm, sm = world_model.make_map(M)
@@ -77,16 +77,15 @@ def main():
     if dist is not None:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dist.broadcast(map_t, src=0)
+        lxdist.broadcast_map(map_t, dist, src=0)
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
 
     # ---- this rank's streams and staged sweeps (distinct trajectories per rank and stream)
     sweeps = [[None] * ns for _ in range(T)]
     starts = []
-    for s in range(ns):
-        gs = rank * ns + s
-        start = (3.0 * (gs % 8) - 10.0, 0.0, -40.0 + 9.0 * (gs // 8) + 2.0 * (gs % 3))
+    for s, gs in enumerate(lxdist.stream_ids(rank, world, ns)):
+        start = lxdist.stream_start(gs)
         poses = synth.trajectory(T, start=start)
         starts.append(np.array([0, 0, 0, start[0], start[1], start[2]], np.float32))
         for t in range(T):
@@ -128,10 +127,7 @@ def main():
         queries += tm["queries"]
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(et, op=dist.ReduceOp.MAX)
-        elapsed = float(et.item())
+    elapsed = lxdist.max_over_ranks(elapsed, dist, dev)
 
     # pose sanity of this rank's streams against ground truth (not the parity check — that is tests/)
     stats = [pipe.get(s)[3] for s in range(ns)]

@@ -1,0 +1,55 @@
+"""Multi-GPU plumbing of the batched-sweep mode (harness side; torch.distributed is transport only).
+
+The path shards by independent streams: rank r owns streams [r*S, (r+1)*S) — no data-path collective.
+The only exchange is the frozen map: one broadcast from rank 0 per map epoch (RCCL over xGMI with backend "nccl";
+gloo on CPU for the tests), after which every rank builds its own spatial index.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def stream_ids(rank: int, world: int, streams_per_rank: int):
+    """Global stream ids owned by `rank` (contiguous block)."""
+    assert 0 <= rank < world
+    return list(range(rank * streams_per_rank, (rank + 1) * streams_per_rank))
+
+
+def stream_start(gs: int):
+    """Deterministic start position of global stream `gs` inside the synthetic hall (x, y, z)."""
+    return (3.0 * (gs % 8) - 10.0, 0.0, -40.0 + 9.0 * ((gs // 8) % 8) + 2.0 * (gs % 3))
+
+
+def split_map(n_points: int, corner_fraction: float = 0.1):
+    n_corner = int(round(n_points * corner_fraction))
+    return n_corner, n_points - n_corner
+
+
+def broadcast_map(map_tensor, dist, src: int = 0):
+    """Ship the (M,4) float32 map tensor from `src` to every rank, in place.  Returns the tensor."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(map_tensor, src=src)
+    return map_tensor
+
+
+def max_over_ranks(value: float, dist, device=None) -> float:
+    """The job-level step time is the slowest rank's."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_poses(poses: np.ndarray, dist, device=None) -> np.ndarray:
+    """All ranks' (S,6) poses stacked in global stream order (tiny all-gather; reporting only)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return np.asarray(poses, np.float32)
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(poses, np.float32))
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return torch.cat(out, 0).cpu().numpy()

@@ -147,6 +147,10 @@ class LaserOdometry:
         t6 = _f32(t6)
         self.o.L.orc_odom_set_transform(self.h, t6.ctypes.data_as(C.c_void_p))
 
+    def update_imu(self, t12):
+        t12 = _f32(t12)
+        self.o.L.orc_odom_update_imu(self.h, t12.ctypes.data_as(C.c_void_p))
+
     def process(self):
         self.o.L.orc_odom_process(self.h)
 

@@ -1,0 +1,96 @@
+"""Generates the golden fixtures in this directory from the ORACLE (oracle/liboracle.so, the -ffp-contract=off build).
+
+The reference repository has no golden vectors for this path and cannot be built here (PCL / Eigen / ROS absent), so
+these fixtures are oracle outputs on seeded synthetic inputs — "parity unpinned" by the reference, pinned against this
+file's checker.  Re-run:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle_py as op  # noqa: E402
+from loam_velodyne_amd import synth  # noqa: E402
+
+orc = op.Oracle()
+AZ = 600          # VLP-16 at 600 azimuth steps: 9,600 points per sweep keeps the fixtures small
+world = synth.World(half_extent=45.0)
+
+
+def sweeps_for(start, n, seed0):
+    poses = synth.trajectory(n, start=start)
+    return [synth.make_sweep(world, "VLP-16", poses[t], poses[t + 1], seed=seed0 + t, az_steps=AZ) for t in range(n)], poses
+
+
+# ---- 1. feature extraction
+sw, _ = sweeps_for((0.0, 0.0, 0.0), 2, 500)
+sr = op.ScanRegistration(orc)
+f = sr.process(sw[1].points, sw[1].ring_sizes)
+np.savez_compressed(os.path.join(HERE, "features_vlp16.npz"), points=sw[1].points, ring_sizes=sw[1].ring_sizes,
+                    sharp=f["sharp"], less_sharp=f["less_sharp"], flat=f["flat"], less_flat=f["less_flat"])
+
+# ---- 2. streaming pipeline against a frozen map (2 streams x 4 sweeps)
+corner_map, surf_map = world.make_map(40000)
+NS, T = 2, 4
+out = dict(corner_map=corner_map, surf_map=surf_map)
+for s in range(NS):
+    start = (1.5 * s - 0.5, 0.0, 2.5 * s)
+    sws, _ = sweeps_for(start, T, 700 + 50 * s)
+    osr, ood, omp = op.ScanRegistration(orc), op.LaserOdometry(orc), op.LaserMapping(orc)
+    omp.set_frozen(corner_map, surf_map)
+    st = np.array([0, 0, 0, start[0], start[1], start[2]], np.float32)
+    omp.set_transform("aft", st)
+    out[f"start_{s}"] = st
+    sums, afts = [], []
+    for t in range(T):
+        out[f"points_{s}_{t}"] = sws[t].points
+        out[f"rings_{s}_{t}"] = sws[t].ring_sizes
+        ff = osr.process(sws[t].points, sws[t].ring_sizes)
+        ood.set_features(ff)
+        ood.process()
+        if t > 0:
+            omp.set_transform("sum", ood.transform_sum)
+            omp.register_frozen(ood.last_corner(), ood.last_surf(), omp.associate())
+        sums.append(ood.transform_sum)
+        afts.append(omp.transform("aft"))
+    out[f"sum_{s}"] = np.array(sums)
+    out[f"aft_{s}"] = np.array(afts)
+np.savez_compressed(os.path.join(HERE, "pipeline_vlp16.npz"), **out)
+
+# ---- 3. sequential mapping with a live map (one process() per step from a recorded prior state)
+sws, _ = sweeps_for((0.0, 0.0, 0.0), 5, 900)
+osr, ood, omp = op.ScanRegistration(orc), op.LaserOdometry(orc), op.LaserMapping(orc)
+out = {}
+for t in range(5):
+    ff = osr.process(sws[t].points, sws[t].ring_sizes)
+    ood.set_features(ff)
+    ood.process()
+    full_end = ood.full_to_end()
+    lc, ls, ts = ood.last_corner(), ood.last_surf(), ood.transform_sum
+    if t >= 3:   # record the complete prior state of the last two steps
+        out[f"pre_corner_cubes_{t}"] = omp.cloud("corner_cubes")
+        out[f"pre_surf_cubes_{t}"] = omp.cloud("surf_cubes")
+        out[f"pre_aft_{t}"] = omp.transform("aft")
+        out[f"pre_bef_{t}"] = omp.transform("bef")
+        out[f"corner_last_{t}"] = lc
+        out[f"surf_last_{t}"] = ls
+        out[f"full_{t}"] = full_end[::8].copy()
+        out[f"sum_{t}"] = ts
+    omp.set_inputs(lc, ls, full_end, ts)
+    omp.process()
+    if t >= 3:
+        out[f"post_aft_{t}"] = omp.transform("aft")
+        out[f"post_bef_{t}"] = omp.transform("bef")
+        out[f"post_full_{t}"] = omp.cloud("full_res")[::8].copy()
+        out[f"post_n_corner_{t}"] = np.array(len(omp.cloud("corner_cubes")))
+        out[f"post_n_surf_{t}"] = np.array(len(omp.cloud("surf_cubes")))
+        st = omp.stats()
+        out[f"post_stats_{t}"] = np.array([st["iterations"], st["sel"], st["corner_ds"], st["surf_ds"]])
+np.savez_compressed(os.path.join(HERE, "mapping_seq_vlp16.npz"), **out)
+for fn in sorted(os.listdir(HERE)):
+    if fn.endswith(".npz"):
+        print(fn, os.path.getsize(os.path.join(HERE, fn)) // 1024, "KiB")

@@ -1,0 +1,82 @@
+"""GPU: feature extraction through the C-ABI vs the oracle — integer/index work, so the bar is bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as op
+from conftest import GOLDEN
+from loam_velodyne_amd import loamx, synth
+
+pytestmark = pytest.mark.gpu
+NAMES = ("sharp", "less_sharp", "flat", "less_flat")
+
+
+def _same(fo, fg):
+    for n in NAMES:
+        assert fo[n].shape == fg[n].shape, n
+        assert np.array_equal(fo[n], fg[n]), n
+
+
+@pytest.mark.parametrize("sensor", ["VLP-16", "HDL-32", "HDL-64E"])
+def test_full_size_sweeps_bit_exact(orc, small_world, sensor):
+    poses = synth.trajectory(2)
+    osr, gsr = op.ScanRegistration(orc), loamx.ScanRegistration()
+    for k in range(2):
+        sw = synth.make_sweep(small_world, sensor, poses[k], poses[k + 1], seed=k)
+        _same(osr.process(sw.points, sw.ring_sizes), gsr.process(sw.points, sw.ring_sizes))
+
+
+def test_golden_fixture(orc):
+    g = np.load(os.path.join(GOLDEN, "features_vlp16.npz"))
+    fg = loamx.ScanRegistration().process(g["points"], g["ring_sizes"])
+    for n in NAMES:
+        assert np.array_equal(fg[n], g[n]), n
+
+
+def test_ragged_empty_and_short_rings(orc, small_world):
+    sw = synth.make_sweep(small_world, "VLP-16", np.zeros(6), np.zeros(6), seed=4, az_steps=700)
+    pts = sw.points.reshape(16, 700, 4)
+    rng = np.random.default_rng(0)
+    sizes = [700, 0, 11, 10, 350, 699, 1, 64, 700, 12, 257, 0, 700, 33, 500, 128]   # <= 2*5+1 points => ring skipped
+    rings = [pts[r, :n] for r, n in enumerate(sizes)]
+    cloud = np.concatenate(rings, 0)
+    _same(op.ScanRegistration(orc).process(cloud, sizes), loamx.ScanRegistration().process(cloud, sizes))
+
+
+def test_nondefault_parameters(orc, small_world):
+    sw = synth.make_sweep(small_world, "HDL-32", np.zeros(6), np.zeros(6), seed=5, az_steps=1000)
+    cfg = dict(nFeatureRegions=4, curvatureRegion=3, maxCornerSharp=3, maxSurfaceFlat=2, lessFlatFilterSize=0.3,
+               surfaceCurvatureThreshold=0.2)
+    g = loamx.ScanRegistration(n_feature_regions=4, curvature_region=3, max_corner_sharp=3, max_surface_flat=2,
+                               less_flat_filter_size=0.3, surface_curvature_threshold=0.2)
+    _same(op.ScanRegistration(orc, **cfg).process(sw.points, sw.ring_sizes), g.process(sw.points, sw.ring_sizes))
+
+
+def test_pcl_layout_io(small_world):
+    """32-byte pcl::PointXYZI records in and out give the same points as packed float4."""
+    sw = synth.make_sweep(small_world, "VLP-16", np.zeros(6), np.zeros(6), seed=6, az_steps=600)
+    g = loamx.ScanRegistration()
+    a = g.process(sw.points, sw.ring_sizes)
+    b = g.process(loamx.to_pcl_layout(sw.points), sw.ring_sizes, pcl_layout=True)
+    for n in NAMES:
+        assert np.array_equal(a[n][:, :3], b[n][:, :3]) and np.array_equal(a[n][:, 3], b[n][:, 4])
+        assert np.all(b[n][:, 3] == 1.0)
+
+
+def test_error_behaviour(small_world):
+    import ctypes as C
+    g = loamx.ScanRegistration()
+    pts = np.zeros((100, 4), np.float32)
+    with pytest.raises(loamx.LoamxError):          # ring sizes do not add up
+        g.process(pts, [50, 40])
+    with pytest.raises(loamx.LoamxError):          # invalid parameter, same rule as the reference's parameter parsing
+        loamx.ScanRegistration(max_corner_sharp=0)
+    # undersized output buffer: LOAMX_E_CAPACITY with the needed count reported
+    sw = synth.make_sweep(small_world, "VLP-16", np.zeros(6), np.zeros(6), seed=7, az_steps=600)
+    rs = np.ascontiguousarray(sw.ring_sizes, np.uint32)
+    cin = loamx.cloud_of(sw.points)
+    small = np.zeros((4, 4), np.float32)
+    cs = loamx.cloud_of(small)
+    rc = loamx.lib().loamx_scanreg_process(g.h, C.byref(cin), rs.ctypes.data_as(C.c_void_p), len(rs), C.byref(cs), None, None, None)
+    assert rc == loamx.E_CAPACITY and cs.count > 4

@@ -214,98 +214,117 @@ template <int M, int N> __device__ inline void qr_solve(float (&A)[M][N], float 
       if (c < nonzero && perm[c] == j) x[j] = y[c];
 }
 
-// ---- 6x6 helpers for the once-per-iteration solve (one thread; dynamic indexing is fine here) --------------------
-__device__ inline void eig6_sym(const float* Ain, float* w, float* V) {
-  float A[6][6], Q[6][6];
+// ---- 6x6 helpers for the once-per-iteration solve (one thread).  Work arrays live in a caller-provided LDS
+// workspace `ws` (>= 216 floats): dynamically indexed private arrays would be placed in scratch (global memory), whose
+// latency dominates a serial solve.
+__device__ inline void eig6_sym(const float* Ain, float* w, float* V, float* ws) {
+  float* A = ws;        // 36
+  float* Q = ws + 36;   // 36
   for (int r = 0; r < 6; r++)
-    for (int c = 0; c <= r; c++) A[r][c] = A[c][r] = Ain[r * 6 + c];
+    for (int c = 0; c <= r; c++) A[r * 6 + c] = A[c * 6 + r] = Ain[r * 6 + c];
   for (int r = 0; r < 6; r++)
-    for (int c = 0; c < 6; c++) Q[r][c] = (r == c) ? 1.f : 0.f;
+    for (int c = 0; c < 6; c++) Q[r * 6 + c] = (r == c) ? 1.f : 0.f;
   for (int sweep = 0; sweep < 16; sweep++) {
     float off = 0.f, diag = 0.f;
     for (int r = 0; r < 6; r++) {
-      diag += A[r][r] * A[r][r];
-      for (int c = 0; c < r; c++) off += A[r][c] * A[r][c];
+      diag += A[r * 6 + r] * A[r * 6 + r];
+      for (int c = 0; c < r; c++) off += A[r * 6 + c] * A[r * 6 + c];
     }
     if (off <= 1e-20f * diag || off == 0.f) break;
     for (int p = 0; p < 5; p++)
       for (int q = p + 1; q < 6; q++) {
-        float apq = A[p][q];
+        float apq = A[p * 6 + q];
         if (apq == 0.f) continue;
-        float theta = (A[q][q] - A[p][p]) / (2.f * apq);
+        float theta = (A[q * 6 + q] - A[p * 6 + p]) / (2.f * apq);
         float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
         float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
         for (int k = 0; k < 6; k++) {
-          float akp = A[k][p], akq = A[k][q];
-          A[k][p] = c * akp - s * akq;
-          A[k][q] = s * akp + c * akq;
+          float akp = A[k * 6 + p], akq = A[k * 6 + q];
+          A[k * 6 + p] = c * akp - s * akq;
+          A[k * 6 + q] = s * akp + c * akq;
         }
         for (int k = 0; k < 6; k++) {
-          float apk = A[p][k], aqk = A[q][k];
-          A[p][k] = c * apk - s * aqk;
-          A[q][k] = s * apk + c * aqk;
+          float apk = A[p * 6 + k], aqk = A[q * 6 + k];
+          A[p * 6 + k] = c * apk - s * aqk;
+          A[q * 6 + k] = s * apk + c * aqk;
         }
         for (int k = 0; k < 6; k++) {
-          float qkp = Q[k][p], qkq = Q[k][q];
-          Q[k][p] = c * qkp - s * qkq;
-          Q[k][q] = s * qkp + c * qkq;
+          float qkp = Q[k * 6 + p], qkq = Q[k * 6 + q];
+          Q[k * 6 + p] = c * qkp - s * qkq;
+          Q[k * 6 + q] = s * qkp + c * qkq;
         }
       }
   }
   int order[6];
+#pragma unroll
   for (int k = 0; k < 6; k++) order[k] = k;
-  for (int a = 1; a < 6; a++)
-    for (int b = a; b > 0 && A[order[b]][order[b]] < A[order[b - 1]][order[b - 1]]; b--) {
-      int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t;
+  // insertion sort ascending, stable (small fixed network, compile-time indices)
+#pragma unroll
+  for (int a_ = 1; a_ < 6; a_++) {
+#pragma unroll
+    for (int b_ = 5; b_ > 0; b_--) {
+      if (b_ <= a_) {
+        const float eb = A[order[b_] * 6 + order[b_]], ea = A[order[b_ - 1] * 6 + order[b_ - 1]];
+        if (eb < ea) { int t = order[b_]; order[b_] = order[b_ - 1]; order[b_ - 1] = t; }
+      }
     }
+  }
   for (int k = 0; k < 6; k++) {
-    w[k] = A[order[k]][order[k]];
-    for (int r = 0; r < 6; r++) V[r * 6 + k] = Q[r][order[k]];
+    w[k] = A[order[k] * 6 + order[k]];
+    for (int r = 0; r < 6; r++) V[r * 6 + k] = Q[r * 6 + order[k]];
   }
 }
 
-__device__ inline bool inverse6(const float* Ain, float* inv) {
-  float A[6][12];
+__device__ inline bool inverse6(const float* Ain, float* inv, float* ws) {
+  float* A = ws;   // 6 x 12
   for (int r = 0; r < 6; r++)
     for (int c = 0; c < 6; c++) {
-      A[r][c] = Ain[r * 6 + c];
-      A[r][6 + c] = (r == c) ? 1.f : 0.f;
+      A[r * 12 + c] = Ain[r * 6 + c];
+      A[r * 12 + 6 + c] = (r == c) ? 1.f : 0.f;
     }
   for (int k = 0; k < 6; k++) {
     int piv = k;
     for (int r = k + 1; r < 6; r++)
-      if (fabsf(A[r][k]) > fabsf(A[piv][k])) piv = r;
-    if (A[piv][k] == 0.f) return false;
+      if (fabsf(A[r * 12 + k]) > fabsf(A[piv * 12 + k])) piv = r;
+    if (A[piv * 12 + k] == 0.f) return false;
     if (piv != k)
-      for (int c = 0; c < 12; c++) { float t = A[k][c]; A[k][c] = A[piv][c]; A[piv][c] = t; }
-    float d = 1.f / A[k][k];
-    for (int c = 0; c < 12; c++) A[k][c] *= d;
+      for (int c = 0; c < 12; c++) { float t = A[k * 12 + c]; A[k * 12 + c] = A[piv * 12 + c]; A[piv * 12 + c] = t; }
+    float d = 1.f / A[k * 12 + k];
+    for (int c = 0; c < 12; c++) A[k * 12 + c] *= d;
     for (int r = 0; r < 6; r++)
       if (r != k) {
-        float f = A[r][k];
+        float f = A[r * 12 + k];
         if (f != 0.f)
-          for (int c = 0; c < 12; c++) A[r][c] -= f * A[k][c];
+          for (int c = 0; c < 12; c++) A[r * 12 + c] -= f * A[k * 12 + c];
       }
   }
   for (int r = 0; r < 6; r++)
-    for (int c = 0; c < 6; c++) inv[r * 6 + c] = A[r][6 + c];
+    for (int c = 0; c < 6; c++) inv[r * 6 + c] = A[r * 12 + 6 + c];
   return true;
 }
 
 // P = V^-1 * V2, V2 = V with ROW i zeroed while ascending eigenvalue i < thr (BasicLaserMapping.cpp:875-898)
-__device__ inline bool degeneracy_projector(const float* AtA, float thr, float* P) {
-  float w[6], V[36], V2[36], Vi[36];
-  eig6_sym(AtA, w, V);
+__device__ inline bool degeneracy_projector(const float* AtA, float thr, float* P, float* ws) {
+  float w[6];
+  float* V = ws + 72;     // 36
+  float* V2 = ws + 108;   // 36
+  float* Vi = ws + 144;   // 36
+  eig6_sym(AtA, w, V, ws);
   for (int k = 0; k < 36; k++) V2[k] = V[k];
   bool degenerate = false;
-  for (int i = 0; i < 6; i++) {
-    if (w[i] < thr) {
-      for (int j = 0; j < 6; j++) V2[i * 6 + j] = 0.f;
-      degenerate = true;
-    } else
-      break;
+  {
+    bool go = true;   // ascending order: stop at the first eigenvalue that reaches the threshold
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      if (go && w[i] < thr) {
+        for (int j = 0; j < 6; j++) V2[i * 6 + j] = 0.f;
+        degenerate = true;
+      } else {
+        go = false;
+      }
+    }
   }
-  if (!inverse6(V, Vi)) {
+  if (!inverse6(V, Vi, ws)) {
     for (int k = 0; k < 36; k++) P[k] = (k % 7 == 0) ? 1.f : 0.f;
     return degenerate;
   }

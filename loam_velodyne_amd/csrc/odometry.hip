@@ -3,10 +3,10 @@
 // The problem is small (<= 768 sharp + 1536 flat features against the previous sweep's <= ~60 k feature points) and
 // strictly iterative (<= 25 dependent Gauss-Newton steps), i.e. latency-bound.  Per group of 5 iterations, for all
 // streams of a batch at once:
-//   k_odom_nn      (:250-256, :368-372)  thread per feature: transformToStart + exact 1-NN (5 m gate) in the previous
-//                  cloud through a uniform grid searched in expanding shells (replaces the kd-tree of :203-204 / :662-663)
-//   k_odom_window  (:258-302, :374-435)  wave per feature: the +-2.5-ring window scans over the ring-ordered previous
-//                  cloud, lanes striding the window, ballot for the loop's break, shuffle arg-min with scan-order tie-break
+//   k_odom_corr    (:250-302, :368-435)  one wave per feature: transformToStart, exact 1-NN (5 m gate) in the previous cloud
+//                  through a uniform grid searched in expanding shells with the lanes striding each cell row (replaces the
+//                  kd-tree of :203-204 / :662-663), then the +-2.5-ring window scans over the ring-ordered previous cloud,
+//                  ballot for the loop's break, shuffle arg-min with scan-order tie-break
 //   k_odom_lm      (:304-361, :437-481, :497-622)  one PERSISTENT workgroup per stream runs the 5 iterations without a
 //                  kernel boundary: thread per feature point-to-line / point-to-plane coefficients and Jacobian row with
 //                  the de-skew chain rule, J^T J / J^T r reduced with wave shuffles (double accumulators), thread 0:
@@ -114,36 +114,79 @@ __device__ inline void wave_argmin(float& d, int& j, int& order) {
   }
 }
 
-// ---- phase A: nearest neighbour per feature; grid = (ceil(maxFeat/256), streams)
-__global__ __launch_bounds__(256) void k_odom_nn(OdomProblem* __restrict__ probs, OdomParams P) {
-  OdomProblem& pb = probs[blockIdx.y];
-  if (pb.done) return;
-  const int nSharp = (int)pb.n_sharp, nFeat = nSharp + (int)pb.n_flat;
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= nFeat) return;
-  float T[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) T[k] = pb.transform[k];
-  const bool corner = f < nSharp;
-  const float4 pi = corner ? pb.sharp[f] : pb.flat[f - nSharp];
-  float x, y, z;
-  transform_to_start(T, P.scan_period, pi, x, y, z);
-  const int c = corner ? nn1(*pb.lc_desc, pb.lc_sorted, pb.lc_cell, x, y, z) : nn1(*pb.ls_desc, pb.ls_sorted, pb.ls_cell, x, y, z);
-  pb.ind[5 * f] = c;
-  pb.ind[5 * f + 1] = -1;
-  pb.ind[5 * f + 2] = -1;
+// exact nearest neighbour (d2 < 25) searched by a WHOLE WAVE: the lanes stride over the candidate points of each cell
+// row; after every shell the lane minima are combined so that pruning and termination stay wave-uniform.
+__device__ inline int nn1_wave(const GridDesc& g, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, float qx,
+                               float qy, float qz, int lane) {
+  float best = 25.0f;           // wave-uniform bound (only candidates with d2 < 25 are admissible)
+  float lbest = 25.0f;          // this lane's best
+  uint32_t lid = 0xffffffffu;
+  int best_id = -1;
+  const float h = 1.0f / g.inv_h;
+  const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+  for (int L = 0;; L++) {
+    for (int dz = -L; dz <= L; dz++) {
+      const int z = cz + dz;
+      if (z < 0 || z >= g.nz) continue;
+      const float gz = dz == 0 ? 0.f : (dz > 0 ? ((float)z - fz) : (fz - (float)(z + 1))) * h;
+      for (int dy = -L; dy <= L; dy++) {
+        const int y = cy + dy;
+        if (y < 0 || y >= g.ny) continue;
+        const float gy = dy == 0 ? 0.f : (dy > 0 ? ((float)y - fy) : (fy - (float)(y + 1))) * h;
+        const float gyz = (gy * gy + gz * gz) * 0.9999f;
+        if (gyz >= best) continue;
+        const bool face = (dz == -L || dz == L || dy == -L || dy == L);
+        const float rx = sqrtf(best - gyz) * g.inv_h * 1.0001f + 1e-3f;
+        const int xlo = (int)floorf(fx - rx), xhi = (int)floorf(fx + rx);
+        const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
+        for (int part = 0; part < 2; part++) {
+          int xa, xb;
+          if (face) {
+            if (part) break;
+            xa = cx - L; xb = cx + L;
+          } else {
+            xa = xb = part ? cx + L : cx - L;
+            if (L == 0 && part) break;
+          }
+          if (xa < xlo) xa = xlo;
+          if (xb > xhi) xb = xhi;
+          if (xa < 0) xa = 0;
+          if (xb > g.nx - 1) xb = g.nx - 1;
+          if (xa > xb) continue;
+          const uint32_t beg = cell_start[row + xa], end = cell_start[row + xb + 1];
+          for (uint32_t k = beg + lane; k < end; k += 64) {
+            const float4 p = sorted[k];
+            const float dx = qx - p.x, dy2 = qy - p.y, dz2 = qz - p.z;
+            const float d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
+            const uint32_t id = __float_as_uint(p.w);
+            if (d2 < lbest || (d2 == lbest && lid != 0xffffffffu && id < lid)) { lbest = d2; lid = id; }
+          }
+        }
+      }
+    }
+    // combine: smallest distance, ties to the lowest original index
+    float d = lbest;
+    int j = (int)lid, o_ = (int)lid;   // order key = original index (< 2^31)
+    if (lid == 0xffffffffu) { j = -1; o_ = 0x7fffffff; }
+    wave_argmin(d, j, o_);
+    if (j >= 0 && d < 25.0f) { best = d; best_id = j; }
+    const float cover = (float)L * h;
+    if (best <= cover * cover) break;
+    if (cover * cover >= 25.0f) break;
+  }
+  return best_id;
 }
 
-// ---- phase B: ring-window scans, one wave per feature; grid = (ceil(maxFeat/4), streams), 256 threads
-__global__ __launch_bounds__(256) void k_odom_window(OdomProblem* __restrict__ probs, OdomParams P) {
+// ---- phases A+B: correspondences of one feature by one wave: exact 1-NN, then the ring-window scans;
+// grid = (ceil(maxFeat/4), streams), 256 threads
+__global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ probs, OdomParams P) {
   OdomProblem& pb = probs[blockIdx.y];
   if (pb.done) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nSharp = (int)pb.n_sharp, nFlat = (int)pb.n_flat, nFeat = nSharp + nFlat;
   const int f = blockIdx.x * 4 + wid;
   if (f >= nFeat) return;
-  const int closest = pb.ind[5 * f];
-  if (closest < 0) return;   // wave-uniform
   float T[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) T[k] = pb.transform[k];
@@ -151,6 +194,12 @@ __global__ __launch_bounds__(256) void k_odom_window(OdomProblem* __restrict__ p
   const float4 pi = corner ? pb.sharp[f] : pb.flat[f - nSharp];
   float x, y, z;
   transform_to_start(T, P.scan_period, pi, x, y, z);
+  const int closest = corner ? nn1_wave(*pb.lc_desc, pb.lc_sorted, pb.lc_cell, x, y, z, lane)
+                             : nn1_wave(*pb.ls_desc, pb.ls_sorted, pb.ls_cell, x, y, z, lane);
+  if (closest < 0) {   // wave-uniform
+    if (lane == 0) { pb.ind[5 * f] = -1; pb.ind[5 * f + 1] = -1; pb.ind[5 * f + 2] = -1; }
+    return;
+  }
   const float4* last = corner ? pb.last_corner : pb.last_surf;
   const int nLast = corner ? (int)pb.n_last_corner : (int)pb.n_last_surf;
   const int nCur = corner ? nSharp : nFlat;
@@ -201,6 +250,7 @@ __global__ __launch_bounds__(256) void k_odom_window(OdomProblem* __restrict__ p
   wave_argmin(d2, j2, o2);
   if (!corner) wave_argmin(d3, j3, o3);
   if (lane == 0) {
+    pb.ind[5 * f] = closest;
     pb.ind[5 * f + 1] = j2;
     pb.ind[5 * f + 2] = corner ? -1 : j3;
   }
@@ -216,6 +266,7 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
   __shared__ float trig[6];
   __shared__ double red[OD_WAVES][LX_NSUM];
   __shared__ int sh_done;
+  __shared__ float ws[216];
   if (tid < 6) T[tid] = pb.transform[tid];
   if (tid == 0) sh_done = 0;
   __syncthreads();
@@ -330,7 +381,7 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
           for (int j = i; j < 6; j++) { AtA[i * 6 + j] = AtA[j * 6 + i] = (float)sums[k]; k++; }
         for (int i = 0; i < 6; i++) AtB[i] = (float)sums[21 + i];
         qr_solve6(AtA, AtB, X);
-        if (iter == 0) pb.stats.degenerate = degeneracy_projector(AtA, 10.f, pb.matP) ? 1 : 0;
+        if (iter == 0) pb.stats.degenerate = degeneracy_projector(AtA, 10.f, pb.matP, ws) ? 1 : 0;
         if (pb.stats.degenerate) {
           float X2[6];
           for (int r = 0; r < 6; r++) X2[r] = X[r];
@@ -501,8 +552,7 @@ void OdometryBatch::process_subset(const std::vector<uint32_t>& which, const Odo
     if (max_feat) {
       for (int it0 = 0; it0 < params.max_iterations; it0 += 5) {
         const int nit = std::min(5, params.max_iterations - it0);
-        hipLaunchKernelGGL(k_odom_nn, dim3((max_feat + 255) / 256, na), dim3(256), 0, st_, prob_.p, params);
-        hipLaunchKernelGGL(k_odom_window, dim3((max_feat + 3) / 4, na), dim3(256), 0, st_, prob_.p, params);
+        hipLaunchKernelGGL(k_odom_corr, dim3((max_feat + 3) / 4, na), dim3(256), 0, st_, prob_.p, params);
         hipLaunchKernelGGL(k_odom_lm, dim3(na), dim3(OD_THREADS), 0, st_, prob_.p, params, it0, nit);
       }
     }

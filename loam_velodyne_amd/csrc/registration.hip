@@ -68,12 +68,18 @@ __global__ __launch_bounds__(256) void k_bbox(const float4* __restrict__ pts, ui
       mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, 64));
     }
   }
-  if ((threadIdx.x & 63) == 0) {
+  __shared__ float red[4][6];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) {
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      atomicMin(&enc[a], enc_f32(mn[a]));
-      atomicMax(&enc[3 + a], enc_f32(mx[a]));
-    }
+    for (int a = 0; a < 3; a++) { red[wid][a] = mn[a]; red[wid][3 + a] = mx[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    float v = red[0][a];
+    for (int w = 1; w < 4; w++) v = a < 3 ? fminf(v, red[w][a]) : fmaxf(v, red[w][a]);
+    if (a < 3) atomicMin(&enc[a], enc_f32(v)); else atomicMax(&enc[a], enc_f32(v));
   }
 }
 
@@ -150,7 +156,7 @@ void SubMapIndex::build(const float4* d_pts, uint32_t n) {
   cursor_.reserve((size_t)LX_MAX_CELLS + 2);
   hipLaunchKernelGGL(k_init_bbox, dim3(1), dim3(16), 0, st_, scratch_.p);
   const uint32_t nb = (n + 255) / 256;
-  hipLaunchKernelGGL(k_bbox, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, st_, d_pts, n, scratch_.p);
+  hipLaunchKernelGGL(k_bbox, dim3(nb < 128 ? nb : 128), dim3(256), 0, st_, d_pts, n, scratch_.p);
   hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(1), 0, st_, scratch_.p, d_desc_.p, LX_MAX_CELLS);
   hipLaunchKernelGGL(k_zero_u32_dn, dim3(2048), dim3(256), 0, st_, cursor_.p, scratch_.p + 6);
   hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st_, d_pts, n, d_desc_.p, cell_of_.p, cursor_.p);
@@ -395,6 +401,7 @@ __global__ __launch_bounds__(64) void k_solve(const uint32_t* __restrict__ ds_of
   const uint32_t nq = ds_off[2 * s + 2] - ds_off[2 * s];
   const uint32_t nact = (nq + LX_RES_THREADS - 1) / LX_RES_THREADS;
   __shared__ double sums[LX_NSUM];
+  __shared__ float ws[216];
   if (threadIdx.x < LX_NSUM) {
     double x = 0.0;
     for (uint32_t b = 0; b < nact; b++) x += partials[((size_t)s * nblk + b) * LX_NSUM + threadIdx.x];
@@ -421,7 +428,7 @@ __global__ __launch_bounds__(64) void k_solve(const uint32_t* __restrict__ ds_of
   for (int i = 0; i < 6; i++) AtB[i] = (float)sums[21 + i];
   qr_solve6(AtA, AtB, X);
   float* P = matP + 36 * s;
-  if (iter == 0) st.degenerate = degeneracy_projector(AtA, 100.f, P) ? 1 : 0;
+  if (iter == 0) st.degenerate = degeneracy_projector(AtA, 100.f, P, ws) ? 1 : 0;
   if (st.degenerate) {
     float X2[6];
     for (int r = 0; r < 6; r++) X2[r] = X[r];

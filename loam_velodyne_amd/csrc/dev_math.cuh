@@ -304,7 +304,41 @@ __device__ inline bool inverse6(const float* Ain, float* inv, float* ws) {
 }
 
 // P = V^-1 * V2, V2 = V with ROW i zeroed while ascending eigenvalue i < thr (BasicLaserMapping.cpp:875-898)
+// Certificate that every eigenvalue of the symmetric 6x6 AtA exceeds thr*(1+1e-3): a Cholesky factorisation of
+// AtA - thr*(1+1e-3)*I in double succeeds with pivots well above rounding noise.  When it holds the reference's loop
+// (BasicLaserMapping.cpp:883-897) zeroes nothing, isDegenerate stays false and matP is never used, so the 6x6
+// eigen-decomposition can be skipped; borderline and degenerate cases take the full path below.
+__device__ inline bool certainly_not_degenerate(const float* AtA, float thr) {
+  double L[6][6];
+  const double shift = (double)thr * 1.001;
+  double scale = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) scale = fmax(scale, fabs((double)AtA[i * 6 + i]));
+  const double tiny = 1e-6 * scale;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double dj = (double)AtA[j * 6 + j] - shift;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k < j) dj -= L[j][k] * L[j][k];
+    if (!(dj > tiny)) return false;
+    const double lj = sqrt(dj);
+    L[j][j] = lj;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+      if (i > j) {
+        double s = (double)AtA[i * 6 + j];
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+          if (k < j) s -= L[i][k] * L[j][k];
+        L[i][j] = s / lj;
+      }
+  }
+  return true;
+}
+
 __device__ inline bool degeneracy_projector(const float* AtA, float thr, float* P, float* ws) {
+  if (certainly_not_degenerate(AtA, thr)) return false;
   float w[6];
   float* V = ws + 72;     // 36
   float* V2 = ws + 108;   // 36

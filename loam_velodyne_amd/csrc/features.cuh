@@ -54,7 +54,7 @@ class FeatureExtractor {
   DevBuf<float4> cloud_;
   DevBuf<uint32_t> ring_off_, ring_sweep_base_;   // ring_off_[nring+1] global point offsets; sweep base offset per ring
   DevBuf<float> curv_;
-  DevBuf<uint8_t> flags_, lf_valid_;
+  DevBuf<uint8_t> flags_, gap_, lf_valid_;
   DevBuf<float4> slots_[3];       // per-ring fixed-capacity pick slots (sharp / less sharp / flat)
   DevBuf<uint32_t> slot_cnt_[3];  // per-ring counts
   DevBuf<float4> out_[3];

@@ -26,13 +26,17 @@ __device__ inline float sqdiff3w(const float4& a, const float4& b, float wb) {
 
 // grid = (ceil(max_ring_len/256), nring)
 __global__ __launch_bounds__(256) void k_feat_point(const float4* __restrict__ cloud, const uint32_t* __restrict__ ring_off, int cr,
-                                                    float* __restrict__ curv, uint8_t* __restrict__ flags) {
+                                                    float* __restrict__ curv, uint8_t* __restrict__ flags, uint8_t* __restrict__ gap) {
   const uint32_t r = blockIdx.y;
   const uint32_t s0 = ring_off[r], e1 = ring_off[r + 1];
   const uint32_t len = e1 - s0;
   if (len <= 2u * cr + 1u) return;
   const uint32_t e0 = e1 - 1;
   const uint32_t i = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > e0) return;
+  // gap[i]: the step to the next point exceeds markAsPicked's 0.05 m^2 limit (:372, :380) — precomputed so that the
+  // sequential picking loop never waits on global memory
+  if (i < e0) gap[i] = ((double)sqdiff3(cloud[i + 1], cloud[i]) > 0.05) ? 1 : 0;
   if (i < s0 + cr || i > e0 - cr) return;
   const float4 p = cloud[i];
   // curvature (:293-306): diff = -2*cr*p + sum_j (p[i+j] + p[i-j])
@@ -79,17 +83,12 @@ struct RingLds {
 // LDS writes of this wave become visible to its own later LDS reads (one wave works on the pick lists at a time)
 __device__ inline void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 
-// suppress the neighbours of a picked point (markAsPicked :367-386); one whole wave participates
-__device__ inline void mark_as_picked(const float4* __restrict__ cloud, uint32_t g /* global index */, uint32_t scan_i, int cr,
-                                      uint8_t* flags, int lane) {
+// suppress the neighbours of a picked point (markAsPicked :367-386); one whole wave participates.
+// gaps[k] = 1 when |p[k+1] - p[k]|^2 > 0.05 (ring-relative k)
+__device__ inline void mark_as_picked(uint32_t scan_i, int cr, uint8_t* flags, const uint8_t* gaps, int lane) {
   bool brk = false;
-  if (lane < cr) {
-    const int i = lane + 1;
-    brk = (double)sqdiff3(cloud[g + i], cloud[g + i - 1]) > 0.05;
-  } else if (lane >= 32 && lane < 32 + cr) {
-    const int i = lane - 32 + 1;
-    brk = (double)sqdiff3(cloud[g - i], cloud[g - i + 1]) > 0.05;
-  }
+  if (lane < cr) brk = gaps[scan_i + lane] != 0;                               // forward step i = lane+1: p[idx+i] vs p[idx+i-1]
+  else if (lane >= 32 && lane < 32 + cr) brk = gaps[scan_i - (lane - 32) - 1] != 0;   // backward step i: p[idx-i] vs p[idx-i+1]
   const unsigned long long m = __ballot(brk);
   const uint32_t mf = (uint32_t)(m & 0xffffffffull), mb = (uint32_t)(m >> 32);
   const int nf = mf ? __builtin_ctz(mf) : cr;
@@ -102,14 +101,17 @@ __device__ inline void mark_as_picked(const float4* __restrict__ cloud, uint32_t
 
 constexpr int FEAT_WAVES = 6;   // regions sorted concurrently per ring
 
-// one workgroup of FEAT_WAVES waves per ring.  Dynamic LDS: flags[flag_bytes] | per wave { c[nmax] | sorted[nmax] | label[nmax] }
+// one workgroup of FEAT_WAVES waves per ring.  Dynamic LDS: flags[flag_bytes] | gaps[flag_bytes] | per wave { c | sorted | label }[nmax]
 __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
     const float4* __restrict__ cloud, const uint32_t* __restrict__ ring_off, const uint32_t* __restrict__ ring_sweep_base, FeatParams P,
-    const float* __restrict__ curv, const uint8_t* __restrict__ gflags, uint32_t flag_bytes, uint32_t nmax, float4* __restrict__ slotS,
+    const float* __restrict__ curv, const uint8_t* __restrict__ gflags, const uint8_t* __restrict__ ggap, uint32_t flag_bytes,
+    uint32_t nmax, float4* __restrict__ slotS,
     float4* __restrict__ slotLS, float4* __restrict__ slotF, uint32_t* __restrict__ cntS, uint32_t* __restrict__ cntLS,
     uint32_t* __restrict__ cntF, uint8_t* __restrict__ lf_valid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint8_t* flags = (uint8_t*)smem;
+  uint8_t* gaps = flags + flag_bytes;
+  char* wave_base = smem + 2 * (size_t)flag_bytes;
   const size_t wave_bytes = (size_t)nmax * 9;
   __shared__ uint32_t reg_n[FEAT_WAVES], reg_gsp[FEAT_WAVES], reg_scan[FEAT_WAVES];
 
@@ -123,8 +125,11 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
     const uint32_t base = ring_sweep_base[r];
     // indices relative to the sweep's cloud, exactly the values the reference's integer region formula sees (:180-183)
     const unsigned long long s0 = s0g - base, e0 = s0 + len - 1;
-    for (uint32_t k = tid; k < len; k += blockDim.x) flags[k] = gflags[s0g + k];
-    float* c = (float*)(smem + flag_bytes + wid * wave_bytes);
+    for (uint32_t k = tid; k < len; k += blockDim.x) {
+      flags[k] = gflags[s0g + k];
+      gaps[k] = k + 1 < len ? ggap[s0g + k] : 1;
+    }
+    float* c = (float*)(wave_base + wid * wave_bytes);
     uint32_t* sorted = (uint32_t*)(c + nmax);
     int8_t* label = (int8_t*)(sorted + nmax);
     for (int jb = 0; jb < nreg; jb += FEAT_WAVES) {
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
           const uint32_t rn = reg_n[w];
           if (rn == 0) continue;
           const uint32_t rgsp = reg_gsp[w], rscan = reg_scan[w];
-          const float* rc = (const float*)(smem + flag_bytes + w * wave_bytes);
+          const float* rc = (const float*)(wave_base + w * wave_bytes);
           const uint32_t* rsorted = (const uint32_t*)(rc + nmax);
           int8_t* rlabel = (int8_t*)(rsorted + nmax);
           // corner picks from the largest curvature down (:197-217)
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
                 }
                 if (picked <= P.max_sharp) nS++;
                 nLS++;
-                mark_as_picked(cloud, rgsp + pe, rscan + pe, cr, flags, lane);
+                mark_as_picked(rscan + pe, cr, flags, gaps, lane);
                 pos = pos - 1 - fo;
               } else if (fs < 64) {
                 break;   // sorted: nothing further exceeds the threshold
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
                   slotF[(size_t)r * capF + nF] = cloud[rgsp + pe];
                 }
                 nF++;
-                mark_as_picked(cloud, rgsp + pe, rscan + pe, cr, flags, lane);
+                mark_as_picked(rscan + pe, cr, flags, gaps, lane);
                 pos = pos + fo + 1;
               } else if (fs < 64) {
                 break;
@@ -348,6 +353,7 @@ void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uin
   cloud_.reserve(n_ + 1);
   curv_.reserve(n_ + 1);
   flags_.reserve(n_ + 1);
+  gap_.reserve(n_ + 1);
   lf_valid_.reserve(n_ + 1);
   lf_out_.reserve(n_ + 1);
   ring_off_.reserve(nring_ + 2);
@@ -378,18 +384,18 @@ void FeatureExtractor::run_async() {
   LX_HIP(hipMemsetAsync(lf_valid_.p, 0, n_ + 1, st_));
   if (n_ && max_ring_len_) {
     hipLaunchKernelGGL(k_feat_point, dim3((max_ring_len_ + 255) / 256, nring_), dim3(256), 0, st_, cloud_.p, ring_off_.p, cr, curv_.p,
-                       flags_.p);
+                       flags_.p, gap_.p);
   }
   const uint32_t flag_bytes = (max_ring_len_ + 15u) & ~15u;
   const uint32_t nmax = (max_ring_len_ / (uint32_t)params.n_regions + 4u + 15u) & ~15u;
-  const size_t lds = (size_t)flag_bytes + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) + 16;
+  const size_t lds = 2 * (size_t)flag_bytes + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) + 16;
   LX_REQUIRE(lds <= 160 * 1024, "scan ring too long for the LDS staging of k_feat_ring");
   const uint32_t caps[3] = {(uint32_t)(params.max_sharp * params.n_regions), (uint32_t)(params.max_less_sharp * params.n_regions),
                             (uint32_t)(params.max_flat * params.n_regions)};
   if (lds > 64 * 1024)
     LX_HIP(hipFuncSetAttribute((const void*)k_feat_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_feat_ring, dim3(nring_), dim3(64 * FEAT_WAVES), lds, st_, cloud_.p, ring_off_.p, ring_sweep_base_.p, params, curv_.p,
-                     flags_.p, flag_bytes, nmax, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p,
+                     flags_.p, gap_.p, flag_bytes, nmax, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p,
                      lf_valid_.p);
   uint32_t* pre[3] = {slot_cnt_[0].p + nring_ + 1, slot_cnt_[1].p + nring_ + 1, slot_cnt_[2].p + nring_ + 1};
   hipLaunchKernelGGL(k_feat_prefix, dim3(3), dim3(1024), 0, st_, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p, nring_, pre[0], pre[1],

@@ -18,10 +18,8 @@ namespace loamx {
 constexpr int OD_THREADS = 512;
 constexpr int OD_WAVES = OD_THREADS / 64;
 
-__device__ inline void sincos_f(float a, float& s, float& c) {
-  s = (float)sin((double)a);
-  c = (float)cos((double)a);
-}
+// per-point de-skew angles (|a| << 1): float sincos (<= 2 ulp); the once-per-iteration pose trig stays in double
+__device__ inline void sincos_f(float a, float& s, float& c) { sincosf(a, &s, &c); }
 
 // transformToStart (:40-53)
 __device__ inline void transform_to_start(const float* T, float scan_period, const float4 pi, float& x, float& y, float& z) {
@@ -267,6 +265,8 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
   __shared__ double red[OD_WAVES][LX_NSUM];
   __shared__ int sh_done;
   __shared__ float ws[216];
+  __shared__ double sums[LX_NSUM];
+  __shared__ float AtA[36], AtB[6], X[6], X2[6];
   if (tid < 6) T[tid] = pb.transform[tid];
   if (tid == 0) sh_done = 0;
   __syncthreads();
@@ -365,7 +365,6 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
     }
     __syncthreads();
     if (tid == 0) {
-      double sums[LX_NSUM];
       for (int t = 0; t < LX_NSUM; t++) {
         double x = 0.0;
         for (int w = 0; w < OD_WAVES; w++) x += red[w][t];
@@ -375,7 +374,6 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
       pb.stats.iterations = iter + 1;
       pb.stats.sel = sel;
       if (sel >= 10) {   // :485-488
-        float AtA[36], AtB[6], X[6];
         int k = 0;
         for (int i = 0; i < 6; i++)
           for (int j = i; j < 6; j++) { AtA[i * 6 + j] = AtA[j * 6 + i] = (float)sums[k]; k++; }
@@ -383,7 +381,6 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
         qr_solve6(AtA, AtB, X);
         if (iter == 0) pb.stats.degenerate = degeneracy_projector(AtA, 10.f, pb.matP, ws) ? 1 : 0;
         if (pb.stats.degenerate) {
-          float X2[6];
           for (int r = 0; r < 6; r++) X2[r] = X[r];
           for (int r = 0; r < 6; r++) {
             float acc = 0.f;

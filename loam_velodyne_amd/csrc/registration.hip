@@ -392,19 +392,31 @@ __global__ __launch_bounds__(LX_RES_THREADS) void k_residual(
   }
 }
 
-// one wave per sweep: fixed-order reduction of the block partials, then lane 0 solves and updates the pose
-__global__ __launch_bounds__(64) void k_solve(const uint32_t* __restrict__ ds_off, Pose* __restrict__ poses, SweepStats* __restrict__ stats,
-                                              float* __restrict__ matP, const double* __restrict__ partials, uint32_t nblk, int iter,
-                                              float delta_t_abort, float delta_r_abort) {
+// one workgroup per sweep: fixed-order (deterministic) reduction of the block partials — 9 groups of 28 threads each
+// walk every 9th block, then the 9 group sums are added in order — then thread 0 solves and updates the pose
+constexpr int LX_SOLVE_GROUPS = 9;
+__global__ __launch_bounds__(256) void k_solve(const uint32_t* __restrict__ ds_off, Pose* __restrict__ poses, SweepStats* __restrict__ stats,
+                                               float* __restrict__ matP, const double* __restrict__ partials, uint32_t nblk, int iter,
+                                               float delta_t_abort, float delta_r_abort) {
   const uint32_t s = blockIdx.x;
   if (stats[s].done) return;
   const uint32_t nq = ds_off[2 * s + 2] - ds_off[2 * s];
   const uint32_t nact = (nq + LX_RES_THREADS - 1) / LX_RES_THREADS;
+  __shared__ double gsum[LX_SOLVE_GROUPS][LX_NSUM];
   __shared__ double sums[LX_NSUM];
   __shared__ float ws[216];
+  __shared__ float AtA[36], AtB[6], X[6], X2[6];
+  if (threadIdx.x < LX_SOLVE_GROUPS * LX_NSUM) {
+    const uint32_t g = threadIdx.x / LX_NSUM, t = threadIdx.x % LX_NSUM;
+    double x = 0.0;
+    for (uint32_t b = g; b < nact; b += LX_SOLVE_GROUPS) x += partials[((size_t)s * nblk + b) * LX_NSUM + t];
+    gsum[g][t] = x;
+  }
+  __syncthreads();
   if (threadIdx.x < LX_NSUM) {
     double x = 0.0;
-    for (uint32_t b = 0; b < nact; b++) x += partials[((size_t)s * nblk + b) * LX_NSUM + threadIdx.x];
+#pragma unroll
+    for (int g = 0; g < LX_SOLVE_GROUPS; g++) x += gsum[g][threadIdx.x];
     sums[threadIdx.x] = x;
   }
   __syncthreads();
@@ -418,7 +430,6 @@ __global__ __launch_bounds__(64) void k_solve(const uint32_t* __restrict__ ds_of
     stats[s] = st;
     return;
   }
-  float AtA[36], AtB[6], X[6];
   int k = 0;
   for (int i = 0; i < 6; i++)
     for (int j = i; j < 6; j++) {
@@ -430,7 +441,6 @@ __global__ __launch_bounds__(64) void k_solve(const uint32_t* __restrict__ ds_of
   float* P = matP + 36 * s;
   if (iter == 0) st.degenerate = degeneracy_projector(AtA, 100.f, P, ws) ? 1 : 0;
   if (st.degenerate) {
-    float X2[6];
     for (int r = 0; r < 6; r++) X2[r] = X[r];
     for (int r = 0; r < 6; r++) {
       float acc = 0.f;
@@ -638,7 +648,7 @@ void Registrar::run_async() {
         LX_HIP(hipEventRecord(ev_[3 + 2 * n_res_launch_], st_));
         n_res_launch_++;
       }
-      hipLaunchKernelGGL(k_solve, dim3(ns), dim3(64), 0, st_, ds_off_.p, poses_.p, stats_.p, matP_.p, partials_.p, nblk_, it,
+      hipLaunchKernelGGL(k_solve, dim3(ns), dim3(256), 0, st_, ds_off_.p, poses_.p, stats_.p, matP_.p, partials_.p, nblk_, it,
                          params.delta_t_abort, params.delta_r_abort);
     }
   }

@@ -50,7 +50,7 @@ int loamx_odom_process(loamx_odom* h, const loamx_cloud* sharp, const loamx_clou
                        const loamx_cloud* less_flat) {
   return guard([&]() {
     LX_REQUIRE(h && sharp && less_sharp && flat && less_flat, "NULL argument");
-    return h->od.process_host(0, sharp, less_sharp, flat, less_flat);
+    return h->od.process_host(sharp, less_sharp, flat, less_flat);
   });
 }
 int loamx_odom_get_transform(loamx_odom* h, float t[6]) {

@@ -22,8 +22,10 @@ struct OdomProblem {
   const float4* flat; uint32_t n_flat;
   const float4* last_corner; uint32_t n_last_corner;     // ring-ordered clouds (scan windows walk these)
   const float4* last_surf; uint32_t n_last_surf;
-  const float4* lc_sorted; const uint32_t* lc_cell; const GridDesc* lc_desc;   // grid index over last_corner
-  const float4* ls_sorted; const uint32_t* ls_cell; const GridDesc* ls_desc;   // grid index over last_surf
+  const float4* sorted;            // concatenated cell-sorted points of the batch index
+  const uint32_t* cell_table;      // concatenated cell tables
+  const GridDescB* lc_desc;        // grid over last_corner
+  const GridDescB* ls_desc;        // grid over last_surf
   int* ind;            // 5 ints per feature: corner (ind1, ind2, -, -, -) / surf (ind1, ind2, ind3, -, -)
   float transform[6];  // in: initial _transform, out: optimised
   OdomStats stats;
@@ -31,12 +33,23 @@ struct OdomProblem {
   float matP[36];
 };
 
-// device pointers to one sweep's four feature clouds
+// one sweep's four feature clouds on the device.  less_sharp / less_flat of ALL streams must be contiguous in stream
+// order (that is how the feature extractor emits them): stream s's cloud starts where stream s-1's ends.
 struct OdomInput {
   const float4* sharp; uint32_t n_sharp;
   const float4* less_sharp; uint32_t n_less_sharp;
   const float4* flat; uint32_t n_flat;
   const float4* less_flat; uint32_t n_less_flat;
+};
+
+struct ToEndParams {
+  float T[6];
+  float sT[3], cT[3];                   // sin/cos of the transform angles (x, y, z)
+  float shift[3];                       // imuShiftFromStart
+  float s_start[3], c_start[3];         // imu pitch/yaw/roll start (x=pitch, y=yaw, z=roll)
+  float s_end[3], c_end[3];
+  float scan_period;
+  int enabled;
 };
 
 struct OdomStream {
@@ -46,10 +59,7 @@ struct OdomStream {
   HAngle imu_roll_start, imu_pitch_start, imu_yaw_start, imu_roll_end, imu_pitch_end, imu_yaw_end;
   HVec3 imu_shift, imu_velo;
   OdomStats stats = {0, 0, 0, 0};
-  DevBuf<float4> cur_corner, cur_surf, last_corner, last_surf;   // less-sharp / less-flat of the current and previous sweep
   uint32_t n_last_corner = 0, n_last_surf = 0;
-  SubMapIndex idx_corner, idx_surf;
-  DevBuf<int> ind;
 };
 
 class OdometryBatch {
@@ -61,27 +71,38 @@ class OdometryBatch {
   OdomStream& stream_state(uint32_t s) { return *streams_[s]; }
   hipStream_t stream() const { return st_; }
   void update_imu(uint32_t s, const float* t12);
-  // one sweep per stream, inputs already on the device (same HIP stream or synchronised).  Synchronous.
+  // one sweep for EVERY stream, inputs already on the device (same HIP stream or synchronised).  Synchronous.
   // rc[s] = LOAMX_SKIPPED for a stream's first (initialising) sweep.
   void process(const OdomInput* in, int* rc);
-  // host-cloud convenience for stream s only (other streams untouched)
-  int process_host(uint32_t s, const loamx_cloud* sharp, const loamx_cloud* less_sharp, const loamx_cloud* flat,
-                   const loamx_cloud* less_flat);
+  // host-cloud convenience (single-stream handles)
+  int process_host(const loamx_cloud* sharp, const loamx_cloud* less_sharp, const loamx_cloud* flat, const loamx_cloud* less_flat);
   int get_last_clouds(uint32_t s, loamx_cloud* corner, loamx_cloud* surf);
   int transform_to_end_host(uint32_t s, loamx_cloud* cloud);
   // in place on device points with stream s's current transform (async on the stream)
   void to_end_device(uint32_t s, float4* pts, uint32_t n);
+  // device views of the re-projected clouds handed on to mapping
+  const float4* d_last_corner(uint32_t s) const { return last_.p + h_last_off_[s]; }
+  const float4* d_last_surf(uint32_t s) const { return last_.p + h_last_off_[n_streams() + s]; }
 
  private:
   int device_;
   hipStream_t st_ = nullptr;
   bool own_stream_ = false;
   std::vector<OdomStream*> streams_;
+  // clouds of all streams, concatenated: [corner_0 .. corner_{ns-1} | surf_0 .. surf_{ns-1}], offsets 2*ns+1
+  DevBuf<float4> cur_, last_;
+  std::vector<uint32_t> h_cur_off_, h_last_off_;
+  DevBuf<uint32_t> d_cur_off_;
+  SubMapIndexBatch index_;
+  DevBuf<int> ind_;
   DevBuf<OdomProblem> prob_;
   PinBuf<OdomProblem> h_prob_;
+  DevBuf<ToEndParams> te_;
+  PinBuf<ToEndParams> h_te_;
+  PinBuf<uint32_t> h_off_pin_;
   PinBuf<float4> h_stage_;
   DevBuf<float4> up_[4], tmp_cloud_;
-  void process_subset(const std::vector<uint32_t>& which, const OdomInput* in, int* rc);
+  ToEndParams to_end_params(uint32_t s, bool enabled) const;
 };
 
 }  // namespace loamx

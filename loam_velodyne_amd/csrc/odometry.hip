@@ -41,66 +41,6 @@ __device__ inline float sqd(const float4& a, float x, float y, float z) {
   return dx * dx + dy * dy + dz * dz;
 }
 
-// exact nearest neighbour with squared distance < 25 (:253-256); returns the ORIGINAL index or -1.
-// Expanding shells of grid cells around the query's cell; a row of cells is skipped when its (y,z) slab is already
-// farther than the best distance found, and the x-run of a row is clipped to the cells the best-distance ball can
-// reach (bounds shrunk by a relative 1e-4 so float rounding can only make the search visit MORE cells, never fewer).
-__device__ inline int nn1(const GridDesc& g, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, float qx,
-                          float qy, float qz) {
-  float best = 25.0f;   // only candidates with d2 < 25 are admissible
-  uint32_t best_id = 0xffffffffu;
-  const float h = 1.0f / g.inv_h;
-  const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
-  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
-  for (int L = 0;; L++) {
-    for (int dz = -L; dz <= L; dz++) {
-      const int z = cz + dz;
-      if (z < 0 || z >= g.nz) continue;
-      // distance from the query to the slab of cells z (0 inside)
-      const float gz = dz == 0 ? 0.f : (dz > 0 ? ((float)z - fz) : (fz - (float)(z + 1))) * h;
-      for (int dy = -L; dy <= L; dy++) {
-        const int y = cy + dy;
-        if (y < 0 || y >= g.ny) continue;
-        const float gy = dy == 0 ? 0.f : (dy > 0 ? ((float)y - fy) : (fy - (float)(y + 1))) * h;
-        const float gyz = (gy * gy + gz * gz) * 0.9999f;
-        if (gyz >= best) continue;
-        const bool face = (dz == -L || dz == L || dy == -L || dy == L);
-        // reach of the current best ball along x, in cells
-        const float rx = sqrtf(best - gyz) * g.inv_h * 1.0001f + 1e-3f;
-        const int xlo = (int)floorf(fx - rx), xhi = (int)floorf(fx + rx);
-        const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
-        for (int part = 0; part < 2; part++) {
-          int xa, xb;
-          if (face) {
-            if (part) break;
-            xa = cx - L; xb = cx + L;
-          } else {
-            xa = xb = part ? cx + L : cx - L;
-            if (L == 0 && part) break;
-          }
-          if (xa < xlo) xa = xlo;
-          if (xb > xhi) xb = xhi;
-          if (xa < 0) xa = 0;
-          if (xb > g.nx - 1) xb = g.nx - 1;
-          if (xa > xb) continue;
-          const uint32_t beg = cell_start[row + xa], end = cell_start[row + xb + 1];
-          for (uint32_t k = beg; k < end; k++) {
-            const float4 p = sorted[k];
-            const float dx = qx - p.x, dy2 = qy - p.y, dz2 = qz - p.z;
-            const float d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
-            const uint32_t id = __float_as_uint(p.w);
-            if (d2 < best || (d2 == best && best_id != 0xffffffffu && id < best_id)) { best = d2; best_id = id; }
-          }
-        }
-      }
-    }
-    const float cover = (float)L * h;   // every point within `cover` of the query has been visited
-    if (best <= cover * cover) break;
-    if (cover * cover >= 25.0f) break;
-  }
-  return best_id != 0xffffffffu ? (int)best_id : -1;
-}
-
 // wave-level arg-min of (d, order); every lane gets the winner
 __device__ inline void wave_argmin(float& d, int& j, int& order) {
 #pragma unroll
@@ -192,8 +132,8 @@ __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ pro
   const float4 pi = corner ? pb.sharp[f] : pb.flat[f - nSharp];
   float x, y, z;
   transform_to_start(T, P.scan_period, pi, x, y, z);
-  const int closest = corner ? nn1_wave(*pb.lc_desc, pb.lc_sorted, pb.lc_cell, x, y, z, lane)
-                             : nn1_wave(*pb.ls_desc, pb.ls_sorted, pb.ls_cell, x, y, z, lane);
+  const GridDescB gd = corner ? *pb.lc_desc : *pb.ls_desc;
+  const int closest = nn1_wave(gd.g, pb.sorted, pb.cell_table + gd.cell_base, x, y, z, lane);
   if (closest < 0) {   // wave-uniform
     if (lane == 0) { pb.ind[5 * f] = -1; pb.ind[5 * f + 1] = -1; pb.ind[5 * f + 2] = -1; }
     return;
@@ -407,20 +347,8 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
   if (tid == 0 && sh_done) pb.done = 1;
 }
 
-struct ToEndParams {
-  float T[6];
-  float sT[3], cT[3];                   // sin/cos of the transform angles (x, y, z)
-  float shift[3];                       // imuShiftFromStart
-  float s_start[3], c_start[3];         // imu pitch/yaw/roll start (x=pitch, y=yaw, z=roll)
-  float s_end[3], c_end[3];
-  float scan_period;
-};
-
-// transformToEnd (:57-87)
-__global__ __launch_bounds__(256) void k_transform_to_end(float4* __restrict__ pts, uint32_t n, ToEndParams P) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 p = pts[i];
+// transformToEnd (:57-87) of one point
+__device__ inline float4 to_end_point(float4 p, const ToEndParams& P) {
   const float s = (1.f / P.scan_period) * (p.w - (float)(int)p.w);
   float x = p.x - s * P.T[3], y = p.y - s * P.T[4], z = p.z - s * P.T[5];
   float sx, cx, sy, cy, sz, cz;
@@ -434,7 +362,26 @@ __global__ __launch_bounds__(256) void k_transform_to_end(float4* __restrict__ p
   z += P.T[5] - P.shift[2];
   rot_z(x, y, P.c_start[2], P.s_start[2]); rot_x(y, z, P.c_start[0], P.s_start[0]); rot_y(x, z, P.c_start[1], P.s_start[1]);
   rot_y(x, z, P.c_end[1], -P.s_end[1]); rot_x(y, z, P.c_end[0], -P.s_end[0]); rot_z(x, y, P.c_end[2], -P.s_end[2]);
-  pts[i] = make_float4(x, y, z, (float)(int)p.w);
+  return make_float4(x, y, z, (float)(int)p.w);
+}
+__global__ __launch_bounds__(256) void k_transform_to_end(float4* __restrict__ pts, uint32_t n, ToEndParams P) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  pts[i] = to_end_point(pts[i], P);
+}
+// all clouds of a batch: cloud k belongs to stream k % ns
+__global__ __launch_bounds__(256) void k_transform_to_end_batch(float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off,
+                                                                uint32_t K, uint32_t ns, const ToEndParams* __restrict__ params) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t lo = 0, hi = K;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= i) lo = mid; else hi = mid;
+  }
+  const ToEndParams P = params[lo % ns];
+  if (!P.enabled) return;
+  pts[i] = to_end_point(pts[i], P);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -447,13 +394,16 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
     LX_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
     own_stream_ = true;
   }
-  for (uint32_t s = 0; s < n_streams; s++) {
-    streams_.push_back(new OdomStream());
-    streams_.back()->idx_corner.init(st_);
-    streams_.back()->idx_surf.init(st_);
-  }
+  for (uint32_t s = 0; s < n_streams; s++) streams_.push_back(new OdomStream());
+  index_.init(st_);
   prob_.reserve(n_streams);
   h_prob_.reserve(n_streams);
+  te_.reserve(n_streams);
+  h_te_.reserve(n_streams);
+  d_cur_off_.reserve(2 * n_streams + 2);
+  h_off_pin_.reserve(2 * n_streams + 2);
+  h_cur_off_.assign(2 * n_streams + 1, 0);
+  h_last_off_.assign(2 * n_streams + 1, 0);
 }
 
 OdometryBatch::~OdometryBatch() {
@@ -469,9 +419,8 @@ void OdometryBatch::update_imu(uint32_t s, const float* t) {
   S.imu_velo = {t[9], t[10], t[11]};
 }
 
-void OdometryBatch::to_end_device(uint32_t s, float4* pts, uint32_t n) {
-  if (!n) return;
-  OdomStream& S = *streams_[s];
+ToEndParams OdometryBatch::to_end_params(uint32_t s, bool enabled) const {
+  const OdomStream& S = *streams_[s];
   ToEndParams P;
   S.transform.get(P.T);
   const HAngle* ta[3] = {&S.transform.rot_x, &S.transform.rot_y, &S.transform.rot_z};
@@ -484,63 +433,84 @@ void OdometryBatch::to_end_device(uint32_t s, float4* pts, uint32_t n) {
   }
   P.shift[0] = S.imu_shift.x; P.shift[1] = S.imu_shift.y; P.shift[2] = S.imu_shift.z;
   P.scan_period = params.scan_period;
-  hipLaunchKernelGGL(k_transform_to_end, dim3((n + 255) / 256), dim3(256), 0, st_, pts, n, P);
+  P.enabled = enabled ? 1 : 0;
+  return P;
+}
+
+void OdometryBatch::to_end_device(uint32_t s, float4* pts, uint32_t n) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_transform_to_end, dim3((n + 255) / 256), dim3(256), 0, st_, pts, n, to_end_params(s, true));
 }
 
 void OdometryBatch::process(const OdomInput* in, int* rc) {
-  std::vector<uint32_t> all(streams_.size());
-  for (uint32_t s = 0; s < all.size(); s++) all[s] = s;
-  process_subset(all, in, rc);
-}
-
-// `in` and `rc` are indexed by position in `which`
-void OdometryBatch::process_subset(const std::vector<uint32_t>& which, const OdomInput* in, int* rc) {
   LX_HIP(hipSetDevice(device_));
-  const uint32_t nw = (uint32_t)which.size();
-  std::vector<uint32_t> active;   // positions whose stream runs the optimisation
-  uint32_t max_feat = 0;
-  for (uint32_t k = 0; k < nw; k++) {
-    OdomStream& S = *streams_[which[k]];
-    const OdomInput& I = in[k];
-    // the current less-sharp / less-flat clouds are re-projected in place later, so they are copied
-    S.cur_corner.reserve(I.n_less_sharp + 1);
-    S.cur_surf.reserve(I.n_less_flat + 1);
-    if (I.n_less_sharp) LX_HIP(hipMemcpyAsync(S.cur_corner.p, I.less_sharp, sizeof(float4) * I.n_less_sharp, hipMemcpyDeviceToDevice, st_));
-    if (I.n_less_flat) LX_HIP(hipMemcpyAsync(S.cur_surf.p, I.less_flat, sizeof(float4) * I.n_less_flat, hipMemcpyDeviceToDevice, st_));
-    if (!S.inited) {   // :198-211
-      std::swap(S.cur_corner.p, S.last_corner.p); std::swap(S.cur_corner.cap, S.last_corner.cap);
-      std::swap(S.cur_surf.p, S.last_surf.p); std::swap(S.cur_surf.cap, S.last_surf.cap);
-      S.n_last_corner = I.n_less_sharp;
-      S.n_last_surf = I.n_less_flat;
-      S.idx_corner.build(S.last_corner.p, S.n_last_corner);
-      S.idx_surf.build(S.last_surf.p, S.n_last_surf);
+  const uint32_t ns = n_streams(), K = 2 * ns;
+  // ---- stage the current less-sharp / less-flat clouds of all streams (they are re-projected in place later)
+  for (uint32_t s = 0; s < ns; s++) {
+    h_cur_off_[s + 1] = h_cur_off_[s] + in[s].n_less_sharp;
+    if (s > 0) LX_REQUIRE(in[s].less_sharp == in[s - 1].less_sharp + in[s - 1].n_less_sharp || in[s].n_less_sharp == 0 || in[s - 1].n_less_sharp == 0,
+                          "less_sharp clouds of the streams must be contiguous");
+  }
+  for (uint32_t s = 0; s < ns; s++) h_cur_off_[ns + s + 1] = h_cur_off_[ns + s] + in[s].n_less_flat;
+  const uint32_t n_corner_all = h_cur_off_[ns], n_all = h_cur_off_[K];
+  cur_.reserve((size_t)n_all + 1);
+  // per-type bulk copies when the inputs are contiguous, else per stream
+  bool contig_c = true, contig_s = true;
+  for (uint32_t s = 1; s < ns; s++) {
+    contig_c = contig_c && in[s].less_sharp == in[s - 1].less_sharp + in[s - 1].n_less_sharp;
+    contig_s = contig_s && in[s].less_flat == in[s - 1].less_flat + in[s - 1].n_less_flat;
+  }
+  if (contig_c) {
+    if (n_corner_all) LX_HIP(hipMemcpyAsync(cur_.p, in[0].less_sharp, sizeof(float4) * n_corner_all, hipMemcpyDeviceToDevice, st_));
+  } else {
+    for (uint32_t s = 0; s < ns; s++)
+      if (in[s].n_less_sharp) LX_HIP(hipMemcpyAsync(cur_.p + h_cur_off_[s], in[s].less_sharp, sizeof(float4) * in[s].n_less_sharp, hipMemcpyDeviceToDevice, st_));
+  }
+  if (contig_s) {
+    if (n_all > n_corner_all) LX_HIP(hipMemcpyAsync(cur_.p + n_corner_all, in[0].less_flat, sizeof(float4) * (n_all - n_corner_all), hipMemcpyDeviceToDevice, st_));
+  } else {
+    for (uint32_t s = 0; s < ns; s++)
+      if (in[s].n_less_flat) LX_HIP(hipMemcpyAsync(cur_.p + h_cur_off_[ns + s], in[s].less_flat, sizeof(float4) * in[s].n_less_flat, hipMemcpyDeviceToDevice, st_));
+  }
+
+  // ---- problems of the streams that optimise this sweep
+  std::vector<uint32_t> active;
+  uint32_t max_feat = 0, ind_total = 0;
+  std::vector<uint32_t> ind_off(ns + 1, 0);
+  for (uint32_t s = 0; s < ns; s++) ind_off[s + 1] = ind_off[s] + 5 * (in[s].n_sharp + in[s].n_flat) + 5;
+  ind_total = ind_off[ns];
+  ind_.reserve(ind_total + 8);
+  for (uint32_t s = 0; s < ns; s++) {
+    OdomStream& S = *streams_[s];
+    const OdomInput& I = in[s];
+    if (!S.inited) {   // :198-211: only stash the clouds and seed transformSum with the IMU start angles
       S.transform_sum.rot_x = HAngle(S.transform_sum.rot_x.r + S.imu_pitch_start.r);
       S.transform_sum.rot_z = HAngle(S.transform_sum.rot_z.r + S.imu_roll_start.r);
-      S.inited = true;
-      rc[k] = LOAMX_SKIPPED;
+      rc[s] = LOAMX_SKIPPED;
       continue;
     }
-    rc[k] = LOAMX_OK;
+    rc[s] = LOAMX_OK;
     S.frame++;
     S.transform.pos.x -= S.imu_velo.x * params.scan_period;
     S.transform.pos.y -= S.imu_velo.y * params.scan_period;
     S.transform.pos.z -= S.imu_velo.z * params.scan_period;
     S.stats = {0, 0, (int)S.frame, 0};
     if (S.n_last_corner > 10 && S.n_last_surf > 100) {
-      S.ind.reserve((size_t)5 * (I.n_sharp + I.n_flat) + 5);
       OdomProblem& pb = h_prob_.p[active.size()];
       pb.sharp = I.sharp; pb.n_sharp = I.n_sharp;
       pb.flat = I.flat; pb.n_flat = I.n_flat;
-      pb.last_corner = S.last_corner.p; pb.n_last_corner = S.n_last_corner;
-      pb.last_surf = S.last_surf.p; pb.n_last_surf = S.n_last_surf;
-      pb.lc_sorted = S.idx_corner.sorted(); pb.lc_cell = S.idx_corner.cell_start(); pb.lc_desc = S.idx_corner.desc();
-      pb.ls_sorted = S.idx_surf.sorted(); pb.ls_cell = S.idx_surf.cell_start(); pb.ls_desc = S.idx_surf.desc();
-      pb.ind = S.ind.p;
+      pb.last_corner = last_.p + h_last_off_[s]; pb.n_last_corner = S.n_last_corner;
+      pb.last_surf = last_.p + h_last_off_[ns + s]; pb.n_last_surf = S.n_last_surf;
+      pb.sorted = index_.sorted();
+      pb.cell_table = index_.cell_table();
+      pb.lc_desc = index_.desc(s);
+      pb.ls_desc = index_.desc(ns + s);
+      pb.ind = ind_.p + ind_off[s];
       S.transform.get(pb.transform);
       pb.stats = {0, 0, 0, 0};
       pb.done = 0;
       max_feat = std::max(max_feat, I.n_sharp + I.n_flat);
-      active.push_back(k);
+      active.push_back(s);
     }
   }
   const uint32_t na = (uint32_t)active.size();
@@ -556,7 +526,7 @@ void OdometryBatch::process_subset(const std::vector<uint32_t>& which, const Odo
     LX_HIP(hipMemcpyAsync(h_prob_.p, prob_.p, sizeof(OdomProblem) * na, hipMemcpyDeviceToHost, st_));
     LX_HIP(hipStreamSynchronize(st_));
     for (uint32_t a = 0; a < na; a++) {
-      OdomStream& S = *streams_[which[active[a]]];
+      OdomStream& S = *streams_[active[a]];
       // _transform.rot_* = rad + x re-derives the cached sin/cos (:599-601)
       S.transform.set(h_prob_.p[a].transform);
       S.stats.iterations = h_prob_.p[a].stats.iterations;
@@ -564,38 +534,42 @@ void OdometryBatch::process_subset(const std::vector<uint32_t>& which, const Odo
       S.stats.degenerate = h_prob_.p[a].stats.degenerate;
     }
   }
-  for (uint32_t k = 0; k < nw; k++) {
-    if (rc[k] != LOAMX_OK) continue;
-    OdomStream& S = *streams_[which[k]];
-    const OdomInput& I = in[k];
-    // pose integration (:626-649)
-    HAngle rx, ry, rz;
-    accumulate_rotation(S.transform_sum.rot_x, S.transform_sum.rot_y, S.transform_sum.rot_z, -S.transform.rot_x,
-                        HAngle((float)(-S.transform.rot_y.r * 1.05)), -S.transform.rot_z, rx, ry, rz);
-    HVec3 v{S.transform.pos.x - S.imu_shift.x, S.transform.pos.y - S.imu_shift.y, (float)(S.transform.pos.z * 1.05 - S.imu_shift.z)};
-    h_rot_zxy(v, rz, rx, ry);
-    HVec3 trans{S.transform_sum.pos.x - v.x, S.transform_sum.pos.y - v.y, S.transform_sum.pos.z - v.z};
-    plugin_imu_rotation(rx, ry, rz, S.imu_pitch_start, S.imu_yaw_start, S.imu_roll_start, S.imu_pitch_end, S.imu_yaw_end, S.imu_roll_end,
-                        rx, ry, rz);
-    S.transform_sum.rot_x = rx; S.transform_sum.rot_y = ry; S.transform_sum.rot_z = rz;
-    S.transform_sum.pos = trans;
-    // re-project to the sweep end and hand over as "last" clouds (:651-664)
-    to_end_device(which[k], S.cur_corner.p, I.n_less_sharp);
-    to_end_device(which[k], S.cur_surf.p, I.n_less_flat);
-    std::swap(S.cur_corner.p, S.last_corner.p); std::swap(S.cur_corner.cap, S.last_corner.cap);
-    std::swap(S.cur_surf.p, S.last_surf.p); std::swap(S.cur_surf.cap, S.last_surf.cap);
-    S.n_last_corner = I.n_less_sharp;
-    S.n_last_surf = I.n_less_flat;
-    if (S.n_last_corner > 10 && S.n_last_surf > 100) {
-      S.idx_corner.build(S.last_corner.p, S.n_last_corner);
-      S.idx_surf.build(S.last_surf.p, S.n_last_surf);
+  // ---- pose integration (:626-649) and the re-projection parameters of every stream
+  for (uint32_t s = 0; s < ns; s++) {
+    OdomStream& S = *streams_[s];
+    if (rc[s] == LOAMX_OK) {
+      HAngle rx, ry, rz;
+      accumulate_rotation(S.transform_sum.rot_x, S.transform_sum.rot_y, S.transform_sum.rot_z, -S.transform.rot_x,
+                          HAngle((float)(-S.transform.rot_y.r * 1.05)), -S.transform.rot_z, rx, ry, rz);
+      HVec3 v{S.transform.pos.x - S.imu_shift.x, S.transform.pos.y - S.imu_shift.y, (float)(S.transform.pos.z * 1.05 - S.imu_shift.z)};
+      h_rot_zxy(v, rz, rx, ry);
+      HVec3 trans{S.transform_sum.pos.x - v.x, S.transform_sum.pos.y - v.y, S.transform_sum.pos.z - v.z};
+      plugin_imu_rotation(rx, ry, rz, S.imu_pitch_start, S.imu_yaw_start, S.imu_roll_start, S.imu_pitch_end, S.imu_yaw_end,
+                          S.imu_roll_end, rx, ry, rz);
+      S.transform_sum.rot_x = rx; S.transform_sum.rot_y = ry; S.transform_sum.rot_z = rz;
+      S.transform_sum.pos = trans;
     }
+    h_te_.p[s] = to_end_params(s, rc[s] == LOAMX_OK);   // a first sweep is stored as it came (:200-201)
+    S.inited = true;
+    S.n_last_corner = in[s].n_less_sharp;
+    S.n_last_surf = in[s].n_less_flat;
   }
+  // ---- re-project to the sweep end (:651-652), hand over as "last" clouds and rebuild their index (:654-664)
+  memcpy(h_off_pin_.p, h_cur_off_.data(), sizeof(uint32_t) * (K + 1));
+  LX_HIP(hipMemcpyAsync(d_cur_off_.p, h_off_pin_.p, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st_));
+  LX_HIP(hipMemcpyAsync(te_.p, h_te_.p, sizeof(ToEndParams) * ns, hipMemcpyHostToDevice, st_));
+  if (n_all)
+    hipLaunchKernelGGL(k_transform_to_end_batch, dim3((n_all + 255) / 256), dim3(256), 0, st_, cur_.p, n_all, d_cur_off_.p, K, ns, te_.p);
+  std::swap(cur_.p, last_.p);
+  std::swap(cur_.cap, last_.cap);
+  h_last_off_ = h_cur_off_;
+  index_.build(last_.p, h_last_off_.data(), K);
   LX_HIP(hipStreamSynchronize(st_));
 }
 
-int OdometryBatch::process_host(uint32_t s, const loamx_cloud* sharp, const loamx_cloud* less_sharp, const loamx_cloud* flat,
+int OdometryBatch::process_host(const loamx_cloud* sharp, const loamx_cloud* less_sharp, const loamx_cloud* flat,
                                 const loamx_cloud* less_flat) {
+  LX_REQUIRE(n_streams() == 1, "process_host is the single-stream entry point");
   LX_HIP(hipSetDevice(device_));
   const loamx_cloud* cl[4] = {sharp, less_sharp, flat, less_flat};
   for (int k = 0; k < 4; k++) {
@@ -608,7 +582,7 @@ int OdometryBatch::process_host(uint32_t s, const loamx_cloud* sharp, const loam
   }
   OdomInput in{up_[0].p, sharp->count, up_[1].p, less_sharp->count, up_[2].p, flat->count, up_[3].p, less_flat->count};
   int rc = LOAMX_OK;
-  process_subset({s}, &in, &rc);
+  process(&in, &rc);
   return rc;
 }
 
@@ -620,14 +594,14 @@ int OdometryBatch::get_last_clouds(uint32_t s, loamx_cloud* corner, loamx_cloud*
   if (corner) {
     check_cloud(corner, false);
     tmp.resize(S.n_last_corner);
-    if (S.n_last_corner) LX_HIP(hipMemcpy(tmp.data(), S.last_corner.p, sizeof(float4) * S.n_last_corner, hipMemcpyDeviceToHost));
+    if (S.n_last_corner) LX_HIP(hipMemcpy(tmp.data(), d_last_corner(s), sizeof(float4) * S.n_last_corner, hipMemcpyDeviceToHost));
     int r = unpack_cloud(tmp.data(), S.n_last_corner, corner);
     if (r != LOAMX_OK) rc = r;
   }
   if (surf) {
     check_cloud(surf, false);
     tmp.resize(S.n_last_surf);
-    if (S.n_last_surf) LX_HIP(hipMemcpy(tmp.data(), S.last_surf.p, sizeof(float4) * S.n_last_surf, hipMemcpyDeviceToHost));
+    if (S.n_last_surf) LX_HIP(hipMemcpy(tmp.data(), d_last_surf(s), sizeof(float4) * S.n_last_surf, hipMemcpyDeviceToHost));
     int r = unpack_cloud(tmp.data(), S.n_last_surf, surf);
     if (r != LOAMX_OK) rc = r;
   }

@@ -110,8 +110,8 @@ class Pipeline {
       P.tobe.get(g);
       guess.insert(guess.end(), g, g + 6);
       const uint32_t k = (uint32_t)who.size();
-      cl[k] = O.last_corner.p; ncl[k] = O.n_last_corner;
-      sl[k] = O.last_surf.p; nsl[k] = O.n_last_surf;
+      cl[k] = odom.d_last_corner(s); ncl[k] = O.n_last_corner;
+      sl[k] = odom.d_last_surf(s); nsl[k] = O.n_last_surf;
       // the full-resolution cloud is re-projected to the sweep end before it is registered (LaserOdometry.cpp:326)
       const uint32_t np = F.point_base(s + 1) - F.point_base(s);
       full_tmp[s]->reserve(np + 1);

@@ -37,6 +37,32 @@ class SubMapIndex {
   DevBuf<GridDesc> d_desc_;
 };
 
+// The same index over K clouds at once (one set of launches): clouds are concatenated, cloud c = [off[c], off[c+1]).
+// All cell tables live in one array (cloud c's table starts at desc[c].cell_base) and one global scan yields start
+// offsets that index the concatenated sorted array directly; .w of a sorted point = its index inside its own cloud.
+struct GridDescB {
+  GridDesc g;
+  uint32_t cell_base;   // first entry of this cloud's cell table
+  uint32_t pt_base;     // off[c]
+};
+class SubMapIndexBatch {
+ public:
+  void init(hipStream_t st);
+  // d_pts: concatenated points; h_off: K+1 host offsets.  Asynchronous on the stream.
+  void build(const float4* d_pts, const uint32_t* h_off, uint32_t K);
+  const float4* sorted() const { return sorted_.p; }
+  const uint32_t* cell_start(uint32_t c) const { return cell_start_.p; }   // tables are addressed through desc(c)->cell_base
+  const GridDescB* desc(uint32_t c) const { return d_desc_.p + c; }
+  const uint32_t* cell_table() const { return cell_start_.p; }
+
+ private:
+  hipStream_t st_ = nullptr;
+  DevBuf<float4> sorted_;
+  DevBuf<uint32_t> cell_of_, cell_start_, cursor_, tile_sums_, scratch_, d_off_, enc_;
+  DevBuf<GridDescB> d_desc_;
+  PinBuf<uint32_t> h_off_pin_;
+};
+
 struct SweepStats {
   int iterations, sel, corner_q, surf_q, degenerate, done, pad0, pad1;
 };

@@ -167,6 +167,146 @@ void SubMapIndex::build(const float4* d_pts, uint32_t n) {
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// SubMapIndexBatch: the same counting-sort build for K clouds with one set of launches
+// scratch: [0] total cells + 1, [1] scan total, [2] total cells
+// ----------------------------------------------------------------------------------------------------------------
+__global__ void k_bb_init(uint32_t* enc, uint32_t K) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 6 * K) enc[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+}
+// grid = (blocks, K)
+__global__ __launch_bounds__(256) void k_bb_bbox(const float4* __restrict__ pts, const uint32_t* __restrict__ off, uint32_t* __restrict__ enc) {
+  const uint32_t c = blockIdx.y;
+  const uint32_t a0 = off[c], a1 = off[c + 1];
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (uint32_t i = a0 + blockIdx.x * blockDim.x + threadIdx.x; i < a1; i += gridDim.x * blockDim.x) {
+    const float4 p = pts[i];
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], d, 64));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, 64));
+    }
+  }
+  __shared__ float red[4][6];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { red[wid][a] = mn[a]; red[wid][3 + a] = mx[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6 && a1 > a0 + blockIdx.x * blockDim.x) {
+    const int a = threadIdx.x;
+    float v = red[0][a];
+    for (int w = 1; w < 4; w++) v = a < 3 ? fminf(v, red[w][a]) : fmaxf(v, red[w][a]);
+    if (a < 3) atomicMin(&enc[6 * c + a], enc_f32(v)); else atomicMax(&enc[6 * c + a], enc_f32(v));
+  }
+}
+// one thread: grid descriptors, per-cloud cell budget, table bases
+__global__ void k_bb_setup(const uint32_t* __restrict__ enc, const uint32_t* __restrict__ off, uint32_t K, GridDescB* __restrict__ desc,
+                           uint32_t* __restrict__ scratch, uint32_t max_cells_total) {
+  const uint32_t budget = max_cells_total / (K ? K : 1);
+  uint32_t base = 0;
+  for (uint32_t c = 0; c < K; c++) {
+    GridDescB d;
+    d.pt_base = off[c];
+    d.cell_base = base;
+    if (off[c + 1] == off[c]) {   // empty cloud: a 1-cell grid
+      d.g.ox = d.g.oy = d.g.oz = 0.f; d.g.inv_h = 1.f; d.g.nx = d.g.ny = d.g.nz = 1; d.g.ncell = 1;
+    } else {
+      float mn[3], mx[3];
+      for (int a = 0; a < 3; a++) { mn[a] = dec_f32(enc[6 * c + a]); mx[a] = dec_f32(enc[6 * c + 3 + a]); }
+      float h = 1.05f;
+      for (;;) {
+        d.g.inv_h = 1.0f / h;
+        d.g.ox = mn[0]; d.g.oy = mn[1]; d.g.oz = mn[2];
+        d.g.nx = (int)floorf((mx[0] - mn[0]) * d.g.inv_h) + 1;
+        d.g.ny = (int)floorf((mx[1] - mn[1]) * d.g.inv_h) + 1;
+        d.g.nz = (int)floorf((mx[2] - mn[2]) * d.g.inv_h) + 1;
+        const unsigned long long nc = (unsigned long long)d.g.nx * d.g.ny * d.g.nz;
+        if (nc <= budget) { d.g.ncell = (uint32_t)nc; break; }
+        h *= 1.25f;
+      }
+    }
+    desc[c] = d;
+    base += d.g.ncell;
+  }
+  scratch[0] = base + 1;
+  scratch[2] = base;
+}
+__global__ __launch_bounds__(256) void k_bb_count(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off, uint32_t K,
+                                                  const GridDescB* __restrict__ desc, uint32_t* __restrict__ cell_of,
+                                                  uint32_t* __restrict__ counts) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t lo = 0, hi = K;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= i) lo = mid; else hi = mid;
+  }
+  const GridDescB d = desc[lo];
+  const float4 p = pts[i];
+  int cx, cy, cz;
+  cell_coords(d.g, p.x, p.y, p.z, cx, cy, cz);
+  const uint32_t c = d.cell_base + ((uint32_t)cz * d.g.ny + cy) * d.g.nx + cx;
+  cell_of[i] = c;
+  atomicAdd(&counts[c], 1u);
+}
+__global__ __launch_bounds__(256) void k_bb_scatter(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off, uint32_t K,
+                                                    const uint32_t* __restrict__ cell_of, uint32_t* __restrict__ cursor,
+                                                    float4* __restrict__ sorted) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t lo = 0, hi = K;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= i) lo = mid; else hi = mid;
+  }
+  float4 p = pts[i];
+  const uint32_t pos = atomicAdd(&cursor[cell_of[i]], 1u);
+  p.w = __uint_as_float(i - off[lo]);   // index inside its own cloud
+  sorted[pos] = p;
+}
+
+void SubMapIndexBatch::init(hipStream_t st) {
+  st_ = st;
+  scratch_.reserve(16);
+  tile_sums_.reserve(8192);
+}
+
+void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_t K) {
+  LX_REQUIRE(K >= 1 && K <= 4096, "too many clouds in one index batch");
+  const uint32_t n = h_off[K];
+  d_off_.reserve(K + 2);
+  d_desc_.reserve(K + 1);
+  enc_.reserve((size_t)6 * K + 6);
+  h_off_pin_.reserve(K + 2);
+  memcpy(h_off_pin_.p, h_off, sizeof(uint32_t) * (K + 1));
+  LX_HIP(hipMemcpyAsync(d_off_.p, h_off_pin_.p, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st_));
+  sorted_.reserve((size_t)n + 1);
+  cell_of_.reserve((size_t)n + 1);
+  cell_start_.reserve((size_t)LX_MAX_CELLS + 2);
+  cursor_.reserve((size_t)LX_MAX_CELLS + 2);
+  hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K);
+  uint32_t max_len = 0;
+  for (uint32_t c = 0; c < K; c++) max_len = std::max(max_len, h_off[c + 1] - h_off[c]);
+  const uint32_t nbx = std::min<uint32_t>(std::max<uint32_t>((max_len + 255) / 256, 1u), 32u);
+  hipLaunchKernelGGL(k_bb_bbox, dim3(nbx, K), dim3(256), 0, st_, d_pts, d_off_.p, enc_.p);
+  hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1), 0, st_, enc_.p, d_off_.p, K, d_desc_.p, scratch_.p, LX_MAX_CELLS);
+  hipLaunchKernelGGL(k_zero_u32_dn, dim3(2048), dim3(256), 0, st_, cursor_.p, scratch_.p + 0);
+  if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off_.p, K, d_desc_.p, cell_of_.p, cursor_.p);
+  exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 2, scratch_.p + 1, LX_MAX_CELLS, st_);
+  hipLaunchKernelGGL(k_copy_u32_dn, dim3(2048), dim3(256), 0, st_, cell_start_.p, cursor_.p, scratch_.p + 0);
+  if (n) hipLaunchKernelGGL(k_bb_scatter, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off_.p, K, cell_of_.p, cursor_.p, sorted_.p);
+  LX_HIP(hipGetLastError());
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // stack round trip + voxel keys
 // ----------------------------------------------------------------------------------------------------------------
 // seg_minmax: per segment min ix,iy,iz / max ix,iy,iz

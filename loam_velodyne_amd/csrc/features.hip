@@ -111,9 +111,13 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint8_t* flags = (uint8_t*)smem;
   uint8_t* gaps = flags + flag_bytes;
-  char* wave_base = smem + 2 * (size_t)flag_bytes;
+  // picked point indices (global); the points themselves are copied out after the sequential part
+  uint32_t* pickS = (uint32_t*)(smem + 2 * (size_t)flag_bytes);
+  uint32_t* pickLS = pickS + P.max_sharp * P.n_regions;
+  uint32_t* pickF = pickLS + P.max_less_sharp * P.n_regions;
+  char* wave_base = (char*)(pickF + ((P.max_flat * P.n_regions + 3) & ~3));
   const size_t wave_bytes = (size_t)nmax * 9;
-  __shared__ uint32_t reg_n[FEAT_WAVES], reg_gsp[FEAT_WAVES], reg_scan[FEAT_WAVES];
+  __shared__ uint32_t reg_n[FEAT_WAVES], reg_gsp[FEAT_WAVES], reg_scan[FEAT_WAVES], npick[3];
 
   const uint32_t r = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -186,15 +190,14 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
               if (fo < fs) {
                 const uint32_t pe = __shfl(e, fo, 64);
                 picked++;
-                const float4 pt = cloud[rgsp + pe];
                 if (lane == 0) {
                   if (picked <= P.max_sharp) {
                     rlabel[pe] = 2;
-                    slotS[(size_t)r * capS + nS] = pt;
+                    pickS[nS] = rgsp + pe;
                   } else {
                     rlabel[pe] = 1;
                   }
-                  slotLS[(size_t)r * capLS + nLS] = pt;
+                  pickLS[nLS] = rgsp + pe;
                 }
                 if (picked <= P.max_sharp) nS++;
                 nLS++;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
                 picked++;
                 if (lane == 0) {
                   rlabel[pe] = -1;
-                  slotF[(size_t)r * capF + nF] = cloud[rgsp + pe];
+                  pickF[nF] = rgsp + pe;
                 }
                 nF++;
                 mark_as_picked(rscan + pe, cr, flags, gaps, lane);
@@ -250,7 +253,12 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
     cntS[r] = nS;
     cntLS[r] = nLS;
     cntF[r] = nF;
+    npick[0] = nS; npick[1] = nLS; npick[2] = nF;
   }
+  __syncthreads();
+  for (uint32_t k = tid; k < npick[0]; k += blockDim.x) slotS[(size_t)r * capS + k] = cloud[pickS[k]];
+  for (uint32_t k = tid; k < npick[1]; k += blockDim.x) slotLS[(size_t)r * capLS + k] = cloud[pickLS[k]];
+  for (uint32_t k = tid; k < npick[2]; k += blockDim.x) slotF[(size_t)r * capF + k] = cloud[pickF[k]];
 }
 
 // exclusive prefix of per-ring counts -> prefix[nring+1]; one block per kind
@@ -386,12 +394,12 @@ void FeatureExtractor::run_async() {
     hipLaunchKernelGGL(k_feat_point, dim3((max_ring_len_ + 255) / 256, nring_), dim3(256), 0, st_, cloud_.p, ring_off_.p, cr, curv_.p,
                        flags_.p, gap_.p);
   }
-  const uint32_t flag_bytes = (max_ring_len_ + 15u) & ~15u;
-  const uint32_t nmax = (max_ring_len_ / (uint32_t)params.n_regions + 4u + 15u) & ~15u;
-  const size_t lds = 2 * (size_t)flag_bytes + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) + 16;
-  LX_REQUIRE(lds <= 160 * 1024, "scan ring too long for the LDS staging of k_feat_ring");
   const uint32_t caps[3] = {(uint32_t)(params.max_sharp * params.n_regions), (uint32_t)(params.max_less_sharp * params.n_regions),
                             (uint32_t)(params.max_flat * params.n_regions)};
+  const uint32_t flag_bytes = (max_ring_len_ + 15u) & ~15u;
+  const uint32_t nmax = (max_ring_len_ / (uint32_t)params.n_regions + 4u + 15u) & ~15u;
+  const size_t lds = 2 * (size_t)flag_bytes + 4 * (size_t)(caps[0] + caps[1] + ((caps[2] + 3) & ~3u)) + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) + 16;
+  LX_REQUIRE(lds <= 160 * 1024, "scan ring too long for the LDS staging of k_feat_ring");
   if (lds > 64 * 1024)
     LX_HIP(hipFuncSetAttribute((const void*)k_feat_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_feat_ring, dim3(nring_), dim3(64 * FEAT_WAVES), lds, st_, cloud_.p, ring_off_.p, ring_sweep_base_.p, params, curv_.p,

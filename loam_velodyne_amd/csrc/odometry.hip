@@ -52,8 +52,12 @@ __device__ inline void wave_argmin(float& d, int& j, int& order) {
   }
 }
 
-// exact nearest neighbour (d2 < 25) searched by a WHOLE WAVE: the lanes stride over the candidate points of each cell
-// row; after every shell the lane minima are combined so that pruning and termination stay wave-uniform.
+// exact nearest neighbour (d2 < 25) searched by a WHOLE WAVE.  Per shell of grid cells: every lane first fetches the
+// cell range of "its" (y,z) row (all cell_start loads of the shell are in flight together), then the rows are walked
+// with the lanes striding over each row's contiguous candidate run; after every shell the lane minima are combined so
+// that pruning and termination stay wave-uniform.  A row is skipped when its (y,z) slab is already farther than the
+// best distance, and its x-run is clipped to the cells the best-distance ball can reach (bounds shrunk by a relative
+// 1e-4 so float rounding can only make the search visit MORE cells, never fewer).
 __device__ inline int nn1_wave(const GridDesc& g, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, float qx,
                                float qy, float qz, int lane) {
   float best = 25.0f;           // wave-uniform bound (only candidates with d2 < 25 are admissible)
@@ -64,35 +68,47 @@ __device__ inline int nn1_wave(const GridDesc& g, const float4* __restrict__ sor
   const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
   const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
   for (int L = 0;; L++) {
-    for (int dz = -L; dz <= L; dz++) {
-      const int z = cz + dz;
-      if (z < 0 || z >= g.nz) continue;
-      const float gz = dz == 0 ? 0.f : (dz > 0 ? ((float)z - fz) : (fz - (float)(z + 1))) * h;
-      for (int dy = -L; dy <= L; dy++) {
-        const int y = cy + dy;
-        if (y < 0 || y >= g.ny) continue;
-        const float gy = dy == 0 ? 0.f : (dy > 0 ? ((float)y - fy) : (fy - (float)(y + 1))) * h;
-        const float gyz = (gy * gy + gz * gz) * 0.9999f;
-        if (gyz >= best) continue;
-        const bool face = (dz == -L || dz == L || dy == -L || dy == L);
-        const float rx = sqrtf(best - gyz) * g.inv_h * 1.0001f + 1e-3f;
-        const int xlo = (int)floorf(fx - rx), xhi = (int)floorf(fx + rx);
-        const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
-        for (int part = 0; part < 2; part++) {
-          int xa, xb;
-          if (face) {
-            if (part) break;
-            xa = cx - L; xb = cx + L;
-          } else {
-            xa = xb = part ? cx + L : cx - L;
-            if (L == 0 && part) break;
+    const int side = 2 * L + 1, nrows = side * side;
+    for (int r0 = 0; r0 < nrows; r0 += 64) {
+      // ---- lane r: ranges of row r0 + lane
+      uint32_t b0 = 0, e0 = 0, b1 = 0, e1 = 0;
+      {
+        const int rr = r0 + lane;
+        if (rr < nrows) {
+          const int dz = rr / side - L, dy = rr % side - L;
+          const int z = cz + dz, y = cy + dy;
+          if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+            const float gz = dz == 0 ? 0.f : (dz > 0 ? ((float)z - fz) : (fz - (float)(z + 1))) * h;
+            const float gy = dy == 0 ? 0.f : (dy > 0 ? ((float)y - fy) : (fy - (float)(y + 1))) * h;
+            const float gyz = (gy * gy + gz * gz) * 0.9999f;
+            if (gyz < best) {
+              const float rx = sqrtf(best - gyz) * g.inv_h * 1.0001f + 1e-3f;
+              const int xlo = (int)floorf(fx - rx), xhi = (int)floorf(fx + rx);
+              const bool face = (dz == -L || dz == L || dy == -L || dy == L);
+              const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
+              // on a face row the whole x-run [cx-L, cx+L] is new; otherwise only its two end cells
+              int xa = cx - L, xb = face ? cx + L : cx - L;
+              if (xa < xlo) xa = xlo;
+              if (xb > xhi) xb = xhi;
+              if (xa < 0) xa = 0;
+              if (xb > g.nx - 1) xb = g.nx - 1;
+              if (xa <= xb) { b0 = cell_start[row + xa]; e0 = cell_start[row + xb + 1]; }
+              if (!face && L > 0) {
+                const int xc = cx + L;
+                if (xc >= xlo && xc <= xhi && xc >= 0 && xc <= g.nx - 1) { b1 = cell_start[row + xc]; e1 = cell_start[row + xc + 1]; }
+              }
+            }
           }
-          if (xa < xlo) xa = xlo;
-          if (xb > xhi) xb = xhi;
-          if (xa < 0) xa = 0;
-          if (xb > g.nx - 1) xb = g.nx - 1;
-          if (xa > xb) continue;
-          const uint32_t beg = cell_start[row + xa], end = cell_start[row + xb + 1];
+        }
+      }
+      // ---- walk the non-empty runs
+      unsigned long long todo = __ballot(e0 > b0 || e1 > b1);
+      while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t rb0 = __shfl(b0, src, 64), re0 = __shfl(e0, src, 64), rb1 = __shfl(b1, src, 64), re1 = __shfl(e1, src, 64);
+        for (int part = 0; part < 2; part++) {
+          const uint32_t beg = part ? rb1 : rb0, end = part ? re1 : re0;
           for (uint32_t k = beg + lane; k < end; k += 64) {
             const float4 p = sorted[k];
             const float dx = qx - p.x, dy2 = qy - p.y, dz2 = qz - p.z;
@@ -145,45 +161,69 @@ __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ pro
   const int cscan = (int)last[closest].w;
   float d2 = 25.f, d3 = 25.f;
   int j2 = -1, j3 = -1, o2 = 0x7fffffff, o3 = 0x7fffffff;
-  for (int base = closest + 1; base < bound; base += 64) {
-    const int j = base + lane;
-    const bool in = j < bound;
-    const float4 q = in ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int ring = (int)q.w;
-    const bool brk = in && ((double)ring > (double)cscan + 2.5);
-    const unsigned long long mb = __ballot(brk);
-    const int fb = mb ? __builtin_ctzll(mb) : 64;
-    if (in && lane < fb) {
-      const float d = sqd(q, x, y, z);
-      const int order = j - (closest + 1);
-      if (corner) {
-        if (ring > cscan && d < d2) { d2 = d; j2 = j; o2 = order; }
-      } else {
-        if (ring <= cscan) { if (d < d2) { d2 = d; j2 = j; o2 = order; } }
-        else { if (d < d3) { d3 = d; j3 = j; o3 = order; } }
-      }
+  // forward window (:262-279 / :378-403): 4 x 64 points are fetched per trip, then examined in scan order
+  for (int base = closest + 1; base < bound; base += 256) {
+    float4 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = base + 64 * u + lane;
+      q[u] = j < bound ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (mb) break;
+    bool stop = false;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (stop) continue;
+      const int j = base + 64 * u + lane;
+      const bool in = j < bound;
+      const int ring = (int)q[u].w;
+      const bool brk = in && ((double)ring > (double)cscan + 2.5);
+      const unsigned long long mb = __ballot(brk);
+      const int fb = mb ? __builtin_ctzll(mb) : 64;
+      if (in && lane < fb) {
+        const float d = sqd(q[u], x, y, z);
+        const int order = j - (closest + 1);
+        if (corner) {
+          if (ring > cscan && d < d2) { d2 = d; j2 = j; o2 = order; }
+        } else {
+          if (ring <= cscan) { if (d < d2) { d2 = d; j2 = j; o2 = order; } }
+          else { if (d < d3) { d3 = d; j3 = j; o3 = order; } }
+        }
+      }
+      if (mb) stop = true;
+    }
+    if (stop) break;
   }
-  for (int base = closest - 1; base >= 0; base -= 64) {
-    const int j = base - lane;
-    const bool in = j >= 0;
-    const float4 q = in ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int ring = (int)q.w;
-    const bool brk = in && ((double)ring < (double)cscan - 2.5);
-    const unsigned long long mb = __ballot(brk);
-    const int fb = mb ? __builtin_ctzll(mb) : 64;
-    if (in && lane < fb) {
-      const float d = sqd(q, x, y, z);
-      const int order = 0x40000000 + (closest - 1 - j);   // backward candidates come after all forward ones
-      if (corner) {
-        if (ring < cscan && d < d2) { d2 = d; j2 = j; o2 = order; }
-      } else {
-        if (ring >= cscan) { if (d < d2) { d2 = d; j2 = j; o2 = order; } }
-        else { if (d < d3) { d3 = d; j3 = j; o3 = order; } }
-      }
+  // backward window (:280-297 / :404-429)
+  for (int base = closest - 1; base >= 0; base -= 256) {
+    float4 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = base - 64 * u - lane;
+      q[u] = j >= 0 ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (mb) break;
+    bool stop = false;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (stop) continue;
+      const int j = base - 64 * u - lane;
+      const bool in = j >= 0;
+      const int ring = (int)q[u].w;
+      const bool brk = in && ((double)ring < (double)cscan - 2.5);
+      const unsigned long long mb = __ballot(brk);
+      const int fb = mb ? __builtin_ctzll(mb) : 64;
+      if (in && lane < fb) {
+        const float d = sqd(q[u], x, y, z);
+        const int order = 0x40000000 + (closest - 1 - j);   // backward candidates come after all forward ones
+        if (corner) {
+          if (ring < cscan && d < d2) { d2 = d; j2 = j; o2 = order; }
+        } else {
+          if (ring >= cscan) { if (d < d2) { d2 = d; j2 = j; o2 = order; } }
+          else { if (d < d3) { d3 = d; j3 = j; o3 = order; } }
+        }
+      }
+      if (mb) stop = true;
+    }
+    if (stop) break;
   }
   wave_argmin(d2, j2, o2);
   if (!corner) wave_argmin(d3, j3, o3);

@@ -360,7 +360,9 @@ __device__ inline void knn_insert(float (&bd)[5], uint32_t (&bi)[5], uint32_t (&
   }
 }
 
-// exact 5-NN within the 1 m gate; returns true when 5 neighbours with d2 < 1 exist (== pointSearchSqDis[4] < 1.0)
+// exact 5-NN within the 1 m gate; returns true when 5 neighbours with d2 < 1 exist (== pointSearchSqDis[4] < 1.0).
+// Latency shaping: the 9 (y,z) rows' cell ranges are fetched up front (18 independent loads in flight), and the
+// candidates of a row are loaded four at a time before any of them is used.
 __device__ inline bool knn5(const GridDesc& g, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start, float qx,
                             float qy, float qz, uint32_t (&bp)[5]) {
   float bd[5];
@@ -369,21 +371,31 @@ __device__ inline bool knn5(const GridDesc& g, const float4* __restrict__ pts, c
   for (int j = 0; j < 5; j++) { bd[j] = FLT_MAX; bi[j] = 0xffffffffu; bp[j] = 0u; }
   // unclamped cell of the query; the searched ranges are clamped, so points binned into border cells are still found
   const int cx = (int)floorf((qx - g.ox) * g.inv_h), cy = (int)floorf((qy - g.oy) * g.inv_h), cz = (int)floorf((qz - g.oz) * g.inv_h);
-  const int x0 = clampi(cx - 1, 0, g.nx - 1), x1 = clampi(cx + 1, 0, g.nx - 1);
-  const int y0 = clampi(cy - 1, 0, g.ny - 1), y1 = clampi(cy + 1, 0, g.ny - 1);
-  const int z0 = clampi(cz - 1, 0, g.nz - 1), z1 = clampi(cz + 1, 0, g.nz - 1);
   if (cx + 1 < 0 || cx - 1 > g.nx - 1 || cy + 1 < 0 || cy - 1 > g.ny - 1 || cz + 1 < 0 || cz - 1 > g.nz - 1) return false;
-  for (int z = z0; z <= z1; z++)
-    for (int y = y0; y <= y1; y++) {
-      const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
-      const uint32_t beg = cell_start[row + x0], end = cell_start[row + x1 + 1];   // x is the fastest cell axis: one run
-      for (uint32_t k = beg; k < end; k++) {
-        const float4 p = pts[k];
-        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+  const int x0 = clampi(cx - 1, 0, g.nx - 1), x1 = clampi(cx + 1, 0, g.nx - 1);
+  uint32_t beg[9], end[9];
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+    const bool ok = z >= 0 && z < g.nz && y >= 0 && y < g.ny;   // a clamped duplicate row would only repeat candidates
+    const uint32_t row = ok ? ((uint32_t)z * g.ny + y) * g.nx : 0u;
+    beg[r] = ok ? cell_start[row + x0] : 0u;                     // x is the fastest cell axis: one contiguous run
+    end[r] = ok ? cell_start[row + x1 + 1] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    for (uint32_t k = beg[r]; k < end[r]; k += 4) {
+      float4 p[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) p[u] = (k + u < end[r]) ? pts[k + u] : make_float4(1e30f, 1e30f, 1e30f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
         const float d2 = dx * dx + dy * dy + dz * dz;   // x -> y -> z accumulation (nanoflann.hpp:372-379)
-        if (d2 < 1.0f) knn_insert(bd, bi, bp, d2, __float_as_uint(p.w), k);
+        if (d2 < 1.0f) knn_insert(bd, bi, bp, d2, __float_as_uint(p[u].w), k + u);
       }
     }
+  }
   return bi[4] != 0xffffffffu;
 }
 

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
   uint32_t* pickS = (uint32_t*)(smem + 2 * (size_t)flag_bytes);
   uint32_t* pickLS = pickS + P.max_sharp * P.n_regions;
   uint32_t* pickF = pickLS + P.max_less_sharp * P.n_regions;
-  char* wave_base = (char*)(pickF + ((P.max_flat * P.n_regions + 3) & ~3));
+  char* wave_base = smem + ((2 * (size_t)flag_bytes + 4 * (size_t)((P.max_sharp + P.max_less_sharp + P.max_flat) * P.n_regions) + 15) & ~(size_t)15);
   const size_t wave_bytes = (size_t)nmax * 9;
   __shared__ uint32_t reg_n[FEAT_WAVES], reg_gsp[FEAT_WAVES], reg_scan[FEAT_WAVES], npick[3];
 
@@ -153,14 +153,20 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
         c[e] = curv[gsp + e];
         label[e] = 0;   // SURFACE_LESS_FLAT
       }
+      if (lane < 4 && n) c[n + lane] = __builtin_inff();   // padding for the 4-wide reads below (never counted)
       __syncthreads();
-      // stable ascending order (:311-317): rank = #smaller + #equal-before.  Every wave sorts its own region.
+      // stable ascending order (:311-317): rank = #smaller + #equal-before.  Every wave sorts its own region;
+      // the curvatures are read four at a time (ds_read_b128, all lanes the same address = broadcast).
       for (uint32_t e = lane; e < n; e += 64) {
         const float ce = c[e];
         uint32_t rank = 0;
-        for (uint32_t q = 0; q < n; q++) {
-          const float cq = c[q];
-          rank += (cq < ce || (cq == ce && q < e)) ? 1u : 0u;
+        const float4* c4 = (const float4*)c;
+        for (uint32_t q = 0; q < n; q += 4) {
+          const float4 v = c4[q >> 2];
+          rank += (v.x < ce || (v.x == ce && q < e)) ? 1u : 0u;
+          rank += (v.y < ce || (v.y == ce && q + 1 < e)) ? 1u : 0u;
+          rank += (v.z < ce || (v.z == ce && q + 2 < e)) ? 1u : 0u;
+          rank += (v.w < ce || (v.w == ce && q + 3 < e)) ? 1u : 0u;
         }
         sorted[rank] = e;
       }
@@ -397,8 +403,8 @@ void FeatureExtractor::run_async() {
   const uint32_t caps[3] = {(uint32_t)(params.max_sharp * params.n_regions), (uint32_t)(params.max_less_sharp * params.n_regions),
                             (uint32_t)(params.max_flat * params.n_regions)};
   const uint32_t flag_bytes = (max_ring_len_ + 15u) & ~15u;
-  const uint32_t nmax = (max_ring_len_ / (uint32_t)params.n_regions + 4u + 15u) & ~15u;
-  const size_t lds = 2 * (size_t)flag_bytes + 4 * (size_t)(caps[0] + caps[1] + ((caps[2] + 3) & ~3u)) + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) + 16;
+  const uint32_t nmax = (max_ring_len_ / (uint32_t)params.n_regions + 8u + 15u) & ~15u;
+  const size_t lds = ((2 * (size_t)flag_bytes + 4 * (size_t)(caps[0] + caps[1] + caps[2]) + 15) & ~(size_t)15) + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) + 16;
   LX_REQUIRE(lds <= 160 * 1024, "scan ring too long for the LDS staging of k_feat_ring");
   if (lds > 64 * 1024)
     LX_HIP(hipFuncSetAttribute((const void*)k_feat_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

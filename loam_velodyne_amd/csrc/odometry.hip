@@ -17,6 +17,7 @@ namespace loamx {
 
 constexpr int OD_THREADS = 512;
 constexpr int OD_WAVES = OD_THREADS / 64;
+// features per thread kept in registers: 6 x 512 = 3072 covers 64-ring sensors (2304); 16 x 512 = 8192 is the fallback
 
 // per-point de-skew angles (|a| << 1): float sincos (<= 2 ulp); the once-per-iteration pose trig stays in double
 __device__ inline void sincos_f(float a, float& s, float& c) { sincosf(a, &s, &c); }
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ pro
 }
 
 // ---- phase C: iterations [iter0, iter0 + n_iters) of one stream in one persistent workgroup
+template <int OD_FPT>
 __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict__ probs, OdomParams P, int iter0, int n_iters) {
   OdomProblem& pb = probs[blockIdx.x];
   if (pb.done) return;
@@ -251,6 +253,29 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
   if (tid == 0) sh_done = 0;
   __syncthreads();
 
+  // the correspondences are fixed for the iterations of this launch: keep each thread's features (raw point + tripod
+  // points) in registers instead of re-gathering them from HBM every iteration
+  float4 fpo[OD_FPT], ft1[OD_FPT], ft2[OD_FPT], ft3[OD_FPT];
+  bool fvalid[OD_FPT], fcorner[OD_FPT];
+#pragma unroll
+  for (int u = 0; u < OD_FPT; u++) {
+    const int f = tid + u * OD_THREADS;
+    fvalid[u] = false;
+    fcorner[u] = f < nSharp;
+    fpo[u] = ft1[u] = ft2[u] = ft3[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < nFeat) {
+      const int i1 = pb.ind[5 * f], i2 = pb.ind[5 * f + 1], i3 = pb.ind[5 * f + 2];
+      if (fcorner[u] ? (i2 >= 0) : (i2 >= 0 && i3 >= 0)) {
+        fvalid[u] = true;
+        fpo[u] = fcorner[u] ? pb.sharp[f] : pb.flat[f - nSharp];
+        const float4* last = fcorner[u] ? pb.last_corner : pb.last_surf;
+        ft1[u] = last[i1];
+        ft2[u] = last[i2];
+        if (!fcorner[u]) ft3[u] = last[i3];
+      }
+    }
+  }
+
   for (int iter = iter0; iter < iter0 + n_iters; iter++) {
     // ---- phase C: residual rows + normal equations
     if (tid == 0) {
@@ -262,17 +287,18 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
     double v[LX_NSUM];
 #pragma unroll
     for (int k = 0; k < LX_NSUM; k++) v[k] = 0.0;
-    for (int f = tid; f < nFeat; f += OD_THREADS) {
-      const bool corner = f < nSharp;
-      const float4 po = corner ? pb.sharp[f] : pb.flat[f - nSharp];
-      const int i1 = pb.ind[5 * f], i2 = pb.ind[5 * f + 1], i3 = pb.ind[5 * f + 2];
+#pragma unroll
+    for (int u = 0; u < OD_FPT; u++) {
+      if (!fvalid[u]) continue;
+      const bool corner = fcorner[u];
+      const float4 po = fpo[u];
       float cx = 0.f, cy = 0.f, cz = 0.f, ci = 0.f;
       bool sel = false;
-      if (corner ? (i2 >= 0) : (i2 >= 0 && i3 >= 0)) {
+      {
         float x0, y0, z0;
         transform_to_start(T, P.scan_period, po, x0, y0, z0);
         if (corner) {
-          const float4 t1 = pb.last_corner[i1], t2 = pb.last_corner[i2];
+          const float4 t1 = ft1[u], t2 = ft2[u];
           const float x1 = t1.x, y1 = t1.y, z1 = t1.z, x2 = t2.x, y2 = t2.y, z2 = t2.z;
           const float a012 = sqrtf(((x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1)) * ((x0 - x1) * (y0 - y2) - (x0 - x2) * (y0 - y1)) +
                                    ((x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1)) * ((x0 - x1) * (z0 - z2) - (x0 - x2) * (z0 - z1)) +
@@ -290,7 +316,7 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
           cx = s * la; cy = s * lb; cz = s * lc; ci = s * ld2;
           sel = ((double)s > 0.1) && (ld2 != 0);
         } else {
-          const float4 t1 = pb.last_surf[i1], t2 = pb.last_surf[i2], t3 = pb.last_surf[i3];
+          const float4 t1 = ft1[u], t2 = ft2[u], t3 = ft3[u];
           float pa = (t2.y - t1.y) * (t3.z - t1.z) - (t3.y - t1.y) * (t2.z - t1.z);
           float pbb = (t2.z - t1.z) * (t3.x - t1.x) - (t3.z - t1.z) * (t2.x - t1.x);
           float pc = (t2.x - t1.x) * (t3.y - t1.y) - (t3.x - t1.x) * (t2.y - t1.y);
@@ -554,13 +580,17 @@ void OdometryBatch::process(const OdomInput* in, int* rc) {
     }
   }
   const uint32_t na = (uint32_t)active.size();
+  if (max_feat > 16 * OD_THREADS) throw Error(LOAMX_E_CAPACITY, "more than 8192 sharp+flat features in one sweep");
   if (na) {
     LX_HIP(hipMemcpyAsync(prob_.p, h_prob_.p, sizeof(OdomProblem) * na, hipMemcpyHostToDevice, st_));
     if (max_feat) {
       for (int it0 = 0; it0 < params.max_iterations; it0 += 5) {
         const int nit = std::min(5, params.max_iterations - it0);
         hipLaunchKernelGGL(k_odom_corr, dim3((max_feat + 3) / 4, na), dim3(256), 0, st_, prob_.p, params);
-        hipLaunchKernelGGL(k_odom_lm, dim3(na), dim3(OD_THREADS), 0, st_, prob_.p, params, it0, nit);
+        if (max_feat <= 6 * OD_THREADS)
+          hipLaunchKernelGGL(k_odom_lm<6>, dim3(na), dim3(OD_THREADS), 0, st_, prob_.p, params, it0, nit);
+        else
+          hipLaunchKernelGGL(k_odom_lm<16>, dim3(na), dim3(OD_THREADS), 0, st_, prob_.p, params, it0, nit);
       }
     }
     LX_HIP(hipMemcpyAsync(h_prob_.p, prob_.p, sizeof(OdomProblem) * na, hipMemcpyDeviceToHost, st_));

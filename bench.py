@@ -9,7 +9,7 @@ All sweeps are staged in HBM before the timed region; the map is generated on ra
 with one RCCL broadcast (torch.distributed, backend "nccl" = RCCL over xGMI) — the only collective on the path; the
 streams themselves are sharded with no data-path exchange.
 
-One JSON line on rank 0 (the driver's contract) plus `roofline` (dominant kernel: k_residual, algorithmic bytes =
+One JSON line on rank 0 (the driver's contract) plus `roofline` (dominant kernel: k_knn5, algorithmic bytes =
 72 B x query-iterations, duration from HIP events on the library's own stream) and `cpu_baseline` (the oracle = CPU
 restatement of the reference, -O3 -march=native, single thread, on a bounded sample of the same workload).
 """
@@ -172,7 +172,7 @@ def main():
                 "path_hbm_frac": round(float(bytes_per_sweep * value / world / (HBM_PEAK_GBS * 1e9)), 6),
             },
             "roofline": {
-                "kernel": "loamx::k_residual",
+                "kernel": "loamx::k_knn5",
                 "bound": "hbm",
                 "achieved": round(achieved, 3),
                 "peak": HBM_PEAK_GBS,

@@ -135,6 +135,8 @@ class Registrar {
   DevBuf<SweepStats> stats_;
   DevBuf<float> matP_;        // 36 per sweep
   DevBuf<double> partials_;   // per sweep x blocks x LX_NSUM
+  DevBuf<uint32_t> nb_;       // 5 neighbour positions per query
+  DevBuf<float4> qstate_;     // per query: position at its last full search + squared re-validation bound
   uint32_t nblk_ = 0;
 
   std::vector<hipEvent_t> ev_;   // timing events: [0]=run start, [1]=run end, then pairs per residual launch

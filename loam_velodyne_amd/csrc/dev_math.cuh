@@ -371,6 +371,97 @@ __device__ inline bool degeneracy_projector(const float* AtA, float thr, float* 
   return degenerate;
 }
 
+// 6x6 column-pivoted Householder QR solve spread over the lanes of a wave: lane (l & 7) = c < 6 owns COLUMN c of A,
+// lane 6 owns the right-hand side; every arithmetic operation is the one the scalar qr_solve<6,6> performs on that
+// element, in the same order, so the result is bit-identical — only the serial dependency chain shrinks ~8x.
+// Must be called by all 64 lanes of a wave (groups of 8 compute redundantly); AtA/AtB/X are in LDS or global memory.
+__device__ inline void qr_solve6_coop(const float* AtA, const float* AtB, float* X) {
+  const int gl = (int)(threadIdx.x & 7);
+  float a[6];
+#pragma unroll
+  for (int r = 0; r < 6; r++) a[r] = gl < 6 ? AtA[r * 6 + gl] : (gl == 6 ? AtB[r] : 0.f);
+  int perm = gl;   // lane c: original column index currently stored in this lane
+  // largest initial column norm
+  float s0 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 6; r++) s0 += a[r] * a[r];
+  float nrm = gl < 6 ? sqrtf(s0) : 0.f;
+  float maxnorm = 0.f;
+#pragma unroll
+  for (int c = 0; c < 6; c++) maxnorm = fmaxf(maxnorm, __shfl(nrm, c, 8));
+  const float thr_helper = (maxnorm * FLT_EPSILON) * (maxnorm * FLT_EPSILON) / 6.0f;
+  int nonzero = 6;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    // pivot: first column (from k upwards) with the largest remaining squared norm
+    float s = 0.f;
+#pragma unroll
+    for (int r = k; r < 6; r++) s += a[r] * a[r];
+    int best = k;
+    float bestn = -1.f;
+#pragma unroll
+    for (int c = k; c < 6; c++) {
+      const float sc = __shfl(s, c, 8);
+      if (sc > bestn) { bestn = sc; best = c; }
+    }
+    if (nonzero == 6 && bestn < thr_helper * float(6 - k)) nonzero = k;
+    // swap columns k and best
+    const int partner = gl == k ? best : (gl == best ? k : gl);
+#pragma unroll
+    for (int r = 0; r < 6; r++) a[r] = __shfl(a[r], partner, 8);
+    perm = __shfl(perm, partner, 8);
+    // Householder vector from column k (computed by its owner, broadcast)
+    float tail = 0.f;
+#pragma unroll
+    for (int r = k + 1; r < 6; r++) tail += a[r] * a[r];
+    const float c0 = a[k];
+    float tau, beta, v[6];
+    if (tail <= FLT_MIN) {
+      tau = 0.f;
+      beta = c0;
+#pragma unroll
+      for (int r = 0; r < 6; r++) v[r] = 0.f;
+    } else {
+      beta = sqrtf(c0 * c0 + tail);
+      if (c0 >= 0.f) beta = -beta;
+#pragma unroll
+      for (int r = 0; r < 6; r++) v[r] = r > k ? a[r] / (c0 - beta) : 0.f;
+      tau = (beta - c0) / beta;
+    }
+    v[k] = 1.f;
+    tau = __shfl(tau, k, 8);
+    beta = __shfl(beta, k, 8);
+#pragma unroll
+    for (int r = 0; r < 6; r++) v[r] = __shfl(v[r], k, 8);
+    if (gl == k) {
+      a[k] = beta;
+#pragma unroll
+      for (int r = k + 1; r < 6; r++) a[r] = 0.f;
+    } else if (gl > k && gl <= 6) {   // remaining columns and the right-hand side
+      float dot = 0.f;
+#pragma unroll
+      for (int r = k; r < 6; r++) dot += v[r] * a[r];
+      dot *= tau;
+#pragma unroll
+      for (int r = k; r < 6; r++) a[r] -= dot * v[r];
+    }
+  }
+  // back substitution on the leading nonzero x nonzero block: y[k] ends up in lane k
+  float y = 0.f;
+#pragma unroll
+  for (int k = 5; k >= 0; k--) {
+    float sacc = __shfl(a[k], 6, 8);   // b[k]
+#pragma unroll
+    for (int c = k + 1; c < 6; c++) {
+      const float term = __shfl(a[k] * y, c, 8);   // A[k][c] * y[c] from the lane owning column c
+      if (c < nonzero) sacc -= term;
+    }
+    const float diag = __shfl(a[k], k, 8);
+    if (gl == k && k < nonzero) y = sacc / diag;
+  }
+  if (threadIdx.x < 6) X[perm] = gl < nonzero ? y : 0.f;
+}
+
 // 6x6 column-pivoted QR solve on plain arrays (single thread)
 __device__ inline void qr_solve6(const float* AtA, const float* AtB, float* X) {
   float A[6][6], b[6], x[6];

@@ -370,21 +370,26 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
       if (lane == 0) red[wid][t] = x;
     }
     __syncthreads();
+    if (tid < LX_NSUM) {
+      double x = 0.0;
+      for (int w = 0; w < OD_WAVES; w++) x += red[w][tid];
+      sums[tid] = x;
+    }
+    __syncthreads();
+    const int sel = (int)sums[27];   // block-uniform
     if (tid == 0) {
-      for (int t = 0; t < LX_NSUM; t++) {
-        double x = 0.0;
-        for (int w = 0; w < OD_WAVES; w++) x += red[w][t];
-        sums[t] = x;
-      }
-      const int sel = (int)sums[27];
       pb.stats.iterations = iter + 1;
       pb.stats.sel = sel;
+      int k = 0;
+      for (int i = 0; i < 6; i++)
+        for (int j = i; j < 6; j++) { AtA[i * 6 + j] = AtA[j * 6 + i] = (float)sums[k]; k++; }
+      for (int i = 0; i < 6; i++) AtB[i] = (float)sums[21 + i];
+    }
+    __syncthreads();
+    if (sel >= 10 && tid < 64) qr_solve6_coop(AtA, AtB, X);   // wave 0, all lanes (:559)
+    __syncthreads();
+    if (tid == 0) {
       if (sel >= 10) {   // :485-488
-        int k = 0;
-        for (int i = 0; i < 6; i++)
-          for (int j = i; j < 6; j++) { AtA[i * 6 + j] = AtA[j * 6 + i] = (float)sums[k]; k++; }
-        for (int i = 0; i < 6; i++) AtB[i] = (float)sums[21 + i];
-        qr_solve6(AtA, AtB, X);
         if (iter == 0) pb.stats.degenerate = degeneracy_projector(AtA, 10.f, pb.matP, ws) ? 1 : 0;
         if (pb.stats.degenerate) {
           for (int r = 0; r < 6; r++) X2[r] = X[r];

@@ -732,24 +732,29 @@ __global__ __launch_bounds__(256) void k_solve(const uint32_t* __restrict__ ds_o
     sums[threadIdx.x] = x;
   }
   __syncthreads();
+  const int sel_rows = (int)sums[27];   // block-uniform
+  if (threadIdx.x == 0) {
+    int k = 0;
+    for (int i = 0; i < 6; i++)
+      for (int j = i; j < 6; j++) {
+        AtA[i * 6 + j] = AtA[j * 6 + i] = (float)sums[k];
+        k++;
+      }
+    for (int i = 0; i < 6; i++) AtB[i] = (float)sums[21 + i];
+  }
+  __syncthreads();
+  if (sel_rows >= 50 && threadIdx.x < 64) qr_solve6_coop(AtA, AtB, X);   // wave 0, all lanes
+  __syncthreads();
   if (threadIdx.x != 0) return;
   SweepStats st = stats[s];
   st.iterations = iter + 1;
-  st.sel = (int)sums[27];
+  st.sel = sel_rows;
   st.corner_q = (int)(ds_off[2 * s + 1] - ds_off[2 * s]);
   st.surf_q = (int)(ds_off[2 * s + 2] - ds_off[2 * s + 1]);
   if (st.sel < 50) {   // BasicLaserMapping.cpp:826-828: the iteration is burnt, pose untouched
     stats[s] = st;
     return;
   }
-  int k = 0;
-  for (int i = 0; i < 6; i++)
-    for (int j = i; j < 6; j++) {
-      AtA[i * 6 + j] = AtA[j * 6 + i] = (float)sums[k];
-      k++;
-    }
-  for (int i = 0; i < 6; i++) AtB[i] = (float)sums[21 + i];
-  qr_solve6(AtA, AtB, X);
   float* P = matP + 36 * s;
   if (iter == 0) st.degenerate = degeneracy_projector(AtA, 100.f, P, ws) ? 1 : 0;
   if (st.degenerate) {

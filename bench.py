@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 STREAMS_PER_GPU = 8
+HANDLES_PER_GPU = 1      # >1: split the streams over several pipeline handles driven from host threads (measured: no gain)
 SENSOR = "HDL-64E"
 MAP_POINTS = 1_000_000
 HBM_PEAK_GBS = 8000.0
@@ -40,6 +41,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--map-points", type=int, default=MAP_POINTS)
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU)
+    ap.add_argument("--handles", type=int, default=HANDLES_PER_GPU,
+                    help="pipeline handles per GPU, each on its own HIP stream and host thread, sharing the streams evenly")
     args = ap.parse_args()
 
     import torch
@@ -93,13 +96,28 @@ def main():
             sweeps[t][s] = (sw.points, sw.ring_sizes)
     n_points = len(sweeps[0][0][0])
 
-    pipe = loamx.Pipeline(ns, scanreg=dict(device=local_rank), odom=dict(device=local_rank), mapping=dict(device=local_rank))
+    H = max(1, min(args.handles, ns))
+    assert ns % H == 0, "--streams must be a multiple of --handles"
+    per = ns // H
     torch.cuda.synchronize()
-    pipe.set_frozen_device(map_t.data_ptr(), n_corner, map_t.data_ptr() + 16 * n_corner, n_surf)
-    for s in range(ns):
-        pipe.set_state(s, aft=starts[s])
-    pipe.upload(sweeps)
-    pipe.set_timing(True)
+    pipes = []
+    for h in range(H):
+        p = loamx.Pipeline(per, scanreg=dict(device=local_rank), odom=dict(device=local_rank), mapping=dict(device=local_rank))
+        p.set_frozen_device(map_t.data_ptr(), n_corner, map_t.data_ptr() + 16 * n_corner, n_surf)
+        for k in range(per):
+            p.set_state(k, aft=starts[h * per + k])
+        p.upload([[sweeps[t][h * per + k] for k in range(per)] for t in range(T)])
+        p.set_timing(True)
+        pipes.append(p)
+
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=H)
+
+    def run_step(t):
+        if H == 1:
+            pipes[0].step(t)
+        else:
+            list(pool.map(lambda p: p.step(t), pipes))   # ctypes releases the GIL: the handles really run concurrently
 
     def sync_all():
         torch.cuda.synchronize()
@@ -109,7 +127,7 @@ def main():
 
     # ---- warm-up (includes every stream's initialising first sweep)
     for t in range(1 + W):
-        pipe.step(t)
+        run_step(t)
     sync_all()
     stage = np.zeros(4)
     res_ms = 0.0
@@ -118,19 +136,20 @@ def main():
     queries = 0
     t0 = time.perf_counter()
     for t in range(1 + W, T):
-        pipe.step(t)
-        tm = pipe.timing()   # event read-back of the step that just finished (the step itself is synchronous)
-        stage += [tm["features_ms"], tm["odometry_ms"], tm["registration_ms"], tm["step_ms"]]
-        res_ms += tm["residual_ms"]
-        res_launches += tm["residual_launches"]
-        q_iters += tm["query_iterations"]
-        queries += tm["queries"]
+        run_step(t)
+        for p in pipes:   # event read-back of the step that just finished (the step itself is synchronous)
+            tm = p.timing()
+            stage += np.array([tm["features_ms"], tm["odometry_ms"], tm["registration_ms"], tm["step_ms"]]) / H
+            res_ms += tm["residual_ms"]
+            res_launches += tm["residual_launches"]
+            q_iters += tm["query_iterations"]
+            queries += tm["queries"]
     sync_all()
     elapsed = time.perf_counter() - t0
     elapsed = lxdist.max_over_ranks(elapsed, dist, dev)
 
     # pose sanity of this rank's streams against ground truth (not the parity check — that is tests/)
-    stats = [pipe.get(s)[3] for s in range(ns)]
+    stats = [p.get(k)[3] for p in pipes for k in range(per)]
     sweeps_total = world * ns * K
     value = sweeps_total / elapsed
 
@@ -160,6 +179,7 @@ def main():
                 "workload": f"{SENSOR} 64x2048 sweeps ({n_points} pts), {M}-pt frozen sub-map, {ns} streams/GPU "
                             "(BASELINE configs[3]: batch 32 over 4 GPUs), full path per sweep",
                 "streams_per_gpu": ns,
+                "handles_per_gpu": H,
                 "sweep_points": n_points,
                 "map_points": M,
                 "mean_map_iterations": round(float(iters_map), 2),

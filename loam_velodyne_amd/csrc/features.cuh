@@ -59,7 +59,8 @@ class FeatureExtractor {
   DevBuf<uint32_t> slot_cnt_[3];  // per-ring counts
   DevBuf<float4> out_[3];
   DevBuf<uint32_t> out_off_[3], sweep_ring_base_;
-  DevBuf<float4> lf_out_;
+  DevBuf<float4> lf_out_, lf_slots_;
+  DevBuf<uint32_t> lf_cnt_;
   DevBuf<uint32_t> lf_off_;
   VoxelPipeline vox_;
   PinBuf<uint32_t> h_off_;

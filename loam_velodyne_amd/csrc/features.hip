@@ -267,6 +267,125 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
   for (uint32_t k = tid; k < npick[2]; k += blockDim.x) slotF[(size_t)r * capF + k] = cloud[pickF[k]];
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Per-ring pcl::VoxelGrid of the less-flat candidates (:246-252) in ONE workgroup per ring: the ring's candidates
+// (<= 4096) are compacted, keyed (voxel key << 12 | position, so equal voxels keep input order), bitonic-sorted in LDS,
+// and every voxel run is averaged by one thread in input order.  Same membership, order and float arithmetic as the
+// generic VoxelPipeline (which remains the fallback for longer rings); output goes to the ring's own slot range.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int LFV_THREADS = 256;
+constexpr uint32_t LFV_MAX = 4096;
+
+__global__ __launch_bounds__(LFV_THREADS) void k_feat_lf_voxel(const float4* __restrict__ cloud, const uint32_t* __restrict__ ring_off,
+                                                               const uint8_t* __restrict__ lf_valid, float inv_leaf, uint32_t P,
+                                                               float4* __restrict__ slots, uint32_t* __restrict__ cnt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* keys = (unsigned long long*)smem;   // P entries
+  __shared__ uint32_t sc[17];
+  __shared__ int mm[6];
+  const uint32_t r = blockIdx.x, tid = threadIdx.x;
+  const uint32_t s0 = ring_off[r], len = ring_off[r + 1] - s0;
+  if (tid < 3) mm[tid] = 2147483647;
+  else if (tid < 6) mm[tid] = -2147483647 - 1;
+  for (uint32_t k = tid; k < P; k += LFV_THREADS) keys[k] = ~0ull;
+  __syncthreads();
+  // ---- compact the candidates (order preserved): keys[j] temporarily holds the ring-relative index
+  uint32_t base = 0;
+  for (uint32_t b = 0; b < len; b += LFV_THREADS) {
+    const uint32_t i = b + tid;
+    const uint32_t v = (i < len && lf_valid[s0 + i]) ? 1u : 0u;
+    uint32_t total;
+    const uint32_t ex = block_excl_scan(v, sc, total);
+    if (v) keys[base + ex] = i;
+    base += total;
+  }
+  const uint32_t m = base;
+  __syncthreads();
+  // ---- voxel coordinates and their bounds
+  int ix = 0, iy = 0, iz = 0;
+  // (each thread handles candidates j = tid, tid + 256, ...; coordinates are recomputed when the key is formed)
+  for (uint32_t j = tid; j < m; j += LFV_THREADS) {
+    const float4 p = cloud[s0 + (uint32_t)keys[j]];
+    ix = (int)floorf(p.x * inv_leaf); iy = (int)floorf(p.y * inv_leaf); iz = (int)floorf(p.z * inv_leaf);
+    atomicMin(&mm[0], ix); atomicMin(&mm[1], iy); atomicMin(&mm[2], iz);
+    atomicMax(&mm[3], ix); atomicMax(&mm[4], iy); atomicMax(&mm[5], iz);
+  }
+  __syncthreads();
+  const long long dx = (long long)mm[3] - mm[0] + 1, dy = (long long)mm[4] - mm[1] + 1, dz = (long long)mm[5] - mm[2] + 1;
+  const bool pass = m > 0 && (dx * dy * dz > 2147483647LL || dx > 4096 || dy > 4096 || dz > 4096);   // PCL: leaf too small
+  for (uint32_t j = tid; j < m; j += LFV_THREADS) {
+    const uint32_t li = (uint32_t)keys[j];
+    unsigned long long k;
+    if (pass) {
+      k = (unsigned long long)j;
+    } else {
+      const float4 p = cloud[s0 + li];
+      const int jx = (int)floorf(p.x * inv_leaf), jy = (int)floorf(p.y * inv_leaf), jz = (int)floorf(p.z * inv_leaf);
+      k = ((unsigned long long)(jz - mm[2]) << 24) | ((unsigned long long)(jy - mm[1]) << 12) | (unsigned long long)(jx - mm[0]);
+    }
+    keys[j] = (k << 12) | li;   // li < 4096: unique keys, equal voxels stay in input order
+  }
+  __syncthreads();
+  // ---- bitonic sort of P keys (padding = ~0 sorts last)
+  for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
+    for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+      for (uint32_t i = tid; i < P; i += LFV_THREADS) {
+        const uint32_t l = i ^ j2;
+        if (l > i) {
+          const unsigned long long a = keys[i], b = keys[l];
+          const bool up = (i & k2) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- voxel heads -> output positions -> means
+  uint32_t obase = 0;
+  for (uint32_t b = 0; b < m; b += LFV_THREADS) {
+    const uint32_t j = b + tid;
+    const bool head = j < m && (j == 0 || (keys[j] >> 12) != (keys[j - 1] >> 12));
+    uint32_t total;
+    const uint32_t ex = block_excl_scan(head ? 1u : 0u, sc, total);
+    if (head) {
+      const unsigned long long vk = keys[j] >> 12;
+      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+      uint32_t e = j;
+      do {
+        const float4 p = cloud[s0 + (uint32_t)(keys[e] & 4095ull)];
+        sx += p.x; sy += p.y; sz += p.z; si += p.w;
+        e++;
+      } while (e < m && (keys[e] >> 12) == vk);
+      const float c = (float)(e - j);
+      slots[s0 + obase + ex] = make_float4(sx / c, sy / c, sz / c, si / c);
+    }
+    obase += total;
+  }
+  if (tid == 0) cnt[r] = obase;
+}
+
+// lf_off = exclusive prefix of the per-ring voxel counts (one block)
+__global__ __launch_bounds__(1024) void k_feat_lf_prefix(const uint32_t* __restrict__ cnt, uint32_t nring, uint32_t* __restrict__ off) {
+  __shared__ uint32_t lds[17];
+  uint32_t carry = 0;
+  for (uint32_t b = 0; b < nring; b += 1024) {
+    const uint32_t i = b + threadIdx.x;
+    const uint32_t v = i < nring ? cnt[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_excl_scan(v, lds, total);
+    if (i < nring) off[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) off[nring] = carry;
+}
+__global__ __launch_bounds__(256) void k_feat_lf_copy(const float4* __restrict__ slots, const uint32_t* __restrict__ ring_off,
+                                                      const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                                      float4* __restrict__ out) {
+  const uint32_t r = blockIdx.x;
+  const uint32_t n = cnt[r], src = ring_off[r], dst = off[r];
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) out[dst + k] = slots[src + k];
+}
+
 // exclusive prefix of per-ring counts -> prefix[nring+1]; one block per kind
 __global__ __launch_bounds__(1024) void k_feat_prefix(const uint32_t* __restrict__ c0, const uint32_t* __restrict__ c1,
                                                       const uint32_t* __restrict__ c2, uint32_t nring, uint32_t* __restrict__ p0,
@@ -370,6 +489,8 @@ void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uin
   gap_.reserve(n_ + 1);
   lf_valid_.reserve(n_ + 1);
   lf_out_.reserve(n_ + 1);
+  lf_slots_.reserve(n_ + 1);
+  lf_cnt_.reserve(nring_ + 2);
   ring_off_.reserve(nring_ + 2);
   ring_sweep_base_.reserve(nring_ + 2);
   lf_off_.reserve(nring_ + 2);
@@ -382,7 +503,7 @@ void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uin
     slot_cnt_[k].reserve(2 * (size_t)nring_ + 4);   // counts [0,nring) + prefix [nring+1 .. 2nring+2)
     out_off_[k].reserve(nsw + 2);
   }
-  vox_.reserve(n_ + 1, nring_);
+  if (max_ring_len_ > 4096) vox_.reserve(n_ + 1, nring_);
   if (n_) LX_HIP(hipMemcpyAsync(cloud_.p, h_cloud_.p, sizeof(float4) * n_, hipMemcpyHostToDevice, st_));
   LX_HIP(hipMemcpyAsync(ring_off_.p, h_ring_off_.data(), sizeof(uint32_t) * (nring_ + 1), hipMemcpyHostToDevice, st_));
   LX_HIP(hipMemcpyAsync(ring_sweep_base_.p, h_ring_sweep_base_.data(), sizeof(uint32_t) * nring_, hipMemcpyHostToDevice, st_));
@@ -420,8 +541,17 @@ void FeatureExtractor::run_async() {
                      out_off_[0].p, out_off_[1].p, out_off_[2].p);
   // per-ring voxel grid of the less-flat candidates
   const float inv = 1.0f / params.less_flat_leaf;
-  vox_.compute_ijk(cloud_.p, lf_valid_.p, n_, ring_off_.p, nring_, inv, inv);
-  vox_.sort_reduce(cloud_.p, lf_valid_.p, n_, ring_off_.p, nring_, lf_out_.p, lf_off_.p);
+  if (max_ring_len_ <= LFV_MAX) {
+    uint32_t P = 2;
+    while (P < max_ring_len_) P <<= 1;
+    hipLaunchKernelGGL(k_feat_lf_voxel, dim3(nring_), dim3(LFV_THREADS), (size_t)P * 8, st_, cloud_.p, ring_off_.p, lf_valid_.p, inv, P,
+                       lf_slots_.p, lf_cnt_.p);
+    hipLaunchKernelGGL(k_feat_lf_prefix, dim3(1), dim3(1024), 0, st_, lf_cnt_.p, nring_, lf_off_.p);
+    hipLaunchKernelGGL(k_feat_lf_copy, dim3(nring_), dim3(256), 0, st_, lf_slots_.p, ring_off_.p, lf_cnt_.p, lf_off_.p, lf_out_.p);
+  } else {   // very long rings: generic segmented pipeline (global radix sort)
+    vox_.compute_ijk(cloud_.p, lf_valid_.p, n_, ring_off_.p, nring_, inv, inv);
+    vox_.sort_reduce(cloud_.p, lf_valid_.p, n_, ring_off_.p, nring_, lf_out_.p, lf_off_.p);
+  }
   LX_HIP(hipGetLastError());
 }
 

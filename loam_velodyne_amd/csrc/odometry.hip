@@ -455,6 +455,20 @@ __global__ __launch_bounds__(256) void k_transform_to_end_batch(float4* __restri
   pts[i] = to_end_point(pts[i], P);
 }
 
+// segment k of dst = re-projected copy of src[k] with the parameters of stream sid[k]
+__global__ __launch_bounds__(256) void k_to_end_gather(float4* __restrict__ dst, uint32_t n, const uint32_t* __restrict__ off, uint32_t K,
+                                                       const float4* const* __restrict__ src, const uint32_t* __restrict__ sid,
+                                                       const ToEndParams* __restrict__ params) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t lo = 0, hi = K;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= i) lo = mid; else hi = mid;
+  }
+  dst[i] = to_end_point(src[lo][i - off[lo]], params[sid[lo]]);
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_stream) : device_(device) {
   select_device(device);
@@ -640,6 +654,31 @@ void OdometryBatch::process(const OdomInput* in, int* rc) {
   h_last_off_ = h_cur_off_;
   index_.build(last_.p, h_last_off_.data(), K);
   LX_HIP(hipStreamSynchronize(st_));
+}
+
+void OdometryBatch::to_end_gather(float4* dst, const uint32_t* h_off, const float4* const* src, const uint32_t* stream_id, uint32_t K) {
+  const uint32_t n = h_off[K];
+  if (!n) return;
+  // staging layout in pinned memory: params[ns] | src ptrs[K] | off[K+1] | sid[K]
+  const uint32_t ns = n_streams();
+  const size_t bytes = sizeof(ToEndParams) * ns + sizeof(float4*) * K + sizeof(uint32_t) * (2 * (size_t)K + 2) + 64;
+  h_gather_.reserve(bytes);
+  d_gather_.reserve(bytes);
+  char* h = h_gather_.p;
+  ToEndParams* hp = (ToEndParams*)h;
+  for (uint32_t s = 0; s < ns; s++) hp[s] = to_end_params(s, true);
+  const size_t o_src = (sizeof(ToEndParams) * ns + 15) & ~(size_t)15;
+  const float4** hs = (const float4**)(h + o_src);
+  for (uint32_t k = 0; k < K; k++) hs[k] = src[k];
+  const size_t o_off = o_src + sizeof(float4*) * K;
+  uint32_t* ho = (uint32_t*)(h + o_off);
+  memcpy(ho, h_off, sizeof(uint32_t) * (K + 1));
+  uint32_t* hsid = ho + K + 1;
+  memcpy(hsid, stream_id, sizeof(uint32_t) * K);
+  LX_HIP(hipMemcpyAsync(d_gather_.p, h, o_off + sizeof(uint32_t) * (2 * (size_t)K + 1), hipMemcpyHostToDevice, st_));
+  char* d = d_gather_.p;
+  hipLaunchKernelGGL(k_to_end_gather, dim3((n + 255) / 256), dim3(256), 0, st_, dst, n, (const uint32_t*)(d + o_off), K,
+                     (const float4* const*)(d + o_src), (const uint32_t*)(d + o_off) + K + 1, (const ToEndParams*)d);
 }
 
 int OdometryBatch::process_host(const loamx_cloud* sharp, const loamx_cloud* less_sharp, const loamx_cloud* flat,

@@ -31,7 +31,6 @@ class Pipeline {
     odom.params.max_iterations = oc.max_iterations;
     odom.params.delta_t_abort = oc.delta_t_abort;
     odom.params.delta_r_abort = oc.delta_r_abort;
-    for (uint32_t s = 0; s < n_streams; s++) full_tmp.push_back(std::make_unique<DevBuf<float4>>());
     device = mc.device;
   }
   Registrar reg;
@@ -41,7 +40,6 @@ class Pipeline {
   int device;
   std::vector<PipeStreamState> st;
   std::vector<std::unique_ptr<FeatureExtractor>> fx;   // one staged batch per step
-  std::vector<std::unique_ptr<DevBuf<float4>>> full_tmp;
   PinBuf<uint32_t> h_off;
   float last_ms[4] = {0, 0, 0, 0};
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -98,7 +96,7 @@ class Pipeline {
     odom.process(in.data(), rc.data());
     if (timing) LX_HIP(hipEventRecord(ev[2], s_));
     // ---- registration against the frozen sub-map
-    std::vector<const float4*> cl(ns), sl(ns), fr(ns);
+    std::vector<const float4*> cl(ns), sl(ns), fsrc(ns);
     std::vector<uint32_t> ncl(ns), nsl(ns), nfr(ns), who;
     std::vector<float> guess;
     for (uint32_t s = 0; s < ns; s++) {
@@ -112,18 +110,20 @@ class Pipeline {
       const uint32_t k = (uint32_t)who.size();
       cl[k] = odom.d_last_corner(s); ncl[k] = O.n_last_corner;
       sl[k] = odom.d_last_surf(s); nsl[k] = O.n_last_surf;
-      // the full-resolution cloud is re-projected to the sweep end before it is registered (LaserOdometry.cpp:326)
-      const uint32_t np = F.point_base(s + 1) - F.point_base(s);
-      full_tmp[s]->reserve(np + 1);
-      if (np) LX_HIP(hipMemcpyAsync(full_tmp[s]->p, F.d_cloud() + F.point_base(s), sizeof(float4) * np, hipMemcpyDeviceToDevice, s_));
-      odom.to_end_device(s, full_tmp[s]->p, np);
-      fr[k] = full_tmp[s]->p; nfr[k] = np;
+      fsrc[k] = F.d_cloud() + F.point_base(s);
+      nfr[k] = F.point_base(s + 1) - F.point_base(s);
       who.push_back(s);
     }
     int ret = LOAMX_SKIPPED;
     if (!who.empty()) {
       const uint32_t nw = (uint32_t)who.size();
-      reg.upload_device(nw, cl.data(), ncl.data(), sl.data(), nsl.data(), fr.data(), nfr.data(), guess.data());
+      // the full-resolution clouds are re-projected to the sweep end before they are registered (LaserOdometry.cpp:326):
+      // one fused kernel writes them straight into the registrar's staging area
+      float4* full_dst = reg.stage_full(nw, nfr.data());
+      std::vector<uint32_t> foff(nw + 1, 0);
+      for (uint32_t k = 0; k < nw; k++) foff[k + 1] = foff[k] + nfr[k];
+      odom.to_end_gather(full_dst, foff.data(), fsrc.data(), who.data(), nw);
+      reg.upload_device(nw, cl.data(), ncl.data(), sl.data(), nsl.data(), nullptr, nullptr, guess.data());
       reg.run_async();
       if (timing) LX_HIP(hipEventRecord(ev[3], s_));
       std::vector<float> poses(6 * nw);

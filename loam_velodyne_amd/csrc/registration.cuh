@@ -92,6 +92,9 @@ class Registrar {
   // same with device-resident packed float4 inputs (copied device-to-device; async on the stream)
   void upload_device(uint32_t n_sweeps, const float4* const* corner_last, const uint32_t* n_corner, const float4* const* surf_last,
                      const uint32_t* n_surf, const float4* const* full_res, const uint32_t* n_full, const float* guess6);
+  // reserve the full-resolution staging area for the next upload_device() and return it: the caller fills
+  // [full_offset(s), full_offset(s+1)) itself (e.g. with a fused re-projection kernel) and passes full_res = NULL
+  float4* stage_full(uint32_t n_sweeps, const uint32_t* n_full);
   // device-only: stack round trip + voxel DS + LM iterations (+ full-res registration)
   void run_async();
   void sync();
@@ -128,6 +131,8 @@ class Registrar {
   DevBuf<float4> in_, stack_, ds_pts_, full_;
   DevBuf<uint32_t> seg_off_, full_off_, ds_off_;
   DevBuf<float> guess_;
+  DevBuf<const float4*> src_ptrs_;
+  bool full_staged_ = false;
   VoxelPipeline vox_;
   uint32_t n_in_ = 0, n_full_ = 0, max_q_per_sweep_ = 0;
 

@@ -790,6 +790,15 @@ __global__ __launch_bounds__(256) void k_transform_full(float4* __restrict__ ful
   full[i] = p;
 }
 
+// copy nseg source ranges into one destination array: segment k -> dst[off[k] .. off[k+1])
+__global__ __launch_bounds__(256) void k_gather_segments(float4* __restrict__ dst, const uint32_t* __restrict__ off, uint32_t nseg,
+                                                         const float4* const* __restrict__ src, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = vox_find_seg(off, nseg, i);
+  dst[i] = src[k][i - off[k]];
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // Registrar (host)
 // ----------------------------------------------------------------------------------------------------------------
@@ -802,7 +811,7 @@ Registrar::Registrar(int device, uint32_t max_sweeps) : device_(device), max_swe
   stats_.reserve(max_sweeps);
   matP_.reserve((size_t)36 * max_sweeps);
   guess_.reserve((size_t)6 * max_sweeps);
-  h_guess_.reserve((size_t)16 * max_sweeps + 16);
+  h_guess_.reserve((size_t)64 * max_sweeps + 64);
   seg_off_.reserve(2 * max_sweeps + 2);
   full_off_.reserve(max_sweeps + 2);
   ds_off_.reserve(2 * max_sweeps + 2);
@@ -894,46 +903,65 @@ void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const 
   LX_HIP(hipStreamSynchronize(st_));   // host staging buffers are reused by the caller after return
 }
 
+float4* Registrar::stage_full(uint32_t n_sweeps, const uint32_t* n_full) {
+  LX_REQUIRE(n_sweeps >= 1 && n_sweeps <= max_sweeps_, "n_sweeps out of range for this handle");
+  h_full_off_.assign(n_sweeps + 1, 0);
+  for (uint32_t s = 0; s < n_sweeps; s++) h_full_off_[s + 1] = h_full_off_[s] + n_full[s];
+  n_full_ = h_full_off_[n_sweeps];
+  full_.reserve((size_t)n_full_ + 1);
+  full_staged_ = true;
+  return full_.p;
+}
+
 void Registrar::upload_device(uint32_t n_sweeps, const float4* const* corner_last, const uint32_t* n_corner,
                               const float4* const* surf_last, const uint32_t* n_surf, const float4* const* full_res,
                               const uint32_t* n_full, const float* guess6) {
   LX_REQUIRE(n_sweeps >= 1 && n_sweeps <= max_sweeps_, "n_sweeps out of range for this handle");
   LX_HIP(hipSetDevice(device_));
   n_sweeps_ = n_sweeps;
+  const bool staged = full_staged_ && !full_res;   // the caller wrote the full-resolution clouds through stage_full()
+  full_staged_ = false;
   h_seg_off_.assign(2 * n_sweeps + 1, 0);
-  h_full_off_.assign(n_sweeps + 1, 0);
+  if (!staged) h_full_off_.assign(n_sweeps + 1, 0);
   max_q_per_sweep_ = 0;
   for (uint32_t s = 0; s < n_sweeps; s++) {
     h_seg_off_[2 * s + 1] = h_seg_off_[2 * s] + n_corner[s];
     h_seg_off_[2 * s + 2] = h_seg_off_[2 * s + 1] + n_surf[s];
     max_q_per_sweep_ = std::max(max_q_per_sweep_, n_corner[s] + n_surf[s]);
-    h_full_off_[s + 1] = h_full_off_[s] + (full_res ? n_full[s] : 0u);
+    if (!staged) h_full_off_[s + 1] = h_full_off_[s] + (full_res ? n_full[s] : 0u);
   }
   n_in_ = h_seg_off_[2 * n_sweeps];
-  n_full_ = h_full_off_[n_sweeps];
+  if (!staged) n_full_ = h_full_off_[n_sweeps];
   in_.reserve(n_in_ + 1);
   stack_.reserve(n_in_ + 1);
   ds_pts_.reserve(n_in_ + 1);
   vox_.reserve(n_in_ + 1, 2 * n_sweeps);
   LX_REQUIRE(n_in_ < SCAN_MAX_N, "too many feature points in one batch");
-  for (uint32_t s = 0; s < n_sweeps; s++) {
-    if (n_corner[s]) LX_HIP(hipMemcpyAsync(in_.p + h_seg_off_[2 * s], corner_last[s], sizeof(float4) * n_corner[s], hipMemcpyDeviceToDevice, st_));
-    if (n_surf[s]) LX_HIP(hipMemcpyAsync(in_.p + h_seg_off_[2 * s + 1], surf_last[s], sizeof(float4) * n_surf[s], hipMemcpyDeviceToDevice, st_));
-  }
-  // offsets / guesses go through the pinned buffers owned by this object (valid until the next upload)
-  h_guess_.reserve((size_t)6 * n_sweeps + 2 * (3 * (size_t)n_sweeps + 2));
+  // offsets / guesses / source pointers go through pinned memory owned by this object (valid until the next upload)
+  const size_t nseg = 2 * (size_t)n_sweeps;
+  h_guess_.reserve((size_t)6 * n_sweeps + 2 * (3 * (size_t)n_sweeps + 2) + 4 * (nseg + n_sweeps + 2));
   memcpy(h_guess_.p, guess6, sizeof(float) * 6 * n_sweeps);
   uint32_t* hoff = (uint32_t*)(h_guess_.p + 6 * n_sweeps);
-  memcpy(hoff, h_seg_off_.data(), sizeof(uint32_t) * (2 * n_sweeps + 1));
-  uint32_t* hfull = hoff + (2 * n_sweeps + 1);
+  memcpy(hoff, h_seg_off_.data(), sizeof(uint32_t) * (nseg + 1));
+  uint32_t* hfull = hoff + (nseg + 1);
   memcpy(hfull, h_full_off_.data(), sizeof(uint32_t) * (n_sweeps + 1));
+  const float4** hsrc = (const float4**)(((uintptr_t)(hfull + n_sweeps + 1) + 15) & ~(uintptr_t)15);
+  for (uint32_t s = 0; s < n_sweeps; s++) { hsrc[2 * s] = corner_last[s]; hsrc[2 * s + 1] = surf_last[s]; }
+  const float4** hfsrc = hsrc + nseg;
+  if (full_res) for (uint32_t s = 0; s < n_sweeps; s++) hfsrc[s] = full_res[s];
+  src_ptrs_.reserve(nseg + n_sweeps + 2);
   LX_HIP(hipMemcpyAsync(guess_.p, h_guess_.p, sizeof(float) * 6 * n_sweeps, hipMemcpyHostToDevice, st_));
-  LX_HIP(hipMemcpyAsync(seg_off_.p, hoff, sizeof(uint32_t) * (2 * n_sweeps + 1), hipMemcpyHostToDevice, st_));
+  LX_HIP(hipMemcpyAsync(seg_off_.p, hoff, sizeof(uint32_t) * (nseg + 1), hipMemcpyHostToDevice, st_));
+  LX_HIP(hipMemcpyAsync(src_ptrs_.p, hsrc, sizeof(float4*) * (nseg + n_sweeps), hipMemcpyHostToDevice, st_));
+  if (n_in_)
+    hipLaunchKernelGGL(k_gather_segments, dim3((n_in_ + 255) / 256), dim3(256), 0, st_, in_.p, seg_off_.p, (uint32_t)nseg,
+                       (const float4* const*)src_ptrs_.p, n_in_);
   if (n_full_) {
     full_.reserve(n_full_);
-    for (uint32_t s = 0; s < n_sweeps; s++)
-      if (n_full[s]) LX_HIP(hipMemcpyAsync(full_.p + h_full_off_[s], full_res[s], sizeof(float4) * n_full[s], hipMemcpyDeviceToDevice, st_));
     LX_HIP(hipMemcpyAsync(full_off_.p, hfull, sizeof(uint32_t) * (n_sweeps + 1), hipMemcpyHostToDevice, st_));
+    if (!staged)
+      hipLaunchKernelGGL(k_gather_segments, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, full_off_.p, n_sweeps,
+                         (const float4* const*)(src_ptrs_.p + nseg), n_full_);
   }
   nblk_ = (max_q_per_sweep_ + LX_RES_THREADS - 1) / LX_RES_THREADS;
   if (nblk_ == 0) nblk_ = 1;

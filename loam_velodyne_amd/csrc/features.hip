@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
 // and every voxel run is averaged by one thread in input order.  Same membership, order and float arithmetic as the
 // generic VoxelPipeline (which remains the fallback for longer rings); output goes to the ring's own slot range.
 // ----------------------------------------------------------------------------------------------------------------
-constexpr int LFV_THREADS = 256;
+constexpr int LFV_THREADS = 1024;
 constexpr uint32_t LFV_MAX = 4096;
 
 __global__ __launch_bounds__(LFV_THREADS) void k_feat_lf_voxel(const float4* __restrict__ cloud, const uint32_t* __restrict__ ring_off,

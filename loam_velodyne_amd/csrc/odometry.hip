@@ -278,10 +278,9 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
 
   for (int iter = iter0; iter < iter0 + n_iters; iter++) {
     // ---- phase C: residual rows + normal equations
-    if (tid == 0) {
-      trig[0] = (float)sin((double)T[0]); trig[1] = (float)cos((double)T[0]);
-      trig[2] = (float)sin((double)T[1]); trig[3] = (float)cos((double)T[1]);
-      trig[4] = (float)sin((double)T[2]); trig[5] = (float)cos((double)T[2]);
+    if (tid < 6) {   // sin/cos of the three angles, one per lane, double then rounded (see pose_set_angles)
+      const double ang = (double)T[tid >> 1];
+      trig[tid] = (float)((tid & 1) ? cos(ang) : sin(ang));
     }
     __syncthreads();
     double v[LX_NSUM];
@@ -374,18 +373,22 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
       double x = 0.0;
       for (int w = 0; w < OD_WAVES; w++) x += red[w][tid];
       sums[tid] = x;
+      // scatter straight into the symmetric 6x6 / right-hand side (sum index t -> (i, j) of the upper triangle)
+      if (tid < 21) {
+        int i = 0, rem = tid;
+        while (rem >= 6 - i) { rem -= 6 - i; i++; }
+        const int j = i + rem;
+        AtA[i * 6 + j] = AtA[j * 6 + i] = (float)x;
+      } else if (tid < 27) {
+        AtB[tid - 21] = (float)x;
+      }
     }
     __syncthreads();
     const int sel = (int)sums[27];   // block-uniform
     if (tid == 0) {
       pb.stats.iterations = iter + 1;
       pb.stats.sel = sel;
-      int k = 0;
-      for (int i = 0; i < 6; i++)
-        for (int j = i; j < 6; j++) { AtA[i * 6 + j] = AtA[j * 6 + i] = (float)sums[k]; k++; }
-      for (int i = 0; i < 6; i++) AtB[i] = (float)sums[21 + i];
     }
-    __syncthreads();
     if (sel >= 10 && tid < 64) qr_solve6_coop(AtA, AtB, X);   // wave 0, all lanes (:559)
     __syncthreads();
     if (tid == 0) {

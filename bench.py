@@ -198,7 +198,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": None,
+                "traffic": pmc_traffic(),
+                "traffic_note": "bytes of one FULL-SEARCH launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, "
+                                "profiles/r01_pmc_summary.json); achieved/avg_launch_us average over all timed launches incl. "
+                                "the no-op launches after convergence",
                 "avg_launch_us": round(avg_launch_ms * 1e3, 3),
                 "launches": res_launches,
                 "algorithmic_bytes_per_launch": round(72.0 * q_iters / max(res_launches, 1), 1),
@@ -210,6 +213,18 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per full-search launch of the dominant kernel from the committed PMC passes of this same command
+    (profiles/r01_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs, FETCH_SIZE
+    doubled per MI355X_MICROARCH.md).  bench.py cannot run the profiler on itself, so the figure is read, not measured
+    live; None when the file is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            return json.load(f)["k_knn5_full_search_launch"]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(sweeps, starts, map_t):

@@ -40,16 +40,49 @@ class Pipeline {
   int device;
   std::vector<PipeStreamState> st;
   std::vector<std::unique_ptr<FeatureExtractor>> fx;   // one staged batch per step
-  PinBuf<uint32_t> h_off;
+  // feature extraction of step t+1 is independent of odometry / registration of step t (in the reference they are
+  // different ROS nodes): it runs on its own HIP stream, launched one step ahead, and overlaps with them
+  hipStream_t fstream = nullptr;
+  bool prefetch = true;
+  std::vector<char> launched;
+  PinBuf<uint32_t> h_off2[2];
+  hipEvent_t evF[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   float last_ms[4] = {0, 0, 0, 0};
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool timing = false;
 
+  ~Pipeline() {
+    fx.clear();
+    for (auto& a : evF) for (auto& e : a) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (fstream) (void)hipStreamDestroy(fstream);
+  }
+
+  void launch_features(uint32_t t) {
+    FeatureExtractor& F = *fx[t];
+    const uint32_t ns = n_streams_, nring = F.total_rings();
+    PinBuf<uint32_t>& hb = h_off2[t & 1];
+    hb.reserve(3 * (ns + 1) + nring + 2);
+    uint32_t* ho[3] = {hb.p, hb.p + (ns + 1), hb.p + 2 * (ns + 1)};
+    uint32_t* hlf = hb.p + 3 * (ns + 1);
+    for (auto& e : evF[t & 1]) if (!e) LX_HIP(hipEventCreate(&e));
+    LX_HIP(hipEventRecord(evF[t & 1][0], fstream));
+    F.run_async();
+    for (int k = 0; k < 3; k++) LX_HIP(hipMemcpyAsync(ho[k], F.d_feat_off(k), sizeof(uint32_t) * (ns + 1), hipMemcpyDeviceToHost, fstream));
+    LX_HIP(hipMemcpyAsync(hlf, F.d_less_flat_ring_off(), sizeof(uint32_t) * (nring + 1), hipMemcpyDeviceToHost, fstream));
+    LX_HIP(hipEventRecord(evF[t & 1][1], fstream));
+    launched[t] = 1;
+  }
+
   void upload(uint32_t n_steps, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
     LX_REQUIRE(n_steps >= 1 && clouds && ring_size && n_rings, "invalid argument");
+    LX_HIP(hipSetDevice(device));
+    if (!fstream) LX_HIP(hipStreamCreateWithFlags(&fstream, hipStreamNonBlocking));
+    LX_HIP(hipStreamSynchronize(fstream));
     fx.clear();
+    launched.assign(n_steps, 0);
     for (uint32_t t = 0; t < n_steps; t++) {
-      auto f = std::make_unique<FeatureExtractor>(device, reg.stream());
+      auto f = std::make_unique<FeatureExtractor>(device, fstream);
       FeatParams& p = f->params;
       p.scan_period = fcfg.scan_period;
       p.n_regions = fcfg.n_feature_regions;
@@ -75,16 +108,15 @@ class Pipeline {
         if (!e) LX_HIP(hipEventCreate(&e));
       LX_HIP(hipEventRecord(ev[0], s_));
     }
-    // ---- features
-    F.run_async();
-    const uint32_t nring = F.total_rings();
-    h_off.reserve(3 * (ns + 1) + nring + 2);
-    uint32_t* ho[3] = {h_off.p, h_off.p + (ns + 1), h_off.p + 2 * (ns + 1)};
-    uint32_t* hlf = h_off.p + 3 * (ns + 1);
-    for (int k = 0; k < 3; k++) LX_HIP(hipMemcpyAsync(ho[k], F.d_feat_off(k), sizeof(uint32_t) * (ns + 1), hipMemcpyDeviceToHost, s_));
-    LX_HIP(hipMemcpyAsync(hlf, F.d_less_flat_ring_off(), sizeof(uint32_t) * (nring + 1), hipMemcpyDeviceToHost, s_));
+    // ---- features: this step's (launched one step ahead when possible), then prefetch the next step's
+    if (!launched[t]) launch_features(t);
+    if (prefetch && t + 1 < fx.size() && !launched[t + 1]) launch_features(t + 1);
+    uint32_t* hb = h_off2[t & 1].p;
+    uint32_t* ho[3] = {hb, hb + (ns + 1), hb + 2 * (ns + 1)};
+    uint32_t* hlf = hb + 3 * (ns + 1);
+    LX_HIP(hipEventSynchronize(evF[t & 1][1]));
+    launched[t] = 0;
     if (timing) LX_HIP(hipEventRecord(ev[1], s_));
-    LX_HIP(hipStreamSynchronize(s_));
     // ---- odometry
     std::vector<OdomInput> in(ns);
     std::vector<int> rc(ns, 0);
@@ -146,7 +178,8 @@ class Pipeline {
     }
     if (timing) {
       LX_HIP(hipEventSynchronize(ev[3]));
-      for (int k = 0; k < 3; k++) LX_HIP(hipEventElapsedTime(&last_ms[k], ev[k], ev[k + 1]));
+      for (int k = 1; k < 3; k++) LX_HIP(hipEventElapsedTime(&last_ms[k], ev[k], ev[k + 1]));
+      LX_HIP(hipEventElapsedTime(&last_ms[0], evF[t & 1][0], evF[t & 1][1]));   // on the feature stream (overlapped)
       LX_HIP(hipEventElapsedTime(&last_ms[3], ev[0], ev[3]));
     }
     return ret;

@@ -220,6 +220,11 @@ int loamx_pipeline_get(loamx_pipeline* h, uint32_t stream, float* transform, flo
                        int* stats8);
 /* registered full-resolution cloud of the k-th stream that was registered in the last step */
 int loamx_pipeline_download_full_res(loamx_pipeline* h, uint32_t slot, loamx_cloud* out);
+/* Look-ahead (default on): while step t's registration runs, the odometry of step t+1 and the feature extraction of
+ * step t+2 already execute on their own HIP streams (they are independent ROS nodes in the reference).  Results are
+ * identical; loamx_pipeline_get() always reports the sweep that was registered last.  Turn it off when per-stream
+ * state is changed with loamx_pipeline_set_state() between steps. */
+int loamx_pipeline_set_lookahead(loamx_pipeline* h, int on);
 int loamx_pipeline_set_timing(loamx_pipeline* h, int on);
 /* stage_ms: features, odometry, registration, whole step (HIP events on the pipeline's stream);
  * reg_ms / counts as loamx_batch_get_timing */

@@ -80,8 +80,10 @@ class OdometryBatch {
   int transform_to_end_host(uint32_t s, loamx_cloud* cloud);
   // in place on device points with stream s's current transform (async on the stream)
   void to_end_device(uint32_t s, float4* pts, uint32_t n);
-  // dst[h_off[k] .. h_off[k+1]) = transformToEnd(src[k]) with stream stream_id[k]'s current transform; one launch
-  void to_end_gather(float4* dst, const uint32_t* h_off, const float4* const* src, const uint32_t* stream_id, uint32_t K);
+  // dst[h_off[k] .. h_off[k+1]) = transformToEnd(src[k]) with seg_params[k]; one launch on `stream`
+  void to_end_gather(float4* dst, const uint32_t* h_off, const float4* const* src, const ToEndParams* seg_params, uint32_t K,
+                     hipStream_t stream);
+  ToEndParams to_end_params(uint32_t s, bool enabled) const;
   // device views of the re-projected clouds handed on to mapping
   const float4* d_last_corner(uint32_t s) const { return last_.p + h_last_off_[s]; }
   const float4* d_last_surf(uint32_t s) const { return last_.p + h_last_off_[n_streams() + s]; }
@@ -106,7 +108,6 @@ class OdometryBatch {
   DevBuf<float4> up_[4], tmp_cloud_;
   PinBuf<char> h_gather_;
   DevBuf<char> d_gather_;
-  ToEndParams to_end_params(uint32_t s, bool enabled) const;
 };
 
 }  // namespace loamx

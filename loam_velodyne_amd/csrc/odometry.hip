@@ -659,17 +659,18 @@ void OdometryBatch::process(const OdomInput* in, int* rc) {
   LX_HIP(hipStreamSynchronize(st_));
 }
 
-void OdometryBatch::to_end_gather(float4* dst, const uint32_t* h_off, const float4* const* src, const uint32_t* stream_id, uint32_t K) {
+void OdometryBatch::to_end_gather(float4* dst, const uint32_t* h_off, const float4* const* src, const ToEndParams* seg_params, uint32_t K,
+                                  hipStream_t stream) {
   const uint32_t n = h_off[K];
   if (!n) return;
-  // staging layout in pinned memory: params[ns] | src ptrs[K] | off[K+1] | sid[K]
-  const uint32_t ns = n_streams();
+  // staging layout in pinned memory: params[K] | src ptrs[K] | off[K+1] | sid[K] (sid[k] = k)
+  const uint32_t ns = K;
   const size_t bytes = sizeof(ToEndParams) * ns + sizeof(float4*) * K + sizeof(uint32_t) * (2 * (size_t)K + 2) + 64;
   h_gather_.reserve(bytes);
   d_gather_.reserve(bytes);
   char* h = h_gather_.p;
   ToEndParams* hp = (ToEndParams*)h;
-  for (uint32_t s = 0; s < ns; s++) hp[s] = to_end_params(s, true);
+  for (uint32_t s = 0; s < ns; s++) hp[s] = seg_params[s];
   const size_t o_src = (sizeof(ToEndParams) * ns + 15) & ~(size_t)15;
   const float4** hs = (const float4**)(h + o_src);
   for (uint32_t k = 0; k < K; k++) hs[k] = src[k];
@@ -677,10 +678,10 @@ void OdometryBatch::to_end_gather(float4* dst, const uint32_t* h_off, const floa
   uint32_t* ho = (uint32_t*)(h + o_off);
   memcpy(ho, h_off, sizeof(uint32_t) * (K + 1));
   uint32_t* hsid = ho + K + 1;
-  memcpy(hsid, stream_id, sizeof(uint32_t) * K);
-  LX_HIP(hipMemcpyAsync(d_gather_.p, h, o_off + sizeof(uint32_t) * (2 * (size_t)K + 1), hipMemcpyHostToDevice, st_));
+  for (uint32_t k = 0; k < K; k++) hsid[k] = k;
+  LX_HIP(hipMemcpyAsync(d_gather_.p, h, o_off + sizeof(uint32_t) * (2 * (size_t)K + 1), hipMemcpyHostToDevice, stream));
   char* d = d_gather_.p;
-  hipLaunchKernelGGL(k_to_end_gather, dim3((n + 255) / 256), dim3(256), 0, st_, dst, n, (const uint32_t*)(d + o_off), K,
+  hipLaunchKernelGGL(k_to_end_gather, dim3((n + 255) / 256), dim3(256), 0, stream, dst, n, (const uint32_t*)(d + o_off), K,
                      (const float4* const*)(d + o_src), (const uint32_t*)(d + o_off) + K + 1, (const ToEndParams*)d);
 }
 

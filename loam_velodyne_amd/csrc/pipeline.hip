@@ -12,8 +12,19 @@
 
 namespace loamx {
 
+// what odometry hands on to the registration of the same sweep
+struct OdomPub {
+  HTwist transform, transform_sum;
+  OdomStats stats = {0, 0, 0, 0};
+  int rc = LOAMX_SKIPPED;
+  const float4* last_corner = nullptr; uint32_t n_last_corner = 0;
+  const float4* last_surf = nullptr; uint32_t n_last_surf = 0;
+  ToEndParams to_end;
+};
+
 struct PipeStreamState {
   HTwist bef, aft, tobe, incre;   // mapping-side transforms (transformSum comes from the odometry stream)
+  OdomPub cur, next;              // odometry results of the step being registered / of the look-ahead step
   SweepStats map_stats = {0, 0, 0, 0, 0, 0, 0, 0};
   bool mapped = false;
 };
@@ -21,7 +32,7 @@ struct PipeStreamState {
 class Pipeline {
  public:
   Pipeline(const loamx_scanreg_config& fc, const loamx_odom_config& oc, const loamx_map_config& mc, uint32_t n_streams)
-      : reg(mc.device, n_streams), odom(mc.device, n_streams, reg.stream()), fcfg(fc), n_streams_(n_streams), st(n_streams) {
+      : reg(mc.device, n_streams), odom(mc.device, n_streams, nullptr), fcfg(fc), n_streams_(n_streams), st(n_streams) {
     reg.params.max_iterations = mc.max_iterations;
     reg.params.delta_t_abort = mc.delta_t_abort;
     reg.params.delta_r_abort = mc.delta_r_abort;
@@ -45,8 +56,11 @@ class Pipeline {
   hipStream_t fstream = nullptr;
   bool prefetch = true;
   std::vector<char> launched;
-  PinBuf<uint32_t> h_off2[2];
-  hipEvent_t evF[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  PinBuf<uint32_t> h_off3[3];
+  hipEvent_t evF[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  hipEvent_t evO[2] = {nullptr, nullptr};
+  float feat_ms[3] = {0, 0, 0}, odom_ms = 0, odom_ms_next = 0;
+  int odom_ready_step = -1;
   float last_ms[4] = {0, 0, 0, 0};
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool timing = false;
@@ -55,22 +69,23 @@ class Pipeline {
     fx.clear();
     for (auto& a : evF) for (auto& e : a) if (e) (void)hipEventDestroy(e);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : evO) if (e) (void)hipEventDestroy(e);
     if (fstream) (void)hipStreamDestroy(fstream);
   }
 
   void launch_features(uint32_t t) {
     FeatureExtractor& F = *fx[t];
     const uint32_t ns = n_streams_, nring = F.total_rings();
-    PinBuf<uint32_t>& hb = h_off2[t & 1];
+    PinBuf<uint32_t>& hb = h_off3[t % 3];
     hb.reserve(3 * (ns + 1) + nring + 2);
     uint32_t* ho[3] = {hb.p, hb.p + (ns + 1), hb.p + 2 * (ns + 1)};
     uint32_t* hlf = hb.p + 3 * (ns + 1);
-    for (auto& e : evF[t & 1]) if (!e) LX_HIP(hipEventCreate(&e));
-    LX_HIP(hipEventRecord(evF[t & 1][0], fstream));
+    for (auto& e : evF[t % 3]) if (!e) LX_HIP(hipEventCreate(&e));
+    LX_HIP(hipEventRecord(evF[t % 3][0], fstream));
     F.run_async();
     for (int k = 0; k < 3; k++) LX_HIP(hipMemcpyAsync(ho[k], F.d_feat_off(k), sizeof(uint32_t) * (ns + 1), hipMemcpyDeviceToHost, fstream));
     LX_HIP(hipMemcpyAsync(hlf, F.d_less_flat_ring_off(), sizeof(uint32_t) * (nring + 1), hipMemcpyDeviceToHost, fstream));
-    LX_HIP(hipEventRecord(evF[t & 1][1], fstream));
+    LX_HIP(hipEventRecord(evF[t % 3][1], fstream));
     launched[t] = 1;
   }
 
@@ -81,6 +96,7 @@ class Pipeline {
     LX_HIP(hipStreamSynchronize(fstream));
     fx.clear();
     launched.assign(n_steps, 0);
+    odom_ready_step = -1;
     for (uint32_t t = 0; t < n_steps; t++) {
       auto f = std::make_unique<FeatureExtractor>(device, fstream);
       FeatParams& p = f->params;
@@ -97,27 +113,17 @@ class Pipeline {
     }
   }
 
-  int step(uint32_t t) {
-    LX_REQUIRE(t < fx.size(), "step index beyond the staged sweeps");
-    LX_HIP(hipSetDevice(device));
-    hipStream_t s_ = reg.stream();
+  // odometry of staged step t for every stream (needs its features); results go to st[s].next
+  void run_odometry(uint32_t t) {
     const uint32_t ns = n_streams_;
     FeatureExtractor& F = *fx[t];
-    if (timing) {
-      for (auto& e : ev)
-        if (!e) LX_HIP(hipEventCreate(&e));
-      LX_HIP(hipEventRecord(ev[0], s_));
-    }
-    // ---- features: this step's (launched one step ahead when possible), then prefetch the next step's
     if (!launched[t]) launch_features(t);
-    if (prefetch && t + 1 < fx.size() && !launched[t + 1]) launch_features(t + 1);
-    uint32_t* hb = h_off2[t & 1].p;
+    uint32_t* hb = h_off3[t % 3].p;
     uint32_t* ho[3] = {hb, hb + (ns + 1), hb + 2 * (ns + 1)};
     uint32_t* hlf = hb + 3 * (ns + 1);
-    LX_HIP(hipEventSynchronize(evF[t & 1][1]));
+    LX_HIP(hipEventSynchronize(evF[t % 3][1]));
     launched[t] = 0;
-    if (timing) LX_HIP(hipEventRecord(ev[1], s_));
-    // ---- odometry
+    if (timing) LX_HIP(hipEventElapsedTime(&feat_ms[t % 3], evF[t % 3][0], evF[t % 3][1]));
     std::vector<OdomInput> in(ns);
     std::vector<int> rc(ns, 0);
     for (uint32_t s = 0; s < ns; s++) {
@@ -125,39 +131,95 @@ class Pipeline {
       in[s] = OdomInput{F.d_feat(0) + ho[0][s], ho[0][s + 1] - ho[0][s], F.d_feat(1) + ho[1][s], ho[1][s + 1] - ho[1][s],
                         F.d_feat(2) + ho[2][s], ho[2][s + 1] - ho[2][s], F.d_less_flat() + la, lb - la};
     }
-    odom.process(in.data(), rc.data());
-    if (timing) LX_HIP(hipEventRecord(ev[2], s_));
-    // ---- registration against the frozen sub-map
+    if (timing) {
+      if (!evO[0]) { LX_HIP(hipEventCreate(&evO[0])); LX_HIP(hipEventCreate(&evO[1])); }
+      LX_HIP(hipEventRecord(evO[0], odom.stream()));
+    }
+    odom.process(in.data(), rc.data());   // synchronous on the odometry stream
+    if (timing) {
+      LX_HIP(hipEventRecord(evO[1], odom.stream()));
+      LX_HIP(hipEventSynchronize(evO[1]));
+      LX_HIP(hipEventElapsedTime(&odom_ms_next, evO[0], evO[1]));
+    }
+    for (uint32_t s = 0; s < ns; s++) {
+      OdomStream& O = odom.stream_state(s);
+      OdomPub& N = st[s].next;
+      N.transform = O.transform;
+      N.transform_sum = O.transform_sum;
+      N.stats = O.stats;
+      N.rc = rc[s];
+      N.last_corner = odom.d_last_corner(s); N.n_last_corner = O.n_last_corner;
+      N.last_surf = odom.d_last_surf(s); N.n_last_surf = O.n_last_surf;
+      N.to_end = odom.to_end_params(s, true);
+    }
+    odom_ready_step = (int)t;
+  }
+
+  // Software pipeline over consecutive steps (the stages are separate ROS nodes in the reference, so nothing in a later
+  // stage of step t feeds an earlier stage of step t+1):
+  //   registration M(t) on the registrar's stream  ||  odometry O(t+1) on the odometry stream  ||  features F(t+2)
+  // step(t) returns when M(t) is complete; O(t+1) / F(t+2) are look-ahead whose results are kept for the next call.
+  int step(uint32_t t) {
+    LX_REQUIRE(t < fx.size(), "step index beyond the staged sweeps");
+    LX_HIP(hipSetDevice(device));
+    hipStream_t s_ = reg.stream();
+    const uint32_t ns = n_streams_;
+    if (timing) {
+      for (auto& e : ev)
+        if (!e) LX_HIP(hipEventCreate(&e));
+    }
+    // ---- this step's odometry: from the look-ahead of the previous call, or now
+    if (odom_ready_step != (int)t) {
+      if (prefetch && t + 1 < fx.size() && !launched[t + 1]) { if (!launched[t]) launch_features(t); launch_features(t + 1); }
+      run_odometry(t);
+    }
+    odom_ms = odom_ms_next;
+    for (uint32_t s = 0; s < ns; s++) st[s].cur = st[s].next;
+    odom_ready_step = -1;
+    FeatureExtractor& F = *fx[t];
+    const float f_ms = feat_ms[t % 3];
+    // ---- registration against the frozen sub-map: enqueue everything for M(t) (asynchronous)
+    if (timing) LX_HIP(hipEventRecord(ev[0], s_));
     std::vector<const float4*> cl(ns), sl(ns), fsrc(ns);
     std::vector<uint32_t> ncl(ns), nsl(ns), nfr(ns), who;
     std::vector<float> guess;
+    std::vector<ToEndParams> tep;
     for (uint32_t s = 0; s < ns; s++) {
-      if (rc[s] != LOAMX_OK) continue;   // a stream's first sweep only initialises the odometry
-      OdomStream& O = odom.stream_state(s);
       PipeStreamState& P = st[s];
-      transform_associate_to_map(O.transform_sum, P.bef, P.aft, P.incre, P.tobe);
+      if (P.cur.rc != LOAMX_OK) continue;   // a stream's first sweep only initialises the odometry
+      transform_associate_to_map(P.cur.transform_sum, P.bef, P.aft, P.incre, P.tobe);
       float g[6];
       P.tobe.get(g);
       guess.insert(guess.end(), g, g + 6);
       const uint32_t k = (uint32_t)who.size();
-      cl[k] = odom.d_last_corner(s); ncl[k] = O.n_last_corner;
-      sl[k] = odom.d_last_surf(s); nsl[k] = O.n_last_surf;
+      cl[k] = P.cur.last_corner; ncl[k] = P.cur.n_last_corner;
+      sl[k] = P.cur.last_surf; nsl[k] = P.cur.n_last_surf;
       fsrc[k] = F.d_cloud() + F.point_base(s);
       nfr[k] = F.point_base(s + 1) - F.point_base(s);
+      tep.push_back(P.cur.to_end);
       who.push_back(s);
     }
-    int ret = LOAMX_SKIPPED;
-    if (!who.empty()) {
-      const uint32_t nw = (uint32_t)who.size();
+    const uint32_t nw = (uint32_t)who.size();
+    if (nw) {
       // the full-resolution clouds are re-projected to the sweep end before they are registered (LaserOdometry.cpp:326):
       // one fused kernel writes them straight into the registrar's staging area
       float4* full_dst = reg.stage_full(nw, nfr.data());
       std::vector<uint32_t> foff(nw + 1, 0);
       for (uint32_t k = 0; k < nw; k++) foff[k + 1] = foff[k] + nfr[k];
-      odom.to_end_gather(full_dst, foff.data(), fsrc.data(), who.data(), nw);
+      odom.to_end_gather(full_dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
       reg.upload_device(nw, cl.data(), ncl.data(), sl.data(), nsl.data(), nullptr, nullptr, guess.data());
       reg.run_async();
-      if (timing) LX_HIP(hipEventRecord(ev[3], s_));
+    }
+    if (timing) LX_HIP(hipEventRecord(ev[1], s_));
+    // ---- look-ahead while M(t) runs: features of step t+2, odometry of step t+1
+    if (prefetch && t + 1 < fx.size()) {
+      if (!launched[t + 1]) launch_features(t + 1);
+      if (t + 2 < fx.size() && !launched[t + 2]) launch_features(t + 2);
+      run_odometry(t + 1);
+    }
+    // ---- finish M(t)
+    int ret = LOAMX_SKIPPED;
+    if (nw) {
       std::vector<float> poses(6 * nw);
       std::vector<SweepStats> ss(nw);
       reg.download(poses.data(), nullptr);
@@ -168,19 +230,18 @@ class Pipeline {
         P.mapped = true;
         if (reg.submap_sufficient()) {   // transformUpdate (BasicLaserMapping.cpp:171-203, :628-629)
           P.tobe.set(&poses[6 * k]);
-          P.bef = odom.stream_state(who[k]).transform_sum;
+          P.bef = P.cur.transform_sum;
           P.aft = P.tobe;
         }
       }
       ret = LOAMX_OK;
-    } else if (timing) {
-      LX_HIP(hipEventRecord(ev[3], s_));
     }
     if (timing) {
-      LX_HIP(hipEventSynchronize(ev[3]));
-      for (int k = 1; k < 3; k++) LX_HIP(hipEventElapsedTime(&last_ms[k], ev[k], ev[k + 1]));
-      LX_HIP(hipEventElapsedTime(&last_ms[0], evF[t & 1][0], evF[t & 1][1]));   // on the feature stream (overlapped)
-      LX_HIP(hipEventElapsedTime(&last_ms[3], ev[0], ev[3]));
+      LX_HIP(hipEventSynchronize(ev[1]));
+      last_ms[0] = f_ms;       // on the feature stream (overlapped)
+      last_ms[1] = odom_ms;    // on the odometry stream (overlapped with the previous step's registration)
+      LX_HIP(hipEventElapsedTime(&last_ms[2], ev[0], ev[1]));
+      last_ms[3] = last_ms[2];
     }
     return ret;
   }
@@ -232,6 +293,7 @@ int loamx_pipeline_set_state(loamx_pipeline* h, uint32_t stream, const float* tr
     LX_REQUIRE(h && stream < h->p.n_streams_, "invalid stream");
     if (transform) h->p.odom.stream_state(stream).transform.set(transform);
     if (transform_sum) h->p.odom.stream_state(stream).transform_sum.set(transform_sum);
+    h->p.odom_ready_step = -1;   // any look-ahead was computed from the old state
     if (bef) h->p.st[stream].bef.set(bef);
     if (aft) h->p.st[stream].aft.set(aft);
     return LOAMX_OK;
@@ -247,8 +309,8 @@ int loamx_pipeline_step(loamx_pipeline* h, uint32_t step) {
 int loamx_pipeline_get(loamx_pipeline* h, uint32_t stream, float* transform, float* transform_sum, float* aft, int* stats8) {
   return guard([&]() {
     LX_REQUIRE(h && stream < h->p.n_streams_, "invalid stream");
-    OdomStream& O = h->p.odom.stream_state(stream);
     PipeStreamState& P = h->p.st[stream];
+    const OdomPub& O = P.cur;   // the sweep that was registered last (odometry itself may already be one sweep ahead)
     if (transform) O.transform.get(transform);
     if (transform_sum) O.transform_sum.get(transform_sum);
     if (aft) P.aft.get(aft);
@@ -261,6 +323,13 @@ int loamx_pipeline_get(loamx_pipeline* h, uint32_t stream, float* transform, flo
 }
 int loamx_pipeline_download_full_res(loamx_pipeline* h, uint32_t slot, loamx_cloud* out) {
   return guard([&]() { LX_REQUIRE(h && out, "NULL argument"); return h->p.reg.download_full_res(slot, out); });
+}
+int loamx_pipeline_set_lookahead(loamx_pipeline* h, int on) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    h->p.prefetch = on != 0;
+    return LOAMX_OK;
+  });
 }
 int loamx_pipeline_set_timing(loamx_pipeline* h, int on) {
   return guard([&]() {

@@ -73,7 +73,9 @@ class OdometryBatch {
   void update_imu(uint32_t s, const float* t12);
   // one sweep for EVERY stream, inputs already on the device (same HIP stream or synchronised).  Synchronous.
   // rc[s] = LOAMX_SKIPPED for a stream's first (initialising) sweep.
-  void process(const OdomInput* in, int* rc);
+  // defer_tail: return once the poses are known; the re-projected clouds / their index are ready at tail_event()
+  void process(const OdomInput* in, int* rc, bool defer_tail = false);
+  hipEvent_t tail_event() const { return tail_pending_ ? ev_tail_ : nullptr; }
   // host-cloud convenience (single-stream handles)
   int process_host(const loamx_cloud* sharp, const loamx_cloud* less_sharp, const loamx_cloud* flat, const loamx_cloud* less_flat);
   int get_last_clouds(uint32_t s, loamx_cloud* corner, loamx_cloud* surf);
@@ -106,6 +108,8 @@ class OdometryBatch {
   PinBuf<uint32_t> h_off_pin_;
   PinBuf<float4> h_stage_;
   DevBuf<float4> up_[4], tmp_cloud_;
+  hipEvent_t ev_tail_ = nullptr;
+  bool tail_pending_ = false;
   PinBuf<char> h_gather_;
   DevBuf<char> d_gather_;
 };

@@ -495,6 +495,7 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
 }
 
 OdometryBatch::~OdometryBatch() {
+  if (ev_tail_) (void)hipEventDestroy(ev_tail_);
   for (auto* p : streams_) delete p;
   if (own_stream_ && st_) (void)hipStreamDestroy(st_);
 }
@@ -530,9 +531,13 @@ void OdometryBatch::to_end_device(uint32_t s, float4* pts, uint32_t n) {
   hipLaunchKernelGGL(k_transform_to_end, dim3((n + 255) / 256), dim3(256), 0, st_, pts, n, to_end_params(s, true));
 }
 
-void OdometryBatch::process(const OdomInput* in, int* rc) {
+void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   LX_HIP(hipSetDevice(device_));
   const uint32_t ns = n_streams(), K = 2 * ns;
+  if (tail_pending_) {   // the previous call's re-projection / index build still reads the pinned staging buffers
+    LX_HIP(hipEventSynchronize(ev_tail_));
+    tail_pending_ = false;
+  }
   // ---- stage the current less-sharp / less-flat clouds of all streams (they are re-projected in place later)
   for (uint32_t s = 0; s < ns; s++) {
     h_cur_off_[s + 1] = h_cur_off_[s] + in[s].n_less_sharp;
@@ -656,7 +661,13 @@ void OdometryBatch::process(const OdomInput* in, int* rc) {
   std::swap(cur_.cap, last_.cap);
   h_last_off_ = h_cur_off_;
   index_.build(last_.p, h_last_off_.data(), K);
-  LX_HIP(hipStreamSynchronize(st_));
+  if (defer_tail) {   // the caller orders its consumers behind tail_event() instead of blocking the host here
+    if (!ev_tail_) LX_HIP(hipEventCreateWithFlags(&ev_tail_, hipEventDisableTiming));
+    LX_HIP(hipEventRecord(ev_tail_, st_));
+    tail_pending_ = true;
+  } else {
+    LX_HIP(hipStreamSynchronize(st_));
+  }
 }
 
 void OdometryBatch::to_end_gather(float4* dst, const uint32_t* h_off, const float4* const* src, const ToEndParams* seg_params, uint32_t K,
@@ -706,6 +717,7 @@ int OdometryBatch::process_host(const loamx_cloud* sharp, const loamx_cloud* les
 
 int OdometryBatch::get_last_clouds(uint32_t s, loamx_cloud* corner, loamx_cloud* surf) {
   LX_HIP(hipSetDevice(device_));
+  LX_HIP(hipStreamSynchronize(st_));
   OdomStream& S = *streams_[s];
   int rc = LOAMX_OK;
   std::vector<float4> tmp;

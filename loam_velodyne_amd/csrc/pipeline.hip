@@ -8,6 +8,7 @@
 #include "features.cuh"
 #include "odometry.cuh"
 #include "registration.cuh"
+#include <future>
 #include <memory>
 
 namespace loamx {
@@ -135,7 +136,7 @@ class Pipeline {
       if (!evO[0]) { LX_HIP(hipEventCreate(&evO[0])); LX_HIP(hipEventCreate(&evO[1])); }
       LX_HIP(hipEventRecord(evO[0], odom.stream()));
     }
-    odom.process(in.data(), rc.data());   // synchronous on the odometry stream
+    odom.process(in.data(), rc.data(), true);   // returns once the poses are known; clouds ready at odom.tail_event()
     if (timing) {
       LX_HIP(hipEventRecord(evO[1], odom.stream()));
       LX_HIP(hipEventSynchronize(evO[1]));
@@ -178,6 +179,20 @@ class Pipeline {
     odom_ready_step = -1;
     FeatureExtractor& F = *fx[t];
     const float f_ms = feat_ms[t % 3];
+    // ---- look-ahead while M(t) runs: features of step t+2 and, on a host thread of its own (it blocks on its
+    // Gauss-Newton results), the odometry of step t+1
+    // (the re-projected "last" clouds of THIS sweep are produced at the tail of the odometry stream: order the
+    // registrar's stream behind it before the odometry thread re-arms the event)
+    if (hipEvent_t te = odom.tail_event()) LX_HIP(hipStreamWaitEvent(s_, te, 0));
+    std::future<void> ahead;
+    if (prefetch && t + 1 < fx.size()) {
+      if (!launched[t + 1]) launch_features(t + 1);
+      if (t + 2 < fx.size() && !launched[t + 2]) launch_features(t + 2);
+      ahead = std::async(std::launch::async, [this, t]() {
+        LX_HIP(hipSetDevice(device));
+        run_odometry(t + 1);
+      });
+    }
     // ---- registration against the frozen sub-map: enqueue everything for M(t) (asynchronous)
     if (timing) LX_HIP(hipEventRecord(ev[0], s_));
     std::vector<const float4*> cl(ns), sl(ns), fsrc(ns);
@@ -211,12 +226,8 @@ class Pipeline {
       reg.run_async();
     }
     if (timing) LX_HIP(hipEventRecord(ev[1], s_));
-    // ---- look-ahead while M(t) runs: features of step t+2, odometry of step t+1
-    if (prefetch && t + 1 < fx.size()) {
-      if (!launched[t + 1]) launch_features(t + 1);
-      if (t + 2 < fx.size() && !launched[t + 2]) launch_features(t + 2);
-      run_odometry(t + 1);
-    }
+    // ---- join the look-ahead
+    if (ahead.valid()) ahead.get();   // rethrows a failure of the odometry thread
     // ---- finish M(t)
     int ret = LOAMX_SKIPPED;
     if (nw) {

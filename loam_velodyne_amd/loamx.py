@@ -428,6 +428,9 @@ class Pipeline:
         _check(lib().loamx_pipeline_download_full_res(self.h, slot, C.byref(c)))
         return out[:c.count]
 
+    def set_lookahead(self, on: bool):
+        _check(lib().loamx_pipeline_set_lookahead(self.h, 1 if on else 0))
+
     def set_timing(self, on: bool):
         _check(lib().loamx_pipeline_set_timing(self.h, 1 if on else 0))
 

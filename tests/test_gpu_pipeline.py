@@ -58,6 +58,35 @@ def test_streams_are_independent(orc, small_world):
             assert np.array_equal(x, y)
 
 
+def test_lookahead_is_transparent(small_world):
+    """The software pipeline across steps (registration t || odometry t+1 || features t+2 on separate HIP streams and a
+    host thread) must not change any result: bit-identical to the strictly sequential execution."""
+    cm, sm = small_world.make_map(40000)
+    T, ns = 5, 3
+    data = []
+    for s in range(ns):
+        poses = synth.trajectory(T, start=(1.0 * s, 0.0, 2.0 * s))
+        data.append([synth.make_sweep(small_world, "VLP-16", poses[t], poses[t + 1], seed=30 * s + t, az_steps=800) for t in range(T)])
+
+    def run(lookahead):
+        p = loamx.Pipeline(ns)
+        p.set_lookahead(lookahead)
+        p.set_frozen(cm, sm)
+        for s in range(ns):
+            p.set_state(s, aft=np.array([0, 0, 0, 1.0 * s, 0, 2.0 * s], np.float32))
+        p.upload([[(data[s][t].points, data[s][t].ring_sizes) for s in range(ns)] for t in range(T)])
+        out = []
+        for t in range(T):
+            rc = p.step(t)
+            out.append((rc, [p.get(s) for s in range(ns)]))
+        return out
+    a, b = run(True), run(False)
+    for (rca, ga), (rcb, gb) in zip(a, b):
+        assert rca == rcb
+        for (tra, tsa, afa, sta), (trb, tsb, afb, stb) in zip(ga, gb):
+            assert np.array_equal(tra, trb) and np.array_equal(tsa, tsb) and np.array_equal(afa, afb) and sta == stb
+
+
 def test_cpp_adapter_matches(orc, small_world, tmp_path):
     """The header-only C++ classes with the reference's member names (loam_velodyne_amd/adapter) drive the same library:
     scan registration -> odometry -> mapping exactly as the reference's node loop wires them."""

@@ -389,6 +389,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   float g6[6];
   tobe.get(g6);
   reg.upload(1, corner_last, surf_last, full_res, g6);
+  reg.early_exit = true;   // process() is blocking
   reg.run_async();
   last_optimized = reg.submap_sufficient();
 

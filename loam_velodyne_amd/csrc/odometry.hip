@@ -15,9 +15,9 @@
 
 namespace loamx {
 
-constexpr int OD_THREADS = 512;
+constexpr int OD_THREADS = 256;
 constexpr int OD_WAVES = OD_THREADS / 64;
-// features per thread kept in registers: 6 x 512 = 3072 covers 64-ring sensors (2304); 16 x 512 = 8192 is the fallback
+// k_odom_lm: up to 16 workgroups x 256 threads x 2 features per thread kept in registers = 8192 features per sweep
 
 // per-point de-skew angles (|a| << 1): float sincos (<= 2 ulp); the once-per-iteration pose trig stays in double
 __device__ inline void sincos_f(float a, float& s, float& c) { sincosf(a, &s, &c); }
@@ -235,17 +235,24 @@ __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ pro
   }
 }
 
-// ---- phase C: iterations [iter0, iter0 + n_iters) of one stream in one persistent workgroup
+// ---- phase C: iterations [iter0, iter0 + n_iters) of one stream in gridDim.x PERSISTENT workgroups (grid = NB x streams).
+// The features of a stream are dealt out over its NB workgroups (one CU cannot evaluate 2304 rows in less than ~16 us,
+// nine can).  Per iteration every workgroup reduces its rows to 28 double sums, publishes them and takes a ticket; the
+// workgroup that draws the last ticket adds the NB partial sums in workgroup order (deterministic), solves, updates the
+// pose and bumps the stream's generation counter, on which the others spin.  NB x streams <= 16 x 64 workgroups are all
+// resident, so the spin cannot deadlock.
 template <int OD_FPT>
 __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict__ probs, OdomParams P, int iter0, int n_iters) {
-  OdomProblem& pb = probs[blockIdx.x];
+  OdomProblem& pb = probs[blockIdx.y];
   if (pb.done) return;
+  const unsigned NB = gridDim.x;
+  const unsigned gen0 = __hip_atomic_load(&pb.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int nSharp = (int)pb.n_sharp, nFlat = (int)pb.n_flat, nFeat = nSharp + nFlat;
   __shared__ float T[6];
   __shared__ float trig[6];
   __shared__ double red[OD_WAVES][LX_NSUM];
-  __shared__ int sh_done;
+  __shared__ int sh_done, sh_last;
   __shared__ float ws[216];
   __shared__ double sums[LX_NSUM];
   __shared__ float AtA[36], AtB[6], X[6], X2[6];
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
   bool fvalid[OD_FPT], fcorner[OD_FPT];
 #pragma unroll
   for (int u = 0; u < OD_FPT; u++) {
-    const int f = tid + u * OD_THREADS;
+    const int f = (u * (int)NB + (int)blockIdx.x) * OD_THREADS + tid;
     fvalid[u] = false;
     fcorner[u] = f < nSharp;
     fpo[u] = ft1[u] = ft2[u] = ft3[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -372,7 +379,41 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
     if (tid < LX_NSUM) {
       double x = 0.0;
       for (int w = 0; w < OD_WAVES; w++) x += red[w][tid];
-      sums[tid] = x;
+      if (NB > 1) {
+        pb.part[blockIdx.x * LX_NSUM + tid] = x;
+        __threadfence();   // release the partial sum before the ticket is drawn
+      } else {
+        sums[tid] = x;
+      }
+    }
+    if (NB > 1) {
+      __syncthreads();
+      if (tid == 0) sh_last = atomicAdd(&pb.ticket, 1u) == NB - 1 ? 1 : 0;
+      __syncthreads();
+      if (!sh_last) {
+        // wait for the solving workgroup, then pick up the new pose
+        if (tid == 0) {
+          const unsigned target = gen0 + (unsigned)(iter - iter0) + 1u;
+          while (__hip_atomic_load(&pb.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != target) __builtin_amdgcn_s_sleep(2);
+          __threadfence();   // acquire
+          sh_done = __hip_atomic_load(&pb.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (tid < 6) T[tid] = __hip_atomic_load(&pb.transform[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (sh_done) break;
+        continue;
+      }
+      __threadfence();   // acquire the other workgroups' partial sums
+      if (tid < LX_NSUM) {
+        double x = 0.0;
+        for (unsigned b = 0; b < NB; b++) x += __hip_atomic_load(&pb.part[b * LX_NSUM + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sums[tid] = x;
+      }
+      __syncthreads();
+    }
+    if (tid < LX_NSUM) {
+      const double x = sums[tid];
       // scatter straight into the symmetric 6x6 / right-hand side (sum index t -> (i, j) of the upper triangle)
       if (tid < 21) {
         int i = 0, rem = tid;
@@ -413,12 +454,18 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
         const float deltaT = (float)sqrt((double)t0 * t0 + (double)t1 * t1 + (double)t2 * t2);
         if (deltaR < P.delta_r_abort && deltaT < P.delta_t_abort) sh_done = 1;
       }
+      // publish (the other workgroups of the stream are spinning on gen)
+      for (int r = 0; r < 6; r++) pb.transform[r] = T[r];
+      if (sh_done) pb.done = 1;
+      if (NB > 1) {
+        atomicExch(&pb.ticket, 0u);
+        __threadfence();
+        __hip_atomic_store(&pb.gen, gen0 + (unsigned)(iter - iter0) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     __syncthreads();
     if (sh_done) break;
   }
-  if (tid < 6) pb.transform[tid] = T[tid];
-  if (tid == 0 && sh_done) pb.done = 1;
 }
 
 // transformToEnd (:57-87) of one point
@@ -485,6 +532,7 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
   for (uint32_t s = 0; s < n_streams; s++) streams_.push_back(new OdomStream());
   index_.init(st_);
   prob_.reserve(n_streams);
+  part_.reserve((size_t)n_streams * 16 * LX_NSUM);
   h_prob_.reserve(n_streams);
   te_.reserve(n_streams);
   h_te_.reserve(n_streams);
@@ -602,22 +650,25 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       S.transform.get(pb.transform);
       pb.stats = {0, 0, 0, 0};
       pb.done = 0;
+      pb.ticket = 0; pb.gen = 0;
+      pb.part = part_.p + (size_t)active.size() * 16 * LX_NSUM;
       max_feat = std::max(max_feat, I.n_sharp + I.n_flat);
       active.push_back(s);
     }
   }
   const uint32_t na = (uint32_t)active.size();
-  if (max_feat > 16 * OD_THREADS) throw Error(LOAMX_E_CAPACITY, "more than 8192 sharp+flat features in one sweep");
+  if (max_feat > 32 * OD_THREADS) throw Error(LOAMX_E_CAPACITY, "more than 8192 sharp+flat features in one sweep");
   if (na) {
     LX_HIP(hipMemcpyAsync(prob_.p, h_prob_.p, sizeof(OdomProblem) * na, hipMemcpyHostToDevice, st_));
     if (max_feat) {
       for (int it0 = 0; it0 < params.max_iterations; it0 += 5) {
         const int nit = std::min(5, params.max_iterations - it0);
         hipLaunchKernelGGL(k_odom_corr, dim3((max_feat + 3) / 4, na), dim3(256), 0, st_, prob_.p, params);
-        if (max_feat <= 6 * OD_THREADS)
-          hipLaunchKernelGGL(k_odom_lm<6>, dim3(na), dim3(OD_THREADS), 0, st_, prob_.p, params, it0, nit);
+        const uint32_t nb = std::min<uint32_t>(16u, (max_feat + OD_THREADS - 1) / OD_THREADS);
+        if (max_feat <= nb * OD_THREADS)
+          hipLaunchKernelGGL(k_odom_lm<1>, dim3(nb, na), dim3(OD_THREADS), 0, st_, prob_.p, params, it0, nit);
         else
-          hipLaunchKernelGGL(k_odom_lm<16>, dim3(na), dim3(OD_THREADS), 0, st_, prob_.p, params, it0, nit);
+          hipLaunchKernelGGL(k_odom_lm<2>, dim3(nb, na), dim3(OD_THREADS), 0, st_, prob_.p, params, it0, nit);
       }
     }
     LX_HIP(hipMemcpyAsync(h_prob_.p, prob_.p, sizeof(OdomProblem) * na, hipMemcpyDeviceToHost, st_));

@@ -35,6 +35,7 @@ class Pipeline {
   Pipeline(const loamx_scanreg_config& fc, const loamx_odom_config& oc, const loamx_map_config& mc, uint32_t n_streams)
       : reg(mc.device, n_streams), odom(mc.device, n_streams, nullptr), fcfg(fc), n_streams_(n_streams), st(n_streams) {
     reg.params.max_iterations = mc.max_iterations;
+    reg.early_exit = true;   // step() blocks on M(t) anyway
     reg.params.delta_t_abort = mc.delta_t_abort;
     reg.params.delta_r_abort = mc.delta_r_abort;
     reg.params.corner_leaf = mc.corner_filter_size;

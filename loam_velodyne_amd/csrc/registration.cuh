@@ -80,6 +80,7 @@ class Registrar {
   ~Registrar();
   RegParams params;
   SubMapIndex corner_index, surf_index;
+  bool early_exit = false;    // run_async() may block on the done flags to skip the launches after convergence
   hipStream_t stream() const { return st_; }
 
   // frozen sub-map (host records or device float4)
@@ -135,6 +136,9 @@ class Registrar {
   bool full_staged_ = false;
   VoxelPipeline vox_;
   uint32_t n_in_ = 0, n_full_ = 0, max_q_per_sweep_ = 0;
+  int pred_iters_ = 4;        // early_exit: iterations to enqueue before the first look at the done flags
+  int knn_lpq_ = 4;           // lanes per query in k_knn5 (tuning knob: LOAMX_KNN_LPQ = 1|2|4|8|16)
+  void launch_knn5(int it);
 
   DevBuf<Pose> poses_;
   DevBuf<SweepStats> stats_;

@@ -362,14 +362,18 @@ __device__ inline void knn_insert(float (&bd)[5], uint32_t (&bi)[5], uint32_t (&
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// k_knn5: the neighbour search of one Gauss-Newton iteration, 16 lanes per query (4 queries per wave64).
-// Full search:
-//   1. lanes 0..8 of a group fetch the cell ranges of the 9 (y,z) rows of the 3x3x3 neighbourhood (x is the fastest cell
-//      axis, so a row is one contiguous run) — 18 independent loads in flight per query;
-//   2. the runs are concatenated logically (group prefix sum) and the 16 lanes stride over the candidates, so a
-//      query's ~60 candidate points are fetched in ~4 rounds of 16 independent 16-byte loads;
-//   3. every lane keeps its own sorted top-6; six rounds of a 16-lane arg-min butterfly on (d2, original index)
-//      pop the global top-6 — the same strict total order as a sequential scan, so the result is identical.
+// k_knn5<LPQ>: the neighbour search of one Gauss-Newton iteration.  A 256-thread workgroup owns QB = 256/LPQ queries.
+// Phase A (one lane per query, threads 0..QB-1):
+//   pointAssociateToMap, then re-validation of the remembered neighbours (below); a query that needs a search gets a
+//   slot in the workgroup's LDS work list together with the cell ranges of the 9 (y,z) rows of its 3x3x3 neighbourhood
+//   (x is the fastest cell axis, so a row is one contiguous run) and their exclusive prefix — 18 independent loads.
+// Phase B (LPQ lanes per listed query; waves beyond the list exit):
+//   the runs are concatenated logically and the LPQ lanes stride over the candidates (adjacent lanes read adjacent
+//   points), four independent 16-byte loads in flight per lane; every lane keeps its own sorted top-6 and six rounds of
+//   an LPQ-lane arg-min butterfly on (d2, original index) pop the global top-6 — the same strict total order as a
+//   sequential scan, so the result does not depend on LPQ.
+// The kernel is bound by issue slots and load latency, not by bytes: ~60 candidates per query cost ~25 lane-instructions
+// each, so the fewer lanes idle in per-query fixed work (prefix, butterfly) the better — LPQ=4 measured best.
 // Re-validation (iterations after a query's last full search): the pose moves by millimetres between Gauss-Newton
 // steps, so the neighbour SET almost never changes.  With q0 the query position at its last full search, delta =
 // |q - q0| and r6 the distance from q0 to its 6th neighbour (or 1.05 m, the radius the 27 cells are guaranteed to
@@ -381,181 +385,216 @@ __device__ inline void knn_insert(float (&bd)[5], uint32_t (&bi)[5], uint32_t (&
 //         nb[5*q+4] = 0xffffffff when pointSearchSqDis[4] >= 1.0 (BasicLaserMapping.cpp:671, :760).
 // Algorithmic bytes: 12 B query + 5 x 12 B neighbours = 72 B per query.
 // ----------------------------------------------------------------------------------------------------------------
-constexpr int KNN_GROUP = 16;
-constexpr int KNN_QPB = 256 / KNN_GROUP;   // queries per 256-thread block
 constexpr float KNN_COVER2 = 1.05f * 1.05f * 0.9999f;   // every map point within this squared radius has been visited
 
-__device__ inline void knn_insert6(float (&bd)[6], uint32_t (&bi)[6], uint32_t (&bp)[6], float d2, uint32_t id, uint32_t pos) {
-  if (!(d2 < bd[5] || (d2 == bd[5] && id < bi[5]))) return;
-  bd[5] = d2; bi[5] = id; bp[5] = pos;
+// Branch-free insertion into a lane's ascending top-6.  A candidate's rank key is (bits(d2) << 32) | original index:
+// d2 >= +0 and finite, so the unsigned order of the float bits is the order of the values and one 64-bit compare is the
+// strict (d2, index) order of a sequential scan.
+__device__ inline void knn_insert6(unsigned long long (&bk)[6], uint32_t (&bp)[6], unsigned long long key, uint32_t pos) {
+  bool lt[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) lt[j] = key < bk[j];
 #pragma unroll
   for (int j = 5; j > 0; j--) {
-    const bool sw = (bd[j] < bd[j - 1]) || (bd[j] == bd[j - 1] && bi[j] < bi[j - 1]);
-    if (sw) {
-      float td = bd[j]; bd[j] = bd[j - 1]; bd[j - 1] = td;
-      uint32_t ti = bi[j]; bi[j] = bi[j - 1]; bi[j - 1] = ti;
-      uint32_t tp = bp[j]; bp[j] = bp[j - 1]; bp[j - 1] = tp;
-    }
+    bk[j] = lt[j - 1] ? bk[j - 1] : (lt[j] ? key : bk[j]);
+    bp[j] = lt[j - 1] ? bp[j - 1] : (lt[j] ? pos : bp[j]);
   }
+  bk[0] = lt[0] ? key : bk[0];
+  bp[0] = lt[0] ? pos : bp[0];
 }
+constexpr unsigned long long KNN_NONE = 0x7f7fffffffffffffull;   // (FLT_MAX, 0xffffffff): empty slot
 
-__global__ __launch_bounds__(256) void k_knn5(const float4* __restrict__ ds_pts, const uint32_t* __restrict__ ds_off,
+template <int LPQ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_knn5(const float4* __restrict__ ds_pts, const uint32_t* __restrict__ ds_off,
                                               const Pose* __restrict__ poses, const SweepStats* __restrict__ stats,
                                               const GridDesc* __restrict__ cdesc, const float4* __restrict__ cpts,
                                               const uint32_t* __restrict__ cstart, const GridDesc* __restrict__ sdesc,
                                               const float4* __restrict__ spts, const uint32_t* __restrict__ sstart,
                                               uint32_t* __restrict__ nb, float4* __restrict__ qstate, int iter) {
+  constexpr int QB = 256 / LPQ;
+  __shared__ uint32_t s_rb[9 * QB];    // run begin,        [run][slot]
+  __shared__ uint32_t s_rp[10 * QB];   // exclusive prefix, [run][slot]; entry 9 = candidate count
+  __shared__ float4 s_q[QB];           // query in the map frame, .w = bits of the query index
+  __shared__ uint32_t s_n;
   const uint32_t s = blockIdx.y;
   if (stats[s].done) return;
   const uint32_t q0 = ds_off[2 * s], qm = ds_off[2 * s + 1], q1 = ds_off[2 * s + 2];
   // XCD-aware order: workgroup b runs on XCD b % 8, so give every XCD one contiguous eighth of the (voxel-ordered,
   // i.e. spatially coherent) query list — its private L2 then only has to hold that part of the map
-  const uint32_t nblk_act = (q1 - q0 + KNN_QPB - 1) / KNN_QPB;   // workgroups this sweep really needs (<= gridDim.x)
+  const uint32_t nblk_act = (q1 - q0 + QB - 1) / QB;   // workgroups this sweep really needs (<= gridDim.x)
   const uint32_t per = (nblk_act + 7) / 8;
   if (blockIdx.x / 8 >= per) return;
   const uint32_t bx = (blockIdx.x % 8) * per + blockIdx.x / 8;
-  const uint32_t first = q0 + bx * KNN_QPB;
+  const uint32_t first = q0 + bx * QB;
   if (first >= q1) return;
-  const int gl = threadIdx.x & (KNN_GROUP - 1);
-  const uint32_t q = first + (threadIdx.x / KNN_GROUP);
-  const bool qok = q < q1;
-  const bool corner = q < qm;
-  const GridDesc g = corner ? *cdesc : *sdesc;
-  const float4* __restrict__ pts = corner ? cpts : spts;
-  const uint32_t* __restrict__ cell_start = corner ? cstart : sstart;
-  float qx = 0.f, qy = 0.f, qz = 0.f;
-  if (qok) {
-    const Pose T = poses[s];
-    const float4 po = ds_pts[q];
-    qx = po.x; qy = po.y; qz = po.z;
-    to_map(T, qx, qy, qz);
-  }
-  // ---- re-validation of the remembered neighbours
-  bool need_search = qok;
-  if (iter > 0 && qok) {
-    const float4 st = qstate[q];
-    const float ddx = qx - st.x, ddy = qy - st.y, ddz = qz - st.z;
-    const float delta = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
-    const uint32_t mypos = gl < 5 ? nb[5 * (size_t)q + gl] : 0u;
-    const uint32_t p4 = __shfl(mypos, 4, KNN_GROUP);
-    if (p4 == 0xffffffffu) {
-      // rejected at the last search: st.w = squared distance to the 5th neighbour then (or the covered radius)
-      if (sqrtf(st.w) * 0.99999f - delta - 1e-6f >= 1.0f) need_search = false;
-    } else {
-      float d2 = 0.f;
-      uint32_t id = 0u;
-      if (gl < 5) {
-        const float4 p = pts[mypos];
-        const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-        d2 = dx * dx + dy * dy + dz * dz;
-        id = __float_as_uint(p.w);
-      }
-      float dmax = gl < 5 ? d2 : 0.f;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+
+  // ---- phase A
+  if (threadIdx.x < QB) {
+    const uint32_t q = first + threadIdx.x;
+    const bool qok = q < q1;
+    const bool corner = q < qm;
+    const float4* __restrict__ pts = corner ? cpts : spts;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (qok) {
+      const Pose T = poses[s];
+      const float4 po = ds_pts[q];
+      qx = po.x; qy = po.y; qz = po.z;
+      to_map(T, qx, qy, qz);
+    }
+    bool need_search = qok;
+    if (iter > 0 && qok) {
+      const float4 st = qstate[q];
+      const float ddx = qx - st.x, ddy = qy - st.y, ddz = qz - st.z;
+      const float delta = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+      uint32_t np[5];
 #pragma unroll
-      for (int m = 4; m > 0; m >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, m, 8));
-      dmax = __shfl(dmax, 0, KNN_GROUP);
-      if (dmax < 1.0f && sqrtf(dmax) + delta < sqrtf(st.w) * 0.99999f - 1e-6f) {
-        // same set; restore ascending (d2, index) order
-        int rank = 0;
+      for (int j = 0; j < 5; j++) np[j] = nb[5 * (size_t)q + j];
+      if (np[4] == 0xffffffffu) {
+        // rejected at the last search: st.w = squared distance to the 5th neighbour then (or the covered radius)
+        if (sqrtf(st.w) * 0.99999f - delta - 1e-6f >= 1.0f) need_search = false;
+      } else {
+        float d2[5];
+        uint32_t id[5];
+        float dmax = 0.f;
 #pragma unroll
         for (int j = 0; j < 5; j++) {
-          const float oj = __shfl(d2, j, KNN_GROUP);
-          const uint32_t ij = __shfl(id, j, KNN_GROUP);
-          if (oj < d2 || (oj == d2 && ij < id)) rank++;
+          const float4 p = pts[np[j]];
+          const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+          d2[j] = dx * dx + dy * dy + dz * dz;
+          id[j] = __float_as_uint(p.w);
+          dmax = fmaxf(dmax, d2[j]);
         }
-        if (gl < 5) nb[5 * (size_t)q + rank] = mypos;
-        need_search = false;
+        if (dmax < 1.0f && sqrtf(dmax) + delta < sqrtf(st.w) * 0.99999f - 1e-6f) {
+          // same set; restore ascending (d2, index) order
+#pragma unroll
+          for (int j = 0; j < 5; j++) {
+            int rank = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+              if (d2[k] < d2[j] || (d2[k] == d2[j] && id[k] < id[j])) rank++;
+            nb[5 * (size_t)q + rank] = np[j];
+          }
+          need_search = false;
+        }
       }
     }
-  }
-  // uniform across the group by construction; skip the search when no group of this wave needs it
-  if (!__any(need_search)) return;
-
-  // ---- 1. row ranges
-  const int cx = (int)floorf((qx - g.ox) * g.inv_h), cy = (int)floorf((qy - g.oy) * g.inv_h), cz = (int)floorf((qz - g.oz) * g.inv_h);
-  const bool inside = need_search && !(cx + 1 < 0 || cx - 1 > g.nx - 1 || cy + 1 < 0 || cy - 1 > g.ny - 1 || cz + 1 < 0 || cz - 1 > g.nz - 1);
-  uint32_t beg = 0, len = 0;
-  if (inside && gl < 9) {
-    const int z = cz + gl / 3 - 1, y = cy + gl % 3 - 1;
-    if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+    // work-list slot (wave-aggregated)
+    const unsigned long long mneed = __ballot(need_search);
+    uint32_t base = 0;
+    if (mneed) {
+      const int leader = __builtin_ctzll(mneed);
+      if ((int)__lane_id() == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(mneed));
+      base = __shfl(base, leader, 64);
+    }
+    if (need_search) {
+      const uint32_t slot = base + (uint32_t)__popcll(mneed & ((1ull << __lane_id()) - 1ull));
+      s_q[slot] = make_float4(qx, qy, qz, __uint_as_float(q));
+      const GridDesc g = corner ? *cdesc : *sdesc;
+      const uint32_t* __restrict__ cell_start = corner ? cstart : sstart;
+      const int cx = (int)floorf((qx - g.ox) * g.inv_h), cy = (int)floorf((qy - g.oy) * g.inv_h), cz = (int)floorf((qz - g.oz) * g.inv_h);
+      const bool inside = !(cx + 1 < 0 || cx - 1 > g.nx - 1 || cy + 1 < 0 || cy - 1 > g.ny - 1 || cz + 1 < 0 || cz - 1 > g.nz - 1);
       const int x0 = clampi(cx - 1, 0, g.nx - 1), x1 = clampi(cx + 1, 0, g.nx - 1);
-      const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
-      beg = cell_start[row + x0];
-      len = cell_start[row + x1 + 1] - beg;
+      uint32_t beg[9], end[9];
+#pragma unroll
+      for (int r = 0; r < 9; r++) {
+        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+        beg[r] = 0; end[r] = 0;
+        if (inside && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+          const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
+          beg[r] = cell_start[row + x0];
+          end[r] = cell_start[row + x1 + 1];
+        }
+      }
+      uint32_t acc = 0;
+#pragma unroll
+      for (int r = 0; r < 9; r++) {
+        s_rb[r * QB + slot] = beg[r];
+        s_rp[r * QB + slot] = acc;
+        acc += end[r] - beg[r];
+      }
+      s_rp[9 * QB + slot] = acc;
     }
   }
-  // ---- 2. exclusive prefix of the run lengths inside the group; every lane gets all 9 (begin, prefix) pairs
-  uint32_t inc = len;
+  __syncthreads();
+
+  // ---- phase B
+  const uint32_t grp = threadIdx.x / LPQ;
+  const int gl = threadIdx.x % LPQ;
+  if (grp >= s_n) return;
+  const float4 qq = s_q[grp];
+  const uint32_t q = __float_as_uint(qq.w);
+  const float qx = qq.x, qy = qq.y, qz = qq.z;
+  const float4* __restrict__ pts = q < qm ? cpts : spts;
+  const uint32_t total = s_rp[9 * QB + grp];
+  unsigned long long bk[6];
+  uint32_t bp[6];
 #pragma unroll
-  for (int d = 1; d < KNN_GROUP; d <<= 1) {
-    const uint32_t o = __shfl_up(inc, d, KNN_GROUP);
-    if (gl >= d) inc += o;
-  }
-  const uint32_t total = __shfl(inc, 8, KNN_GROUP);
-  const uint32_t ex = inc - len;
-  uint32_t rb[9], rp[9];
+  for (int j = 0; j < 6; j++) { bk[j] = KNN_NONE; bp[j] = 0u; }
+  int r = 0;
+  uint32_t bound = s_rp[QB + grp];   // first candidate number of the next run
+  uint32_t off = s_rb[grp];          // position = off + candidate number inside the current run
+  for (uint32_t c = gl; c < total; c += 4 * LPQ) {
+    uint32_t pos[4];
+    float4 p[4];
 #pragma unroll
-  for (int r = 0; r < 9; r++) {
-    rb[r] = __shfl(beg, r, KNN_GROUP);
-    rp[r] = __shfl(ex, r, KNN_GROUP);
-  }
-  float bd[6];
-  uint32_t bi[6], bp[6];
-#pragma unroll
-  for (int j = 0; j < 6; j++) { bd[j] = FLT_MAX; bi[j] = 0xffffffffu; bp[j] = 0u; }
-  for (uint32_t c = gl; c < total; c += 2 * KNN_GROUP) {
-    uint32_t pos[2];
-    float4 p[2];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const uint32_t cc = c + u * KNN_GROUP;
-      uint32_t b = rb[0], pr = 0;
-#pragma unroll
-      for (int r = 1; r < 9; r++)
-        if (rp[r] <= cc) { b = rb[r]; pr = rp[r]; }   // prefixes are non-decreasing: the last run starting at or before cc
-      pos[u] = b + (cc - pr);
-      p[u] = cc < total ? pts[pos[u]] : make_float4(1e30f, 1e30f, 1e30f, 0.f);
+    for (int u = 0; u < 4; u++) {
+      const uint32_t cc = c + u * LPQ;
+      pos[u] = 0;
+      if (cc < total) {
+        while (cc >= bound) {   // rp[9] = total > cc terminates
+          r++;
+          bound = s_rp[(r + 1) * QB + grp];
+          off = s_rb[r * QB + grp] - s_rp[r * QB + grp];
+        }
+        pos[u] = off + cc;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < 4; u++) p[u] = (c + u * LPQ) < total ? pts[pos[u]] : make_float4(1e30f, 1e30f, 1e30f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
       const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
       const float d2 = dx * dx + dy * dy + dz * dz;   // x -> y -> z accumulation (nanoflann.hpp:372-379)
-      if (d2 < KNN_COVER2) knn_insert6(bd, bi, bp, d2, __float_as_uint(p[u].w), pos[u]);
+      const unsigned long long key = d2 < KNN_COVER2 ? ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(p[u].w) : KNN_NONE;
+      knn_insert6(bk, bp, key, pos[u]);
     }
   }
-  // ---- 3. pop the group's six best
-  int head = 0;
-  uint32_t win_pos = 0xffffffffu;   // lane k of the group keeps winner k
-  float d5 = FLT_MAX, d6 = FLT_MAX; // squared distances of the 5th and 6th neighbour (FLT_MAX: none inside the covered radius)
+  // ---- pop the group's six best (every lane of the group ends up with the same winners)
+  uint32_t win[6];
+  float wd[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) {
-    float d = FLT_MAX;
-    uint32_t id = 0xffffffffu, pp = 0u;
-#pragma unroll
-    for (int j = 0; j < 6; j++)
-      if (head == j) { d = bd[j]; id = bi[j]; pp = bp[j]; }
+    unsigned long long key = bk[0];
+    uint32_t pp = bp[0];
     int owner = gl;
 #pragma unroll
-    for (int m = KNN_GROUP / 2; m > 0; m >>= 1) {
-      const float od = __shfl_xor(d, m, KNN_GROUP);
-      const uint32_t oi = __shfl_xor(id, m, KNN_GROUP), op = __shfl_xor(pp, m, KNN_GROUP);
-      const int oo = __shfl_xor(owner, m, KNN_GROUP);
-      if (od < d || (od == d && oi < id)) { d = od; id = oi; pp = op; owner = oo; }
+    for (int m = LPQ / 2; m > 0; m >>= 1) {
+      const unsigned long long ok = __shfl_xor(key, m, LPQ);
+      const uint32_t op = __shfl_xor(pp, m, LPQ);
+      const int oo = __shfl_xor(owner, m, LPQ);
+      if (ok < key) { key = ok; pp = op; owner = oo; }   // distinct points have distinct keys; empty slots tie harmlessly
     }
-    if (owner == gl && id != 0xffffffffu) head++;
-    if (gl == k) win_pos = pp;
-    if (k == 4) d5 = id != 0xffffffffu ? d : FLT_MAX;
-    if (k == 5) d6 = id != 0xffffffffu ? d : FLT_MAX;
+    if (LPQ > 1 || k < 5) {
+      if (owner == gl) {   // the winner's lane advances its list
+#pragma unroll
+        for (int j = 0; j < 5; j++) { bk[j] = bk[j + 1]; bp[j] = bp[j + 1]; }
+        bk[5] = KNN_NONE;
+      }
+    }
+    win[k] = pp;
+    wd[k] = key != KNN_NONE ? __uint_as_float((uint32_t)(key >> 32)) : FLT_MAX;
   }
-  if (need_search) {
-    const bool valid = d5 < 1.0f;   // == pointSearchSqDis[4] < 1.0
-    if (gl < 5) nb[5 * (size_t)q + gl] = (gl == 4 && !valid) ? 0xffffffffu : win_pos;
-    if (gl == 0) {
-      // bound for the re-validation: 6th neighbour (valid query) or 5th neighbour (rejected query), capped by the
-      // radius the visited cells are guaranteed to cover
-      const float bound = fminf(valid ? d6 : d5, KNN_COVER2);
-      qstate[q] = make_float4(qx, qy, qz, bound);
-    }
+  if (gl == 0) {
+    const float d5 = wd[4], d6 = wd[5];   // FLT_MAX: none inside the covered radius
+    const bool valid = d5 < 1.0f;         // == pointSearchSqDis[4] < 1.0
+#pragma unroll
+    for (int k = 0; k < 5; k++) nb[5 * (size_t)q + k] = (k == 4 && !valid) ? 0xffffffffu : win[k];
+    // bound for the re-validation: 6th neighbour (valid query) or 5th neighbour (rejected query), capped by the
+    // radius the visited cells are guaranteed to cover
+    const float bnd = fminf(valid ? d6 : d5, KNN_COVER2);
+    qstate[q] = make_float4(qx, qy, qz, bnd);
   }
 }
 
@@ -807,6 +846,10 @@ Registrar::Registrar(int device, uint32_t max_sweeps) : device_(device), max_swe
   LX_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
   corner_index.init(st_);
   surf_index.init(st_);
+  if (const char* e = getenv("LOAMX_KNN_LPQ")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) knn_lpq_ = v;
+  }
   poses_.reserve(max_sweeps);
   stats_.reserve(max_sweeps);
   matP_.reserve((size_t)36 * max_sweeps);
@@ -970,6 +1013,26 @@ void Registrar::upload_device(uint32_t n_sweeps, const float4* const* corner_las
   qstate_.reserve((size_t)n_in_ + 8);
 }
 
+template <int LPQ>
+static void launch_knn5_t(Registrar& r, uint32_t max_q, uint32_t ns, hipStream_t st, const float4* ds_pts, const uint32_t* ds_off, const Pose* poses,
+                          const SweepStats* stats, uint32_t* nb, float4* qstate, int it) {
+  constexpr uint32_t QB = 256 / LPQ;
+  hipLaunchKernelGGL(k_knn5<LPQ>, dim3(8 * ((max_q + 8 * QB - 1) / (8 * QB)), ns), dim3(256), 0, st, ds_pts, ds_off, poses, stats,
+                     r.corner_index.desc(), r.corner_index.sorted(), r.corner_index.cell_start(), r.surf_index.desc(),
+                     r.surf_index.sorted(), r.surf_index.cell_start(), nb, qstate, it);
+}
+
+void Registrar::launch_knn5(int it) {
+  const uint32_t ns = n_sweeps_;
+  switch (knn_lpq_) {
+    case 1: launch_knn5_t<1>(*this, max_q_per_sweep_, ns, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p, nb_.p, qstate_.p, it); break;
+    case 2: launch_knn5_t<2>(*this, max_q_per_sweep_, ns, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p, nb_.p, qstate_.p, it); break;
+    case 8: launch_knn5_t<8>(*this, max_q_per_sweep_, ns, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p, nb_.p, qstate_.p, it); break;
+    case 16: launch_knn5_t<16>(*this, max_q_per_sweep_, ns, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p, nb_.p, qstate_.p, it); break;
+    default: launch_knn5_t<4>(*this, max_q_per_sweep_, ns, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p, nb_.p, qstate_.p, it); break;
+  }
+}
+
 void Registrar::run_async() {
   LX_REQUIRE(n_sweeps_ > 0, "run() before upload()");
   LX_HIP(hipSetDevice(device_));
@@ -987,20 +1050,38 @@ void Registrar::run_async() {
     LX_HIP(hipMemsetAsync(ds_off_.p, 0, sizeof(uint32_t) * (nseg + 1), st_));
   }
   if (submap_sufficient() && n > 0) {   // BasicLaserMapping.cpp:628-629 guard
-    for (int it = 0; it < params.max_iterations; it++) {
-      const bool tm = timing_ && n_res_launch_ < 64;
-      if (tm) LX_HIP(hipEventRecord(ev_[2 + 2 * n_res_launch_], st_));
-      hipLaunchKernelGGL(k_knn5, dim3(8 * ((max_q_per_sweep_ + 8 * KNN_QPB - 1) / (8 * KNN_QPB)), ns), dim3(256), 0, st_, ds_pts_.p, ds_off_.p, poses_.p,
-                         stats_.p, corner_index.desc(), corner_index.sorted(), corner_index.cell_start(), surf_index.desc(),
-                         surf_index.sorted(), surf_index.cell_start(), nb_.p, qstate_.p, it);
-      if (tm) {   // the timed kernel is the neighbour search (the path's dominant gather)
-        LX_HIP(hipEventRecord(ev_[3 + 2 * n_res_launch_], st_));
-        n_res_launch_++;
+    // Converged sweeps turn the remaining launches into no-ops on the device (stats.done), which keeps run_async()
+    // free of host round trips.  A blocking caller (early_exit) instead enqueues as many iterations as the previous
+    // call needed, looks at the flags, and stops launching once every sweep is done.
+    int it = 0;
+    int chunk = early_exit ? std::min(std::max(pred_iters_, 2), params.max_iterations) : params.max_iterations;
+    while (it < params.max_iterations) {
+      const int end = std::min(params.max_iterations, it + chunk);
+      for (; it < end; it++) {
+        const bool tm = timing_ && n_res_launch_ < 64;
+        if (tm) LX_HIP(hipEventRecord(ev_[2 + 2 * n_res_launch_], st_));
+        launch_knn5(it);
+        if (tm) {   // the timed kernel is the neighbour search (the path's dominant gather)
+          LX_HIP(hipEventRecord(ev_[3 + 2 * n_res_launch_], st_));
+          n_res_launch_++;
+        }
+        hipLaunchKernelGGL(k_residual, dim3(nblk_, ns), dim3(LX_RES_THREADS), 0, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p,
+                           corner_index.sorted(), surf_index.sorted(), nb_.p, partials_.p, nblk_);
+        hipLaunchKernelGGL(k_solve, dim3(ns), dim3(256), 0, st_, ds_off_.p, poses_.p, stats_.p, matP_.p, partials_.p, nblk_, it,
+                           params.delta_t_abort, params.delta_r_abort);
       }
-      hipLaunchKernelGGL(k_residual, dim3(nblk_, ns), dim3(LX_RES_THREADS), 0, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p,
-                         corner_index.sorted(), surf_index.sorted(), nb_.p, partials_.p, nblk_);
-      hipLaunchKernelGGL(k_solve, dim3(ns), dim3(256), 0, st_, ds_off_.p, poses_.p, stats_.p, matP_.p, partials_.p, nblk_, it,
-                         params.delta_t_abort, params.delta_r_abort);
+      if (!early_exit || it >= params.max_iterations) break;
+      LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * ns, hipMemcpyDeviceToHost, st_));
+      LX_HIP(hipStreamSynchronize(st_));
+      bool all_done = true;
+      int need = 0;
+      for (uint32_t k = 0; k < ns; k++) {
+        all_done = all_done && h_stats_.p[k].done;
+        need = std::max(need, h_stats_.p[k].iterations);
+      }
+      if (all_done) { pred_iters_ = need; break; }
+      pred_iters_ = it + 1;
+      chunk = 1;
     }
   }
   if (n_full_)

@@ -23,35 +23,58 @@ __device__ inline uint32_t vox_find_seg(const uint32_t* __restrict__ off, uint32
   return lo;
 }
 
-// per-segment integer bounds.  Must be called by ALL lanes of the wave (no early returns before it); `active` marks
-// the lanes that carry a point.  Lanes sharing the segment of the first active lane are reduced with shuffles and
-// issue one set of atomics; stragglers (a wave straddling a segment border) fall back to their own atomics.
+// per-segment integer bounds.  Must be called by ALL threads of the block (no early returns before it); `active`
+// marks the threads that carry a point.  Three levels keep the global atomics rare: lanes sharing the segment of the
+// wave's first active lane are reduced with shuffles; waves whose segment is the block's lead segment (the segment of
+// the block's first point — almost always, segments are thousands of points long) combine in LDS; one thread per bound
+// then issues the block's global atomics.  Stragglers (a wave or lane straddling a segment border) use their own.
 __device__ inline void seg_minmax_update(int* __restrict__ seg_minmax, bool active, uint32_t seg, int ix, int iy, int iz) {
+  __shared__ int blk_mm[6];
+  __shared__ uint32_t blk_seg;
+  __shared__ int blk_used;
+  if (threadIdx.x == 0) { blk_seg = seg; blk_used = 0; }
+  if (threadIdx.x < 6) blk_mm[threadIdx.x] = threadIdx.x < 3 ? 2147483647 : (-2147483647 - 1);
+  __syncthreads();
+  const uint32_t lead = blk_seg;   // (thread 0 may be inactive: then nobody matches a stale value only by accident, which is harmless)
   const unsigned long long mact = __ballot(active);
-  if (mact == 0) return;
-  const int leader = __builtin_ctzll(mact);
-  const uint32_t first = __shfl(seg, leader, 64);
-  const bool same = active && seg == first;
-  int v[6] = {same ? ix : 2147483647, same ? iy : 2147483647, same ? iz : 2147483647,
-              same ? ix : (-2147483647 - 1), same ? iy : (-2147483647 - 1), same ? iz : (-2147483647 - 1)};
+  if (mact != 0) {
+    const int leader = __builtin_ctzll(mact);
+    const uint32_t first = __shfl(seg, leader, 64);
+    const bool same = active && seg == first;
+    int v[6] = {same ? ix : 2147483647, same ? iy : 2147483647, same ? iz : 2147483647,
+                same ? ix : (-2147483647 - 1), same ? iy : (-2147483647 - 1), same ? iz : (-2147483647 - 1)};
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
+    for (int d = 32; d > 0; d >>= 1) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const int a = __shfl_xor(v[k], d, 64), b = __shfl_xor(v[3 + k], d, 64);
-      v[k] = a < v[k] ? a : v[k];
-      v[3 + k] = b > v[3 + k] ? b : v[3 + k];
+      for (int k = 0; k < 3; k++) {
+        const int a_ = __shfl_xor(v[k], d, 64), b_ = __shfl_xor(v[3 + k], d, 64);
+        v[k] = a_ < v[k] ? a_ : v[k];
+        v[3 + k] = b_ > v[3 + k] ? b_ : v[3 + k];
+      }
+    }
+    if ((int)__lane_id() == leader) {
+      if (first == lead) {
+        // LDS combine for the lead segment
+        atomicMin(&blk_mm[0], v[0]); atomicMin(&blk_mm[1], v[1]); atomicMin(&blk_mm[2], v[2]);
+        atomicMax(&blk_mm[3], v[3]); atomicMax(&blk_mm[4], v[4]); atomicMax(&blk_mm[5], v[5]);
+        blk_used = 1;
+      } else {
+        int* mm = seg_minmax + 6 * first;
+        atomicMin(&mm[0], v[0]); atomicMin(&mm[1], v[1]); atomicMin(&mm[2], v[2]);
+        atomicMax(&mm[3], v[3]); atomicMax(&mm[4], v[4]); atomicMax(&mm[5], v[5]);
+      }
+    }
+    if (active && !same) {
+      int* mm = seg_minmax + 6 * seg;
+      atomicMin(&mm[0], ix); atomicMin(&mm[1], iy); atomicMin(&mm[2], iz);
+      atomicMax(&mm[3], ix); atomicMax(&mm[4], iy); atomicMax(&mm[5], iz);
     }
   }
-  if ((int)__lane_id() == leader) {
-    int* mm = seg_minmax + 6 * first;
-    atomicMin(&mm[0], v[0]); atomicMin(&mm[1], v[1]); atomicMin(&mm[2], v[2]);
-    atomicMax(&mm[3], v[3]); atomicMax(&mm[4], v[4]); atomicMax(&mm[5], v[5]);
-  }
-  if (active && !same) {
-    int* mm = seg_minmax + 6 * seg;
-    atomicMin(&mm[0], ix); atomicMin(&mm[1], iy); atomicMin(&mm[2], iz);
-    atomicMax(&mm[3], ix); atomicMax(&mm[4], iy); atomicMax(&mm[5], iz);
+  __syncthreads();
+  if (threadIdx.x < 6 && blk_used) {
+    int* mm = seg_minmax + 6 * lead;
+    if (threadIdx.x < 3) atomicMin(&mm[threadIdx.x], blk_mm[threadIdx.x]);
+    else atomicMax(&mm[threadIdx.x], blk_mm[threadIdx.x]);
   }
 }
 

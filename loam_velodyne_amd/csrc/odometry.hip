@@ -16,7 +16,8 @@
 namespace loamx {
 
 constexpr int OD_THREADS = 256;
-constexpr int OD_WAVES = OD_THREADS / 64;
+constexpr int OD_TR_STRIDE = OD_THREADS + 2;        // k_odom_lm LDS transpose: row stride in doubles (bank spread)
+constexpr int OD_PART_STRIDE = 16 * LX_NSUM + 16;   // per stream: 16 workgroups' partial sums (+ 16 slots for LOAMX_PROF_LM timestamps)
 // k_odom_lm: up to 16 workgroups x 256 threads x 2 features per thread kept in registers = 8192 features per sweep
 
 // per-point de-skew angles (|a| << 1): float sincos (<= 2 ulp); the once-per-iteration pose trig stays in double
@@ -241,17 +242,23 @@ __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ pro
 // workgroup that draws the last ticket adds the NB partial sums in workgroup order (deterministic), solves, updates the
 // pose and bumps the stream's generation counter, on which the others spin.  NB x streams <= 16 x 64 workgroups are all
 // resident, so the spin cannot deadlock.
+#ifdef LOAMX_PROF_LM
+#define LM_TS(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && iter == iter0 + 1) pb.part[16 * LX_NSUM + (k)] = (double)wall_clock64(); } while (0)
+#else
+#define LM_TS(k) do { } while (0)
+#endif
 template <int OD_FPT>
 __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict__ probs, OdomParams P, int iter0, int n_iters) {
   OdomProblem& pb = probs[blockIdx.y];
   if (pb.done) return;
   const unsigned NB = gridDim.x;
   const unsigned gen0 = __hip_atomic_load(&pb.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x;
   const int nSharp = (int)pb.n_sharp, nFlat = (int)pb.n_flat, nFeat = nSharp + nFlat;
   __shared__ float T[6];
   __shared__ float trig[6];
-  __shared__ double red[OD_WAVES][LX_NSUM];
+  __shared__ double red[8][LX_NSUM];
+  __shared__ double tr[LX_NSUM * OD_TR_STRIDE];
   __shared__ int sh_done, sh_last;
   __shared__ float ws[216];
   __shared__ double sums[LX_NSUM];
@@ -285,11 +292,13 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
 
   for (int iter = iter0; iter < iter0 + n_iters; iter++) {
     // ---- phase C: residual rows + normal equations
+    LM_TS(0);
     if (tid < 6) {   // sin/cos of the three angles, one per lane, double then rounded (see pose_set_angles)
       const double ang = (double)T[tid >> 1];
       trig[tid] = (float)((tid & 1) ? cos(ang) : sin(ang));
     }
     __syncthreads();
+    LM_TS(1);
     double v[LX_NSUM];
 #pragma unroll
     for (int k = 0; k < LX_NSUM; k++) v[k] = 0.0;
@@ -368,17 +377,27 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
         v[k] += 1.0;
       }
     }
+    LM_TS(2);
+    // transposed reduction through LDS (28 dependent 64-bit shuffle chains cost ~6 us; this is < 1 us): column c of the
+    // 256 x 28 table is summed by 8 threads (rows g, g+8, ...), then the 8 strands in order — a fixed order, so the
+    // sums are deterministic
 #pragma unroll
-    for (int t = 0; t < LX_NSUM; t++) {
-      double x = v[t];
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
-      if (lane == 0) red[wid][t] = x;
+    for (int t = 0; t < LX_NSUM; t++) tr[t * OD_TR_STRIDE + tid] = v[t];
+    __syncthreads();
+    if (tid < 8 * LX_NSUM) {
+      const int c = tid % LX_NSUM, g = tid / LX_NSUM;
+      const double* col = tr + c * OD_TR_STRIDE + g;
+      double x = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < OD_THREADS / 8; j++) x += col[8 * j];
+      red[g][c] = x;
     }
     __syncthreads();
+    LM_TS(3);
     if (tid < LX_NSUM) {
       double x = 0.0;
-      for (int w = 0; w < OD_WAVES; w++) x += red[w][tid];
+#pragma unroll
+      for (int w = 0; w < 8; w++) x += red[w][tid];
       if (NB > 1) {
         pb.part[blockIdx.x * LX_NSUM + tid] = x;
         __threadfence();   // release the partial sum before the ticket is drawn
@@ -388,8 +407,10 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
     }
     if (NB > 1) {
       __syncthreads();
+      LM_TS(4);
       if (tid == 0) sh_last = atomicAdd(&pb.ticket, 1u) == NB - 1 ? 1 : 0;
       __syncthreads();
+      LM_TS(5);
       if (!sh_last) {
         // wait for the solving workgroup, then pick up the new pose
         if (tid == 0) {
@@ -400,14 +421,18 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
         }
         __syncthreads();
         if (tid < 6) T[tid] = __hip_atomic_load(&pb.transform[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        LM_TS(6);
         __syncthreads();
         if (sh_done) break;
         continue;
       }
       __threadfence();   // acquire the other workgroups' partial sums
+      for (unsigned e = tid; e < NB * LX_NSUM; e += OD_THREADS)
+        tr[e] = __hip_atomic_load(&pb.part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
       if (tid < LX_NSUM) {
         double x = 0.0;
-        for (unsigned b = 0; b < NB; b++) x += __hip_atomic_load(&pb.part[b * LX_NSUM + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (unsigned b = 0; b < NB; b++) x += tr[b * LX_NSUM + tid];   // workgroup order: deterministic
         sums[tid] = x;
       }
       __syncthreads();
@@ -426,12 +451,14 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
     }
     __syncthreads();
     const int sel = (int)sums[27];   // block-uniform
+    LM_TS(7);
     if (tid == 0) {
       pb.stats.iterations = iter + 1;
       pb.stats.sel = sel;
     }
     if (sel >= 10 && tid < 64) qr_solve6_coop(AtA, AtB, X);   // wave 0, all lanes (:559)
     __syncthreads();
+    LM_TS(8);
     if (tid == 0) {
       if (sel >= 10) {   // :485-488
         if (iter == 0) pb.stats.degenerate = degeneracy_projector(AtA, 10.f, pb.matP, ws) ? 1 : 0;
@@ -462,6 +489,7 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
         __threadfence();
         __hip_atomic_store(&pb.gen, gen0 + (unsigned)(iter - iter0) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      LM_TS(9);
     }
     __syncthreads();
     if (sh_done) break;
@@ -532,7 +560,7 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
   for (uint32_t s = 0; s < n_streams; s++) streams_.push_back(new OdomStream());
   index_.init(st_);
   prob_.reserve(n_streams);
-  part_.reserve((size_t)n_streams * 16 * LX_NSUM);
+  part_.reserve((size_t)n_streams * OD_PART_STRIDE);
   h_prob_.reserve(n_streams);
   te_.reserve(n_streams);
   h_te_.reserve(n_streams);
@@ -651,7 +679,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       pb.stats = {0, 0, 0, 0};
       pb.done = 0;
       pb.ticket = 0; pb.gen = 0;
-      pb.part = part_.p + (size_t)active.size() * 16 * LX_NSUM;
+      pb.part = part_.p + (size_t)active.size() * OD_PART_STRIDE;
       max_feat = std::max(max_feat, I.n_sharp + I.n_flat);
       active.push_back(s);
     }
@@ -673,6 +701,15 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
     }
     LX_HIP(hipMemcpyAsync(h_prob_.p, prob_.p, sizeof(OdomProblem) * na, hipMemcpyDeviceToHost, st_));
     LX_HIP(hipStreamSynchronize(st_));
+#ifdef LOAMX_PROF_LM
+    {
+      double ts[16];
+      LX_HIP(hipMemcpy(ts, part_.p + 16 * LX_NSUM, sizeof(ts), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[lm ts, 10ns ticks]");
+      for (int k = 1; k < 10; k++) fprintf(stderr, " %d:%+.0f", k, ts[k] - ts[0]);
+      fprintf(stderr, "\n");
+    }
+#endif
     for (uint32_t a = 0; a < na; a++) {
       OdomStream& S = *streams_[active[a]];
       // _transform.rot_* = rad + x re-derives the cached sin/cos (:599-601)

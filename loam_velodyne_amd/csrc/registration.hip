@@ -725,20 +725,31 @@ __global__ __launch_bounds__(LX_RES_THREADS) void k_residual(
   for (int i = 0; i < 6; i++) v[k++] = (double)(a[i] * bb);
   v[k] = sel ? 1.0 : 0.0;
 
-  __shared__ double red[LX_RES_THREADS / 64][LX_NSUM];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  // transposed reduction through LDS, two halves of 14 sums (28 dependent 64-bit shuffle chains are several times
+  // slower): column c of the 256 x 14 table is summed by 8 threads (rows g, g+8, ...), then the 8 strands in order
+  constexpr int TRS = LX_RES_THREADS + 2, HALF = LX_NSUM / 2;
+  __shared__ double tr[HALF * TRS];
+  __shared__ double red[8][LX_NSUM];
 #pragma unroll
-  for (int t = 0; t < LX_NSUM; t++) {
-    double x = v[t];
+  for (int h = 0; h < 2; h++) {
+    if (h) __syncthreads();
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
-    if (lane == 0) red[wid][t] = x;
+    for (int t = 0; t < HALF; t++) tr[t * TRS + threadIdx.x] = v[h * HALF + t];
+    __syncthreads();
+    if (threadIdx.x < 8 * HALF) {
+      const int c = threadIdx.x % HALF, g = threadIdx.x / HALF;
+      const double* col = tr + c * TRS + g;
+      double x = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < LX_RES_THREADS / 8; j++) x += col[8 * j];
+      red[g][h * HALF + c] = x;
+    }
   }
   __syncthreads();
   if (threadIdx.x < LX_NSUM) {
     double x = 0.0;
 #pragma unroll
-    for (int w = 0; w < LX_RES_THREADS / 64; w++) x += red[w][threadIdx.x];
+    for (int w = 0; w < 8; w++) x += red[w][threadIdx.x];
     partials[((size_t)s * nblk + blockIdx.x) * LX_NSUM + threadIdx.x] = x;
   }
 }

@@ -371,12 +371,15 @@ __device__ inline bool degeneracy_projector(const float* AtA, float thr, float* 
   return degenerate;
 }
 
-// 6x6 column-pivoted Householder QR solve spread over the lanes of a wave: lane (l & 7) = c < 6 owns COLUMN c of A,
-// lane 6 owns the right-hand side; every arithmetic operation is the one the scalar qr_solve<6,6> performs on that
-// element, in the same order, so the result is bit-identical — only the serial dependency chain shrinks ~8x.
-// Must be called by all 64 lanes of a wave (groups of 8 compute redundantly); AtA/AtB/X are in LDS or global memory.
+// 6x6 column-pivoted Householder QR solve spread over the lanes of a wave: lane c < 6 owns COLUMN c of A, lane 6 owns the
+// right-hand side; every arithmetic operation is the one the scalar qr_solve<6,6> performs on that element, in the same
+// order, so the result is bit-identical — only the serial dependency chain shrinks.  Values travel between lanes with
+// v_readlane (a few cycles) instead of ds_bpermute (~60 cycles each on the critical path).
+// Must be called by ALL 64 lanes of wave 0 of the workgroup; AtA/AtB/X are in LDS or global memory.
+__device__ inline float lane_get(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+
 __device__ inline void qr_solve6_coop(const float* AtA, const float* AtB, float* X) {
-  const int gl = (int)(threadIdx.x & 7);
+  const int gl = (int)(threadIdx.x & 63);
   float a[6];
 #pragma unroll
   for (int r = 0; r < 6; r++) a[r] = gl < 6 ? AtA[r * 6 + gl] : (gl == 6 ? AtB[r] : 0.f);
@@ -385,10 +388,10 @@ __device__ inline void qr_solve6_coop(const float* AtA, const float* AtB, float*
   float s0 = 0.f;
 #pragma unroll
   for (int r = 0; r < 6; r++) s0 += a[r] * a[r];
-  float nrm = gl < 6 ? sqrtf(s0) : 0.f;
+  const float nrm = gl < 6 ? sqrtf(s0) : 0.f;
   float maxnorm = 0.f;
 #pragma unroll
-  for (int c = 0; c < 6; c++) maxnorm = fmaxf(maxnorm, __shfl(nrm, c, 8));
+  for (int c = 0; c < 6; c++) maxnorm = fmaxf(maxnorm, lane_get(nrm, c));
   const float thr_helper = (maxnorm * FLT_EPSILON) * (maxnorm * FLT_EPSILON) / 6.0f;
   int nonzero = 6;
 #pragma unroll
@@ -401,16 +404,22 @@ __device__ inline void qr_solve6_coop(const float* AtA, const float* AtB, float*
     float bestn = -1.f;
 #pragma unroll
     for (int c = k; c < 6; c++) {
-      const float sc = __shfl(s, c, 8);
+      const float sc = lane_get(s, c);
       if (sc > bestn) { bestn = sc; best = c; }
     }
+    best = __builtin_amdgcn_readfirstlane(best);
     if (nonzero == 6 && bestn < thr_helper * float(6 - k)) nonzero = k;
     // swap columns k and best
-    const int partner = gl == k ? best : (gl == best ? k : gl);
 #pragma unroll
-    for (int r = 0; r < 6; r++) a[r] = __shfl(a[r], partner, 8);
-    perm = __shfl(perm, partner, 8);
-    // Householder vector from column k (computed by its owner, broadcast)
+    for (int r = 0; r < 6; r++) {
+      const float ak = lane_get(a[r], k), ab = lane_get(a[r], best);
+      a[r] = gl == k ? ab : (gl == best ? ak : a[r]);
+    }
+    {
+      const int pk = __builtin_amdgcn_readlane(perm, k), pb = __builtin_amdgcn_readlane(perm, best);
+      perm = gl == k ? pb : (gl == best ? pk : perm);
+    }
+    // Householder vector from column k (every lane computes one from its own column; lane k's is broadcast)
     float tail = 0.f;
 #pragma unroll
     for (int r = k + 1; r < 6; r++) tail += a[r] * a[r];
@@ -429,10 +438,10 @@ __device__ inline void qr_solve6_coop(const float* AtA, const float* AtB, float*
       tau = (beta - c0) / beta;
     }
     v[k] = 1.f;
-    tau = __shfl(tau, k, 8);
-    beta = __shfl(beta, k, 8);
+    tau = lane_get(tau, k);
+    beta = lane_get(beta, k);
 #pragma unroll
-    for (int r = 0; r < 6; r++) v[r] = __shfl(v[r], k, 8);
+    for (int r = k + 1; r < 6; r++) v[r] = lane_get(v[r], k);
     if (gl == k) {
       a[k] = beta;
 #pragma unroll
@@ -450,16 +459,16 @@ __device__ inline void qr_solve6_coop(const float* AtA, const float* AtB, float*
   float y = 0.f;
 #pragma unroll
   for (int k = 5; k >= 0; k--) {
-    float sacc = __shfl(a[k], 6, 8);   // b[k]
+    float sacc = lane_get(a[k], 6);   // b[k]
 #pragma unroll
     for (int c = k + 1; c < 6; c++) {
-      const float term = __shfl(a[k] * y, c, 8);   // A[k][c] * y[c] from the lane owning column c
+      const float term = lane_get(a[k] * y, c);   // A[k][c] * y[c] from the lane owning column c
       if (c < nonzero) sacc -= term;
     }
-    const float diag = __shfl(a[k], k, 8);
+    const float diag = lane_get(a[k], k);
     if (gl == k && k < nonzero) y = sacc / diag;
   }
-  if (threadIdx.x < 6) X[perm] = gl < nonzero ? y : 0.f;
+  if (gl < 6) X[perm] = gl < nonzero ? y : 0.f;
 }
 
 // 6x6 column-pivoted QR solve on plain arrays (single thread)

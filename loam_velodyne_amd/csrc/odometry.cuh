@@ -31,8 +31,8 @@ struct OdomProblem {
   OdomStats stats;
   int done;
   float matP[36];
-  unsigned ticket, gen;   // k_odom_lm: arrivals of the current iteration / iterations completed (per-stream barrier)
-  double* part;           // k_odom_lm: [16][LX_NSUM] partial normal equations of the stream's workgroups
+  unsigned ticket;        // k_odom_lm: workgroup arrivals since the problem was set up (per-stream barrier)
+  double* part;           // k_odom_lm: [2][16][LX_NSUM] partial normal equations of the stream's workgroups
 };
 
 // one sweep's four feature clouds on the device.  less_sharp / less_flat of ALL streams must be contiguous in stream

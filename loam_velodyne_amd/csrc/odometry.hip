@@ -17,7 +17,7 @@ namespace loamx {
 
 constexpr int OD_THREADS = 256;
 constexpr int OD_TR_STRIDE = OD_THREADS + 2;        // k_odom_lm LDS transpose: row stride in doubles (bank spread)
-constexpr int OD_PART_STRIDE = 16 * LX_NSUM + 16;   // per stream: 16 workgroups' partial sums (+ 16 slots for LOAMX_PROF_LM timestamps)
+constexpr int OD_PART_STRIDE = 2 * 16 * LX_NSUM + 16;   // per stream: 2 x 16 workgroups' partial sums (+ 16 slots for LOAMX_PROF_LM timestamps)
 // k_odom_lm: up to 16 workgroups x 256 threads x 2 features per thread kept in registers = 8192 features per sweep
 
 // per-point de-skew angles (|a| << 1): float sincos (<= 2 ulp); the once-per-iteration pose trig stays in double
@@ -238,12 +238,13 @@ __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ pro
 
 // ---- phase C: iterations [iter0, iter0 + n_iters) of one stream in gridDim.x PERSISTENT workgroups (grid = NB x streams).
 // The features of a stream are dealt out over its NB workgroups (one CU cannot evaluate 2304 rows in less than ~16 us,
-// nine can).  Per iteration every workgroup reduces its rows to 28 double sums, publishes them and takes a ticket; the
-// workgroup that draws the last ticket adds the NB partial sums in workgroup order (deterministic), solves, updates the
-// pose and bumps the stream's generation counter, on which the others spin.  NB x streams <= 16 x 64 workgroups are all
-// resident, so the spin cannot deadlock.
+// nine can).  Per iteration every workgroup reduces its rows to 28 double sums, publishes them (double-buffered by
+// iteration parity) and counts itself in on the stream's arrival counter; once all NB have arrived EVERY workgroup adds
+// the NB partial sums in workgroup order and solves — the same deterministic arithmetic everywhere, so all of them hold
+// the same new pose without a second exchange.  Workgroup 0 records the results.  NB x streams <= 16 x 64 workgroups
+// are all resident, so the spin cannot deadlock.
 #ifdef LOAMX_PROF_LM
-#define LM_TS(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && iter == iter0 + 1) pb.part[16 * LX_NSUM + (k)] = (double)wall_clock64(); } while (0)
+#define LM_TS(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && iter == iter0 + 1) pb.part[32 * LX_NSUM + (k)] = (double)wall_clock64(); } while (0)
 #else
 #define LM_TS(k) do { } while (0)
 #endif
@@ -252,19 +253,20 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
   OdomProblem& pb = probs[blockIdx.y];
   if (pb.done) return;
   const unsigned NB = gridDim.x;
-  const unsigned gen0 = __hip_atomic_load(&pb.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int tid = threadIdx.x;
   const int nSharp = (int)pb.n_sharp, nFlat = (int)pb.n_flat, nFeat = nSharp + nFlat;
   __shared__ float T[6];
   __shared__ float trig[6];
   __shared__ double red[8][LX_NSUM];
   __shared__ double tr[LX_NSUM * OD_TR_STRIDE];
-  __shared__ int sh_done, sh_last;
+  __shared__ int sh_done, sh_degen;
+  __shared__ float matP[36];
   __shared__ float ws[216];
   __shared__ double sums[LX_NSUM];
   __shared__ float AtA[36], AtB[6], X[6], X2[6];
   if (tid < 6) T[tid] = pb.transform[tid];
-  if (tid == 0) sh_done = 0;
+  if (tid == 0) { sh_done = 0; sh_degen = pb.stats.degenerate; }
+  if (tid < 36) matP[tid] = pb.matP[tid];   // set at iteration 0 (an earlier launch when iter0 > 0)
   __syncthreads();
 
   // the correspondences are fixed for the iterations of this launch: keep each thread's features (raw point + tripod
@@ -399,8 +401,8 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
 #pragma unroll
       for (int w = 0; w < 8; w++) x += red[w][tid];
       if (NB > 1) {
-        pb.part[blockIdx.x * LX_NSUM + tid] = x;
-        __threadfence();   // release the partial sum before the ticket is drawn
+        pb.part[(((unsigned)iter & 1u) * 16u + blockIdx.x) * LX_NSUM + tid] = x;
+        __threadfence();   // release the partial sums before this workgroup is counted in
       } else {
         sums[tid] = x;
       }
@@ -408,27 +410,16 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
     if (NB > 1) {
       __syncthreads();
       LM_TS(4);
-      if (tid == 0) sh_last = atomicAdd(&pb.ticket, 1u) == NB - 1 ? 1 : 0;
+      if (tid == 0) {
+        atomicAdd(&pb.ticket, 1u);
+        const unsigned target = NB * (unsigned)(iter + 1);   // the host zeroes the counter; every iteration adds NB
+        while (__hip_atomic_load(&pb.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        __threadfence();   // acquire the other workgroups' partial sums
+      }
       __syncthreads();
       LM_TS(5);
-      if (!sh_last) {
-        // wait for the solving workgroup, then pick up the new pose
-        if (tid == 0) {
-          const unsigned target = gen0 + (unsigned)(iter - iter0) + 1u;
-          while (__hip_atomic_load(&pb.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != target) __builtin_amdgcn_s_sleep(2);
-          __threadfence();   // acquire
-          sh_done = __hip_atomic_load(&pb.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        if (tid < 6) T[tid] = __hip_atomic_load(&pb.transform[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        LM_TS(6);
-        __syncthreads();
-        if (sh_done) break;
-        continue;
-      }
-      __threadfence();   // acquire the other workgroups' partial sums
       for (unsigned e = tid; e < NB * LX_NSUM; e += OD_THREADS)
-        tr[e] = __hip_atomic_load(&pb.part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tr[e] = __hip_atomic_load(&pb.part[((unsigned)iter & 1u) * 16u * LX_NSUM + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
       if (tid < LX_NSUM) {
         double x = 0.0;
@@ -452,7 +443,7 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
     __syncthreads();
     const int sel = (int)sums[27];   // block-uniform
     LM_TS(7);
-    if (tid == 0) {
+    if (tid == 0 && blockIdx.x == 0) {
       pb.stats.iterations = iter + 1;
       pb.stats.sel = sel;
     }
@@ -461,12 +452,18 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
     LM_TS(8);
     if (tid == 0) {
       if (sel >= 10) {   // :485-488
-        if (iter == 0) pb.stats.degenerate = degeneracy_projector(AtA, 10.f, pb.matP, ws) ? 1 : 0;
-        if (pb.stats.degenerate) {
+        if (iter == 0) {
+          sh_degen = degeneracy_projector(AtA, 10.f, matP, ws) ? 1 : 0;
+          if (blockIdx.x == 0) {
+            pb.stats.degenerate = sh_degen;
+            for (int k = 0; k < 36; k++) pb.matP[k] = matP[k];
+          }
+        }
+        if (sh_degen) {
           for (int r = 0; r < 6; r++) X2[r] = X[r];
           for (int r = 0; r < 6; r++) {
             float acc = 0.f;
-            for (int c = 0; c < 6; c++) acc += pb.matP[r * 6 + c] * X2[c];
+            for (int c = 0; c < 6; c++) acc += matP[r * 6 + c] * X2[c];
             X[r] = acc;
           }
         }
@@ -481,13 +478,9 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
         const float deltaT = (float)sqrt((double)t0 * t0 + (double)t1 * t1 + (double)t2 * t2);
         if (deltaR < P.delta_r_abort && deltaT < P.delta_t_abort) sh_done = 1;
       }
-      // publish (the other workgroups of the stream are spinning on gen)
-      for (int r = 0; r < 6; r++) pb.transform[r] = T[r];
-      if (sh_done) pb.done = 1;
-      if (NB > 1) {
-        atomicExch(&pb.ticket, 0u);
-        __threadfence();
-        __hip_atomic_store(&pb.gen, gen0 + (unsigned)(iter - iter0) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (blockIdx.x == 0) {
+        for (int r = 0; r < 6; r++) pb.transform[r] = T[r];
+        if (sh_done) pb.done = 1;
       }
       LM_TS(9);
     }
@@ -519,8 +512,12 @@ __global__ __launch_bounds__(256) void k_transform_to_end(float4* __restrict__ p
   pts[i] = to_end_point(pts[i], P);
 }
 // all clouds of a batch: cloud k belongs to stream k % ns
+// src_c / src_s: when given, point i is read from the (contiguous) source clouds instead of pts — the staging copy of the
+// current clouds is fused into the re-projection
 __global__ __launch_bounds__(256) void k_transform_to_end_batch(float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off,
-                                                                uint32_t K, uint32_t ns, const ToEndParams* __restrict__ params) {
+                                                                uint32_t K, uint32_t ns, const ToEndParams* __restrict__ params,
+                                                                const float4* __restrict__ src_c, const float4* __restrict__ src_s,
+                                                                uint32_t n_corner_all) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t lo = 0, hi = K;
@@ -529,6 +526,11 @@ __global__ __launch_bounds__(256) void k_transform_to_end_batch(float4* __restri
     if (off[mid] <= i) lo = mid; else hi = mid;
   }
   const ToEndParams P = params[lo % ns];
+  if (src_c) {
+    const float4 p = i < n_corner_all ? src_c[i] : src_s[i - n_corner_all];
+    pts[i] = P.enabled ? to_end_point(p, P) : p;
+    return;
+  }
   if (!P.enabled) return;
   pts[i] = to_end_point(pts[i], P);
 }
@@ -558,6 +560,9 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
     own_stream_ = true;
   }
   for (uint32_t s = 0; s < n_streams; s++) streams_.push_back(new OdomStream());
+  // nn1_wave is exact for any cell size; coarser cells than the map index keep the cell tables (rebuilt every sweep) small
+  index_.cell_size = 2.1f;
+  if (const char* e = getenv("LOAMX_ODOM_CELL")) { const float v = (float)atof(e); if (v >= 0.25f && v <= 16.f) index_.cell_size = v; }
   index_.init(st_);
   prob_.reserve(n_streams);
   part_.reserve((size_t)n_streams * OD_PART_STRIDE);
@@ -629,13 +634,19 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
     contig_c = contig_c && in[s].less_sharp == in[s - 1].less_sharp + in[s - 1].n_less_sharp;
     contig_s = contig_s && in[s].less_flat == in[s - 1].less_flat + in[s - 1].n_less_flat;
   }
-  if (contig_c) {
+  // contiguous inputs (the feature extractor's layout) are not staged at all: the re-projection at the tail reads them
+  const bool fused_stage = contig_c && contig_s;
+  const float4* src_c = fused_stage ? in[0].less_sharp : nullptr;
+  const float4* src_s = fused_stage ? in[0].less_flat : nullptr;
+  if (fused_stage) {
+  } else if (contig_c) {
     if (n_corner_all) LX_HIP(hipMemcpyAsync(cur_.p, in[0].less_sharp, sizeof(float4) * n_corner_all, hipMemcpyDeviceToDevice, st_));
   } else {
     for (uint32_t s = 0; s < ns; s++)
       if (in[s].n_less_sharp) LX_HIP(hipMemcpyAsync(cur_.p + h_cur_off_[s], in[s].less_sharp, sizeof(float4) * in[s].n_less_sharp, hipMemcpyDeviceToDevice, st_));
   }
-  if (contig_s) {
+  if (fused_stage) {
+  } else if (contig_s) {
     if (n_all > n_corner_all) LX_HIP(hipMemcpyAsync(cur_.p + n_corner_all, in[0].less_flat, sizeof(float4) * (n_all - n_corner_all), hipMemcpyDeviceToDevice, st_));
   } else {
     for (uint32_t s = 0; s < ns; s++)
@@ -678,7 +689,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       S.transform.get(pb.transform);
       pb.stats = {0, 0, 0, 0};
       pb.done = 0;
-      pb.ticket = 0; pb.gen = 0;
+      pb.ticket = 0;
       pb.part = part_.p + (size_t)active.size() * OD_PART_STRIDE;
       max_feat = std::max(max_feat, I.n_sharp + I.n_flat);
       active.push_back(s);
@@ -704,7 +715,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
 #ifdef LOAMX_PROF_LM
     {
       double ts[16];
-      LX_HIP(hipMemcpy(ts, part_.p + 16 * LX_NSUM, sizeof(ts), hipMemcpyDeviceToHost));
+      LX_HIP(hipMemcpy(ts, part_.p + 32 * LX_NSUM, sizeof(ts), hipMemcpyDeviceToHost));
       fprintf(stderr, "[lm ts, 10ns ticks]");
       for (int k = 1; k < 10; k++) fprintf(stderr, " %d:%+.0f", k, ts[k] - ts[0]);
       fprintf(stderr, "\n");
@@ -744,7 +755,8 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   LX_HIP(hipMemcpyAsync(d_cur_off_.p, h_off_pin_.p, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st_));
   LX_HIP(hipMemcpyAsync(te_.p, h_te_.p, sizeof(ToEndParams) * ns, hipMemcpyHostToDevice, st_));
   if (n_all)
-    hipLaunchKernelGGL(k_transform_to_end_batch, dim3((n_all + 255) / 256), dim3(256), 0, st_, cur_.p, n_all, d_cur_off_.p, K, ns, te_.p);
+    hipLaunchKernelGGL(k_transform_to_end_batch, dim3((n_all + 255) / 256), dim3(256), 0, st_, cur_.p, n_all, d_cur_off_.p, K, ns, te_.p, src_c,
+                       src_s, n_corner_all);
   std::swap(cur_.p, last_.p);
   std::swap(cur_.cap, last_.cap);
   h_last_off_ = h_cur_off_;

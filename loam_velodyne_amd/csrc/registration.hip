@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_bb_bbox(const float4* __restrict__ pts,
 }
 // one thread: grid descriptors, per-cloud cell budget, table bases
 __global__ void k_bb_setup(const uint32_t* __restrict__ enc, const uint32_t* __restrict__ off, uint32_t K, GridDescB* __restrict__ desc,
-                           uint32_t* __restrict__ scratch, uint32_t max_cells_total) {
+                           uint32_t* __restrict__ scratch, uint32_t max_cells_total, float cell0) {
   const uint32_t budget = max_cells_total / (K ? K : 1);
   uint32_t base = 0;
   for (uint32_t c = 0; c < K; c++) {
@@ -222,7 +222,7 @@ __global__ void k_bb_setup(const uint32_t* __restrict__ enc, const uint32_t* __r
     } else {
       float mn[3], mx[3];
       for (int a = 0; a < 3; a++) { mn[a] = dec_f32(enc[6 * c + a]); mx[a] = dec_f32(enc[6 * c + 3 + a]); }
-      float h = 1.05f;
+      float h = cell0;
       for (;;) {
         d.g.inv_h = 1.0f / h;
         d.g.ox = mn[0]; d.g.oy = mn[1]; d.g.oz = mn[2];
@@ -298,7 +298,7 @@ void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_
   for (uint32_t c = 0; c < K; c++) max_len = std::max(max_len, h_off[c + 1] - h_off[c]);
   const uint32_t nbx = std::min<uint32_t>(std::max<uint32_t>((max_len + 255) / 256, 1u), 32u);
   hipLaunchKernelGGL(k_bb_bbox, dim3(nbx, K), dim3(256), 0, st_, d_pts, d_off_.p, enc_.p);
-  hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1), 0, st_, enc_.p, d_off_.p, K, d_desc_.p, scratch_.p, LX_MAX_CELLS);
+  hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1), 0, st_, enc_.p, d_off_.p, K, d_desc_.p, scratch_.p, LX_MAX_CELLS, cell_size);
   hipLaunchKernelGGL(k_zero_u32_dn, dim3(2048), dim3(256), 0, st_, cursor_.p, scratch_.p + 0);
   if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off_.p, K, d_desc_.p, cell_of_.p, cursor_.p);
   exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 2, scratch_.p + 1, LX_MAX_CELLS, st_);

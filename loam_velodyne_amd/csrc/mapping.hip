@@ -430,7 +430,8 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   // ---- results
   float pose6[6];
   int stats4[4];
-  reg.download(pose6, stats4);   // synchronises the stream
+  reg.sync();   // the histogram / counter copies above
+  reg.download(pose6, stats4);
   LX_HIP(hipGetLastError());
   for (int t = 0; t < 2; t++) {
     TypeMap& T = tm[t];

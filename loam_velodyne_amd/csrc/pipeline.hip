@@ -8,7 +8,10 @@
 #include "features.cuh"
 #include "odometry.cuh"
 #include "registration.cuh"
-#include <future>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <memory>
 
 namespace loamx {
@@ -45,6 +48,7 @@ class Pipeline {
     odom.params.delta_t_abort = oc.delta_t_abort;
     odom.params.delta_r_abort = oc.delta_r_abort;
     device = mc.device;
+    if (getenv("LOAMX_NO_LOOKAHEAD")) prefetch = false;   // debugging / profiling: run the stages one after the other
   }
   Registrar reg;
   OdometryBatch odom;
@@ -60,18 +64,77 @@ class Pipeline {
   std::vector<char> launched;
   PinBuf<uint32_t> h_off3[3];
   hipEvent_t evF[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-  hipEvent_t evO[2] = {nullptr, nullptr};
-  float feat_ms[3] = {0, 0, 0}, odom_ms = 0, odom_ms_next = 0;
+  // stage timers are read lazily (an elapsed time is taken once both events have completed) so that measuring never
+  // makes the host wait for a stage
+  struct LazyTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool pending = false;
+    float ms = 0.f;
+    void create() { if (!a) { LX_HIP(hipEventCreate(&a)); LX_HIP(hipEventCreate(&b)); } }
+    void resolve() {
+      if (pending && hipEventQuery(b) == hipSuccess) { LX_HIP(hipEventElapsedTime(&ms, a, b)); pending = false; }
+    }
+    void destroy() { if (a) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); a = b = nullptr; } }
+  };
+  LazyTimer tmO[2], tmM[2];   // by step parity
+  float feat_ms[3] = {0, 0, 0};
   int odom_ready_step = -1;
   float last_ms[4] = {0, 0, 0, 0};
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool timing = false;
 
+  // the odometry look-ahead runs on a persistent host thread (it blocks on its Gauss-Newton results)
+  std::thread worker;
+  std::mutex mu;
+  std::condition_variable cv;
+  int job = -1;
+  bool job_done = true, quit = false;
+  std::exception_ptr job_err;
+  void worker_main() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      int t;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return job >= 0 || quit; });
+        if (quit) return;
+        t = job;
+        job = -1;
+      }
+      std::exception_ptr err;
+      try { trO[0] = tr_us(); run_odometry((uint32_t)t); trO[3] = tr_us(); } catch (...) { err = std::current_exception(); }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        job_err = err;
+        job_done = true;
+      }
+      cv.notify_all();
+    }
+  }
+  void kick(uint32_t t) {
+    if (!worker.joinable()) worker = std::thread([this] { worker_main(); });
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = (int)t;
+      job_done = false;
+    }
+    cv.notify_all();
+  }
+  void join_job() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return job_done; });
+    if (job_err) { std::exception_ptr e = job_err; job_err = nullptr; std::rethrow_exception(e); }
+  }
+
   ~Pipeline() {
+    if (worker.joinable()) {
+      { std::lock_guard<std::mutex> lk(mu); quit = true; }
+      cv.notify_all();
+      worker.join();
+    }
     fx.clear();
     for (auto& a : evF) for (auto& e : a) if (e) (void)hipEventDestroy(e);
-    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-    for (auto& e : evO) if (e) (void)hipEventDestroy(e);
+    for (auto& tm : tmO) tm.destroy();
+    for (auto& tm : tmM) tm.destroy();
     if (fstream) (void)hipStreamDestroy(fstream);
   }
 
@@ -124,6 +187,7 @@ class Pipeline {
     uint32_t* ho[3] = {hb, hb + (ns + 1), hb + 2 * (ns + 1)};
     uint32_t* hlf = hb + 3 * (ns + 1);
     LX_HIP(hipEventSynchronize(evF[t % 3][1]));
+    trO[1] = tr_us();
     launched[t] = 0;
     if (timing) LX_HIP(hipEventElapsedTime(&feat_ms[t % 3], evF[t % 3][0], evF[t % 3][1]));
     std::vector<OdomInput> in(ns);
@@ -133,15 +197,17 @@ class Pipeline {
       in[s] = OdomInput{F.d_feat(0) + ho[0][s], ho[0][s + 1] - ho[0][s], F.d_feat(1) + ho[1][s], ho[1][s + 1] - ho[1][s],
                         F.d_feat(2) + ho[2][s], ho[2][s + 1] - ho[2][s], F.d_less_flat() + la, lb - la};
     }
+    LazyTimer& tm = tmO[t & 1];
     if (timing) {
-      if (!evO[0]) { LX_HIP(hipEventCreate(&evO[0])); LX_HIP(hipEventCreate(&evO[1])); }
-      LX_HIP(hipEventRecord(evO[0], odom.stream()));
+      tm.create();
+      tm.pending = false;
+      LX_HIP(hipEventRecord(tm.a, odom.stream()));
     }
     odom.process(in.data(), rc.data(), true);   // returns once the poses are known; clouds ready at odom.tail_event()
+    trO[2] = tr_us();
     if (timing) {
-      LX_HIP(hipEventRecord(evO[1], odom.stream()));
-      LX_HIP(hipEventSynchronize(evO[1]));
-      LX_HIP(hipEventElapsedTime(&odom_ms_next, evO[0], evO[1]));
+      LX_HIP(hipEventRecord(tm.b, odom.stream()));
+      tm.pending = true;
     }
     for (uint32_t s = 0; s < ns; s++) {
       OdomStream& O = odom.stream_state(s);
@@ -161,98 +227,125 @@ class Pipeline {
   // stage of step t feeds an earlier stage of step t+1):
   //   registration M(t) on the registrar's stream  ||  odometry O(t+1) on the odometry stream  ||  features F(t+2)
   // step(t) returns when M(t) is complete; O(t+1) / F(t+2) are look-ahead whose results are kept for the next call.
+  // host-side timeline of one step (LOAMX_PIPE_TRACE=1): microseconds since step() entry
+  bool trace = getenv("LOAMX_PIPE_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point tr0;
+  double tr_us() const { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); }
+  double trO[4] = {0, 0, 0, 0};
+
   int step(uint32_t t) {
     LX_REQUIRE(t < fx.size(), "step index beyond the staged sweeps");
+    tr0 = std::chrono::steady_clock::now();
+    double trM[6] = {0, 0, 0, 0, 0, 0};
     LX_HIP(hipSetDevice(device));
     hipStream_t s_ = reg.stream();
     const uint32_t ns = n_streams_;
-    if (timing) {
-      for (auto& e : ev)
-        if (!e) LX_HIP(hipEventCreate(&e));
-    }
     // ---- this step's odometry: from the look-ahead of the previous call, or now
     if (odom_ready_step != (int)t) {
       if (prefetch && t + 1 < fx.size() && !launched[t + 1]) { if (!launched[t]) launch_features(t); launch_features(t + 1); }
       run_odometry(t);
     }
-    odom_ms = odom_ms_next;
     for (uint32_t s = 0; s < ns; s++) st[s].cur = st[s].next;
     odom_ready_step = -1;
     FeatureExtractor& F = *fx[t];
     const float f_ms = feat_ms[t % 3];
-    // ---- look-ahead while M(t) runs: features of step t+2 and, on a host thread of its own (it blocks on its
-    // Gauss-Newton results), the odometry of step t+1
+    // ---- look-ahead while M(t) runs: the odometry of step t+1 on the worker thread, started first (it is the longest
+    // chain), and the features of step t+2, enqueued while this thread waits for M(t)'s first look at the flags.
     // (the re-projected "last" clouds of THIS sweep are produced at the tail of the odometry stream: order the
     // registrar's stream behind it before the odometry thread re-arms the event)
     if (hipEvent_t te = odom.tail_event()) LX_HIP(hipStreamWaitEvent(s_, te, 0));
-    std::future<void> ahead;
-    if (prefetch && t + 1 < fx.size()) {
+    const bool ahead = prefetch && t + 1 < fx.size();
+    if (ahead) {
       if (!launched[t + 1]) launch_features(t + 1);
-      if (t + 2 < fx.size() && !launched[t + 2]) launch_features(t + 2);
-      ahead = std::async(std::launch::async, [this, t]() {
-        LX_HIP(hipSetDevice(device));
-        run_odometry(t + 1);
-      });
+      kick(t + 1);
     }
-    // ---- registration against the frozen sub-map: enqueue everything for M(t) (asynchronous)
-    if (timing) LX_HIP(hipEventRecord(ev[0], s_));
-    std::vector<const float4*> cl(ns), sl(ns), fsrc(ns);
-    std::vector<uint32_t> ncl(ns), nsl(ns), nfr(ns), who;
-    std::vector<float> guess;
-    std::vector<ToEndParams> tep;
-    for (uint32_t s = 0; s < ns; s++) {
-      PipeStreamState& P = st[s];
-      if (P.cur.rc != LOAMX_OK) continue;   // a stream's first sweep only initialises the odometry
-      transform_associate_to_map(P.cur.transform_sum, P.bef, P.aft, P.incre, P.tobe);
-      float g[6];
-      P.tobe.get(g);
-      guess.insert(guess.end(), g, g + 6);
-      const uint32_t k = (uint32_t)who.size();
-      cl[k] = P.cur.last_corner; ncl[k] = P.cur.n_last_corner;
-      sl[k] = P.cur.last_surf; nsl[k] = P.cur.n_last_surf;
-      fsrc[k] = F.d_cloud() + F.point_base(s);
-      nfr[k] = F.point_base(s + 1) - F.point_base(s);
-      tep.push_back(P.cur.to_end);
-      who.push_back(s);
-    }
-    const uint32_t nw = (uint32_t)who.size();
-    if (nw) {
-      // the full-resolution clouds are re-projected to the sweep end before they are registered (LaserOdometry.cpp:326):
-      // one fused kernel writes them straight into the registrar's staging area
-      float4* full_dst = reg.stage_full(nw, nfr.data());
-      std::vector<uint32_t> foff(nw + 1, 0);
-      for (uint32_t k = 0; k < nw; k++) foff[k + 1] = foff[k] + nfr[k];
-      odom.to_end_gather(full_dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
-      reg.upload_device(nw, cl.data(), ncl.data(), sl.data(), nsl.data(), nullptr, nullptr, guess.data());
-      reg.run_async();
-    }
-    if (timing) LX_HIP(hipEventRecord(ev[1], s_));
-    // ---- join the look-ahead
-    if (ahead.valid()) ahead.get();   // rethrows a failure of the odometry thread
-    // ---- finish M(t)
+    bool f2_pending = ahead && t + 2 < fx.size() && !launched[t + 2];
+    auto launch_f2 = [&]() {
+      if (f2_pending) { f2_pending = false; launch_features(t + 2); }
+    };
     int ret = LOAMX_SKIPPED;
-    if (nw) {
-      std::vector<float> poses(6 * nw);
-      std::vector<SweepStats> ss(nw);
-      reg.download(poses.data(), nullptr);
-      reg.download_stats(ss.data());
-      for (uint32_t k = 0; k < nw; k++) {
-        PipeStreamState& P = st[who[k]];
-        P.map_stats = ss[k];
-        P.mapped = true;
-        if (reg.submap_sufficient()) {   // transformUpdate (BasicLaserMapping.cpp:171-203, :628-629)
-          P.tobe.set(&poses[6 * k]);
-          P.bef = P.cur.transform_sum;
-          P.aft = P.tobe;
-        }
+    try {
+      trM[0] = tr_us();
+      // ---- registration against the frozen sub-map: enqueue everything for M(t)
+      LazyTimer& tm = tmM[t & 1];
+      if (timing) {
+        tm.create();
+        tm.pending = false;
+        LX_HIP(hipEventRecord(tm.a, s_));
       }
-      ret = LOAMX_OK;
+      std::vector<const float4*> cl(ns), sl(ns), fsrc(ns);
+      std::vector<uint32_t> ncl(ns), nsl(ns), nfr(ns), who;
+      std::vector<float> guess;
+      std::vector<ToEndParams> tep;
+      for (uint32_t s = 0; s < ns; s++) {
+        PipeStreamState& P = st[s];
+        if (P.cur.rc != LOAMX_OK) continue;   // a stream's first sweep only initialises the odometry
+        transform_associate_to_map(P.cur.transform_sum, P.bef, P.aft, P.incre, P.tobe);
+        float g[6];
+        P.tobe.get(g);
+        guess.insert(guess.end(), g, g + 6);
+        const uint32_t k = (uint32_t)who.size();
+        cl[k] = P.cur.last_corner; ncl[k] = P.cur.n_last_corner;
+        sl[k] = P.cur.last_surf; nsl[k] = P.cur.n_last_surf;
+        fsrc[k] = F.d_cloud() + F.point_base(s);
+        nfr[k] = F.point_base(s + 1) - F.point_base(s);
+        tep.push_back(P.cur.to_end);
+        who.push_back(s);
+      }
+      const uint32_t nw = (uint32_t)who.size();
+      if (nw) {
+        // the full-resolution clouds are re-projected to the sweep end before they are registered (LaserOdometry.cpp:326):
+        // one fused kernel writes them straight into the registrar's staging area
+        float4* full_dst = reg.stage_full(nw, nfr.data());
+        std::vector<uint32_t> foff(nw + 1, 0);
+        for (uint32_t k = 0; k < nw; k++) foff[k + 1] = foff[k] + nfr[k];
+        odom.to_end_gather(full_dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
+        reg.upload_device(nw, cl.data(), ncl.data(), sl.data(), nsl.data(), nullptr, nullptr, guess.data());
+        reg.on_first_wait = launch_f2;
+        reg.run_async();
+        reg.on_first_wait = nullptr;
+      }
+      launch_f2();
+      if (timing) {
+        LX_HIP(hipEventRecord(tm.b, s_));
+        tm.pending = true;
+      }
+      trM[1] = tr_us();
+      // ---- finish M(t)
+      if (nw) {
+        std::vector<float> poses(6 * nw);
+        std::vector<SweepStats> ss(nw);
+        reg.download(poses.data(), nullptr);
+        reg.download_stats(ss.data());
+        for (uint32_t k = 0; k < nw; k++) {
+          PipeStreamState& P = st[who[k]];
+          P.map_stats = ss[k];
+          P.mapped = true;
+          if (reg.submap_sufficient()) {   // transformUpdate (BasicLaserMapping.cpp:171-203, :628-629)
+            P.tobe.set(&poses[6 * k]);
+            P.bef = P.cur.transform_sum;
+            P.aft = P.tobe;
+          }
+        }
+        ret = LOAMX_OK;
+      }
+      trM[2] = tr_us();
+    } catch (...) {
+      if (ahead) { try { join_job(); } catch (...) {} }
+      throw;
     }
+    // ---- join the look-ahead
+    if (ahead) join_job();   // rethrows a failure of the odometry thread
+    trM[3] = tr_us();
+    if (trace)
+      fprintf(stderr, "[pipe t=%u] M-start %.0f  M-enqueued %.0f  M-downloaded %.0f  O-joined %.0f | O thread: start %.0f feat-ready %.0f process-done %.0f end %.0f\n", t,
+              trM[0], trM[1], trM[2], trM[3], trO[0], trO[1], trO[2], trO[3]);
     if (timing) {
-      LX_HIP(hipEventSynchronize(ev[1]));
-      last_ms[0] = f_ms;       // on the feature stream (overlapped)
-      last_ms[1] = odom_ms;    // on the odometry stream (overlapped with the previous step's registration)
-      LX_HIP(hipEventElapsedTime(&last_ms[2], ev[0], ev[1]));
+      for (auto& x : tmO) x.resolve();
+      for (auto& x : tmM) x.resolve();
+      last_ms[0] = f_ms;               // on the feature stream (overlapped)
+      last_ms[1] = tmO[t & 1].ms;      // on the odometry stream (overlapped with the previous step's registration)
+      last_ms[2] = tmM[t & 1].pending ? tmM[(t + 1) & 1].ms : tmM[t & 1].ms;   // the previous step's while this one is in flight
       last_ms[3] = last_ms[2];
     }
     return ret;

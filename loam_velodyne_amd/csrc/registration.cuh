@@ -1,6 +1,7 @@
 // Scan-to-map registration engine shared by the batched mode (loamx_batch_*) and the sequential
 // BasicLaserMapping replacement (loamx_map_*).  Host classes; kernels live in registration.hip.
 #pragma once
+#include <functional>
 #include "common.h"
 #include "dev_math.cuh"
 #include "voxel.cuh"
@@ -81,6 +82,7 @@ class Registrar {
   ~Registrar();
   RegParams params;
   SubMapIndex corner_index, surf_index;
+  std::function<void()> on_first_wait;   // early_exit: called once, right before run_async() first blocks on the flags
   bool early_exit = false;    // run_async() may block on the done flags to skip the launches after convergence
   hipStream_t stream() const { return st_; }
 
@@ -137,6 +139,7 @@ class Registrar {
   bool full_staged_ = false;
   VoxelPipeline vox_;
   uint32_t n_in_ = 0, n_full_ = 0, max_q_per_sweep_ = 0;
+  bool host_results_valid_ = false;   // h_poses_ / h_stats_ hold this run's final values
   int pred_iters_ = 4;        // early_exit: iterations to enqueue before the first look at the done flags
   int knn_lpq_ = 4;           // lanes per query in k_knn5 (tuning knob: LOAMX_KNN_LPQ = 1|2|4|8|16)
   void launch_knn5(int it);

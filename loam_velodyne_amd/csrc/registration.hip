@@ -240,38 +240,70 @@ __global__ void k_bb_setup(const uint32_t* __restrict__ enc, const uint32_t* __r
   scratch[0] = base + 1;
   scratch[2] = base;
 }
+// Points arrive in scan order, so neighbouring lanes mostly fall into the same cell: one atomic per RUN of equal cells
+// in a wave instead of one per point (64 lanes hammering two or three counters serialise in L2).
+// run_head_len: for the calling lane, the lane that starts its run and, if it is that lane, the run's length.
+__device__ inline void wave_runs(uint32_t key, bool active, int& head_lane, int& run_len) {
+  const int lane = (int)__lane_id();
+  const uint32_t prev = __shfl_up(key, 1, 64);
+  const unsigned long long act = __ballot(active);
+  const unsigned long long heads = __ballot(active && (lane == 0 || prev != key || !((act >> (lane > 0 ? lane - 1 : 0)) & 1ull)));
+  const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+  const unsigned long long below = heads & upto;
+  head_lane = below ? 63 - __builtin_clzll(below) : lane;
+  const unsigned long long stops = (heads | ~act) & ~upto;   // next head, or the first inactive lane
+  const int end = stops ? __builtin_ctzll(stops) : 64;
+  run_len = end - lane;   // meaningful on the head lane
+}
+
 __global__ __launch_bounds__(256) void k_bb_count(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off, uint32_t K,
                                                   const GridDescB* __restrict__ desc, uint32_t* __restrict__ cell_of,
                                                   uint32_t* __restrict__ counts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t lo = 0, hi = K;
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (off[mid] <= i) lo = mid; else hi = mid;
+  const bool active = i < n;
+  uint32_t c = 0;
+  if (active) {
+    uint32_t lo = 0, hi = K;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    const GridDescB d = desc[lo];
+    const float4 p = pts[i];
+    int cx, cy, cz;
+    cell_coords(d.g, p.x, p.y, p.z, cx, cy, cz);
+    c = d.cell_base + ((uint32_t)cz * d.g.ny + cy) * d.g.nx + cx;
+    cell_of[i] = c;
   }
-  const GridDescB d = desc[lo];
-  const float4 p = pts[i];
-  int cx, cy, cz;
-  cell_coords(d.g, p.x, p.y, p.z, cx, cy, cz);
-  const uint32_t c = d.cell_base + ((uint32_t)cz * d.g.ny + cy) * d.g.nx + cx;
-  cell_of[i] = c;
-  atomicAdd(&counts[c], 1u);
+  int head, len;
+  wave_runs(c, active, head, len);
+  if (active && head == (int)__lane_id()) atomicAdd(&counts[c], (uint32_t)len);
 }
+
 __global__ __launch_bounds__(256) void k_bb_scatter(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off, uint32_t K,
                                                     const uint32_t* __restrict__ cell_of, uint32_t* __restrict__ cursor,
                                                     float4* __restrict__ sorted) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t lo = 0, hi = K;
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (off[mid] <= i) lo = mid; else hi = mid;
+  const bool active = i < n;
+  uint32_t c = 0, lo = 0;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    uint32_t hi = K;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    p = pts[i];
+    c = cell_of[i];
   }
-  float4 p = pts[i];
-  const uint32_t pos = atomicAdd(&cursor[cell_of[i]], 1u);
+  int head, len;
+  wave_runs(c, active, head, len);   // one cursor bump per run of equal cells (see k_bb_count)
+  uint32_t base = 0;
+  if (active && head == (int)__lane_id()) base = atomicAdd(&cursor[c], (uint32_t)len);
+  base = __shfl(base, head, 64);
+  if (!active) return;
   p.w = __uint_as_float(i - off[lo]);   // index inside its own cloud
-  sorted[pos] = p;
+  sorted[base + ((int)__lane_id() - head)] = p;
 }
 
 void SubMapIndexBatch::init(hipStream_t st) {
@@ -1050,6 +1082,7 @@ void Registrar::run_async() {
   const uint32_t ns = n_sweeps_, nseg = 2 * ns, n = n_in_;
   if (timing_) LX_HIP(hipEventRecord(ev_[0], st_));
   n_res_launch_ = 0;
+  host_results_valid_ = false;
   hipLaunchKernelGGL(k_pose_init, dim3((ns + 63) / 64), dim3(64), 0, st_, guess_.p, ns, poses_.p, stats_.p);
   if (n > 0) {
     const uint32_t nb = (n + 255) / 256;
@@ -1065,6 +1098,7 @@ void Registrar::run_async() {
     // free of host round trips.  A blocking caller (early_exit) instead enqueues as many iterations as the previous
     // call needed, looks at the flags, and stops launching once every sweep is done.
     int it = 0;
+    bool waited = false;
     int chunk = early_exit ? std::min(std::max(pred_iters_, 2), params.max_iterations) : params.max_iterations;
     while (it < params.max_iterations) {
       const int end = std::min(params.max_iterations, it + chunk);
@@ -1083,6 +1117,8 @@ void Registrar::run_async() {
       }
       if (!early_exit || it >= params.max_iterations) break;
       LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * ns, hipMemcpyDeviceToHost, st_));
+      LX_HIP(hipMemcpyAsync(h_poses_.p, poses_.p, sizeof(Pose) * ns, hipMemcpyDeviceToHost, st_));
+      if (on_first_wait && !waited) { waited = true; on_first_wait(); }   // host work that overlaps the wait
       LX_HIP(hipStreamSynchronize(st_));
       bool all_done = true;
       int need = 0;
@@ -1090,7 +1126,7 @@ void Registrar::run_async() {
         all_done = all_done && h_stats_.p[k].done;
         need = std::max(need, h_stats_.p[k].iterations);
       }
-      if (all_done) { pred_iters_ = need; break; }
+      if (all_done) { pred_iters_ = need; host_results_valid_ = true; break; }   // poses / stats are final and on the host
       pred_iters_ = it + 1;
       chunk = 1;
     }
@@ -1104,16 +1140,20 @@ void Registrar::run_async() {
 void Registrar::sync() { LX_HIP(hipStreamSynchronize(st_)); }
 
 void Registrar::download_stats(SweepStats* out) {
-  LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * n_sweeps_, hipMemcpyDeviceToHost, st_));
-  LX_HIP(hipStreamSynchronize(st_));
+  if (!host_results_valid_) {
+    LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * n_sweeps_, hipMemcpyDeviceToHost, st_));
+    LX_HIP(hipStreamSynchronize(st_));
+  }
   memcpy(out, h_stats_.p, sizeof(SweepStats) * n_sweeps_);
 }
 
 void Registrar::download(float* poses6, int* stats4) {
   LX_REQUIRE(n_sweeps_ > 0, "download() before run()");
-  LX_HIP(hipMemcpyAsync(h_poses_.p, poses_.p, sizeof(Pose) * n_sweeps_, hipMemcpyDeviceToHost, st_));
-  LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * n_sweeps_, hipMemcpyDeviceToHost, st_));
-  LX_HIP(hipStreamSynchronize(st_));
+  if (!host_results_valid_) {   // (an early-exit run that saw every sweep converge already holds the final values)
+    LX_HIP(hipMemcpyAsync(h_poses_.p, poses_.p, sizeof(Pose) * n_sweeps_, hipMemcpyDeviceToHost, st_));
+    LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * n_sweeps_, hipMemcpyDeviceToHost, st_));
+    LX_HIP(hipStreamSynchronize(st_));
+  }
   for (uint32_t s = 0; s < n_sweeps_; s++) {
     if (poses6) {
       const Pose& T = h_poses_.p[s];

@@ -149,6 +149,7 @@ class Registrar {
   DevBuf<float> matP_;        // 36 per sweep
   DevBuf<double> partials_;   // per sweep x blocks x LX_NSUM
   DevBuf<uint32_t> nb_;       // 5 neighbour positions per query
+  DevBuf<uint32_t> arrive_;   // per sweep: k_residual workgroups that have delivered their partial sums
   DevBuf<float4> qstate_;     // per query: position at its last full search + squared re-validation bound
   uint32_t nblk_ = 0;
 

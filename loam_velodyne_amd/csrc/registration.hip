@@ -7,7 +7,8 @@
 //   k_knn5           per query (16 lanes each): pointAssociateToMap + exact 5-NN within the 1 m gate  (:668-671, :757-760)
 //   k_residual       per query (thread each): 3x3 eigen edge fit or 5x3 QR plane fit, residual + weight, Jacobian row,
 //                    block-reduced J^T J / J^T r                                                   (:673-866)
-//   k_solve          6x6 column-pivoted QR, degeneracy projector, pose update, convergence test   (:867-922)
+//   solve_sweep      (last workgroup of k_residual) 6x6 column-pivoted QR, degeneracy projector, pose update,
+//                    convergence test   (:867-922)
 //   k_transform_full transformFullResToMap                                                         (:235-240)
 // HBM-bound gather work: no MFMA (the only dense contraction is 6x6).  Points are packed float4 so a neighbour is one
 // 16-byte load; queries are processed in voxel order, so the lanes of a wave walk the same few grid cells.
@@ -709,93 +710,13 @@ __device__ inline void surf_row(const Pose& T, const float4 po, const float4* __
 }
 
 // grid = (blocks per sweep, sweeps).  partials[(s*nblk + b)*LX_NSUM + k]
-__global__ __launch_bounds__(LX_RES_THREADS) void k_residual(
-    const float4* __restrict__ ds_pts, const uint32_t* __restrict__ ds_off, const Pose* __restrict__ poses,
-    const SweepStats* __restrict__ stats, const float4* __restrict__ cpts, const float4* __restrict__ spts,
-    const uint32_t* __restrict__ nb, double* __restrict__ partials, uint32_t nblk) {
-  const uint32_t s = blockIdx.y;
-  if (stats[s].done) return;
-  const uint32_t q0 = ds_off[2 * s], qm = ds_off[2 * s + 1], q1 = ds_off[2 * s + 2];
-  const uint32_t first = q0 + blockIdx.x * LX_RES_THREADS;
-  if (first >= q1) return;
-  const uint32_t q = first + threadIdx.x;
-  const Pose T = poses[s];
-
-  float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bb = 0.f;
-  bool sel = false;
-  if (q < q1) {
-    const float4 po = ds_pts[q];
-    float cx, cy, cz, ci;
-    uint32_t bp[5];
-#pragma unroll
-    for (int j = 0; j < 5; j++) bp[j] = nb[5 * (size_t)q + j];
-    if (q < qm) corner_row(T, po, cpts, bp, cx, cy, cz, ci, sel);
-    else surf_row(T, po, spts, bp, cx, cy, cz, ci, sel);
-    if (sel) {
-      // Jacobian row, BasicLaserMapping.cpp:842-861
-      const float srx = T.srx, crx = T.crx, sry = T.sry, cry = T.cry, srz = T.srz, crz = T.crz;
-      a[0] = (crx * sry * srz * po.x + crx * crz * sry * po.y - srx * sry * po.z) * cx +
-             (-srx * srz * po.x - crz * srx * po.y - crx * po.z) * cy +
-             (crx * cry * srz * po.x + crx * cry * crz * po.y - cry * srx * po.z) * cz;
-      a[1] = ((cry * srx * srz - crz * sry) * po.x + (sry * srz + cry * crz * srx) * po.y + crx * cry * po.z) * cx +
-             ((-cry * crz - srx * sry * srz) * po.x + (cry * srz - crz * srx * sry) * po.y - crx * sry * po.z) * cz;
-      a[2] = ((crz * srx * sry - cry * srz) * po.x + (-cry * crz - srx * sry * srz) * po.y) * cx +
-             (crx * crz * po.x - crx * srz * po.y) * cy +
-             ((sry * srz + cry * crz * srx) * po.x + (crz * sry - cry * srx * srz) * po.y) * cz;
-      a[3] = cx; a[4] = cy; a[5] = cz;
-      bb = -ci;
-    }
-  }
-  // products in float (as Eigen's float A^T A forms them), accumulated in double
-  double v[LX_NSUM];
-  int k = 0;
-#pragma unroll
-  for (int i = 0; i < 6; i++)
-#pragma unroll
-    for (int j = i; j < 6; j++) v[k++] = (double)(a[i] * a[j]);
-#pragma unroll
-  for (int i = 0; i < 6; i++) v[k++] = (double)(a[i] * bb);
-  v[k] = sel ? 1.0 : 0.0;
-
-  // transposed reduction through LDS, two halves of 14 sums (28 dependent 64-bit shuffle chains are several times
-  // slower): column c of the 256 x 14 table is summed by 8 threads (rows g, g+8, ...), then the 8 strands in order
-  constexpr int TRS = LX_RES_THREADS + 2, HALF = LX_NSUM / 2;
-  __shared__ double tr[HALF * TRS];
-  __shared__ double red[8][LX_NSUM];
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    if (h) __syncthreads();
-#pragma unroll
-    for (int t = 0; t < HALF; t++) tr[t * TRS + threadIdx.x] = v[h * HALF + t];
-    __syncthreads();
-    if (threadIdx.x < 8 * HALF) {
-      const int c = threadIdx.x % HALF, g = threadIdx.x / HALF;
-      const double* col = tr + c * TRS + g;
-      double x = 0.0;
-#pragma unroll 8
-      for (int j = 0; j < LX_RES_THREADS / 8; j++) x += col[8 * j];
-      red[g][h * HALF + c] = x;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < LX_NSUM) {
-    double x = 0.0;
-#pragma unroll
-    for (int w = 0; w < 8; w++) x += red[w][threadIdx.x];
-    partials[((size_t)s * nblk + blockIdx.x) * LX_NSUM + threadIdx.x] = x;
-  }
-}
-
-// one workgroup per sweep: fixed-order (deterministic) reduction of the block partials — 9 groups of 28 threads each
-// walk every 9th block, then the 9 group sums are added in order — then thread 0 solves and updates the pose
+// the update step of one sweep, run by the LAST workgroup of k_residual to finish (all 256 threads): fixed-order
+// (deterministic) reduction of the block partials — 9 groups of 28 threads each walk every 9th block, then the 9 group
+// sums are added in order — then wave 0 solves and thread 0 updates the pose
 constexpr int LX_SOLVE_GROUPS = 9;
-__global__ __launch_bounds__(256) void k_solve(const uint32_t* __restrict__ ds_off, Pose* __restrict__ poses, SweepStats* __restrict__ stats,
-                                               float* __restrict__ matP, const double* __restrict__ partials, uint32_t nblk, int iter,
-                                               float delta_t_abort, float delta_r_abort) {
-  const uint32_t s = blockIdx.x;
-  if (stats[s].done) return;
-  const uint32_t nq = ds_off[2 * s + 2] - ds_off[2 * s];
-  const uint32_t nact = (nq + LX_RES_THREADS - 1) / LX_RES_THREADS;
+__device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_off, Pose* __restrict__ poses, SweepStats* __restrict__ stats,
+                                   float* __restrict__ matP, const double* partials, uint32_t nblk, uint32_t nact, int iter,
+                                   float delta_t_abort, float delta_r_abort) {
   __shared__ double gsum[LX_SOLVE_GROUPS][LX_NSUM];
   __shared__ double sums[LX_NSUM];
   __shared__ float ws[216];
@@ -861,6 +782,101 @@ __global__ __launch_bounds__(256) void k_solve(const uint32_t* __restrict__ ds_o
   stats[s] = st;
 }
 
+
+__global__ __launch_bounds__(LX_RES_THREADS) void k_residual(
+    const float4* __restrict__ ds_pts, const uint32_t* __restrict__ ds_off, const Pose* __restrict__ poses,
+    const SweepStats* __restrict__ stats, const float4* __restrict__ cpts, const float4* __restrict__ spts,
+    const uint32_t* __restrict__ nb, double* partials, uint32_t nblk, Pose* poses_rw, SweepStats* stats_rw,
+    float* __restrict__ matP, uint32_t* __restrict__ arrive, int iter, float delta_t_abort, float delta_r_abort) {
+  const uint32_t s = blockIdx.y;
+  if (stats[s].done) return;
+  const uint32_t q0 = ds_off[2 * s], qm = ds_off[2 * s + 1], q1 = ds_off[2 * s + 2];
+  const uint32_t first = q0 + blockIdx.x * LX_RES_THREADS;
+  // (a sweep without queries still burns the iteration: its workgroup 0 contributes zeros and runs the update)
+  if (first >= q1 && !(q1 == q0 && blockIdx.x == 0)) return;
+  const uint32_t q = first + threadIdx.x;
+  const Pose T = poses[s];
+
+  float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bb = 0.f;
+  bool sel = false;
+  if (q < q1) {
+    const float4 po = ds_pts[q];
+    float cx, cy, cz, ci;
+    uint32_t bp[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) bp[j] = nb[5 * (size_t)q + j];
+    if (q < qm) corner_row(T, po, cpts, bp, cx, cy, cz, ci, sel);
+    else surf_row(T, po, spts, bp, cx, cy, cz, ci, sel);
+    if (sel) {
+      // Jacobian row, BasicLaserMapping.cpp:842-861
+      const float srx = T.srx, crx = T.crx, sry = T.sry, cry = T.cry, srz = T.srz, crz = T.crz;
+      a[0] = (crx * sry * srz * po.x + crx * crz * sry * po.y - srx * sry * po.z) * cx +
+             (-srx * srz * po.x - crz * srx * po.y - crx * po.z) * cy +
+             (crx * cry * srz * po.x + crx * cry * crz * po.y - cry * srx * po.z) * cz;
+      a[1] = ((cry * srx * srz - crz * sry) * po.x + (sry * srz + cry * crz * srx) * po.y + crx * cry * po.z) * cx +
+             ((-cry * crz - srx * sry * srz) * po.x + (cry * srz - crz * srx * sry) * po.y - crx * sry * po.z) * cz;
+      a[2] = ((crz * srx * sry - cry * srz) * po.x + (-cry * crz - srx * sry * srz) * po.y) * cx +
+             (crx * crz * po.x - crx * srz * po.y) * cy +
+             ((sry * srz + cry * crz * srx) * po.x + (crz * sry - cry * srx * srz) * po.y) * cz;
+      a[3] = cx; a[4] = cy; a[5] = cz;
+      bb = -ci;
+    }
+  }
+  // products in float (as Eigen's float A^T A forms them), accumulated in double
+  double v[LX_NSUM];
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = i; j < 6; j++) v[k++] = (double)(a[i] * a[j]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) v[k++] = (double)(a[i] * bb);
+  v[k] = sel ? 1.0 : 0.0;
+
+  // transposed reduction through LDS, two halves of 14 sums (28 dependent 64-bit shuffle chains are several times
+  // slower): column c of the 256 x 14 table is summed by 8 threads (rows g, g+8, ...), then the 8 strands in order
+  constexpr int TRS = LX_RES_THREADS + 2, HALF = LX_NSUM / 2;
+  __shared__ double tr[HALF * TRS];
+  __shared__ double red[8][LX_NSUM];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    if (h) __syncthreads();
+#pragma unroll
+    for (int t = 0; t < HALF; t++) tr[t * TRS + threadIdx.x] = v[h * HALF + t];
+    __syncthreads();
+    if (threadIdx.x < 8 * HALF) {
+      const int c = threadIdx.x % HALF, g = threadIdx.x / HALF;
+      const double* col = tr + c * TRS + g;
+      double x = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < LX_RES_THREADS / 8; j++) x += col[8 * j];
+      red[g][h * HALF + c] = x;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < LX_NSUM) {
+    double x = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) x += red[w][threadIdx.x];
+    partials[((size_t)s * nblk + blockIdx.x) * LX_NSUM + threadIdx.x] = x;
+    __threadfence();   // release the partial sums before this workgroup is counted in
+  }
+  // ---- the last workgroup of the sweep to arrive runs the update (saves a kernel boundary per iteration)
+  __shared__ int sh_last;
+  const uint32_t nq = q1 - q0;
+  const uint32_t nact = nq ? (nq + LX_RES_THREADS - 1) / LX_RES_THREADS : 1u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool last = atomicAdd(&arrive[s], 1u) == nact - 1;
+    if (last) atomicExch(&arrive[s], 0u);   // ready for the next iteration (nobody else touches it before the next launch)
+    sh_last = last ? 1 : 0;
+  }
+  __syncthreads();
+  if (!sh_last) return;
+  __threadfence();   // acquire the other workgroups' partial sums
+  solve_sweep(s, ds_off, poses_rw, stats_rw, matP, partials, nblk, nact, iter, delta_t_abort, delta_r_abort);
+}
+
 __global__ __launch_bounds__(256) void k_transform_full(float4* __restrict__ full, uint32_t n, const uint32_t* __restrict__ full_off,
                                                         uint32_t ns, const Pose* __restrict__ poses) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -896,6 +912,8 @@ Registrar::Registrar(int device, uint32_t max_sweeps) : device_(device), max_swe
   poses_.reserve(max_sweeps);
   stats_.reserve(max_sweeps);
   matP_.reserve((size_t)36 * max_sweeps);
+  arrive_.reserve(max_sweeps);
+  LX_HIP(hipMemsetAsync(arrive_.p, 0, sizeof(uint32_t) * max_sweeps, st_));
   guess_.reserve((size_t)6 * max_sweeps);
   h_guess_.reserve((size_t)64 * max_sweeps + 64);
   seg_off_.reserve(2 * max_sweeps + 2);
@@ -1111,9 +1129,8 @@ void Registrar::run_async() {
           n_res_launch_++;
         }
         hipLaunchKernelGGL(k_residual, dim3(nblk_, ns), dim3(LX_RES_THREADS), 0, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p,
-                           corner_index.sorted(), surf_index.sorted(), nb_.p, partials_.p, nblk_);
-        hipLaunchKernelGGL(k_solve, dim3(ns), dim3(256), 0, st_, ds_off_.p, poses_.p, stats_.p, matP_.p, partials_.p, nblk_, it,
-                           params.delta_t_abort, params.delta_r_abort);
+                           corner_index.sorted(), surf_index.sorted(), nb_.p, partials_.p, nblk_, poses_.p, stats_.p, matP_.p,
+                           arrive_.p, it, params.delta_t_abort, params.delta_r_abort);
       }
       if (!early_exit || it >= params.max_iterations) break;
       LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * ns, hipMemcpyDeviceToHost, st_));

@@ -104,6 +104,7 @@ class VoxelPipeline {
   DevBuf<int> ijk_, seg_minmax_;
   DevBuf<unsigned long long> keys_, keys_sorted_;
   DevBuf<uint32_t> vals_, vals_sorted_, head_, head_scan_, tile_sums_, scratch_;
+  DevBuf<float4> gathered_;   // the points in sorted order
   DevBuf<char> sort_tmp_;
   size_t sort_tmp_bytes_ = 0;
 };

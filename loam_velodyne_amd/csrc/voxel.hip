@@ -56,29 +56,47 @@ __global__ __launch_bounds__(256) void k_vox_keys(uint32_t n, const uint8_t* __r
   keys[i] = ((unsigned long long)seg << VOX_SEG_SHIFT) | k;
 }
 
-__global__ __launch_bounds__(256) void k_vox_heads(const unsigned long long* __restrict__ keys, uint32_t n, uint32_t nseg,
-                                                   uint32_t* __restrict__ head) {
+// head flags of the voxel runs; the points are gathered into sorted order on the way (coalesced stores), so that the
+// reduction reads them contiguously instead of chasing vals[] -> pts[] one dependent load after the other
+__global__ __launch_bounds__(256) void k_vox_heads(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                   const float4* __restrict__ pts, uint32_t n, uint32_t nseg,
+                                                   uint32_t* __restrict__ head, float4* __restrict__ gathered) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned long long k = keys[i];
   const bool ignored = (k >> VOX_SEG_SHIFT) >= nseg;
   head[i] = (!ignored && (i == 0 || k != keys[i - 1])) ? 1u : 0u;
+  gathered[i] = pts[vals[i]];
 }
 
-// one thread per voxel head: float mean of x,y,z,intensity over the run, accumulated in input order
-__global__ __launch_bounds__(256) void k_vox_reduce(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+// one thread per voxel head: float mean of x,y,z,intensity over the run, accumulated in input order (the sort is stable).
+// The workgroup's 256 sorted points and keys are staged in LDS; a run that continues into the next workgroup's range is
+// finished from memory.
+__global__ __launch_bounds__(256) void k_vox_reduce(const unsigned long long* __restrict__ keys, const float4* __restrict__ gathered,
                                                     const uint32_t* __restrict__ head, const uint32_t* __restrict__ head_scan,
-                                                    uint32_t n, const float4* __restrict__ pts, float4* __restrict__ out) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+                                                    uint32_t n, float4* __restrict__ out) {
+  __shared__ float4 sp[256];
+  __shared__ unsigned long long sk[256];
+  const uint32_t base = blockIdx.x * blockDim.x, i = base + threadIdx.x;
+  if (i < n) { sp[threadIdx.x] = gathered[i]; sk[threadIdx.x] = keys[i]; }
+  __syncthreads();
   if (i >= n || !head[i]) return;
-  const unsigned long long k = keys[i];
+  const unsigned long long k = sk[threadIdx.x];
   float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
   uint32_t j = i;
+  const uint32_t lim = base + 256 < n ? base + 256 : n;
   do {
-    const float4 p = pts[vals[j]];
+    const float4 p = sp[j - base];
     sx += p.x; sy += p.y; sz += p.z; si += p.w;
     j++;
-  } while (j < n && keys[j] == k);
+  } while (j < lim && sk[j - base] == k);
+  if (j == lim) {
+    while (j < n && keys[j] == k) {
+      const float4 p = gathered[j];
+      sx += p.x; sy += p.y; sz += p.z; si += p.w;
+      j++;
+    }
+  }
   const float cnt = (float)(j - i);
   out[head_scan[i]] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
 }
@@ -113,6 +131,7 @@ void VoxelPipeline::reserve(uint32_t n, uint32_t nseg) {
   vals_sorted_.reserve(n + 1);
   head_.reserve(n + 2);
   head_scan_.reserve(n + 2);
+  gathered_.reserve(n + 1);
   size_t need = 0;
   LX_HIP(rocprim::radix_sort_pairs(nullptr, need, keys_.p, keys_sorted_.p, vals_.p, vals_sorted_.p, (size_t)(n ? n : 1), 0, 48, st_));
   if (need > sort_tmp_bytes_) {
@@ -146,10 +165,10 @@ void VoxelPipeline::sort_reduce(const float4* pts, const uint8_t* valid, uint32_
   while ((1u << seg_bits) <= nseg) seg_bits++;
   LX_HIP(rocprim::radix_sort_pairs(sort_tmp_.p, tmp, keys_.p, keys_sorted_.p, vals_.p, vals_sorted_.p, (size_t)n, 0,
                                    VOX_SEG_SHIFT + seg_bits, st_));
-  hipLaunchKernelGGL(k_vox_heads, dim3(nb), dim3(256), 0, st_, keys_sorted_.p, n, nseg, head_.p);
+  hipLaunchKernelGGL(k_vox_heads, dim3(nb), dim3(256), 0, st_, keys_sorted_.p, vals_sorted_.p, pts, n, nseg, head_.p, gathered_.p);
   hipLaunchKernelGGL(k_vox_set_u32, dim3(1), dim3(1), 0, st_, scratch_.p, n);
   exclusive_scan_u32(head_.p, head_scan_.p, tile_sums_.p, scratch_.p, scratch_.p + 1, n, st_);
-  hipLaunchKernelGGL(k_vox_reduce, dim3(nb), dim3(256), 0, st_, keys_sorted_.p, vals_sorted_.p, head_.p, head_scan_.p, n, pts, out);
+  hipLaunchKernelGGL(k_vox_reduce, dim3(nb), dim3(256), 0, st_, keys_sorted_.p, gathered_.p, head_.p, head_scan_.p, n, out);
   hipLaunchKernelGGL(k_vox_offsets, dim3((nseg + 64) / 64), dim3(64), 0, st_, keys_sorted_.p, head_scan_.p, n, nseg, d_out_off);
   LX_HIP(hipGetLastError());
 }

@@ -31,6 +31,7 @@ struct OdomProblem {
   OdomStats stats;
   int done;
   float matP[36];
+  int stream_id;          // index of the stream this problem belongs to
   unsigned ticket;        // k_odom_lm: workgroup arrivals since the problem was set up (per-stream barrier)
   double* part;           // k_odom_lm: [2][16][LX_NSUM] partial normal equations of the stream's workgroups
 };
@@ -111,7 +112,7 @@ class OdometryBatch {
   PinBuf<uint32_t> h_off_pin_;
   PinBuf<float4> h_stage_;
   DevBuf<float4> up_[4], tmp_cloud_;
-  hipEvent_t ev_tail_ = nullptr;
+  hipEvent_t ev_tail_ = nullptr, ev_pose_ = nullptr;
   bool tail_pending_ = false;
   PinBuf<char> h_gather_;
   DevBuf<char> d_gather_;

@@ -511,6 +511,20 @@ __global__ __launch_bounds__(256) void k_transform_to_end(float4* __restrict__ p
   if (i >= n) return;
   pts[i] = to_end_point(pts[i], P);
 }
+// the optimised transform of every active stream goes into its re-projection parameters on the device, so that the
+// tail of the sweep (re-projection, index build) is enqueued behind the iterations without a host round trip
+__global__ void k_te_patch(const OdomProblem* __restrict__ probs, uint32_t na, ToEndParams* __restrict__ te) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= na) return;
+  const OdomProblem& pb = probs[a];
+  ToEndParams& P = te[pb.stream_id];
+  for (int k = 0; k < 6; k++) P.T[k] = pb.transform[k];
+  for (int k = 0; k < 3; k++) {   // the host caches sin/cos of a float angle (Angle.h); double-then-round is within an ulp of it
+    P.sT[k] = (float)sin((double)pb.transform[k]);
+    P.cT[k] = (float)cos((double)pb.transform[k]);
+  }
+}
+
 // all clouds of a batch: cloud k belongs to stream k % ns
 // src_c / src_s: when given, point i is read from the (contiguous) source clouds instead of pts — the staging copy of the
 // current clouds is fused into the re-projection
@@ -577,6 +591,7 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
 
 OdometryBatch::~OdometryBatch() {
   if (ev_tail_) (void)hipEventDestroy(ev_tail_);
+  if (ev_pose_) (void)hipEventDestroy(ev_pose_);
   for (auto* p : streams_) delete p;
   if (own_stream_ && st_) (void)hipStreamDestroy(st_);
 }
@@ -690,6 +705,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       pb.stats = {0, 0, 0, 0};
       pb.done = 0;
       pb.ticket = 0;
+      pb.stream_id = (int)s;
       pb.part = part_.p + (size_t)active.size() * OD_PART_STRIDE;
       max_feat = std::max(max_feat, I.n_sharp + I.n_flat);
       active.push_back(s);
@@ -697,6 +713,12 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   }
   const uint32_t na = (uint32_t)active.size();
   if (max_feat > 32 * OD_THREADS) throw Error(LOAMX_E_CAPACITY, "more than 8192 sharp+flat features in one sweep");
+  // ---- everything the device needs for the whole sweep goes up first: problems, cloud offsets, re-projection
+  // parameters (those of the optimising streams are completed on the device, k_te_patch)
+  for (uint32_t s = 0; s < ns; s++) h_te_.p[s] = to_end_params(s, rc[s] == LOAMX_OK);   // a first sweep is stored as it came (:200-201)
+  memcpy(h_off_pin_.p, h_cur_off_.data(), sizeof(uint32_t) * (K + 1));
+  LX_HIP(hipMemcpyAsync(d_cur_off_.p, h_off_pin_.p, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st_));
+  LX_HIP(hipMemcpyAsync(te_.p, h_te_.p, sizeof(ToEndParams) * ns, hipMemcpyHostToDevice, st_));
   if (na) {
     LX_HIP(hipMemcpyAsync(prob_.p, h_prob_.p, sizeof(OdomProblem) * na, hipMemcpyHostToDevice, st_));
     if (max_feat) {
@@ -711,7 +733,24 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       }
     }
     LX_HIP(hipMemcpyAsync(h_prob_.p, prob_.p, sizeof(OdomProblem) * na, hipMemcpyDeviceToHost, st_));
-    LX_HIP(hipStreamSynchronize(st_));
+    if (!ev_pose_) LX_HIP(hipEventCreateWithFlags(&ev_pose_, hipEventDisableTiming));
+    LX_HIP(hipEventRecord(ev_pose_, st_));
+    hipLaunchKernelGGL(k_te_patch, dim3((na + 63) / 64), dim3(64), 0, st_, prob_.p, na, te_.p);
+  }
+  // ---- re-project to the sweep end (:651-652), hand over as "last" clouds and rebuild their index (:654-664): enqueued
+  // right behind the iterations; the host only waits for the poses
+  if (n_all)
+    hipLaunchKernelGGL(k_transform_to_end_batch, dim3((n_all + 255) / 256), dim3(256), 0, st_, cur_.p, n_all, d_cur_off_.p, K, ns, te_.p, src_c,
+                       src_s, n_corner_all);
+  std::swap(cur_.p, last_.p);
+  std::swap(cur_.cap, last_.cap);
+  h_last_off_ = h_cur_off_;
+  index_.build(last_.p, h_last_off_.data(), K);
+  if (!ev_tail_) LX_HIP(hipEventCreateWithFlags(&ev_tail_, hipEventDisableTiming));
+  LX_HIP(hipEventRecord(ev_tail_, st_));
+  tail_pending_ = true;
+  if (na) {
+    LX_HIP(hipEventSynchronize(ev_pose_));
 #ifdef LOAMX_PROF_LM
     {
       double ts[16];
@@ -730,7 +769,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       S.stats.degenerate = h_prob_.p[a].stats.degenerate;
     }
   }
-  // ---- pose integration (:626-649) and the re-projection parameters of every stream
+  // ---- pose integration (:626-649)
   for (uint32_t s = 0; s < ns; s++) {
     OdomStream& S = *streams_[s];
     if (rc[s] == LOAMX_OK) {
@@ -745,28 +784,13 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       S.transform_sum.rot_x = rx; S.transform_sum.rot_y = ry; S.transform_sum.rot_z = rz;
       S.transform_sum.pos = trans;
     }
-    h_te_.p[s] = to_end_params(s, rc[s] == LOAMX_OK);   // a first sweep is stored as it came (:200-201)
     S.inited = true;
     S.n_last_corner = in[s].n_less_sharp;
     S.n_last_surf = in[s].n_less_flat;
   }
-  // ---- re-project to the sweep end (:651-652), hand over as "last" clouds and rebuild their index (:654-664)
-  memcpy(h_off_pin_.p, h_cur_off_.data(), sizeof(uint32_t) * (K + 1));
-  LX_HIP(hipMemcpyAsync(d_cur_off_.p, h_off_pin_.p, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st_));
-  LX_HIP(hipMemcpyAsync(te_.p, h_te_.p, sizeof(ToEndParams) * ns, hipMemcpyHostToDevice, st_));
-  if (n_all)
-    hipLaunchKernelGGL(k_transform_to_end_batch, dim3((n_all + 255) / 256), dim3(256), 0, st_, cur_.p, n_all, d_cur_off_.p, K, ns, te_.p, src_c,
-                       src_s, n_corner_all);
-  std::swap(cur_.p, last_.p);
-  std::swap(cur_.cap, last_.cap);
-  h_last_off_ = h_cur_off_;
-  index_.build(last_.p, h_last_off_.data(), K);
-  if (defer_tail) {   // the caller orders its consumers behind tail_event() instead of blocking the host here
-    if (!ev_tail_) LX_HIP(hipEventCreateWithFlags(&ev_tail_, hipEventDisableTiming));
-    LX_HIP(hipEventRecord(ev_tail_, st_));
-    tail_pending_ = true;
-  } else {
+  if (!defer_tail) {   // (a deferring caller orders its consumers behind tail_event() instead of blocking the host here)
     LX_HIP(hipStreamSynchronize(st_));
+    tail_pending_ = false;
   }
 }
 

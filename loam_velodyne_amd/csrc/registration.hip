@@ -13,6 +13,7 @@
 // HBM-bound gather work: no MFMA (the only dense contraction is 6x6).  Points are packed float4 so a neighbour is one
 // 16-byte load; queries are processed in voxel order, so the lanes of a wave walk the same few grid cells.
 #include "registration.cuh"
+#include <chrono>
 #include "scan.cuh"
 #include "voxel.cuh"
 
@@ -1094,8 +1095,15 @@ void Registrar::launch_knn5(int it) {
   }
 }
 
+static double host_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 void Registrar::run_async() {
   LX_REQUIRE(n_sweeps_ > 0, "run() before upload()");
+  static const bool trace = getenv("LOAMX_REG_TRACE") != nullptr;
+  const double th0 = trace ? host_us() : 0.0;
+  double th1 = 0, th2 = 0, th3 = 0;
   LX_HIP(hipSetDevice(device_));
   const uint32_t ns = n_sweeps_, nseg = 2 * ns, n = n_in_;
   if (timing_) LX_HIP(hipEventRecord(ev_[0], st_));
@@ -1111,6 +1119,7 @@ void Registrar::run_async() {
   } else {
     LX_HIP(hipMemsetAsync(ds_off_.p, 0, sizeof(uint32_t) * (nseg + 1), st_));
   }
+  if (trace) th1 = host_us();
   if (submap_sufficient() && n > 0) {   // BasicLaserMapping.cpp:628-629 guard
     // Converged sweeps turn the remaining launches into no-ops on the device (stats.done), which keeps run_async()
     // free of host round trips.  A blocking caller (early_exit) instead enqueues as many iterations as the previous
@@ -1135,7 +1144,9 @@ void Registrar::run_async() {
       if (!early_exit || it >= params.max_iterations) break;
       LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * ns, hipMemcpyDeviceToHost, st_));
       LX_HIP(hipMemcpyAsync(h_poses_.p, poses_.p, sizeof(Pose) * ns, hipMemcpyDeviceToHost, st_));
+      if (trace && th2 == 0) th2 = host_us();
       if (on_first_wait && !waited) { waited = true; on_first_wait(); }   // host work that overlaps the wait
+      if (trace && th3 == 0) th3 = host_us();
       LX_HIP(hipStreamSynchronize(st_));
       bool all_done = true;
       int need = 0;
@@ -1152,6 +1163,9 @@ void Registrar::run_async() {
     hipLaunchKernelGGL(k_transform_full, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, n_full_, full_off_.p, ns, poses_.p);
   if (timing_) { LX_HIP(hipEventRecord(ev_[1], st_)); timed_run_ = true; }
   LX_HIP(hipGetLastError());
+  if (trace)
+    fprintf(stderr, "[reg] voxel stage enqueued %.0f us, first iterations enqueued %.0f, callback done %.0f, run_async returns %.0f\n", th1 - th0,
+            th2 - th0, th3 - th0, host_us() - th0);
 }
 
 void Registrar::sync() { LX_HIP(hipStreamSynchronize(st_)); }

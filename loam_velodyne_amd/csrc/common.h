@@ -121,4 +121,16 @@ inline int unpack_cloud(const float4* src, uint32_t n, loamx_cloud* c) {
 
 void select_device(int device);   // throws LOAMX_E_NOGPU
 
+// HIP stream with a relative priority: +1 = highest the device offers, 0 = default, -1 = lowest.  The stages of the
+// pipeline run on streams of their own; the latency-critical ones (registration, odometry) outrank feature extraction,
+// whose wide kernels would otherwise delay their short dependent launches.
+inline hipStream_t create_stream(int rel_priority) {
+  int lo = 0, hi = 0;   // numerically lower = higher priority
+  LX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  const int prio = rel_priority > 0 ? hi : (rel_priority < 0 ? lo : (lo + hi) / 2);
+  hipStream_t st = nullptr;
+  LX_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio));
+  return st;
+}
+
 }  // namespace loamx

@@ -570,7 +570,7 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
   if (shared_stream) {
     st_ = shared_stream;
   } else {
-    LX_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    st_ = create_stream(+1);
     own_stream_ = true;
   }
   for (uint32_t s = 0; s < n_streams; s++) streams_.push_back(new OdomStream());

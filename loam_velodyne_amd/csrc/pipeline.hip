@@ -157,7 +157,7 @@ class Pipeline {
   void upload(uint32_t n_steps, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
     LX_REQUIRE(n_steps >= 1 && clouds && ring_size && n_rings, "invalid argument");
     LX_HIP(hipSetDevice(device));
-    if (!fstream) LX_HIP(hipStreamCreateWithFlags(&fstream, hipStreamNonBlocking));
+    if (!fstream) fstream = create_stream(-1);
     LX_HIP(hipStreamSynchronize(fstream));
     fx.clear();
     launched.assign(n_steps, 0);

@@ -149,6 +149,13 @@ class Registrar {
   DevBuf<float> matP_;        // 36 per sweep
   DevBuf<double> partials_;   // per sweep x blocks x LX_NSUM
   DevBuf<uint32_t> nb_;       // 5 neighbour positions per query
+  // views of the per-run parameters (separate buffers after upload(), one block after upload_device())
+  const float* d_guess_ = nullptr;
+  const uint32_t* d_seg_off_ = nullptr;
+  const uint32_t* d_full_off_ = nullptr;
+  const float4* const* d_src_ = nullptr;
+  DevBuf<char> blob_;
+  PinBuf<char> h_blob_;
   DevBuf<uint32_t> arrive_;   // per sweep: k_residual workgroups that have delivered their partial sums
   DevBuf<float4> qstate_;     // per query: position at its last full search + squared re-validation bound
   uint32_t nblk_ = 0;

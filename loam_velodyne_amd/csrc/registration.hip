@@ -345,9 +345,11 @@ void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_
 // stack round trip + voxel keys
 // ----------------------------------------------------------------------------------------------------------------
 // seg_minmax: per segment min ix,iy,iz / max ix,iy,iz
-__global__ __launch_bounds__(256) void k_stack(const float4* __restrict__ in, uint32_t n, const uint32_t* __restrict__ seg_off,
-                                               uint32_t nseg, const Pose* __restrict__ poses, float inv_corner, float inv_surf,
-                                               float4* __restrict__ stack, int* __restrict__ ijk, int* __restrict__ seg_minmax) {
+// src: when given, segment k's points are read from src[k] (device-resident inputs are not gathered first)
+__global__ __launch_bounds__(256) void k_stack(const float4* __restrict__ in, const float4* const* __restrict__ src, uint32_t n,
+                                               const uint32_t* __restrict__ seg_off, uint32_t nseg, const Pose* __restrict__ poses,
+                                               float inv_corner, float inv_surf, float4* __restrict__ stack, int* __restrict__ ijk,
+                                               int* __restrict__ seg_minmax) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
   uint32_t seg = 0;
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256) void k_stack(const float4* __restrict__ in, ui
   if (active) {
     seg = vox_find_seg(seg_off, nseg, i);
     const Pose T = poses[seg >> 1];
-    const float4 p = in[i];
+    const float4 p = src ? src[seg][i - seg_off[seg]] : in[i];
     float x = p.x, y = p.y, z = p.z;
     to_map(T, x, y, z);
     to_be_mapped(T, x, y, z);
@@ -370,9 +372,12 @@ __global__ __launch_bounds__(256) void k_stack(const float4* __restrict__ in, ui
 // ----------------------------------------------------------------------------------------------------------------
 // Gauss-Newton iteration
 // ----------------------------------------------------------------------------------------------------------------
-__global__ void k_pose_init(const float* __restrict__ guess, uint32_t ns, Pose* __restrict__ poses, SweepStats* __restrict__ stats) {
+// (also resets the voxel bounds of the sweep's two segments: one launch less in front of k_stack)
+__global__ void k_pose_init(const float* __restrict__ guess, uint32_t ns, Pose* __restrict__ poses, SweepStats* __restrict__ stats,
+                            int* __restrict__ seg_minmax) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
+  for (int k = 0; k < 12; k++) seg_minmax[12 * s + k] = (k % 6) < 3 ? 2147483647 : (-2147483647 - 1);
   Pose T;
   pose_set_angles(T, guess[6 * s], guess[6 * s + 1], guess[6 * s + 2]);
   T.tx = guess[6 * s + 3]; T.ty = guess[6 * s + 4]; T.tz = guess[6 * s + 5];
@@ -903,7 +908,7 @@ __global__ __launch_bounds__(256) void k_gather_segments(float4* __restrict__ ds
 // ----------------------------------------------------------------------------------------------------------------
 Registrar::Registrar(int device, uint32_t max_sweeps) : device_(device), max_sweeps_(max_sweeps) {
   select_device(device);
-  LX_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+  st_ = create_stream(+1);
   corner_index.init(st_);
   surf_index.init(st_);
   if (const char* e = getenv("LOAMX_KNN_LPQ")) {
@@ -1000,6 +1005,7 @@ void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const 
   }
   memcpy(h_guess_.p, guess6, sizeof(float) * 6 * n_sweeps);
   LX_HIP(hipMemcpyAsync(guess_.p, h_guess_.p, sizeof(float) * 6 * n_sweeps, hipMemcpyHostToDevice, st_));
+  d_guess_ = guess_.p; d_seg_off_ = seg_off_.p; d_full_off_ = full_off_.p; d_src_ = nullptr;
   nblk_ = (max_q_per_sweep_ + LX_RES_THREADS - 1) / LX_RES_THREADS;
   if (nblk_ == 0) nblk_ = 1;
   partials_.reserve((size_t)n_sweeps * nblk_ * LX_NSUM);
@@ -1042,31 +1048,29 @@ void Registrar::upload_device(uint32_t n_sweeps, const float4* const* corner_las
   ds_pts_.reserve(n_in_ + 1);
   vox_.reserve(n_in_ + 1, 2 * n_sweeps);
   LX_REQUIRE(n_in_ < SCAN_MAX_N, "too many feature points in one batch");
-  // offsets / guesses / source pointers go through pinned memory owned by this object (valid until the next upload)
+  // guesses / offsets / source pointers travel as ONE block through pinned memory owned by this object
   const size_t nseg = 2 * (size_t)n_sweeps;
-  h_guess_.reserve((size_t)6 * n_sweeps + 2 * (3 * (size_t)n_sweeps + 2) + 4 * (nseg + n_sweeps + 2));
-  memcpy(h_guess_.p, guess6, sizeof(float) * 6 * n_sweeps);
-  uint32_t* hoff = (uint32_t*)(h_guess_.p + 6 * n_sweeps);
-  memcpy(hoff, h_seg_off_.data(), sizeof(uint32_t) * (nseg + 1));
-  uint32_t* hfull = hoff + (nseg + 1);
-  memcpy(hfull, h_full_off_.data(), sizeof(uint32_t) * (n_sweeps + 1));
-  const float4** hsrc = (const float4**)(((uintptr_t)(hfull + n_sweeps + 1) + 15) & ~(uintptr_t)15);
+  const size_t o_off = sizeof(float) * 6 * n_sweeps, o_full = o_off + sizeof(uint32_t) * (nseg + 1);
+  const size_t o_src = (o_full + sizeof(uint32_t) * (n_sweeps + 1) + 15) & ~(size_t)15;
+  const size_t bytes = o_src + sizeof(float4*) * (nseg + n_sweeps);
+  h_blob_.reserve(bytes + 16);
+  blob_.reserve(bytes + 16);
+  memcpy(h_blob_.p, guess6, sizeof(float) * 6 * n_sweeps);
+  memcpy(h_blob_.p + o_off, h_seg_off_.data(), sizeof(uint32_t) * (nseg + 1));
+  memcpy(h_blob_.p + o_full, h_full_off_.data(), sizeof(uint32_t) * (n_sweeps + 1));
+  const float4** hsrc = (const float4**)(h_blob_.p + o_src);
   for (uint32_t s = 0; s < n_sweeps; s++) { hsrc[2 * s] = corner_last[s]; hsrc[2 * s + 1] = surf_last[s]; }
-  const float4** hfsrc = hsrc + nseg;
-  if (full_res) for (uint32_t s = 0; s < n_sweeps; s++) hfsrc[s] = full_res[s];
-  src_ptrs_.reserve(nseg + n_sweeps + 2);
-  LX_HIP(hipMemcpyAsync(guess_.p, h_guess_.p, sizeof(float) * 6 * n_sweeps, hipMemcpyHostToDevice, st_));
-  LX_HIP(hipMemcpyAsync(seg_off_.p, hoff, sizeof(uint32_t) * (nseg + 1), hipMemcpyHostToDevice, st_));
-  LX_HIP(hipMemcpyAsync(src_ptrs_.p, hsrc, sizeof(float4*) * (nseg + n_sweeps), hipMemcpyHostToDevice, st_));
-  if (n_in_)
-    hipLaunchKernelGGL(k_gather_segments, dim3((n_in_ + 255) / 256), dim3(256), 0, st_, in_.p, seg_off_.p, (uint32_t)nseg,
-                       (const float4* const*)src_ptrs_.p, n_in_);
+  for (uint32_t s = 0; s < n_sweeps; s++) hsrc[nseg + s] = full_res ? full_res[s] : nullptr;
+  LX_HIP(hipMemcpyAsync(blob_.p, h_blob_.p, bytes, hipMemcpyHostToDevice, st_));
+  d_guess_ = (const float*)blob_.p;
+  d_seg_off_ = (const uint32_t*)(blob_.p + o_off);
+  d_full_off_ = (const uint32_t*)(blob_.p + o_full);
+  d_src_ = (const float4* const*)(blob_.p + o_src);
   if (n_full_) {
     full_.reserve(n_full_);
-    LX_HIP(hipMemcpyAsync(full_off_.p, hfull, sizeof(uint32_t) * (n_sweeps + 1), hipMemcpyHostToDevice, st_));
     if (!staged)
-      hipLaunchKernelGGL(k_gather_segments, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, full_off_.p, n_sweeps,
-                         (const float4* const*)(src_ptrs_.p + nseg), n_full_);
+      hipLaunchKernelGGL(k_gather_segments, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, d_full_off_, n_sweeps, d_src_ + nseg,
+                         n_full_);
   }
   nblk_ = (max_q_per_sweep_ + LX_RES_THREADS - 1) / LX_RES_THREADS;
   if (nblk_ == 0) nblk_ = 1;
@@ -1109,13 +1113,12 @@ void Registrar::run_async() {
   if (timing_) LX_HIP(hipEventRecord(ev_[0], st_));
   n_res_launch_ = 0;
   host_results_valid_ = false;
-  hipLaunchKernelGGL(k_pose_init, dim3((ns + 63) / 64), dim3(64), 0, st_, guess_.p, ns, poses_.p, stats_.p);
+  hipLaunchKernelGGL(k_pose_init, dim3((ns + 63) / 64), dim3(64), 0, st_, d_guess_, ns, poses_.p, stats_.p, vox_.seg_minmax());
   if (n > 0) {
     const uint32_t nb = (n + 255) / 256;
-    vox_.reset_minmax(nseg);
-    hipLaunchKernelGGL(k_stack, dim3(nb), dim3(256), 0, st_, in_.p, n, seg_off_.p, nseg, poses_.p, 1.0f / params.corner_leaf,
+    hipLaunchKernelGGL(k_stack, dim3(nb), dim3(256), 0, st_, in_.p, d_src_, n, d_seg_off_, nseg, poses_.p, 1.0f / params.corner_leaf,
                        1.0f / params.surf_leaf, stack_.p, vox_.ijk(), vox_.seg_minmax());
-    vox_.sort_reduce(stack_.p, nullptr, n, seg_off_.p, nseg, ds_pts_.p, ds_off_.p);
+    vox_.sort_reduce(stack_.p, nullptr, n, d_seg_off_, nseg, ds_pts_.p, ds_off_.p);
   } else {
     LX_HIP(hipMemsetAsync(ds_off_.p, 0, sizeof(uint32_t) * (nseg + 1), st_));
   }
@@ -1160,7 +1163,7 @@ void Registrar::run_async() {
     }
   }
   if (n_full_)
-    hipLaunchKernelGGL(k_transform_full, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, n_full_, full_off_.p, ns, poses_.p);
+    hipLaunchKernelGGL(k_transform_full, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, n_full_, d_full_off_, ns, poses_.p);
   if (timing_) { LX_HIP(hipEventRecord(ev_[1], st_)); timed_run_ = true; }
   LX_HIP(hipGetLastError());
   if (trace)

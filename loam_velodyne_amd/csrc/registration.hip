@@ -443,17 +443,89 @@ __device__ inline void knn_insert6(unsigned long long (&bk)[6], uint32_t (&bp)[6
 }
 constexpr unsigned long long KNN_NONE = 0x7f7fffffffffffffull;   // (FLT_MAX, 0xffffffff): empty slot
 
+#ifdef LOAMX_PROF_KNN
+__device__ unsigned long long g_knn_ts[8];
+#define KNN_TS(k) do { if (blockIdx.x == 8 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && threadIdx.x / 64 == (k == 0 || k == 1 ? 0 : 1) && iter == 0) g_knn_ts[k] = wall_clock64(); } while (0)
+#else
+#define KNN_TS(k) do { } while (0)
+#endif
+
+// strided scan of a concatenated run list by the LPQ lanes of a group: table entries [run][slot] in LDS,
+// rp[nruns] = candidate count
+template <int LPQ, int QB>
+__device__ inline void knn_scan_runs(const float4* __restrict__ pts, const uint32_t* s_rb, const uint32_t* s_rp, uint32_t grp, int gl,
+                                     float qx, float qy, float qz, uint32_t total, unsigned long long (&bk)[6], uint32_t (&bp)[6]) {
+  int r = 0;
+  uint32_t bound = s_rp[QB + grp];   // first candidate number of the next run
+  uint32_t off = s_rb[grp];          // position = off + candidate number inside the current run
+  for (uint32_t c = gl; c < total; c += 4 * LPQ) {
+    uint32_t pos[4];
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t cc = c + u * LPQ;
+      pos[u] = 0;
+      if (cc < total) {
+        while (cc >= bound) {   // rp[last] = total > cc terminates
+          r++;
+          bound = s_rp[(r + 1) * QB + grp];
+          off = s_rb[r * QB + grp] - s_rp[r * QB + grp];
+        }
+        pos[u] = off + cc;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) p[u] = (c + u * LPQ) < total ? pts[pos[u]] : make_float4(1e30f, 1e30f, 1e30f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+      const float d2 = dx * dx + dy * dy + dz * dz;   // x -> y -> z accumulation (nanoflann.hpp:372-379)
+      const unsigned long long key = d2 < KNN_COVER2 ? ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(p[u].w) : KNN_NONE;
+      knn_insert6(bk, bp, key, pos[u]);
+    }
+  }
+}
+
+// pop the group's six best (destructive on the lane lists); every lane of the group ends up with the same winners
 template <int LPQ>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_knn5(const float4* __restrict__ ds_pts, const uint32_t* __restrict__ ds_off,
+__device__ inline void knn_pop6(unsigned long long (&bk)[6], uint32_t (&bp)[6], int gl, unsigned long long (&wk)[6], uint32_t (&win)[6]) {
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    unsigned long long key = bk[0];
+    uint32_t pp = bp[0];
+    int owner = gl;
+#pragma unroll
+    for (int m = LPQ / 2; m > 0; m >>= 1) {
+      const unsigned long long ok = __shfl_xor(key, m, LPQ);
+      const uint32_t op = __shfl_xor(pp, m, LPQ);
+      const int oo = __shfl_xor(owner, m, LPQ);
+      if (ok < key) { key = ok; pp = op; owner = oo; }   // distinct points have distinct keys; empty slots tie harmlessly
+    }
+    if (LPQ > 1 || k < 5) {
+      if (owner == gl) {   // the winner's lane advances its list
+#pragma unroll
+        for (int j = 0; j < 5; j++) { bk[j] = bk[j + 1]; bp[j] = bp[j + 1]; }
+        bk[5] = KNN_NONE;
+      }
+    }
+    wk[k] = key;
+    win[k] = pp;
+  }
+}
+
+template <int LPQ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_knn5(const float4* __restrict__ ds_pts, const uint32_t* __restrict__ ds_off,
                                               const Pose* __restrict__ poses, const SweepStats* __restrict__ stats,
                                               const GridDesc* __restrict__ cdesc, const float4* __restrict__ cpts,
                                               const uint32_t* __restrict__ cstart, const GridDesc* __restrict__ sdesc,
                                               const float4* __restrict__ spts, const uint32_t* __restrict__ sstart,
                                               uint32_t* __restrict__ nb, float4* __restrict__ qstate, int iter) {
   constexpr int QB = 256 / LPQ;
-  __shared__ uint32_t s_rb[9 * QB];    // run begin,        [run][slot]
-  __shared__ uint32_t s_rp[10 * QB];   // exclusive prefix, [run][slot]; entry 9 = candidate count
-  __shared__ float4 s_q[QB];           // query in the map frame, .w = bits of the query index
+  constexpr int NRUN = 10;              // 8 rows + the two outer cells of the centre row
+  __shared__ uint32_t s_rb[NRUN * QB];         // run begin,        [run][slot]
+  __shared__ uint32_t s_rp[(NRUN + 1) * QB];   // exclusive prefix, [run][slot]; entry NRUN = candidate count
+  __shared__ float4 s_q[QB];            // query in the map frame, .w = bits of the query index
+  __shared__ uint32_t s_ob[2 * QB];     // the query's own cell: begin / end ([0][slot] = begin, [1][slot] = end)
   __shared__ uint32_t s_n;
   const uint32_t s = blockIdx.y;
   if (stats[s].done) return;
@@ -466,6 +538,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   const uint32_t bx = (blockIdx.x % 8) * per + blockIdx.x / 8;
   const uint32_t first = q0 + bx * QB;
   if (first >= q1) return;
+  KNN_TS(0);
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
 
@@ -530,33 +603,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     if (need_search) {
       const uint32_t slot = base + (uint32_t)__popcll(mneed & ((1ull << __lane_id()) - 1ull));
       s_q[slot] = make_float4(qx, qy, qz, __uint_as_float(q));
+      // the query's own cell (when it lies inside the grid)
       const GridDesc g = corner ? *cdesc : *sdesc;
       const uint32_t* __restrict__ cell_start = corner ? cstart : sstart;
       const int cx = (int)floorf((qx - g.ox) * g.inv_h), cy = (int)floorf((qy - g.oy) * g.inv_h), cz = (int)floorf((qz - g.oz) * g.inv_h);
-      const bool inside = !(cx + 1 < 0 || cx - 1 > g.nx - 1 || cy + 1 < 0 || cy - 1 > g.ny - 1 || cz + 1 < 0 || cz - 1 > g.nz - 1);
-      const int x0 = clampi(cx - 1, 0, g.nx - 1), x1 = clampi(cx + 1, 0, g.nx - 1);
-      uint32_t beg[9], end[9];
-#pragma unroll
-      for (int r = 0; r < 9; r++) {
-        const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
-        beg[r] = 0; end[r] = 0;
-        if (inside && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
-          const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
-          beg[r] = cell_start[row + x0];
-          end[r] = cell_start[row + x1 + 1];
-        }
+      uint32_t ob = 0, oe = 0;
+      if (cx >= 0 && cx < g.nx && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
+        const uint32_t c = ((uint32_t)cz * g.ny + cy) * g.nx + cx;
+        ob = cell_start[c];
+        oe = cell_start[c + 1];
       }
-      uint32_t acc = 0;
-#pragma unroll
-      for (int r = 0; r < 9; r++) {
-        s_rb[r * QB + slot] = beg[r];
-        s_rp[r * QB + slot] = acc;
-        acc += end[r] - beg[r];
-      }
-      s_rp[9 * QB + slot] = acc;
+      s_ob[slot] = ob;
+      s_ob[QB + slot] = oe;
     }
   }
   __syncthreads();
+  KNN_TS(1);
+  KNN_TS(2);
 
   // ---- phase B
   const uint32_t grp = threadIdx.x / LPQ;
@@ -565,68 +628,108 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   const float4 qq = s_q[grp];
   const uint32_t q = __float_as_uint(qq.w);
   const float qx = qq.x, qy = qq.y, qz = qq.z;
-  const float4* __restrict__ pts = q < qm ? cpts : spts;
-  const uint32_t total = s_rp[9 * QB + grp];
-  unsigned long long bk[6];
-  uint32_t bp[6];
+  const bool corner = q < qm;
+  const float4* __restrict__ pts = corner ? cpts : spts;
+  unsigned long long bk[6], wk[6];
+  uint32_t bp[6], win[6];
 #pragma unroll
   for (int j = 0; j < 6; j++) { bk[j] = KNN_NONE; bp[j] = 0u; }
-  int r = 0;
-  uint32_t bound = s_rp[QB + grp];   // first candidate number of the next run
-  uint32_t off = s_rb[grp];          // position = off + candidate number inside the current run
-  for (uint32_t c = gl; c < total; c += 4 * LPQ) {
-    uint32_t pos[4];
-    float4 p[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const uint32_t cc = c + u * LPQ;
-      pos[u] = 0;
-      if (cc < total) {
-        while (cc >= bound) {   // rp[9] = total > cc terminates
-          r++;
-          bound = s_rp[(r + 1) * QB + grp];
-          off = s_rb[r * QB + grp] - s_rp[r * QB + grp];
+  // B1: the own cell — in a dense map it already holds the five neighbours, and the sixth-best distance found here
+  // bounds what the other 26 cells can still contribute
+  {
+    const uint32_t ob = s_ob[grp], oe = s_ob[QB + grp];
+    for (uint32_t c = ob + gl; c < oe; c += 2 * LPQ) {
+      const uint32_t c1 = c + LPQ;
+      const float4 p0 = pts[c];
+      const float4 p1 = c1 < oe ? pts[c1] : make_float4(1e30f, 1e30f, 1e30f, 0.f);
+      {
+        const float dx = qx - p0.x, dy = qy - p0.y, dz = qz - p0.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        knn_insert6(bk, bp, d2 < KNN_COVER2 ? ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(p0.w) : KNN_NONE, c);
+      }
+      {
+        const float dx = qx - p1.x, dy = qy - p1.y, dz = qz - p1.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        knn_insert6(bk, bp, d2 < KNN_COVER2 ? ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(p1.w) : KNN_NONE, c1);
+      }
+    }
+  }
+  knn_pop6<LPQ>(bk, bp, gl, wk, win);
+  // squared radius that still matters: the sixth-best so far (none: the radius the 27 cells cover)
+  const float rad2 = wk[5] != KNN_NONE ? __uint_as_float((uint32_t)(wk[5] >> 32)) : KNN_COVER2;
+  // B2: the other cells, pruned by rad2.  Lane gl prepares rows gl, gl + LPQ, ...: row r = (dz, dy) in {-1,0,1}^2, its
+  // cells cx-1 .. cx+1 are one contiguous run; the centre row contributes its two outer cells only.
+  // Gaps are measured in cell units with the same float expression that assigned the points to cells, shrunk by
+  // 1e-4 relative + 1e-5 so that rounding can only make the visit larger.
+  {
+    const GridDesc g = corner ? *cdesc : *sdesc;
+    const uint32_t* __restrict__ cell_start = corner ? cstart : sstart;
+    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+    const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+    const float h = 1.0f / g.inv_h;
+    const float r2c = rad2 * g.inv_h * g.inv_h;   // in cell units
+    auto gap = [](float f, int c, int d) {        // distance (cell units) from coordinate f in cell c to the cell c + d
+      const float v = d == 0 ? 0.f : (d > 0 ? (float)(c + 1) - f : f - (float)c);
+      const float w = v * 0.9999f - 1e-5f;
+      return w > 0.f ? w : 0.f;
+    };
+    (void)h;
+    const float gxl = gap(fx, cx, -1), gxr = gap(fx, cx, +1);
+    for (int r = gl; r < NRUN; r += LPQ) {
+      uint32_t beg = 0, end = 0;
+      if (r < 9 && r != 4) {
+        const int dz = r / 3 - 1, dy = r % 3 - 1;
+        const int z = cz + dz, y = cy + dy;
+        const float gy = gap(fy, cy, dy), gz = gap(fz, cz, dz);
+        const float gyz = gy * gy + gz * gz;
+        if (z >= 0 && z < g.nz && y >= 0 && y < g.ny && gyz < r2c) {
+          int xa = (gyz + gxl * gxl < r2c) ? cx - 1 : cx, xb = (gyz + gxr * gxr < r2c) ? cx + 1 : cx;
+          if (xa < 0) xa = 0;
+          if (xb > g.nx - 1) xb = g.nx - 1;
+          if (xa <= xb) {
+            const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
+            beg = cell_start[row + xa];
+            end = cell_start[row + xb + 1];
+          }
         }
-        pos[u] = off + cc;
+      } else if (cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
+        // r == 4: the cell left of the own cell; r == 9: the cell right of it.  (A query outside the grid in x has no own
+        // cell: its nearest column is then visited as one of these two.)
+        const int x = r == 4 ? cx - 1 : cx + 1;
+        const float gx = r == 4 ? gxl : gxr;
+        if (x >= 0 && x < g.nx && gx * gx < r2c) {
+          const uint32_t c = ((uint32_t)cz * g.ny + cy) * g.nx + x;
+          beg = cell_start[c];
+          end = cell_start[c + 1];
+        }
       }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) p[u] = (c + u * LPQ) < total ? pts[pos[u]] : make_float4(1e30f, 1e30f, 1e30f, 0.f);
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
-      const float d2 = dx * dx + dy * dy + dz * dz;   // x -> y -> z accumulation (nanoflann.hpp:372-379)
-      const unsigned long long key = d2 < KNN_COVER2 ? ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(p[u].w) : KNN_NONE;
-      knn_insert6(bk, bp, key, pos[u]);
+      s_rb[r * QB + grp] = beg;
+      s_rp[r * QB + grp] = end - beg;   // length for now
     }
   }
-  // ---- pop the group's six best (every lane of the group ends up with the same winners)
-  uint32_t win[6];
-  float wd[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) {
-    unsigned long long key = bk[0];
-    uint32_t pp = bp[0];
-    int owner = gl;
-#pragma unroll
-    for (int m = LPQ / 2; m > 0; m >>= 1) {
-      const unsigned long long ok = __shfl_xor(key, m, LPQ);
-      const uint32_t op = __shfl_xor(pp, m, LPQ);
-      const int oo = __shfl_xor(owner, m, LPQ);
-      if (ok < key) { key = ok; pp = op; owner = oo; }   // distinct points have distinct keys; empty slots tie harmlessly
-    }
-    if (LPQ > 1 || k < 5) {
-      if (owner == gl) {   // the winner's lane advances its list
-#pragma unroll
-        for (int j = 0; j < 5; j++) { bk[j] = bk[j + 1]; bp[j] = bp[j + 1]; }
-        bk[5] = KNN_NONE;
-      }
-    }
-    win[k] = pp;
-    wd[k] = key != KNN_NONE ? __uint_as_float((uint32_t)(key >> 32)) : FLT_MAX;
-  }
+  __builtin_amdgcn_wave_barrier();   // the group's lanes are in one wave: LDS writes above are visible below
+  uint32_t total = 0;
   if (gl == 0) {
-    const float d5 = wd[4], d6 = wd[5];   // FLT_MAX: none inside the covered radius
+#pragma unroll
+    for (int r = 0; r < NRUN; r++) {
+      const uint32_t len = s_rp[r * QB + grp];
+      s_rp[r * QB + grp] = total;
+      total += len;
+    }
+    s_rp[NRUN * QB + grp] = total;
+  }
+  __builtin_amdgcn_wave_barrier();
+  total = s_rp[NRUN * QB + grp];
+  // re-seed the lists with the winners so far (lane 0 holds them, in order) and scan what is left
+#pragma unroll
+  for (int k = 0; k < 6; k++) { bk[k] = gl == 0 ? wk[k] : KNN_NONE; bp[k] = win[k]; }
+  KNN_TS(3);
+  if (total) knn_scan_runs<LPQ, QB>(pts, s_rb, s_rp, grp, gl, qx, qy, qz, total, bk, bp);
+  knn_pop6<LPQ>(bk, bp, gl, wk, win);
+  KNN_TS(4);
+  if (gl == 0) {
+    const float d5 = wk[4] != KNN_NONE ? __uint_as_float((uint32_t)(wk[4] >> 32)) : FLT_MAX;   // FLT_MAX: none inside the covered radius
+    const float d6 = wk[5] != KNN_NONE ? __uint_as_float((uint32_t)(wk[5] >> 32)) : FLT_MAX;
     const bool valid = d5 < 1.0f;         // == pointSearchSqDis[4] < 1.0
 #pragma unroll
     for (int k = 0; k < 5; k++) nb[5 * (size_t)q + k] = (k == 4 && !valid) ? 0xffffffffu : win[k];
@@ -1166,6 +1269,15 @@ void Registrar::run_async() {
     hipLaunchKernelGGL(k_transform_full, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, n_full_, d_full_off_, ns, poses_.p);
   if (timing_) { LX_HIP(hipEventRecord(ev_[1], st_)); timed_run_ = true; }
   LX_HIP(hipGetLastError());
+#ifdef LOAMX_PROF_KNN
+  {
+    unsigned long long ts[8];
+    LX_HIP(hipStreamSynchronize(st_));
+    LX_HIP(hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_knn_ts), sizeof(ts)));
+    fprintf(stderr, "[knn ts, 10ns ticks] phaseA %lld  (wave1 wait %lld)  scan %lld  pop %lld\n", (long long)(ts[1] - ts[0]), (long long)(ts[2] - ts[0]),
+            (long long)(ts[3] - ts[2]), (long long)(ts[4] - ts[3]));
+  }
+#endif
   if (trace)
     fprintf(stderr, "[reg] voxel stage enqueued %.0f us, first iterations enqueued %.0f, callback done %.0f, run_async returns %.0f\n", th1 - th0,
             th2 - th0, th3 - th0, host_us() - th0);

@@ -99,13 +99,19 @@ __device__ inline void mark_as_picked(uint32_t scan_i, int cr, uint8_t* flags, c
   wave_lds_sync();
 }
 
+#ifdef LOAMX_PROF_FEAT
+__device__ unsigned long long g_feat_ts[8];
+#define FT_TS(k) do { if (blockIdx.x == 100 && threadIdx.x == 0) g_feat_ts[k] = wall_clock64(); } while (0)
+#else
+#define FT_TS(k) do { } while (0)
+#endif
 constexpr int FEAT_WAVES = 6;   // regions sorted concurrently per ring
 
 // one workgroup of FEAT_WAVES waves per ring.  Dynamic LDS: flags[flag_bytes] | gaps[flag_bytes] | per wave { c | sorted | label }[nmax]
 __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
     const float4* __restrict__ cloud, const uint32_t* __restrict__ ring_off, const uint32_t* __restrict__ ring_sweep_base, FeatParams P,
     const float* __restrict__ curv, const uint8_t* __restrict__ gflags, const uint8_t* __restrict__ ggap, uint32_t flag_bytes,
-    uint32_t nmax, float4* __restrict__ slotS,
+    uint32_t nmax, uint32_t sortP, float4* __restrict__ slotS,
     float4* __restrict__ slotLS, float4* __restrict__ slotF, uint32_t* __restrict__ cntS, uint32_t* __restrict__ cntLS,
     uint32_t* __restrict__ cntF, uint8_t* __restrict__ lf_valid) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,6 +131,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
   const int cr = P.curv_region, nreg = P.n_regions;
   const uint32_t capS = P.max_sharp * nreg, capLS = P.max_less_sharp * nreg, capF = P.max_flat * nreg;
   uint32_t nS = 0, nLS = 0, nF = 0;   // maintained by wave 0
+  FT_TS(0);
   if (len > 2u * cr + 1u) {           // block-uniform
     const uint32_t base = ring_sweep_base[r];
     // indices relative to the sweep's cloud, exactly the values the reference's integer region formula sees (:180-183)
@@ -155,22 +162,31 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
       }
       if (lane < 4 && n) c[n + lane] = __builtin_inff();   // padding for the 4-wide reads below (never counted)
       __syncthreads();
-      // stable ascending order (:311-317): rank = #smaller + #equal-before.  Every wave sorts its own region;
-      // the curvatures are read four at a time (ds_read_b128, all lanes the same address = broadcast).
-      for (uint32_t e = lane; e < n; e += 64) {
-        const float ce = c[e];
-        uint32_t rank = 0;
-        const float4* c4 = (const float4*)c;
-        for (uint32_t q = 0; q < n; q += 4) {
-          const float4 v = c4[q >> 2];
-          rank += (v.x < ce || (v.x == ce && q < e)) ? 1u : 0u;
-          rank += (v.y < ce || (v.y == ce && q + 1 < e)) ? 1u : 0u;
-          rank += (v.z < ce || (v.z == ce && q + 2 < e)) ? 1u : 0u;
-          rank += (v.w < ce || (v.w == ce && q + 3 < e)) ? 1u : 0u;
+      FT_TS(1);
+      // stable ascending order (:311-317): every wave sorts its own region with a bitonic network over unique 64-bit keys
+      // (curvature bits << 32 | position: curvatures are sums of squares, so their bit patterns order like the values and
+      // equal curvatures keep their input order).  (The earlier rank sort — #smaller + #equal-before per element — was
+      // O(n^2) and took two thirds of this kernel.)
+      {
+        unsigned long long* keys = (unsigned long long*)(wave_base + FEAT_WAVES * wave_bytes + (size_t)wid * sortP * 8);
+        for (uint32_t e = lane; e < sortP; e += 64)
+          keys[e] = e < n ? ((unsigned long long)__float_as_uint(c[e]) << 32) | e : ~0ull;
+        wave_lds_sync();
+        for (uint32_t k = 2; k <= sortP; k <<= 1) {
+          for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = lane; t < sortP / 2; t += 64) {
+              const uint32_t i = ((t / j) * 2 * j) + (t % j), l = i + j;
+              const unsigned long long a = keys[i], b = keys[l];
+              const bool up = (i & k) == 0;
+              if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+            }
+            wave_lds_sync();
+          }
         }
-        sorted[rank] = e;
+        for (uint32_t e = lane; e < n; e += 64) sorted[e] = (uint32_t)keys[e];
       }
       __syncthreads();
+      FT_TS(2);
       // the order-dependent greedy picks: wave 0 walks the regions of this group in order
       if (wid == 0) {
         for (int w = 0; w < FEAT_WAVES && jb + w < nreg; w++) {
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
         }
       }
       __syncthreads();
+      FT_TS(3);
       // less-flat candidates: everything in the region that is not a corner (:238-242)
       for (uint32_t e = lane; e < n; e += 64) lf_valid[gsp + e] = label[e] <= 0 ? 1 : 0;
       __syncthreads();
@@ -265,6 +282,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
   for (uint32_t k = tid; k < npick[0]; k += blockDim.x) slotS[(size_t)r * capS + k] = cloud[pickS[k]];
   for (uint32_t k = tid; k < npick[1]; k += blockDim.x) slotLS[(size_t)r * capLS + k] = cloud[pickLS[k]];
   for (uint32_t k = tid; k < npick[2]; k += blockDim.x) slotF[(size_t)r * capF + k] = cloud[pickF[k]];
+  FT_TS(4);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -525,12 +543,15 @@ void FeatureExtractor::run_async() {
                             (uint32_t)(params.max_flat * params.n_regions)};
   const uint32_t flag_bytes = (max_ring_len_ + 15u) & ~15u;
   const uint32_t nmax = (max_ring_len_ / (uint32_t)params.n_regions + 8u + 15u) & ~15u;
-  const size_t lds = ((2 * (size_t)flag_bytes + 4 * (size_t)(caps[0] + caps[1] + caps[2]) + 15) & ~(size_t)15) + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) + 16;
+  uint32_t sortP = 64;   // bitonic sort size of one region
+  while (sortP < nmax) sortP <<= 1;
+  const size_t lds = ((2 * (size_t)flag_bytes + 4 * (size_t)(caps[0] + caps[1] + caps[2]) + 15) & ~(size_t)15) + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) +
+                     (size_t)FEAT_WAVES * sortP * 8 + 16;
   LX_REQUIRE(lds <= 160 * 1024, "scan ring too long for the LDS staging of k_feat_ring");
   if (lds > 64 * 1024)
     LX_HIP(hipFuncSetAttribute((const void*)k_feat_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_feat_ring, dim3(nring_), dim3(64 * FEAT_WAVES), lds, st_, cloud_.p, ring_off_.p, ring_sweep_base_.p, params, curv_.p,
-                     flags_.p, gap_.p, flag_bytes, nmax, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p,
+                     flags_.p, gap_.p, flag_bytes, nmax, sortP, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p,
                      lf_valid_.p);
   uint32_t* pre[3] = {slot_cnt_[0].p + nring_ + 1, slot_cnt_[1].p + nring_ + 1, slot_cnt_[2].p + nring_ + 1};
   hipLaunchKernelGGL(k_feat_prefix, dim3(3), dim3(1024), 0, st_, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p, nring_, pre[0], pre[1],
@@ -552,6 +573,15 @@ void FeatureExtractor::run_async() {
     vox_.compute_ijk(cloud_.p, lf_valid_.p, n_, ring_off_.p, nring_, inv, inv);
     vox_.sort_reduce(cloud_.p, lf_valid_.p, n_, ring_off_.p, nring_, lf_out_.p, lf_off_.p);
   }
+#ifdef LOAMX_PROF_FEAT
+  {
+    unsigned long long ts[8];
+    LX_HIP(hipStreamSynchronize(st_));
+    LX_HIP(hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_feat_ts), sizeof(ts)));
+    fprintf(stderr, "[feat_ring ts, 10ns ticks] load %lld  rank-sort %lld  picks %lld  tail %lld\n", (long long)(ts[1] - ts[0]), (long long)(ts[2] - ts[1]),
+            (long long)(ts[3] - ts[2]), (long long)(ts[4] - ts[3]));
+  }
+#endif
   LX_HIP(hipGetLastError());
 }
 

@@ -344,21 +344,30 @@ __global__ __launch_bounds__(LFV_THREADS) void k_feat_lf_voxel(const float4* __r
     keys[j] = (k << 12) | li;   // li < 4096: unique keys, equal voxels stay in input order
   }
   __syncthreads();
-  // ---- bitonic sort of P keys (padding = ~0 sorts last)
-  for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
-    for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-      for (uint32_t i = tid; i < P; i += LFV_THREADS) {
-        const uint32_t l = i ^ j2;
-        if (l > i) {
+  // ---- bitonic sort of P keys (padding = ~0 sorts last).  Every thread owns one compare-exchange per stage (P/2 <= 1024
+  // pairs).  Stages whose partner distance is below 128 stay inside one wave's 128-key chunk and only need the wave's own
+  // LDS ordering; the workgroup barrier is kept for the 10 wide stages (it was 66 barriers before).
+  {
+    const uint32_t npairs = P >> 1;
+    for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
+      for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+        for (uint32_t t = tid; t < npairs; t += LFV_THREADS) {
+          const uint32_t i = ((t / j2) * 2 * j2) + (t % j2), l = i + j2;
           const unsigned long long a = keys[i], b = keys[l];
           const bool up = (i & k2) == 0;
           if ((a > b) == up) { keys[i] = b; keys[l] = a; }
         }
+        if (j2 >= 128 || (j2 >= 64 && npairs > LFV_THREADS)) __syncthreads();   // pairs t of a wave span keys [128w, 128w+128) when j2 <= 64
+        else wave_lds_sync();
       }
-      __syncthreads();
+      __syncthreads();   // (k2 changes the direction pattern; cheap relative to the stages saved)
     }
   }
-  // ---- voxel heads -> output positions -> means
+  // ---- voxel heads -> output positions -> means.  The sorted points are first gathered into LDS (one parallel gather)
+  // so that the in-order sums below do not chase cloud[] one dependent load after the other.
+  float4* sp = (float4*)(smem + (size_t)P * 8);
+  for (uint32_t j = tid; j < m; j += LFV_THREADS) sp[j] = cloud[s0 + (uint32_t)(keys[j] & 4095ull)];
+  __syncthreads();
   uint32_t obase = 0;
   for (uint32_t b = 0; b < m; b += LFV_THREADS) {
     const uint32_t j = b + tid;
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(LFV_THREADS) void k_feat_lf_voxel(const float4* __r
       float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
       uint32_t e = j;
       do {
-        const float4 p = cloud[s0 + (uint32_t)(keys[e] & 4095ull)];
+        const float4 p = sp[e];
         sx += p.x; sy += p.y; sz += p.z; si += p.w;
         e++;
       } while (e < m && (keys[e] >> 12) == vk);
@@ -565,7 +574,9 @@ void FeatureExtractor::run_async() {
   if (max_ring_len_ <= LFV_MAX) {
     uint32_t P = 2;
     while (P < max_ring_len_) P <<= 1;
-    hipLaunchKernelGGL(k_feat_lf_voxel, dim3(nring_), dim3(LFV_THREADS), (size_t)P * 8, st_, cloud_.p, ring_off_.p, lf_valid_.p, inv, P,
+    if ((size_t)P * 24 > 64 * 1024)
+      LX_HIP(hipFuncSetAttribute((const void*)k_feat_lf_voxel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)P * 24)));
+    hipLaunchKernelGGL(k_feat_lf_voxel, dim3(nring_), dim3(LFV_THREADS), (size_t)P * 24, st_, cloud_.p, ring_off_.p, lf_valid_.p, inv, P,
                        lf_slots_.p, lf_cnt_.p);
     hipLaunchKernelGGL(k_feat_lf_prefix, dim3(1), dim3(1024), 0, st_, lf_cnt_.p, nring_, lf_off_.p);
     hipLaunchKernelGGL(k_feat_lf_copy, dim3(nring_), dim3(256), 0, st_, lf_slots_.p, ring_off_.p, lf_cnt_.p, lf_off_.p, lf_out_.p);

@@ -88,6 +88,23 @@ void loamx_scanreg_destroy(loamx_scanreg* h);
 int loamx_scanreg_process(loamx_scanreg* h, const loamx_cloud* cloud, const uint32_t* ring_size, uint32_t n_rings,
                           loamx_cloud* sharp, loamx_cloud* less_sharp, loamx_cloud* flat, loamx_cloud* less_flat);
 
+/* Raw-sweep ingestion + feature extraction: loam::MultiScanRegistration::process(laserCloudIn, scanTime)
+ * (src/lib/MultiScanRegistration.cpp:160-238) followed by processScanlines.  `mapper` mirrors loam::MultiScanMapper
+ * (include/loam_velodyne/MultiScanRegistration.h:47-89; presets .h:60-75; validation .cpp:107-127).
+ * raw_xyz: `count` records with x, y, z float32 at byte offsets 0/4/8 (sensor axes: x forward, y left, z up — the
+ * /velodyne_points payload), `stride` bytes apart, in firing order.
+ * Outputs (any may be NULL): `full` = the binned cloud in the LOAM frame, rings concatenated, intensity = ring + relTime
+ * (laserCloud()); ring_size[n_scan_rings] = points per ring; then the four feature clouds as in loamx_scanreg_process. */
+typedef struct loamx_multiscan_mapper {
+  float lower_bound_deg;  /* vertical angle of the first ring */
+  float upper_bound_deg;  /* vertical angle of the last ring */
+  uint32_t n_scan_rings;
+} loamx_multiscan_mapper;
+int loamx_multiscan_mapper_preset(const char* sensor /* "VLP-16" | "HDL-32" | "HDL-64E" */, loamx_multiscan_mapper* out);
+int loamx_scanreg_process_raw(loamx_scanreg* h, const loamx_multiscan_mapper* mapper, const void* raw_xyz, uint32_t count,
+                              uint32_t stride, loamx_cloud* full, uint32_t* ring_size, loamx_cloud* sharp, loamx_cloud* less_sharp,
+                              loamx_cloud* flat, loamx_cloud* less_flat);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Sweep-to-sweep odometry  (BasicLaserOdometry)
  * ---------------------------------------------------------------------------------------------------------- */

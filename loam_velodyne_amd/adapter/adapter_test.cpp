@@ -34,6 +34,33 @@ int main(int argc, char** argv) {
         }
       }
       scanReg.processScanlines(std::chrono::system_clock::now(), rings);
+      if (k == 0) {
+        // the raw entry point (MultiScanRegistration::process): the same sweep as a driver delivers it — sensor axes, firing
+        // order — must give the same ring sizes and the same picks as the pre-binned call above (VLP-16 mapper)
+        bool equal_rings = true;
+        for (int r = 1; r < n_rings; r++) equal_rings = equal_rings && sizes[r] == sizes[0];
+        if (equal_rings && n_rings == 16) {
+          loamx_pcl::PointCloud<loamx_pcl::PointXYZ> raw;
+          raw.points.resize((size_t)n_rings * sizes[0]);
+          for (int a = 0; a < sizes[0]; a++)
+            for (int r = 0; r < n_rings; r++) {
+              const auto& p = rings[r].points[a];
+              auto& q = raw.points[(size_t)a * n_rings + r];
+              q.x = p.z; q.y = p.x; q.z = p.y;   // inverse of the axis remap at MultiScanRegistration.cpp:184-186
+            }
+          loam::BasicScanRegistration rawReg;
+          rawReg.configure();
+          rawReg.processRawSweep(std::chrono::system_clock::now(), raw, -15.f, 15.f, 16);
+          bool ok = rawReg.laserCloud().size() == scanReg.laserCloud().size() &&
+                    rawReg.cornerPointsSharp().size() == scanReg.cornerPointsSharp().size() &&
+                    rawReg.surfacePointsFlat().size() == scanReg.surfacePointsFlat().size();
+          for (int r = 0; ok && r < n_rings; r++) ok = rawReg.ringSizes()[r] == (uint32_t)sizes[r];
+          for (size_t i = 0; ok && i < rawReg.cornerPointsSharp().size(); i++)
+            ok = rawReg.cornerPointsSharp().points[i].x == scanReg.cornerPointsSharp().points[i].x &&
+                 rawReg.cornerPointsSharp().points[i].z == scanReg.cornerPointsSharp().points[i].z;
+          if (!ok) { std::fprintf(stderr, "error: raw-sweep ingestion disagrees with the pre-binned path\n"); return 3; }
+        }
+      }
       *odom.cornerPointsSharp() = scanReg.cornerPointsSharp();
       *odom.cornerPointsLessSharp() = scanReg.cornerPointsLessSharp();
       *odom.surfPointsFlat() = scanReg.surfacePointsFlat();

@@ -148,6 +148,28 @@ class BasicScanRegistration {
     _cornerPointsSharp.points.resize(o[0].count); _cornerPointsLessSharp.points.resize(o[1].count);
     _surfacePointsFlat.points.resize(o[2].count); _surfacePointsLessFlat.points.resize(o[3].count);
   }
+  // The body of MultiScanRegistration::process(laserCloudIn, scanTime) — src/lib/MultiScanRegistration.cpp:160-238 — plus the
+  // processScanlines it ends with, in one call: laserCloudIn is the raw /velodyne_points payload (pcl::PointXYZ records in
+  // sensor axes, firing order); ring binning, relTime and feature extraction run on the device.
+  template <class TimeT, class CloudXYZ>
+  void processRawSweep(const TimeT&, CloudXYZ const& laserCloudIn, float lowerBoundDeg, float upperBoundDeg, uint16_t nScanRings) {
+    if (!_h && !configure(_config)) throw std::runtime_error(std::string("loamx: ") + loamx_last_error());
+    const size_t n = laserCloudIn.points.size() + 16;
+    _laserCloud.points.resize(n);
+    _cornerPointsSharp.points.resize(n); _cornerPointsLessSharp.points.resize(n);
+    _surfacePointsFlat.points.resize(n); _surfacePointsLessFlat.points.resize(n);
+    loamx_cloud full = {_laserCloud.points.data(), (uint32_t)n, 32, 16, 0};
+    loamx_cloud o[4] = {{_cornerPointsSharp.points.data(), (uint32_t)n, 32, 16, 0}, {_cornerPointsLessSharp.points.data(), (uint32_t)n, 32, 16, 0},
+                        {_surfacePointsFlat.points.data(), (uint32_t)n, 32, 16, 0}, {_surfacePointsLessFlat.points.data(), (uint32_t)n, 32, 16, 0}};
+    const loamx_multiscan_mapper m = {lowerBoundDeg, upperBoundDeg, nScanRings};
+    _ringSizes.assign(nScanRings, 0);
+    detail::check(loamx_scanreg_process_raw(_h, &m, laserCloudIn.points.data(), (uint32_t)laserCloudIn.points.size(),
+                                            (uint32_t)sizeof(laserCloudIn.points[0]), &full, _ringSizes.data(), &o[0], &o[1], &o[2], &o[3]));
+    _laserCloud.points.resize(full.count);
+    _cornerPointsSharp.points.resize(o[0].count); _cornerPointsLessSharp.points.resize(o[1].count);
+    _surfacePointsFlat.points.resize(o[2].count); _surfacePointsLessFlat.points.resize(o[3].count);
+  }
+  auto const& ringSizes() { return _ringSizes; }      // points per scan ring of the last raw sweep
   auto const& imuTransform() { return _imuTrans; }   // IMU-less: zeros
   auto const& laserCloud() { return _laserCloud; }
   auto const& cornerPointsSharp() { return _cornerPointsSharp; }
@@ -161,6 +183,7 @@ class BasicScanRegistration {
   RegistrationParams _config;
   CloudXYZI _laserCloud, _cornerPointsSharp, _cornerPointsLessSharp, _surfacePointsFlat, _surfacePointsLessFlat;
   std::array<loamx_pcl::PointXYZ, 4> _imuTrans{};
+  std::vector<uint32_t> _ringSizes;
 };
 
 class BasicLaserOdometry {

@@ -1,5 +1,6 @@
 // C-ABI: feature extraction (loamx_scanreg_*) — shim over loamx::FeatureExtractor.
 #include "features.cuh"
+#include <string>
 
 using namespace loamx;
 
@@ -61,6 +62,36 @@ int loamx_scanreg_process(loamx_scanreg* h, const loamx_cloud* cloud, const uint
     h->fx.run_async();
     h->fx.sync();
     return h->fx.download(0, sharp, less_sharp, flat, less_flat);
+  });
+}
+
+// MultiScanMapper presets (include/loam_velodyne/MultiScanRegistration.h:60-75)
+int loamx_multiscan_mapper_preset(const char* sensor, loamx_multiscan_mapper* out) {
+  return guard([&]() {
+    LX_REQUIRE(sensor && out, "NULL argument");
+    const std::string s(sensor);
+    if (s == "VLP-16") *out = {-15.f, 15.f, 16};
+    else if (s == "HDL-32") *out = {-30.67f, 10.67f, 32};
+    else if (s == "HDL-64E") *out = {-24.9f, 2.f, 64};
+    else throw Error(LOAMX_E_INVALID, "unknown lidar model (VLP-16, HDL-32, HDL-64E)");   // MultiScanRegistration.cpp:100-104
+    return LOAMX_OK;
+  });
+}
+
+int loamx_scanreg_process_raw(loamx_scanreg* h, const loamx_multiscan_mapper* mapper, const void* raw_xyz, uint32_t count, uint32_t stride,
+                              loamx_cloud* full, uint32_t* ring_size, loamx_cloud* sharp, loamx_cloud* less_sharp, loamx_cloud* flat,
+                              loamx_cloud* less_flat) {
+  return guard([&]() {
+    LX_REQUIRE(h && mapper, "NULL argument");
+    // the reference validates minVerticalAngle/maxVerticalAngle/nScanRings the same way (MultiScanRegistration.cpp:107-127)
+    LX_REQUIRE(mapper->upper_bound_deg > mapper->lower_bound_deg, "invalid vertical range (upper <= lower)");
+    LX_REQUIRE(mapper->n_scan_rings >= 2, "invalid number of scan rings (n < 2)");
+    h->fx.upload_raw(raw_xyz, count, stride, mapper->lower_bound_deg, mapper->upper_bound_deg, mapper->n_scan_rings);
+    h->fx.run_async();
+    h->fx.sync();
+    int rc = h->fx.download_cloud(0, full, ring_size);
+    const int rc2 = h->fx.download(0, sharp, less_sharp, flat, less_flat);
+    return rc != LOAMX_OK ? rc : rc2;
   });
 }
 

@@ -1,6 +1,7 @@
 // Per-sweep feature extraction (BasicScanRegistration::extractFeatures, IMU-less) for a batch of sweeps.
 #pragma once
 #include "common.h"
+#include "ingest.cuh"
 #include "voxel.cuh"
 
 namespace loamx {
@@ -25,6 +26,9 @@ class FeatureExtractor {
 
   // stage nsw sweeps: cloud[s] = rings concatenated, ring_size[s][0..n_rings[s])
   void upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings);
+  // one raw revolution in sensor axes / firing order (MultiScanRegistration::process): binned into rings on the device
+  void upload_raw(const void* raw_xyz, uint32_t count, uint32_t stride, float lower_deg, float upper_deg, uint32_t n_scan_rings);
+  int download_cloud(uint32_t sweep, loamx_cloud* full, uint32_t* ring_size_out);
   void run_async();
   void sync();
   // host copies of one sweep's outputs (after sync); any pointer may be NULL
@@ -45,6 +49,13 @@ class FeatureExtractor {
   uint32_t total_rings() const { return nring_; }
 
  private:
+  void check_params_() const;
+  void layout_(uint32_t nsw, const uint32_t* const* ring_size, const uint32_t* n_rings);
+  void allocate_();
+  RawBinner binner_;
+  DevBuf<float4> raw_;
+  DevBuf<uint32_t> raw_ring_cnt_;
+  PinBuf<uint32_t> h_raw_ring_cnt_;
   int device_;
   hipStream_t st_ = nullptr;
   bool own_stream_ = false;

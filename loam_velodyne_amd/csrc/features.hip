@@ -477,13 +477,15 @@ FeatureExtractor::~FeatureExtractor() {
   if (own_stream_ && st_) (void)hipStreamDestroy(st_);
 }
 
-void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
-  LX_REQUIRE(nsw >= 1 && clouds && ring_size && n_rings, "invalid sweep batch");
+void FeatureExtractor::check_params_() const {
   LX_REQUIRE(params.curv_region >= 1 && params.curv_region <= 16, "curvature_region must be in [1,16]");
   LX_REQUIRE(params.n_regions >= 1 && params.n_regions <= 64, "n_feature_regions must be in [1,64]");
   LX_REQUIRE(params.max_sharp >= 0 && params.max_flat >= 0 && params.max_less_sharp >= params.max_sharp, "invalid pick limits");
   LX_REQUIRE(params.less_flat_leaf > 0.f, "less_flat_filter_size must be positive");
-  LX_HIP(hipSetDevice(device_));
+}
+
+// host bookkeeping of a batch: ring offsets, sweep bases, longest ring
+void FeatureExtractor::layout_(uint32_t nsw, const uint32_t* const* ring_size, const uint32_t* n_rings) {
   nsw_ = nsw;
   h_ring_off_.assign(1, 0);
   h_ring_base_.assign(nsw + 1, 0);
@@ -492,7 +494,6 @@ void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uin
   max_ring_len_ = 0;
   uint32_t pt = 0;
   for (uint32_t s = 0; s < nsw; s++) {
-    check_cloud(&clouds[s], false);
     uint32_t sum = 0;
     for (uint32_t r = 0; r < n_rings[s]; r++) {
       sum += ring_size[s][r];
@@ -500,7 +501,6 @@ void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uin
       h_ring_sweep_base_.push_back(pt);
       max_ring_len_ = std::max(max_ring_len_, ring_size[s][r]);
     }
-    LX_REQUIRE(sum == clouds[s].count, "ring sizes do not add up to the cloud size");
     pt += sum;
     h_pt_base_[s + 1] = pt;
     h_ring_base_[s + 1] = h_ring_base_[s] + n_rings[s];
@@ -508,8 +508,11 @@ void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uin
   n_ = pt;
   nring_ = h_ring_base_[nsw];
   LX_REQUIRE(nring_ >= 1, "no scan rings");
-  h_cloud_.reserve(n_ + 1);
-  for (uint32_t s = 0; s < nsw; s++) pack_cloud(&clouds[s], h_cloud_.p + h_pt_base_[s]);
+}
+
+// device buffers for the laid-out batch + the small tables (the cloud itself is already in / copied to cloud_)
+void FeatureExtractor::allocate_() {
+  const uint32_t nsw = nsw_;
   cloud_.reserve(n_ + 1);
   curv_.reserve(n_ + 1);
   flags_.reserve(n_ + 1);
@@ -531,11 +534,75 @@ void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uin
     out_off_[k].reserve(nsw + 2);
   }
   if (max_ring_len_ > 4096) vox_.reserve(n_ + 1, nring_);
-  if (n_) LX_HIP(hipMemcpyAsync(cloud_.p, h_cloud_.p, sizeof(float4) * n_, hipMemcpyHostToDevice, st_));
   LX_HIP(hipMemcpyAsync(ring_off_.p, h_ring_off_.data(), sizeof(uint32_t) * (nring_ + 1), hipMemcpyHostToDevice, st_));
   LX_HIP(hipMemcpyAsync(ring_sweep_base_.p, h_ring_sweep_base_.data(), sizeof(uint32_t) * nring_, hipMemcpyHostToDevice, st_));
   LX_HIP(hipMemcpyAsync(sweep_ring_base_.p, h_ring_base_.data(), sizeof(uint32_t) * (nsw + 1), hipMemcpyHostToDevice, st_));
+}
+
+void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
+  LX_REQUIRE(nsw >= 1 && clouds && ring_size && n_rings, "invalid sweep batch");
+  check_params_();
+  LX_HIP(hipSetDevice(device_));
+  for (uint32_t s = 0; s < nsw; s++) {
+    check_cloud(&clouds[s], false);
+    uint32_t sum = 0;
+    for (uint32_t r = 0; r < n_rings[s]; r++) sum += ring_size[s][r];
+    LX_REQUIRE(sum == clouds[s].count, "ring sizes do not add up to the cloud size");
+  }
+  layout_(nsw, ring_size, n_rings);
+  h_cloud_.reserve(n_ + 1);
+  for (uint32_t s = 0; s < nsw; s++) pack_cloud(&clouds[s], h_cloud_.p + h_pt_base_[s]);
+  allocate_();
+  if (n_) LX_HIP(hipMemcpyAsync(cloud_.p, h_cloud_.p, sizeof(float4) * n_, hipMemcpyHostToDevice, st_));
   LX_HIP(hipStreamSynchronize(st_));
+}
+
+// One raw revolution (MultiScanRegistration::process, src/lib/MultiScanRegistration.cpp:160-238): records with x, y, z
+// float32 at byte offsets 0/4/8 in sensor axes, firing order.  The sweep is binned into rings on the device (ingest.hip);
+// only the ring sizes come back to the host, which needs them to lay out the per-ring work.
+void FeatureExtractor::upload_raw(const void* raw_xyz, uint32_t count, uint32_t stride, float lower_deg, float upper_deg, uint32_t n_scan_rings) {
+  LX_REQUIRE(raw_xyz || count == 0, "NULL raw cloud");
+  LX_REQUIRE(stride >= 12 && stride % 4 == 0, "raw stride must be a multiple of 4 and at least 12");
+  LX_REQUIRE(n_scan_rings >= 1 && n_scan_rings <= RawBinner::MAX_RINGS, "n_scan_rings must be in [1, 256]");
+  LX_REQUIRE(upper_deg != lower_deg, "vertical bounds must differ");
+  check_params_();
+  LX_HIP(hipSetDevice(device_));
+  h_cloud_.reserve(count + 1);
+  for (uint32_t i = 0; i < count; i++) {
+    const float* p = (const float*)((const char*)raw_xyz + (size_t)i * stride);
+    h_cloud_.p[i] = make_float4(p[0], p[1], p[2], 0.f);
+  }
+  raw_.reserve(count + 1);
+  cloud_.reserve(count + 1);
+  raw_ring_cnt_.reserve(RawBinner::MAX_RINGS);
+  h_raw_ring_cnt_.reserve(RawBinner::MAX_RINGS);
+  if (count) LX_HIP(hipMemcpyAsync(raw_.p, h_cloud_.p, sizeof(float4) * count, hipMemcpyHostToDevice, st_));
+  MapperParams M;
+  M.lower = lower_deg; M.upper = upper_deg; M.n_rings = n_scan_rings;
+  M.factor = (float)((int)n_scan_rings - 1) / (upper_deg - lower_deg);   // (nScanRings - 1) / (upperBound - lowerBound), :41-50
+  binner_.init(st_);
+  binner_.run(raw_.p, count, M, params.scan_period, cloud_.p, raw_ring_cnt_.p);
+  LX_HIP(hipMemcpyAsync(h_raw_ring_cnt_.p, raw_ring_cnt_.p, sizeof(uint32_t) * n_scan_rings, hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipStreamSynchronize(st_));
+  const uint32_t* rs[1] = {h_raw_ring_cnt_.p};
+  layout_(1, rs, &n_scan_rings);
+  allocate_();   // (cloud_ already holds the binned sweep; reserve() keeps the contents when the capacity suffices)
+  LX_HIP(hipStreamSynchronize(st_));
+}
+
+// the (binned) input cloud of a sweep and its ring sizes
+int FeatureExtractor::download_cloud(uint32_t sweep, loamx_cloud* full, uint32_t* ring_size_out) {
+  LX_REQUIRE(sweep < nsw_, "sweep index out of range");
+  const uint32_t r0 = h_ring_base_[sweep], r1 = h_ring_base_[sweep + 1];
+  if (ring_size_out)
+    for (uint32_t r = r0; r < r1; r++) ring_size_out[r - r0] = h_ring_off_[r + 1] - h_ring_off_[r];
+  if (!full) return LOAMX_OK;
+  check_cloud(full, false);
+  const uint32_t a = h_pt_base_[sweep], b = h_pt_base_[sweep + 1];
+  std::vector<float4> tmp(b - a);
+  if (b > a) LX_HIP(hipMemcpyAsync(tmp.data(), cloud_.p + a, sizeof(float4) * (b - a), hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipStreamSynchronize(st_));
+  return unpack_cloud(tmp.data(), b - a, full);
 }
 
 void FeatureExtractor::run_async() {

@@ -181,6 +181,11 @@ class Batch:
         return int(lib().loamx_batch_stream(self.h) or 0)
 
 
+class MultiScanMapper(C.Structure):
+    """loamx_multiscan_mapper (loam::MultiScanMapper)."""
+    _fields_ = [("lower_bound_deg", C.c_float), ("upper_bound_deg", C.c_float), ("n_scan_rings", C.c_uint32)]
+
+
 class ScanRegistration:
     """loamx_scanreg_*: BasicScanRegistration::processScanlines / extractFeatures on the GPU."""
     NAMES = ("sharp", "less_sharp", "flat", "less_flat")
@@ -210,6 +215,27 @@ class ScanRegistration:
                                            C.byref(cl[1]), C.byref(cl[2]), C.byref(cl[3])))
         res = {name: outs[k][:cl[k].count].copy() for k, name in enumerate(self.NAMES)}
         res["full"] = pts[:, :4].copy() if pts.shape[1] == 4 else pts
+        return res
+
+    def process_raw(self, raw_xyz, sensor="VLP-16", mapper=None):
+        """loamx_scanreg_process_raw: MultiScanRegistration::process on a raw (n,3) firing-order cloud in sensor axes.
+        mapper = (lower_deg, upper_deg, n_rings) overrides the sensor preset.  Adds "full" and "ring_sizes"."""
+        raw = np.ascontiguousarray(raw_xyz, np.float32).reshape(-1, 3)
+        m = MultiScanMapper()
+        if mapper is None:
+            _check(lib().loamx_multiscan_mapper_preset(sensor.encode(), C.byref(m)))
+        else:
+            m.lower_bound_deg, m.upper_bound_deg, m.n_scan_rings = float(mapper[0]), float(mapper[1]), int(mapper[2])
+        n = len(raw)
+        outs = [np.zeros((max(n, 1), 4), np.float32) for _ in range(5)]
+        cl = [cloud_of(o) for o in outs]
+        rs = np.zeros(max(int(m.n_scan_rings), 1), np.uint32)
+        _check(lib().loamx_scanreg_process_raw(self.h, C.byref(m), raw.ctypes.data_as(C.c_void_p), n, 12, C.byref(cl[4]),
+                                               rs.ctypes.data_as(C.c_void_p), C.byref(cl[0]), C.byref(cl[1]), C.byref(cl[2]),
+                                               C.byref(cl[3])))
+        res = {name: outs[k][:cl[k].count].copy() for k, name in enumerate(self.NAMES)}
+        res["full"] = outs[4][:cl[4].count].copy()
+        res["ring_sizes"] = rs.astype(np.int32)
         return res
 
 

@@ -197,6 +197,24 @@ def make_sweep(world: World, sensor: str, pose_start, pose_end, noise: float = 0
     return Sweep(pts, np.full(R, A, np.int32), pose_start.astype(np.float32), pose_end.astype(np.float32))
 
 
+def to_raw(sweep: Sweep, bad_every: int = 0) -> np.ndarray:
+    """The sweep as a Velodyne driver delivers it (what MultiScanRegistration::process consumes): (N,3) float32 in SENSOR
+    axes (x forward, y left, z up — the inverse of the remap at MultiScanRegistration.cpp:184-186) in firing order
+    (azimuth-major, all lasers of one firing together).  bad_every > 0 plants a NaN return, a zero return and a return far
+    outside the vertical field of view at every bad_every-th firing, as real packets contain them."""
+    R = len(sweep.ring_sizes)
+    A = int(sweep.ring_sizes[0])
+    assert np.all(sweep.ring_sizes == A)
+    p = sweep.points.reshape(R, A, 4)
+    raw = np.stack([p[..., 2], p[..., 0], p[..., 1]], axis=-1).transpose(1, 0, 2).copy()   # (A, R, 3)
+    if bad_every:
+        for a in range(bad_every // 2, A - 1, bad_every):   # (never the first / last return: they define startOri / endOri)
+            raw[a, 0 % R] = np.nan
+            raw[a, 1 % R] = 0.0
+            raw[a, 2 % R] = (0.1, 0.1, 50.0)
+    return raw.reshape(-1, 3).astype(np.float32)
+
+
 def trajectory(n_sweeps: int, step: float = 1.0, yaw_step_deg: float = 0.5, start=(0.0, 0.0, 0.0), n_static: int = 1):
     """Sweep boundary poses (n_sweeps+1, 6).  The first `n_static` sweeps are taken at rest (the reference keeps the
     very first sweep un-de-skewed, BasicLaserOdometry.cpp:198-211, so a moving first sweep would smear the map);

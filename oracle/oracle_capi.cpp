@@ -2,6 +2,7 @@
 // bench.py's cpu_baseline leg can drive it through ctypes.  Never linked into the product library.
 #include "oracle_mapping.hpp"
 #include "oracle_features.hpp"
+#include "oracle_ingest.hpp"
 #include <chrono>
 
 using namespace loam_oracle;
@@ -84,6 +85,25 @@ int orc_scanreg_get(void* h, int which, float* out, int cap) {
   auto* s = (ScanRegistration*)h;
   const Cloud* c[5] = {&s->laserCloud, &s->cornerSharp, &s->cornerLessSharp, &s->surfFlat, &s->surfLessFlat};
   return from_cloud(*c[which], out, cap);
+}
+
+// ---- raw-sweep ingestion (MultiScanRegistration::process) ----
+// raw: n x (x, y, z) in sensor axes, firing order.  out: binned points (rings concatenated, 4 floats each, cap points),
+// ring_sizes[n_rings].  Returns the number of points kept.
+int orc_multiscan_bin(const float* raw, int n, float lower_deg, float upper_deg, int n_rings, float scan_period, float* out, int cap,
+                      int* ring_sizes) {
+  MultiScanMapper m;
+  m.set(lower_deg, upper_deg, (uint16_t)n_rings);
+  std::vector<Cloud> scans = bin_sweep(raw, (size_t)n, m, scan_period);
+  int total = 0;
+  for (int r = 0; r < n_rings; r++) {
+    ring_sizes[r] = (int)scans[r].size();
+    for (const Pt& p : scans[r]) {
+      if (total < cap) { out[4 * total] = p.x; out[4 * total + 1] = p.y; out[4 * total + 2] = p.z; out[4 * total + 3] = p.i; }
+      total++;
+    }
+  }
+  return total;
 }
 
 // ---- odometry ----

@@ -105,6 +105,22 @@ def _get_cloud(fn, h, which, cap_hint=0):
     return out[:n].copy()
 
 
+MAPPERS = {"VLP-16": (-15.0, 15.0, 16), "HDL-32": (-30.67, 10.67, 32), "HDL-64E": (-24.9, 2.0, 64)}   # MultiScanRegistration.h:60-75
+
+
+def multiscan_bin(orc: "Oracle", raw_xyz, mapper="VLP-16", scan_period=0.1):
+    """oracle restatement of MultiScanRegistration::process: raw (n,3) sensor-axes points in firing order ->
+    (binned points (m,4) with rings concatenated, ring_sizes (n_rings,))."""
+    lo, hi, nr = MAPPERS[mapper] if isinstance(mapper, str) else mapper
+    raw = np.ascontiguousarray(raw_xyz, np.float32).reshape(-1, 3)
+    out = np.zeros((max(len(raw), 1), 4), np.float32)
+    rs = np.zeros(nr, np.int32)
+    orc.L.orc_multiscan_bin.restype = C.c_int
+    m = orc.L.orc_multiscan_bin(raw.ctypes.data_as(C.c_void_p), len(raw), C.c_float(lo), C.c_float(hi), int(nr), C.c_float(scan_period),
+                                out.ctypes.data_as(C.c_void_p), len(out), rs.ctypes.data_as(C.c_void_p))
+    return out[:m].copy(), rs
+
+
 class ScanRegistration:
     """oracle restatement of BasicScanRegistration (IMU-less)."""
     NAMES = ("full", "sharp", "less_sharp", "flat", "less_flat")

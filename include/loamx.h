@@ -13,6 +13,7 @@
  *                                                        (process src/lib/BasicLaserMapping.cpp:266-599,
  *                                                         optimizeTransformTobeMapped :626-926,
  *                                                         updateOdometry :607-621)
+ *   loamx_tm_*       <->  loam::BasicTransformMaintenance include/loam_velodyne/BasicTransformMaintenance.h:44-66
  *   loamx_batch_*    new: the batched-sweep mode of BASELINE.json's north_star (independent sweeps against a frozen
  *                    shared map) — the unit that is sharded across GPUs.
  *
@@ -173,6 +174,23 @@ int loamx_map_get_cubes(loamx_map* h, int which, loamx_cloud* out);
 /* diagnostics of the last process(): iterations, rows selected, corner queries, surf queries, corner sub-map size,
  * surf sub-map size, degenerate flag, optimised flag */
 int loamx_map_get_stats(loamx_map* h, int stats[8]);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Pose fusion after the path  (BasicTransformMaintenance, include/loam_velodyne/BasicTransformMaintenance.h:44-66,
+ * src/lib/BasicTransformMaintenance.cpp:46-178) and the orientation convention of the nodes' nav_msgs/Odometry
+ * messages (src/lib/LaserOdometry.cpp:300-308, src/lib/LaserMapping.cpp:205-213, src/lib/TransformMaintenance.cpp:
+ * 66-115).  Host arithmetic only: these entry points need no device.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct loamx_tm loamx_tm;
+loamx_tm* loamx_tm_create(void);
+void loamx_tm_destroy(loamx_tm* h);
+int loamx_tm_update_odometry(loamx_tm* h, const float transform_sum[6]);                                  /* updateOdometry */
+int loamx_tm_update_mapping_transform(loamx_tm* h, const float aft_mapped[6], const float bef_mapped[6]); /* updateMappingTransform */
+int loamx_tm_associate_to_map(loamx_tm* h);                                                                /* transformAssociateToMap */
+int loamx_tm_get_mapped(loamx_tm* h, float transform_mapped[6]);                                           /* transformMapped() */
+/* (rot_x, rot_y, rot_z) -> message orientation (x, y, z, w), and back */
+int loamx_wire_pose_to_quat(const float rot_xyz[3], double quat_xyzw[4]);
+int loamx_wire_quat_to_pose(const double quat_xyzw[4], float rot_xyz[3]);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Batched-sweep mode: B independent sweeps registered against one frozen sub-map.

@@ -3,6 +3,7 @@
 // a binary file written by tests/test_gpu_adapter.py:
 //   int32 n_sweeps; per sweep: int32 n_rings, int32 ring_size[n_rings], float32 xyzi[sum][4]
 // Prints one line per sweep: "k transformSum[6] transformAftMapped[6]".
+#include <cmath>
 #include <cstdio>
 #include <chrono>
 #include "loam_velodyne/loamx_adapter.h"
@@ -18,6 +19,7 @@ int main(int argc, char** argv) {
     scanReg.configure();
     loam::BasicLaserOdometry odom;
     loam::BasicLaserMapping mapping;
+    loam::BasicTransformMaintenance maintenance;   // fed like TransformMaintenance.cpp:66-115 feeds the original
     for (int k = 0; k < n_sweeps; k++) {
       int32_t n_rings = 0;
       if (std::fread(&n_rings, 4, 1, f) != 1) return 2;
@@ -76,6 +78,12 @@ int main(int argc, char** argv) {
       float s[6], a[6];
       odom.transformSum().to(s);
       mapping.transformAftMapped().to(a);
+      maintenance.updateOdometry(s[0], s[1], s[2], s[3], s[4], s[5]);
+      maintenance.updateMappingTransform(mapping.transformAftMapped(), mapping.transformBefMapped());
+      maintenance.transformAssociateToMap();
+      // right after a mapping update transformBefMapped == transformSum, so the fused pose is the mapping result
+      for (int c = 0; c < 6; c++)
+        if (std::fabs(maintenance.transformMapped()[c] - a[c]) > 1e-5f) { std::fprintf(stderr, "error: transform maintenance disagrees with the mapping pose\n"); return 4; }
       std::printf("%d %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", k, s[0], s[1], s[2], s[3], s[4], s[5], a[0], a[1], a[2],
                   a[3], a[4], a[5]);
     }

@@ -322,4 +322,38 @@ class BasicLaserMapping {
   }
 };
 
+// BasicTransformMaintenance (include/loam_velodyne/BasicTransformMaintenance.h:44-66) over loamx_tm_*
+class BasicTransformMaintenance {
+ public:
+  BasicTransformMaintenance() : _h(loamx_tm_create()) {}
+  ~BasicTransformMaintenance() { loamx_tm_destroy(_h); }
+  BasicTransformMaintenance(const BasicTransformMaintenance&) = delete;
+  BasicTransformMaintenance& operator=(const BasicTransformMaintenance&) = delete;
+  void updateOdometry(double pitch, double yaw, double roll, double x, double y, double z) {
+    const float t[6] = {(float)pitch, (float)yaw, (float)roll, (float)x, (float)y, (float)z};
+    detail::check(loamx_tm_update_odometry(_h, t));
+  }
+  void updateMappingTransform(double pitch, double yaw, double roll, double x, double y, double z, double twist_rot_x, double twist_rot_y,
+                              double twist_rot_z, double twist_pos_x, double twist_pos_y, double twist_pos_z) {
+    const float a[6] = {(float)pitch, (float)yaw, (float)roll, (float)x, (float)y, (float)z};
+    const float b[6] = {(float)twist_rot_x, (float)twist_rot_y, (float)twist_rot_z, (float)twist_pos_x, (float)twist_pos_y, (float)twist_pos_z};
+    detail::check(loamx_tm_update_mapping_transform(_h, a, b));
+  }
+  void updateMappingTransform(Twist const& transformAftMapped, Twist const& transformBefMapped) {
+    float a[6], b[6];
+    transformAftMapped.to(a);
+    transformBefMapped.to(b);
+    detail::check(loamx_tm_update_mapping_transform(_h, a, b));
+  }
+  void transformAssociateToMap() {
+    detail::check(loamx_tm_associate_to_map(_h));
+    detail::check(loamx_tm_get_mapped(_h, _transformMapped));
+  }
+  auto const& transformMapped() const { return _transformMapped; }
+
+ private:
+  loamx_tm* _h;
+  float _transformMapped[6]{};
+};
+
 }  // namespace loam

@@ -181,6 +181,49 @@ class Batch:
         return int(lib().loamx_batch_stream(self.h) or 0)
 
 
+class TransformMaintenance:
+    """loamx_tm_*: BasicTransformMaintenance (host arithmetic, no device)."""
+
+    def __init__(self):
+        lib().loamx_tm_create.restype = C.c_void_p
+        self.h = C.c_void_p(lib().loamx_tm_create())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().loamx_tm_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def update_odometry(self, transform_sum):
+        t = np.ascontiguousarray(transform_sum, np.float32)
+        _check(lib().loamx_tm_update_odometry(self.h, t.ctypes.data_as(C.c_void_p)))
+
+    def update_mapping_transform(self, aft_mapped, bef_mapped):
+        a, b = np.ascontiguousarray(aft_mapped, np.float32), np.ascontiguousarray(bef_mapped, np.float32)
+        _check(lib().loamx_tm_update_mapping_transform(self.h, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)))
+
+    def associate_to_map(self):
+        _check(lib().loamx_tm_associate_to_map(self.h))
+        out = np.zeros(6, np.float32)
+        _check(lib().loamx_tm_get_mapped(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
+def wire_pose_to_quat(rot_xyz):
+    r = np.ascontiguousarray(rot_xyz, np.float32)
+    q = np.zeros(4, np.float64)
+    _check(lib().loamx_wire_pose_to_quat(r.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p)))
+    return q
+
+
+def wire_quat_to_pose(quat_xyzw):
+    q = np.ascontiguousarray(quat_xyzw, np.float64)
+    r = np.zeros(3, np.float32)
+    _check(lib().loamx_wire_quat_to_pose(q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p)))
+    return r
+
+
 class MultiScanMapper(C.Structure):
     """loamx_multiscan_mapper (loam::MultiScanMapper)."""
     _fields_ = [("lower_bound_deg", C.c_float), ("upper_bound_deg", C.c_float), ("n_scan_rings", C.c_uint32)]

@@ -3,6 +3,7 @@
 #include "oracle_mapping.hpp"
 #include "oracle_features.hpp"
 #include "oracle_ingest.hpp"
+#include "oracle_maintenance.hpp"
 #include <chrono>
 
 using namespace loam_oracle;
@@ -105,6 +106,19 @@ int orc_multiscan_bin(const float* raw, int n, float lower_deg, float upper_deg,
   }
   return total;
 }
+
+// ---- transform maintenance (BasicTransformMaintenance) + wire conversions ----
+void orc_tm_associate(const float* sum6, const float* bef6, const float* aft6, float* mapped6) {
+  TransformMaintenance t;
+  t.update_odometry(sum6[0], sum6[1], sum6[2], sum6[3], sum6[4], sum6[5]);
+  double a[6], b[6];
+  for (int k = 0; k < 6; k++) { a[k] = aft6[k]; b[k] = bef6[k]; }
+  t.update_mapping_transform(a, b);
+  t.transform_associate_to_map();
+  for (int k = 0; k < 6; k++) mapped6[k] = t.transformMapped[k];
+}
+void orc_wire_pose_to_quat(const float* rot3, double* q4) { wire_pose_to_quat(rot3, q4); }
+void orc_wire_quat_to_pose(const double* q4, float* rot3) { wire_quat_to_pose(q4, rot3); }
 
 // ---- odometry ----
 void* orc_odom_create() { return new LaserOdometry(); }

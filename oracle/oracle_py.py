@@ -121,6 +121,28 @@ def multiscan_bin(orc: "Oracle", raw_xyz, mapper="VLP-16", scan_period=0.1):
     return out[:m].copy(), rs
 
 
+def tm_associate(orc: "Oracle", transform_sum, bef_mapped, aft_mapped):
+    """oracle restatement of BasicTransformMaintenance::transformAssociateToMap -> transformMapped (6,)."""
+    s, b, a = _f32(transform_sum), _f32(bef_mapped), _f32(aft_mapped)
+    out = np.zeros(6, np.float32)
+    orc.L.orc_tm_associate(s.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def wire_pose_to_quat(orc: "Oracle", rot3):
+    r = _f32(rot3)
+    q = np.zeros(4, np.float64)
+    orc.L.orc_wire_pose_to_quat(r.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p))
+    return q
+
+
+def wire_quat_to_pose(orc: "Oracle", q4):
+    q = np.ascontiguousarray(q4, np.float64)
+    r = np.zeros(3, np.float32)
+    orc.L.orc_wire_quat_to_pose(q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p))
+    return r
+
+
 class ScanRegistration:
     """oracle restatement of BasicScanRegistration (IMU-less)."""
     NAMES = ("full", "sharp", "less_sharp", "flat", "less_flat")

@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--map-points", type=int, default=MAP_POINTS)
+    ap.add_argument("--map-epoch-steps", type=int, default=0,
+                    help="E > 0: a new map epoch every E steps inside the timed region — rank 0's map is re-broadcast (RCCL, async), "
+                         "indexed in the background and swapped in at the epoch boundary (BASELINE configs[4] double buffering)")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU)
     ap.add_argument("--handles", type=int, default=HANDLES_PER_GPU,
                     help="pipeline handles per GPU, each on its own HIP stream and host thread, sharing the streams evenly")
@@ -134,8 +137,36 @@ def main():
     res_launches = 0
     q_iters = 0
     queries = 0
+    # double-buffered map epochs (off by default): epoch k+1 is broadcast and indexed in the background during epoch k
+    # and swapped in before the first step of epoch k+1
+    E = args.map_epoch_steps
+    map_nexts = [torch.empty_like(map_t), torch.empty_like(map_t)] if E > 0 else None   # ping-pong: a buffer is rewritten only
+    # after a registration against the index built from it has been observed complete
+    ev_map = torch.cuda.Event() if E > 0 else None
+    if E > 0:   # one untimed stage + swap so that the second set of index buffers exists before the timed region
+        for p in pipes:
+            p.stage_frozen_device(map_t.data_ptr(), n_corner, map_t.data_ptr() + 16 * n_corner, n_surf)
+        torch.cuda.synchronize()
+        for p in pipes:
+            p.swap_frozen()
+        sync_all()
+    n_epochs = 0
     t0 = time.perf_counter()
     for t in range(1 + W, T):
+        if E > 0:
+            k = (t - (1 + W)) % E
+            if k == 0:
+                for p in pipes:
+                    if p.swap_frozen():
+                        n_epochs += 1
+                map_next = map_nexts[((t - (1 + W)) // E) % 2]
+                if rank == 0:
+                    map_next.copy_(map_t, non_blocking=True)   # (the next epoch's map: same content, new buffer)
+                if dist is not None:
+                    dist.broadcast(map_next, src=0, async_op=True).wait()   # orders torch's stream behind RCCL's, not the host
+                ev_map.record()
+                for p in pipes:   # the index build waits for the event on the device; nothing blocks here
+                    p.stage_frozen_device(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, ev_map.cuda_event)
         run_step(t)
         for p in pipes:   # event read-back of the step that just finished (the step itself is synchronous)
             tm = p.timing()
@@ -188,6 +219,8 @@ def main():
                 "stage_ms_per_step": {"features": round(stage[0] / K, 4), "odometry": round(stage[1] / K, 4),
                                       "registration": round(stage[2] / K, 4), "gpu_step": round(stage[3] / K, 4)},
                 "map_broadcast_ms": round(t_bcast * 1e3, 3),
+                "map_epoch_steps": E,
+                "map_epochs_swapped": n_epochs,
                 "path_algorithmic_bytes_per_sweep": round(float(bytes_per_sweep), 1),
                 "path_hbm_frac": round(float(bytes_per_sweep * value / world / (HBM_PEAK_GBS * 1e9)), 6),
             },

@@ -210,6 +210,15 @@ int loamx_batch_set_frozen_device(loamx_batch* h, const void* d_corner_xyzi, uin
                                   uint32_t n_surf);
 /* sweep s uses corner_last[s], surf_last[s], full_res[s] (full_res may be NULL) and guess[s][6] =
  * initial transformTobeMapped */
+/* Double-buffered map epochs (BASELINE configs[4]): index the NEXT epoch's sub-map on a stream of its own
+ * while sweeps are still registered against the current one, then make it current at a batch boundary.  The device
+ * buffers are only read until the staged build has finished (hipDeviceSynchronize / the next swap), the index keeps a
+ * cell-sorted copy.  wait_event (may be NULL): a hipEvent_t recorded behind whatever fills the buffers (a copy, an RCCL
+ * broadcast) — the build is ordered behind it on the device, the host does not wait.  swap returns LOAMX_SKIPPED when nothing is staged. */
+int loamx_batch_stage_frozen_device(loamx_batch* h, const void* d_corner_xyzi, uint32_t n_corner, const void* d_surf_xyzi,
+                                    uint32_t n_surf, void* wait_event /* hipEvent_t of the buffers' producer, or NULL */);
+int loamx_batch_stage_frozen(loamx_batch* h, const loamx_cloud* corner_map, const loamx_cloud* surf_map);   /* host clouds */
+int loamx_batch_swap_frozen(loamx_batch* h);
 int loamx_batch_upload(loamx_batch* h, uint32_t n_sweeps, const loamx_cloud* corner_last, const loamx_cloud* surf_last,
                        const loamx_cloud* full_res, const float* guess6);
 int loamx_batch_run(loamx_batch* h);
@@ -241,6 +250,11 @@ void loamx_pipeline_destroy(loamx_pipeline* h);
 int loamx_pipeline_set_frozen(loamx_pipeline* h, const loamx_cloud* corner_map, const loamx_cloud* surf_map);
 int loamx_pipeline_set_frozen_device(loamx_pipeline* h, const void* d_corner_xyzi, uint32_t n_corner, const void* d_surf_xyzi,
                                      uint32_t n_surf);
+/* double-buffered map epochs, as loamx_batch_stage_frozen_device / loamx_batch_swap_frozen; swap between two steps */
+int loamx_pipeline_stage_frozen_device(loamx_pipeline* h, const void* d_corner_xyzi, uint32_t n_corner, const void* d_surf_xyzi,
+                                       uint32_t n_surf, void* wait_event);
+int loamx_pipeline_stage_frozen(loamx_pipeline* h, const loamx_cloud* corner_map, const loamx_cloud* surf_map);
+int loamx_pipeline_swap_frozen(loamx_pipeline* h);
 /* seed a stream's state; any pointer may be NULL (left unchanged) */
 int loamx_pipeline_set_state(loamx_pipeline* h, uint32_t stream, const float* transform, const float* transform_sum,
                              const float* bef_mapped, const float* aft_mapped);

@@ -61,6 +61,29 @@ int loamx_batch_set_frozen_device(loamx_batch* h, const void* d_corner, uint32_t
     return LOAMX_OK;
   });
 }
+int loamx_batch_stage_frozen_device(loamx_batch* h, const void* d_corner, uint32_t nc, const void* d_surf, uint32_t ns, void* wait_event) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    LX_REQUIRE((d_corner || nc == 0) && (d_surf || ns == 0), "NULL device pointer");
+    h->reg.stage_submap_device((const float4*)d_corner, nc, (const float4*)d_surf, ns, (hipEvent_t)wait_event);
+    return LOAMX_OK;
+  });
+}
+int loamx_batch_stage_frozen(loamx_batch* h, const loamx_cloud* corner_map, const loamx_cloud* surf_map) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    h->reg.stage_submap_host(corner_map, surf_map);
+    return LOAMX_OK;
+  });
+}
+int loamx_batch_swap_frozen(loamx_batch* h) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    if (!h->reg.submap_staged()) return (int)LOAMX_SKIPPED;
+    h->reg.swap_submap();
+    return (int)LOAMX_OK;
+  });
+}
 int loamx_batch_upload(loamx_batch* h, uint32_t n_sweeps, const loamx_cloud* corner_last, const loamx_cloud* surf_last,
                        const loamx_cloud* full_res, const float* guess6) {
   return guard([&]() {

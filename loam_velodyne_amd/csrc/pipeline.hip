@@ -392,6 +392,28 @@ int loamx_pipeline_set_frozen_device(loamx_pipeline* h, const void* d_corner, ui
     return LOAMX_OK;
   });
 }
+int loamx_pipeline_stage_frozen_device(loamx_pipeline* h, const void* d_corner, uint32_t nc, const void* d_surf, uint32_t ns, void* wait_event) {
+  return guard([&]() {
+    LX_REQUIRE(h && (d_corner || !nc) && (d_surf || !ns), "NULL argument");
+    h->p.reg.stage_submap_device((const float4*)d_corner, nc, (const float4*)d_surf, ns, (hipEvent_t)wait_event);
+    return LOAMX_OK;
+  });
+}
+int loamx_pipeline_stage_frozen(loamx_pipeline* h, const loamx_cloud* corner_map, const loamx_cloud* surf_map) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    h->p.reg.stage_submap_host(corner_map, surf_map);
+    return LOAMX_OK;
+  });
+}
+int loamx_pipeline_swap_frozen(loamx_pipeline* h) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    if (!h->p.reg.submap_staged()) return (int)LOAMX_SKIPPED;
+    h->p.reg.swap_submap();
+    return (int)LOAMX_OK;
+  });
+}
 int loamx_pipeline_set_state(loamx_pipeline* h, uint32_t stream, const float* transform, const float* transform_sum, const float* bef,
                              const float* aft) {
   return guard([&]() {

@@ -25,6 +25,9 @@ class SubMapIndex {
   void init(hipStream_t st);
   // (re)build over n device points (packed float4; .w ignored).  Asynchronous on the stream.
   void build(const float4* d_pts, uint32_t n);
+  // exchange contents with another index (buffers, sizes and the streams they are bound to stay with the contents' owner)
+  void swap(SubMapIndex& o);
+  void bind(hipStream_t st) { st_ = st; }
   uint32_t size() const { return n_; }
   const float4* sorted() const { return sorted_.p; }          // .w = original index (bit pattern)
   const uint32_t* cell_start() const { return cell_start_.p; }
@@ -82,6 +85,13 @@ class Registrar {
   ~Registrar();
   RegParams params;
   SubMapIndex corner_index, surf_index;
+  // Double-buffered sub-map (BASELINE configs[4]): the NEXT epoch's map is indexed on a stream of its own
+  // while sweeps are still registered against the current one; swap_submap() makes it current at a batch boundary.
+  // The caller's buffers are only read until the staged build has finished (the index keeps a cell-sorted copy).
+  void stage_submap_device(const float4* d_corner, uint32_t nc, const float4* d_surf, uint32_t ns, hipEvent_t wait_for = nullptr);
+  void stage_submap_host(const loamx_cloud* corner, const loamx_cloud* surf);
+  bool submap_staged() const { return next_staged_; }
+  void swap_submap();
   std::function<void()> on_first_wait;   // early_exit: called once, right before run_async() first blocks on the flags
   bool early_exit = false;    // run_async() may block on the done flags to skip the launches after convergence
   hipStream_t stream() const { return st_; }
@@ -156,6 +166,12 @@ class Registrar {
   const float4* const* d_src_ = nullptr;
   DevBuf<char> blob_;
   PinBuf<char> h_blob_;
+  SubMapIndex corner_next_, surf_next_;
+  DevBuf<float4> next_corner_, next_surf_;
+  PinBuf<float4> h_next_corner_, h_next_surf_;
+  hipStream_t st_build_ = nullptr;
+  hipEvent_t ev_build_ = nullptr, ev_swap_ = nullptr;
+  bool next_staged_ = false, swapped_once_ = false;
   DevBuf<uint32_t> arrive_;   // per sweep: k_residual workgroups that have delivered their partial sums
   DevBuf<float4> qstate_;     // per query: position at its last full search + squared re-validation bound
   uint32_t nblk_ = 0;

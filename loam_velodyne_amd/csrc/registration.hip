@@ -150,6 +150,13 @@ void SubMapIndex::init(hipStream_t st) {
   tile_sums_.reserve(8192);
 }
 
+void SubMapIndex::swap(SubMapIndex& o) {
+  std::swap(n_, o.n_);
+  auto sw = [](auto& a, auto& b) { std::swap(a.p, b.p); std::swap(a.cap, b.cap); };
+  sw(sorted_, o.sorted_); sw(cell_of_, o.cell_of_); sw(cell_start_, o.cell_start_); sw(cursor_, o.cursor_);
+  sw(tile_sums_, o.tile_sums_); sw(scratch_, o.scratch_); sw(d_desc_, o.d_desc_);
+}
+
 void SubMapIndex::build(const float4* d_pts, uint32_t n) {
   n_ = n;
   if (n == 0) return;
@@ -1037,6 +1044,9 @@ Registrar::Registrar(int device, uint32_t max_sweeps) : device_(device), max_swe
 
 Registrar::~Registrar() {
   for (auto& e : ev_) (void)hipEventDestroy(e);
+  if (ev_build_) (void)hipEventDestroy(ev_build_);
+  if (ev_swap_) (void)hipEventDestroy(ev_swap_);
+  if (st_build_) { (void)hipStreamSynchronize(st_build_); (void)hipStreamDestroy(st_build_); }
   if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -1063,6 +1073,58 @@ void Registrar::set_submap_device(const float4* d_corner, uint32_t nc, const flo
   corner_index.build(d_corner, nc);
   surf_index.build(d_surf, ns);
   if (sync) LX_HIP(hipStreamSynchronize(st_));
+}
+
+void Registrar::stage_submap_device(const float4* d_corner, uint32_t nc, const float4* d_surf, uint32_t ns, hipEvent_t wait_for) {
+  LX_HIP(hipSetDevice(device_));
+  if (!st_build_) {
+    st_build_ = create_stream(0);   // (a lowest-priority stream is starved for milliseconds by the two latency-critical ones)
+    LX_HIP(hipEventCreateWithFlags(&ev_build_, hipEventDisableTiming));
+    LX_HIP(hipEventCreateWithFlags(&ev_swap_, hipEventDisableTiming));
+    corner_next_.init(st_build_);
+    surf_next_.init(st_build_);
+  }
+  // the buffers being rebuilt held the previous epoch's index until the last swap: registrations enqueued before that swap
+  // may still read them
+  if (swapped_once_) LX_HIP(hipStreamWaitEvent(st_build_, ev_swap_, 0));
+  if (wait_for) LX_HIP(hipStreamWaitEvent(st_build_, wait_for, 0));   // the producer of the caller's buffers (a copy, an RCCL broadcast)
+  corner_next_.bind(st_build_);
+  surf_next_.bind(st_build_);
+  corner_next_.build(d_corner, nc);
+  surf_next_.build(d_surf, ns);
+  LX_HIP(hipEventRecord(ev_build_, st_build_));
+  next_staged_ = true;
+}
+
+void Registrar::stage_submap_host(const loamx_cloud* corner, const loamx_cloud* surf) {
+  check_cloud(corner, false);
+  check_cloud(surf, false);
+  LX_HIP(hipSetDevice(device_));
+  if (st_build_) LX_HIP(hipStreamSynchronize(st_build_));   // the pinned staging buffers of an earlier staging are free again
+  h_next_corner_.reserve(corner->count + 1);
+  h_next_surf_.reserve(surf->count + 1);
+  pack_cloud(corner, h_next_corner_.p);
+  pack_cloud(surf, h_next_surf_.p);
+  next_corner_.reserve(corner->count + 1);
+  next_surf_.reserve(surf->count + 1);
+  if (!st_build_) stage_submap_device(nullptr, 0, nullptr, 0);   // creates the build stream and events
+  LX_HIP(hipMemcpyAsync(next_corner_.p, h_next_corner_.p, sizeof(float4) * corner->count, hipMemcpyHostToDevice, st_build_));
+  LX_HIP(hipMemcpyAsync(next_surf_.p, h_next_surf_.p, sizeof(float4) * surf->count, hipMemcpyHostToDevice, st_build_));
+  stage_submap_device(next_corner_.p, corner->count, next_surf_.p, surf->count);
+}
+
+void Registrar::swap_submap() {
+  LX_REQUIRE(next_staged_, "swap_submap() without a staged sub-map");
+  LX_HIP(hipSetDevice(device_));
+  LX_HIP(hipStreamWaitEvent(st_, ev_build_, 0));   // registrations enqueued from now on see the finished index
+  LX_HIP(hipEventRecord(ev_swap_, st_));           // ... and everything enqueued so far still used the old one
+  corner_index.swap(corner_next_);
+  surf_index.swap(surf_next_);
+  corner_index.bind(st_);
+  surf_index.bind(st_);
+  next_staged_ = false;
+  swapped_once_ = true;
+  host_results_valid_ = false;
 }
 
 void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const loamx_cloud* surf_last, const loamx_cloud* full_res,

@@ -131,6 +131,19 @@ class Batch:
     def set_frozen_device(self, d_corner_ptr: int, n_corner: int, d_surf_ptr: int, n_surf: int):
         _check(lib().loamx_batch_set_frozen_device(self.h, C.c_void_p(d_corner_ptr), n_corner, C.c_void_p(d_surf_ptr), n_surf))
 
+    def stage_frozen_device(self, d_corner_ptr: int, n_corner: int, d_surf_ptr: int, n_surf: int, wait_event: int = 0):
+        """index the NEXT epoch's sub-map in the background (double-buffered map epochs); wait_event = raw hipEvent_t"""
+        _check(lib().loamx_batch_stage_frozen_device(self.h, C.c_void_p(d_corner_ptr), n_corner, C.c_void_p(d_surf_ptr), n_surf,
+                                                     C.c_void_p(wait_event or None)))
+
+    def stage_frozen(self, corner_map, surf_map):
+        cm, sm = as_points(corner_map), as_points(surf_map)
+        cc, sc = cloud_of(cm), cloud_of(sm)
+        _check(lib().loamx_batch_stage_frozen(self.h, C.byref(cc), C.byref(sc)))
+
+    def swap_frozen(self) -> bool:
+        return _check(lib().loamx_batch_swap_frozen(self.h)) == OK
+
     def upload(self, corner_last, surf_last, guesses, full_res=None):
         n = len(corner_last)
         assert len(surf_last) == n and len(guesses) == n
@@ -453,6 +466,19 @@ class Pipeline:
 
     def set_frozen_device(self, d_corner_ptr, n_corner, d_surf_ptr, n_surf):
         _check(lib().loamx_pipeline_set_frozen_device(self.h, C.c_void_p(d_corner_ptr), n_corner, C.c_void_p(d_surf_ptr), n_surf))
+
+    def stage_frozen_device(self, d_corner_ptr, n_corner, d_surf_ptr, n_surf, wait_event: int = 0):
+        """index the NEXT epoch's sub-map in the background (double-buffered map epochs); wait_event = raw hipEvent_t"""
+        _check(lib().loamx_pipeline_stage_frozen_device(self.h, C.c_void_p(d_corner_ptr), n_corner, C.c_void_p(d_surf_ptr), n_surf,
+                                                        C.c_void_p(wait_event or None)))
+
+    def stage_frozen(self, corner_map, surf_map):
+        cm, sm = as_points(corner_map), as_points(surf_map)
+        cc, sc = cloud_of(cm), cloud_of(sm)
+        _check(lib().loamx_pipeline_stage_frozen(self.h, C.byref(cc), C.byref(sc)))
+
+    def swap_frozen(self) -> bool:
+        return _check(lib().loamx_pipeline_swap_frozen(self.h)) == OK
 
     def set_state(self, stream, transform=None, transform_sum=None, bef=None, aft=None):
         def p(a):

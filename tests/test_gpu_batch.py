@@ -149,3 +149,42 @@ def test_invalid_arguments():
         b.upload([z] * 3, [z] * 3, np.zeros((3, 6), np.float32))
     with pytest.raises(loamx.LoamxError):            # run before upload
         loamx.Batch(1).run()
+
+
+def test_double_buffered_map_epochs(orc):
+    """BASELINE configs[4]: the next epoch's sub-map is indexed in the background while sweeps are registered against the
+    current one; after the swap the results are exactly those of a handle that was given the new map outright — and the
+    registrations that ran in between still saw the OLD map."""
+    world_a, world_b = synth.World(half_extent=65.0), synth.World(half_extent=65.0, seed=5)
+    cm_a, sm_a = world_a.make_map(100000)
+    cm_b, sm_b = world_b.make_map(120000)
+    cl, sl, guesses, _ = _inputs(orc, world_a, "VLP-16", 4)
+
+    def fresh(cm, sm):
+        b = loamx.Batch(4)
+        b.set_frozen(cm, sm)
+        b.upload(cl, sl, guesses)
+        assert b.run() == loamx.OK
+        return b.download()
+    ref_a, ref_b = fresh(cm_a, sm_a), fresh(cm_b, sm_b)
+    assert not np.array_equal(ref_a[0], ref_b[0])
+    b = loamx.Batch(4)
+    b.set_frozen(cm_a, sm_a)
+    assert b.swap_frozen() is False                                  # nothing staged yet
+    b.stage_frozen(cm_b, sm_b)
+    b.upload(cl, sl, guesses)
+    assert b.run() == loamx.OK                                       # still epoch A
+    pa, sa = b.download()
+    assert np.array_equal(pa, ref_a[0]) and np.array_equal(sa, ref_a[1])
+    assert b.swap_frozen() is True
+    b.upload(cl, sl, guesses)
+    assert b.run() == loamx.OK                                       # epoch B
+    pb, sb = b.download()
+    assert np.array_equal(pb, ref_b[0]) and np.array_equal(sb, ref_b[1])
+    # and back again: the buffers of epoch A are recycled for the next staging
+    b.stage_frozen(cm_a, sm_a)
+    assert b.swap_frozen() is True
+    b.upload(cl, sl, guesses)
+    assert b.run() == loamx.OK
+    pa2, sa2 = b.download()
+    assert np.array_equal(pa2, ref_a[0]) and np.array_equal(sa2, ref_a[1])

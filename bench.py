@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--map-epoch-steps", type=int, default=0,
                     help="E > 0: a new map epoch every E steps inside the timed region — rank 0's map is re-broadcast (RCCL, async), "
                          "indexed in the background and swapped in at the epoch boundary (BASELINE configs[4] double buffering)")
+    ap.add_argument("--sensor", default=SENSOR, choices=["HDL-32", "HDL-64E", "VLP-16"], help="parity / side configurations (BASELINE configs[1], [2])")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU)
     ap.add_argument("--handles", type=int, default=HANDLES_PER_GPU,
                     help="pipeline handles per GPU, each on its own HIP stream and host thread, sharing the streams evenly")
@@ -95,7 +96,7 @@ def main():
         poses = synth.trajectory(T, start=start)
         starts.append(np.array([0, 0, 0, start[0], start[1], start[2]], np.float32))
         for t in range(T):
-            sw = synth.make_sweep(world_model, SENSOR, poses[t], poses[t + 1], seed=1000 * gs + t)
+            sw = synth.make_sweep(world_model, args.sensor, poses[t], poses[t + 1], seed=1000 * gs + t)
             sweeps[t][s] = (sw.points, sw.ring_sizes)
     n_points = len(sweeps[0][0][0])
 
@@ -189,7 +190,7 @@ def main():
         iters_odom = np.mean([st["odom_iterations"] for st in stats])
         q_per_sweep = queries / max(ns * K, 1)
         # BASELINE.md / SURVEY.md §8d algorithmic bytes per registered sweep (S = streams sharing the frozen map epoch)
-        k_feat = 768 + 1536
+        k_feat = 36 * synth.SENSORS[args.sensor][0]   # (2 sharp + 4 flat) x 6 regions per ring
         bytes_per_sweep = 32 * n_points + 16 * M / (ns * K) + 72 * (q_iters / max(ns * K, 1)) + 48 * iters_odom * k_feat
         avg_launch_ms = res_ms / max(res_launches, 1)
         achieved = (72.0 * q_iters / max(res_launches, 1)) / (avg_launch_ms * 1e-3) / 1e9 if res_launches else 0.0
@@ -207,7 +208,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{SENSOR} 64x2048 sweeps ({n_points} pts), {M}-pt frozen sub-map, {ns} streams/GPU "
+                "workload": f"{args.sensor} {synth.SENSORS[args.sensor][0]}x{synth.SENSORS[args.sensor][1]} sweeps ({n_points} pts), {M}-pt frozen sub-map, {ns} streams/GPU "
                             "(BASELINE configs[3]: batch 32 over 4 GPUs), full path per sweep",
                 "streams_per_gpu": ns,
                 "handles_per_gpu": H,
@@ -304,7 +305,7 @@ def cpu_baseline(sweeps, starts, map_t):
         "unit": "sweeps/s",
         "cores": 1,
         "kind": "port",
-        "sample": "stream 0, 2 registered HDL-64E sweeps (after 1 initialising sweep) vs the same 1M-pt map; kd-tree build excluded",
+        "sample": "stream 0, 2 registered sweeps of the benchmarked sensor (after 1 initialising sweep) vs the same frozen map; kd-tree build excluded",
         "seconds_per_sweep": round(sec, 4),
         "stage_seconds": {"features": round(stage[0] / 2, 4), "odometry": round(stage[1] / 2, 4), "registration": round(stage[2] / 2, 4)},
         "kdtree_build_seconds": round(t_build, 4),

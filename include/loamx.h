@@ -164,6 +164,11 @@ int loamx_map_process(loamx_map* h, const loamx_cloud* corner_last, const loamx_
 /* which: 0 transformAftMapped, 1 transformBefMapped, 2 transformTobeMapped, 3 transformSum */
 int loamx_map_get_transform(loamx_map* h, int which, float transform[6]);
 int loamx_map_set_transform(loamx_map* h, int which, const float transform[6]);
+/* updateIMU(IMUState2) (BasicLaserMapping.cpp:602-605, .h:47-75) and the laserOdometryTime argument of process()
+ * (:266): with a non-empty IMU history transformUpdate blends 0.2 % of the interpolated IMU roll / pitch into the pose
+ * (:173-200).  Times in seconds on a common clock. */
+int loamx_map_update_imu(loamx_map* h, double stamp_sec, float roll, float pitch);
+int loamx_map_set_time(loamx_map* h, double laser_odometry_time_sec);
 int loamx_map_has_fresh_map(loamx_map* h);
 /* laserCloudSurroundDS() */
 int loamx_map_get_surround(loamx_map* h, loamx_cloud* out);

@@ -264,6 +264,14 @@ class BasicLaserMapping {
     _cfg.max_iterations = (int)maxIterations;
   }
   ~BasicLaserMapping() { loamx_map_destroy(_h); }
+  // updateIMU(IMUState2) (:602-605): stamp in seconds on the clock of the process() times
+  void updateIMU(double stampSec, float roll, float pitch) { ensure(); detail::check(loamx_map_update_imu(_h, stampSec, roll, pitch)); }
+  // process(laserOdometryTime) with the time as seconds (needed by the IMU blend of transformUpdate only)
+  bool processAt(double laserOdometryTimeSec) {
+    ensure();
+    detail::check(loamx_map_set_time(_h, laserOdometryTimeSec));
+    return process(0);
+  }
   template <class TimeT> bool process(TimeT const&) {   // BasicLaserMapping.cpp:266-599
     ensure();
     loamx_cloud a = detail::in_cloud(_laserCloudCornerLast), b = detail::in_cloud(_laserCloudSurfLast), f = detail::in_cloud(_laserCloudFullRes);

@@ -11,6 +11,7 @@
 //   k_map_append / k_map_hist                   next map = rest ++ filtered; per-cube counts for the host directory
 // Host: closed-form pose prediction (:103-167), cube window + field-of-view selection (:300-500), transformUpdate.
 #include "registration.cuh"
+#include <deque>
 #include "host_math.h"
 #include "scan.cuh"
 
@@ -218,6 +219,30 @@ class Mapper {
   bool fresh_map = false;
   SweepStats last_stats = {0, 0, 0, 0, 0, 0, 0, 0};
   bool last_optimized = false;
+  // IMUState2 history (BasicLaserMapping.h:47-75, capacity 200 :56), stamps / laserOdometryTime in seconds
+  struct ImuState2 { double stamp; float roll, pitch; };
+  std::deque<ImuState2> imu_history;
+  double laser_odometry_time = 0.0;
+  void update_imu(double stamp, float roll, float pitch) {   // updateIMU :602-605
+    if (imu_history.size() >= 200) imu_history.pop_front();
+    imu_history.push_back({stamp, roll, pitch});
+  }
+  // the IMU part of transformUpdate (:173-200) applied to (rot_x, rot_z) of a pose
+  void imu_blend_pose(float* p6) const {
+    size_t i = 0;
+    while (i < imu_history.size() - 1 && (laser_odometry_time - imu_history[i].stamp) + cfg.scan_period > 0) i++;
+    float roll, pitch;
+    if (i == 0 || (laser_odometry_time - imu_history[i].stamp) + cfg.scan_period > 0) {
+      roll = imu_history[i].roll; pitch = imu_history[i].pitch;
+    } else {
+      const float ratio = (float)(((imu_history[i].stamp - laser_odometry_time) - cfg.scan_period) / (imu_history[i].stamp - imu_history[i - 1].stamp));
+      const float inv = 1 - ratio;
+      roll = imu_history[i].roll * inv + imu_history[i - 1].roll * ratio;
+      pitch = imu_history[i].pitch * inv + imu_history[i - 1].pitch * ratio;
+    }
+    p6[0] = (float)(0.998 * p6[0] + 0.002 * pitch);
+    p6[2] = (float)(0.998 * p6[2] + 0.002 * roll);
+  }
   uint32_t last_sub[2] = {0, 0};
   TypeMap tm[2];
   DevBuf<short> slot_lut;
@@ -390,8 +415,18 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   tobe.get(g6);
   reg.upload(1, corner_last, surf_last, full_res, g6);
   reg.early_exit = true;   // process() is blocking
+  const bool imu_blend = !imu_history.empty();
+  reg.defer_full = imu_blend;
   reg.run_async();
   last_optimized = reg.submap_sufficient();
+  if (imu_blend) {
+    // transformUpdate with IMU data (:171-200) changes transformTobeMapped before the new features are inserted into the map
+    // and before the full-resolution cloud is registered: blend on the host, hand the pose back to the device
+    float p6[6];
+    reg.download(p6, nullptr);
+    if (last_optimized) imu_blend_pose(p6);
+    reg.finish_with_poses(p6);
+  }
 
   // ---- map insertion + per-cube re-filtering
   for (int t = 0; t < 2; t++) {
@@ -445,7 +480,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   last_stats = ss;
   int rc = LOAMX_OK;
   if (last_optimized) {
-    // transformUpdate (:171-203, IMU-less): only reached when the optimisation ran (:628-629)
+    // transformUpdate (:171-203; the IMU blend, if any, is already in pose6): only reached when the optimisation ran (:628-629)
     tobe.set(pose6);
     bef = sum;
     aft = tobe;
@@ -602,6 +637,20 @@ int loamx_map_set_transform(loamx_map* h, int which, const float t[6]) {
     LX_REQUIRE(h && t && which >= 0 && which < 4, "invalid argument");
     HTwist* tw[4] = {&h->m.aft, &h->m.bef, &h->m.tobe, &h->m.sum};
     tw[which]->set(t);
+    return LOAMX_OK;
+  });
+}
+int loamx_map_update_imu(loamx_map* h, double stamp_sec, float roll, float pitch) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    h->m.update_imu(stamp_sec, roll, pitch);
+    return LOAMX_OK;
+  });
+}
+int loamx_map_set_time(loamx_map* h, double laser_odometry_time_sec) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    h->m.laser_odometry_time = laser_odometry_time_sec;
     return LOAMX_OK;
   });
 }

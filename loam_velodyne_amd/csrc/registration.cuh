@@ -92,6 +92,8 @@ class Registrar {
   void stage_submap_host(const loamx_cloud* corner, const loamx_cloud* surf);
   bool submap_staged() const { return next_staged_; }
   void swap_submap();
+  bool defer_full = false;    // run_async() leaves the full-resolution clouds unregistered; finish_with_poses() does it
+  void finish_with_poses(const float* poses6);
   std::function<void()> on_first_wait;   // early_exit: called once, right before run_async() first blocks on the flags
   bool early_exit = false;    // run_async() may block on the done flags to skip the launches after convergence
   hipStream_t stream() const { return st_; }

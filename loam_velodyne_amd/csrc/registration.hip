@@ -393,6 +393,16 @@ __global__ void k_pose_init(const float* __restrict__ guess, uint32_t ns, Pose* 
   stats[s] = z;
 }
 
+// overwrite the poses with host-supplied ones (the IMU blend of transformUpdate happens on the host)
+__global__ void k_pose_set(const float* __restrict__ p6, uint32_t ns, Pose* __restrict__ poses) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  Pose T;
+  pose_set_angles(T, p6[6 * s], p6[6 * s + 1], p6[6 * s + 2]);
+  T.tx = p6[6 * s + 3]; T.ty = p6[6 * s + 4]; T.tz = p6[6 * s + 5];
+  poses[s] = T;
+}
+
 __device__ inline void knn_insert(float (&bd)[5], uint32_t (&bi)[5], uint32_t (&bp)[5], float d2, uint32_t id, uint32_t pos) {
   if (!(d2 < bd[4] || (d2 == bd[4] && id < bi[4]))) return;
   bd[4] = d2; bi[4] = id; bp[4] = pos;
@@ -1327,7 +1337,7 @@ void Registrar::run_async() {
       chunk = 1;
     }
   }
-  if (n_full_)
+  if (n_full_ && !defer_full)
     hipLaunchKernelGGL(k_transform_full, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, n_full_, d_full_off_, ns, poses_.p);
   if (timing_) { LX_HIP(hipEventRecord(ev_[1], st_)); timed_run_ = true; }
   LX_HIP(hipGetLastError());
@@ -1343,6 +1353,21 @@ void Registrar::run_async() {
   if (trace)
     fprintf(stderr, "[reg] voxel stage enqueued %.0f us, first iterations enqueued %.0f, callback done %.0f, run_async returns %.0f\n", th1 - th0,
             th2 - th0, th3 - th0, host_us() - th0);
+}
+
+// replace the device poses (6 floats per sweep) and register the full-resolution clouds with them — the tail of a
+// run_async() that ran with defer_full
+void Registrar::finish_with_poses(const float* poses6) {
+  const uint32_t ns = n_sweeps_;
+  h_guess_.reserve((size_t)6 * ns + 8);
+  memcpy(h_guess_.p, poses6, sizeof(float) * 6 * ns);
+  guess_.reserve((size_t)6 * ns + 8);
+  LX_HIP(hipMemcpyAsync(guess_.p, h_guess_.p, sizeof(float) * 6 * ns, hipMemcpyHostToDevice, st_));
+  hipLaunchKernelGGL(k_pose_set, dim3((ns + 63) / 64), dim3(64), 0, st_, guess_.p, ns, poses_.p);
+  if (n_full_)
+    hipLaunchKernelGGL(k_transform_full, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, n_full_, d_full_off_, ns, poses_.p);
+  host_results_valid_ = false;
+  LX_HIP(hipGetLastError());
 }
 
 void Registrar::sync() { LX_HIP(hipStreamSynchronize(st_)); }

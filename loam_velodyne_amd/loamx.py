@@ -383,6 +383,14 @@ class LaserMapping:
         t = np.ascontiguousarray(t6, np.float32)
         _check(lib().loamx_map_update_odometry(self.h, t.ctypes.data_as(C.c_void_p)))
 
+    def update_imu(self, stamp, roll, pitch):
+        """updateIMU(IMUState2); stamp in seconds"""
+        _check(lib().loamx_map_update_imu(self.h, C.c_double(stamp), C.c_float(roll), C.c_float(pitch)))
+
+    def set_time(self, t):
+        """the laserOdometryTime argument of process()"""
+        _check(lib().loamx_map_set_time(self.h, C.c_double(t)))
+
     def process(self, corner_last, surf_last, full_res=None):
         c, s = as_points(corner_last), as_points(surf_last)
         cc, sc = cloud_of(c), cloud_of(s)

@@ -168,6 +168,8 @@ void orc_map_set_cloud(void* h, int which, const float* pts, int n) {
 }
 void orc_map_update_odometry(void* h, const float* t6) { ((LaserMapping*)h)->update_odometry(t6); }
 int orc_map_process(void* h) { return ((LaserMapping*)h)->process() ? 1 : 0; }
+void orc_map_update_imu(void* h, double stamp, float roll, float pitch) { ((LaserMapping*)h)->update_imu(stamp, roll, pitch); }
+void orc_map_set_time(void* h, double t) { ((LaserMapping*)h)->laserOdometryTime = t; }
 // which: 0 aft, 1 bef, 2 tobe, 3 sum
 void orc_map_get_transform(void* h, int which, float* t6) {
   auto* m = (LaserMapping*)h;

@@ -13,6 +13,7 @@
 // (stack round trip, voxel down-sampling, optimize) against a caller-provided sub-map, which is the unit the batched
 // multi-GPU mode shards.
 #pragma once
+#include <deque>
 #include "oracle_odometry.hpp"
 
 namespace loam_oracle {
@@ -103,7 +104,38 @@ class LaserMapping {
     transformTobeMapped.pos = transformAftMapped.pos - v;
   }
 
-  void transform_update() {
+  // IMUState2 (BasicLaserMapping.h:47-75) history; stamps and laserOdometryTime in seconds (the reference's Time /
+  // toSec arithmetic is double seconds, time_utils.h)
+  struct ImuState2 {
+    double stamp = 0;
+    Angle roll, pitch;
+  };
+  std::deque<ImuState2> imuHistory;   // CircularBuffer<IMUState2>, capacity 200 (BasicLaserMapping.cpp:56)
+  size_t imuCapacity = 200;
+  double laserOdometryTime = 0;
+  void update_imu(double stamp, float roll, float pitch) {   // :602-605 (+ CircularBuffer::push, CircularBuffer.h:111-119)
+    if (imuHistory.size() >= imuCapacity) imuHistory.pop_front();
+    ImuState2 st;
+    st.stamp = stamp; st.roll = Angle(roll); st.pitch = Angle(pitch);
+    imuHistory.push_back(st);
+  }
+
+  void transform_update() {   // :171-203
+    if (0 < imuHistory.size()) {
+      size_t imuIdx = 0;
+      while (imuIdx < imuHistory.size() - 1 && (laserOdometryTime - imuHistory[imuIdx].stamp) + scanPeriod > 0) imuIdx++;
+      ImuState2 imuCur;
+      if (imuIdx == 0 || (laserOdometryTime - imuHistory[imuIdx].stamp) + scanPeriod > 0) {
+        imuCur = imuHistory[imuIdx];   // scan time newer than the newest or older than the oldest IMU message
+      } else {
+        float ratio = ((imuHistory[imuIdx].stamp - laserOdometryTime) - scanPeriod) / (imuHistory[imuIdx].stamp - imuHistory[imuIdx - 1].stamp);
+        float invRatio = 1 - ratio;   // IMUState2::interpolate(hist[idx], hist[idx-1], ratio, imuCur), .h:65-74
+        imuCur.roll = Angle(imuHistory[imuIdx].roll.rad() * invRatio + imuHistory[imuIdx - 1].roll.rad() * ratio);
+        imuCur.pitch = Angle(imuHistory[imuIdx].pitch.rad() * invRatio + imuHistory[imuIdx - 1].pitch.rad() * ratio);
+      }
+      transformTobeMapped.rot_x = Angle((float)(0.998 * transformTobeMapped.rot_x.rad() + 0.002 * imuCur.pitch.rad()));
+      transformTobeMapped.rot_z = Angle((float)(0.998 * transformTobeMapped.rot_z.rad() + 0.002 * imuCur.roll.rad()));
+    }
     transformBefMapped = transformSum;
     transformAftMapped = transformTobeMapped;
   }

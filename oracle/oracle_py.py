@@ -242,6 +242,14 @@ class LaserMapping:
         t = _f32(transform_sum)
         self.o.L.orc_map_update_odometry(self.h, t.ctypes.data_as(C.c_void_p))
 
+    def update_imu(self, stamp, roll, pitch):
+        """updateIMU(IMUState2): stamp in seconds"""
+        self.o.L.orc_map_update_imu(self.h, C.c_double(stamp), C.c_float(roll), C.c_float(pitch))
+
+    def set_time(self, t):
+        """the laserOdometryTime argument of process()"""
+        self.o.L.orc_map_set_time(self.h, C.c_double(t))
+
     def process(self):
         return bool(self.o.L.orc_map_process(self.h))
 

@@ -126,3 +126,55 @@ def test_first_frames_and_window_shift(orc):
             assert np.abs(omp.transform("tobe") - g.transform("tobe")).max() < POSE_TOL
             assert len(omp.cloud("corner_cubes")) == len(g.cubes("corner"))
             assert len(omp.cloud("surf_cubes")) == len(g.cubes("surf"))
+
+
+def test_imu_blend_in_transform_update(orc, small_world):
+    """updateIMU(IMUState2) + laserOdometryTime (mapping side): with an IMU history transformUpdate
+    blends 0.2 % of the interpolated IMU roll / pitch into transformTobeMapped BEFORE the new features are inserted and the
+    full-resolution cloud is registered (BasicLaserMapping.cpp:171-203).  Per step from an identical prior state."""
+    n = 5
+    poses = synth.trajectory(n)
+    osr, ood, omp = op.ScanRegistration(orc), op.LaserOdometry(orc), op.LaserMapping(orc)
+    rng = np.random.default_rng(3)
+    imu = [(0.1 * k + 0.0137 * j, 0.02 * np.sin(0.3 * k + j), 0.03 * np.cos(0.2 * k - j)) for k in range(n + 1) for j in range(7)]
+    fed = 0
+    for k in range(n):
+        sw = synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=k, az_steps=900)
+        ood.set_features(osr.process(sw.points, sw.ring_sizes))
+        ood.process()
+        full_end, lc, ls, ts = ood.full_to_end(), ood.last_corner(), ood.last_surf(), ood.transform_sum
+        g = loamx.LaserMapping()
+        pre_c, pre_s, pre_aft, pre_bef = omp.cloud("corner_cubes"), omp.cloud("surf_cubes"), omp.transform("aft"), omp.transform("bef")
+        g.load_cubes(pre_c, pre_s)
+        g.set_transform("aft", pre_aft)
+        g.set_transform("bef", pre_bef)
+        g.update_odometry(ts)
+        t_odo = 0.1 * k + 0.033            # between IMU samples: exercises the interpolation branch
+        new = [m for m in imu if m[0] <= t_odo + 0.15]
+        for m in new[fed:]:
+            omp.update_imu(*m)
+        for m in new:                      # the fresh GPU handle gets the whole history so far
+            g.update_imu(*m)
+        fed = len(new)
+        omp.set_time(t_odo)
+        g.set_time(t_odo)
+        omp.set_inputs(lc, ls, full_end, ts)
+        assert omp.process()
+        rc, gfull = g.process(lc, ls, full_end)
+        assert rc == loamx.OK
+        for which in ("aft", "bef", "tobe"):
+            assert np.abs(omp.transform(which) - g.transform(which)).max() < POSE_TOL, (k, which)
+        assert np.abs(omp.cloud("full_res") - gfull).max() < 1e-3
+        # the blend really happened: the same step from the same state without IMU data ends 0.2 % of the way elsewhere
+        g2 = loamx.LaserMapping()
+        g2.load_cubes(pre_c, pre_s)
+        g2.set_transform("aft", pre_aft)
+        g2.set_transform("bef", pre_bef)
+        g2.update_odometry(ts)
+        g2.process(lc, ls, full_end)
+        plain, blended = g2.transform("tobe"), g.transform("tobe")
+        if g.stats()["optimized"]:
+            pitch_i = (blended[0] - 0.998 * plain[0]) / 0.002      # the IMU pitch the blend must have used
+            roll_i = (blended[2] - 0.998 * plain[2]) / 0.002
+            assert abs(pitch_i) < 0.035 and abs(roll_i) < 0.035 and abs(blended[0] - plain[0]) > 1e-7
+            assert np.abs(blended[[1, 3, 4, 5]] - plain[[1, 3, 4, 5]]).max() < 1e-6

@@ -106,6 +106,16 @@ int loamx_scanreg_process_raw(loamx_scanreg* h, const loamx_multiscan_mapper* ma
                               uint32_t stride, loamx_cloud* full, uint32_t* ring_size, loamx_cloud* sharp, loamx_cloud* less_sharp,
                               loamx_cloud* flat, loamx_cloud* less_flat);
 
+/* IMU data for the scan registration: updateIMUData (BasicScanRegistration.cpp:82-98) feeds the
+ * handle's IMU history (capacity 200, RegistrationParams::imuHistorySize); loamx_scanreg_set_time gives the scanTime of the
+ * next process call (times in seconds on one clock); with a non-empty history loamx_scanreg_process_raw de-skews every
+ * kept point (projectPointToStartOfSweep :101-147) and loamx_scanreg_get_imu_trans returns imuTransform() (:258-281):
+ * start angles, current angles, position shift, velocity change — what loamx_odom_update_imu consumes.
+ * acc_xyz: local acceleration with gravity removed and axes remapped as ScanRegistration.cpp:171-174 does. */
+int loamx_scanreg_update_imu(loamx_scanreg* h, double stamp_sec, float roll, float pitch, float yaw, const float acc_xyz[3]);
+int loamx_scanreg_set_time(loamx_scanreg* h, double scan_time_sec);
+int loamx_scanreg_get_imu_trans(loamx_scanreg* h, float imu_trans[12]);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Sweep-to-sweep odometry  (BasicLaserOdometry)
  * ---------------------------------------------------------------------------------------------------------- */

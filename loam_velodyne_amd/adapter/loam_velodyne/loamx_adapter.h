@@ -170,7 +170,24 @@ class BasicScanRegistration {
     _surfacePointsFlat.points.resize(o[2].count); _surfacePointsLessFlat.points.resize(o[3].count);
   }
   auto const& ringSizes() { return _ringSizes; }      // points per scan ring of the last raw sweep
-  auto const& imuTransform() { return _imuTrans; }   // IMU-less: zeros
+  // updateIMUData(acc, newState) — BasicScanRegistration.cpp:82-98 — with the state spelled out: stamp in seconds on the
+  // clock of the scan times, roll / pitch / yaw, local acceleration (gravity removed, axes remapped: ScanRegistration.cpp:171-174)
+  void updateIMUData(double stampSec, float roll, float pitch, float yaw, float accX, float accY, float accZ) {
+    if (!_h && !configure(_config)) throw std::runtime_error(std::string("loamx: ") + loamx_last_error());
+    const float acc[3] = {accX, accY, accZ};
+    detail::check(loamx_scanreg_update_imu(_h, stampSec, roll, pitch, yaw, acc));
+  }
+  // the scanTime of the next processScanlines / processRawSweep call, in seconds (only the IMU path looks at it)
+  void setScanTime(double scanTimeSec) {
+    if (!_h && !configure(_config)) throw std::runtime_error(std::string("loamx: ") + loamx_last_error());
+    detail::check(loamx_scanreg_set_time(_h, scanTimeSec));
+  }
+  auto const& imuTransform() {   // updateIMUTransform (:258-281); zeros without IMU data
+    float t[12] = {0};
+    if (_h) detail::check(loamx_scanreg_get_imu_trans(_h, t));
+    for (int k = 0; k < 4; k++) { _imuTrans[k].x = t[3 * k]; _imuTrans[k].y = t[3 * k + 1]; _imuTrans[k].z = t[3 * k + 2]; }
+    return _imuTrans;
+  }
   auto const& laserCloud() { return _laserCloud; }
   auto const& cornerPointsSharp() { return _cornerPointsSharp; }
   auto const& cornerPointsLessSharp() { return _cornerPointsLessSharp; }

@@ -58,6 +58,7 @@ int loamx_scanreg_process(loamx_scanreg* h, const loamx_cloud* cloud, const uint
   return guard([&]() {
     LX_REQUIRE(h && cloud && ring_size && n_rings > 0, "NULL / empty argument");
     const uint32_t* rs[1] = {ring_size};
+    h->fx.begin_sweep();   // reset(scanTime) / updateIMUTransform() of processScanlines (identities without IMU data)
     h->fx.upload(1, cloud, rs, &n_rings);
     h->fx.run_async();
     h->fx.sync();
@@ -92,6 +93,30 @@ int loamx_scanreg_process_raw(loamx_scanreg* h, const loamx_multiscan_mapper* ma
     int rc = h->fx.download_cloud(0, full, ring_size);
     const int rc2 = h->fx.download(0, sharp, less_sharp, flat, less_flat);
     return rc != LOAMX_OK ? rc : rc2;
+  });
+}
+
+// updateIMUData(acc, newState) — BasicScanRegistration.cpp:82-98; acc = local acceleration with gravity removed and axes
+// remapped as ScanRegistration::handleIMUMessage does (src/lib/ScanRegistration.cpp:164-184)
+int loamx_scanreg_update_imu(loamx_scanreg* h, double stamp_sec, float roll, float pitch, float yaw, const float acc_xyz[3]) {
+  return guard([&]() {
+    LX_REQUIRE(h && acc_xyz, "NULL argument");
+    h->fx.update_imu_data(stamp_sec, roll, pitch, yaw, acc_xyz);
+    return LOAMX_OK;
+  });
+}
+int loamx_scanreg_set_time(loamx_scanreg* h, double scan_time_sec) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    h->fx.set_scan_time(scan_time_sec);
+    return LOAMX_OK;
+  });
+}
+int loamx_scanreg_get_imu_trans(loamx_scanreg* h, float imu_trans[12]) {
+  return guard([&]() {
+    LX_REQUIRE(h && imu_trans, "NULL argument");
+    for (int k = 0; k < 12; k++) imu_trans[k] = h->fx.imu_trans()[k];
+    return LOAMX_OK;
   });
 }
 

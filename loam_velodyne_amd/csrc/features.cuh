@@ -1,7 +1,9 @@
 // Per-sweep feature extraction (BasicScanRegistration::extractFeatures, IMU-less) for a batch of sweeps.
 #pragma once
 #include "common.h"
+#include "host_math.h"
 #include "ingest.cuh"
+#include <deque>
 #include "voxel.cuh"
 
 namespace loamx {
@@ -26,8 +28,15 @@ class FeatureExtractor {
 
   // stage nsw sweeps: cloud[s] = rings concatenated, ring_size[s][0..n_rings[s])
   void upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings);
-  // one raw revolution in sensor axes / firing order (MultiScanRegistration::process): binned into rings on the device
+  // one raw revolution in sensor axes / firing order (MultiScanRegistration::process): binned into rings on the device and,
+  // with IMU data, de-skewed point by point (projectPointToStartOfSweep)
   void upload_raw(const void* raw_xyz, uint32_t count, uint32_t stride, float lower_deg, float upper_deg, uint32_t n_scan_rings);
+  // ---- IMU state machine of BasicScanRegistration (src/lib/BasicScanRegistration.cpp:55-152, :258-281); times in seconds
+  void update_imu_data(double stamp, float roll, float pitch, float yaw, const float acc[3]);   // updateIMUData :82-98
+  void set_scan_time(double t) { next_scan_time_ = t; }     // the scanTime argument of the next process call
+  void begin_sweep();                                       // reset(scanTime) + updateIMUTransform() around processScanlines
+  const float* imu_trans() const { return imu_trans_; }     // imuTransform(): 4 x (x, y, z)
+  int imu_history_size = 200;                               // RegistrationParams::imuHistorySize
   int download_cloud(uint32_t sweep, loamx_cloud* full, uint32_t* ring_size_out);
   void run_async();
   void sync();
@@ -49,6 +58,24 @@ class FeatureExtractor {
   uint32_t total_rings() const { return nring_; }
 
  private:
+  struct ImuState {
+    double stamp = 0;
+    HAngle roll, pitch, yaw;
+    HVec3 position, velocity, acceleration;
+  };
+  std::deque<ImuState> imu_hist_;
+  size_t imu_idx_ = 0;
+  ImuState imu_start_, imu_cur_;
+  HVec3 imu_shift_;
+  double scan_time_ = 0, sweep_start_ = 0, next_scan_time_ = 0;
+  float imu_trans_[12] = {0};
+  void imu_interpolate_for_(float rel_time, ImuState& out);
+  DevBuf<double> imu_dt_, imu_dstamp_;
+  DevBuf<float> imu_state_;
+  DevBuf<ImuLast> imu_last_;
+  PinBuf<double> h_imu_d_;
+  PinBuf<float> h_imu_f_;
+  PinBuf<ImuLast> h_imu_last_;
   void check_params_() const;
   void layout_(uint32_t nsw, const uint32_t* const* ring_size, const uint32_t* n_rings);
   void allocate_();

@@ -581,13 +581,113 @@ void FeatureExtractor::upload_raw(const void* raw_xyz, uint32_t count, uint32_t 
   M.lower = lower_deg; M.upper = upper_deg; M.n_rings = n_scan_rings;
   M.factor = (float)((int)n_scan_rings - 1) / (upper_deg - lower_deg);   // (nScanRings - 1) / (upperBound - lowerBound), :41-50
   binner_.init(st_);
-  binner_.run(raw_.p, count, M, params.scan_period, cloud_.p, raw_ring_cnt_.p);
+  // IMU de-skew (projectPointToStartOfSweep, :231): the state the PREVIOUS reset() left behind — the reference projects the
+  // points of a sweep before processScanlines resets the state with this sweep's scan time
+  ImuTable I;
+  const uint32_t H = (uint32_t)imu_hist_.size();
+  if (H) {
+    h_imu_d_.reserve(2 * (size_t)H);
+    h_imu_f_.reserve(9 * (size_t)H);
+    for (uint32_t j = 0; j < H; j++) {
+      const ImuState& s = imu_hist_[j];
+      h_imu_d_.p[j] = scan_time_ - s.stamp;
+      h_imu_d_.p[H + j] = j ? s.stamp - imu_hist_[j - 1].stamp : 1.0;
+      float* o = h_imu_f_.p + 9 * (size_t)j;
+      o[0] = s.roll.r; o[1] = s.pitch.r; o[2] = s.yaw.r;
+      o[3] = s.position.x; o[4] = s.position.y; o[5] = s.position.z;
+      o[6] = s.velocity.x; o[7] = s.velocity.y; o[8] = s.velocity.z;
+    }
+    imu_dt_.reserve(2 * (size_t)H);
+    imu_state_.reserve(9 * (size_t)H);
+    imu_last_.reserve(1);
+    h_imu_last_.reserve(1);
+    LX_HIP(hipMemcpyAsync(imu_dt_.p, h_imu_d_.p, sizeof(double) * 2 * H, hipMemcpyHostToDevice, st_));
+    LX_HIP(hipMemcpyAsync(imu_state_.p, h_imu_f_.p, sizeof(float) * 9 * H, hipMemcpyHostToDevice, st_));
+    LX_HIP(hipMemsetAsync(imu_last_.p, 0, sizeof(ImuLast), st_));
+    I.H = H;
+    I.idx0 = (uint32_t)std::min(imu_idx_, (size_t)H - 1);
+    I.dt = imu_dt_.p;
+    I.dstamp = imu_dt_.p + H;
+    I.state = imu_state_.p;
+    const HAngle* sa[3] = {&imu_start_.roll, &imu_start_.pitch, &imu_start_.yaw};
+    for (int k = 0; k < 3; k++) { I.start_c[k] = sa[k]->c; I.start_s[k] = sa[k]->s; }
+    I.start_pos[0] = imu_start_.position.x; I.start_pos[1] = imu_start_.position.y; I.start_pos[2] = imu_start_.position.z;
+    I.start_vel[0] = imu_start_.velocity.x; I.start_vel[1] = imu_start_.velocity.y; I.start_vel[2] = imu_start_.velocity.z;
+    I.rel_sweep_base = scan_time_ - sweep_start_;
+  }
+  binner_.run(raw_.p, count, M, params.scan_period, cloud_.p, raw_ring_cnt_.p, H ? &I : nullptr, H ? imu_last_.p : nullptr);
   LX_HIP(hipMemcpyAsync(h_raw_ring_cnt_.p, raw_ring_cnt_.p, sizeof(uint32_t) * n_scan_rings, hipMemcpyDeviceToHost, st_));
+  if (H) LX_HIP(hipMemcpyAsync(h_imu_last_.p, imu_last_.p, sizeof(ImuLast), hipMemcpyDeviceToHost, st_));
   LX_HIP(hipStreamSynchronize(st_));
+  if (H && h_imu_last_.p->valid) {   // _imuCur / _imuPositionShift / _imuIdx as the last kept point left them
+    const ImuLast& L = *h_imu_last_.p;
+    imu_cur_.roll = HAngle(L.roll); imu_cur_.pitch = HAngle(L.pitch); imu_cur_.yaw = HAngle(L.yaw);
+    imu_cur_.position = {L.pos[0], L.pos[1], L.pos[2]};
+    imu_cur_.velocity = {L.vel[0], L.vel[1], L.vel[2]};
+    imu_shift_ = {L.shift[0], L.shift[1], L.shift[2]};
+    imu_idx_ = L.idx;
+  }
+  begin_sweep();   // processScanlines: reset(scanTime) ... updateIMUTransform()
   const uint32_t* rs[1] = {h_raw_ring_cnt_.p};
   layout_(1, rs, &n_scan_rings);
   allocate_();   // (cloud_ already holds the binned sweep; reserve() keeps the contents when the capacity suffices)
   LX_HIP(hipStreamSynchronize(st_));
+}
+
+// ---- IMU state machine (host): the reference keeps it in BasicScanRegistration; the per-point part runs in ingest.hip
+void FeatureExtractor::update_imu_data(double stamp, float roll, float pitch, float yaw, const float acc_in[3]) {
+  ImuState st;
+  st.stamp = stamp; st.roll = HAngle(roll); st.pitch = HAngle(pitch); st.yaw = HAngle(yaw);
+  st.acceleration = {acc_in[0], acc_in[1], acc_in[2]};
+  if (!imu_hist_.empty()) {   // accumulate IMU position and velocity over time (:84-95)
+    HVec3 acc = st.acceleration;
+    h_rot_zxy(acc, st.roll, st.pitch, st.yaw);
+    const ImuState& prev = imu_hist_.back();
+    const float dt = (float)(stamp - prev.stamp);
+    st.position = {prev.position.x + prev.velocity.x * dt + 0.5f * acc.x * dt * dt, prev.position.y + prev.velocity.y * dt + 0.5f * acc.y * dt * dt,
+                   prev.position.z + prev.velocity.z * dt + 0.5f * acc.z * dt * dt};
+    st.velocity = {prev.velocity.x + acc.x * dt, prev.velocity.y + acc.y * dt, prev.velocity.z + acc.z * dt};
+  }
+  if (imu_hist_.size() >= (size_t)std::max(imu_history_size, 1)) imu_hist_.pop_front();   // CircularBuffer::push, CircularBuffer.h:111-119
+  imu_hist_.push_back(st);
+}
+
+void FeatureExtractor::imu_interpolate_for_(float rel, ImuState& out) {   // interpolateIMUStateFor :133-147
+  double td = (scan_time_ - imu_hist_[imu_idx_].stamp) + rel;
+  while (imu_idx_ < imu_hist_.size() - 1 && td > 0) {
+    imu_idx_++;
+    td = (scan_time_ - imu_hist_[imu_idx_].stamp) + rel;
+  }
+  if (imu_idx_ == 0 || td > 0) {
+    out = imu_hist_[imu_idx_];
+  } else {
+    const ImuState &a = imu_hist_[imu_idx_], &b = imu_hist_[imu_idx_ - 1];   // IMUState::interpolate(a, b, ratio), .h:107-131
+    const float ratio = (float)(-td / (a.stamp - b.stamp)), inv = 1 - ratio;
+    out.roll = HAngle(a.roll.r * inv + b.roll.r * ratio);
+    out.pitch = HAngle(a.pitch.r * inv + b.pitch.r * ratio);
+    if (a.yaw.r - b.yaw.r > M_PI) out.yaw = HAngle((float)(a.yaw.r * inv + (b.yaw.r + 2 * M_PI) * ratio));
+    else if (a.yaw.r - b.yaw.r < -M_PI) out.yaw = HAngle((float)(a.yaw.r * inv + (b.yaw.r - 2 * M_PI) * ratio));
+    else out.yaw = HAngle(a.yaw.r * inv + b.yaw.r * ratio);
+    out.velocity = {a.velocity.x * inv + b.velocity.x * ratio, a.velocity.y * inv + b.velocity.y * ratio, a.velocity.z * inv + b.velocity.z * ratio};
+    out.position = {a.position.x * inv + b.position.x * ratio, a.position.y * inv + b.position.y * ratio, a.position.z * inv + b.position.z * ratio};
+  }
+}
+
+// reset(scanTime) (:55-79) followed by updateIMUTransform() (:258-281): the latter only needs _imuStart (set by the reset) and
+// _imuCur / _imuPositionShift (left behind by the projection loop), so both are done up front
+void FeatureExtractor::begin_sweep() {
+  scan_time_ = next_scan_time_;
+  imu_idx_ = 0;
+  if (!imu_hist_.empty()) imu_interpolate_for_(0.f, imu_start_);
+  sweep_start_ = scan_time_;
+  imu_trans_[0] = imu_start_.pitch.r; imu_trans_[1] = imu_start_.yaw.r; imu_trans_[2] = imu_start_.roll.r;
+  imu_trans_[3] = imu_cur_.pitch.r; imu_trans_[4] = imu_cur_.yaw.r; imu_trans_[5] = imu_cur_.roll.r;
+  HVec3 sh = imu_shift_;
+  h_rot_yxz(sh, -imu_start_.yaw, -imu_start_.pitch, -imu_start_.roll);
+  imu_trans_[6] = sh.x; imu_trans_[7] = sh.y; imu_trans_[8] = sh.z;
+  HVec3 v{imu_cur_.velocity.x - imu_start_.velocity.x, imu_cur_.velocity.y - imu_start_.velocity.y, imu_cur_.velocity.z - imu_start_.velocity.z};
+  h_rot_yxz(v, -imu_start_.yaw, -imu_start_.pitch, -imu_start_.roll);
+  imu_trans_[9] = v.x; imu_trans_[10] = v.y; imu_trans_[11] = v.z;
 }
 
 // the (binned) input cloud of a sweep and its ring sizes

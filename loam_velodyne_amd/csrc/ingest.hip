@@ -52,7 +52,104 @@ __device__ inline float ori_second_half(float x, float z, float endOri) {
   return ori;
 }
 
-__global__ void k_raw_init(uint32_t* scratch) { scratch[0] = 0xffffffffu; }
+__global__ void k_raw_init(uint32_t* scratch, uint32_t* imu_first, uint32_t H) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0) { scratch[0] = 0xffffffffu; scratch[1] = 0u; }   // j* (first kept point that sets halfPassed), last kept point
+  if (e < H) imu_first[e] = 0xffffffffu;
+}
+
+// relTime of kept point i (:209-228); x, z in the LOAM frame
+__device__ inline float rel_time_of(uint32_t i, float x, float z, float startOri, float endOri, uint32_t jstar, float scan_period) {
+  bool passes;
+  float ori = ori_first_half(x, z, startOri, passes);
+  if (i > jstar) ori = ori_second_half(x, z, endOri);   // halfPassed was set by an earlier kept point
+  return scan_period * (ori - startOri) / (endOri - startOri);
+}
+
+// interpolateIMUStateFor's index search for one point on its own (:135-139): smallest j with dt[j] + relTime <= 0, else H-1
+__device__ inline uint32_t imu_need(const ImuTable& I, float relTime) {
+  uint32_t lo = 0, hi = I.H - 1;   // dt is decreasing in j
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (I.dt[mid] + (double)relTime > 0) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// _imuIdx only ever moves forward while the points are walked in firing order: idx(i) = max(idx0, max_{kept j <= i} need(j)).
+// k_raw_imu_need records, per history index v, the first kept point that needs at least ... exactly v; the suffix minimum
+// over v turns that into "first point that needs >= v", which is non-decreasing in v and binary-searchable per point.
+__global__ __launch_bounds__(256) void k_raw_imu_need(const float4* __restrict__ raw, uint32_t n, float scan_period, const int* __restrict__ ring_of,
+                                                      const uint32_t* __restrict__ jstar, ImuTable I, uint32_t* __restrict__ first) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || ring_of[i] < 0) return;
+  float startOri, endOri;
+  sweep_oris(raw, n, startOri, endOri);
+  const float4 r = raw[i];
+  const float relTime = rel_time_of(i, r.y, r.x, startOri, endOri, *jstar, scan_period);
+  const uint32_t v = imu_need(I, relTime);
+  if (v > I.idx0) atomicMin(&first[v], i);
+}
+__global__ void k_raw_imu_suffix(uint32_t* __restrict__ first, uint32_t H) {
+  uint32_t m = 0xffffffffu;
+  for (int v = (int)H - 1; v >= 0; v--) {
+    m = first[v] < m ? first[v] : m;
+    first[v] = m;
+  }
+}
+
+// Angle(float): cached sin / cos of a float angle (Angle.h:16-30); double-then-round, within an ulp of the host's float libm
+struct DAngle { float c, s; };
+__device__ inline DAngle dangle(float r) { return {(float)cos((double)r), (float)sin((double)r)}; }
+__device__ inline void d_rot_x(float& y, float& z, float c, float s) { const float y0 = y; y = c * y0 - s * z; z = s * y0 + c * z; }
+__device__ inline void d_rot_y(float& x, float& z, float c, float s) { const float x0 = x; x = c * x0 + s * z; z = c * z - s * x0; }
+__device__ inline void d_rot_z(float& x, float& y, float c, float s) { const float x0 = x; x = c * x0 - s * y; y = s * x0 + c * y; }
+
+// setIMUTransformFor + transformToStartIMU for kept point i (:112-131)
+__device__ inline void imu_project(const ImuTable& I, const uint32_t* __restrict__ first, uint32_t i, float relTime, float& x, float& y, float& z,
+                                   ImuLast* last_out) {
+  // _imuIdx after this point
+  uint32_t idx = I.idx0;
+  {
+    uint32_t lo = I.idx0, hi = I.H - 1;   // largest v in (idx0, H-1] with first[v] <= i
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      if (first[mid] <= i) lo = mid; else hi = mid - 1;
+    }
+    idx = lo;
+  }
+  const double timeDiff = I.dt[idx] + (double)relTime;
+  float cur[9];
+  if (idx == 0 || timeDiff > 0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) cur[k] = I.state[9 * idx + k];
+  } else {
+    const float ratio = (float)(-timeDiff / I.dstamp[idx]), inv = 1 - ratio;   // IMUState::interpolate(hist[idx], hist[idx-1], ratio)
+    const float* a = I.state + 9 * idx;
+    const float* b = I.state + 9 * (idx - 1);
+    cur[0] = a[0] * inv + b[0] * ratio;
+    cur[1] = a[1] * inv + b[1] * ratio;
+    if ((double)(a[2] - b[2]) > PI_D) cur[2] = (float)((double)(a[2] * inv) + ((double)b[2] + 2 * PI_D) * (double)ratio);
+    else if ((double)(a[2] - b[2]) < -PI_D) cur[2] = (float)((double)(a[2] * inv) + ((double)b[2] - 2 * PI_D) * (double)ratio);
+    else cur[2] = a[2] * inv + b[2] * ratio;
+#pragma unroll
+    for (int k = 3; k < 9; k++) cur[k] = a[k] * inv + b[k] * ratio;
+  }
+  const float relSweepTime = (float)(I.rel_sweep_base + (double)relTime);
+  const float sx = cur[3] - I.start_pos[0] - I.start_vel[0] * relSweepTime;
+  const float sy = cur[4] - I.start_pos[1] - I.start_vel[1] * relSweepTime;
+  const float sz = cur[5] - I.start_pos[2] - I.start_vel[2] * relSweepTime;
+  const DAngle ro = dangle(cur[0]), pi = dangle(cur[1]), ya = dangle(cur[2]);
+  d_rot_z(x, y, ro.c, ro.s); d_rot_x(y, z, pi.c, pi.s); d_rot_y(x, z, ya.c, ya.s);   // rotateZXY(roll, pitch, yaw)
+  x += sx; y += sy; z += sz;
+  d_rot_y(x, z, I.start_c[2], -I.start_s[2]); d_rot_x(y, z, I.start_c[1], -I.start_s[1]); d_rot_z(x, y, I.start_c[0], -I.start_s[0]);   // rotateYXZ(-yaw, -pitch, -roll)
+  if (last_out) {
+    last_out->roll = cur[0]; last_out->pitch = cur[1]; last_out->yaw = cur[2];
+    for (int k = 0; k < 3; k++) { last_out->pos[k] = cur[3 + k]; last_out->vel[k] = cur[6 + k]; }
+    last_out->shift[0] = sx; last_out->shift[1] = sy; last_out->shift[2] = sz;
+    last_out->idx = idx; last_out->valid = 1u;
+  }
+}
 
 __global__ __launch_bounds__(256) void k_raw_classify(const float4* __restrict__ raw, uint32_t n, MapperParams M, int* __restrict__ ring_of,
                                                       uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ jstar) {
@@ -71,6 +168,7 @@ __global__ __launch_bounds__(256) void k_raw_classify(const float4* __restrict__
       bool passes;
       (void)ori_first_half(x, z, startOri, passes);
       if (passes) atomicMin(jstar, i);
+      atomicMax(jstar + 1, i);   // last kept point
     }
   }
   __syncthreads();
@@ -104,7 +202,8 @@ __global__ __launch_bounds__(256) void k_raw_colscan(const uint32_t* __restrict_
 __global__ __launch_bounds__(256) void k_raw_scatter(const float4* __restrict__ raw, uint32_t n, MapperParams M, float scan_period,
                                                      const int* __restrict__ ring_of, const uint32_t* __restrict__ blk_pre,
                                                      const uint32_t* __restrict__ ring_cnt, const uint32_t* __restrict__ jstar,
-                                                     float4* __restrict__ out) {
+                                                     float4* __restrict__ out, ImuTable I, const uint32_t* __restrict__ imu_first,
+                                                     ImuLast* __restrict__ d_last) {
   __shared__ uint32_t ring_off[RawBinner::MAX_RINGS];
   __shared__ uint32_t wcnt[4][RawBinner::MAX_RINGS];
   // ring offsets (exclusive scan of the ring totals; <= 256 rings)
@@ -137,17 +236,16 @@ __global__ __launch_bounds__(256) void k_raw_scatter(const float4* __restrict__ 
   float startOri, endOri;
   sweep_oris(raw, n, startOri, endOri);
   const float4 r = raw[i];
-  const float x = r.y, y = r.z, z = r.x;
-  bool passes;
-  float ori = ori_first_half(x, z, startOri, passes);
-  if (i > *jstar) ori = ori_second_half(x, z, endOri);   // halfPassed was set by an earlier kept point
-  const float relTime = scan_period * (ori - startOri) / (endOri - startOri);   // :228
-  out[pos] = make_float4(x, y, z, (float)id + relTime);                          // :229
+  float x = r.y, y = r.z, z = r.x;
+  const float relTime = rel_time_of(i, x, z, startOri, endOri, jstar[0], scan_period);   // :228
+  if (I.H) imu_project(I, imu_first, i, relTime, x, y, z, i == jstar[1] ? d_last : nullptr);   // :231
+  out[pos] = make_float4(x, y, z, (float)id + relTime);                                  // :229
 }
 
 }  // namespace
 
-void RawBinner::run(const float4* d_raw, uint32_t n, const MapperParams& m, float scan_period, float4* d_out, uint32_t* d_ring_cnt) {
+void RawBinner::run(const float4* d_raw, uint32_t n, const MapperParams& m, float scan_period, float4* d_out, uint32_t* d_ring_cnt,
+                    const ImuTable* imu, ImuLast* d_last) {
   LX_REQUIRE(m.n_rings >= 1 && m.n_rings <= MAX_RINGS, "n_scan_rings must be in [1, 256]");
   if (n == 0) {
     LX_HIP(hipMemsetAsync(d_ring_cnt, 0, sizeof(uint32_t) * m.n_rings, st_));
@@ -158,11 +256,18 @@ void RawBinner::run(const float4* d_raw, uint32_t n, const MapperParams& m, floa
   blk_cnt_.reserve((size_t)nb * m.n_rings + 1);
   blk_pre_.reserve((size_t)nb * m.n_rings + 1);
   scratch_.reserve(4);
-  hipLaunchKernelGGL(k_raw_init, dim3(1), dim3(1), 0, st_, scratch_.p);
+  ImuTable I;
+  if (imu) I = *imu;
+  imu_first_.reserve(I.H + 1);
+  hipLaunchKernelGGL(k_raw_init, dim3((I.H + 256) / 256), dim3(256), 0, st_, scratch_.p, imu_first_.p, I.H);
   hipLaunchKernelGGL(k_raw_classify, dim3(nb), dim3(256), 0, st_, d_raw, n, m, ring_of_.p, blk_cnt_.p, scratch_.p);
   hipLaunchKernelGGL(k_raw_colscan, dim3(m.n_rings), dim3(256), 0, st_, blk_cnt_.p, nb, m.n_rings, blk_pre_.p, d_ring_cnt);
+  if (I.H) {
+    hipLaunchKernelGGL(k_raw_imu_need, dim3(nb), dim3(256), 0, st_, d_raw, n, scan_period, ring_of_.p, scratch_.p, I, imu_first_.p);
+    hipLaunchKernelGGL(k_raw_imu_suffix, dim3(1), dim3(1), 0, st_, imu_first_.p, I.H);
+  }
   hipLaunchKernelGGL(k_raw_scatter, dim3(nb), dim3(256), 0, st_, d_raw, n, m, scan_period, ring_of_.p, blk_pre_.p, d_ring_cnt, scratch_.p,
-                     d_out);
+                     d_out, I, imu_first_.p, d_last);
   LX_HIP(hipGetLastError());
 }
 

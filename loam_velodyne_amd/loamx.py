@@ -273,6 +273,21 @@ class ScanRegistration:
         res["full"] = pts[:, :4].copy() if pts.shape[1] == 4 else pts
         return res
 
+    def update_imu(self, stamp, roll, pitch, yaw, acc):
+        """loamx_scanreg_update_imu (updateIMUData); stamp in seconds"""
+        a = np.ascontiguousarray(acc, np.float32)
+        _check(lib().loamx_scanreg_update_imu(self.h, C.c_double(stamp), C.c_float(roll), C.c_float(pitch), C.c_float(yaw),
+                                              a.ctypes.data_as(C.c_void_p)))
+
+    def set_time(self, t):
+        """the scanTime of the next process call"""
+        _check(lib().loamx_scanreg_set_time(self.h, C.c_double(t)))
+
+    def imu_trans(self):
+        out = np.zeros(12, np.float32)
+        _check(lib().loamx_scanreg_get_imu_trans(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def process_raw(self, raw_xyz, sensor="VLP-16", mapper=None):
         """loamx_scanreg_process_raw: MultiScanRegistration::process on a raw (n,3) firing-order cloud in sensor axes.
         mapper = (lower_deg, upper_deg, n_rings) overrides the sensor preset.  Adds "full" and "ring_sizes"."""

@@ -107,6 +107,30 @@ int orc_multiscan_bin(const float* raw, int n, float lower_deg, float upper_deg,
   return total;
 }
 
+// ---- scan registration with IMU data ----
+// updateIMUData: stamp (s), roll / pitch / yaw, acceleration (local frame, gravity already removed as ScanRegistration.cpp:171-174 does)
+void orc_scanreg_update_imu(void* h, double stamp, float roll, float pitch, float yaw, float ax, float ay, float az) {
+  auto* s = (ScanRegistration*)h;
+  ScanRegistration::IMUState st;
+  st.stamp = stamp; st.roll = Angle(roll); st.pitch = Angle(pitch); st.yaw = Angle(yaw);
+  st.acceleration = {ax, ay, az};
+  s->update_imu_data({ax, ay, az}, st);
+}
+// MultiScanRegistration::process(laserCloudIn, scanTime) on the handle's IMU state; returns points kept
+int orc_scanreg_process_raw(void* h, const float* raw, int n, double scan_time, float lower_deg, float upper_deg, int n_rings, int* ring_sizes) {
+  auto* s = (ScanRegistration*)h;
+  MultiScanMapper m;
+  m.set(lower_deg, upper_deg, (uint16_t)n_rings);
+  std::vector<Cloud> scans = bin_sweep(raw, (size_t)n, m, s->cfg.scanPeriod, s);
+  int total = 0;
+  for (int r = 0; r < n_rings; r++) { ring_sizes[r] = (int)scans[r].size(); total += ring_sizes[r]; }
+  s->process_scanlines_at(scan_time, scans);
+  return total;
+}
+void orc_scanreg_get_imu_trans(void* h, float* out12) {
+  for (int k = 0; k < 12; k++) out12[k] = ((ScanRegistration*)h)->imuTrans[k];
+}
+
 // ---- transform maintenance (BasicTransformMaintenance) + wire conversions ----
 void orc_tm_associate(const float* sum6, const float* bef6, const float* aft6, float* mapped6) {
   TransformMaintenance t;

@@ -8,10 +8,17 @@
 //   mark_as_picked      -> :367-386
 //   RegistrationParams  -> include/loam_velodyne/BasicScanRegistration.h:34-72, .cpp:9-26
 //   PointLabel          -> .h:24-30
-// The IMU functions (:82-152, :258-281) are a "next" row: with an empty IMU history they are
-// identities and imuTrans is all zeros, which is what this restatement returns.
+// IMU state:
+//   update_imu_data / project_point_to_start_of_sweep / set_imu_transform_for / transform_to_start_imu /
+//   interpolate_imu_state_for -> :82-152;  reset -> :55-79;  update_imu_transform -> :258-281;
+//   IMUState + interpolate -> include/loam_velodyne/BasicScanRegistration.h:77-132;  CircularBuffer.h:111-119 (push).
+// Times are double seconds on any common clock (the reference's Time / toSec, time_utils.h).  NOTE the reference's
+// order of events, reproduced as is: MultiScanRegistration::process projects the points of a sweep (:231) BEFORE
+// processScanlines calls reset(scanTime) (:31), so a sweep is de-skewed with the scan time / start state the PREVIOUS
+// sweep's reset left behind (a default-constructed Time and state for the very first sweep).
 #pragma once
 #include "oracle_cloud.hpp"
+#include <deque>
 
 namespace loam_oracle {
 
@@ -35,6 +42,98 @@ class ScanRegistration {
   Cloud laserCloud, cornerSharp, cornerLessSharp, surfFlat, surfLessFlat;
   std::vector<std::pair<size_t, size_t>> scanIndices;  // inclusive [first, second]
   float imuTrans[12] = {0};
+
+  // ---- IMU state
+  struct IMUState {
+    double stamp = 0;
+    Angle roll, pitch, yaw;
+    Vec3 position, velocity, acceleration;
+  };
+  std::deque<IMUState> imuHistory;   // CircularBuffer<IMUState>, capacity cfg.imuHistorySize (configure :48-53)
+  size_t imuIdx = 0;
+  IMUState imuStart, imuCur;
+  Vec3 imuPositionShift;
+  double scanTime = 0, sweepStart = 0;
+  bool has_imu() const { return !imuHistory.empty(); }
+
+  // updateIMUData(acc, newState) :82-98 — acc in the local frame, newState with stamp / roll / pitch / yaw / acceleration set
+  void update_imu_data(Vec3 acc, IMUState newState) {
+    if (!imuHistory.empty()) {
+      rotateZXY(acc, newState.roll, newState.pitch, newState.yaw);
+      const IMUState& prev = imuHistory.back();
+      const float timeDiff = (float)(newState.stamp - prev.stamp);
+      newState.position = {prev.position.x + prev.velocity.x * timeDiff + 0.5f * acc.x * timeDiff * timeDiff,
+                           prev.position.y + prev.velocity.y * timeDiff + 0.5f * acc.y * timeDiff * timeDiff,
+                           prev.position.z + prev.velocity.z * timeDiff + 0.5f * acc.z * timeDiff * timeDiff};
+      newState.velocity = {prev.velocity.x + acc.x * timeDiff, prev.velocity.y + acc.y * timeDiff, prev.velocity.z + acc.z * timeDiff};
+    }
+    if (imuHistory.size() >= (size_t)cfg.imuHistorySize) imuHistory.pop_front();
+    imuHistory.push_back(newState);
+  }
+  static void interpolate(const IMUState& start, const IMUState& end, float ratio, IMUState& result) {   // .h:107-131
+    const float invRatio = 1 - ratio;
+    result.roll = Angle(start.roll.rad() * invRatio + end.roll.rad() * ratio);
+    result.pitch = Angle(start.pitch.rad() * invRatio + end.pitch.rad() * ratio);
+    if (start.yaw.rad() - end.yaw.rad() > M_PI) {
+      result.yaw = Angle((float)(start.yaw.rad() * invRatio + (end.yaw.rad() + 2 * M_PI) * ratio));
+    } else if (start.yaw.rad() - end.yaw.rad() < -M_PI) {
+      result.yaw = Angle((float)(start.yaw.rad() * invRatio + (end.yaw.rad() - 2 * M_PI) * ratio));
+    } else {
+      result.yaw = Angle(start.yaw.rad() * invRatio + end.yaw.rad() * ratio);
+    }
+    result.velocity = {start.velocity.x * invRatio + end.velocity.x * ratio, start.velocity.y * invRatio + end.velocity.y * ratio,
+                       start.velocity.z * invRatio + end.velocity.z * ratio};
+    result.position = {start.position.x * invRatio + end.position.x * ratio, start.position.y * invRatio + end.position.y * ratio,
+                       start.position.z * invRatio + end.position.z * ratio};
+  }
+  void interpolate_imu_state_for(float relTime, IMUState& out) {   // :133-147
+    double timeDiff = (scanTime - imuHistory[imuIdx].stamp) + relTime;
+    while (imuIdx < imuHistory.size() - 1 && timeDiff > 0) {
+      imuIdx++;
+      timeDiff = (scanTime - imuHistory[imuIdx].stamp) + relTime;
+    }
+    if (imuIdx == 0 || timeDiff > 0) {
+      out = imuHistory[imuIdx];
+    } else {
+      const float ratio = (float)(-timeDiff / (imuHistory[imuIdx].stamp - imuHistory[imuIdx - 1].stamp));
+      interpolate(imuHistory[imuIdx], imuHistory[imuIdx - 1], ratio, out);
+    }
+  }
+  void project_point_to_start_of_sweep(Pt& point, float relTime) {   // :101-131
+    if (!has_imu()) return;
+    interpolate_imu_state_for(relTime, imuCur);                       // setIMUTransformFor :112-118
+    const float relSweepTime = (float)((scanTime - sweepStart) + relTime);
+    imuPositionShift = {imuCur.position.x - imuStart.position.x - imuStart.velocity.x * relSweepTime,
+                        imuCur.position.y - imuStart.position.y - imuStart.velocity.y * relSweepTime,
+                        imuCur.position.z - imuStart.position.z - imuStart.velocity.z * relSweepTime};
+    rotateZXY(point, imuCur.roll, imuCur.pitch, imuCur.yaw);          // transformToStartIMU :122-131
+    point.x += imuPositionShift.x;
+    point.y += imuPositionShift.y;
+    point.z += imuPositionShift.z;
+    rotateYXZ(point, -imuStart.yaw, -imuStart.pitch, -imuStart.roll);
+  }
+  void reset(double t) {   // :55-79
+    scanTime = t;
+    imuIdx = 0;
+    if (has_imu()) interpolate_imu_state_for(0, imuStart);
+    sweepStart = t;
+  }
+  void update_imu_transform() {   // :258-281
+    imuTrans[0] = imuStart.pitch.rad(); imuTrans[1] = imuStart.yaw.rad(); imuTrans[2] = imuStart.roll.rad();
+    imuTrans[3] = imuCur.pitch.rad(); imuTrans[4] = imuCur.yaw.rad(); imuTrans[5] = imuCur.roll.rad();
+    Vec3 shift = imuPositionShift;
+    rotateYXZ(shift, -imuStart.yaw, -imuStart.pitch, -imuStart.roll);
+    imuTrans[6] = shift.x; imuTrans[7] = shift.y; imuTrans[8] = shift.z;
+    Vec3 vel = {imuCur.velocity.x - imuStart.velocity.x, imuCur.velocity.y - imuStart.velocity.y, imuCur.velocity.z - imuStart.velocity.z};
+    rotateYXZ(vel, -imuStart.yaw, -imuStart.pitch, -imuStart.roll);
+    imuTrans[9] = vel.x; imuTrans[10] = vel.y; imuTrans[11] = vel.z;
+  }
+  // processScanlines(scanTime, laserCloudScans) :28-46 with the IMU bookkeeping around it
+  void process_scanlines_at(double t, const std::vector<Cloud>& rings) {
+    reset(t);
+    process_scanlines(rings);
+    update_imu_transform();
+  }
 
   // rings: one cloud per scan ring, already in the LOAM camera frame, intensity = ring + relTime.
   void process_scanlines(const std::vector<Cloud>& rings) {

@@ -6,10 +6,11 @@
 //   bin_sweep                               -> MultiScanRegistration::process, src/lib/MultiScanRegistration.cpp:160-238
 // Input: the raw points of one revolution in sensor axes (x forward, y left, z up) in firing order; output: one cloud per
 // scan ring in the LOAM camera frame (x = y_in, y = z_in, z = x_in), intensity = ring + relTime.
-// projectPointToStartOfSweep (:231, BasicScanRegistration.cpp:101-109) is an identity without IMU data (row f2).
+// projectPointToStartOfSweep (:231, BasicScanRegistration.cpp:101-109) de-skews with the IMU state of the scan
+// registration passed in (identity without IMU data).
 // Types follow the reference: float everywhere, with the double promotions that the M_PI / 0.0001 / 0.5 literals cause.
 #pragma once
-#include "oracle_cloud.hpp"
+#include "oracle_features.hpp"
 #include <cmath>
 
 namespace loam_oracle {
@@ -28,7 +29,8 @@ struct MultiScanMapper {
 };
 
 // raw: n records of (x, y, z); returns one cloud per ring
-inline std::vector<Cloud> bin_sweep(const float* raw, size_t n, const MultiScanMapper& mapper, float scanPeriod) {
+// sr (optional): the scan registration whose IMU state de-skews every kept point (projectPointToStartOfSweep :231)
+inline std::vector<Cloud> bin_sweep(const float* raw, size_t n, const MultiScanMapper& mapper, float scanPeriod, ScanRegistration* sr = nullptr) {
   std::vector<Cloud> scans(mapper.nScanRings);
   if (n == 0) return scans;
   // scan start and end orientations (:165-173)
@@ -68,6 +70,7 @@ inline std::vector<Cloud> bin_sweep(const float* raw, size_t n, const MultiScanM
     }
     float relTime = scanPeriod * (ori - startOri) / (endOri - startOri);   // :228
     point.i = scanID + relTime;                                             // :229
+    if (sr) sr->project_point_to_start_of_sweep(point, relTime);            // :231
     scans[scanID].push_back(point);
   }
   return scans;

@@ -160,6 +160,25 @@ class ScanRegistration:
     def __del__(self):
         self.o.L.orc_scanreg_destroy(self.h)
 
+    def update_imu(self, stamp, roll, pitch, yaw, acc):
+        """updateIMUData: stamp in seconds, acc = local acceleration with gravity removed (ScanRegistration.cpp:171-174)"""
+        self.o.L.orc_scanreg_update_imu(self.h, C.c_double(stamp), C.c_float(roll), C.c_float(pitch), C.c_float(yaw),
+                                        C.c_float(acc[0]), C.c_float(acc[1]), C.c_float(acc[2]))
+
+    def process_raw(self, raw_xyz, scan_time, mapper="VLP-16"):
+        """MultiScanRegistration::process(laserCloudIn, scanTime) with this handle's IMU state"""
+        lo, hi, nr = MAPPERS[mapper] if isinstance(mapper, str) else mapper
+        raw = np.ascontiguousarray(raw_xyz, np.float32).reshape(-1, 3)
+        rs = np.zeros(nr, np.int32)
+        self.o.L.orc_scanreg_process_raw(self.h, raw.ctypes.data_as(C.c_void_p), len(raw), C.c_double(scan_time), C.c_float(lo), C.c_float(hi),
+                                         int(nr), rs.ctypes.data_as(C.c_void_p))
+        res = {n: _get_cloud(self.o.L.orc_scanreg_get, self.h, k) for k, n in enumerate(self.NAMES)}
+        res["ring_sizes"] = rs
+        it = np.zeros(12, np.float32)
+        self.o.L.orc_scanreg_get_imu_trans(self.h, it.ctypes.data_as(C.c_void_p))
+        res["imu_trans"] = it
+        return res
+
     def process(self, pts, ring_sizes):
         pts = _pts(pts)
         rs = np.ascontiguousarray(ring_sizes, np.int32)

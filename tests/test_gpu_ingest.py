@@ -54,3 +54,35 @@ def test_custom_mapper_and_errors():
         loamx.ScanRegistration().process_raw(raw, sensor="VLP-128")
     e = loamx.ScanRegistration().process_raw(np.zeros((0, 3), np.float32), "VLP-16")
     assert len(e["full"]) == 0 and e["ring_sizes"].sum() == 0
+
+
+def test_imu_deskew_matches_oracle(orc, small_world):
+    """updateIMUData + projectPointToStartOfSweep + updateIMUTransform, sweep after sweep, with IMU messages
+    arriving between the sweeps (the history is a 200-deep ring buffer, so indices shift once it is full)."""
+    rng = np.random.default_rng(21)
+    osr, gsr = op.ScanRegistration(orc), loamx.ScanRegistration()
+    t_imu, k_imu = 0.0, 0
+    for k in range(4):
+        t_scan = 0.1 * (k + 1)
+        while t_imu < t_scan + 0.12:                      # ~130 messages per sweep: the buffer wraps during the second sweep
+            roll, pitch, yaw = 0.02 * np.sin(3 * t_imu), 0.015 * np.cos(2 * t_imu), 0.4 * t_imu + (6.2 if k_imu % 97 == 50 else 0.0)
+            acc = (0.8 * np.sin(5 * t_imu), 0.1, -0.5 * np.cos(4 * t_imu))
+            osr.update_imu(t_imu, roll, pitch, yaw, acc)
+            gsr.update_imu(t_imu, roll, pitch, yaw, acc)
+            t_imu += 0.00077
+            k_imu += 1
+        sw = synth.make_sweep(small_world, "VLP-16", np.zeros(6), np.array([0.0, 0.04, 0.0, 0.1, 0.0, 0.5]), seed=30 + k, az_steps=700)
+        raw = synth.to_raw(sw, bad_every=33)
+        o = osr.process_raw(raw, t_scan, "VLP-16")
+        gsr.set_time(t_scan)
+        g = gsr.process_raw(raw, "VLP-16")
+        assert np.array_equal(g["ring_sizes"], o["ring_sizes"])
+        # de-skewed coordinates (range <= 90 m): relTime differs by an ulp between the two libm's, the interpolation ratio
+        # (IMU samples 0.77 ms apart) amplifies that by 1e2, and the planted 6.2 rad yaw wrap makes one interval 0.08 rad wide
+        assert np.abs(g["full"][:, :3] - o["full"][:, :3]).max() < 1e-4, k
+        assert np.all(np.abs(g["full"][:, 3] - o["full"][:, 3]) <= 2 * np.spacing(np.maximum(np.abs(o["full"][:, 3]), np.float32(1.0))))
+        assert np.abs(gsr.imu_trans() - o["imu_trans"]).max() < 2e-5, (k, gsr.imu_trans(), o["imu_trans"])
+        if k >= 1:
+            assert np.abs(o["imu_trans"]).max() > 1e-3                              # the IMU path is really active
+        for name in ("sharp", "less_sharp", "flat", "less_flat"):
+            assert abs(len(g[name]) - len(o[name])) <= max(2, len(o[name]) // 100), (k, name)

@@ -471,15 +471,4 @@ __device__ inline void qr_solve6_coop(const float* AtA, const float* AtB, float*
   if (gl < 6) X[perm] = gl < nonzero ? y : 0.f;
 }
 
-// 6x6 column-pivoted QR solve on plain arrays (single thread)
-__device__ inline void qr_solve6(const float* AtA, const float* AtB, float* X) {
-  float A[6][6], b[6], x[6];
-  for (int r = 0; r < 6; r++) {
-    b[r] = AtB[r];
-    for (int c = 0; c < 6; c++) A[r][c] = AtA[r * 6 + c];
-  }
-  qr_solve<6, 6>(A, b, x);
-  for (int r = 0; r < 6; r++) X[r] = x[r];
-}
-
 }  // namespace loamx

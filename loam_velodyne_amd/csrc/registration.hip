@@ -26,21 +26,11 @@ __device__ inline uint32_t enc_f32(float f) {
   uint32_t u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-__host__ __device__ inline float dec_f32(uint32_t u) {
+__device__ inline float dec_f32(uint32_t u) {
   u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-#ifdef __HIP_DEVICE_COMPILE__
   return __uint_as_float(u);
-#else
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-#endif
 }
 
-__global__ void k_fill_u32(uint32_t* p, uint32_t n, uint32_t v) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
 __global__ void k_init_bbox(uint32_t* scratch) {
   const uint32_t t = threadIdx.x;
   if (t < 3) scratch[t] = 0xffffffffu;
@@ -403,19 +393,6 @@ __global__ void k_pose_set(const float* __restrict__ p6, uint32_t ns, Pose* __re
   poses[s] = T;
 }
 
-__device__ inline void knn_insert(float (&bd)[5], uint32_t (&bi)[5], uint32_t (&bp)[5], float d2, uint32_t id, uint32_t pos) {
-  if (!(d2 < bd[4] || (d2 == bd[4] && id < bi[4]))) return;
-  bd[4] = d2; bi[4] = id; bp[4] = pos;
-#pragma unroll
-  for (int j = 4; j > 0; j--) {
-    const bool sw = (bd[j] < bd[j - 1]) || (bd[j] == bd[j - 1] && bi[j] < bi[j - 1]);
-    if (sw) {
-      float td = bd[j]; bd[j] = bd[j - 1]; bd[j - 1] = td;
-      uint32_t ti = bi[j]; bi[j] = bi[j - 1]; bi[j - 1] = ti;
-      uint32_t tp = bp[j]; bp[j] = bp[j - 1]; bp[j - 1] = tp;
-    }
-  }
-}
 
 // ----------------------------------------------------------------------------------------------------------------
 // k_knn5<LPQ>: the neighbour search of one Gauss-Newton iteration.  A 256-thread workgroup owns QB = 256/LPQ queries.

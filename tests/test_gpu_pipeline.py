@@ -124,3 +124,45 @@ def test_cpp_adapter_matches(orc, small_world, tmp_path):
         omp.process()
         assert np.abs(rows[k, :6] - ood.transform_sum).max() < POSE_TOL
     assert np.abs(rows[-1, 6:] - omp.transform("aft")).max() < 2e-3     # free-running live map: see test_gpu_mapping
+
+
+def test_full_size_hdl64_pipeline_vs_oracle(orc):
+    """BASELINE configs[3] shapes — HDL-64E sweeps (64 x 2048 = 131,072 points), 1,000,000-point frozen map — through the whole
+    streaming path (features -> odometry -> registration, look-ahead on) for 2 streams x 3 sweeps against the oracle chain."""
+    world = synth.World(half_extent=125.0)
+    cm, sm = world.make_map(1000000)
+    NS, T = 2, 3
+    starts = [(3.0 * s - 1.0, 0.0, 4.0 * s) for s in range(NS)]
+    data = []
+    for s in range(NS):
+        poses = synth.trajectory(T, start=starts[s])
+        data.append([synth.make_sweep(world, "HDL-64E", poses[t], poses[t + 1], seed=77 * s + t) for t in range(T)])
+    assert data[0][0].points.shape == (131072, 4)
+    pipe = loamx.Pipeline(NS)
+    pipe.set_frozen(cm, sm)
+    for s in range(NS):
+        pipe.set_state(s, aft=np.array([0, 0, 0, *starts[s]], np.float32))
+    pipe.upload([[(data[s][t].points, data[s][t].ring_sizes) for s in range(NS)] for t in range(T)])
+    got = []
+    for t in range(T):
+        assert pipe.step(t) == (loamx.SKIPPED if t == 0 else loamx.OK)
+        got.append([pipe.get(s) for s in range(NS)])
+    for s in range(NS):
+        osr, ood, omp = op.ScanRegistration(orc), op.LaserOdometry(orc), op.LaserMapping(orc)
+        omp.set_frozen(cm, sm)
+        omp.set_transform("aft", np.array([0, 0, 0, *starts[s]], np.float32))
+        for t in range(T):
+            ood.set_features(osr.process(data[s][t].points, data[s][t].ring_sizes))
+            ood.process()
+            if t > 0:
+                omp.set_transform("sum", ood.transform_sum)
+                omp.register_frozen(ood.last_corner(), ood.last_surf(), omp.associate())
+            tr, ts, aft, st = got[t][s]
+            assert np.abs(ts - ood.transform_sum).max() < POSE_TOL, (s, t)
+            assert np.abs(aft - omp.transform("aft")).max() < POSE_TOL, (s, t)
+            if t > 0:
+                assert st["odom_iterations"] == ood.stats()["iterations"] and st["map_iterations"] == omp.stats()["iterations"]
+        # sanity against ground truth (not the parity check): after two moving sweeps the registered position is near the
+        # sensor position at the end of the last sweep (LOAM with a 25 / 10 iteration budget, not a converged optimum)
+        gt = synth.trajectory(T, start=starts[s])[T]
+        assert np.abs(got[T - 1][s][2][3:] - gt[3:]).max() < 0.3

@@ -32,6 +32,7 @@ struct OdomProblem {
   int done;
   float matP[36];
   int stream_id;          // index of the stream this problem belongs to
+  OdomProblem* host_mirror;   // pinned host copy that k_odom_lm fills with transform / stats / done (no D2H copy on the stream)
   unsigned ticket;        // k_odom_lm: workgroup arrivals since the problem was set up (per-stream barrier)
   double* part;           // k_odom_lm: [2][16][LX_NSUM] partial normal equations of the stream's workgroups
 };
@@ -106,7 +107,7 @@ class OdometryBatch {
   DevBuf<int> ind_;
   DevBuf<OdomProblem> prob_;
   DevBuf<double> part_;
-  PinBuf<OdomProblem> h_prob_;
+  PinBuf<OdomProblem> h_prob_, h_mirror_;
   DevBuf<ToEndParams> te_;
   PinBuf<ToEndParams> h_te_;
   PinBuf<uint32_t> h_off_pin_;

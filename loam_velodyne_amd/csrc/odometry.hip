@@ -492,6 +492,15 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
       if (blockIdx.x == 0) {
         for (int r = 0; r < 6; r++) pb.transform[r] = T[r];
         if (sh_done) pb.done = 1;
+        // results also go to the host-visible mirror once they are final for this launch: the host then needs no copy on
+        // the stream, only the event behind the last launch
+        if (pb.host_mirror && (sh_done || iter == iter0 + n_iters - 1)) {
+          OdomProblem* hm = pb.host_mirror;
+          for (int r = 0; r < 6; r++) hm->transform[r] = T[r];
+          hm->stats = pb.stats;
+          hm->stats.iterations = iter + 1;
+          hm->done = sh_done;
+        }
       }
       LM_TS(9);
     }
@@ -590,6 +599,7 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
   if (const char* e = getenv("LOAMX_ODOM_CELL")) { const float v = (float)atof(e); if (v >= 0.25f && v <= 16.f) index_.cell_size = v; }
   index_.init(st_);
   prob_.reserve(n_streams);
+  h_mirror_.reserve(n_streams);
   part_.reserve((size_t)n_streams * OD_PART_STRIDE);
   h_prob_.reserve(n_streams);
   te_.reserve(n_streams);
@@ -717,6 +727,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       pb.done = 0;
       pb.ticket = 0;
       pb.stream_id = (int)s;
+      pb.host_mirror = h_mirror_.p + active.size();
       pb.part = part_.p + (size_t)active.size() * OD_PART_STRIDE;
       max_feat = std::max(max_feat, I.n_sharp + I.n_flat);
       max_sharp = std::max(max_sharp, I.n_sharp);
@@ -745,7 +756,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
           hipLaunchKernelGGL(k_odom_lm<2>, dim3(nb, na), dim3(OD_THREADS), 0, st_, prob_.p, params, it0, nit);
       }
     }
-    LX_HIP(hipMemcpyAsync(h_prob_.p, prob_.p, sizeof(OdomProblem) * na, hipMemcpyDeviceToHost, st_));
+    if (!max_feat) LX_HIP(hipMemcpyAsync(h_mirror_.p, prob_.p, sizeof(OdomProblem) * na, hipMemcpyDeviceToHost, st_));   // (no launch wrote the mirror)
     if (!ev_pose_) LX_HIP(hipEventCreateWithFlags(&ev_pose_, hipEventDisableTiming));
     LX_HIP(hipEventRecord(ev_pose_, st_));
     hipLaunchKernelGGL(k_te_patch, dim3((na + 63) / 64), dim3(64), 0, st_, prob_.p, na, te_.p);
@@ -776,10 +787,10 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
     for (uint32_t a = 0; a < na; a++) {
       OdomStream& S = *streams_[active[a]];
       // _transform.rot_* = rad + x re-derives the cached sin/cos (:599-601)
-      S.transform.set(h_prob_.p[a].transform);
-      S.stats.iterations = h_prob_.p[a].stats.iterations;
-      S.stats.sel = h_prob_.p[a].stats.sel;
-      S.stats.degenerate = h_prob_.p[a].stats.degenerate;
+      S.transform.set(h_mirror_.p[a].transform);
+      S.stats.iterations = h_mirror_.p[a].stats.iterations;
+      S.stats.sel = h_mirror_.p[a].stats.sel;
+      S.stats.degenerate = h_mirror_.p[a].stats.degenerate;
     }
   }
   // ---- pose integration (:626-649)

@@ -819,7 +819,7 @@ __device__ inline void surf_row(const Pose& T, const float4 po, const float4* __
 constexpr int LX_SOLVE_GROUPS = 9;
 __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_off, Pose* __restrict__ poses, SweepStats* __restrict__ stats,
                                    float* __restrict__ matP, const double* partials, uint32_t nblk, uint32_t nact, int iter,
-                                   float delta_t_abort, float delta_r_abort) {
+                                   float delta_t_abort, float delta_r_abort, SweepStats* host_stats, Pose* host_poses) {
   __shared__ double gsum[LX_SOLVE_GROUPS][LX_NSUM];
   __shared__ double sums[LX_NSUM];
   __shared__ float ws[216];
@@ -859,6 +859,7 @@ __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_o
   st.surf_q = (int)(ds_off[2 * s + 2] - ds_off[2 * s + 1]);
   if (st.sel < 50) {   // BasicLaserMapping.cpp:826-828: the iteration is burnt, pose untouched
     stats[s] = st;
+    if (host_stats) { host_stats[s] = st; host_poses[s] = poses[s]; }
     return;
   }
   float* P = matP + 36 * s;
@@ -883,6 +884,9 @@ __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_o
   const float deltaT = (float)sqrt((double)t0 * t0 + (double)t1 * t1 + (double)t2 * t2);
   if (deltaR < delta_r_abort && deltaT < delta_t_abort) st.done = 1;
   stats[s] = st;
+  // mirror in host-visible (pinned, mapped) memory: a blocking caller reads flags and poses after a stream sync, without
+  // two more copies on the stream
+  if (host_stats) { host_stats[s] = st; host_poses[s] = T; }
 }
 
 
@@ -890,7 +894,8 @@ __global__ __launch_bounds__(LX_RES_THREADS) void k_residual(
     const float4* __restrict__ ds_pts, const uint32_t* __restrict__ ds_off, const Pose* __restrict__ poses,
     const SweepStats* __restrict__ stats, const float4* __restrict__ cpts, const float4* __restrict__ spts,
     const uint32_t* __restrict__ nb, double* partials, uint32_t nblk, Pose* poses_rw, SweepStats* stats_rw,
-    float* __restrict__ matP, uint32_t* __restrict__ arrive, int iter, float delta_t_abort, float delta_r_abort) {
+    float* __restrict__ matP, uint32_t* __restrict__ arrive, int iter, float delta_t_abort, float delta_r_abort,
+    SweepStats* host_stats, Pose* host_poses) {
   const uint32_t s = blockIdx.y;
   if (stats[s].done) return;
   const uint32_t q0 = ds_off[2 * s], qm = ds_off[2 * s + 1], q1 = ds_off[2 * s + 2];
@@ -977,7 +982,7 @@ __global__ __launch_bounds__(LX_RES_THREADS) void k_residual(
   __syncthreads();
   if (!sh_last) return;
   __threadfence();   // acquire the other workgroups' partial sums
-  solve_sweep(s, ds_off, poses_rw, stats_rw, matP, partials, nblk, nact, iter, delta_t_abort, delta_r_abort);
+  solve_sweep(s, ds_off, poses_rw, stats_rw, matP, partials, nblk, nact, iter, delta_t_abort, delta_r_abort, host_stats, host_poses);
 }
 
 __global__ __launch_bounds__(256) void k_transform_full(float4* __restrict__ full, uint32_t n, const uint32_t* __restrict__ full_off,
@@ -1265,6 +1270,7 @@ void Registrar::run_async() {
   if (timing_) LX_HIP(hipEventRecord(ev_[0], st_));
   n_res_launch_ = 0;
   host_results_valid_ = false;
+  if (early_exit) memset(h_stats_.p, 0, sizeof(SweepStats) * ns);   // mirrors of sweeps that never reach an update stay "not done"
   hipLaunchKernelGGL(k_pose_init, dim3((ns + 63) / 64), dim3(64), 0, st_, d_guess_, ns, poses_.p, stats_.p, vox_.seg_minmax());
   if (n > 0) {
     const uint32_t nb = (n + 255) / 256;
@@ -1294,11 +1300,11 @@ void Registrar::run_async() {
         }
         hipLaunchKernelGGL(k_residual, dim3(nblk_, ns), dim3(LX_RES_THREADS), 0, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p,
                            corner_index.sorted(), surf_index.sorted(), nb_.p, partials_.p, nblk_, poses_.p, stats_.p, matP_.p,
-                           arrive_.p, it, params.delta_t_abort, params.delta_r_abort);
+                           arrive_.p, it, params.delta_t_abort, params.delta_r_abort, early_exit ? h_stats_.p : nullptr,
+                           early_exit ? h_poses_.p : nullptr);
       }
       if (!early_exit || it >= params.max_iterations) break;
-      LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * ns, hipMemcpyDeviceToHost, st_));
-      LX_HIP(hipMemcpyAsync(h_poses_.p, poses_.p, sizeof(Pose) * ns, hipMemcpyDeviceToHost, st_));
+      // (flags and poses are mirrored into h_stats_ / h_poses_ by the update step itself: nothing to copy)
       if (trace && th2 == 0) th2 = host_us();
       if (on_first_wait && !waited) { waited = true; on_first_wait(); }   // host work that overlaps the wait
       if (trace && th3 == 0) th3 = host_us();

@@ -8,7 +8,6 @@ __global__ void k_vox_init_minmax(int* mm, uint32_t nseg) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 6 * nseg) mm[i] = (i % 6) < 3 ? 2147483647 : (-2147483647 - 1);
 }
-__global__ void k_vox_set_u32(uint32_t* p, uint32_t v) { *p = v; }
 
 __global__ __launch_bounds__(256) void k_vox_ijk(const float4* __restrict__ pts, const uint8_t* __restrict__ valid, uint32_t n,
                                                  const uint32_t* __restrict__ seg_off, const uint32_t* __restrict__ seg_ids,
@@ -60,8 +59,9 @@ __global__ __launch_bounds__(256) void k_vox_keys(uint32_t n, const uint8_t* __r
 // reduction reads them contiguously instead of chasing vals[] -> pts[] one dependent load after the other
 __global__ __launch_bounds__(256) void k_vox_heads(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                    const float4* __restrict__ pts, uint32_t n, uint32_t nseg,
-                                                   uint32_t* __restrict__ head, float4* __restrict__ gathered) {
+                                                   uint32_t* __restrict__ head, float4* __restrict__ gathered, uint32_t* __restrict__ d_n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *d_n = n;   // element count for the device-n scan that follows
   if (i >= n) return;
   const unsigned long long k = keys[i];
   const bool ignored = (k >> VOX_SEG_SHIFT) >= nseg;
@@ -165,8 +165,8 @@ void VoxelPipeline::sort_reduce(const float4* pts, const uint8_t* valid, uint32_
   while ((1u << seg_bits) <= nseg) seg_bits++;
   LX_HIP(rocprim::radix_sort_pairs(sort_tmp_.p, tmp, keys_.p, keys_sorted_.p, vals_.p, vals_sorted_.p, (size_t)n, 0,
                                    VOX_SEG_SHIFT + seg_bits, st_));
-  hipLaunchKernelGGL(k_vox_heads, dim3(nb), dim3(256), 0, st_, keys_sorted_.p, vals_sorted_.p, pts, n, nseg, head_.p, gathered_.p);
-  hipLaunchKernelGGL(k_vox_set_u32, dim3(1), dim3(1), 0, st_, scratch_.p, n);
+  hipLaunchKernelGGL(k_vox_heads, dim3(nb), dim3(256), 0, st_, keys_sorted_.p, vals_sorted_.p, pts, n, nseg, head_.p, gathered_.p,
+                     scratch_.p);
   exclusive_scan_u32(head_.p, head_scan_.p, tile_sums_.p, scratch_.p, scratch_.p + 1, n, st_);
   hipLaunchKernelGGL(k_vox_reduce, dim3(nb), dim3(256), 0, st_, keys_sorted_.p, gathered_.p, head_.p, head_scan_.p, n, out);
   hipLaunchKernelGGL(k_vox_offsets, dim3((nseg + 64) / 64), dim3(64), 0, st_, keys_sorted_.p, head_scan_.p, n, nseg, d_out_off);

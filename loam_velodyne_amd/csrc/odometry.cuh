@@ -16,6 +16,8 @@ struct OdomStats {
   int iterations, sel, frame, degenerate;
 };
 
+struct ToEndParams;
+
 // device-side description of one stream's odometry problem
 struct OdomProblem {
   const float4* sharp; uint32_t n_sharp;
@@ -32,6 +34,7 @@ struct OdomProblem {
   int done;
   float matP[36];
   int stream_id;          // index of the stream this problem belongs to
+  ToEndParams* te_out;        // re-projection parameters of this stream (completed by k_odom_lm)
   OdomProblem* host_mirror;   // pinned host copy that k_odom_lm fills with transform / stats / done (no D2H copy on the stream)
   unsigned ticket;        // k_odom_lm: workgroup arrivals since the problem was set up (per-stream barrier)
   double* part;           // k_odom_lm: [2][16][LX_NSUM] partial normal equations of the stream's workgroups

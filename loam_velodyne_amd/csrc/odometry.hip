@@ -494,6 +494,16 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
         if (sh_done) pb.done = 1;
         // results also go to the host-visible mirror once they are final for this launch: the host then needs no copy on
         // the stream, only the event behind the last launch
+        if (sh_done || iter == iter0 + n_iters - 1) {
+          // ... and into the re-projection parameters of the sweep's tail (transformToEnd with the optimised transform): the
+          // tail is enqueued right behind the last launch, no host round trip and no extra kernel
+          ToEndParams& P = *pb.te_out;
+          for (int k = 0; k < 6; k++) P.T[k] = T[k];
+          for (int k = 0; k < 3; k++) {   // the host caches sin/cos of a float angle (Angle.h); double-then-round is within an ulp of it
+            P.sT[k] = (float)sin((double)T[k]);
+            P.cT[k] = (float)cos((double)T[k]);
+          }
+        }
         if (pb.host_mirror && (sh_done || iter == iter0 + n_iters - 1)) {
           OdomProblem* hm = pb.host_mirror;
           for (int r = 0; r < 6; r++) hm->transform[r] = T[r];
@@ -728,6 +738,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       pb.ticket = 0;
       pb.stream_id = (int)s;
       pb.host_mirror = h_mirror_.p + active.size();
+      pb.te_out = te_.p + s;
       pb.part = part_.p + (size_t)active.size() * OD_PART_STRIDE;
       max_feat = std::max(max_feat, I.n_sharp + I.n_flat);
       max_sharp = std::max(max_sharp, I.n_sharp);
@@ -743,6 +754,8 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   memcpy(h_off_pin_.p, h_cur_off_.data(), sizeof(uint32_t) * (K + 1));
   LX_HIP(hipMemcpyAsync(d_cur_off_.p, h_off_pin_.p, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st_));
   LX_HIP(hipMemcpyAsync(te_.p, h_te_.p, sizeof(ToEndParams) * ns, hipMemcpyHostToDevice, st_));
+  index_.prepare(K);   // bounding-box accumulators of the NEXT index: reset here, far ahead of the tail
+  const bool index_prepared = true;
   if (na) {
     LX_HIP(hipMemcpyAsync(prob_.p, h_prob_.p, sizeof(OdomProblem) * na, hipMemcpyHostToDevice, st_));
     if (max_feat) {
@@ -759,7 +772,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
     if (!max_feat) LX_HIP(hipMemcpyAsync(h_mirror_.p, prob_.p, sizeof(OdomProblem) * na, hipMemcpyDeviceToHost, st_));   // (no launch wrote the mirror)
     if (!ev_pose_) LX_HIP(hipEventCreateWithFlags(&ev_pose_, hipEventDisableTiming));
     LX_HIP(hipEventRecord(ev_pose_, st_));
-    hipLaunchKernelGGL(k_te_patch, dim3((na + 63) / 64), dim3(64), 0, st_, prob_.p, na, te_.p);
+    if (!max_feat) hipLaunchKernelGGL(k_te_patch, dim3((na + 63) / 64), dim3(64), 0, st_, prob_.p, na, te_.p);   // (otherwise k_odom_lm did it)
   }
   // ---- re-project to the sweep end (:651-652), hand over as "last" clouds and rebuild their index (:654-664): enqueued
   // right behind the iterations; the host only waits for the poses
@@ -769,7 +782,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   std::swap(cur_.p, last_.p);
   std::swap(cur_.cap, last_.cap);
   h_last_off_ = h_cur_off_;
-  index_.build(last_.p, h_last_off_.data(), K);
+  index_.build(last_.p, h_last_off_.data(), K, d_cur_off_.p, index_prepared);
   if (!ev_tail_) LX_HIP(hipEventCreateWithFlags(&ev_tail_, hipEventDisableTiming));
   LX_HIP(hipEventRecord(ev_tail_, st_));
   tail_pending_ = true;

@@ -53,7 +53,9 @@ class SubMapIndexBatch {
  public:
   void init(hipStream_t st);
   // d_pts: concatenated points; h_off: K+1 host offsets.  Asynchronous on the stream.
-  void build(const float4* d_pts, const uint32_t* h_off, uint32_t K);
+  // d_off_ready: the K+1 offsets already on the device (skips the upload); prepared: prepare(K) was enqueued earlier
+  void build(const float4* d_pts, const uint32_t* h_off, uint32_t K, const uint32_t* d_off_ready = nullptr, bool prepared = false);
+  void prepare(uint32_t K);
   float cell_size = 1.05f;   // initial cell edge (grown by 1.25x while the cell table would exceed its budget)
   const float4* sorted() const { return sorted_.p; }
   const uint32_t* cell_start(uint32_t c) const { return cell_start_.p; }   // tables are addressed through desc(c)->cell_base

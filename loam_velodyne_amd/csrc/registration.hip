@@ -116,11 +116,6 @@ __global__ __launch_bounds__(256) void k_cell_count(const float4* __restrict__ p
   atomicAdd(&counts[c], 1u);
 }
 
-__global__ __launch_bounds__(256) void k_copy_u32_dn(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
-                                                     const uint32_t* d_n) {
-  const uint32_t n = *d_n;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[i];
-}
 
 __global__ __launch_bounds__(256) void k_cell_scatter(const float4* __restrict__ pts, uint32_t n,
                                                       const uint32_t* __restrict__ cell_of, uint32_t* __restrict__ cursor,
@@ -160,8 +155,7 @@ void SubMapIndex::build(const float4* d_pts, uint32_t n) {
   hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(1), 0, st_, scratch_.p, d_desc_.p, LX_MAX_CELLS);
   hipLaunchKernelGGL(k_zero_u32_dn, dim3(2048), dim3(256), 0, st_, cursor_.p, scratch_.p + 6);
   hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st_, d_pts, n, d_desc_.p, cell_of_.p, cursor_.p);
-  exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 8, scratch_.p + 7, LX_MAX_CELLS, st_);
-  hipLaunchKernelGGL(k_copy_u32_dn, dim3(2048), dim3(256), 0, st_, cell_start_.p, cursor_.p, scratch_.p + 6);
+  exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 8, scratch_.p + 7, LX_MAX_CELLS, st_, cursor_.p);
   hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(256), 0, st_, d_pts, n, cell_of_.p, cursor_.p, sorted_.p);
   LX_HIP(hipGetLastError());
 }
@@ -311,30 +305,41 @@ void SubMapIndexBatch::init(hipStream_t st) {
   tile_sums_.reserve(8192);
 }
 
-void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_t K) {
+// the bounding-box accumulators can be reset long before the points exist (e.g. ahead of the iterations whose result the
+// points depend on): build(..., prepared = true) then skips that launch
+void SubMapIndexBatch::prepare(uint32_t K) {
+  LX_REQUIRE(K >= 1 && K <= 4096, "too many clouds in one index batch");
+  enc_.reserve((size_t)6 * K + 6);
+  hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K);
+}
+
+void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_t K, const uint32_t* d_off_ready, bool prepared) {
   LX_REQUIRE(K >= 1 && K <= 4096, "too many clouds in one index batch");
   const uint32_t n = h_off[K];
   d_off_.reserve(K + 2);
   d_desc_.reserve(K + 1);
   enc_.reserve((size_t)6 * K + 6);
-  h_off_pin_.reserve(K + 2);
-  memcpy(h_off_pin_.p, h_off, sizeof(uint32_t) * (K + 1));
-  LX_HIP(hipMemcpyAsync(d_off_.p, h_off_pin_.p, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st_));
+  const uint32_t* d_off = d_off_ready;   // the caller may already hold the offsets on the device
+  if (!d_off) {
+    h_off_pin_.reserve(K + 2);
+    memcpy(h_off_pin_.p, h_off, sizeof(uint32_t) * (K + 1));
+    LX_HIP(hipMemcpyAsync(d_off_.p, h_off_pin_.p, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st_));
+    d_off = d_off_.p;
+  }
   sorted_.reserve((size_t)n + 1);
   cell_of_.reserve((size_t)n + 1);
   cell_start_.reserve((size_t)LX_MAX_CELLS + 2);
   cursor_.reserve((size_t)LX_MAX_CELLS + 2);
-  hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K);
+  if (!prepared) hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K);
   uint32_t max_len = 0;
   for (uint32_t c = 0; c < K; c++) max_len = std::max(max_len, h_off[c + 1] - h_off[c]);
   const uint32_t nbx = std::min<uint32_t>(std::max<uint32_t>((max_len + 255) / 256, 1u), 32u);
-  hipLaunchKernelGGL(k_bb_bbox, dim3(nbx, K), dim3(256), 0, st_, d_pts, d_off_.p, enc_.p);
-  hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1), 0, st_, enc_.p, d_off_.p, K, d_desc_.p, scratch_.p, LX_MAX_CELLS, cell_size);
+  hipLaunchKernelGGL(k_bb_bbox, dim3(nbx, K), dim3(256), 0, st_, d_pts, d_off, enc_.p);
+  hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1), 0, st_, enc_.p, d_off, K, d_desc_.p, scratch_.p, LX_MAX_CELLS, cell_size);
   hipLaunchKernelGGL(k_zero_u32_dn, dim3(2048), dim3(256), 0, st_, cursor_.p, scratch_.p + 0);
-  if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off_.p, K, d_desc_.p, cell_of_.p, cursor_.p);
-  exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 2, scratch_.p + 1, LX_MAX_CELLS, st_);
-  hipLaunchKernelGGL(k_copy_u32_dn, dim3(2048), dim3(256), 0, st_, cell_start_.p, cursor_.p, scratch_.p + 0);
-  if (n) hipLaunchKernelGGL(k_bb_scatter, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off_.p, K, cell_of_.p, cursor_.p, sorted_.p);
+  if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, d_desc_.p, cell_of_.p, cursor_.p);
+  exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 2, scratch_.p + 1, LX_MAX_CELLS, st_, cursor_.p);
+  if (n) hipLaunchKernelGGL(k_bb_scatter, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, cell_of_.p, cursor_.p, sorted_.p);
   LX_HIP(hipGetLastError());
 }
 

@@ -47,8 +47,10 @@ __global__ __launch_bounds__(1024) void k_scan_sums(uint32_t* __restrict__ tile_
 }
 
 // out[i] += tile offset; also writes out[n] = total (so out is a proper "starts" array of n+1 entries)
+// out2 (optional): a second copy of the result (counting sorts keep one as the table and consume the other as cursors)
 __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ tile_sums,
-                                                  const uint32_t* __restrict__ d_n, const uint32_t* __restrict__ d_total) {
+                                                  const uint32_t* __restrict__ d_n, const uint32_t* __restrict__ d_total,
+                                                  uint32_t* __restrict__ out2) {
   const uint32_t n = *d_n;
   const uint32_t base = blockIdx.x * SCAN_TILE;
   if (base >= n) return;
@@ -56,16 +58,23 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, co
   const uint32_t i0 = base + threadIdx.x * 8;
 #pragma unroll
   for (int k = 0; k < 8; k++)
-    if (i0 + k < n) out[i0 + k] += off;
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *d_total;
+    if (i0 + k < n) {
+      const uint32_t v = out[i0 + k] + off;
+      out[i0 + k] = v;
+      if (out2) out2[i0 + k] = v;
+    }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out[n] = *d_total;
+    if (out2) out2[n] = *d_total;
+  }
 }
 
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums /* >= 8192 */, const uint32_t* d_n,
-                               uint32_t* d_total, uint32_t max_n, hipStream_t st) {
+                               uint32_t* d_total, uint32_t max_n, hipStream_t st, uint32_t* out2) {
   const uint32_t ntiles = (max_n + SCAN_TILE - 1) / SCAN_TILE;
   hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, st, in, out, tile_sums, d_n);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums, d_n, d_total);
-  hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, st, out, tile_sums, d_n, d_total);
+  hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, st, out, tile_sums, d_n, d_total, out2);
 }
 
 __global__ void k_scan_set_n(uint32_t* p, uint32_t v) { *p = v; }

@@ -41,7 +41,7 @@ class RawBinner {
  private:
   hipStream_t st_ = nullptr;
   DevBuf<int> ring_of_;
-  DevBuf<uint32_t> blk_cnt_, blk_pre_, scratch_, imu_first_;
+  DevBuf<uint32_t> blk_cnt_, blk_pre_, scratch_, imu_first_, blk_idx_;
 };
 
 }  // namespace loamx

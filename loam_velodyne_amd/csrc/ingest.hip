@@ -52,9 +52,17 @@ __device__ inline float ori_second_half(float x, float z, float endOri) {
   return ori;
 }
 
-__global__ void k_raw_init(uint32_t* scratch, uint32_t* imu_first, uint32_t H) {
+// scratch: [0] j* (first kept point that sets halfPassed), [1] last kept point, [2] startOri, [3] endOri (float bits)
+__global__ void k_raw_init(const float4* __restrict__ raw, uint32_t n, uint32_t* scratch, uint32_t* imu_first, uint32_t H) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e == 0) { scratch[0] = 0xffffffffu; scratch[1] = 0u; }   // j* (first kept point that sets halfPassed), last kept point
+  if (e == 0) {
+    scratch[0] = 0xffffffffu;
+    scratch[1] = 0u;
+    float startOri, endOri;
+    sweep_oris(raw, n, startOri, endOri);
+    scratch[2] = __float_as_uint(startOri);
+    scratch[3] = __float_as_uint(endOri);
+  }
   if (e < H) imu_first[e] = 0xffffffffu;
 }
 
@@ -82,20 +90,37 @@ __device__ inline uint32_t imu_need(const ImuTable& I, float relTime) {
 __global__ __launch_bounds__(256) void k_raw_imu_need(const float4* __restrict__ raw, uint32_t n, float scan_period, const int* __restrict__ ring_of,
                                                       const uint32_t* __restrict__ jstar, ImuTable I, uint32_t* __restrict__ first) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || ring_of[i] < 0) return;
-  float startOri, endOri;
-  sweep_oris(raw, n, startOri, endOri);
-  const float4 r = raw[i];
-  const float relTime = rel_time_of(i, r.y, r.x, startOri, endOri, *jstar, scan_period);
-  const uint32_t v = imu_need(I, relTime);
-  if (v > I.idx0) atomicMin(&first[v], i);
-}
-__global__ void k_raw_imu_suffix(uint32_t* __restrict__ first, uint32_t H) {
-  uint32_t m = 0xffffffffu;
-  for (int v = (int)H - 1; v >= 0; v--) {
-    m = first[v] < m ? first[v] : m;
-    first[v] = m;
+  const bool active = i < n && ring_of[i] >= 0;
+  uint32_t v = 0;
+  if (active) {
+    const float startOri = __uint_as_float(jstar[2]), endOri = __uint_as_float(jstar[3]);
+    const float4 r = raw[i];
+    const float relTime = rel_time_of(i, r.y, r.x, startOri, endOri, jstar[0], scan_period);
+    v = imu_need(I, relTime);
   }
+  // neighbouring points need the same history index: only the first lane of a run of equal v (it has the run's smallest
+  // point index) issues the atomic
+  const int lane = threadIdx.x & 63;
+  const uint32_t pv = __shfl_up(v, 1, 64);
+  const unsigned long long act = __ballot(active);
+  const bool head = active && (lane == 0 || pv != v || !((act >> (lane > 0 ? lane - 1 : 0)) & 1ull));
+  if (head && v > I.idx0) atomicMin(&first[v], i);
+}
+// first[v] = min over u >= v (one workgroup; H <= 4096: Hillis-Steele steps over LDS)
+__global__ __launch_bounds__(1024) void k_raw_imu_suffix(uint32_t* __restrict__ first, uint32_t H) {
+  __shared__ uint32_t a[4096];
+  for (uint32_t v = threadIdx.x; v < H; v += blockDim.x) a[v] = first[v];
+  __syncthreads();
+  for (uint32_t d = 1; d < H; d <<= 1) {
+    uint32_t t[4];
+    int k = 0;
+    for (uint32_t v = threadIdx.x; v < H; v += blockDim.x, k++) t[k] = v + d < H ? min(a[v], a[v + d]) : a[v];
+    __syncthreads();
+    k = 0;
+    for (uint32_t v = threadIdx.x; v < H; v += blockDim.x, k++) a[v] = t[k];
+    __syncthreads();
+  }
+  for (uint32_t v = threadIdx.x; v < H; v += blockDim.x) first[v] = a[v];
 }
 
 // Angle(float): cached sin / cos of a float angle (Angle.h:16-30); double-then-round, within an ulp of the host's float libm
@@ -151,35 +176,58 @@ __device__ inline void imu_project(const ImuTable& I, const uint32_t* __restrict
   }
 }
 
+// per workgroup: ring histogram, first point that would set halfPassed, last kept point (k_raw_colscan reduces the two
+// index arrays — thousands of atomics on ONE global word per launch serialise for tens of microseconds)
 __global__ __launch_bounds__(256) void k_raw_classify(const float4* __restrict__ raw, uint32_t n, MapperParams M, int* __restrict__ ring_of,
-                                                      uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ jstar) {
+                                                      uint32_t* __restrict__ blk_cnt, const uint32_t* __restrict__ jstar,
+                                                      uint32_t* __restrict__ blk_first_pass, uint32_t* __restrict__ blk_last_kept) {
   __shared__ uint32_t hist[RawBinner::MAX_RINGS];
+  __shared__ uint32_t s_first, s_last;
+  if (threadIdx.x == 0) { s_first = 0xffffffffu; s_last = 0u; }
   for (uint32_t r = threadIdx.x; r < M.n_rings; r += blockDim.x) hist[r] = 0;
   __syncthreads();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool kept = false, passes = false;
   if (i < n) {
-    float startOri, endOri;
-    sweep_oris(raw, n, startOri, endOri);
+    const float startOri = __uint_as_float(jstar[2]);
     float x, y, z;
     const int id = classify(raw[i], M, x, y, z);
     ring_of[i] = id;
     if (id >= 0) {
+      kept = true;
       atomicAdd(&hist[id], 1u);
-      bool passes;
       (void)ori_first_half(x, z, startOri, passes);
-      if (passes) atomicMin(jstar, i);
-      atomicMax(jstar + 1, i);   // last kept point
     }
   }
+  // one atomic per wave: the lowest passing lane holds the wave's smallest index, the highest kept lane its largest
+  const unsigned long long mp = __ballot(passes), mk = __ballot(kept);
+  const int lane = threadIdx.x & 63;
+  if (mp && lane == __builtin_ctzll(mp)) atomicMin(&s_first, i);
+  if (mk && lane == 63 - __builtin_clzll(mk)) atomicMax(&s_last, i + 1u);   // (+1: 0 = no kept point in this workgroup)
   __syncthreads();
+  if (threadIdx.x == 0) { blk_first_pass[blockIdx.x] = s_first; blk_last_kept[blockIdx.x] = s_last; }
   for (uint32_t r = threadIdx.x; r < M.n_rings; r += blockDim.x) blk_cnt[(size_t)blockIdx.x * M.n_rings + r] = hist[r];
 }
 
 // one workgroup per ring: exclusive scan of the ring's column of workgroup counts
+// (workgroup 0 also reduces the per-workgroup first-pass / last-kept indices into scratch[0] / scratch[1])
 __global__ __launch_bounds__(256) void k_raw_colscan(const uint32_t* __restrict__ blk_cnt, uint32_t nblk, uint32_t nrings,
-                                                     uint32_t* __restrict__ blk_pre, uint32_t* __restrict__ ring_cnt) {
+                                                     uint32_t* __restrict__ blk_pre, uint32_t* __restrict__ ring_cnt,
+                                                     const uint32_t* __restrict__ blk_first_pass, const uint32_t* __restrict__ blk_last_kept,
+                                                     uint32_t* __restrict__ scratch) {
   __shared__ uint32_t sc[256];
   const uint32_t r = blockIdx.x;
+  if (r == 0) {
+    __shared__ uint32_t s_first, s_last;
+    if (threadIdx.x == 0) { s_first = 0xffffffffu; s_last = 0u; }
+    __syncthreads();
+    uint32_t f = 0xffffffffu, l = 0u;
+    for (uint32_t b = threadIdx.x; b < nblk; b += 256) { f = min(f, blk_first_pass[b]); l = max(l, blk_last_kept[b]); }
+    atomicMin(&s_first, f);
+    atomicMax(&s_last, l);
+    __syncthreads();
+    if (threadIdx.x == 0) { scratch[0] = s_first; scratch[1] = s_last ? s_last - 1u : 0u; }
+  }
   uint32_t base = 0;
   for (uint32_t b0 = 0; b0 < nblk; b0 += 256) {
     const uint32_t b = b0 + threadIdx.x;
@@ -233,8 +281,7 @@ __global__ __launch_bounds__(256) void k_raw_scatter(const float4* __restrict__ 
   if (id < 0) return;
   for (int w = 0; w < wid; w++) rank += wcnt[w][id];
   const uint32_t pos = ring_off[id] + blk_pre[(size_t)blockIdx.x * M.n_rings + id] + rank;
-  float startOri, endOri;
-  sweep_oris(raw, n, startOri, endOri);
+  const float startOri = __uint_as_float(jstar[2]), endOri = __uint_as_float(jstar[3]);
   const float4 r = raw[i];
   float x = r.y, y = r.z, z = r.x;
   const float relTime = rel_time_of(i, x, z, startOri, endOri, jstar[0], scan_period);   // :228
@@ -255,16 +302,19 @@ void RawBinner::run(const float4* d_raw, uint32_t n, const MapperParams& m, floa
   ring_of_.reserve(n + 1);
   blk_cnt_.reserve((size_t)nb * m.n_rings + 1);
   blk_pre_.reserve((size_t)nb * m.n_rings + 1);
-  scratch_.reserve(4);
+  scratch_.reserve(8);
   ImuTable I;
   if (imu) I = *imu;
+  LX_REQUIRE(I.H <= 4096, "IMU history longer than 4096 states");
   imu_first_.reserve(I.H + 1);
-  hipLaunchKernelGGL(k_raw_init, dim3((I.H + 256) / 256), dim3(256), 0, st_, scratch_.p, imu_first_.p, I.H);
-  hipLaunchKernelGGL(k_raw_classify, dim3(nb), dim3(256), 0, st_, d_raw, n, m, ring_of_.p, blk_cnt_.p, scratch_.p);
-  hipLaunchKernelGGL(k_raw_colscan, dim3(m.n_rings), dim3(256), 0, st_, blk_cnt_.p, nb, m.n_rings, blk_pre_.p, d_ring_cnt);
+  hipLaunchKernelGGL(k_raw_init, dim3((I.H + 256) / 256), dim3(256), 0, st_, d_raw, n, scratch_.p, imu_first_.p, I.H);
+  blk_idx_.reserve(2 * (size_t)nb + 2);
+  hipLaunchKernelGGL(k_raw_classify, dim3(nb), dim3(256), 0, st_, d_raw, n, m, ring_of_.p, blk_cnt_.p, scratch_.p, blk_idx_.p, blk_idx_.p + nb);
+  hipLaunchKernelGGL(k_raw_colscan, dim3(m.n_rings), dim3(256), 0, st_, blk_cnt_.p, nb, m.n_rings, blk_pre_.p, d_ring_cnt, blk_idx_.p,
+                     blk_idx_.p + nb, scratch_.p);
   if (I.H) {
     hipLaunchKernelGGL(k_raw_imu_need, dim3(nb), dim3(256), 0, st_, d_raw, n, scan_period, ring_of_.p, scratch_.p, I, imu_first_.p);
-    hipLaunchKernelGGL(k_raw_imu_suffix, dim3(1), dim3(1), 0, st_, imu_first_.p, I.H);
+    hipLaunchKernelGGL(k_raw_imu_suffix, dim3(1), dim3(1024), 0, st_, imu_first_.p, I.H);
   }
   hipLaunchKernelGGL(k_raw_scatter, dim3(nb), dim3(256), 0, st_, d_raw, n, m, scan_period, ring_of_.p, blk_pre_.p, d_ring_cnt, scratch_.p,
                      d_out, I, imu_first_.p, d_last);

@@ -8,6 +8,8 @@
 #include "features.cuh"
 #include "odometry.cuh"
 #include "registration.cuh"
+#include <atomic>
+#include <functional>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -82,30 +84,41 @@ class Pipeline {
   float last_ms[4] = {0, 0, 0, 0};
   bool timing = false;
 
-  // the odometry look-ahead runs on a persistent host thread (it blocks on its Gauss-Newton results)
+  // the odometry look-ahead runs on a persistent host thread (it blocks on its Gauss-Newton results).  Hand-overs between
+  // the two threads happen every ~0.7 ms, so both sides spin briefly on an atomic before they fall back to the condition
+  // variable (a sleeping thread costs tens of microseconds to wake, on the critical path of every step)
   std::thread worker;
   std::mutex mu;
   std::condition_variable cv;
-  int job = -1;
-  bool job_done = true, quit = false;
+  std::atomic<int> job{-1};
+  std::atomic<bool> job_done{true};
+  bool quit = false;
   std::exception_ptr job_err;
+  static bool spin_until(const std::function<bool()>& ready, double max_us) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!ready()) {
+      if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > max_us) return false;
+      __builtin_ia32_pause();
+    }
+    return true;
+  }
   void worker_main() {
     (void)hipSetDevice(device);
     for (;;) {
       int t;
-      {
+      if (!spin_until([&] { return job.load(std::memory_order_acquire) >= 0; }, 400.0)) {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return job >= 0 || quit; });
+        cv.wait(lk, [&] { return job.load(std::memory_order_acquire) >= 0 || quit; });
         if (quit) return;
-        t = job;
-        job = -1;
       }
+      t = job.exchange(-1, std::memory_order_acq_rel);
+      if (t < 0) continue;
       std::exception_ptr err;
       try { trO[0] = tr_us(); run_odometry((uint32_t)t); trO[3] = tr_us(); } catch (...) { err = std::current_exception(); }
       {
         std::lock_guard<std::mutex> lk(mu);
         job_err = err;
-        job_done = true;
+        job_done.store(true, std::memory_order_release);
       }
       cv.notify_all();
     }
@@ -114,21 +127,24 @@ class Pipeline {
     if (!worker.joinable()) worker = std::thread([this] { worker_main(); });
     {
       std::lock_guard<std::mutex> lk(mu);
-      job = (int)t;
-      job_done = false;
+      job_done.store(false, std::memory_order_release);
+      job.store((int)t, std::memory_order_release);
     }
     cv.notify_all();
   }
   void join_job() {
-    std::unique_lock<std::mutex> lk(mu);
-    cv.wait(lk, [&] { return job_done; });
+    if (!spin_until([&] { return job_done.load(std::memory_order_acquire); }, 2000.0)) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return job_done.load(std::memory_order_acquire); });
+    }
+    std::lock_guard<std::mutex> lk(mu);
     if (job_err) { std::exception_ptr e = job_err; job_err = nullptr; std::rethrow_exception(e); }
   }
 
   ~Pipeline() {
     if (worker.joinable()) {
       { std::lock_guard<std::mutex> lk(mu); quit = true; }
-      cv.notify_all();
+      cv.notify_all();   // (the worker leaves its spin phase after 0.4 ms and then sees quit)
       worker.join();
     }
     fx.clear();

@@ -73,3 +73,37 @@ def test_position_shift_from_acceleration(orc, small_world):
     shift = res["full"][:, 0] - pts[:, 0]
     assert np.abs(shift - 0.5 * a * rel ** 2).max() < 2e-3
     assert np.abs(res["full"][:, 1:3] - pts[:, 1:3]).max() < 1e-5
+
+
+def test_mapping_blend_is_the_stated_formula(orc, small_world):
+    """transformUpdate with IMU data (BasicLaserMapping.cpp:171-203): from one prior state, the pose with an IMU history is
+    0.998 x (pose without) + 0.002 x (interpolated IMU pitch / roll) on rot_x / rot_z and identical elsewhere."""
+    poses = synth.trajectory(3)
+    osr, ood = op.ScanRegistration(orc), op.LaserOdometry(orc)
+    plain, blend = op.LaserMapping(orc), op.LaserMapping(orc)
+    imu = [(0.05 * j, 0.03 * np.cos(j), 0.02 * np.sin(j)) for j in range(12)]      # stamp, roll, pitch
+    for k in range(3):
+        sw = synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=k, az_steps=700)
+        ood.set_features(osr.process(sw.points, sw.ring_sizes))
+        ood.process()
+        lc, ls, fe, ts = ood.last_corner(), ood.last_surf(), ood.full_to_end(), ood.transform_sum
+        if k == 2:
+            # same prior state for both
+            blend.load_cubes(plain.cloud("corner_cubes"), plain.cloud("surf_cubes"))
+            blend.set_transform("aft", plain.transform("aft"))
+            blend.set_transform("bef", plain.transform("bef"))
+            for m in imu:
+                blend.update_imu(*m)
+            t_odo = 0.23                                       # + scanPeriod 0.1 -> 0.33: between the samples at 0.30 and 0.35
+            blend.set_time(t_odo)
+            blend.set_inputs(lc, ls, fe, ts)
+            assert blend.process()
+        plain.set_inputs(lc, ls, fe, ts)
+        assert plain.process()
+    a, b = plain.transform("aft"), blend.transform("aft")
+    # interpolated state at t_odo + scanPeriod = 0.33 between samples 6 (0.30) and 7 (0.35): ratio = (0.35 - 0.33) / 0.05 = 0.4
+    roll = imu[7][1] * 0.6 + imu[6][1] * 0.4
+    pitch = imu[7][2] * 0.6 + imu[6][2] * 0.4
+    assert abs(b[0] - (0.998 * a[0] + 0.002 * pitch)) < 2e-6
+    assert abs(b[2] - (0.998 * a[2] + 0.002 * roll)) < 2e-6
+    assert np.abs(b[[1, 3, 4, 5]] - a[[1, 3, 4, 5]]).max() < 1e-6

@@ -131,6 +131,26 @@ void orc_scanreg_get_imu_trans(void* h, float* out12) {
   for (int k = 0; k < 12; k++) out12[k] = ((ScanRegistration*)h)->imuTrans[k];
 }
 
+// ---- math primitives as the oracle restates them (pinned against the reference's own headers in tests/) ----
+void orc_angle(float rad, int negate, float add, float* out3) {
+  Angle a(rad);
+  if (add != 0.f) a += add;
+  const Angle b = negate ? -a : a;
+  out3[0] = b.rad(); out3[1] = b.cos(); out3[2] = b.sin();
+}
+// which: 0 rotateZXY, 1 rotateYXZ, 2 rotX, 3 rotY, 4 rotZ
+void orc_rotate(int which, float* p3, float a0, float a1, float a2) {
+  Vec3 v{p3[0], p3[1], p3[2]};
+  switch (which) {
+    case 0: rotateZXY(v, Angle(a0), Angle(a1), Angle(a2)); break;
+    case 1: rotateYXZ(v, Angle(a0), Angle(a1), Angle(a2)); break;
+    case 2: rotX(v, Angle(a0)); break;
+    case 3: rotY(v, Angle(a0)); break;
+    default: rotZ(v, Angle(a0)); break;
+  }
+  p3[0] = v.x; p3[1] = v.y; p3[2] = v.z;
+}
+
 // ---- transform maintenance (BasicTransformMaintenance) + wire conversions ----
 void orc_tm_associate(const float* sum6, const float* bef6, const float* aft6, float* mapped6) {
   TransformMaintenance t;
@@ -143,6 +163,22 @@ void orc_tm_associate(const float* sum6, const float* bef6, const float* aft6, f
 }
 void orc_wire_pose_to_quat(const float* rot3, double* q4) { wire_pose_to_quat(rot3, q4); }
 void orc_wire_quat_to_pose(const double* q4, float* rot3) { wire_quat_to_pose(q4, rot3); }
+
+// the kept points of a raw sweep in firing order, before any IMU projection: out5 = (x, y, z, intensity, relTime) per point,
+// ring[] their scan ids; returns the count (tests feed these to the reference's projectPointToStartOfSweep)
+int orc_multiscan_trace(const float* raw, int n, float lower_deg, float upper_deg, int n_rings, float scan_period, float* out5, int* ring, int cap) {
+  MultiScanMapper m;
+  m.set(lower_deg, upper_deg, (uint16_t)n_rings);
+  BinTrace tr;
+  bin_sweep(raw, (size_t)n, m, scan_period, nullptr, &tr);
+  const int cnt = (int)tr.points.size();
+  for (int i = 0; i < cnt && i < cap; i++) {
+    out5[5 * i] = tr.points[i].x; out5[5 * i + 1] = tr.points[i].y; out5[5 * i + 2] = tr.points[i].z; out5[5 * i + 3] = tr.points[i].i;
+    out5[5 * i + 4] = tr.relTime[i];
+    ring[i] = tr.ring[i];
+  }
+  return cnt;
+}
 
 // ---- odometry ----
 void* orc_odom_create() { return new LaserOdometry(); }

@@ -49,7 +49,7 @@ class ScanRegistration {
     Angle roll, pitch, yaw;
     Vec3 position, velocity, acceleration;
   };
-  std::deque<IMUState> imuHistory;   // CircularBuffer<IMUState>, capacity cfg.imuHistorySize (configure :48-53)
+  std::deque<IMUState> imuHistory;   // CircularBuffer<IMUState>, capacity max(200, cfg.imuHistorySize) (configure :48-53, see update_imu_data)
   size_t imuIdx = 0;
   IMUState imuStart, imuCur;
   Vec3 imuPositionShift;
@@ -67,7 +67,9 @@ class ScanRegistration {
                            prev.position.z + prev.velocity.z * timeDiff + 0.5f * acc.z * timeDiff * timeDiff};
       newState.velocity = {prev.velocity.x + acc.x * timeDiff, prev.velocity.y + acc.y * timeDiff, prev.velocity.z + acc.z * timeDiff};
     }
-    if (imuHistory.size() >= (size_t)cfg.imuHistorySize) imuHistory.pop_front();
+    // capacity: the buffer is constructed with 200 slots and configure() only ever GROWS it (ensureCapacity, CircularBuffer.h:
+    // 53-66: `_capacity < reqCapacity`), so an imuHistorySize below 200 has no effect
+    if (imuHistory.size() >= (size_t)std::max(200, cfg.imuHistorySize)) imuHistory.pop_front();
     imuHistory.push_back(newState);
   }
   static void interpolate(const IMUState& start, const IMUState& end, float ratio, IMUState& result) {   // .h:107-131

@@ -30,7 +30,14 @@ struct MultiScanMapper {
 
 // raw: n records of (x, y, z); returns one cloud per ring
 // sr (optional): the scan registration whose IMU state de-skews every kept point (projectPointToStartOfSweep :231)
-inline std::vector<Cloud> bin_sweep(const float* raw, size_t n, const MultiScanMapper& mapper, float scanPeriod, ScanRegistration* sr = nullptr) {
+// trace (optional, tests): the kept points in FIRING order before the IMU projection — (x, y, z, intensity), ring, relTime
+struct BinTrace {
+  Cloud points;
+  std::vector<int> ring;
+  std::vector<float> relTime;
+};
+inline std::vector<Cloud> bin_sweep(const float* raw, size_t n, const MultiScanMapper& mapper, float scanPeriod, ScanRegistration* sr = nullptr,
+                                    BinTrace* trace = nullptr) {
   std::vector<Cloud> scans(mapper.nScanRings);
   if (n == 0) return scans;
   // scan start and end orientations (:165-173)
@@ -70,6 +77,7 @@ inline std::vector<Cloud> bin_sweep(const float* raw, size_t n, const MultiScanM
     }
     float relTime = scanPeriod * (ori - startOri) / (endOri - startOri);   // :228
     point.i = scanID + relTime;                                             // :229
+    if (trace) { trace->points.push_back(point); trace->ring.push_back(scanID); trace->relTime.push_back(relTime); }
     if (sr) sr->project_point_to_start_of_sweep(point, relTime);            // :231
     scans[scanID].push_back(point);
   }

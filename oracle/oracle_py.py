@@ -143,6 +143,18 @@ def wire_quat_to_pose(orc: "Oracle", q4):
     return r
 
 
+def multiscan_trace(orc: "Oracle", raw_xyz, mapper="VLP-16", scan_period=0.1):
+    """kept points of a raw sweep in firing order before any IMU projection: (points (m,4), ring (m,), relTime (m,))"""
+    lo, hi, nr = MAPPERS[mapper] if isinstance(mapper, str) else mapper
+    raw = np.ascontiguousarray(raw_xyz, np.float32).reshape(-1, 3)
+    out = np.zeros((max(len(raw), 1), 5), np.float32)
+    ring = np.zeros(max(len(raw), 1), np.int32)
+    orc.L.orc_multiscan_trace.restype = C.c_int
+    m = orc.L.orc_multiscan_trace(raw.ctypes.data_as(C.c_void_p), len(raw), C.c_float(lo), C.c_float(hi), int(nr), C.c_float(scan_period),
+                                  out.ctypes.data_as(C.c_void_p), ring.ctypes.data_as(C.c_void_p), len(out))
+    return out[:m, :4].copy(), ring[:m].copy(), out[:m, 4].copy()
+
+
 class ScanRegistration:
     """oracle restatement of BasicScanRegistration (IMU-less)."""
     NAMES = ("full", "sharp", "less_sharp", "flat", "less_flat")
@@ -336,3 +348,75 @@ def ref_knn(pts, queries, k):
     L.ref_knn(pts.ctypes.data_as(C.c_void_p), len(pts), q.ctypes.data_as(C.c_void_p), len(q), k,
               idx.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p))
     return idx, d2
+
+
+def ref_small():
+    """The REFERENCE's own BasicTransformMaintenance.cpp, math_utils.h, Angle.h, CircularBuffer.h compiled where they lie
+    (oracle/_ref/libref_loam_small.so, oracle/Makefile target `ref`); None when the library is not built."""
+    path = os.path.join(_HERE, "_ref", "libref_loam_small.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    L.ref_rad2deg.restype = C.c_float
+    L.ref_deg2rad.restype = C.c_float
+    L.ref_circular.restype = C.c_int
+    return L
+
+
+class RefScanRegistration:
+    """The REFERENCE's own BasicScanRegistration (src/lib/BasicScanRegistration.cpp compiled where it lies against
+    oracle/ref_stubs — see oracle/ref_scanreg_shim.cpp for what is and is not the reference's code).  `available()` is False
+    when oracle/_ref/libref_scanreg.so is not built (no /root/reference on this machine)."""
+    NAMES = ("full", "sharp", "less_sharp", "flat", "less_flat")
+    _L = None
+
+    @classmethod
+    def available(cls):
+        if cls._L is None:
+            path = os.path.join(_HERE, "_ref", "libref_scanreg.so")
+            if not os.path.exists(path):
+                return False
+            L = C.CDLL(path)
+            L.ref_sr_create.restype = C.c_void_p
+            L.ref_sr_get.restype = C.c_int
+            cls._L = L
+        return True
+
+    def __init__(self, **cfg):
+        assert self.available()
+        c = dict(scanPeriod=0.1, imuHistorySize=200, nFeatureRegions=6, curvatureRegion=5, maxCornerSharp=2, maxSurfaceFlat=4,
+                 lessFlatFilterSize=0.2, surfaceCurvatureThreshold=0.1)
+        c.update(cfg)
+        self.h = C.c_void_p(self._L.ref_sr_create(C.c_float(c["scanPeriod"]), c["imuHistorySize"], c["nFeatureRegions"], c["curvatureRegion"],
+                                                  c["maxCornerSharp"], c["maxSurfaceFlat"], C.c_float(c["lessFlatFilterSize"]),
+                                                  C.c_float(c["surfaceCurvatureThreshold"])))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self._L.ref_sr_destroy(self.h)
+
+    def update_imu(self, stamp, roll, pitch, yaw, acc):
+        self._L.ref_sr_update_imu(self.h, C.c_double(stamp), C.c_float(roll), C.c_float(pitch), C.c_float(yaw), C.c_float(acc[0]),
+                                  C.c_float(acc[1]), C.c_float(acc[2]))
+
+    def project(self, pts, rel_times):
+        """projectPointToStartOfSweep on every row of pts (n,4), in order"""
+        out = np.ascontiguousarray(pts, np.float32).copy()
+        for i in range(len(out)):
+            self._L.ref_sr_project(self.h, out[i].ctypes.data_as(C.c_void_p), C.c_float(rel_times[i]))
+        return out
+
+    def process(self, pts, ring_sizes, scan_time=0.0):
+        pts = _pts(pts)
+        rs = np.ascontiguousarray(ring_sizes, np.int32)
+        self._L.ref_sr_process(self.h, C.c_double(scan_time), pts.ctypes.data_as(C.c_void_p), rs.ctypes.data_as(C.c_void_p), len(rs))
+        res = {}
+        for k, n in enumerate(self.NAMES):
+            cnt = self._L.ref_sr_get(self.h, k, None, 0)
+            out = np.zeros((max(cnt, 1), 4), np.float32)
+            self._L.ref_sr_get(self.h, k, out.ctypes.data_as(C.c_void_p), cnt)
+            res[n] = out[:cnt].copy()
+        it = np.zeros(12, np.float32)
+        self._L.ref_sr_imu_trans(self.h, it.ctypes.data_as(C.c_void_p))
+        res["imu_trans"] = it
+        return res

@@ -1,0 +1,150 @@
+"""CPU: the oracle (and the product's host-side pose fusion) pinned against the REFERENCE'S OWN CODE where that compiles
+without ROS / PCL / Eigen (oracle/Makefile target `ref`, outputs under oracle/_ref/, sources compiled where they lie):
+  libref_loam_small.so  src/lib/BasicTransformMaintenance.cpp, src/lib/math_utils.h, include/loam_velodyne/Angle.h, CircularBuffer.h
+  libref_scanreg.so     src/lib/BasicScanRegistration.cpp — feature extraction and the IMU state machine
+The only stand-ins are the minimal <pcl/...> headers in oracle/ref_stubs (a point struct, a std::vector cloud, and a VoxelGrid
+interface that forwards to the oracle's voxel grid: the grid itself therefore stays unpinned).  Every comparison is bit for bit.
+The vendored nanoflann is pinned in test_oracle_primitives.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_py as op
+from loam_velodyne_amd import loamx
+
+REF = op.ref_small()
+pytestmark = pytest.mark.skipif(REF is None, reason="oracle/_ref/libref_loam_small.so not built (no /root/reference here)")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_transform_maintenance_oracle_and_product_equal_the_reference_bitwise(orc):
+    rng = np.random.default_rng(11)
+    tm = loamx.TransformMaintenance()
+    for _ in range(500):
+        s, b, a = (np.concatenate([rng.uniform(-1.2, 1.2, 3), rng.uniform(-80, 80, 3)]).astype(np.float32) for _ in range(3))
+        want = np.zeros(6, np.float32)
+        REF.ref_tm_associate(_p(s), _p(b), _p(a), _p(want))
+        assert np.array_equal(op.tm_associate(orc, s, b, a), want)
+        tm.update_odometry(s)
+        tm.update_mapping_transform(a, b)
+        assert np.array_equal(tm.associate_to_map(), want)
+
+
+def test_angle_semantics(orc):
+    """Angle.h: cached float sin / cos, unary minus flips the sine only, += re-derives both."""
+    rng = np.random.default_rng(12)
+    for _ in range(300):
+        rad, add, neg = np.float32(rng.uniform(-7, 7)), np.float32(rng.choice([0.0, rng.uniform(-1, 1)])), int(rng.integers(0, 2))
+        r, o = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        REF.ref_angle(C.c_float(rad), neg, C.c_float(add), _p(r))
+        orc.L.orc_angle(C.c_float(rad), neg, C.c_float(add), _p(o))
+        assert np.array_equal(r, o)
+
+
+def test_rotations(orc):
+    """math_utils.h rotX / rotY / rotZ / rotateZXY / rotateYXZ: same operand order, same float results."""
+    rng = np.random.default_rng(13)
+    for _ in range(500):
+        which = int(rng.integers(0, 5))
+        p = rng.uniform(-60, 60, 3).astype(np.float32)
+        a = rng.uniform(-3.2, 3.2, 3).astype(np.float32)
+        r, o = p.copy(), p.copy()
+        REF.ref_rotate(which, _p(r), C.c_float(a[0]), C.c_float(a[1]), C.c_float(a[2]))
+        orc.L.orc_rotate(which, _p(o), C.c_float(a[0]), C.c_float(a[1]), C.c_float(a[2]))
+        assert np.array_equal(r, o), which
+    for v in (0.1, -2.5, 3.1415927):     # rad2deg / deg2rad go through double (math_utils.h:30-47)
+        f = float(np.float32(v))   # (double arithmetic on the float value, then rounded once)
+        assert REF.ref_rad2deg(C.c_float(v)) == np.float32(f * 180.0 / np.pi)
+        assert REF.ref_deg2rad(C.c_float(v)) == np.float32(f * np.pi / 180.0)
+
+
+def test_circular_buffer_is_a_bounded_fifo():
+    """CircularBuffer.h: push() overwrites the oldest element once full and operator[] counts from the oldest — i.e. the
+    bounded deque (pop_front on overflow) that the oracle and the product keep their IMU histories in."""
+    from collections import deque
+    for cap, n in ((5, 3), (5, 5), (5, 12), (200, 333), (1, 4)):
+        vals = np.arange(100, 100 + n, dtype=np.int32)
+        out = np.zeros(cap, np.int32)
+        size = REF.ref_circular(cap, _p(vals), n, _p(out), cap)
+        d = deque(maxlen=cap)
+        for v in vals:
+            d.append(int(v))
+        assert size == len(d) and out[:size].tolist() == list(d)
+
+
+# ---- the reference's own BasicScanRegistration.cpp (feature extraction + IMU bookkeeping) ---------------------------------
+needs_sr = pytest.mark.skipif(not op.RefScanRegistration.available(), reason="oracle/_ref/libref_scanreg.so not built")
+
+
+@needs_sr
+@pytest.mark.parametrize("sensor,az,cfg", [("VLP-16", 900, {}), ("HDL-32", 700, {}), ("HDL-64E", 512, {}),
+                                           ("VLP-16", 600, dict(nFeatureRegions=4, curvatureRegion=3, maxCornerSharp=3, maxSurfaceFlat=2,
+                                                                surfaceCurvatureThreshold=0.2))])
+def test_feature_extraction_equals_the_reference(orc, small_world, sensor, az, cfg):
+    """processScanlines / extractFeatures (BasicScanRegistration.cpp:28-46, :155-386) run by the reference's own code: sharp,
+    less-sharp and flat picks identical point for point; the less-flat cloud identical too (its candidate set is the
+    reference's, its voxel grid is the oracle's on both sides — see oracle/ref_stubs/pcl/filters/voxel_grid.h)."""
+    from loam_velodyne_amd import synth
+    for seed in (1, 2):
+        sw = synth.make_sweep(small_world, sensor, np.zeros(6), np.array([0.002, 0.02, -0.001, 0.2, 0.01, 0.8]), seed=seed, az_steps=az)
+        o = op.ScanRegistration(orc, **cfg).process(sw.points, sw.ring_sizes)
+        r = op.RefScanRegistration(**cfg).process(sw.points, sw.ring_sizes)
+        for name in ("full", "sharp", "less_sharp", "flat", "less_flat"):
+            assert o[name].shape == r[name].shape, (name, o[name].shape, r[name].shape)
+            assert np.array_equal(o[name], r[name]), name
+
+
+@needs_sr
+def test_ragged_and_short_rings_equal_the_reference(orc):
+    """rings shorter than 2 x curvatureRegion + 1 are skipped (:163-165); empty rings; duplicate / degenerate geometry"""
+    rng = np.random.default_rng(5)
+    sizes = [0, 7, 11, 12, 40, 3, 300]
+    rings = []
+    for r, n in enumerate(sizes):
+        ang = np.sort(rng.uniform(-np.pi, np.pi, n))
+        rad = 5 + 2 * np.sin(3 * ang) + (rng.random(n) < 0.1) * 3          # jumps -> occlusion masks
+        p = np.stack([rad * np.sin(ang), np.full(n, 0.1 * r), rad * np.cos(ang), r + 0.1 * (ang + np.pi) / (2 * np.pi)], 1)
+        rings.append(p.astype(np.float32))
+    pts = np.concatenate(rings)
+    o = op.ScanRegistration(orc).process(pts, sizes)
+    r = op.RefScanRegistration().process(pts, sizes)
+    for name in ("full", "sharp", "less_sharp", "flat", "less_flat"):
+        assert np.array_equal(o[name], r[name]), name
+
+
+@needs_sr
+def test_imu_state_machine_equals_the_reference(orc, small_world):
+    """updateIMUData, projectPointToStartOfSweep (incl. the monotone history index and the stale-scan-time order of events),
+    reset and updateIMUTransform (:55-152, :258-281) by the reference's own code, over sweeps with a wrapping history."""
+    from loam_velodyne_amd import synth
+    o, r = op.ScanRegistration(orc, imuHistorySize=50), op.RefScanRegistration(imuHistorySize=50)
+    rng = np.random.default_rng(9)
+    t_imu, k = 0.0, 0
+    for sweep in range(4):
+        t_scan = 0.125 * (sweep + 1)
+        while t_imu < t_scan + 0.11:
+            args = (t_imu, 0.02 * np.sin(3 * t_imu), 0.015 * np.cos(2 * t_imu), 0.4 * t_imu + (6.2 if k % 41 == 20 else 0.0),
+                    (0.8 * np.sin(5 * t_imu), 0.1, -0.5 * np.cos(4 * t_imu)))
+            o.update_imu(*args)
+            r.update_imu(*args)
+            t_imu += 0.001953125            # 2^-9 s: exact in double, and an integer number of nanoseconds ... / 2 (rounded by the reference's Time)
+            k += 1
+        sw = synth.make_sweep(small_world, "VLP-16", np.zeros(6), np.zeros(6), seed=40 + sweep, az_steps=300)
+        raw = synth.to_raw(sw)
+        # the kept points in FIRING order with their exact relTimes: the reference projects them one by one (:231), then
+        # they are split into rings (stable) as MultiScanRegistration::process does
+        pts_f, ring_f, rel_f = op.multiscan_trace(orc, raw, "VLP-16")
+        proj = r.project(pts_f, rel_f)
+        idx = np.argsort(ring_f, kind="stable")
+        proj_ref, rs = proj[idx], np.bincount(ring_f, minlength=16)
+        res_o = o.process_raw(raw, t_scan, "VLP-16")
+        res_r = r.process(proj_ref, rs, scan_time=t_scan)
+        assert np.array_equal(res_o["full"], proj_ref), sweep                  # bit for bit
+        assert np.array_equal(res_o["imu_trans"], res_r["imu_trans"]), sweep
+        for name in ("sharp", "less_sharp", "flat", "less_flat"):
+            assert np.array_equal(res_o[name], res_r[name]), name
+    assert np.abs(res_r["imu_trans"]).max() > 1e-3

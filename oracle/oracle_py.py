@@ -420,3 +420,131 @@ class RefScanRegistration:
         self._L.ref_sr_imu_trans(self.h, it.ctypes.data_as(C.c_void_p))
         res["imu_trans"] = it
         return res
+
+
+class RefLaserOdometry:
+    """The REFERENCE's own BasicLaserOdometry (src/lib/BasicLaserOdometry.cpp + the vendored nanoflann compiled where they lie
+    against oracle/ref_stubs — see oracle/ref_odometry_shim.cpp for what is and is not the reference's code).  Same surface as
+    LaserOdometry above.  `available()` is False when oracle/_ref/libref_odometry.so is not built."""
+    _L = None
+
+    @classmethod
+    def available(cls):
+        if cls._L is None:
+            path = os.path.join(_HERE, "_ref", "libref_odometry.so")
+            if not os.path.exists(path):
+                return False
+            cls._L = C.CDLL(path)
+            cls._L.ref_odom_create.restype = C.c_void_p
+            cls._L.ref_odom_frame_count.restype = C.c_long
+        return True
+
+    def __init__(self, scanPeriod=0.1, maxIterations=25, deltaTAbort=0.1, deltaRAbort=0.1):
+        assert self.available()
+        self.h = C.c_void_p(self._L.ref_odom_create(C.c_float(scanPeriod), maxIterations, C.c_float(deltaTAbort), C.c_float(deltaRAbort)))
+
+    def __del__(self):
+        self._L.ref_odom_destroy(self.h)
+
+    def set_features(self, f):
+        for k, n in enumerate(ScanRegistration.NAMES):
+            p = _pts(f[n])
+            self._L.ref_odom_set_cloud(self.h, k, p.ctypes.data_as(C.c_void_p), len(p))
+
+    def set_transform(self, t6):
+        t6 = _f32(t6)
+        self._L.ref_odom_set_transform(self.h, t6.ctypes.data_as(C.c_void_p))
+
+    def update_imu(self, t12):
+        t12 = _f32(t12)
+        self._L.ref_odom_update_imu(self.h, t12.ctypes.data_as(C.c_void_p))
+
+    def process(self):
+        self._L.ref_odom_process(self.h)
+
+    def _t(self, fn):
+        t = np.zeros(6, np.float32)
+        fn(self.h, t.ctypes.data_as(C.c_void_p))
+        return t
+
+    @property
+    def transform(self):
+        return self._t(self._L.ref_odom_get_transform)
+
+    @property
+    def transform_sum(self):
+        return self._t(self._L.ref_odom_get_transform_sum)
+
+    def last_corner(self):
+        return _get_cloud(self._L.ref_odom_get_cloud, self.h, 0)
+
+    def last_surf(self):
+        return _get_cloud(self._L.ref_odom_get_cloud, self.h, 1)
+
+    def full_to_end(self):
+        self._L.ref_odom_transform_full_to_end(self.h)
+        return _get_cloud(self._L.ref_odom_get_cloud, self.h, 2)
+
+
+class RefLaserMapping:
+    """The REFERENCE's own BasicLaserMapping (src/lib/BasicLaserMapping.cpp + the vendored nanoflann compiled where they lie
+    against oracle/ref_stubs — see oracle/ref_mapping_shim.cpp for what is and is not the reference's code).  Same surface as
+    the live-map part of LaserMapping above.  `available()` is False when oracle/_ref/libref_mapping.so is not built."""
+    CLOUDS = LaserMapping.CLOUDS
+    _L = None
+
+    @classmethod
+    def available(cls):
+        if cls._L is None:
+            path = os.path.join(_HERE, "_ref", "libref_mapping.so")
+            if not os.path.exists(path):
+                return False
+            cls._L = C.CDLL(path)
+            cls._L.ref_map_create.restype = C.c_void_p
+        return True
+
+    def __init__(self, scanPeriod=0.1, maxIterations=10, deltaTAbort=0.05, deltaRAbort=0.05, cornerLeaf=0.2, surfLeaf=0.4):
+        assert self.available()
+        self.h = C.c_void_p(self._L.ref_map_create(C.c_float(scanPeriod), maxIterations, C.c_float(deltaTAbort), C.c_float(deltaRAbort),
+                                                   C.c_float(cornerLeaf), C.c_float(surfLeaf)))
+        self.t = 0.0
+
+    def __del__(self):
+        self._L.ref_map_destroy(self.h)
+
+    def set_inputs(self, corner_last, surf_last, full_res, transform_sum):
+        for k, p in enumerate((corner_last, surf_last, full_res)):
+            p = _pts(p)
+            self._L.ref_map_set_cloud(self.h, k, p.ctypes.data_as(C.c_void_p), len(p))
+        t = _f32(transform_sum)
+        self._L.ref_map_update_odometry(self.h, t.ctypes.data_as(C.c_void_p))
+
+    def update_imu(self, stamp, roll, pitch):
+        self._L.ref_map_update_imu(self.h, C.c_double(stamp), C.c_float(roll), C.c_float(pitch))
+
+    def set_time(self, t):
+        self.t = float(t)
+
+    def process(self):
+        return bool(self._L.ref_map_process(self.h, C.c_double(self.t)))
+
+    def transform(self, which="aft"):
+        t = np.zeros(6, np.float32)
+        self._L.ref_map_get_transform(self.h, ("aft", "bef", "tobe", "sum").index(which), t.ctypes.data_as(C.c_void_p))
+        return t
+
+    def set_transform(self, which, t6):
+        t6 = _f32(t6)
+        self._L.ref_map_set_transform(self.h, ("aft", "bef", "tobe", "sum").index(which), t6.ctypes.data_as(C.c_void_p))
+
+    def cloud(self, name):
+        return _get_cloud(self._L.ref_map_get_cloud, self.h, self.CLOUDS.index(name))
+
+    def has_fresh_map(self):
+        return bool(self._L.ref_map_has_fresh_map(self.h))
+
+    def grid_center(self):
+        c = np.zeros(3, np.int32)
+        self._L.ref_map_grid_center(self.h, c.ctypes.data_as(C.c_void_p))
+        return c
+

@@ -1,5 +1,5 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  NOT PCL: a std::vector with the handful of members the reference's
-// BasicScanRegistration.{h,cpp} touches (push_back, size, clear, operator[], operator+=, the (width, height) constructor, Ptr),
+// sources touch (push_back, size, clear, operator[], operator+=, the (width, height) constructor, Ptr),
 // so that the reference's feature extraction and IMU bookkeeping compile where they lie (oracle/Makefile target `ref`).
 #pragma once
 #include <cstdint>
@@ -27,6 +27,8 @@ template <class PointT> class PointCloud {
     width = (uint32_t)points.size(); height = 1;
     return *this;
   }
+  typename std::vector<PointT>::iterator begin() { return points.begin(); }
+  typename std::vector<PointT>::iterator end() { return points.end(); }
   typename std::vector<PointT>::const_iterator begin() const { return points.begin(); }
   typename std::vector<PointT>::const_iterator end() const { return points.end(); }
 };

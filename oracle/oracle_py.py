@@ -548,3 +548,74 @@ class RefLaserMapping:
         self._L.ref_map_grid_center(self.h, c.ctypes.data_as(C.c_void_p))
         return c
 
+
+class RefMultiScanRegistration:
+    """The REFERENCE's own MultiScanRegistration (src/lib/MultiScanRegistration.cpp + BasicScanRegistration.cpp compiled where
+    they lie against oracle/ref_stubs — see oracle/ref_multiscan_shim.cpp for what is and is not the reference's code): the
+    sweep ingestion from raw sensor-axes points to the five feature clouds.  `available()` is False when
+    oracle/_ref/libref_multiscan.so is not built."""
+    NAMES = ScanRegistration.NAMES
+    _L = None
+
+    @classmethod
+    def available(cls):
+        if cls._L is None:
+            path = os.path.join(_HERE, "_ref", "libref_multiscan.so")
+            if not os.path.exists(path):
+                return False
+            cls._L = C.CDLL(path)
+            cls._L.ref_ms_create.restype = C.c_void_p
+        return True
+
+    @classmethod
+    def ring_for_angle(cls, mapper, angle_rad):
+        lo, hi, nr = MAPPERS[mapper] if isinstance(mapper, str) else mapper
+        return int(cls._L.ref_ms_ring_for_angle(C.c_float(lo), C.c_float(hi), int(nr), C.c_float(angle_rad)))
+
+    def __init__(self, mapper="VLP-16", **cfg):
+        assert self.available()
+        lo, hi, nr = MAPPERS[mapper] if isinstance(mapper, str) else mapper
+        self.n_rings = int(nr)
+        c = dict(scanPeriod=0.1, imuHistorySize=200, nFeatureRegions=6, curvatureRegion=5, maxCornerSharp=2, maxSurfaceFlat=4,
+                 lessFlatFilterSize=0.2, surfaceCurvatureThreshold=0.1)
+        c.update(cfg)
+        self.h = C.c_void_p(self._L.ref_ms_create(C.c_float(lo), C.c_float(hi), int(nr), C.c_float(c["scanPeriod"]), c["imuHistorySize"],
+                                                  c["nFeatureRegions"], c["curvatureRegion"], c["maxCornerSharp"], c["maxSurfaceFlat"],
+                                                  C.c_float(c["lessFlatFilterSize"]), C.c_float(c["surfaceCurvatureThreshold"])))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self._L.ref_ms_destroy(self.h)
+
+    def update_imu(self, stamp, roll, pitch, yaw, acc):
+        self._L.ref_ms_update_imu(self.h, C.c_double(stamp), C.c_float(roll), C.c_float(pitch), C.c_float(yaw), C.c_float(acc[0]),
+                                  C.c_float(acc[1]), C.c_float(acc[2]))
+
+    def _results(self):
+        res = {}
+        for k, n in enumerate(self.NAMES):
+            cnt = self._L.ref_ms_get(self.h, k, None, 0)
+            out = np.zeros((max(cnt, 1), 4), np.float32)
+            self._L.ref_ms_get(self.h, k, out.ctypes.data_as(C.c_void_p), cnt)
+            res[n] = out[:cnt].copy()
+        rs = np.zeros(self.n_rings, np.int32)
+        self._L.ref_ms_ring_sizes(self.h, rs.ctypes.data_as(C.c_void_p), self.n_rings)
+        res["ring_sizes"] = rs
+        it = np.zeros(12, np.float32)
+        self._L.ref_ms_imu_trans(self.h, it.ctypes.data_as(C.c_void_p))
+        res["imu_trans"] = it
+        return res
+
+    def process_raw(self, raw_xyz, scan_time):
+        """MultiScanRegistration::process(laserCloudIn, scanTime)"""
+        raw = np.ascontiguousarray(raw_xyz, np.float32).reshape(-1, 3)
+        self._L.ref_ms_process(self.h, raw.ctypes.data_as(C.c_void_p), len(raw), C.c_double(scan_time))
+        return self._results()
+
+    def handle_message(self, raw_xyz, sec, nsec):
+        """handleCloudMessage with a (sec, nsec) stamp; None while the start-up delay swallows the message"""
+        raw = np.ascontiguousarray(raw_xyz, np.float32).reshape(-1, 3)
+        if not self._L.ref_ms_handle_message(self.h, raw.ctypes.data_as(C.c_void_p), len(raw), int(sec), int(nsec)):
+            return None
+        return self._results()
+

@@ -263,3 +263,73 @@ def test_mapping_imu_blend_equals_the_reference(orc, small_world):
     o, r, _ = _run_mapping(orc, small_world, "VLP-16", 600, 4, {}, imu=True)
     o2, _, _ = _run_mapping(orc, small_world, "VLP-16", 600, 4, {})
     assert not np.array_equal(o.transform("aft"), o2.transform("aft"))          # the blend took part
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Sweep ingestion: the reference's own MultiScanRegistration.cpp (ring binning, start / end orientation, half-sweep logic,
+# relative times, IMU projection) + BasicScanRegistration.cpp behind inert ROS stand-ins.
+needs_ms = pytest.mark.skipif(not op.RefMultiScanRegistration.available(), reason="oracle/_ref/libref_multiscan.so not built")
+
+
+@needs_ms
+@pytest.mark.parametrize("sensor,az", [("VLP-16", 600), ("HDL-32", 512), ("HDL-64E", 512)])
+def test_raw_ingestion_equals_the_reference(orc, small_world, sensor, az):
+    o, r = op.ScanRegistration(orc), op.RefMultiScanRegistration(sensor)
+    poses = synth.trajectory(3, yaw_step_deg=3.0)
+    for k in range(3):
+        sw = synth.make_sweep(small_world, sensor, poses[k], poses[k + 1], seed=60 + k, az_steps=az)
+        raw = synth.to_raw(sw, bad_every=53)                                   # NaN, zero and out-of-field returns in the packet
+        if k == 2:
+            raw = np.roll(raw, 7 * len(sw.ring_sizes) + 3, axis=0)              # the sweep starts mid-firing at another azimuth
+        a, b = o.process_raw(raw, 0.1 * k, sensor), r.process_raw(raw, 0.1 * k)
+        for name in ("ring_sizes", "full", "sharp", "less_sharp", "flat", "less_flat", "imu_trans"):
+            assert np.array_equal(a[name], b[name]), (k, name)
+        assert len(a["sharp"]) > 50 and a["ring_sizes"].sum() < len(raw)
+
+
+@needs_ms
+def test_raw_ingestion_with_imu_equals_the_reference(orc, small_world):
+    o, r = op.ScanRegistration(orc), op.RefMultiScanRegistration("VLP-16")
+    rng = np.random.default_rng(21)
+    tick = 1.0 / 512                          # exact in double seconds (the oracle's clock) AND in nanoseconds (the reference's)
+    for k in range(3):
+        t_scan = 51 * k * tick
+        for j in range(14):                                                     # ~100 Hz states overlapping the sweep on both sides
+            s = (t_scan + (5 * j - 10) * tick, *rng.uniform(-0.03, 0.03, 3), rng.uniform(-0.5, 0.5, 3))
+            o.update_imu(*s)
+            r.update_imu(*s)
+        sw = synth.make_sweep(small_world, "VLP-16", np.zeros(6), np.zeros(6), seed=80 + k, az_steps=400)
+        raw = synth.to_raw(sw, bad_every=41)
+        a, b = o.process_raw(raw, t_scan, "VLP-16"), r.process_raw(raw, t_scan)
+        for name in ("ring_sizes", "full", "sharp", "less_sharp", "flat", "less_flat", "imu_trans"):
+            assert np.array_equal(a[name], b[name]), (k, name)
+    assert np.abs(b["imu_trans"]).max() > 1e-3
+
+
+@needs_ms
+def test_ring_mapping_equals_the_reference(orc):
+    """getRingForAngle (:64-66) through process(): one return per vertical angle on a dense sweep of angles incl. the
+    half-spacing boundaries (and their float neighbours) and angles outside the field of view — kept / dropped and binned alike"""
+    for sensor in ("VLP-16", "HDL-32", "HDL-64E"):
+        lo, hi, nr = op.MAPPERS[sensor]
+        step = (hi - lo) / (nr - 1)
+        edges = np.float32(lo + step * (np.arange(-2, nr + 2) + 0.5))
+        deg = np.concatenate([np.linspace(lo - 2 * step, hi + 2 * step, 4001), edges, np.nextafter(edges, np.float32(-1e9)),
+                              np.nextafter(edges, np.float32(1e9))]).astype(np.float64)
+        az = np.linspace(0.0, 2 * np.pi, len(deg), endpoint=False)              # one turn, so that the relative times are defined
+        raw = np.stack([np.cos(np.deg2rad(deg)) * np.cos(az) * 10, np.cos(np.deg2rad(deg)) * np.sin(az) * 10, np.sin(np.deg2rad(deg)) * 10], axis=1).astype(np.float32)
+        a, b = op.ScanRegistration(orc).process_raw(raw, 0.0, sensor), op.RefMultiScanRegistration(sensor).process_raw(raw, 0.0)
+        assert np.array_equal(a["ring_sizes"], b["ring_sizes"])
+        assert np.array_equal(a["full"], b["full"])
+        assert 0 < a["ring_sizes"].sum() < len(raw) and a["ring_sizes"].min() > 0
+        # angles below the lowest ring by less than one spacing still land in ring 0 (int() truncates towards zero)
+        assert a["ring_sizes"][0] > 1.3 * a["ring_sizes"][1]
+
+
+@needs_ms
+def test_startup_delay_of_the_message_handler():
+    """handleCloudMessage drops the first 20 messages (:143-149, _systemDelay); ros::Time -> Time keeps the nanoseconds"""
+    r = op.RefMultiScanRegistration("VLP-16")
+    raw = np.array([[10.0, 0.0, 0.0], [0.0, 10.0, 0.0], [-10.0, 0.0, 0.0], [0.0, -10.0, 0.0]], np.float32)
+    got = [r.handle_message(raw, 5, 1000 * k) is not None for k in range(23)]
+    assert got == [False] * 20 + [True] * 3

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp for the rules and the "parity unpinned" note).
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp for the rules and for what is / is not pinned by the reference's own code).
 //
 // Point-cloud primitives whose arithmetic lives OUTSIDE /root/reference:
 //   voxel_grid  -> pcl::VoxelGrid<PointXYZI>::filter as called at BasicLaserMapping.cpp:261-262,

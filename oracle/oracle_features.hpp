@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp for the rules and the "parity unpinned" note).
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp for the rules and for what is / is not pinned by the reference's own code).
 //
 // Per-sweep feature extraction, restating BasicScanRegistration (IMU-less path):
 //   process_scanlines   -> src/lib/BasicScanRegistration.cpp:28-46

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp for the rules and the "parity unpinned" note).
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp for the rules and for what is / is not pinned by the reference's own code).
 //
 // Raw-sweep ingestion, restating the ROS-free part of MultiScanRegistration:
 //   MultiScanMapper::set / getRingForAngle -> src/lib/MultiScanRegistration.cpp:41-66,

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp for the rules and the "parity unpinned" note).
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp for the rules and for what is / is not pinned by the reference's own code).
 //
 // Pose fusion after the path, restating
 //   BasicTransformMaintenance::updateOdometry / updateMappingTransform / transformAssociateToMap

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp for the rules and the "parity unpinned" note).
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp for the rules and for what is / is not pinned by the reference's own code).
 //
 // Scan-to-map registration, restating BasicLaserMapping:
 //   transform_associate_to_map -> src/lib/BasicLaserMapping.cpp:103-167

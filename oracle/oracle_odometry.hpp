@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp for the rules and the "parity unpinned" note).
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_math.hpp for the rules and for what is / is not pinned by the reference's own code).
 //
 // Sweep-to-sweep registration, restating BasicLaserOdometry:
 //   transform_to_start   -> src/lib/BasicLaserOdometry.cpp:40-53

@@ -548,6 +548,25 @@ class RefLaserMapping:
         self._L.ref_map_grid_center(self.h, c.ctypes.data_as(C.c_void_p))
         return c
 
+    def set_frozen(self, corner, surf):
+        self._frozen = (_pts(corner), _pts(surf))
+
+    def register_frozen(self, corner_last, surf_last, guess6):
+        """one sweep against the caller's sub-map through the reference's own optimizeTransformTobeMapped (ref_mapping_shim.cpp)"""
+        for k, p in enumerate((corner_last, surf_last)):
+            p = _pts(p)
+            self._L.ref_map_set_cloud(self.h, k, p.ctypes.data_as(C.c_void_p), len(p))
+        cm, sm = self._frozen
+        g, pose = _f32(guess6), np.zeros(6, np.float32)
+        self._L.ref_map_register_frozen(self.h, cm.ctypes.data_as(C.c_void_p), len(cm), sm.ctypes.data_as(C.c_void_p), len(sm),
+                                        g.ctypes.data_as(C.c_void_p), pose.ctypes.data_as(C.c_void_p))
+        return pose
+
+    def associate(self):
+        t = np.zeros(6, np.float32)
+        self._L.ref_map_associate(self.h, t.ctypes.data_as(C.c_void_p))
+        return t
+
 
 class RefMultiScanRegistration:
     """The REFERENCE's own MultiScanRegistration (src/lib/MultiScanRegistration.cpp + BasicScanRegistration.cpp compiled where

@@ -100,6 +100,44 @@ int ref_map_get_cloud(void* h, int which, float* out, int cap) {
                                                   m->_laserCloudSurfFromMap.get(), m->_laserCloudCornerStackDS.get(), m->_laserCloudSurfStackDS.get()};
   return dump(*c[which], out, cap);
 }
+// Registration of one sweep against a caller-provided sub-map — the unit the batched mode shards (oracle_mapping.hpp
+// register_frozen).  Built ONLY from the reference's own members, in the order process() runs them (:282-292, :511-531):
+// pointAssociateToMap into the stacks, pointAssociateTobeMapped back, the two down-sizing filters, optimizeTransformTobeMapped.
+void ref_map_register_frozen(void* h, const float* corner_map, int ncm, const float* surf_map, int nsm, const float* guess6, float* pose6) {
+  auto* m = (BasicLaserMapping*)h;
+  auto load = [](pcl::PointCloud<pcl::PointXYZI>& c, const float* pts, int n) {
+    c.clear();
+    for (int i = 0; i < n; i++) {
+      pcl::PointXYZI p;
+      p.x = pts[4 * i]; p.y = pts[4 * i + 1]; p.z = pts[4 * i + 2]; p.intensity = pts[4 * i + 3];
+      c.push_back(p);
+    }
+  };
+  load(*m->_laserCloudCornerFromMap, corner_map, ncm);
+  load(*m->_laserCloudSurfFromMap, surf_map, nsm);
+  to_twist(m->_transformTobeMapped, guess6);
+  pcl::PointXYZI pointSel;
+  for (auto const& pt : m->_laserCloudCornerLast->points) { m->pointAssociateToMap(pt, pointSel); m->_laserCloudCornerStack->push_back(pointSel); }
+  for (auto const& pt : m->_laserCloudSurfLast->points) { m->pointAssociateToMap(pt, pointSel); m->_laserCloudSurfStack->push_back(pointSel); }
+  for (auto& pt : *m->_laserCloudCornerStack) m->pointAssociateTobeMapped(pt, pt);
+  for (auto& pt : *m->_laserCloudSurfStack) m->pointAssociateTobeMapped(pt, pt);
+  m->_laserCloudCornerStackDS->clear();
+  m->_downSizeFilterCorner.setInputCloud(m->_laserCloudCornerStack);
+  m->_downSizeFilterCorner.filter(*m->_laserCloudCornerStackDS);
+  m->_laserCloudSurfStackDS->clear();
+  m->_downSizeFilterSurf.setInputCloud(m->_laserCloudSurfStack);
+  m->_downSizeFilterSurf.filter(*m->_laserCloudSurfStackDS);
+  m->_laserCloudCornerStack->clear();
+  m->_laserCloudSurfStack->clear();
+  m->optimizeTransformTobeMapped();
+  from_twist(m->_transformTobeMapped, pose6);
+}
+// transformAssociateToMap (:101-157) with the current sum / bef / aft; returns the predicted transformTobeMapped
+void ref_map_associate(void* h, float* tobe6) {
+  auto* m = (BasicLaserMapping*)h;
+  m->transformAssociateToMap();
+  from_twist(m->_transformTobeMapped, tobe6);
+}
 int ref_map_has_fresh_map(void* h) { return ((BasicLaserMapping*)h)->hasFreshMap() ? 1 : 0; }
 void ref_map_grid_center(void* h, int* c3) {
   auto* m = (BasicLaserMapping*)h;

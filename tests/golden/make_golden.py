@@ -1,8 +1,9 @@
 """Generates the golden fixtures in this directory from the ORACLE (oracle/liboracle.so, the -ffp-contract=off build).
 
-The reference repository has no golden vectors for this path and cannot be built here (PCL / Eigen / ROS absent), so
-these fixtures are oracle outputs on seeded synthetic inputs — "parity unpinned" by the reference, pinned against this
-file's checker.  Re-run:  python tests/golden/make_golden.py
+The reference repository has no golden vectors for this path, so these fixtures are oracle outputs on seeded synthetic
+inputs.  They are NOT oracle-only truth: tests/test_ref_pinning.py (test_golden_*) reproduces every stored value bit for
+bit with the reference's own translation units compiled into oracle/_ref (voxel grid and Eigen solvers excepted, see
+oracle/oracle_math.hpp).  Re-run:  python tests/golden/make_golden.py
 """
 import os
 import sys

@@ -6,6 +6,7 @@ The only stand-ins are the minimal <pcl/...> headers in oracle/ref_stubs (a poin
 interface that forwards to the oracle's voxel grid: the grid itself therefore stays unpinned).  Every comparison is bit for bit.
 The vendored nanoflann is pinned in test_oracle_primitives.py."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -333,3 +334,85 @@ def test_startup_delay_of_the_message_handler():
     raw = np.array([[10.0, 0.0, 0.0], [0.0, 10.0, 0.0], [-10.0, 0.0, 0.0], [0.0, -10.0, 0.0]], np.float32)
     got = [r.handle_message(raw, 5, 1000 * k) is not None for k in range(23)]
     assert got == [False] * 20 + [True] * 3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The committed golden fixtures (tests/golden/*.npz, generated from the oracle by make_golden.py and used by the -m gpu parity
+# tests on the GPU box, where neither /root/reference nor these libraries' sources exist) reproduced by the REFERENCE'S OWN
+# code: what the device path is compared with on the GPU box is what the reference computes, not only what the oracle says.
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+needs_all = pytest.mark.skipif(not (op.RefScanRegistration.available() and op.RefLaserOdometry.available() and op.RefLaserMapping.available()),
+                               reason="oracle/_ref libraries not built")
+
+
+@needs_all
+def test_golden_features_are_the_reference_s():
+    g = np.load(os.path.join(GOLD, "features_vlp16.npz"))
+    f = op.RefScanRegistration().process(g["points"], g["ring_sizes"])
+    for name in ("sharp", "less_sharp", "flat", "less_flat"):
+        assert np.array_equal(f[name], g[name]), name
+
+
+@needs_all
+def test_golden_pipeline_is_the_reference_s():
+    """feature extraction -> odometry -> registration against a frozen map, 2 streams x 4 sweeps"""
+    g = np.load(os.path.join(GOLD, "pipeline_vlp16.npz"))
+    for s in range(2):
+        sr, od, mp = op.RefScanRegistration(), op.RefLaserOdometry(), op.RefLaserMapping()
+        mp.set_frozen(g["corner_map"], g["surf_map"])
+        mp.set_transform("aft", g[f"start_{s}"])
+        for t in range(4):
+            od.set_features(sr.process(g[f"points_{s}_{t}"], g[f"rings_{s}_{t}"]))
+            od.process()
+            if t > 0:
+                mp.set_transform("sum", od.transform_sum)
+                mp.register_frozen(od.last_corner(), od.last_surf(), mp.associate())
+            assert np.array_equal(od.transform_sum, g[f"sum_{s}"][t]), (s, t)
+            assert np.array_equal(mp.transform("aft"), g[f"aft_{s}"][t]), (s, t)
+
+
+@needs_all
+def test_golden_live_map_sequence_is_the_reference_s():
+    """five sweeps through process() with the rolling live map; the recorded prior and posterior states of the last two"""
+    g = np.load(os.path.join(GOLD, "mapping_seq_vlp16.npz"))
+    world = synth.World(half_extent=45.0)
+    poses = synth.trajectory(5, start=(0.0, 0.0, 0.0))
+    sr, od, mp = op.RefScanRegistration(), op.RefLaserOdometry(), op.RefLaserMapping()
+    for t in range(5):
+        sw = synth.make_sweep(world, "VLP-16", poses[t], poses[t + 1], seed=900 + t, az_steps=600)      # make_golden.py part 3
+        od.set_features(sr.process(sw.points, sw.ring_sizes))
+        od.process()
+        full_end = od.full_to_end()
+        lc, ls, ts = od.last_corner(), od.last_surf(), od.transform_sum
+        if t >= 3:
+            assert np.array_equal(mp.cloud("corner_cubes"), g[f"pre_corner_cubes_{t}"])
+            assert np.array_equal(mp.cloud("surf_cubes"), g[f"pre_surf_cubes_{t}"])
+            assert np.array_equal(mp.transform("aft"), g[f"pre_aft_{t}"]) and np.array_equal(mp.transform("bef"), g[f"pre_bef_{t}"])
+            assert np.array_equal(lc, g[f"corner_last_{t}"]) and np.array_equal(ls, g[f"surf_last_{t}"])
+            assert np.array_equal(full_end[::8], g[f"full_{t}"]) and np.array_equal(ts, g[f"sum_{t}"])
+        mp.set_inputs(lc, ls, full_end, ts)
+        mp.process()
+        if t >= 3:
+            assert np.array_equal(mp.transform("aft"), g[f"post_aft_{t}"]) and np.array_equal(mp.transform("bef"), g[f"post_bef_{t}"])
+            assert np.array_equal(mp.cloud("full_res")[::8], g[f"post_full_{t}"])
+            assert len(mp.cloud("corner_cubes")) == int(g[f"post_n_corner_{t}"]) and len(mp.cloud("surf_cubes")) == int(g[f"post_n_surf_{t}"])
+
+
+@needs_all
+def test_frozen_map_registration_equals_the_reference(orc, small_world):
+    """the unit of the batched mode — one sweep against a caller-provided sub-map — for a denser sensor and a larger map,
+    from a perturbed start (several Gauss-Newton iterations, both residual kinds, the degeneracy check)"""
+    corner_map, surf_map = small_world.make_map(120000)
+    gt = np.array([0.004, 0.3, -0.002, 2.0, 0.02, -3.0])
+    sw = synth.make_sweep(small_world, "HDL-32", gt, gt, seed=33, az_steps=1024)
+    f = op.ScanRegistration(orc).process(sw.points, sw.ring_sizes)
+    o, r = op.LaserMapping(orc), op.RefLaserMapping()
+    o.set_frozen(corner_map, surf_map)
+    r.set_frozen(corner_map, surf_map)
+    guess = gt + np.array([0.006, -0.005, 0.004, 0.08, -0.06, 0.09])
+    po, pr = o.register_frozen(f["less_sharp"], f["less_flat"], guess), r.register_frozen(f["less_sharp"], f["less_flat"], guess)
+    assert np.array_equal(po, pr)
+    assert np.array_equal(o.transform("aft"), r.transform("aft"))
+    for name in ("corner_stack_ds", "surf_stack_ds"):
+        assert np.array_equal(o.cloud(name), r.cloud(name)), name
+    assert o.stats()["iterations"] >= 3 and np.abs(po[3:] - gt[3:]).max() < 0.03

@@ -76,8 +76,8 @@ int main(int argc, char** argv) {
       mapping.updateOdometry(odom.transformSum());
       mapping.process(std::chrono::system_clock::now());
       float s[6], a[6];
-      odom.transformSum().to(s);
-      mapping.transformAftMapped().to(a);
+      loam::detail::twist_to(odom.transformSum(), s);
+      loam::detail::twist_to(mapping.transformAftMapped(), a);
       maintenance.updateOdometry(s[0], s[1], s[2], s[3], s[4], s[5]);
       maintenance.updateMappingTransform(mapping.transformAftMapped(), mapping.transformBefMapped());
       maintenance.transformAssociateToMap();

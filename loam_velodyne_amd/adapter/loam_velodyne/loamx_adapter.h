@@ -18,6 +18,15 @@
 #include <vector>
 #include "loamx.h"
 
+// LOAMX_REFERENCE_TYPES (implies LOAMX_USE_PCL): the build sits inside the reference's tree and keeps the reference's own
+// value-type headers — Angle.h, Vector3.h, Twist.h, time_utils.h — so that the wrappers and math_utils.h see exactly the
+// types they were written against; the adapter then adds the reference's time-stamped overloads (IMUState, IMUState2,
+// processScanlines(Time, ...), process(Time)).  adapter/dropin_check.sh compiles the reference's wrapper sources this way.
+#ifdef LOAMX_REFERENCE_TYPES
+#ifndef LOAMX_USE_PCL
+#define LOAMX_USE_PCL
+#endif
+#endif
 #ifdef LOAMX_USE_PCL
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
@@ -70,6 +79,15 @@ inline void check(int rc) {
 }
 }  // namespace detail
 
+}  // namespace loam
+#ifdef LOAMX_REFERENCE_TYPES
+#include "loam_velodyne/Angle.h"
+#include "loam_velodyne/Vector3.h"
+#include "loam_velodyne/Twist.h"
+#include "loam_velodyne/time_utils.h"
+namespace loam {
+#else
+namespace loam {
 // Angle / Twist value types with the accessors the wrappers use (Angle.h:16-67, Twist.h:15-27)
 struct Angle {
   float _rad = 0.f;
@@ -80,6 +98,8 @@ struct Angle {
 };
 struct Vector3 {
   float v[3] = {0.f, 0.f, 0.f};
+  Vector3() = default;
+  Vector3(float x_, float y_, float z_) : v{x_, y_, z_} {}
   float x() const { return v[0]; }
   float y() const { return v[1]; }
   float z() const { return v[2]; }
@@ -87,19 +107,30 @@ struct Vector3 {
 struct Twist {
   Angle rot_x, rot_y, rot_z;
   Vector3 pos;
-  static Twist from(const float* t) {
-    Twist w;
-    w.rot_x = t[0]; w.rot_y = t[1]; w.rot_z = t[2];
-    w.pos.v[0] = t[3]; w.pos.v[1] = t[4]; w.pos.v[2] = t[5];
-    return w;
-  }
-  void to(float* t) const {
-    t[0] = rot_x.rad(); t[1] = rot_y.rad(); t[2] = rot_z.rad(); t[3] = pos.x(); t[4] = pos.y(); t[5] = pos.z();
-  }
 };
+#endif
+
+namespace detail {
+inline Twist twist_from(const float* t) {
+  Twist w;
+  w.rot_x = t[0]; w.rot_y = t[1]; w.rot_z = t[2];
+  w.pos = Vector3(t[3], t[4], t[5]);
+  return w;
+}
+inline void twist_to(const Twist& w, float* t) {
+  t[0] = w.rot_x.rad(); t[1] = w.rot_y.rad(); t[2] = w.rot_z.rad(); t[3] = w.pos.x(); t[4] = w.pos.y(); t[5] = w.pos.z();
+}
+}  // namespace detail
 
 // RegistrationParams (BasicScanRegistration.h:34-72)
 struct RegistrationParams {
+  RegistrationParams() = default;
+  RegistrationParams(const float& scanPeriod_, const int& imuHistorySize_ = 200, const int& nFeatureRegions_ = 6, const int& curvatureRegion_ = 5,
+                     const int& maxCornerSharp_ = 2, const int& maxSurfaceFlat_ = 4, const float& lessFlatFilterSize_ = 0.2f,
+                     const float& surfaceCurvatureThreshold_ = 0.1f)
+      : scanPeriod(scanPeriod_), imuHistorySize(imuHistorySize_), nFeatureRegions(nFeatureRegions_), curvatureRegion(curvatureRegion_),
+        maxCornerSharp(maxCornerSharp_), maxCornerLessSharp(10 * maxCornerSharp_), maxSurfaceFlat(maxSurfaceFlat_),
+        lessFlatFilterSize(lessFlatFilterSize_), surfaceCurvatureThreshold(surfaceCurvatureThreshold_) {}
   float scanPeriod = 0.1f;
   int imuHistorySize = 200;
   int nFeatureRegions = 6;
@@ -111,9 +142,39 @@ struct RegistrationParams {
   float surfaceCurvatureThreshold = 0.1f;
 };
 
+#ifdef LOAMX_REFERENCE_TYPES
+// IMUState (BasicScanRegistration.h:76-132): the record the wrapper's IMU handler fills.  The history, its interpolation and the
+// integration of position / velocity live behind loamx_scanreg_update_imu.
+struct IMUState {
+  Time stamp;
+  Angle roll, pitch, yaw;
+  Vector3 position, velocity, acceleration;
+};
+// IMUState2 (BasicLaserMapping.h:47-76)
+struct IMUState2 {
+  Time stamp;
+  Angle roll, pitch;
+};
+namespace detail {
+inline double seconds(const Time& t) { return toSec(t.time_since_epoch()); }
+}
+#endif
+
 class BasicScanRegistration {
  public:
   ~BasicScanRegistration() { loamx_scanreg_destroy(_h); }
+#ifdef LOAMX_REFERENCE_TYPES
+  // the reference's own signatures (BasicScanRegistration.h:140-150): time points instead of seconds
+  void processScanlines(const Time& scanTime, std::vector<CloudXYZI> const& laserCloudScans) {
+    setScanTime(detail::seconds(scanTime));
+    _sweepStart = scanTime;
+    processScanlines<int>(0, laserCloudScans);
+  }
+  void updateIMUData(Vector3& acc, IMUState& newState) {
+    updateIMUData(detail::seconds(newState.stamp), newState.roll.rad(), newState.pitch.rad(), newState.yaw.rad(), acc.x(), acc.y(), acc.z());
+  }
+  auto const& sweepStart() { return _sweepStart; }
+#endif
   bool configure(const RegistrationParams& config = RegistrationParams()) {
     _config = config;
     loamx_scanreg_destroy(_h);
@@ -182,10 +243,11 @@ class BasicScanRegistration {
     if (!_h && !configure(_config)) throw std::runtime_error(std::string("loamx: ") + loamx_last_error());
     detail::check(loamx_scanreg_set_time(_h, scanTimeSec));
   }
-  auto const& imuTransform() {   // updateIMUTransform (:258-281); zeros without IMU data
+  auto const& imuTransform() {   // updateIMUTransform (:258-281), a cloud of 4 points; zeros without IMU data
     float t[12] = {0};
     if (_h) detail::check(loamx_scanreg_get_imu_trans(_h, t));
-    for (int k = 0; k < 4; k++) { _imuTrans[k].x = t[3 * k]; _imuTrans[k].y = t[3 * k + 1]; _imuTrans[k].z = t[3 * k + 2]; }
+    _imuTrans.points.resize(4);
+    for (int k = 0; k < 4; k++) { _imuTrans.points[k].x = t[3 * k]; _imuTrans.points[k].y = t[3 * k + 1]; _imuTrans.points[k].z = t[3 * k + 2]; }
     return _imuTrans;
   }
   auto const& laserCloud() { return _laserCloud; }
@@ -199,7 +261,10 @@ class BasicScanRegistration {
   loamx_scanreg* _h = nullptr;
   RegistrationParams _config;
   CloudXYZI _laserCloud, _cornerPointsSharp, _cornerPointsLessSharp, _surfacePointsFlat, _surfacePointsLessFlat;
-  std::array<loamx_pcl::PointXYZ, 4> _imuTrans{};
+  loamx_pcl::PointCloud<loamx_pcl::PointXYZ> _imuTrans;
+#ifdef LOAMX_REFERENCE_TYPES
+  Time _sweepStart;
+#endif
   std::vector<uint32_t> _ringSizes;
 };
 
@@ -238,8 +303,8 @@ class BasicLaserOdometry {
     detail::check(rc);
     if (rc == LOAMX_OK) _frameCount++;
     float t[6];
-    detail::check(loamx_odom_get_transform(_h, t)); _transform = Twist::from(t);
-    detail::check(loamx_odom_get_transform_sum(_h, t)); _transformSum = Twist::from(t);
+    detail::check(loamx_odom_get_transform(_h, t)); _transform = detail::twist_from(t);
+    detail::check(loamx_odom_get_transform_sum(_h, t)); _transformSum = detail::twist_from(t);
     detail::out_cloud(*_lastCornerCloud, _cornerPointsLessSharp->size() + 16, [&](loamx_cloud* o) { return loamx_odom_get_last_clouds(_h, o, nullptr); });
     detail::out_cloud(*_lastSurfaceCloud, _surfPointsLessFlat->size() + 16, [&](loamx_cloud* o) { return loamx_odom_get_last_clouds(_h, nullptr, o); });
   }
@@ -281,13 +346,18 @@ class BasicLaserMapping {
     _cfg.max_iterations = (int)maxIterations;
   }
   ~BasicLaserMapping() { loamx_map_destroy(_h); }
+#ifdef LOAMX_REFERENCE_TYPES
+  // the reference's own signatures (BasicLaserMapping.h:85-86)
+  void updateIMU(IMUState2 const& newState) { updateIMU(detail::seconds(newState.stamp), newState.roll.rad(), newState.pitch.rad()); }
+  bool process(Time const& laserOdometryTime) { return processAt(detail::seconds(laserOdometryTime)); }
+#endif
   // updateIMU(IMUState2) (:602-605): stamp in seconds on the clock of the process() times
   void updateIMU(double stampSec, float roll, float pitch) { ensure(); detail::check(loamx_map_update_imu(_h, stampSec, roll, pitch)); }
   // process(laserOdometryTime) with the time as seconds (needed by the IMU blend of transformUpdate only)
   bool processAt(double laserOdometryTimeSec) {
     ensure();
     detail::check(loamx_map_set_time(_h, laserOdometryTimeSec));
-    return process(0);
+    return process<int>(0);
   }
   template <class TimeT> bool process(TimeT const&) {   // BasicLaserMapping.cpp:266-599
     ensure();
@@ -295,8 +365,8 @@ class BasicLaserMapping {
     int rc = loamx_map_process(_h, &a, &b, &f);
     detail::check(rc);
     float t[6];
-    detail::check(loamx_map_get_transform(_h, 0, t)); _transformAftMapped = Twist::from(t);
-    detail::check(loamx_map_get_transform(_h, 1, t)); _transformBefMapped = Twist::from(t);
+    detail::check(loamx_map_get_transform(_h, 0, t)); _transformAftMapped = detail::twist_from(t);
+    detail::check(loamx_map_get_transform(_h, 1, t)); _transformBefMapped = detail::twist_from(t);
     if (loamx_map_has_fresh_map(_h))
       detail::out_cloud(_laserCloudSurroundDS, 1 << 16, [&](loamx_cloud* o) { return loamx_map_get_surround(_h, o); });
     return rc == LOAMX_OK;
@@ -308,7 +378,7 @@ class BasicLaserMapping {
   }
   void updateOdometry(Twist const& twist) {
     float t[6];
-    twist.to(t);
+    detail::twist_to(twist, t);
     ensure();
     detail::check(loamx_map_update_odometry(_h, t));
   }
@@ -366,8 +436,8 @@ class BasicTransformMaintenance {
   }
   void updateMappingTransform(Twist const& transformAftMapped, Twist const& transformBefMapped) {
     float a[6], b[6];
-    transformAftMapped.to(a);
-    transformBefMapped.to(b);
+    detail::twist_to(transformAftMapped, a);
+    detail::twist_to(transformBefMapped, b);
     detail::check(loamx_tm_update_mapping_transform(_h, a, b));
   }
   void transformAssociateToMap() {

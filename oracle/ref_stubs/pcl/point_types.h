@@ -8,13 +8,14 @@
 #define pcl_isfinite(x) std::isfinite(x)
 
 namespace pcl {
-struct PointXYZ {
+// the records have PCL's own size and alignment (16 / 32 bytes, 16-byte aligned: x y z 1 | intensity pad pad pad)
+struct alignas(16) PointXYZ {
   union { float data[4]; struct { float x, y, z; }; };
   PointXYZ() : data{0.f, 0.f, 0.f, 1.f} {}
 };
-struct PointXYZI {
+struct alignas(16) PointXYZI {
   union { float data[4]; struct { float x, y, z; }; };
-  float intensity;
-  PointXYZI() : data{0.f, 0.f, 0.f, 1.f}, intensity(0.f) {}
+  union { struct { float intensity; }; float data_c[4]; };
+  PointXYZI() : data{0.f, 0.f, 0.f, 1.f}, data_c{0.f, 0.f, 0.f, 0.f} {}
 };
 }  // namespace pcl

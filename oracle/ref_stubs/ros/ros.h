@@ -10,10 +10,22 @@
 #define ROS_WARN(...) ((void)0)
 
 namespace ros {
+struct Duration {
+  double s = 0;
+  double toSec() const { return s; }
+};
 struct Time {
   uint32_t sec = 0, nsec = 0;
   Time& fromNSec(uint64_t t) { sec = (uint32_t)(t / 1000000000ull); nsec = (uint32_t)(t % 1000000000ull); return *this; }
+  double toSec() const { return (double)sec + 1e-9 * (double)nsec; }
+  Duration operator-(const Time& o) const { return Duration{((double)sec - (double)o.sec) + 1e-9 * ((double)nsec - (double)o.nsec)}; }
 };
+struct Rate {
+  explicit Rate(double) {}
+  bool sleep() { return true; }
+};
+inline bool ok() { return false; }          // the nodes' spin loops end at once
+inline void spinOnce() {}
 struct Publisher { template <class M> void publish(const M&) const {} };
 struct Subscriber {};
 struct NodeHandle {

@@ -416,3 +416,92 @@ def test_frozen_map_registration_equals_the_reference(orc, small_world):
     for name in ("corner_stack_ds", "surf_stack_ds"):
         assert np.array_equal(o.cloud(name), r.cloud(name)), name
     assert o.stats()["iterations"] >= 3 and np.abs(po[3:] - gt[3:]).max() < 0.03
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The silent guards and the degeneracy handling (SURVEY.md §8c checklist 5-7), oracle vs the compiled reference.
+def _corridor():
+    """two endless walls along z, ground and ceiling: nothing constrains the motion along the corridor"""
+    w = synth.World(half_extent=400.0, pitch=1000.0)
+    w.boxes = np.array([[-6.0, -5.0, -399.0, 399.0], [5.0, 6.0, -399.0, 399.0]])
+    return w
+
+
+@needs_all
+def test_degenerate_corridor_equals_the_reference(orc):
+    """isDegenerate: eigenvalues of AtA below 10 (odometry, :561-597) / 100 (mapping, :869-905) on the first iteration, the
+    projector built from the ROW-zeroed eigenvector matrix and reused by the later iterations"""
+    w = _corridor()
+    poses = synth.trajectory(5, step=1.0, yaw_step_deg=0.0)
+    sr, od, ro, mp, rm = op.ScanRegistration(orc), op.LaserOdometry(orc), op.RefLaserOdometry(), op.LaserMapping(orc), op.RefLaserMapping()
+    degenerate = 0
+    for k in range(5):
+        sw = synth.make_sweep(w, "VLP-16", poses[k], poses[k + 1], seed=k, az_steps=900)
+        f = sr.process(sw.points, sw.ring_sizes)
+        for o in (od, ro):
+            o.set_features(f)
+            o.process()
+        assert np.array_equal(od.transform, ro.transform) and np.array_equal(od.transform_sum, ro.transform_sum), k
+        args = (od.last_corner(), od.last_surf(), od.full_to_end(), od.transform_sum)
+        for m in (mp, rm):
+            m.set_inputs(*args)
+            m.process()
+        for which in ("aft", "bef", "tobe"):
+            assert np.array_equal(mp.transform(which), rm.transform(which)), (k, which)
+        degenerate += mp.stats()["degenerate"]
+    assert degenerate >= 3
+    assert abs(od.transform[5]) < 0.2                                           # 1 m per sweep along the corridor went unobserved
+
+
+@needs_od
+def test_odometry_guards_equal_the_reference(orc, small_world):
+    """(a) fewer than 10 selected rows -> the iteration is skipped and the motion estimate stays (:485-488): the previous sweep
+    is 60 m away, no neighbour within 5 m; (b) previous clouds of <= 10 corner / <= 100 surface points -> no optimisation at
+    all, the pose is still accumulated (:222)"""
+    sw = _sweeps(small_world, "VLP-16", 2, 900)
+    sr = op.ScanRegistration(orc)
+    f0, f1 = sr.process(sw[0].points, sw[0].ring_sizes), sr.process(sw[1].points, sw[1].ring_sizes)
+    far = {n: v + np.array([60.0, 0, 60.0, 0], np.float32) for n, v in f1.items()}
+    tiny = {n: v[:8] if n in ("sharp", "less_sharp") else v[:90] for n, v in f0.items()}
+    for first, second in ((f0, far), (tiny, f1)):
+        o, r = op.LaserOdometry(orc), op.RefLaserOdometry()
+        for od in (o, r):
+            od.set_features(first)
+            od.process()
+            od.set_features(second)
+            od.set_transform([0.001, 0.002, -0.001, 0.05, 0.0, -0.3])
+            od.process()
+        assert np.array_equal(o.transform, r.transform) and np.array_equal(o.transform_sum, r.transform_sum)
+        assert np.array_equal(o.transform, np.float32([0.001, 0.002, -0.001, 0.05, 0.0, -0.3]))      # untouched by the guards
+        assert np.abs(o.transform_sum).max() > 0.1                                                    # but accumulated
+
+
+@needs_mp
+def test_mapping_guards_equal_the_reference(orc, small_world):
+    """(a) a sub-map of <= 10 corner or <= 100 surface points: optimisation AND transformUpdate are skipped (:628-629), Bef / Aft
+    keep their stale values; (b) fewer than 50 selected rows: the iteration is skipped (:826-828) — the sweep sits 40 m above its map"""
+    sw = _sweeps(small_world, "VLP-16", 2, 900)
+    sr, od = op.ScanRegistration(orc), op.LaserOdometry(orc)
+    od.set_features(sr.process(sw[0].points, sw[0].ring_sizes))
+    od.process()
+    lc, ls, full = od.last_corner(), od.last_surf(), od.full_to_end()
+    for case in ("sparse", "far"):
+        o, r = op.LaserMapping(orc), op.RefLaserMapping()
+        for m in (o, r):
+            if case == "sparse":
+                m.set_inputs(lc[:9], ls[:95], full, np.zeros(6, np.float32))
+                m.process()                                                    # frame 0 only inserts; its map stays below the guard
+                m.set_inputs(lc, ls, full, np.float32([0, 0.01, 0, 0.1, 0, 0.5]))
+            else:
+                m.set_inputs(lc, ls, full, np.zeros(6, np.float32))
+                m.process()
+                m.set_inputs(lc, ls, full, np.float32([0, 0, 0, 0, 40.0, 0]))
+            m.process()
+        for which in ("aft", "bef", "tobe", "sum"):
+            assert np.array_equal(o.transform(which), r.transform(which)), (case, which)
+        for name in ("corner_cubes", "surf_cubes"):
+            assert np.array_equal(o.cloud(name), r.cloud(name)), (case, name)
+        if case == "sparse":
+            assert o.stats()["optimized"] == 0 and np.array_equal(o.transform("aft"), np.zeros(6, np.float32))
+        else:
+            assert o.stats()["optimized"] == 1 and o.stats()["sel"] < 50

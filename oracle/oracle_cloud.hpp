@@ -50,7 +50,7 @@ inline void voxel_grid(const Cloud& in, float leaf, Cloud& out) {
     maxb[a] = (int)std::floor(mx[a] * inv);
     d[a] = (int64_t)std::floor(mx[a] * inv) - (int64_t)std::floor(mn[a] * inv) + 1;
   }
-  if (d[0] * d[1] * d[2] > (int64_t)std::numeric_limits<int32_t>::max()) {
+  if ((__int128)d[0] * d[1] * d[2] > (__int128)std::numeric_limits<int32_t>::max()) {   // (128-bit: PCL's own 64-bit product can wrap)
     out = in;  // "Leaf size is too small for the input dataset" -> input copied through
     return;
   }

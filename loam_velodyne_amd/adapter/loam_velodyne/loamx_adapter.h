@@ -174,6 +174,12 @@ class BasicScanRegistration {
     updateIMUData(detail::seconds(newState.stamp), newState.roll.rad(), newState.pitch.rad(), newState.yaw.rad(), acc.x(), acc.y(), acc.z());
   }
   auto const& sweepStart() { return _sweepStart; }
+  // MultiScanRegistration::process(laserCloudIn, scanTime) on the device, with the reference's time point
+  template <class CloudXYZ> void processRawSweep(const Time& scanTime, CloudXYZ const& laserCloudIn, float lowerBoundDeg, float upperBoundDeg, uint16_t nScanRings) {
+    setScanTime(detail::seconds(scanTime));
+    _sweepStart = scanTime;
+    processRawSweep<int, CloudXYZ>(0, laserCloudIn, lowerBoundDeg, upperBoundDeg, nScanRings);
+  }
 #endif
   bool configure(const RegistrationParams& config = RegistrationParams()) {
     _config = config;

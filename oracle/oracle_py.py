@@ -638,3 +638,74 @@ class RefMultiScanRegistration:
             return None
         return self._results()
 
+
+class RefNodes:
+    """The reference's FOUR NODES (MultiScanRegistration -> LaserOdometry -> LaserMapping -> TransformMaintenance: its own node
+    classes and Basic* classes compiled where they lie) in one process over the in-process topic bus of oracle/ref_stubs — see
+    oracle/ref_nodes_shim.cpp.  `lib` selects the build: None = oracle/_ref/libref_nodes.so (the reference, CPU); a path = the same
+    node sources linked against the product's adapter (needs a GPU).  One instance at a time per library (the reference keeps
+    process-global kd-trees, BasicLaserMapping.cpp:623-624)."""
+    TOPICS = ("/laser_odom_to_init", "/aft_mapped_to_init", "/integrated_to_init")
+    _libs = {}
+
+    @classmethod
+    def _load(cls, lib):
+        path = lib or os.path.join(_HERE, "_ref", "libref_nodes.so")
+        if path not in cls._libs:
+            if not os.path.exists(path):
+                return None
+            L = C.CDLL(path)
+            L.nodes_create.restype = C.c_void_p
+            L.nodes_last_error.restype = C.c_char_p
+            cls._libs[path] = L
+        return cls._libs[path]
+
+    @classmethod
+    def available(cls, lib=None):
+        return cls._load(lib) is not None
+
+    def __init__(self, lidar="VLP-16", lib=None, **params):
+        self.L = self._load(lib)
+        assert self.L is not None
+        self.L.nodes_reset_bus()
+        for k, v in dict(lidar=lidar, **params).items():
+            self.L.nodes_set_param(k.encode(), str(v).encode())
+        self.h = C.c_void_p(self.L.nodes_create())
+        assert self.L.nodes_ok(self.h), "node set-up failed: " + self.L.nodes_last_error(self.h).decode()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.nodes_destroy(self.h)
+
+    def push_imu(self, sec, nsec, quat_xyzw, acc_xyz):
+        q = np.ascontiguousarray(quat_xyzw, np.float64)
+        a = np.ascontiguousarray(acc_xyz, np.float64)
+        if self.L.nodes_push_imu(self.h, int(sec), int(nsec), q.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError(self.L.nodes_last_error(self.h).decode())
+
+    def push_cloud(self, raw_xyz, sec, nsec):
+        raw = np.ascontiguousarray(raw_xyz, np.float32).reshape(-1, 3)
+        if self.L.nodes_push_cloud(self.h, raw.ctypes.data_as(C.c_void_p), len(raw), int(sec), int(nsec)) != 0:
+            raise RuntimeError(self.L.nodes_last_error(self.h).decode())
+
+    def odometry(self, topic):
+        """every message published on `topic` so far: (stamps (m,), values (m,13) = quaternion xyzw, position, twist angular, linear)"""
+        w = self.TOPICS.index(topic)
+        m = self.L.nodes_odom_count(self.h, w)
+        stamps, vals = np.zeros(m), np.zeros((m, 13), np.float32)
+        for i in range(m):
+            s = C.c_double()
+            self.L.nodes_odom_get(self.h, w, i, C.byref(s), vals[i].ctypes.data_as(C.c_void_p))
+            stamps[i] = s.value
+        return stamps, vals
+
+    def clouds(self, which):
+        """the payloads published on /velodyne_cloud_registered (0) or /laser_cloud_surround (1), each (n,4)"""
+        out = []
+        for i in range(self.L.nodes_cloud_count(self.h, which)):
+            n = self.L.nodes_cloud_get(self.h, which, i, None, 0)
+            a = np.zeros(max(n, 1), np.float32)
+            self.L.nodes_cloud_get(self.h, which, i, a.ctypes.data_as(C.c_void_p), n)
+            out.append(a[:n].reshape(-1, 4).copy())
+        return out
+

@@ -71,7 +71,8 @@ int ref_ms_handle_message(void* h, const float* raw, int n, unsigned sec, unsign
   auto* m = (MultiScanRegistration*)h;
   auto msg = std::make_shared<sensor_msgs::PointCloud2>();
   msg->header.stamp.sec = sec; msg->header.stamp.nsec = nsec;
-  msg->xyz.assign(raw, raw + 3 * (size_t)n);
+  msg->data.assign(raw, raw + 3 * (size_t)n);
+  msg->floats_per_point = 3;
   const int before = m->_systemDelay;
   m->handleCloudMessage(msg);
   return before > 0 ? 0 : 1;

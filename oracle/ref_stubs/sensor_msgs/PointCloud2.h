@@ -1,4 +1,5 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY.  NOT ROS: a message that carries a time stamp and a flat (x, y, z) payload.
+// ORACLE — TEST INFRASTRUCTURE ONLY.  NOT ROS: a message that carries a time stamp and a flat float payload of `floats_per_point`
+// values per point (3: x y z; 4: x y z intensity) instead of the byte-serialised wire format.
 #pragma once
 #include <string>
 #include <vector>
@@ -7,7 +8,8 @@ namespace std_msgs { struct Header { ros::Time stamp; std::string frame_id; }; }
 namespace sensor_msgs {
 struct PointCloud2 {
   std_msgs::Header header;
-  std::vector<float> xyz;
+  std::vector<float> data;
+  int floats_per_point = 3;
   typedef boost::shared_ptr<PointCloud2> Ptr;
   typedef boost::shared_ptr<PointCloud2 const> ConstPtr;
 };

@@ -1,0 +1,123 @@
+"""Test helper (not a test): the glue of the reference's four ROS nodes restated over ROS-free building blocks, so that the same
+message sequence can be pushed through (a) the oracle's classes, (b) the product's C-ABI handles, and compared with (c) the
+reference's own node classes running over the in-process bus (oracle_py.RefNodes).
+
+What is restated here is only the node glue, each step citing the wrapper it follows:
+  ScanRegistration::handleIMUMessage  src/lib/ScanRegistration.cpp:164-184    quaternion -> roll/pitch/yaw, gravity removal, axis remap
+  LaserOdometry::hasNewData/process/publishResult  src/lib/LaserOdometry.cpp:272-331   ioRatio, transformToEnd of the full cloud
+  LaserMapping::laserOdometryHandler/imuHandler/process/publishResult  src/lib/LaserMapping.cpp:205-222, :252-312
+  TransformMaintenance handlers  src/lib/TransformMaintenance.cpp:66-115
+The backends supply the Basic* behaviour and the wire conversions."""
+import numpy as np
+
+
+class OracleBackend:
+    def __init__(self, orc, op, lidar, scan_period=0.1):
+        self.orc, self.op, self.lidar = orc, op, lidar
+        self.sr, self.od, self.mp = op.ScanRegistration(orc, scanPeriod=scan_period), op.LaserOdometry(orc, scanPeriod=scan_period), op.LaserMapping(orc, scanPeriod=scan_period)
+        self._tm = [np.zeros(6, np.float32)] * 3        # transformSum, befMapped, aftMapped of the maintenance node
+
+    # scan registration
+    def sr_update_imu(self, stamp, roll, pitch, yaw, acc): self.sr.update_imu(stamp, roll, pitch, yaw, acc)
+    def sr_process_raw(self, raw, t): return self.sr.process_raw(raw, t, self.lidar)
+    # odometry
+    def od_update_imu(self, t12): self.od.update_imu(t12)
+    def od_process(self, f):
+        self.od.set_features(f)
+        self.od.process()
+        return self.od.stats()["frame"]
+    def od_transform_sum(self): return self.od.transform_sum
+    def od_last(self): return self.od.last_corner(), self.od.last_surf()
+    def od_full_to_end(self): return self.od.full_to_end()
+    # mapping
+    def mp_update_imu(self, stamp, roll, pitch): self.mp.update_imu(stamp, roll, pitch)
+    def mp_process(self, lc, ls, full, sum6, t):
+        self.mp.set_time(t)
+        self.mp.set_inputs(lc, ls, full, sum6)
+        return self.mp.process()
+    def mp_transform(self, which): return self.mp.transform(which)
+    def mp_full_res(self): return self.mp.cloud("full_res")
+    def mp_fresh_surround(self): return self.mp.cloud("surround_ds") if self.mp.has_fresh_map() else None
+    # maintenance + wire
+    def tm_update_odometry(self, t6): self._tm[0] = np.float32(t6)
+    def tm_update_mapping(self, aft, bef): self._tm[2], self._tm[1] = np.float32(aft), np.float32(bef)
+    def tm_associate(self): return self.op.tm_associate(self.orc, self._tm[0], self._tm[1], self._tm[2])
+    def pose_to_quat(self, rot3): return self.op.wire_pose_to_quat(self.orc, rot3)
+    def quat_to_pose(self, q4): return self.op.wire_quat_to_pose(self.orc, q4)
+
+
+class ProductMaintenanceBackend(OracleBackend):
+    """the oracle for the three device stages, the PRODUCT's host-side pose fusion and wire conversions (loamx_tm_*, loamx_wire_*:
+    no device needed) for the fourth node and every message conversion"""
+    def __init__(self, orc, op, loamx, lidar, scan_period=0.1):
+        super().__init__(orc, op, lidar, scan_period)
+        self.loamx, self.tm = loamx, loamx.TransformMaintenance()
+    def tm_update_odometry(self, t6): self.tm.update_odometry(t6)
+    def tm_update_mapping(self, aft, bef): self.tm.update_mapping_transform(aft, bef)
+    def tm_associate(self): return self.tm.associate_to_map()
+    def pose_to_quat(self, rot3): return self.loamx.wire_pose_to_quat(rot3)
+    def quat_to_pose(self, q4): return self.loamx.wire_quat_to_pose(q4)
+
+
+def _odom_msg(stamp, quat, pos, ang=(0, 0, 0), lin=(0, 0, 0)):
+    """what the collector of ref_nodes_shim.cpp keeps of a nav_msgs/Odometry: 13 values rounded to float"""
+    return stamp, np.float32(np.concatenate([quat, np.float64(pos), np.float64(ang), np.float64(lin)]))
+
+
+class FourNodes:
+    TOPICS = ("/laser_odom_to_init", "/aft_mapped_to_init", "/integrated_to_init")
+
+    def __init__(self, backend, io_ratio=2):
+        self.b, self.io_ratio = backend, io_ratio
+        self.out = {t: [] for t in self.TOPICS}
+        self.registered, self.surround = [], []
+        self._map_in = None            # the odometry node's last publication for the mapping node
+
+    @staticmethod
+    def _rpy(q4):   # tf::Matrix3x3(q).getRPY, double
+        x, y, z, w = (float(v) for v in q4)
+        roll = np.arctan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y))
+        s = 2 * (w * y - z * x)
+        pitch = np.copysign(np.pi / 2, s) if abs(s) >= 1 else np.arcsin(s)
+        yaw = np.arctan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))
+        return roll, pitch, yaw
+
+    def push_imu(self, stamp, quat_xyzw, acc_xyz):
+        roll, pitch, yaw = self._rpy(quat_xyzw)
+        la = np.float64(acc_xyz)
+        acc = np.float32([la[1] - np.sin(roll) * np.cos(pitch) * 9.81, la[2] - np.cos(roll) * np.cos(pitch) * 9.81, la[0] + np.sin(pitch) * 9.81])
+        self.b.sr_update_imu(stamp, np.float32(roll), np.float32(pitch), np.float32(yaw), acc)    # ScanRegistration.cpp:171-183
+        self.b.mp_update_imu(stamp, np.float32(roll), np.float32(pitch))                          # LaserMapping.cpp:217-222
+
+    def push_cloud(self, raw, stamp):
+        b = self.b
+        f = b.sr_process_raw(raw, stamp)                       # MultiScanRegistration::process + publishResult (stamp = sweep start)
+        b.od_update_imu(f["imu_trans"])                        # imuTransHandler -> updateIMU
+        frame = b.od_process(f)                                # all six topics are fresh and carry the same stamp
+        tsum = b.od_transform_sum()
+        q = b.pose_to_quat(tsum[:3])                           # LaserOdometry.cpp:300-308
+        self.out[self.TOPICS[0]].append(_odom_msg(stamp, q, tsum[3:]))
+        # transform maintenance, odometry side (TransformMaintenance.cpp:66-95): the message carries doubles made from floats
+        rot = b.quat_to_pose(q)
+        b.tm_update_odometry(np.concatenate([rot, np.float32(np.float64(tsum[3:]))]))
+        m = b.tm_associate()
+        self.out[self.TOPICS[2]].append(_odom_msg(stamp, b.pose_to_quat(m[:3]), m[3:]))
+        if self.io_ratio < 2 or frame % self.io_ratio == 1:    # LaserOdometry.cpp:320
+            lc, ls = b.od_last()
+            full = b.od_full_to_end()
+            # mapping: laserOdometryHandler (LaserMapping.cpp:205-215) then process (needs the four inputs fresh, same stamp)
+            sum6 = np.concatenate([b.quat_to_pose(q), np.float32(np.float64(tsum[3:]))])
+            if b.mp_process(lc, ls, full, sum6, stamp):
+                sur = b.mp_fresh_surround()
+                if sur is not None:
+                    self.surround.append(sur)
+                self.registered.append(b.mp_full_res())
+                aft, bef = b.mp_transform("aft"), b.mp_transform("bef")
+                qa = b.pose_to_quat(aft[:3])
+                self.out[self.TOPICS[1]].append(_odom_msg(stamp, qa, aft[3:], bef[:3], bef[3:]))
+                # transform maintenance, mapping side (TransformMaintenance.cpp:97-115)
+                b.tm_update_mapping(np.concatenate([b.quat_to_pose(qa), np.float32(np.float64(aft[3:]))]), np.float32(np.float64(bef)))
+
+    def odometry(self, topic):
+        msgs = self.out[topic]
+        return np.array([s for s, _ in msgs]), (np.stack([v for _, v in msgs]) if msgs else np.zeros((0, 13), np.float32))

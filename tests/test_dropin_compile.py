@@ -26,6 +26,13 @@ def test_reference_wrappers_compile_and_link_against_the_adapter():
     for want in ("loam::LaserMapping::process()", "loam::LaserOdometry::process()", "loam::ScanRegistration::handleIMUMessage",
                  "loam::TransformMaintenance::laserOdometryHandler", "loam::LaserMapping::imuHandler"):
         assert want in syms, want
+    # the whole node graph over the product (the four wrappers + the swapped MultiScanRegistration unit + the test harness)
+    nodes = os.path.join(ADAPTER, "_dropin", "libloam_nodes.so")
+    assert os.path.exists(nodes)
+    nsyms = subprocess.run(["nm", "-DC", "--defined-only", nodes], capture_output=True, text=True).stdout
+    for want in ("loam::MultiScanRegistration::handleCloudMessage", "nodes_push_cloud", "loam::LaserMapping::process()"):
+        assert want in nsyms, want
+    assert "loamx_scanreg_process_raw" in subprocess.run(["nm", "-D", "--undefined-only", nodes], capture_output=True, text=True).stdout
     # and the library calls behind them are the C-ABI's, left undefined for libloamx.so to provide
     und = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True).stdout
     for want in ("loamx_map_process", "loamx_odom_process", "loamx_scanreg_update_imu", "loamx_tm_associate_to_map", "loamx_map_update_imu"):

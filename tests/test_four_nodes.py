@@ -1,0 +1,78 @@
+"""CPU: the whole four-node pipeline.  The reference's own node classes — MultiScanRegistration, LaserOdometry, LaserMapping,
+TransformMaintenance with their Basic* cores, compiled where they lie — run in one process over an in-process topic bus
+(oracle/ref_nodes_shim.cpp) and are fed /multi_scan_points and /imu/data messages; the same messages go through the node glue
+restated in tests/four_nodes.py over (a) the oracle and (b) the oracle + the PRODUCT's host-side pose fusion and wire conversions
+(loamx_tm_*, loamx_wire_*).  Every nav_msgs/Odometry the nodes publish and every registered / surround cloud must agree."""
+import numpy as np
+import pytest
+
+import oracle_py as op
+from four_nodes import FourNodes, OracleBackend, ProductMaintenanceBackend
+from loam_velodyne_amd import loamx, synth
+
+pytestmark = pytest.mark.skipif(not op.RefNodes.available(), reason="oracle/_ref/libref_nodes.so not built (no /root/reference here)")
+TICK = 1.0 / 512      # stamps exact both as double seconds and as (sec, nsec)
+
+
+def _stamp(ticks):
+    ns = ticks * 1953125
+    return ticks * TICK, 1000 + ns // 10**9, ns % 10**9
+
+
+def _quat(roll, pitch, yaw):
+    cr, sr, cp, sp, cy, sy = np.cos(roll / 2), np.sin(roll / 2), np.cos(pitch / 2), np.sin(pitch / 2), np.cos(yaw / 2), np.sin(yaw / 2)
+    return np.array([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy])
+
+
+def _run(orc, small_world, backend_cls, lidar, az, n, imu, **extra):
+    ref = op.RefNodes(lidar)
+    mine = FourNodes(backend_cls(orc, op, *extra.get("args", ()), lidar))
+    poses = synth.trajectory(n)
+    rng = np.random.default_rng(5)
+    for k in range(n):
+        if imu:
+            for j in range(11):                                # ~100 Hz messages up to the sweep's stamp
+                t, sec, nsec = _stamp(51 * k + 5 * j - 45)
+                q = _quat(*rng.uniform(-0.02, 0.02, 3))
+                acc = np.array([0.0, 0.0, 9.81]) + rng.uniform(-0.3, 0.3, 3)
+                ref.push_imu(sec, nsec, q, acc)
+                mine.push_imu(1000 + t, q, acc)
+        sw = synth.make_sweep(small_world, lidar, poses[k], poses[k + 1], seed=200 + k, az_steps=az)
+        raw = synth.to_raw(sw, bad_every=89)
+        t, sec, nsec = _stamp(51 * k + 5)
+        ref.push_cloud(raw, sec, nsec)
+        mine.push_cloud(raw, 1000 + t)
+    return ref, mine, poses
+
+
+@pytest.mark.parametrize("lidar,az,imu", [("VLP-16", 900, False), ("VLP-16", 600, True), ("HDL-32", 1024, False)])
+def test_oracle_composition_equals_the_reference_nodes(orc, small_world, lidar, az, imu):
+    ref, mine, poses = _run(orc, small_world, OracleBackend, lidar, az, 7, imu)
+    for topic in ref.TOPICS:
+        sr, vr = ref.odometry(topic)
+        sm, vm = mine.odometry(topic)
+        assert len(sr) == len(sm) and len(sr) == (3 if "aft" in topic else 7), topic
+        assert np.array_equal(sr, sm), topic
+        assert np.array_equal(vr, vm), topic                   # orientation, position, twist of every message, bit for bit
+    for a, b in zip(ref.clouds(0), mine.registered):
+        assert np.array_equal(a, b)                            # /velodyne_cloud_registered
+    sur = ref.clouds(1)
+    assert len(sur) == len(mine.surround) == 1 and np.array_equal(sur[0], mine.surround[0])      # /laser_cloud_surround
+    # and the pipeline does its job: the integrated pose follows the ground truth
+    _, v = ref.odometry("/integrated_to_init")
+    assert np.abs(v[-1, 4:7] - poses[7, 3:]).max() < 0.5
+
+
+def test_product_pose_fusion_in_the_node_graph_equals_the_reference_nodes(orc, small_world):
+    """the fourth node and every message conversion through the product's loamx_tm_* / loamx_wire_* (host code, no device)"""
+    ref = op.RefNodes("VLP-16")
+    mine = FourNodes(ProductMaintenanceBackend(orc, op, loamx, "VLP-16"))
+    poses = synth.trajectory(7)
+    for k in range(7):
+        sw = synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=300 + k, az_steps=600)
+        raw = synth.to_raw(sw)
+        t, sec, nsec = _stamp(51 * k + 5)
+        ref.push_cloud(raw, sec, nsec)
+        mine.push_cloud(raw, 1000 + t)
+    for topic in ref.TOPICS:
+        assert np.array_equal(ref.odometry(topic)[1], mine.odometry(topic)[1]), topic

@@ -1,0 +1,51 @@
+"""GPU: the product behind the reference's own nodes.  loam_velodyne_amd/adapter/_dropin/libloam_nodes.so holds the reference's
+ScanRegistration / LaserOdometry / LaserMapping / TransformMaintenance node sources compiled UNCHANGED against loamx_adapter.h,
+the swapped MultiScanRegistration unit and libloamx.so (adapter/dropin_check.sh, built where /root/reference exists and shipped
+as a binary); oracle/_ref/libref_nodes.so holds the same node sources over the reference's own Basic* cores.  Both are fed the
+same /multi_scan_points and /imu/data messages through the same in-process bus, and every nav_msgs/Odometry they publish is
+compared: odometry to 1e-4, mapping (live rolling map, voxel-threshold feedback) and the fused pose to 2e-3.
+
+First written at the end of round 1 without a GPU at hand: it stays opt-in (LOAMX_NODES_GPU=1) until it has been run once."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as op
+from loam_velodyne_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "loam_velodyne_amd", "adapter", "_dropin", "libloam_nodes.so")
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("LOAMX_NODES_GPU") != "1", reason="opt-in until verified on a GPU (set LOAMX_NODES_GPU=1)"),
+              pytest.mark.skipif(not (os.path.exists(LIB) and op.RefNodes.available()), reason="node-graph libraries not built")]
+
+
+@pytest.mark.parametrize("imu", [False, True])
+def test_product_behind_the_reference_nodes(small_world, imu):
+    ref, dev = op.RefNodes("VLP-16"), op.RefNodes("VLP-16", lib=LIB)
+    poses = synth.trajectory(7)
+    rng = np.random.default_rng(5)
+    for k in range(7):
+        ns = (51 * k + 5) * 1953125
+        if imu:
+            for j in range(11):
+                ni = (51 * k + 5 * j - 45) * 1953125
+                q = np.array([*rng.uniform(-0.01, 0.01, 3), 1.0])
+                q /= np.linalg.norm(q)
+                acc = np.array([0.0, 0.0, 9.81]) + rng.uniform(-0.3, 0.3, 3)
+                for n in (ref, dev):
+                    n.push_imu(1000 + ni // 10**9, ni % 10**9, q, acc)
+        sw = synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=200 + k, az_steps=900)
+        raw = synth.to_raw(sw, bad_every=89)
+        for n in (ref, dev):
+            n.push_cloud(raw, 1000 + ns // 10**9, ns % 10**9)
+    worst = {}
+    for topic, tol in (("/laser_odom_to_init", 1e-4), ("/aft_mapped_to_init", 2e-3), ("/integrated_to_init", 2e-3)):
+        (sr, vr), (sd, vd) = ref.odometry(topic), dev.odometry(topic)
+        assert np.array_equal(sr, sd), topic
+        worst[topic] = float(np.abs(vr - vd).max())
+        assert worst[topic] < tol, (topic, worst)
+    print("max differences per topic:", worst)
+    assert len(ref.clouds(0)) == len(dev.clouds(0)) == 3 and len(ref.clouds(1)) == len(dev.clouds(1)) == 1

@@ -59,6 +59,46 @@ class ProductMaintenanceBackend(OracleBackend):
     def quat_to_pose(self, q4): return self.loamx.wire_quat_to_pose(q4)
 
 
+class LoamxBackend:
+    """every stage through the product's C-ABI handles (loam_velodyne_amd/loamx.py): needs a GPU"""
+    def __init__(self, loamx, lidar, scan_period=0.1):
+        self.loamx, self.lidar = loamx, lidar
+        self.sr = loamx.ScanRegistration(scan_period=scan_period)
+        self.od = loamx.LaserOdometry(scan_period=scan_period)
+        self.mp = loamx.LaserMapping(scan_period=scan_period)
+        self.tm = loamx.TransformMaintenance()
+        self._full = None
+
+    def sr_update_imu(self, stamp, roll, pitch, yaw, acc): self.sr.update_imu(stamp, roll, pitch, yaw, acc)
+    def sr_process_raw(self, raw, t):
+        self.sr.set_time(t)
+        f = self.sr.process_raw(raw, self.lidar)
+        f["imu_trans"] = self.sr.imu_trans()
+        self._full = f["full"]
+        return f
+    def od_update_imu(self, t12): self.od.update_imu(t12)
+    def od_process(self, f):
+        self.od.process(f)
+        return self.od.stats()["frame"]
+    def od_transform_sum(self): return self.od.transform_sum
+    def od_last(self): return self.od.last_clouds()
+    def od_full_to_end(self): return self.od.transform_to_end(self._full)
+    def mp_update_imu(self, stamp, roll, pitch): self.mp.update_imu(stamp, roll, pitch)
+    def mp_process(self, lc, ls, full, sum6, t):
+        self.mp.set_time(t)
+        self.mp.update_odometry(sum6)
+        rc, self._registered = self.mp.process(lc, ls, full)
+        return rc == 0
+    def mp_transform(self, which): return self.mp.transform(which)
+    def mp_full_res(self): return self._registered
+    def mp_fresh_surround(self): return self.mp.surround() if self.mp.has_fresh_map() else None
+    def tm_update_odometry(self, t6): self.tm.update_odometry(t6)
+    def tm_update_mapping(self, aft, bef): self.tm.update_mapping_transform(aft, bef)
+    def tm_associate(self): return self.tm.associate_to_map()
+    def pose_to_quat(self, rot3): return self.loamx.wire_pose_to_quat(rot3)
+    def quat_to_pose(self, q4): return self.loamx.wire_quat_to_pose(q4)
+
+
 def _odom_msg(stamp, quat, pos, ang=(0, 0, 0), lin=(0, 0, 0)):
     """what the collector of ref_nodes_shim.cpp keeps of a nav_msgs/Odometry: 13 values rounded to float"""
     return stamp, np.float32(np.concatenate([quat, np.float64(pos), np.float64(ang), np.float64(lin)]))

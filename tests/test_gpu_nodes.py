@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 
 import oracle_py as op
-from loam_velodyne_amd import synth
+from four_nodes import FourNodes, LoamxBackend
+from loam_velodyne_amd import loamx, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "loam_velodyne_amd", "adapter", "_dropin", "libloam_nodes.so")
@@ -49,3 +50,19 @@ def test_product_behind_the_reference_nodes(small_world, imu):
         assert worst[topic] < tol, (topic, worst)
     print("max differences per topic:", worst)
     assert len(ref.clouds(0)) == len(dev.clouds(0)) == 3 and len(ref.clouds(1)) == len(dev.clouds(1)) == 1
+
+
+def test_c_abi_composition_vs_the_reference_nodes(small_world):
+    """the same message sequence through the node glue of tests/four_nodes.py over the product's C-ABI handles (no C++ adapter)"""
+    ref, dev = op.RefNodes("VLP-16"), FourNodes(LoamxBackend(loamx, "VLP-16"))
+    poses = synth.trajectory(7)
+    for k in range(7):
+        ns = (51 * k + 5) * 1953125
+        sw = synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=200 + k, az_steps=900)
+        raw = synth.to_raw(sw, bad_every=89)
+        ref.push_cloud(raw, 1000 + ns // 10**9, ns % 10**9)
+        dev.push_cloud(raw, 1000 + (51 * k + 5) / 512)
+    for topic, tol in (("/laser_odom_to_init", 1e-4), ("/aft_mapped_to_init", 2e-3), ("/integrated_to_init", 2e-3)):
+        (sr, vr), (sd, vd) = ref.odometry(topic), dev.odometry(topic)
+        assert np.array_equal(sr, sd), topic
+        assert np.abs(vr - vd).max() < tol, (topic, float(np.abs(vr - vd).max()))

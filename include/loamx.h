@@ -107,7 +107,9 @@ int loamx_scanreg_process_raw(loamx_scanreg* h, const loamx_multiscan_mapper* ma
                               loamx_cloud* flat, loamx_cloud* less_flat);
 
 /* IMU data for the scan registration: updateIMUData (BasicScanRegistration.cpp:82-98) feeds the
- * handle's IMU history (capacity 200, RegistrationParams::imuHistorySize); loamx_scanreg_set_time gives the scanTime of the
+ * handle's IMU history (capacity 200: the reference's buffer is created with 200 entries and ensureCapacity only grows it,
+ * include/loam_velodyne/CircularBuffer.h, so every RegistrationParams::imuHistorySize <= 200 behaves as 200; larger histories
+ * are not configurable here); loamx_scanreg_set_time gives the scanTime of the
  * next process call (times in seconds on one clock); with a non-empty history loamx_scanreg_process_raw de-skews every
  * kept point (projectPointToStartOfSweep :101-147) and loamx_scanreg_get_imu_trans returns imuTransform() (:258-281):
  * start angles, current angles, position shift, velocity change — what loamx_odom_update_imu consumes.

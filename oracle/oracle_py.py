@@ -492,11 +492,12 @@ class RefLaserMapping:
     the live-map part of LaserMapping above.  `available()` is False when oracle/_ref/libref_mapping.so is not built."""
     CLOUDS = LaserMapping.CLOUDS
     _L = None
+    _SO = "libref_mapping.so"
 
     @classmethod
     def available(cls):
         if cls._L is None:
-            path = os.path.join(_HERE, "_ref", "libref_mapping.so")
+            path = os.path.join(_HERE, "_ref", cls._SO)
             if not os.path.exists(path):
                 return False
             cls._L = C.CDLL(path)
@@ -708,4 +709,11 @@ class RefNodes:
             self.L.nodes_cloud_get(self.h, which, i, a.ctypes.data_as(C.c_void_p), n)
             out.append(a[:n].reshape(-1, 4).copy())
         return out
+
+
+class RefLaserMappingAlt(RefLaserMapping):
+    """the same reference translation unit over the ALTERNATIVE third-party arithmetic (-DREF_STUB_ALT_ARITH, ref_stubs/Eigen/Core):
+    a sensitivity probe for the operations the stand-in forwards, not a pin"""
+    _L = None
+    _SO = "libref_mapping_alt.so"
 

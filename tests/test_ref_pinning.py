@@ -505,3 +505,52 @@ def test_mapping_guards_equal_the_reference(orc, small_world):
             assert o.stats()["optimized"] == 0 and np.array_equal(o.transform("aft"), np.zeros(6, np.float32))
         else:
             assert o.stats()["optimized"] == 1 and o.stats()["sel"] < 50
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# How much can the five UNPINNED third-party operations matter?  The same reference translation units built over the
+# alternative arithmetic of the Eigen stand-in (-DREF_STUB_ALT_ARITH: double accumulation, normal equations / elimination,
+# double Jacobi) — if the poses barely move between the two builds, the real Eigen's rounding cannot move them much either.
+needs_alt = pytest.mark.skipif(not (op.RefLaserMappingAlt.available() and op.RefNodes.available(os.path.join(os.path.dirname(op.__file__), "_ref", "libref_nodes_alt.so"))),
+                               reason="oracle/_ref/*_alt.so not built")
+
+
+@needs_alt
+def test_third_party_arithmetic_sensitivity_frozen_map(orc, small_world):
+    """the benchmark's unit of work (one sweep against a frozen sub-map): the pose moves by a few 1e-6 at most"""
+    corner_map, surf_map = small_world.make_map(120000)
+    worst = 0.0
+    for trial in range(3):
+        rng = np.random.default_rng(trial)
+        gt = np.array([0.004, 0.3, -0.002, 2.0, 0.02, -3.0]) + rng.uniform(-1, 1, 6) * [0.01, 0.2, 0.01, 3, 0.02, 3]
+        sw = synth.make_sweep(small_world, "HDL-32", gt, gt, seed=33 + trial, az_steps=1024)
+        f = op.ScanRegistration(orc).process(sw.points, sw.ring_sizes)
+        guess = gt + rng.uniform(-1, 1, 6) * [0.006, 0.006, 0.006, 0.08, 0.08, 0.08]
+        res = []
+        for cls in (op.RefLaserMapping, op.RefLaserMappingAlt):
+            m = cls()
+            m.set_frozen(corner_map, surf_map)
+            res.append(m.register_frozen(f["less_sharp"], f["less_flat"], guess))
+        worst = max(worst, float(np.abs(res[0] - res[1]).max()))
+    print(f"frozen-map registration, pose change under the alternative third-party arithmetic: {worst:.2e}")
+    assert worst < 1e-5
+
+
+@needs_alt
+def test_third_party_arithmetic_sensitivity_node_graph(small_world):
+    """the four-node pipeline: the odometry stays within 1e-4; the LIVE-MAP poses are reported, not bounded tightly — the rolling
+    map feeds rounding back through its voxel grids, which is why the device path is compared with the oracle
+    from identical prior states and in frozen-map mode"""
+    alt = os.path.join(os.path.dirname(op.__file__), "_ref", "libref_nodes_alt.so")
+    a, b = op.RefNodes("VLP-16"), op.RefNodes("VLP-16", lib=alt)
+    poses = synth.trajectory(9)
+    for k in range(9):
+        sw = synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=200 + k, az_steps=900)
+        raw = synth.to_raw(sw)
+        ns = (51 * k + 5) * 1953125
+        for n in (a, b):
+            n.push_cloud(raw, 1000 + ns // 10**9, ns % 10**9)
+    d = {t: float(np.abs(a.odometry(t)[1] - b.odometry(t)[1]).max()) for t in a.TOPICS}
+    print("node graph, change under the alternative third-party arithmetic:", d)
+    assert d["/laser_odom_to_init"] < 1e-4
+    assert d["/aft_mapped_to_init"] < 5e-2 and d["/integrated_to_init"] < 5e-2

@@ -3,6 +3,8 @@ TransformMaintenance with their Basic* cores, compiled where they lie — run in
 (oracle/ref_nodes_shim.cpp) and are fed /multi_scan_points and /imu/data messages; the same messages go through the node glue
 restated in tests/four_nodes.py over (a) the oracle and (b) the oracle + the PRODUCT's host-side pose fusion and wire conversions
 (loamx_tm_*, loamx_wire_*).  Every nav_msgs/Odometry the nodes publish and every registered / surround cloud must agree."""
+import os
+
 import numpy as np
 import pytest
 
@@ -76,3 +78,38 @@ def test_product_pose_fusion_in_the_node_graph_equals_the_reference_nodes(orc, s
         mine.push_cloud(raw, 1000 + t)
     for topic in ref.TOPICS:
         assert np.array_equal(ref.odometry(topic)[1], mine.odometry(topic)[1]), topic
+
+
+MOCK = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "loam_velodyne_amd", "adapter", "_dropin", "libloam_nodes_mock.so")
+
+
+@pytest.mark.skipif(not os.path.exists(MOCK), reason="adapter/_dropin/libloam_nodes_mock.so not built (adapter/dropin_check.sh)")
+@pytest.mark.parametrize("imu", [False, True])
+def test_adapter_glue_over_the_oracle_mock(small_world, imu):
+    """Everything ABOVE the C-ABI, end to end, without a GPU: the reference's own node sources compiled against loamx_adapter.h
+    (LOAMX_REFERENCE_TYPES), the swapped MultiScanRegistration unit and the bus harness, linked against an ORACLE-BACKED TEST DOUBLE
+    of the C-ABI (oracle/mock_loamx_capi.cpp — test infrastructure under another library name, never the product).  Since the
+    oracle equals the reference bit for bit, any difference from the reference's own node graph is a bug in the adapter glue:
+    time stamps, sweepStart, the IMU hand-over, capacity retries, the ioRatio bookkeeping, the return-code conventions."""
+    ref, dev = op.RefNodes("VLP-16"), op.RefNodes("VLP-16", lib=MOCK)
+    poses = synth.trajectory(7)
+    rng = np.random.default_rng(5)
+    for k in range(7):
+        if imu:
+            for j in range(11):
+                _, sec, nsec = _stamp(51 * k + 5 * j - 45)
+                q = _quat(*rng.uniform(-0.02, 0.02, 3))
+                acc = np.array([0.0, 0.0, 9.81]) + rng.uniform(-0.3, 0.3, 3)
+                for n in (ref, dev):
+                    n.push_imu(sec, nsec, q, acc)
+        sw = synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=200 + k, az_steps=900)
+        raw = synth.to_raw(sw, bad_every=89)
+        _, sec, nsec = _stamp(51 * k + 5)
+        for n in (ref, dev):
+            n.push_cloud(raw, sec, nsec)
+    for topic in ref.TOPICS:
+        (sr, vr), (sd, vd) = ref.odometry(topic), dev.odometry(topic)
+        assert np.array_equal(sr, sd) and np.array_equal(vr, vd), topic
+    for which in (0, 1):
+        a, b = ref.clouds(which), dev.clouds(which)
+        assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))

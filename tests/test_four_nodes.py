@@ -80,10 +80,10 @@ def test_product_pose_fusion_in_the_node_graph_equals_the_reference_nodes(orc, s
         assert np.array_equal(ref.odometry(topic)[1], mine.odometry(topic)[1]), topic
 
 
-MOCK = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "loam_velodyne_amd", "adapter", "_dropin", "libloam_nodes_mock.so")
+MOCK = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dropin", "libloam_nodes_mock.so")
 
 
-@pytest.mark.skipif(not os.path.exists(MOCK), reason="adapter/_dropin/libloam_nodes_mock.so not built (adapter/dropin_check.sh)")
+@pytest.mark.skipif(not os.path.exists(MOCK), reason="tests/_dropin/libloam_nodes_mock.so not built (tests/dropin_check.sh)")
 @pytest.mark.parametrize("imu", [False, True])
 def test_adapter_glue_over_the_oracle_mock(small_world, imu):
     """Everything ABOVE the C-ABI, end to end, without a GPU: the reference's own node sources compiled against loamx_adapter.h

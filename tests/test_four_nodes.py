@@ -4,6 +4,8 @@ TransformMaintenance with their Basic* cores, compiled where they lie — run in
 restated in tests/four_nodes.py over (a) the oracle and (b) the oracle + the PRODUCT's host-side pose fusion and wire conversions
 (loamx_tm_*, loamx_wire_*).  Every nav_msgs/Odometry the nodes publish and every registered / surround cloud must agree."""
 import os
+import struct
+import subprocess
 
 import numpy as np
 import pytest
@@ -113,3 +115,31 @@ def test_adapter_glue_over_the_oracle_mock(small_world, imu):
     for which in (0, 1):
         a, b = ref.clouds(which), dev.clouds(which)
         assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(MOCK), "adapter_test_mock")), reason="tests/_dropin/adapter_test_mock not built")
+def test_plain_adapter_driver_over_the_oracle_mock(orc, small_world, tmp_path):
+    """loam_velodyne_amd/adapter/adapter_test.cpp (the adapter with its OWN value types, as the GPU test runs it) linked against the
+    oracle-backed test double: scan registration -> odometry -> mapping -> pose fusion must print exactly the oracle chain's poses,
+    and its built-in raw-ingestion and pose-fusion self-checks must hold"""
+    n = 5
+    poses = synth.trajectory(n)
+    sws = [synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=k, az_steps=900) for k in range(n)]
+    path = tmp_path / "sweeps.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("i", n))
+        for sw in sws:
+            f.write(struct.pack("i", len(sw.ring_sizes)))
+            f.write(np.asarray(sw.ring_sizes, np.int32).tobytes())
+            f.write(np.ascontiguousarray(sw.points, np.float32).tobytes())
+    out = subprocess.run([os.path.join(os.path.dirname(MOCK), "adapter_test_mock"), str(path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    rows = np.array([[float(v) for v in line.split()[1:]] for line in out.stdout.strip().splitlines()], np.float32)
+    osr, ood, omp = op.ScanRegistration(orc), op.LaserOdometry(orc), op.LaserMapping(orc)
+    for k, sw in enumerate(sws):
+        ood.set_features(osr.process(sw.points, sw.ring_sizes))
+        ood.process()
+        omp.set_inputs(ood.last_corner(), ood.last_surf(), ood.full_to_end(), ood.transform_sum)
+        omp.process()
+        assert np.array_equal(rows[k, :6], ood.transform_sum), k
+        assert np.array_equal(rows[k, 6:], omp.transform("aft")), k

@@ -21,7 +21,7 @@
 // LOAMX_REFERENCE_TYPES (implies LOAMX_USE_PCL): the build sits inside the reference's tree and keeps the reference's own
 // value-type headers — Angle.h, Vector3.h, Twist.h, time_utils.h — so that the wrappers and math_utils.h see exactly the
 // types they were written against; the adapter then adds the reference's time-stamped overloads (IMUState, IMUState2,
-// processScanlines(Time, ...), process(Time)).  tests/dropin_check.sh compiles the reference's wrapper sources this way.
+// processScanlines(Time, ...), process(Time)).  oracle/dropin_check.sh compiles the reference's wrapper sources this way.
 #ifdef LOAMX_REFERENCE_TYPES
 #ifndef LOAMX_USE_PCL
 #define LOAMX_USE_PCL

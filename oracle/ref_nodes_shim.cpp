@@ -3,7 +3,7 @@
 // the in-process topic bus of oracle/ref_stubs/ros/ros.h and driven by a deterministic schedule (every node keeps up with every
 // message: deliver, process, deliver).  Built twice by the same recipe:
 //   oracle/_ref/libref_nodes.so                       the wrappers + the reference's Basic*.cpp            (CPU, the checker)
-//   tests/_dropin/libloam_nodes.so   the SAME wrappers + loamx_adapter.h + libloamx.so   (the product, needs a GPU)
+//   oracle/_ref/libloam_nodes.so   the SAME wrappers + loamx_adapter.h + libloamx.so   (the product, needs a GPU)
 // so a test can feed both the same /multi_scan_points and /imu/data messages and compare what comes out of /laser_odom_to_init,
 // /aft_mapped_to_init and /integrated_to_init.  Stand-ins: see oracle/ref_stubs (ROS / tf / PCL / Eigen are absent from the image).
 #include <algorithm>

@@ -82,10 +82,10 @@ def test_product_pose_fusion_in_the_node_graph_equals_the_reference_nodes(orc, s
         assert np.array_equal(ref.odometry(topic)[1], mine.odometry(topic)[1]), topic
 
 
-MOCK = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dropin", "libloam_nodes_mock.so")
+MOCK = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libloam_nodes_mock.so")
 
 
-@pytest.mark.skipif(not os.path.exists(MOCK), reason="tests/_dropin/libloam_nodes_mock.so not built (tests/dropin_check.sh)")
+@pytest.mark.skipif(not os.path.exists(MOCK), reason="oracle/_ref/libloam_nodes_mock.so not built (oracle/dropin_check.sh)")
 @pytest.mark.parametrize("imu", [False, True])
 def test_adapter_glue_over_the_oracle_mock(small_world, imu):
     """Everything ABOVE the C-ABI, end to end, without a GPU: the reference's own node sources compiled against loamx_adapter.h
@@ -117,7 +117,7 @@ def test_adapter_glue_over_the_oracle_mock(small_world, imu):
         assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(MOCK), "adapter_test_mock")), reason="tests/_dropin/adapter_test_mock not built")
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(MOCK), "adapter_test_mock")), reason="oracle/_ref/adapter_test_mock not built")
 def test_plain_adapter_driver_over_the_oracle_mock(orc, small_world, tmp_path):
     """loam_velodyne_amd/adapter/adapter_test.cpp (the adapter with its OWN value types, as the GPU test runs it) linked against the
     oracle-backed test double: scan registration -> odometry -> mapping -> pose fusion must print exactly the oracle chain's poses,

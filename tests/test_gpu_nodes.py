@@ -1,6 +1,6 @@
-"""GPU: the product behind the reference's own nodes.  tests/_dropin/libloam_nodes.so holds the reference's
+"""GPU: the product behind the reference's own nodes.  oracle/_ref/libloam_nodes.so holds the reference's
 ScanRegistration / LaserOdometry / LaserMapping / TransformMaintenance node sources compiled UNCHANGED against loamx_adapter.h,
-the swapped MultiScanRegistration unit and libloamx.so (tests/dropin_check.sh, built where /root/reference exists and shipped
+the swapped MultiScanRegistration unit and libloamx.so (oracle/dropin_check.sh, built where /root/reference exists and shipped
 as a binary); oracle/_ref/libref_nodes.so holds the same node sources over the reference's own Basic* cores.  Both are fed the
 same /multi_scan_points and /imu/data messages through the same in-process bus, and every nav_msgs/Odometry they publish is
 compared: odometry to 1e-4, mapping (live rolling map, voxel-threshold feedback) and the fused pose to 2e-3.
@@ -16,7 +16,7 @@ from four_nodes import FourNodes, LoamxBackend
 from loam_velodyne_amd import loamx, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "tests", "_dropin", "libloam_nodes.so")
+LIB = os.path.join(ROOT, "oracle", "_ref", "libloam_nodes.so")
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(os.environ.get("LOAMX_NODES_GPU") != "1", reason="opt-in until verified on a GPU (set LOAMX_NODES_GPU=1)"),

@@ -49,7 +49,7 @@ def _run(orc, small_world, backend_cls, lidar, az, n, imu, **extra):
     return ref, mine, poses
 
 
-@pytest.mark.parametrize("lidar,az,imu", [("VLP-16", 900, False), ("VLP-16", 600, True), ("HDL-32", 1024, False)])
+@pytest.mark.parametrize("lidar,az,imu", [("VLP-16", 900, False), ("VLP-16", 600, True), ("HDL-32", 1024, False), ("HDL-64E", 1024, True)])
 def test_oracle_composition_equals_the_reference_nodes(orc, small_world, lidar, az, imu):
     ref, mine, poses = _run(orc, small_world, OracleBackend, lidar, az, 7, imu)
     for topic in ref.TOPICS:

@@ -133,6 +133,18 @@ int loamx_odom_get_last_clouds(loamx_odom* h, loamx_cloud* lc, loamx_cloud* ls) 
   int rc = write_cloud(h->o.lastCorner, lc);
   return rc == LOAMX_OK ? write_cloud(h->o.lastSurf, ls) : rc;
 }
+int loamx_odom_set_transform(loamx_odom* h, const float t[6]) {
+  h->o.transform.rot_x = t[0]; h->o.transform.rot_y = t[1]; h->o.transform.rot_z = t[2]; h->o.transform.pos = {t[3], t[4], t[5]};
+  return LOAMX_OK;
+}
+int loamx_odom_set_transform_sum(loamx_odom* h, const float t[6]) {
+  h->o.transformSum.rot_x = t[0]; h->o.transformSum.rot_y = t[1]; h->o.transformSum.rot_z = t[2]; h->o.transformSum.pos = {t[3], t[4], t[5]};
+  return LOAMX_OK;
+}
+int loamx_odom_get_stats(loamx_odom* h, int s[4]) {
+  s[0] = h->o.lastIterCount; s[1] = h->o.lastSelNum; s[2] = (int)h->o.frameCount; s[3] = 0;   // (the oracle keeps no degeneracy flag for the odometry)
+  return LOAMX_OK;
+}
 int loamx_odom_transform_to_end(loamx_odom* h, loamx_cloud* cloud) {
   Cloud c = read_cloud(cloud);
   h->o.transform_to_end(c);
@@ -159,6 +171,16 @@ int loamx_map_get_transform(loamx_map* h, int which, float t[6]) {
   twist_to(*w[which], t);
   return LOAMX_OK;
 }
+int loamx_map_set_transform(loamx_map* h, int which, const float t[6]) {
+  Twist* w[4] = {&h->m.transformAftMapped, &h->m.transformBefMapped, &h->m.transformTobeMapped, &h->m.transformSum};
+  w[which]->rot_x = t[0]; w[which]->rot_y = t[1]; w[which]->rot_z = t[2]; w[which]->pos = {t[3], t[4], t[5]};
+  return LOAMX_OK;
+}
+int loamx_map_get_stats(loamx_map* h, int s[8]) {
+  const MappingStats& m = h->m.stats;
+  s[0] = m.iterations; s[1] = m.lastSelNum; s[2] = m.cornerDS; s[3] = m.surfDS; s[4] = m.cornerFromMap; s[5] = m.surfFromMap; s[6] = m.degenerate; s[7] = m.optimized;
+  return LOAMX_OK;
+}
 int loamx_map_update_imu(loamx_map* h, double stamp, float roll, float pitch) { h->m.update_imu(stamp, roll, pitch); return LOAMX_OK; }
 int loamx_map_set_time(loamx_map* h, double t) { h->m.laserOdometryTime = t; return LOAMX_OK; }
 int loamx_map_has_fresh_map(loamx_map* h) { return h->m.downsizedMapCreated ? 1 : 0; }
@@ -176,5 +198,7 @@ int loamx_tm_update_mapping_transform(loamx_tm* h, const float aft[6], const flo
 }
 int loamx_tm_associate_to_map(loamx_tm* h) { h->t.transform_associate_to_map(); return LOAMX_OK; }
 int loamx_tm_get_mapped(loamx_tm* h, float out[6]) { for (int k = 0; k < 6; k++) out[k] = h->t.transformMapped[k]; return LOAMX_OK; }
+int loamx_wire_pose_to_quat(const float rot[3], double q[4]) { wire_pose_to_quat(rot, q); return LOAMX_OK; }
+int loamx_wire_quat_to_pose(const double q[4], float rot[3]) { wire_quat_to_pose(q, rot); return LOAMX_OK; }
 
 }  // extern "C"

@@ -143,3 +143,39 @@ def test_plain_adapter_driver_over_the_oracle_mock(orc, small_world, tmp_path):
         omp.process()
         assert np.array_equal(rows[k, :6], ood.transform_sum), k
         assert np.array_equal(rows[k, 6:], omp.transform("aft")), k
+
+
+def test_python_binding_composition_over_the_oracle_mock(small_world, monkeypatch):
+    """tests/four_nodes.py::LoamxBackend — the node glue over loam_velodyne_amd/loamx.py, the ctypes binding of the C-ABI that the GPU
+    tests and bench.py drive — with the binding pointed (for this test only) at the oracle-backed test double: structure layouts,
+    cloud descriptors, time hand-over and return codes of the binding, checked against the reference's own node graph on the CPU"""
+    import ctypes as C
+    from four_nodes import LoamxBackend
+    mock = os.path.join(os.path.dirname(MOCK), "libloamx_oracle_mock.so")
+    if not os.path.exists(mock):
+        pytest.skip("oracle/_ref/libloamx_oracle_mock.so not built")
+    L = C.CDLL(mock)
+    L.loamx_last_error.restype = C.c_char_p
+    for n in ("loamx_scanreg_create", "loamx_odom_create", "loamx_map_create", "loamx_tm_create"):
+        getattr(L, n).restype = C.c_void_p
+    monkeypatch.setattr(loamx, "_lib", L)
+    ref, dev = op.RefNodes("VLP-16"), FourNodes(LoamxBackend(loamx, "VLP-16"))
+    poses = synth.trajectory(7)
+    rng = np.random.default_rng(5)
+    for k in range(7):
+        for j in range(11):
+            t, sec, nsec = _stamp(51 * k + 5 * j - 45)
+            q = _quat(*rng.uniform(-0.02, 0.02, 3))
+            acc = np.array([0.0, 0.0, 9.81]) + rng.uniform(-0.3, 0.3, 3)
+            ref.push_imu(sec, nsec, q, acc)
+            dev.push_imu(1000 + t, q, acc)
+        sw = synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=200 + k, az_steps=900)
+        raw = synth.to_raw(sw, bad_every=89)
+        t, sec, nsec = _stamp(51 * k + 5)
+        ref.push_cloud(raw, sec, nsec)
+        dev.push_cloud(raw, 1000 + t)
+    for topic in ref.TOPICS:
+        (sr, vr), (sd, vd) = ref.odometry(topic), dev.odometry(topic)
+        assert np.array_equal(sr, sd) and np.array_equal(vr, vd), topic
+    assert all(np.array_equal(a, b) for a, b in zip(ref.clouds(0), dev.registered))
+    assert len(dev.surround) == 1 and np.array_equal(ref.clouds(1)[0], dev.surround[0])

@@ -181,6 +181,22 @@ int loamx_map_get_stats(loamx_map* h, int s[8]) {
   s[0] = m.iterations; s[1] = m.lastSelNum; s[2] = m.cornerDS; s[3] = m.surfDS; s[4] = m.cornerFromMap; s[5] = m.surfFromMap; s[6] = m.degenerate; s[7] = m.optimized;
   return LOAMX_OK;
 }
+int loamx_map_load_cubes(loamx_map* h, const loamx_cloud* corner, const loamx_cloud* surf) {
+  for (int t = 0; t < 2; t++) {
+    const Cloud pts = read_cloud(t == 0 ? corner : surf);
+    auto& arr = t == 0 ? h->m.cornerArray : h->m.surfArray;
+    for (const Pt& q : pts) {
+      const int I = LaserMapping::cube_of(q.x, h->m.cenW), J = LaserMapping::cube_of(q.y, h->m.cenH), K = LaserMapping::cube_of(q.z, h->m.cenD);
+      if (I >= 0 && I < LaserMapping::W && J >= 0 && J < LaserMapping::H && K >= 0 && K < LaserMapping::D) arr[LaserMapping::to_index(I, J, K)].push_back(q);
+    }
+  }
+  return LOAMX_OK;
+}
+int loamx_map_get_cubes(loamx_map* h, int which, loamx_cloud* out) {
+  Cloud all;
+  for (const Cloud& c : (which == 0 ? h->m.cornerArray : h->m.surfArray)) all.insert(all.end(), c.begin(), c.end());
+  return write_cloud(all, out);
+}
 int loamx_map_update_imu(loamx_map* h, double stamp, float roll, float pitch) { h->m.update_imu(stamp, roll, pitch); return LOAMX_OK; }
 int loamx_map_set_time(loamx_map* h, double t) { h->m.laserOdometryTime = t; return LOAMX_OK; }
 int loamx_map_has_fresh_map(loamx_map* h) { return h->m.downsizedMapCreated ? 1 : 0; }

@@ -23,6 +23,9 @@
  *    intensity_offset 16}; a packed float4 is {16, 12}.  Outputs are written with the same description.
  *  - Poses are float[6] = rot_x (pitch), rot_y (yaw), rot_z (roll), x, y, z in the LOAM camera frame, rotation order
  *    R = Ry*Rx*Rz (reference src/lib/math_utils.h:212-238).
+ *  - Point coordinates handed to loamx_scanreg_process, loamx_odom_* and loamx_map_* must be finite.  The reference's own pipeline
+ *    guarantees that (MultiScanRegistration.cpp:187-191 drops non-finite returns — and so does loamx_scanreg_process_raw); its
+ *    pcl::removeNaNFromPointCloud calls in the odometry (BasicLaserOdometry.cpp:230, :252) are therefore not reproduced.
  *  - Return value: 0 = processed, 1 = skipped (mirrors the reference's `false` / silent guards), < 0 = error;
  *    loamx_last_error() gives the text for the calling thread's last failing call.  No exception or abort crosses
  *    the ABI.

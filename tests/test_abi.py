@@ -36,6 +36,15 @@ def test_no_oracle_in_product():
             if fn.endswith((".py", ".hip", ".cuh", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "oracle_py" not in txt and "liboracle" not in txt and '#include "oracle' not in txt, fn
+                assert "oracle_mock" not in txt and "mock_loamx" not in txt, fn     # the C-ABI test double belongs to tests only
+
+
+def test_header_is_plain_c():
+    """include/loamx.h is a C header (extern "C", plain pointers and sizes): it must compile as C99 and as C++11 on its own"""
+    hdr = os.path.join(ROOT, "include", "loamx.h")
+    for cmd in (["gcc", "-std=c99", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr], ["g++", "-std=c++11", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c++", hdr]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
 
 
 def test_fails_loudly_without_gpu():

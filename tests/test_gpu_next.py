@@ -1,8 +1,6 @@
-"""GPU tests written at the end of round 1 WITHOUT a GPU at hand, for cases the CPU-side reference pinning added late
-(tests/test_ref_pinning.py: the degenerate corridor, the silent guards).  Opt-in (LOAMX_NEXT_GPU=1) until they have been run once
-on an MI355X; then the gate goes."""
-import os
-
+"""GPU: the reference's edge-case branches on the device — the degeneracy projector in a featureless corridor
+(BasicLaserOdometry.cpp:561-597, BasicLaserMapping.cpp:869-899), the too-few-rows guards (BasicLaserOdometry.cpp:485-488,
+BasicLaserMapping.cpp:826-828) and the non-finite reset (BasicLaserOdometry.cpp:606-612)."""
 import numpy as np
 import pytest
 
@@ -10,7 +8,7 @@ import oracle_py as op
 from conftest import POSE_TOL
 from loam_velodyne_amd import loamx, synth
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("LOAMX_NEXT_GPU") != "1", reason="opt-in until verified on a GPU (set LOAMX_NEXT_GPU=1)")]
+pytestmark = pytest.mark.gpu
 
 
 def _corridor():

@@ -3,9 +3,7 @@ ScanRegistration / LaserOdometry / LaserMapping / TransformMaintenance node sour
 the swapped MultiScanRegistration unit and libloamx.so (oracle/dropin_check.sh, built where /root/reference exists and shipped
 as a binary); oracle/_ref/libref_nodes.so holds the same node sources over the reference's own Basic* cores.  Both are fed the
 same /multi_scan_points and /imu/data messages through the same in-process bus, and every nav_msgs/Odometry they publish is
-compared: odometry to 1e-4, mapping (live rolling map, voxel-threshold feedback) and the fused pose to 2e-3.
-
-First written at the end of round 1 without a GPU at hand: it stays opt-in (LOAMX_NODES_GPU=1) until it has been run once."""
+compared: odometry to 1e-4, mapping (live rolling map, voxel-threshold feedback) and the fused pose to 2e-3."""
 import os
 
 import numpy as np
@@ -19,7 +17,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "oracle", "_ref", "libloam_nodes.so")
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("LOAMX_NODES_GPU") != "1", reason="opt-in until verified on a GPU (set LOAMX_NODES_GPU=1)"),
               pytest.mark.skipif(not (os.path.exists(LIB) and op.RefNodes.available()), reason="node-graph libraries not built")]
 
 

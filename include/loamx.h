@@ -255,6 +255,13 @@ int loamx_batch_set_timing(loamx_batch* h, int on);
 int loamx_batch_get_timing(loamx_batch* h, float ms[4], uint64_t counts[4]);
 /* raw HIP stream of the handle (hipStream_t) so a harness can bracket it with its own events */
 void* loamx_batch_stream(loamx_batch* h);
+/* Parity hook for the kNN contract (nanoflann_pcl.h:140-152, nanoflann.hpp:115-139, :372-379): runs the library's own
+ * neighbour search (the device routine the Gauss-Newton kernel calls) for n query points given in the MAP frame against
+ * the frozen corner (which = 0) or surf (which = 1) sub-map.  idx5[5 q + k] = index, in the cloud handed to set_frozen, of
+ * the k-th nearest point of query q, d2_5 = its squared distance in float, (dx*dx + dy*dy) + dz*dz; ascending by
+ * (distance, index).  Only neighbours closer than 1.05 m are searched for (the reference rejects a query whose fifth
+ * neighbour is 1 m away or more, BasicLaserMapping.cpp:671, :760): missing entries are 0xffffffff / FLT_MAX. */
+int loamx_batch_knn_probe(loamx_batch* h, int which, const float* queries_xyz, uint32_t n, uint32_t* idx5, float* d2_5);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Streaming pipeline: n independent streams, each advancing one sweep per step through feature extraction ->

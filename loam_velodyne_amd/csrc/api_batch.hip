@@ -141,6 +141,13 @@ int loamx_batch_get_timing(loamx_batch* h, float ms[4], uint64_t counts[4]) {
     return LOAMX_OK;
   });
 }
+int loamx_batch_knn_probe(loamx_batch* h, int which, const float* queries_xyz, uint32_t n, uint32_t* idx5, float* d2_5) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    h->reg.knn_probe(which, queries_xyz, n, idx5, d2_5);
+    return LOAMX_OK;
+  });
+}
 void* loamx_batch_stream(loamx_batch* h) { return h ? (void*)h->reg.stream() : nullptr; }
 
 }  // extern "C"

@@ -337,7 +337,7 @@ __device__ inline bool certainly_not_degenerate(const float* AtA, float thr) {
   return true;
 }
 
-__device__ inline bool degeneracy_projector(const float* AtA, float thr, float* P, float* ws) {
+__device__ __forceinline__ bool degeneracy_projector(const float* AtA, float thr, float* P, float* ws) {
   if (certainly_not_degenerate(AtA, thr)) return false;
   float w[6];
   float* V = ws + 72;     // 36

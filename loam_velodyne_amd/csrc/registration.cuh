@@ -128,6 +128,8 @@ class Registrar {
   const float4* d_full_res() const { return full_.p; }
   uint32_t full_offset(uint32_t s) const { return h_full_off_[s]; }
 
+  // parity hook (loamx_batch_knn_probe): exact 5-NN of n map-frame points in the corner (0) / surf (1) sub-map index
+  void knn_probe(int which, const float* xyz, uint32_t n, uint32_t* idx5, float* d2_5);
   void set_timing(bool on) { timing_ = on; }
   void get_timing(float ms[4], uint64_t counts[4]);
   uint32_t n_sweeps() const { return n_sweeps_; }
@@ -153,16 +155,15 @@ class Registrar {
   bool full_staged_ = false;
   VoxelPipeline vox_;
   uint32_t n_in_ = 0, n_full_ = 0, max_q_per_sweep_ = 0;
-  bool host_results_valid_ = false;   // h_poses_ / h_stats_ hold this run's final values
+  bool mirrors_written_ = false;      // h_poses_ / h_stats_ hold (after a stream sync) this run's final values
+  void run_iterations(bool trace, double& th2, double& th3);
+  void fetch_results();
   int pred_iters_ = 4;        // early_exit: iterations to enqueue before the first look at the done flags
-  int knn_lpq_ = 4;           // lanes per query in k_knn5 (tuning knob: LOAMX_KNN_LPQ = 1|2|4|8|16)
-  void launch_knn5(int it);
 
   DevBuf<Pose> poses_;
   DevBuf<SweepStats> stats_;
   DevBuf<float> matP_;        // 36 per sweep
   DevBuf<double> partials_;   // per sweep x blocks x LX_NSUM
-  DevBuf<uint32_t> nb_;       // 5 neighbour positions per query
   // views of the per-run parameters (separate buffers after upload(), one block after upload_device())
   const float* d_guess_ = nullptr;
   const uint32_t* d_seg_off_ = nullptr;
@@ -176,11 +177,10 @@ class Registrar {
   hipStream_t st_build_ = nullptr;
   hipEvent_t ev_build_ = nullptr, ev_swap_ = nullptr;
   bool next_staged_ = false, swapped_once_ = false;
-  DevBuf<uint32_t> arrive_;   // per sweep: k_residual workgroups that have delivered their partial sums
-  DevBuf<float4> qstate_;     // per query: position at its last full search + squared re-validation bound
+  DevBuf<uint32_t> arrive_;   // per sweep: k_gn_iter workgroups that have delivered their tile sums
   uint32_t nblk_ = 0;
 
-  std::vector<hipEvent_t> ev_;   // timing events: [0]=run start, [1]=run end, then pairs per residual launch
+  std::vector<hipEvent_t> ev_;   // timing events: [0]=run start, [1]=run end, then pairs per Gauss-Newton launch
   int n_res_launch_ = 0;
   PinBuf<SweepStats> h_stats_;
   PinBuf<Pose> h_poses_;

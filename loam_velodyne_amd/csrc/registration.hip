@@ -4,10 +4,10 @@
 //   k_stack          stack round trip  pointAssociateToMap -> pointAssociateTobeMapped        (:282-292, :512-516)
 //   k_keys/sort/k_voxel_reduce   pcl::VoxelGrid on the stack clouds (corner 0.2 m / surf 0.4 m) (:519-527)
 //   SubMapIndex      replaces the two kd-tree rebuilds (:636-637) by a counting-sorted uniform grid
-//   k_knn5           per query (16 lanes each): pointAssociateToMap + exact 5-NN within the 1 m gate  (:668-671, :757-760)
-//   k_residual       per query (thread each): 3x3 eigen edge fit or 5x3 QR plane fit, residual + weight, Jacobian row,
-//                    block-reduced J^T J / J^T r                                                   (:673-866)
-//   solve_sweep      (last workgroup of k_residual) 6x6 column-pivoted QR, degeneracy projector, pose update,
+//   k_gn_iter        one Gauss-Newton iteration, fused: per query (4 lanes each) pointAssociateToMap + exact 5-NN within the
+//                    1 m gate (:668-671, :757-760); per query (one lane) 3x3 eigen edge fit or 5x3 QR plane fit, residual +
+//                    weight, Jacobian row (:673-861); per tile J^T J / J^T r (:864-866)
+//   solve_sweep      (last workgroup of a sweep in k_gn_iter) 6x6 column-pivoted QR, degeneracy projector, pose update,
 //                    convergence test   (:867-922)
 //   k_transform_full transformFullResToMap                                                         (:235-240)
 // HBM-bound gather work: no MFMA (the only dense contraction is 6x6).  Points are packed float4 so a neighbour is one
@@ -376,9 +376,10 @@ __global__ __launch_bounds__(256) void k_stack(const float4* __restrict__ in, co
 // ----------------------------------------------------------------------------------------------------------------
 // (also resets the voxel bounds of the sweep's two segments: one launch less in front of k_stack)
 __global__ void k_pose_init(const float* __restrict__ guess, uint32_t ns, Pose* __restrict__ poses, SweepStats* __restrict__ stats,
-                            int* __restrict__ seg_minmax) {
+                            int* __restrict__ seg_minmax, uint32_t* __restrict__ ticket) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
+  ticket[s] = 0u;   // k_gn_iter's per-sweep arrival counter
   for (int k = 0; k < 12; k++) seg_minmax[12 * s + k] = (k % 6) < 3 ? 2147483647 : (-2147483647 - 1);
   Pose T;
   pose_set_angles(T, guess[6 * s], guess[6 * s + 1], guess[6 * s + 2]);
@@ -400,28 +401,7 @@ __global__ void k_pose_set(const float* __restrict__ p6, uint32_t ns, Pose* __re
 
 
 // ----------------------------------------------------------------------------------------------------------------
-// k_knn5<LPQ>: the neighbour search of one Gauss-Newton iteration.  A 256-thread workgroup owns QB = 256/LPQ queries.
-// Phase A (one lane per query, threads 0..QB-1):
-//   pointAssociateToMap, then re-validation of the remembered neighbours (below); a query that needs a search gets a
-//   slot in the workgroup's LDS work list together with the cell ranges of the 9 (y,z) rows of its 3x3x3 neighbourhood
-//   (x is the fastest cell axis, so a row is one contiguous run) and their exclusive prefix — 18 independent loads.
-// Phase B (LPQ lanes per listed query; waves beyond the list exit):
-//   the runs are concatenated logically and the LPQ lanes stride over the candidates (adjacent lanes read adjacent
-//   points), four independent 16-byte loads in flight per lane; every lane keeps its own sorted top-6 and six rounds of
-//   an LPQ-lane arg-min butterfly on (d2, original index) pop the global top-6 — the same strict total order as a
-//   sequential scan, so the result does not depend on LPQ.
-// The kernel is bound by issue slots and load latency, not by bytes: ~60 candidates per query cost ~25 lane-instructions
-// each, so the fewer lanes idle in per-query fixed work (prefix, butterfly) the better — LPQ=4 measured best.
-// Re-validation (iterations after a query's last full search): the pose moves by millimetres between Gauss-Newton
-// steps, so the neighbour SET almost never changes.  With q0 the query position at its last full search, delta =
-// |q - q0| and r6 the distance from q0 to its 6th neighbour (or 1.05 m, the radius the 27 cells are guaranteed to
-// cover), every other map point is at least r6 - delta away from q.  If the five remembered neighbours are all closer
-// than that (and inside the 1 m gate) they ARE the exact 5-NN of q: only their order by (d2, index) is recomputed —
-// 5 gathers instead of ~60.  Otherwise the full search runs.  A query that had fewer than 5 neighbours in the gate
-// stays rejected while r5 - delta >= 1 m.  Margins (1e-5 relative + 1e-6) make float rounding err towards searching.
-// Output: nb[5*q .. 5*q+4] = positions of the neighbours in the cell-sorted array (ascending distance),
-//         nb[5*q+4] = 0xffffffff when pointSearchSqDis[4] >= 1.0 (BasicLaserMapping.cpp:671, :760).
-// Algorithmic bytes: 12 B query + 5 x 12 B neighbours = 72 B per query.
+// neighbour search helpers (used by knn5_group below)
 // ----------------------------------------------------------------------------------------------------------------
 constexpr float KNN_COVER2 = 1.05f * 1.05f * 0.9999f;   // every map point within this squared radius has been visited
 
@@ -441,49 +421,6 @@ __device__ inline void knn_insert6(unsigned long long (&bk)[6], uint32_t (&bp)[6
   bp[0] = lt[0] ? pos : bp[0];
 }
 constexpr unsigned long long KNN_NONE = 0x7f7fffffffffffffull;   // (FLT_MAX, 0xffffffff): empty slot
-
-#ifdef LOAMX_PROF_KNN
-__device__ unsigned long long g_knn_ts[8];
-#define KNN_TS(k) do { if (blockIdx.x == 8 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && threadIdx.x / 64 == (k == 0 || k == 1 ? 0 : 1) && iter == 0) g_knn_ts[k] = wall_clock64(); } while (0)
-#else
-#define KNN_TS(k) do { } while (0)
-#endif
-
-// strided scan of a concatenated run list by the LPQ lanes of a group: table entries [run][slot] in LDS,
-// rp[nruns] = candidate count
-template <int LPQ, int QB>
-__device__ inline void knn_scan_runs(const float4* __restrict__ pts, const uint32_t* s_rb, const uint32_t* s_rp, uint32_t grp, int gl,
-                                     float qx, float qy, float qz, uint32_t total, unsigned long long (&bk)[6], uint32_t (&bp)[6]) {
-  int r = 0;
-  uint32_t bound = s_rp[QB + grp];   // first candidate number of the next run
-  uint32_t off = s_rb[grp];          // position = off + candidate number inside the current run
-  for (uint32_t c = gl; c < total; c += 4 * LPQ) {
-    uint32_t pos[4];
-    float4 p[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const uint32_t cc = c + u * LPQ;
-      pos[u] = 0;
-      if (cc < total) {
-        while (cc >= bound) {   // rp[last] = total > cc terminates
-          r++;
-          bound = s_rp[(r + 1) * QB + grp];
-          off = s_rb[r * QB + grp] - s_rp[r * QB + grp];
-        }
-        pos[u] = off + cc;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) p[u] = (c + u * LPQ) < total ? pts[pos[u]] : make_float4(1e30f, 1e30f, 1e30f, 0.f);
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
-      const float d2 = dx * dx + dy * dy + dz * dz;   // x -> y -> z accumulation (nanoflann.hpp:372-379)
-      const unsigned long long key = d2 < KNN_COVER2 ? ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(p[u].w) : KNN_NONE;
-      knn_insert6(bk, bp, key, pos[u]);
-    }
-  }
-}
 
 // pop the group's six best (destructive on the lane lists); every lane of the group ends up with the same winners
 template <int LPQ>
@@ -509,233 +446,6 @@ __device__ inline void knn_pop6(unsigned long long (&bk)[6], uint32_t (&bp)[6], 
     }
     wk[k] = key;
     win[k] = pp;
-  }
-}
-
-template <int LPQ>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_knn5(const float4* __restrict__ ds_pts, const uint32_t* __restrict__ ds_off,
-                                              const Pose* __restrict__ poses, const SweepStats* __restrict__ stats,
-                                              const GridDesc* __restrict__ cdesc, const float4* __restrict__ cpts,
-                                              const uint32_t* __restrict__ cstart, const GridDesc* __restrict__ sdesc,
-                                              const float4* __restrict__ spts, const uint32_t* __restrict__ sstart,
-                                              uint32_t* __restrict__ nb, float4* __restrict__ qstate, int iter) {
-  constexpr int QB = 256 / LPQ;
-  constexpr int NRUN = 10;              // 8 rows + the two outer cells of the centre row
-  __shared__ uint32_t s_rb[NRUN * QB];         // run begin,        [run][slot]
-  __shared__ uint32_t s_rp[(NRUN + 1) * QB];   // exclusive prefix, [run][slot]; entry NRUN = candidate count
-  __shared__ float4 s_q[QB];            // query in the map frame, .w = bits of the query index
-  __shared__ uint32_t s_ob[2 * QB];     // the query's own cell: begin / end ([0][slot] = begin, [1][slot] = end)
-  __shared__ uint32_t s_n;
-  const uint32_t s = blockIdx.y;
-  if (stats[s].done) return;
-  const uint32_t q0 = ds_off[2 * s], qm = ds_off[2 * s + 1], q1 = ds_off[2 * s + 2];
-  // XCD-aware order: workgroup b runs on XCD b % 8, so give every XCD one contiguous eighth of the (voxel-ordered,
-  // i.e. spatially coherent) query list — its private L2 then only has to hold that part of the map
-  const uint32_t nblk_act = (q1 - q0 + QB - 1) / QB;   // workgroups this sweep really needs (<= gridDim.x)
-  const uint32_t per = (nblk_act + 7) / 8;
-  if (blockIdx.x / 8 >= per) return;
-  const uint32_t bx = (blockIdx.x % 8) * per + blockIdx.x / 8;
-  const uint32_t first = q0 + bx * QB;
-  if (first >= q1) return;
-  KNN_TS(0);
-  if (threadIdx.x == 0) s_n = 0;
-  __syncthreads();
-
-  // ---- phase A
-  if (threadIdx.x < QB) {
-    const uint32_t q = first + threadIdx.x;
-    const bool qok = q < q1;
-    const bool corner = q < qm;
-    const float4* __restrict__ pts = corner ? cpts : spts;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (qok) {
-      const Pose T = poses[s];
-      const float4 po = ds_pts[q];
-      qx = po.x; qy = po.y; qz = po.z;
-      to_map(T, qx, qy, qz);
-    }
-    bool need_search = qok;
-    if (iter > 0 && qok) {
-      const float4 st = qstate[q];
-      const float ddx = qx - st.x, ddy = qy - st.y, ddz = qz - st.z;
-      const float delta = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
-      uint32_t np[5];
-#pragma unroll
-      for (int j = 0; j < 5; j++) np[j] = nb[5 * (size_t)q + j];
-      if (np[4] == 0xffffffffu) {
-        // rejected at the last search: st.w = squared distance to the 5th neighbour then (or the covered radius)
-        if (sqrtf(st.w) * 0.99999f - delta - 1e-6f >= 1.0f) need_search = false;
-      } else {
-        float d2[5];
-        uint32_t id[5];
-        float dmax = 0.f;
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-          const float4 p = pts[np[j]];
-          const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-          d2[j] = dx * dx + dy * dy + dz * dz;
-          id[j] = __float_as_uint(p.w);
-          dmax = fmaxf(dmax, d2[j]);
-        }
-        if (dmax < 1.0f && sqrtf(dmax) + delta < sqrtf(st.w) * 0.99999f - 1e-6f) {
-          // same set; restore ascending (d2, index) order
-#pragma unroll
-          for (int j = 0; j < 5; j++) {
-            int rank = 0;
-#pragma unroll
-            for (int k = 0; k < 5; k++)
-              if (d2[k] < d2[j] || (d2[k] == d2[j] && id[k] < id[j])) rank++;
-            nb[5 * (size_t)q + rank] = np[j];
-          }
-          need_search = false;
-        }
-      }
-    }
-    // work-list slot (wave-aggregated)
-    const unsigned long long mneed = __ballot(need_search);
-    uint32_t base = 0;
-    if (mneed) {
-      const int leader = __builtin_ctzll(mneed);
-      if ((int)__lane_id() == leader) base = atomicAdd(&s_n, (uint32_t)__popcll(mneed));
-      base = __shfl(base, leader, 64);
-    }
-    if (need_search) {
-      const uint32_t slot = base + (uint32_t)__popcll(mneed & ((1ull << __lane_id()) - 1ull));
-      s_q[slot] = make_float4(qx, qy, qz, __uint_as_float(q));
-      // the query's own cell (when it lies inside the grid)
-      const GridDesc g = corner ? *cdesc : *sdesc;
-      const uint32_t* __restrict__ cell_start = corner ? cstart : sstart;
-      const int cx = (int)floorf((qx - g.ox) * g.inv_h), cy = (int)floorf((qy - g.oy) * g.inv_h), cz = (int)floorf((qz - g.oz) * g.inv_h);
-      uint32_t ob = 0, oe = 0;
-      if (cx >= 0 && cx < g.nx && cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
-        const uint32_t c = ((uint32_t)cz * g.ny + cy) * g.nx + cx;
-        ob = cell_start[c];
-        oe = cell_start[c + 1];
-      }
-      s_ob[slot] = ob;
-      s_ob[QB + slot] = oe;
-    }
-  }
-  __syncthreads();
-  KNN_TS(1);
-  KNN_TS(2);
-
-  // ---- phase B
-  const uint32_t grp = threadIdx.x / LPQ;
-  const int gl = threadIdx.x % LPQ;
-  if (grp >= s_n) return;
-  const float4 qq = s_q[grp];
-  const uint32_t q = __float_as_uint(qq.w);
-  const float qx = qq.x, qy = qq.y, qz = qq.z;
-  const bool corner = q < qm;
-  const float4* __restrict__ pts = corner ? cpts : spts;
-  unsigned long long bk[6], wk[6];
-  uint32_t bp[6], win[6];
-#pragma unroll
-  for (int j = 0; j < 6; j++) { bk[j] = KNN_NONE; bp[j] = 0u; }
-  // B1: the own cell — in a dense map it already holds the five neighbours, and the sixth-best distance found here
-  // bounds what the other 26 cells can still contribute
-  {
-    const uint32_t ob = s_ob[grp], oe = s_ob[QB + grp];
-    for (uint32_t c = ob + gl; c < oe; c += 2 * LPQ) {
-      const uint32_t c1 = c + LPQ;
-      const float4 p0 = pts[c];
-      const float4 p1 = c1 < oe ? pts[c1] : make_float4(1e30f, 1e30f, 1e30f, 0.f);
-      {
-        const float dx = qx - p0.x, dy = qy - p0.y, dz = qz - p0.z;
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        knn_insert6(bk, bp, d2 < KNN_COVER2 ? ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(p0.w) : KNN_NONE, c);
-      }
-      {
-        const float dx = qx - p1.x, dy = qy - p1.y, dz = qz - p1.z;
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        knn_insert6(bk, bp, d2 < KNN_COVER2 ? ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(p1.w) : KNN_NONE, c1);
-      }
-    }
-  }
-  knn_pop6<LPQ>(bk, bp, gl, wk, win);
-  // squared radius that still matters: the sixth-best so far (none: the radius the 27 cells cover)
-  const float rad2 = wk[5] != KNN_NONE ? __uint_as_float((uint32_t)(wk[5] >> 32)) : KNN_COVER2;
-  // B2: the other cells, pruned by rad2.  Lane gl prepares rows gl, gl + LPQ, ...: row r = (dz, dy) in {-1,0,1}^2, its
-  // cells cx-1 .. cx+1 are one contiguous run; the centre row contributes its two outer cells only.
-  // Gaps are measured in cell units with the same float expression that assigned the points to cells, shrunk by
-  // 1e-4 relative + 1e-5 so that rounding can only make the visit larger.
-  {
-    const GridDesc g = corner ? *cdesc : *sdesc;
-    const uint32_t* __restrict__ cell_start = corner ? cstart : sstart;
-    const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
-    const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
-    const float h = 1.0f / g.inv_h;
-    const float r2c = rad2 * g.inv_h * g.inv_h;   // in cell units
-    auto gap = [](float f, int c, int d) {        // distance (cell units) from coordinate f in cell c to the cell c + d
-      const float v = d == 0 ? 0.f : (d > 0 ? (float)(c + 1) - f : f - (float)c);
-      const float w = v * 0.9999f - 1e-5f;
-      return w > 0.f ? w : 0.f;
-    };
-    (void)h;
-    const float gxl = gap(fx, cx, -1), gxr = gap(fx, cx, +1);
-    for (int r = gl; r < NRUN; r += LPQ) {
-      uint32_t beg = 0, end = 0;
-      if (r < 9 && r != 4) {
-        const int dz = r / 3 - 1, dy = r % 3 - 1;
-        const int z = cz + dz, y = cy + dy;
-        const float gy = gap(fy, cy, dy), gz = gap(fz, cz, dz);
-        const float gyz = gy * gy + gz * gz;
-        if (z >= 0 && z < g.nz && y >= 0 && y < g.ny && gyz < r2c) {
-          int xa = (gyz + gxl * gxl < r2c) ? cx - 1 : cx, xb = (gyz + gxr * gxr < r2c) ? cx + 1 : cx;
-          if (xa < 0) xa = 0;
-          if (xb > g.nx - 1) xb = g.nx - 1;
-          if (xa <= xb) {
-            const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
-            beg = cell_start[row + xa];
-            end = cell_start[row + xb + 1];
-          }
-        }
-      } else if (cy >= 0 && cy < g.ny && cz >= 0 && cz < g.nz) {
-        // r == 4: the cell left of the own cell; r == 9: the cell right of it.  (A query outside the grid in x has no own
-        // cell: its nearest column is then visited as one of these two.)
-        const int x = r == 4 ? cx - 1 : cx + 1;
-        const float gx = r == 4 ? gxl : gxr;
-        if (x >= 0 && x < g.nx && gx * gx < r2c) {
-          const uint32_t c = ((uint32_t)cz * g.ny + cy) * g.nx + x;
-          beg = cell_start[c];
-          end = cell_start[c + 1];
-        }
-      }
-      s_rb[r * QB + grp] = beg;
-      s_rp[r * QB + grp] = end - beg;   // length for now
-    }
-  }
-  __builtin_amdgcn_wave_barrier();   // the group's lanes are in one wave: LDS writes above are visible below
-  uint32_t total = 0;
-  if (gl == 0) {
-#pragma unroll
-    for (int r = 0; r < NRUN; r++) {
-      const uint32_t len = s_rp[r * QB + grp];
-      s_rp[r * QB + grp] = total;
-      total += len;
-    }
-    s_rp[NRUN * QB + grp] = total;
-  }
-  __builtin_amdgcn_wave_barrier();
-  total = s_rp[NRUN * QB + grp];
-  // re-seed the lists with the winners so far (lane 0 holds them, in order) and scan what is left
-#pragma unroll
-  for (int k = 0; k < 6; k++) { bk[k] = gl == 0 ? wk[k] : KNN_NONE; bp[k] = win[k]; }
-  KNN_TS(3);
-  if (total) knn_scan_runs<LPQ, QB>(pts, s_rb, s_rp, grp, gl, qx, qy, qz, total, bk, bp);
-  knn_pop6<LPQ>(bk, bp, gl, wk, win);
-  KNN_TS(4);
-  if (gl == 0) {
-    const float d5 = wk[4] != KNN_NONE ? __uint_as_float((uint32_t)(wk[4] >> 32)) : FLT_MAX;   // FLT_MAX: none inside the covered radius
-    const float d6 = wk[5] != KNN_NONE ? __uint_as_float((uint32_t)(wk[5] >> 32)) : FLT_MAX;
-    const bool valid = d5 < 1.0f;         // == pointSearchSqDis[4] < 1.0
-#pragma unroll
-    for (int k = 0; k < 5; k++) nb[5 * (size_t)q + k] = (k == 4 && !valid) ? 0xffffffffu : win[k];
-    // bound for the re-validation: 6th neighbour (valid query) or 5th neighbour (rejected query), capped by the
-    // radius the visited cells are guaranteed to cover
-    const float bnd = fminf(valid ? d6 : d5, KNN_COVER2);
-    qstate[q] = make_float4(qx, qy, qz, bnd);
   }
 }
 
@@ -828,62 +538,93 @@ __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_o
   __shared__ double gsum[LX_SOLVE_GROUPS][LX_NSUM];
   __shared__ double sums[LX_NSUM];
   __shared__ float ws[216];
-  __shared__ float AtA[36], AtB[6], X[6], X2[6];
-  if (threadIdx.x < LX_SOLVE_GROUPS * LX_NSUM) {
-    const uint32_t g = threadIdx.x / LX_NSUM, t = threadIdx.x % LX_NSUM;
+  __shared__ float AtA[36], AtB[6], X[6], X2[6], trig[6];
+  __shared__ Pose sP;
+  __shared__ SweepStats sSt;
+  const int tid = (int)threadIdx.x;
+  if (tid == LX_RES_THREADS - 1) {   // (a lane of the last wave: the loads overlap with the partial sums below)
+    sP = poses[s];
+    sSt = stats[s];
+  }
+  if (tid < LX_SOLVE_GROUPS * LX_NSUM) {
+    const uint32_t g = (uint32_t)tid / LX_NSUM, t = (uint32_t)tid % LX_NSUM;
     double x = 0.0;
-    for (uint32_t b = g; b < nact; b += LX_SOLVE_GROUPS) x += partials[((size_t)s * nblk + b) * LX_NSUM + t];
+    for (uint32_t b0 = g; b0 < nact; b0 += 8 * LX_SOLVE_GROUPS) {   // 8 loads in flight, added in tile order
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t b = b0 + u * LX_SOLVE_GROUPS;
+        v[u] = b < nact ? partials[((size_t)s * nblk + b) * LX_NSUM + t] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (b0 + u * LX_SOLVE_GROUPS < nact) x += v[u];
+    }
     gsum[g][t] = x;
   }
   __syncthreads();
-  if (threadIdx.x < LX_NSUM) {
+  if (tid < LX_NSUM) {
     double x = 0.0;
 #pragma unroll
-    for (int g = 0; g < LX_SOLVE_GROUPS; g++) x += gsum[g][threadIdx.x];
-    sums[threadIdx.x] = x;
+    for (int g = 0; g < LX_SOLVE_GROUPS; g++) x += gsum[g][tid];
+    sums[tid] = x;
+    // scatter straight into the symmetric 6x6 / right-hand side (sum index t -> (i, j) of the upper triangle)
+    if (tid < 21) {
+      int i = 0, rem = tid;
+      while (rem >= 6 - i) { rem -= 6 - i; i++; }
+      const int j = i + rem;
+      AtA[i * 6 + j] = AtA[j * 6 + i] = (float)x;
+    } else if (tid < 27) {
+      AtB[tid - 21] = (float)x;
+    }
   }
   __syncthreads();
   const int sel_rows = (int)sums[27];   // block-uniform
-  if (threadIdx.x == 0) {
-    int k = 0;
-    for (int i = 0; i < 6; i++)
-      for (int j = i; j < 6; j++) {
-        AtA[i * 6 + j] = AtA[j * 6 + i] = (float)sums[k];
-        k++;
+  if (sel_rows < 50) {   // BasicLaserMapping.cpp:826-828: the iteration is burnt, pose untouched
+    if (tid == 0) {
+      SweepStats st = sSt;
+      st.iterations = iter + 1;
+      st.sel = sel_rows;
+      st.corner_q = (int)(ds_off[2 * s + 1] - ds_off[2 * s]);
+      st.surf_q = (int)(ds_off[2 * s + 2] - ds_off[2 * s + 1]);
+      stats[s] = st;
+      if (host_stats) { host_stats[s] = st; host_poses[s] = sP; }
+    }
+    return;
+  }
+  if (tid < 64) qr_solve6_coop(AtA, AtB, X);   // wave 0, all lanes
+  __syncthreads();
+  float* P = matP + 36 * s;
+  if (tid == 0) {
+    if (iter == 0) sSt.degenerate = degeneracy_projector(AtA, 100.f, P, ws) ? 1 : 0;
+    if (sSt.degenerate) {
+      for (int r = 0; r < 6; r++) X2[r] = X[r];
+      for (int r = 0; r < 6; r++) {
+        float acc = 0.f;
+        for (int c = 0; c < 6; c++) acc += P[r * 6 + c] * X2[c];
+        X[r] = acc;
       }
-    for (int i = 0; i < 6; i++) AtB[i] = (float)sums[21 + i];
+    }
   }
   __syncthreads();
-  if (sel_rows >= 50 && threadIdx.x < 64) qr_solve6_coop(AtA, AtB, X);   // wave 0, all lanes
+  if (tid < 6) {   // sin / cos of the new angles, one per lane, double then rounded (pose_set_angles)
+    const float ang = (tid < 2 ? sP.rx : (tid < 4 ? sP.ry : sP.rz)) + X[tid >> 1];
+    trig[tid] = (float)((tid & 1) ? cos((double)ang) : sin((double)ang));
+  }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  SweepStats st = stats[s];
+  if (tid != 0) return;
+  SweepStats st = sSt;
   st.iterations = iter + 1;
   st.sel = sel_rows;
   st.corner_q = (int)(ds_off[2 * s + 1] - ds_off[2 * s]);
   st.surf_q = (int)(ds_off[2 * s + 2] - ds_off[2 * s + 1]);
-  if (st.sel < 50) {   // BasicLaserMapping.cpp:826-828: the iteration is burnt, pose untouched
-    stats[s] = st;
-    if (host_stats) { host_stats[s] = st; host_poses[s] = poses[s]; }
-    return;
-  }
-  float* P = matP + 36 * s;
-  if (iter == 0) st.degenerate = degeneracy_projector(AtA, 100.f, P, ws) ? 1 : 0;
-  if (st.degenerate) {
-    for (int r = 0; r < 6; r++) X2[r] = X[r];
-    for (int r = 0; r < 6; r++) {
-      float acc = 0.f;
-      for (int c = 0; c < 6; c++) acc += P[r * 6 + c] * X2[c];
-      X[r] = acc;
-    }
-  }
-  Pose T = poses[s];
-  pose_set_angles(T, T.rx + X[0], T.ry + X[1], T.rz + X[2]);
+  Pose T = sP;
+  T.rx = T.rx + X[0]; T.ry = T.ry + X[1]; T.rz = T.rz + X[2];
+  T.srx = trig[0]; T.crx = trig[1]; T.sry = trig[2]; T.cry = trig[3]; T.srz = trig[4]; T.crz = trig[5];
   T.tx += X[3]; T.ty += X[4]; T.tz += X[5];
   poses[s] = T;
-  const double r2d = 180.0 / M_PI;   // rad2deg(float) goes through double (math_utils.h:30-33)
+  // rad2deg(float) goes through double (math_utils.h:30-33)
   const float d0 = (float)(X[0] * 180.0 / M_PI), d1 = (float)(X[1] * 180.0 / M_PI), d2 = (float)(X[2] * 180.0 / M_PI);
-  (void)r2d;
   const float deltaR = (float)sqrt((double)d0 * d0 + (double)d1 * d1 + (double)d2 * d2);
   const float t0 = X[3] * 100, t1 = X[4] * 100, t2 = X[5] * 100;
   const float deltaT = (float)sqrt((double)t0 * t0 + (double)t1 * t1 + (double)t2 * t2);
@@ -894,100 +635,343 @@ __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_o
   if (host_stats) { host_stats[s] = st; host_poses[s] = T; }
 }
 
-
-__global__ __launch_bounds__(LX_RES_THREADS) void k_residual(
-    const float4* __restrict__ ds_pts, const uint32_t* __restrict__ ds_off, const Pose* __restrict__ poses,
-    const SweepStats* __restrict__ stats, const float4* __restrict__ cpts, const float4* __restrict__ spts,
-    const uint32_t* __restrict__ nb, double* partials, uint32_t nblk, Pose* poses_rw, SweepStats* stats_rw,
-    float* __restrict__ matP, uint32_t* __restrict__ arrive, int iter, float delta_t_abort, float delta_r_abort,
-    SweepStats* host_stats, Pose* host_poses) {
-  const uint32_t s = blockIdx.y;
-  if (stats[s].done) return;
-  const uint32_t q0 = ds_off[2 * s], qm = ds_off[2 * s + 1], q1 = ds_off[2 * s + 2];
-  const uint32_t first = q0 + blockIdx.x * LX_RES_THREADS;
-  // (a sweep without queries still burns the iteration: its workgroup 0 contributes zeros and runs the update)
-  if (first >= q1 && !(q1 == q0 && blockIdx.x == 0)) return;
-  const uint32_t q = first + threadIdx.x;
-  const Pose T = poses[s];
-
-  float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bb = 0.f;
-  bool sel = false;
-  if (q < q1) {
-    const float4 po = ds_pts[q];
-    float cx, cy, cz, ci;
-    uint32_t bp[5];
+// ----------------------------------------------------------------------------------------------------------------
+// k_gn_iter: ONE Gauss-Newton iteration of every sweep of the batch in one launch (BasicLaserMapping.cpp:660-923) —
+// neighbour search, edge / plane fit, Jacobian row, normal equations and the update step fused; nothing per query goes
+// to HBM between them (round 1 wrote five neighbour positions + a query state per query and re-gathered them).
+//
+// grid = (tiles rounded up to 8, sweeps), 256 threads.  A sweep's down-sampled queries are cut into tiles of 64 (corner
+// tiles first, then surf tiles — the row order of the reference's A; a tile never mixes the two, so the sub-map, the grid
+// descriptor and the fit are uniform per workgroup); XCD x % 8 gets a contiguous eighth of the voxel-ordered tiles, so its
+// private L2 only has to hold that part of the map.  Per workgroup:
+//   search   four lanes per query (knn5_group below): pointAssociateToMap, exact 5-NN inside the 1 m gate; the winners'
+//            positions go to LDS
+//   rows     one lane per query (wave 0): 3x3 Jacobi eigen edge fit or 5x3 pivoted-QR plane fit, weight, Jacobian row
+//   sums     the tile's 28 sums: float products through an LDS-transposed table, fixed-order accumulation in double
+//   update   the LAST workgroup of a sweep to deliver its sums adds the tile partials in a fixed order and runs the update
+//            (solve_sweep: 6x6 pivoted QR on wave 0, iteration-0 degeneracy projector with the row-zeroing quirk :869-899,
+//            pose update :907-912, stop test :914-922) — one kernel boundary per iteration; `done` turns later launches into
+//            no-ops.
+// The sums depend on the tiling (64 queries per tile, tiles in order) only — not on the batch composition.
+// A persistent variant (all iterations in one launch, per-sweep ticket barrier) was built and measured first: it must keep
+// every workgroup of a sweep resident, which caps it at ~2 waves per SIMD, and at that occupancy the search — latency- and
+// issue-bound — ran three times slower than this kernel's 4-5 waves per SIMD (405 us against ~150 us for 3 iterations of
+// 8 HDL-64E sweeps); see DESIGN.md §3.
+//
+// knn5_group — exact five nearest map points by (squared distance, original index):
+//   trip 1   the boundaries of all 27 cells of the query's 3x3x3 neighbourhood: 9 rows (x is the fastest cell axis, so a
+//            row's cells cx-1..cx+1 are one contiguous run) x 4 cell_start entries = 36 independent 4-byte loads dealt over
+//            the group's lanes and exchanged through LDS.  Rows are addressed RELATIVE to the query (centre / nearer side /
+//            farther side per axis).
+//   trip 2   phase 1: the 2x2x2 block of cells nearest to the query (own cell + the neighbours across the nearer faces;
+//            it contains the ball of radius h/2): 4 runs, candidates enumerated flat and strided over the lanes (adjacent
+//            lanes read adjacent points), 4 independent 16-byte loads in flight per lane, branch-free insertion into
+//            per-lane sorted top-6 lists on 64-bit rank keys, then a 4-lane arg-min butterfly pops the group's six best.
+//   trip 3   phase 2: whatever else of the 27 cells lies within the sixth-best distance so far (or the covered radius):
+//            the 4 far cells of the phase-1 rows + the 5 remaining rows clipped in x, pruned with a conservative gap
+//            expression (margins err towards visiting).  Usually empty or one cell.
+// The result is the strict (d2, index) order of a sequential scan over the whole map, independent of the visiting order
+// and of the (nondeterministic) slot order inside a cell.
+// ----------------------------------------------------------------------------------------------------------------
+#ifndef KNN_LPQ
+#define KNN_LPQ 4   // lanes per query in knn5_group
+#endif
+#ifndef KNN_MLP
+#define KNN_MLP 4   // independent 16-byte loads in flight per lane
+#endif
+// flat, strided scan of NR concatenated runs by the LPQ lanes of a group: lane gl takes candidates gl, gl + LPQ, ...
+// (adjacent lanes read adjacent points: a group's load covers one or two cache lines), MLP loads in flight per lane
+template <int NR, int MLP, int LPQ>
+__device__ inline void knn_scan_group(const float4* __restrict__ pts, const uint32_t (&beg)[NR], const uint32_t (&len)[NR], float qx, float qy,
+                                      float qz, int gl, unsigned long long (&bk)[6], uint32_t (&bp)[6]) {
+  uint32_t E[NR], O[NR];   // cumulative candidate count after run k; position = candidate number + O[k] inside run k
+  uint32_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < 5; j++) bp[j] = nb[5 * (size_t)q + j];
-    if (q < qm) corner_row(T, po, cpts, bp, cx, cy, cz, ci, sel);
-    else surf_row(T, po, spts, bp, cx, cy, cz, ci, sel);
-    if (sel) {
-      // Jacobian row, BasicLaserMapping.cpp:842-861
-      const float srx = T.srx, crx = T.crx, sry = T.sry, cry = T.cry, srz = T.srz, crz = T.crz;
-      a[0] = (crx * sry * srz * po.x + crx * crz * sry * po.y - srx * sry * po.z) * cx +
-             (-srx * srz * po.x - crz * srx * po.y - crx * po.z) * cy +
-             (crx * cry * srz * po.x + crx * cry * crz * po.y - cry * srx * po.z) * cz;
-      a[1] = ((cry * srx * srz - crz * sry) * po.x + (sry * srz + cry * crz * srx) * po.y + crx * cry * po.z) * cx +
-             ((-cry * crz - srx * sry * srz) * po.x + (cry * srz - crz * srx * sry) * po.y - crx * sry * po.z) * cz;
-      a[2] = ((crz * srx * sry - cry * srz) * po.x + (-cry * crz - srx * sry * srz) * po.y) * cx +
-             (crx * crz * po.x - crx * srz * po.y) * cy +
-             ((sry * srz + cry * crz * srx) * po.x + (crz * sry - cry * srx * srz) * po.y) * cz;
-      a[3] = cx; a[4] = cy; a[5] = cz;
-      bb = -ci;
+  for (int k = 0; k < NR; k++) {
+    O[k] = beg[k] - acc;
+    acc += len[k];
+    E[k] = acc;
+  }
+  const uint32_t total = acc;
+  for (uint32_t c0 = (uint32_t)gl; c0 < total; c0 += MLP * LPQ) {
+    uint32_t pos[MLP];
+    float4 p[MLP];
+#pragma unroll
+    for (int u = 0; u < MLP; u++) {
+      const uint32_t cc = c0 + u * LPQ;
+      uint32_t o = O[NR - 1];
+#pragma unroll
+      for (int k = NR - 2; k >= 0; k--) o = cc < E[k] ? O[k] : o;
+      pos[u] = cc < total ? cc + o : 0u;   // (slot 0 exists: the index is never empty here)
+    }
+#pragma unroll
+    for (int u = 0; u < MLP; u++) p[u] = pts[pos[u]];
+#pragma unroll
+    for (int u = 0; u < MLP; u++) {
+      const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+      const float d2 = dx * dx + dy * dy + dz * dz;   // x -> y -> z accumulation (nanoflann.hpp:372-379)
+      const bool ok = (c0 + u * LPQ) < total && d2 < KNN_COVER2;
+      const unsigned long long key = ok ? ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(p[u].w) : KNN_NONE;
+      knn_insert6(bk, bp, key, pos[u]);
     }
   }
-  // products in float (as Eigen's float A^T A forms them), accumulated in double
-  double v[LX_NSUM];
-  int k = 0;
-#pragma unroll
-  for (int i = 0; i < 6; i++)
-#pragma unroll
-    for (int j = i; j < 6; j++) v[k++] = (double)(a[i] * a[j]);
-#pragma unroll
-  for (int i = 0; i < 6; i++) v[k++] = (double)(a[i] * bb);
-  v[k] = sel ? 1.0 : 0.0;
+}
 
-  // transposed reduction through LDS, two halves of 14 sums (28 dependent 64-bit shuffle chains are several times
-  // slower): column c of the 256 x 14 table is summed by 8 threads (rows g, g+8, ...), then the 8 strands in order
-  constexpr int TRS = LX_RES_THREADS + 2, HALF = LX_NSUM / 2;
-  __shared__ double tr[HALF * TRS];
+// distance (cell units) from coordinate f inside cell c to the neighbouring cell on side d (-1 / +1), shrunk by 1e-4
+// relative + 1e-5 so that rounding can only make the visit larger
+__device__ inline float knn_gap(float f, int c, int d) {
+  const float v = d > 0 ? (float)(c + 1) - f : f - (float)c;
+  const float w = v * 0.9999f - 1e-5f;
+  return w > 0.f ? w : 0.f;
+}
+
+// The search of ONE query by the LPQ lanes of a group (all in one wave; every lane holds the same qx, qy, qz).
+// tab: the group's column of an LDS table [36][QB] (entry e of this group at tab[e * QB]).
+// out (all lanes): wk[0..5] ascending rank keys (KNN_NONE = empty), win[] = positions in the cell-sorted array
+template <int LPQ, int QB>
+__device__ inline void knn5_group(const GridDesc& g, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start, float qx, float qy,
+                                  float qz, int gl, uint32_t* tab, unsigned long long (&wk)[6], uint32_t (&win)[6]) {
+#pragma unroll
+  for (int j = 0; j < 6; j++) { wk[j] = KNN_NONE; win[j] = 0u; }
+  const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+  // a query farther than two cells outside the grid has no map point within the gate (and the casts below stay in range)
+  if (!(flx >= -2.f && flx <= (float)(g.nx + 1) && fly >= -2.f && fly <= (float)(g.ny + 1) && flz >= -2.f && flz <= (float)(g.nz + 1))) return;   // group-uniform
+  const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+  const int sx = (fx - flx) < 0.5f ? -1 : 1, sy = (fy - fly) < 0.5f ? -1 : 1, sz = (fz - flz) < 0.5f ? -1 : 1;
+  // ---- trip 1: the 36 table entries, dealt over the group's lanes.  Entry e = 4 r + k: cell_start of cell (cx - 1 + k) in
+  // row r = 3 a + b; a (z) and b (y): 0 centre, 1 nearer side, 2 farther side.  Out-of-range x is clamped onto the row's
+  // ends (those cells then come out empty), rows outside the grid are empty.
+  {
+    uint32_t v[(36 + LPQ - 1) / LPQ];
+#pragma unroll
+    for (int i = 0; i < (36 + LPQ - 1) / LPQ; i++) {
+      const int e = gl + LPQ * i;
+      const int r = e >> 2, k = e & 3, a = r / 3, b = r - 3 * a;
+      const int z = cz + (a == 1 ? sz : (a == 2 ? -sz : 0)), y = cy + (b == 1 ? sy : (b == 2 ? -sy : 0));
+      const bool in = e < 36 && z >= 0 && z < g.nz && y >= 0 && y < g.ny;
+      v[i] = in ? cell_start[((uint32_t)z * g.ny + y) * g.nx + clampi(cx - 1 + k, 0, g.nx)] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < (36 + LPQ - 1) / LPQ; i++) {
+      const int e = gl + LPQ * i;
+      if (e < 36) tab[e * QB] = v[i];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();   // the group's lanes are in one wave: the LDS writes above are visible below
+  unsigned long long bk[6];
+  uint32_t bp[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) { bk[j] = KNN_NONE; bp[j] = 0u; }
+  const int kn = sx < 0 ? 0 : 1;   // column of the first of the two cells {cx, cx + sx}; the far cell is column 2 resp. 0
+  // ---- phase 1: rows (a, b) in {0,1}^2 (r = 0, 1, 3, 4), cells cx and cx + sx
+  {
+    uint32_t beg[4], len[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = i < 2 ? i : i + 1;
+      const uint32_t lo = tab[(4 * r + kn) * QB], hi = tab[(4 * r + kn + 2) * QB];
+      beg[i] = lo;
+      len[i] = hi - lo;
+    }
+    knn_scan_group<4, KNN_MLP, LPQ>(pts, beg, len, qx, qy, qz, gl, bk, bp);
+  }
+  knn_pop6<LPQ>(bk, bp, gl, wk, win);
+  // ---- phase 2: everything else within the radius that still matters (the sixth-best so far, or the covered radius)
+  {
+    const float rad2 = wk[5] != KNN_NONE ? __uint_as_float((uint32_t)(wk[5] >> 32)) : KNN_COVER2;
+    const float r2c = rad2 * g.inv_h * g.inv_h;   // in cell units
+    const float gx_near = knn_gap(fx, cx, sx), gx_far = knn_gap(fx, cx, -sx);
+    const float gxl = sx < 0 ? gx_near : gx_far, gxr = sx < 0 ? gx_far : gx_near;
+    const float gy[3] = {0.f, knn_gap(fy, cy, sy), knn_gap(fy, cy, -sy)};
+    const float gz[3] = {0.f, knn_gap(fz, cz, sz), knn_gap(fz, cz, -sz)};
+    uint32_t beg[9], len[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) {
+        const int r = 3 * a + b;
+        const float gyz = gy[b] * gy[b] + gz[a] * gz[a];
+        uint32_t lo = 0u, hi = 0u;
+        if (a < 2 && b < 2) {
+          // a phase-1 row: only its far cell (cx - sx) is left
+          if (gyz + gx_far * gx_far < r2c) { lo = tab[(4 * r + 2 - 2 * kn) * QB]; hi = tab[(4 * r + 3 - 2 * kn) * QB]; }
+        } else if (gyz < r2c) {
+          lo = tab[(4 * r + ((gyz + gxl * gxl < r2c) ? 0 : 1)) * QB];
+          hi = tab[(4 * r + ((gyz + gxr * gxr < r2c) ? 3 : 2)) * QB];
+        }
+        beg[r] = lo;
+        len[r] = hi - lo;
+      }
+    // re-seed the lists with the winners so far (lane 0 holds them, in order) and scan what is left
+#pragma unroll
+    for (int k = 0; k < 6; k++) { bk[k] = gl == 0 ? wk[k] : KNN_NONE; bp[k] = win[k]; }
+    knn_scan_group<9, KNN_MLP, LPQ>(pts, beg, len, qx, qy, qz, gl, bk, bp);
+  }
+  knn_pop6<LPQ>(bk, bp, gl, wk, win);
+}
+
+struct GnArgs {
+  const float4* ds_pts;
+  const uint32_t* ds_off;
+  Pose* poses;
+  SweepStats* stats;
+  const GridDesc* cdesc;
+  const float4* cpts;
+  const uint32_t* cstart;
+  const GridDesc* sdesc;
+  const float4* spts;
+  const uint32_t* sstart;
+  double* partials;      // [sweep][nblk][LX_NSUM]
+  uint32_t* arrive;      // per sweep: workgroups that have delivered their sums (zero between launches)
+  float* matP;           // 36 per sweep
+  SweepStats* host_stats;
+  Pose* host_poses;
+  uint32_t nblk;         // tiles the partials array reserves per sweep
+  int iter;
+  float delta_t_abort, delta_r_abort;
+};
+
+constexpr int GN_TILE = LX_RES_THREADS / KNN_LPQ;   // queries per workgroup
+
+__global__ __launch_bounds__(LX_RES_THREADS) void k_gn_iter(const GnArgs A) {
+  constexpr int TRS = GN_TILE + 1;
+  __shared__ float tr[LX_NSUM * TRS];      // the tile's float products, transposed
+  __shared__ uint32_t s_tab[36 * GN_TILE];   // knn5_group's table staging, [entry][group]
+  __shared__ uint32_t s_nb[5 * GN_TILE];     // the winners' positions, [neighbour][query]
   __shared__ double red[8][LX_NSUM];
+  __shared__ int sh_last;
+  const uint32_t s = blockIdx.y;
+  if (A.stats[s].done) return;
+  const int tid = (int)threadIdx.x;
+  const uint32_t q0 = A.ds_off[2 * s], qm = A.ds_off[2 * s + 1], q1 = A.ds_off[2 * s + 2];
+  const uint32_t tc = (qm - q0 + GN_TILE - 1) / GN_TILE, tsf = (q1 - qm + GN_TILE - 1) / GN_TILE;
+  const uint32_t ntiles = (tc + tsf) ? tc + tsf : 1u;   // (a sweep without queries still burns the iteration: one empty tile)
+  // XCD-aware order: workgroup b runs on XCD b % 8 — every XCD gets a contiguous eighth of the (voxel-ordered) corner tiles
+  // and a contiguous eighth of the surf tiles, the corner tiles first: their fit (a 3x3 Jacobi eigen solver per query) takes
+  // several times longer than the plane fit, so they start early and are spread over all XCDs
+  uint32_t tile;
+  {
+    const uint32_t x = blockIdx.x % 8, j = blockIdx.x / 8;
+    const uint32_t tsurf = ntiles - tc;   // (the empty tile of a sweep without queries counts as a surf tile)
+    const uint32_t c0 = x * tc / 8, c1 = (x + 1) * tc / 8, s0 = x * tsurf / 8, s1 = (x + 1) * tsurf / 8;
+    if (j < c1 - c0) tile = c0 + j;
+    else if (j - (c1 - c0) < s1 - s0) tile = tc + s0 + (j - (c1 - c0));
+    else return;
+  }
+  const bool corner = tile < tc;   // block-uniform
+  const uint32_t qbase = corner ? q0 + tile * GN_TILE : qm + (tile - tc) * GN_TILE;
+  const uint32_t qend = corner ? qm : q1;
+  const Pose T = A.poses[s];
+  // ---- search: KNN_LPQ lanes per query
+  {
+    const int grp = tid / KNN_LPQ, gl = tid % KNN_LPQ;
+    const uint32_t q = qbase + (uint32_t)grp;
+    if (q < qend) {   // group-uniform
+      const float4 po = A.ds_pts[q];
+      float qx = po.x, qy = po.y, qz = po.z;
+      to_map(T, qx, qy, qz);
+      unsigned long long wk[6];
+      uint32_t win[6];
+      knn5_group<KNN_LPQ, GN_TILE>(corner ? *A.cdesc : *A.sdesc, corner ? A.cpts : A.spts, corner ? A.cstart : A.sstart, qx, qy, qz, gl, s_tab + grp, wk,
+                                   win);
+      if (gl == 0) {
+        const float d5 = wk[4] != KNN_NONE ? __uint_as_float((uint32_t)(wk[4] >> 32)) : FLT_MAX;
 #pragma unroll
-  for (int h = 0; h < 2; h++) {
-    if (h) __syncthreads();
-#pragma unroll
-    for (int t = 0; t < HALF; t++) tr[t * TRS + threadIdx.x] = v[h * HALF + t];
-    __syncthreads();
-    if (threadIdx.x < 8 * HALF) {
-      const int c = threadIdx.x % HALF, g = threadIdx.x / HALF;
-      const double* col = tr + c * TRS + g;
-      double x = 0.0;
-#pragma unroll 8
-      for (int j = 0; j < LX_RES_THREADS / 8; j++) x += col[8 * j];
-      red[g][h * HALF + c] = x;
+        for (int j = 0; j < 5; j++) s_nb[j * GN_TILE + grp] = (j == 4 && !(d5 < 1.0f)) ? 0xffffffffu : win[j];   // == pointSearchSqDis[4] < 1.0 (:671, :760)
+      }
     }
   }
   __syncthreads();
-  if (threadIdx.x < LX_NSUM) {
+  // ---- one lane per query (wave 0): edge / plane fit, weight, Jacobian row; float products into the transposed table
+  if (tid < GN_TILE) {
+    const uint32_t q = qbase + (uint32_t)tid;
+    float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bb = 0.f;
+    bool sel = false;
+    if (q < qend) {
+      const float4 po = A.ds_pts[q];
+      uint32_t bp[5];
+#pragma unroll
+      for (int j = 0; j < 5; j++) bp[j] = s_nb[j * GN_TILE + tid];
+      float cx, cy, cz, ci;
+      if (corner) corner_row(T, po, A.cpts, bp, cx, cy, cz, ci, sel);
+      else surf_row(T, po, A.spts, bp, cx, cy, cz, ci, sel);
+      if (sel) {
+        // Jacobian row, BasicLaserMapping.cpp:842-861
+        const float srx = T.srx, crx = T.crx, sry = T.sry, cry = T.cry, srz = T.srz, crz = T.crz;
+        a[0] = (crx * sry * srz * po.x + crx * crz * sry * po.y - srx * sry * po.z) * cx +
+               (-srx * srz * po.x - crz * srx * po.y - crx * po.z) * cy +
+               (crx * cry * srz * po.x + crx * cry * crz * po.y - cry * srx * po.z) * cz;
+        a[1] = ((cry * srx * srz - crz * sry) * po.x + (sry * srz + cry * crz * srx) * po.y + crx * cry * po.z) * cx +
+               ((-cry * crz - srx * sry * srz) * po.x + (cry * srz - crz * srx * sry) * po.y - crx * sry * po.z) * cz;
+        a[2] = ((crz * srx * sry - cry * srz) * po.x + (-cry * crz - srx * sry * srz) * po.y) * cx +
+               (crx * crz * po.x - crx * srz * po.y) * cy +
+               ((sry * srz + cry * crz * srx) * po.x + (crz * sry - cry * srx * srz) * po.y) * cz;
+        a[3] = cx; a[4] = cy; a[5] = cz;
+        bb = -ci;
+      }
+    }
+    // products in float (as Eigen's float A^T A forms them)
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = i; j < 6; j++) tr[(k++) * TRS + tid] = a[i] * a[j];
+#pragma unroll
+    for (int i = 0; i < 6; i++) tr[(k++) * TRS + tid] = a[i] * bb;
+    tr[k * TRS + tid] = sel ? 1.f : 0.f;
+  }
+  __syncthreads();
+  // ---- accumulated in double in a fixed order: column c of the 64 x 28 table is summed by 8 threads (rows g, g + 8, ...),
+  // then the 8 strands in order
+  if (tid < 8 * LX_NSUM) {
+    const int c = tid % LX_NSUM, g8 = tid / LX_NSUM;
+    const float* col = tr + c * TRS + g8;
     double x = 0.0;
 #pragma unroll
-    for (int w = 0; w < 8; w++) x += red[w][threadIdx.x];
-    partials[((size_t)s * nblk + blockIdx.x) * LX_NSUM + threadIdx.x] = x;
-    __threadfence();   // release the partial sums before this workgroup is counted in
+    for (int j = 0; j < GN_TILE / 8; j++) x += (double)col[8 * j];
+    red[g8][c] = x;
   }
-  // ---- the last workgroup of the sweep to arrive runs the update (saves a kernel boundary per iteration)
-  __shared__ int sh_last;
-  const uint32_t nq = q1 - q0;
-  const uint32_t nact = nq ? (nq + LX_RES_THREADS - 1) / LX_RES_THREADS : 1u;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const bool last = atomicAdd(&arrive[s], 1u) == nact - 1;
-    if (last) atomicExch(&arrive[s], 0u);   // ready for the next iteration (nobody else touches it before the next launch)
+  if (tid < LX_NSUM) {
+    double x = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) x += red[w][tid];
+    A.partials[((size_t)s * A.nblk + tile) * LX_NSUM + tid] = x;
+    __threadfence();   // release the tile sums before this workgroup is counted in
+  }
+  // ---- the last workgroup of the sweep to arrive runs the update
+  __syncthreads();
+  if (tid == 0) {
+    const bool last = atomicAdd(&A.arrive[s], 1u) == ntiles - 1;
+    if (last) atomicExch(&A.arrive[s], 0u);   // ready for the next iteration (nobody else touches it before the next launch)
     sh_last = last ? 1 : 0;
   }
   __syncthreads();
   if (!sh_last) return;
-  __threadfence();   // acquire the other workgroups' partial sums
-  solve_sweep(s, ds_off, poses_rw, stats_rw, matP, partials, nblk, nact, iter, delta_t_abort, delta_r_abort, host_stats, host_poses);
+  __threadfence();   // acquire the other workgroups' tile sums
+  solve_sweep(s, A.ds_off, A.poses, A.stats, A.matP, A.partials, A.nblk, ntiles, A.iter, A.delta_t_abort, A.delta_r_abort, A.host_stats, A.host_poses);
+}
+
+// debug / parity hook: the 5-NN search of k_gn_iter for arbitrary map-frame query points (loamx_batch_knn_probe)
+__global__ __launch_bounds__(256) void k_knn_probe(const float4* __restrict__ queries, uint32_t n, const GridDesc* __restrict__ desc,
+                                                   const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start,
+                                                   uint32_t* __restrict__ idx5, float* __restrict__ d2_5) {
+  constexpr int QB = 256 / KNN_LPQ;
+  __shared__ uint32_t tab[36 * QB];
+  const int grp = threadIdx.x / KNN_LPQ, gl = threadIdx.x % KNN_LPQ;
+  const uint32_t q = blockIdx.x * QB + grp;
+  if (q >= n) return;   // group-uniform (no workgroup-level synchronisation below)
+  const float4 p = queries[q];
+  unsigned long long wk[6];
+  uint32_t win[6];
+  knn5_group<KNN_LPQ, QB>(*desc, pts, cell_start, p.x, p.y, p.z, gl, tab + grp, wk, win);
+  if (gl != 0) return;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    idx5[5 * (size_t)q + j] = wk[j] != KNN_NONE ? (uint32_t)(wk[j] & 0xffffffffull) : 0xffffffffu;
+    d2_5[5 * (size_t)q + j] = wk[j] != KNN_NONE ? __uint_as_float((uint32_t)(wk[j] >> 32)) : FLT_MAX;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_transform_full(float4* __restrict__ full, uint32_t n, const uint32_t* __restrict__ full_off,
@@ -1018,10 +1002,6 @@ Registrar::Registrar(int device, uint32_t max_sweeps) : device_(device), max_swe
   st_ = create_stream(+1);
   corner_index.init(st_);
   surf_index.init(st_);
-  if (const char* e = getenv("LOAMX_KNN_LPQ")) {
-    const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) knn_lpq_ = v;
-  }
   poses_.reserve(max_sweeps);
   stats_.reserve(max_sweeps);
   matP_.reserve((size_t)36 * max_sweeps);
@@ -1121,7 +1101,6 @@ void Registrar::swap_submap() {
   surf_index.bind(st_);
   next_staged_ = false;
   swapped_once_ = true;
-  host_results_valid_ = false;
 }
 
 void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const loamx_cloud* surf_last, const loamx_cloud* full_res,
@@ -1168,11 +1147,8 @@ void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const 
   memcpy(h_guess_.p, guess6, sizeof(float) * 6 * n_sweeps);
   LX_HIP(hipMemcpyAsync(guess_.p, h_guess_.p, sizeof(float) * 6 * n_sweeps, hipMemcpyHostToDevice, st_));
   d_guess_ = guess_.p; d_seg_off_ = seg_off_.p; d_full_off_ = full_off_.p; d_src_ = nullptr;
-  nblk_ = (max_q_per_sweep_ + LX_RES_THREADS - 1) / LX_RES_THREADS;
-  if (nblk_ == 0) nblk_ = 1;
+  nblk_ = max_q_per_sweep_ / GN_TILE + 2;   // >= ceil(corner / tile) + ceil(surf / tile) of every sweep
   partials_.reserve((size_t)n_sweeps * nblk_ * LX_NSUM);
-  nb_.reserve((size_t)5 * n_in_ + 8);
-  qstate_.reserve((size_t)n_in_ + 8);
   LX_HIP(hipStreamSynchronize(st_));   // host staging buffers are reused by the caller after return
 }
 
@@ -1234,35 +1210,58 @@ void Registrar::upload_device(uint32_t n_sweeps, const float4* const* corner_las
       hipLaunchKernelGGL(k_gather_segments, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, d_full_off_, n_sweeps, d_src_ + nseg,
                          n_full_);
   }
-  nblk_ = (max_q_per_sweep_ + LX_RES_THREADS - 1) / LX_RES_THREADS;
-  if (nblk_ == 0) nblk_ = 1;
+  nblk_ = max_q_per_sweep_ / GN_TILE + 2;   // >= ceil(corner / tile) + ceil(surf / tile) of every sweep
   partials_.reserve((size_t)n_sweeps * nblk_ * LX_NSUM);
-  nb_.reserve((size_t)5 * n_in_ + 8);
-  qstate_.reserve((size_t)n_in_ + 8);
-}
-
-template <int LPQ>
-static void launch_knn5_t(Registrar& r, uint32_t max_q, uint32_t ns, hipStream_t st, const float4* ds_pts, const uint32_t* ds_off, const Pose* poses,
-                          const SweepStats* stats, uint32_t* nb, float4* qstate, int it) {
-  constexpr uint32_t QB = 256 / LPQ;
-  hipLaunchKernelGGL(k_knn5<LPQ>, dim3(8 * ((max_q + 8 * QB - 1) / (8 * QB)), ns), dim3(256), 0, st, ds_pts, ds_off, poses, stats,
-                     r.corner_index.desc(), r.corner_index.sorted(), r.corner_index.cell_start(), r.surf_index.desc(),
-                     r.surf_index.sorted(), r.surf_index.cell_start(), nb, qstate, it);
-}
-
-void Registrar::launch_knn5(int it) {
-  const uint32_t ns = n_sweeps_;
-  switch (knn_lpq_) {
-    case 1: launch_knn5_t<1>(*this, max_q_per_sweep_, ns, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p, nb_.p, qstate_.p, it); break;
-    case 2: launch_knn5_t<2>(*this, max_q_per_sweep_, ns, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p, nb_.p, qstate_.p, it); break;
-    case 8: launch_knn5_t<8>(*this, max_q_per_sweep_, ns, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p, nb_.p, qstate_.p, it); break;
-    case 16: launch_knn5_t<16>(*this, max_q_per_sweep_, ns, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p, nb_.p, qstate_.p, it); break;
-    default: launch_knn5_t<4>(*this, max_q_per_sweep_, ns, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p, nb_.p, qstate_.p, it); break;
-  }
 }
 
 static double host_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// The Gauss-Newton iterations: one k_gn_iter launch each.  Converged sweeps turn the remaining launches into no-ops on the
+// device (stats.done), which keeps run_async() free of host round trips.  A blocking caller (early_exit) instead enqueues as
+// many iterations as the previous call needed, looks at the flags (mirrored into pinned memory by the update step), and
+// stops launching once every sweep is done.
+void Registrar::run_iterations(bool trace, double& th2, double& th3) {
+  const uint32_t ns = n_sweeps_;
+  GnArgs a;
+  a.ds_pts = ds_pts_.p; a.ds_off = ds_off_.p; a.poses = poses_.p; a.stats = stats_.p;
+  a.cdesc = corner_index.desc(); a.cpts = corner_index.sorted(); a.cstart = corner_index.cell_start();
+  a.sdesc = surf_index.desc(); a.spts = surf_index.sorted(); a.sstart = surf_index.cell_start();
+  a.partials = partials_.p; a.arrive = arrive_.p; a.matP = matP_.p;
+  a.host_stats = h_stats_.p; a.host_poses = h_poses_.p;
+  a.nblk = nblk_; a.delta_t_abort = params.delta_t_abort; a.delta_r_abort = params.delta_r_abort;
+  const dim3 grid(8 * ((nblk_ + 7) / 8 + 1), ns);   // per XCD: ceil(corner tiles / 8) + ceil(surf tiles / 8) workgroups at most
+  int it = 0;
+  bool waited = false;
+  int chunk = early_exit ? std::min(std::max(pred_iters_, 2), params.max_iterations) : params.max_iterations;
+  while (it < params.max_iterations) {
+    const int end = std::min(params.max_iterations, it + chunk);
+    for (; it < end; it++) {
+      const bool tm = timing_ && n_res_launch_ < 64;
+      if (tm) LX_HIP(hipEventRecord(ev_[2 + 2 * n_res_launch_], st_));
+      a.iter = it;
+      hipLaunchKernelGGL(k_gn_iter, grid, dim3(LX_RES_THREADS), 0, st_, a);
+      if (tm) {
+        LX_HIP(hipEventRecord(ev_[3 + 2 * n_res_launch_], st_));
+        n_res_launch_++;
+      }
+    }
+    if (!early_exit || it >= params.max_iterations) break;
+    if (trace && th2 == 0) th2 = host_us();
+    if (on_first_wait && !waited) { waited = true; on_first_wait(); on_first_wait = nullptr; }   // host work that overlaps the wait
+    if (trace && th3 == 0) th3 = host_us();
+    LX_HIP(hipStreamSynchronize(st_));
+    bool all_done = true;
+    int need = 0;
+    for (uint32_t k = 0; k < ns; k++) {
+      all_done = all_done && h_stats_.p[k].done;
+      need = std::max(need, h_stats_.p[k].iterations);
+    }
+    if (all_done) { pred_iters_ = need; mirrors_written_ = true; break; }   // poses / stats are final and on the host
+    pred_iters_ = it + 1;
+    chunk = 1;
+  }
 }
 
 void Registrar::run_async() {
@@ -1274,9 +1273,8 @@ void Registrar::run_async() {
   const uint32_t ns = n_sweeps_, nseg = 2 * ns, n = n_in_;
   if (timing_) LX_HIP(hipEventRecord(ev_[0], st_));
   n_res_launch_ = 0;
-  host_results_valid_ = false;
   if (early_exit) memset(h_stats_.p, 0, sizeof(SweepStats) * ns);   // mirrors of sweeps that never reach an update stay "not done"
-  hipLaunchKernelGGL(k_pose_init, dim3((ns + 63) / 64), dim3(64), 0, st_, d_guess_, ns, poses_.p, stats_.p, vox_.seg_minmax());
+  hipLaunchKernelGGL(k_pose_init, dim3((ns + 63) / 64), dim3(64), 0, st_, d_guess_, ns, poses_.p, stats_.p, vox_.seg_minmax(), arrive_.p);
   if (n > 0) {
     const uint32_t nb = (n + 255) / 256;
     hipLaunchKernelGGL(k_stack, dim3(nb), dim3(256), 0, st_, in_.p, d_src_, n, d_seg_off_, nseg, poses_.p, 1.0f / params.corner_leaf,
@@ -1286,58 +1284,17 @@ void Registrar::run_async() {
     LX_HIP(hipMemsetAsync(ds_off_.p, 0, sizeof(uint32_t) * (nseg + 1), st_));
   }
   if (trace) th1 = host_us();
+  mirrors_written_ = false;
   if (submap_sufficient() && n > 0) {   // BasicLaserMapping.cpp:628-629 guard
-    // Converged sweeps turn the remaining launches into no-ops on the device (stats.done), which keeps run_async()
-    // free of host round trips.  A blocking caller (early_exit) instead enqueues as many iterations as the previous
-    // call needed, looks at the flags, and stops launching once every sweep is done.
-    int it = 0;
-    bool waited = false;
-    int chunk = early_exit ? std::min(std::max(pred_iters_, 2), params.max_iterations) : params.max_iterations;
-    while (it < params.max_iterations) {
-      const int end = std::min(params.max_iterations, it + chunk);
-      for (; it < end; it++) {
-        const bool tm = timing_ && n_res_launch_ < 64;
-        if (tm) LX_HIP(hipEventRecord(ev_[2 + 2 * n_res_launch_], st_));
-        launch_knn5(it);
-        if (tm) {   // the timed kernel is the neighbour search (the path's dominant gather)
-          LX_HIP(hipEventRecord(ev_[3 + 2 * n_res_launch_], st_));
-          n_res_launch_++;
-        }
-        hipLaunchKernelGGL(k_residual, dim3(nblk_, ns), dim3(LX_RES_THREADS), 0, st_, ds_pts_.p, ds_off_.p, poses_.p, stats_.p,
-                           corner_index.sorted(), surf_index.sorted(), nb_.p, partials_.p, nblk_, poses_.p, stats_.p, matP_.p,
-                           arrive_.p, it, params.delta_t_abort, params.delta_r_abort, early_exit ? h_stats_.p : nullptr,
-                           early_exit ? h_poses_.p : nullptr);
-      }
-      if (!early_exit || it >= params.max_iterations) break;
-      // (flags and poses are mirrored into h_stats_ / h_poses_ by the update step itself: nothing to copy)
-      if (trace && th2 == 0) th2 = host_us();
-      if (on_first_wait && !waited) { waited = true; on_first_wait(); }   // host work that overlaps the wait
-      if (trace && th3 == 0) th3 = host_us();
-      LX_HIP(hipStreamSynchronize(st_));
-      bool all_done = true;
-      int need = 0;
-      for (uint32_t k = 0; k < ns; k++) {
-        all_done = all_done && h_stats_.p[k].done;
-        need = std::max(need, h_stats_.p[k].iterations);
-      }
-      if (all_done) { pred_iters_ = need; host_results_valid_ = true; break; }   // poses / stats are final and on the host
-      pred_iters_ = it + 1;
-      chunk = 1;
-    }
+    run_iterations(trace, th2, th3);
+    if (trace && th2 == 0) th2 = host_us();
   }
   if (n_full_ && !defer_full)
     hipLaunchKernelGGL(k_transform_full, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, n_full_, d_full_off_, ns, poses_.p);
   if (timing_) { LX_HIP(hipEventRecord(ev_[1], st_)); timed_run_ = true; }
   LX_HIP(hipGetLastError());
-#ifdef LOAMX_PROF_KNN
-  {
-    unsigned long long ts[8];
-    LX_HIP(hipStreamSynchronize(st_));
-    LX_HIP(hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_knn_ts), sizeof(ts)));
-    fprintf(stderr, "[knn ts, 10ns ticks] phaseA %lld  (wave1 wait %lld)  scan %lld  pop %lld\n", (long long)(ts[1] - ts[0]), (long long)(ts[2] - ts[0]),
-            (long long)(ts[3] - ts[2]), (long long)(ts[4] - ts[3]));
-  }
-#endif
+  if (on_first_wait) on_first_wait();   // host work of the caller that overlaps the device work enqueued above
+  if (trace && th3 == 0) th3 = host_us();
   if (trace)
     fprintf(stderr, "[reg] voxel stage enqueued %.0f us, first iterations enqueued %.0f, callback done %.0f, run_async returns %.0f\n", th1 - th0,
             th2 - th0, th3 - th0, host_us() - th0);
@@ -1354,27 +1311,52 @@ void Registrar::finish_with_poses(const float* poses6) {
   hipLaunchKernelGGL(k_pose_set, dim3((ns + 63) / 64), dim3(64), 0, st_, guess_.p, ns, poses_.p);
   if (n_full_)
     hipLaunchKernelGGL(k_transform_full, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, n_full_, d_full_off_, ns, poses_.p);
-  host_results_valid_ = false;
+  mirrors_written_ = false;   // the device poses were replaced
   LX_HIP(hipGetLastError());
+}
+
+// parity hook: the product's neighbour search for arbitrary map-frame points (see k_knn_probe)
+void Registrar::knn_probe(int which, const float* xyz, uint32_t n, uint32_t* idx5, float* d2_5) {
+  LX_REQUIRE(which == 0 || which == 1, "which must be 0 (corner sub-map) or 1 (surf sub-map)");
+  LX_REQUIRE(xyz && idx5 && d2_5, "NULL argument");
+  SubMapIndex& ix = which == 0 ? corner_index : surf_index;
+  LX_REQUIRE(ix.size() >= 1, "the sub-map is empty");
+  LX_HIP(hipSetDevice(device_));
+  if (!n) return;
+  DevBuf<float4> dq;
+  DevBuf<uint32_t> di;
+  DevBuf<float> dd;
+  dq.reserve(n); di.reserve((size_t)5 * n); dd.reserve((size_t)5 * n);
+  std::vector<float4> hq(n);
+  for (uint32_t i = 0; i < n; i++) hq[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
+  LX_HIP(hipMemcpyAsync(dq.p, hq.data(), sizeof(float4) * n, hipMemcpyHostToDevice, st_));
+  hipLaunchKernelGGL(k_knn_probe, dim3((n + 256 / KNN_LPQ - 1) / (256 / KNN_LPQ)), dim3(256), 0, st_, dq.p, n, ix.desc(), ix.sorted(), ix.cell_start(), di.p, dd.p);
+  LX_HIP(hipMemcpyAsync(idx5, di.p, sizeof(uint32_t) * 5 * n, hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipMemcpyAsync(d2_5, dd.p, sizeof(float) * 5 * n, hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipStreamSynchronize(st_));
 }
 
 void Registrar::sync() { LX_HIP(hipStreamSynchronize(st_)); }
 
-void Registrar::download_stats(SweepStats* out) {
-  if (!host_results_valid_) {
+// final poses / statistics on the host: an early-exit run that saw every sweep converge already holds them (the update
+// step mirrors them into pinned memory), anything else is copied
+void Registrar::fetch_results() {
+  if (!mirrors_written_) {
+    LX_HIP(hipMemcpyAsync(h_poses_.p, poses_.p, sizeof(Pose) * n_sweeps_, hipMemcpyDeviceToHost, st_));
     LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * n_sweeps_, hipMemcpyDeviceToHost, st_));
     LX_HIP(hipStreamSynchronize(st_));
+    mirrors_written_ = true;
   }
+}
+
+void Registrar::download_stats(SweepStats* out) {
+  fetch_results();
   memcpy(out, h_stats_.p, sizeof(SweepStats) * n_sweeps_);
 }
 
 void Registrar::download(float* poses6, int* stats4) {
   LX_REQUIRE(n_sweeps_ > 0, "download() before run()");
-  if (!host_results_valid_) {   // (an early-exit run that saw every sweep converge already holds the final values)
-    LX_HIP(hipMemcpyAsync(h_poses_.p, poses_.p, sizeof(Pose) * n_sweeps_, hipMemcpyDeviceToHost, st_));
-    LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * n_sweeps_, hipMemcpyDeviceToHost, st_));
-    LX_HIP(hipStreamSynchronize(st_));
-  }
+  fetch_results();
   for (uint32_t s = 0; s < n_sweeps_; s++) {
     if (poses6) {
       const Pose& T = h_poses_.p[s];
@@ -1418,7 +1400,7 @@ void Registrar::get_timing(float ms[4], uint64_t counts[4]) {
   if (!timing_ || !timed_run_) return;
   LX_HIP(hipEventSynchronize(ev_[1]));
   LX_HIP(hipEventElapsedTime(&ms[0], ev_[0], ev_[1]));
-  for (int k = 0; k < n_res_launch_; k++) {
+  for (int k = 0; k < n_res_launch_; k++) {   // the Gauss-Newton launches
     float t = 0.f;
     LX_HIP(hipEventElapsedTime(&t, ev_[2 + 2 * k], ev_[3 + 2 * k]));
     ms[1] += t;

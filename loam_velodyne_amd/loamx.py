@@ -179,6 +179,15 @@ class Batch:
         _check(lib().loamx_batch_download_full_res(self.h, sweep, C.byref(c)))
         return out[:c.count]
 
+    def knn_probe(self, which: int, queries_xyz):
+        """the library's own 5-NN search for map-frame points: (indices into the cloud given to set_frozen, squared distances)"""
+        q = np.ascontiguousarray(np.asarray(queries_xyz, np.float32)[:, :3])
+        idx = np.zeros((len(q), 5), np.uint32)
+        d2 = np.zeros((len(q), 5), np.float32)
+        _check(lib().loamx_batch_knn_probe(self.h, which, q.ctypes.data_as(C.c_void_p), len(q), idx.ctypes.data_as(C.c_void_p),
+                                           d2.ctypes.data_as(C.c_void_p)))
+        return idx, d2
+
     def set_timing(self, on: bool):
         _check(lib().loamx_batch_set_timing(self.h, 1 if on else 0))
 

@@ -52,7 +52,7 @@ def test_parity_vlp16_100k(orc):
     assert np.abs(gposes - oposes).max() < POSE_TOL
     for k in range(4):
         assert gstats[k, 0] == ostats[k]["iterations"] and gstats[k, 2] == ostats[k]["corner_ds"] and gstats[k, 3] == ostats[k]["surf_ds"]
-        assert abs(int(gstats[k, 1]) - ostats[k]["sel"]) <= 2          # rows selected: threshold flips reported, not hidden
+        assert int(gstats[k, 1]) == ostats[k]["sel"]                    # rows selected in the last iteration: equal, no flipped threshold
         # transformFullResToMap with the final pose
         R = synth.rot_zxy(*gposes[k, :3])
         want = fulls[k][:, :3].astype(np.float64) @ R.T + gposes[k, 3:]
@@ -92,6 +92,24 @@ def test_full_size_hdl64_1m_map(orc):
     b.run()
     p2, s2 = b.download()
     assert np.abs(p2 - poses).max() < 5e-4 and np.all(s2[:, 0] <= 2)
+
+
+@pytest.mark.parametrize("sensor,map_points,half", [("HDL-32", 500_000, 125.0), ("HDL-64E", 2_000_000, 125.0)])
+def test_full_size_other_configs(orc, sensor, map_points, half):
+    """BASELINE configs[2] (HDL-32, 500 k-pt map) and configs[4] (HDL-64E, 2 M-pt map): frozen-map registration vs the oracle"""
+    world = synth.World(half_extent=half)
+    cm, sm = world.make_map(map_points)
+    cl, sl, guesses, _ = _inputs(orc, world, sensor, 3, seed=7)
+    oposes, ostats = _oracle(orc, cm, sm, cl, sl, guesses)
+    b = loamx.Batch(3)
+    b.set_frozen(cm, sm)
+    b.upload(cl, sl, guesses)
+    assert b.run() == loamx.OK
+    poses, stats = b.download()
+    assert np.abs(poses - oposes).max() < POSE_TOL, float(np.abs(poses - oposes).max())
+    for k in range(3):
+        assert stats[k, 0] == ostats[k]["iterations"] and stats[k, 2] == ostats[k]["corner_ds"] and stats[k, 3] == ostats[k]["surf_ds"]
+        assert int(stats[k, 1]) == ostats[k]["sel"]
 
 
 def test_golden_pipeline_inputs(orc):

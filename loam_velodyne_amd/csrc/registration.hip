@@ -532,6 +532,12 @@ __device__ inline void surf_row(const Pose& T, const float4 po, const float4* __
 // (deterministic) reduction of the block partials — 9 groups of 28 threads each walk every 9th block, then the 9 group
 // sums are added in order — then wave 0 solves and thread 0 updates the pose
 constexpr int LX_SOLVE_GROUPS = 9;
+#ifdef LOAMX_PROF_GN
+__device__ unsigned long long g_solve_ts[16];
+#define SOLVE_TS(k) do { if (s == 0 && iter == 0 && threadIdx.x == 0) g_solve_ts[k] = wall_clock64(); } while (0)
+#else
+#define SOLVE_TS(k) do { } while (0)
+#endif
 __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_off, Pose* __restrict__ poses, SweepStats* __restrict__ stats,
                                    float* __restrict__ matP, const double* partials, uint32_t nblk, uint32_t nact, int iter,
                                    float delta_t_abort, float delta_r_abort, SweepStats* host_stats, Pose* host_poses) {
@@ -542,6 +548,7 @@ __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_o
   __shared__ Pose sP;
   __shared__ SweepStats sSt;
   const int tid = (int)threadIdx.x;
+  SOLVE_TS(0);
   if (tid == LX_RES_THREADS - 1) {   // (a lane of the last wave: the loads overlap with the partial sums below)
     sP = poses[s];
     sSt = stats[s];
@@ -563,6 +570,7 @@ __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_o
     gsum[g][t] = x;
   }
   __syncthreads();
+  SOLVE_TS(1);
   if (tid < LX_NSUM) {
     double x = 0.0;
 #pragma unroll
@@ -592,8 +600,10 @@ __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_o
     }
     return;
   }
+  SOLVE_TS(2);
   if (tid < 64) qr_solve6_coop(AtA, AtB, X);   // wave 0, all lanes
   __syncthreads();
+  SOLVE_TS(3);
   float* P = matP + 36 * s;
   if (tid == 0) {
     if (iter == 0) sSt.degenerate = degeneracy_projector(AtA, 100.f, P, ws) ? 1 : 0;
@@ -607,11 +617,13 @@ __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_o
     }
   }
   __syncthreads();
+  SOLVE_TS(4);
   if (tid < 6) {   // sin / cos of the new angles, one per lane, double then rounded (pose_set_angles)
     const float ang = (tid < 2 ? sP.rx : (tid < 4 ? sP.ry : sP.rz)) + X[tid >> 1];
     trig[tid] = (float)((tid & 1) ? cos((double)ang) : sin((double)ang));
   }
   __syncthreads();
+  SOLVE_TS(5);
   if (tid != 0) return;
   SweepStats st = sSt;
   st.iterations = iter + 1;
@@ -633,6 +645,7 @@ __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_o
   // mirror in host-visible (pinned, mapped) memory: a blocking caller reads flags and poses after a stream sync, without
   // two more copies on the stream
   if (host_stats) { host_stats[s] = st; host_poses[s] = T; }
+  SOLVE_TS(6);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -828,11 +841,17 @@ struct GnArgs {
   SweepStats* host_stats;
   Pose* host_poses;
   uint32_t nblk;         // tiles the partials array reserves per sweep
+  unsigned long long* dbg;   // LOAMX_PROF_GN: per workgroup of sweep 0: 8 wall-clock stamps
   int iter;
   float delta_t_abort, delta_r_abort;
 };
 
 constexpr int GN_TILE = LX_RES_THREADS / KNN_LPQ;   // queries per workgroup
+#ifdef LOAMX_PROF_GN
+#define GN_TS(k) do { if (blockIdx.y == 0 && tid == 0 && A.iter == 0) A.dbg[(size_t)tile * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define GN_TS(k) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(LX_RES_THREADS) void k_gn_iter(const GnArgs A) {
   constexpr int TRS = GN_TILE + 1;
@@ -862,6 +881,7 @@ __global__ __launch_bounds__(LX_RES_THREADS) void k_gn_iter(const GnArgs A) {
   const bool corner = tile < tc;   // block-uniform
   const uint32_t qbase = corner ? q0 + tile * GN_TILE : qm + (tile - tc) * GN_TILE;
   const uint32_t qend = corner ? qm : q1;
+  GN_TS(0);
   const Pose T = A.poses[s];
   // ---- search: KNN_LPQ lanes per query
   {
@@ -883,6 +903,7 @@ __global__ __launch_bounds__(LX_RES_THREADS) void k_gn_iter(const GnArgs A) {
     }
   }
   __syncthreads();
+  GN_TS(1);
   // ---- one lane per query (wave 0): edge / plane fit, weight, Jacobian row; float products into the transposed table
   if (tid < GN_TILE) {
     const uint32_t q = qbase + (uint32_t)tid;
@@ -922,6 +943,7 @@ __global__ __launch_bounds__(LX_RES_THREADS) void k_gn_iter(const GnArgs A) {
     tr[k * TRS + tid] = sel ? 1.f : 0.f;
   }
   __syncthreads();
+  GN_TS(2);
   // ---- accumulated in double in a fixed order: column c of the 64 x 28 table is summed by 8 threads (rows g, g + 8, ...),
   // then the 8 strands in order
   if (tid < 8 * LX_NSUM) {
@@ -942,6 +964,7 @@ __global__ __launch_bounds__(LX_RES_THREADS) void k_gn_iter(const GnArgs A) {
   }
   // ---- the last workgroup of the sweep to arrive runs the update
   __syncthreads();
+  GN_TS(3);
   if (tid == 0) {
     const bool last = atomicAdd(&A.arrive[s], 1u) == ntiles - 1;
     if (last) atomicExch(&A.arrive[s], 0u);   // ready for the next iteration (nobody else touches it before the next launch)
@@ -950,7 +973,9 @@ __global__ __launch_bounds__(LX_RES_THREADS) void k_gn_iter(const GnArgs A) {
   __syncthreads();
   if (!sh_last) return;
   __threadfence();   // acquire the other workgroups' tile sums
+  GN_TS(4);
   solve_sweep(s, A.ds_off, A.poses, A.stats, A.matP, A.partials, A.nblk, ntiles, A.iter, A.delta_t_abort, A.delta_r_abort, A.host_stats, A.host_poses);
+  GN_TS(5);
 }
 
 // debug / parity hook: the 5-NN search of k_gn_iter for arbitrary map-frame query points (loamx_batch_knn_probe)
@@ -1224,6 +1249,7 @@ static double host_us() {
 // stops launching once every sweep is done.
 void Registrar::run_iterations(bool trace, double& th2, double& th3) {
   const uint32_t ns = n_sweeps_;
+  struct ProfDump { std::function<void()> f; ~ProfDump() { if (f) f(); } } prof_dump;
   GnArgs a;
   a.ds_pts = ds_pts_.p; a.ds_off = ds_off_.p; a.poses = poses_.p; a.stats = stats_.p;
   a.cdesc = corner_index.desc(); a.cpts = corner_index.sorted(); a.cstart = corner_index.cell_start();
@@ -1231,7 +1257,33 @@ void Registrar::run_iterations(bool trace, double& th2, double& th3) {
   a.partials = partials_.p; a.arrive = arrive_.p; a.matP = matP_.p;
   a.host_stats = h_stats_.p; a.host_poses = h_poses_.p;
   a.nblk = nblk_; a.delta_t_abort = params.delta_t_abort; a.delta_r_abort = params.delta_r_abort;
-  const dim3 grid(8 * ((nblk_ + 7) / 8 + 1), ns);   // per XCD: ceil(corner tiles / 8) + ceil(surf tiles / 8) workgroups at most
+  const dim3 grid(8 * ((nblk_ + 7) / 8 + 1), ns);
+  a.dbg = nullptr;
+#ifdef LOAMX_PROF_GN
+  static DevBuf<unsigned long long> dbg;
+  dbg.reserve((size_t)nblk_ * 8 + 64);
+  LX_HIP(hipMemsetAsync(dbg.p, 0, sizeof(unsigned long long) * ((size_t)nblk_ * 8 + 64), st_));
+  a.dbg = dbg.p;
+  prof_dump.f = [&]() {
+    std::vector<unsigned long long> h((size_t)nblk_ * 8);
+    (void)hipStreamSynchronize(st_);
+    (void)hipMemcpy(h.data(), dbg.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull;
+    for (uint32_t t = 0; t < nblk_; t++) if (h[8 * t]) t0 = std::min(t0, h[8 * t]);
+    fprintf(stderr, "[gn iter 0, sweep 0: tile: start / search / rows / reduce us (+solve)]");
+    for (uint32_t t = 0; t < nblk_; t++) {
+      const unsigned long long* v = &h[8 * t];
+      if (!v[0]) continue;
+      if (t % 16 == 0 || v[5]) fprintf(stderr, " %u:%.0f/%.0f/%.0f/%.0f", t, (v[0] - t0) * 0.01, (v[1] - v[0]) * 0.01, (v[2] - v[1]) * 0.01, (v[3] - v[2]) * 0.01);
+      if (v[5]) fprintf(stderr, "(+solve %.0f, ends at %.0f)", (v[5] - v[4]) * 0.01, (v[5] - t0) * 0.01);
+    }
+    fprintf(stderr, "\n");
+    unsigned long long ts[16];
+    (void)hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_solve_ts), sizeof(ts));
+    fprintf(stderr, "[solve_sweep, us since entry] partial sums %.1f  sums+AtA %.1f  qr %.1f  projector %.1f  trig %.1f  update+stores %.1f\n", (ts[1] - ts[0]) * 0.01,
+            (ts[2] - ts[0]) * 0.01, (ts[3] - ts[0]) * 0.01, (ts[4] - ts[0]) * 0.01, (ts[5] - ts[0]) * 0.01, (ts[6] - ts[0]) * 0.01);
+  };
+#endif   // per XCD: ceil(corner tiles / 8) + ceil(surf tiles / 8) workgroups at most
   int it = 0;
   bool waited = false;
   int chunk = early_exit ? std::min(std::max(pred_iters_, 2), params.max_iterations) : params.max_iterations;

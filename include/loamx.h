@@ -64,7 +64,7 @@ const char* loamx_last_error(void);
 /* number of visible HIP devices (0 if none / HIP unavailable); never fails */
 int loamx_device_count(void);
 /* ABI version of this header */
-#define LOAMX_ABI_VERSION 1
+#define LOAMX_ABI_VERSION 2
 int loamx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -77,16 +77,25 @@ typedef struct loamx_scanreg_config {
   float scan_period;                 /* 0.1 */
   int n_feature_regions;             /* 6 */
   int curvature_region;              /* 5 */
-  int max_corner_sharp;              /* 2  (max_corner_less_sharp = 10x) */
+  int max_corner_sharp;              /* 2 */
   int max_surface_flat;              /* 4 */
   float less_flat_filter_size;       /* 0.2 */
   float surface_curvature_threshold; /* 0.1 */
   int device;                        /* HIP device ordinal */
+  /* (ABI version 2) */
+  int max_corner_less_sharp;         /* 20; must be >= max_corner_sharp (ScanRegistration.cpp:100-109).  0 = 10 x max_corner_sharp,
+                                        what the RegistrationParams constructor derives (BasicScanRegistration.cpp:22) */
+  int imu_history_size;              /* 200; >= 1 (ScanRegistration.cpp:59-66).  The reference's history buffer is created with 200
+                                        entries and ensureCapacity only grows it (CircularBuffer.h:53-70), so values below 200
+                                        behave as 200; at most 4096 here */
 } loamx_scanreg_config;
 
 void loamx_scanreg_default_config(loamx_scanreg_config* cfg);
 loamx_scanreg* loamx_scanreg_create(const loamx_scanreg_config* cfg);
 void loamx_scanreg_destroy(loamx_scanreg* h);
+/* BasicScanRegistration::configure (BasicScanRegistration.cpp:49-53): new parameters for an existing handle; the IMU history,
+ * the scan time and the sweep state are kept, as in the reference (cfg->device must be the handle's device) */
+int loamx_scanreg_configure(loamx_scanreg* h, const loamx_scanreg_config* cfg);
 /* processScanlines: `cloud` holds the rings concatenated in ring order, ring r occupying ring_size[r] points.
  * Outputs (any may be NULL): sharp, less_sharp, flat, less_flat; count fields return the sizes. */
 int loamx_scanreg_process(loamx_scanreg* h, const loamx_cloud* cloud, const uint32_t* ring_size, uint32_t n_rings,
@@ -110,9 +119,8 @@ int loamx_scanreg_process_raw(loamx_scanreg* h, const loamx_multiscan_mapper* ma
                               loamx_cloud* flat, loamx_cloud* less_flat);
 
 /* IMU data for the scan registration: updateIMUData (BasicScanRegistration.cpp:82-98) feeds the
- * handle's IMU history (capacity 200: the reference's buffer is created with 200 entries and ensureCapacity only grows it,
- * include/loam_velodyne/CircularBuffer.h, so every RegistrationParams::imuHistorySize <= 200 behaves as 200; larger histories
- * are not configurable here); loamx_scanreg_set_time gives the scanTime of the
+ * handle's IMU history (capacity max(200, imu_history_size): the reference's buffer is created with 200 entries and
+ * ensureCapacity only grows it, include/loam_velodyne/CircularBuffer.h); loamx_scanreg_set_time gives the scanTime of the
  * next process call (times in seconds on one clock); with a non-empty history loamx_scanreg_process_raw de-skews every
  * kept point (projectPointToStartOfSweep :101-147) and loamx_scanreg_get_imu_trans returns imuTransform() (:258-281):
  * start angles, current angles, position shift, velocity change — what loamx_odom_update_imu consumes.

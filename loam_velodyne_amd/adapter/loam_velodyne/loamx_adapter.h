@@ -162,7 +162,10 @@ inline double seconds(const Time& t) { return toSec(t.time_since_epoch()); }
 
 class BasicScanRegistration {
  public:
+  BasicScanRegistration() = default;
   ~BasicScanRegistration() { loamx_scanreg_destroy(_h); }
+  BasicScanRegistration(const BasicScanRegistration&) = delete;              // the object owns a device handle
+  BasicScanRegistration& operator=(const BasicScanRegistration&) = delete;
 #ifdef LOAMX_REFERENCE_TYPES
   // the reference's own signatures (BasicScanRegistration.h:140-150): time points instead of seconds
   void processScanlines(const Time& scanTime, std::vector<CloudXYZI> const& laserCloudScans) {
@@ -181,18 +184,22 @@ class BasicScanRegistration {
     processRawSweep<int, CloudXYZ>(0, laserCloudIn, lowerBoundDeg, upperBoundDeg, nScanRings);
   }
 #endif
+  // configure (BasicScanRegistration.cpp:49-53): every RegistrationParams member is forwarded — maxCornerLessSharp and
+  // imuHistorySize too — and an existing handle keeps its IMU history and sweep state, as the reference's object does
   bool configure(const RegistrationParams& config = RegistrationParams()) {
     _config = config;
-    loamx_scanreg_destroy(_h);
     loamx_scanreg_config c;
     loamx_scanreg_default_config(&c);
     c.scan_period = config.scanPeriod;
     c.n_feature_regions = config.nFeatureRegions;
     c.curvature_region = config.curvatureRegion;
     c.max_corner_sharp = config.maxCornerSharp;
+    c.max_corner_less_sharp = config.maxCornerLessSharp;
     c.max_surface_flat = config.maxSurfaceFlat;
     c.less_flat_filter_size = config.lessFlatFilterSize;
     c.surface_curvature_threshold = config.surfaceCurvatureThreshold;
+    c.imu_history_size = config.imuHistorySize;
+    if (_h) return loamx_scanreg_configure(_h, &c) == LOAMX_OK;
     _h = loamx_scanreg_create(&c);
     return _h != nullptr;
   }
@@ -284,6 +291,8 @@ class BasicLaserOdometry {
     _cfg.max_iterations = (int)maxIterations;
   }
   ~BasicLaserOdometry() { loamx_odom_destroy(_h); }
+  BasicLaserOdometry(const BasicLaserOdometry&) = delete;                    // the object owns a device handle
+  BasicLaserOdometry& operator=(const BasicLaserOdometry&) = delete;
   void setScanPeriod(float v) { _cfg.scan_period = v; reset_handle(); }
   void setMaxIterations(size_t v) { _cfg.max_iterations = (int)v; reset_handle(); }
   void setDeltaTAbort(float v) { _cfg.delta_t_abort = v; reset_handle(); }
@@ -352,6 +361,8 @@ class BasicLaserMapping {
     _cfg.max_iterations = (int)maxIterations;
   }
   ~BasicLaserMapping() { loamx_map_destroy(_h); }
+  BasicLaserMapping(const BasicLaserMapping&) = delete;                      // the object owns a device handle
+  BasicLaserMapping& operator=(const BasicLaserMapping&) = delete;
 #ifdef LOAMX_REFERENCE_TYPES
   // the reference's own signatures (BasicLaserMapping.h:85-86)
   void updateIMU(IMUState2 const& newState) { updateIMU(detail::seconds(newState.stamp), newState.roll.rad(), newState.pitch.rad()); }

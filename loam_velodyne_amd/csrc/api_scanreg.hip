@@ -1,5 +1,6 @@
 // C-ABI: feature extraction (loamx_scanreg_*) — shim over loamx::FeatureExtractor.
 #include "features.cuh"
+#include <algorithm>
 #include <string>
 
 using namespace loamx;
@@ -21,6 +22,32 @@ void loamx_scanreg_default_config(loamx_scanreg_config* cfg) {
   cfg->less_flat_filter_size = 0.2f;
   cfg->surface_curvature_threshold = 0.1f;
   cfg->device = 0;
+  cfg->max_corner_less_sharp = 20;
+  cfg->imu_history_size = 200;
+}
+
+// validation as in the reference's parameter parsing (ScanRegistration.cpp:49-138), then RegistrationParams -> FeatParams
+static void apply_scanreg_config(FeatureExtractor& fx, const loamx_scanreg_config& c) {
+  LX_REQUIRE(c.scan_period > 0.f, "scan_period must be positive");
+  LX_REQUIRE(c.n_feature_regions >= 1, "n_feature_regions must be >= 1");
+  LX_REQUIRE(c.curvature_region >= 1, "curvature_region must be >= 1");
+  LX_REQUIRE(c.max_corner_sharp >= 1, "max_corner_sharp must be >= 1");
+  LX_REQUIRE(c.max_surface_flat >= 1, "max_surface_flat must be >= 1");
+  LX_REQUIRE(c.less_flat_filter_size >= 0.001f, "less_flat_filter_size must be >= 0.001");
+  LX_REQUIRE(c.surface_curvature_threshold >= 0.001f, "surface_curvature_threshold must be >= 0.001");
+  const int less_sharp = c.max_corner_less_sharp == 0 ? 10 * c.max_corner_sharp : c.max_corner_less_sharp;   // BasicScanRegistration.cpp:22
+  LX_REQUIRE(less_sharp >= c.max_corner_sharp, "max_corner_less_sharp must be >= max_corner_sharp");          // ScanRegistration.cpp:100-109
+  LX_REQUIRE(c.imu_history_size >= 1 && c.imu_history_size <= 4096, "imu_history_size must be in [1, 4096]");    // :59-66
+  FeatParams& p = fx.params;
+  p.scan_period = c.scan_period;
+  p.n_regions = c.n_feature_regions;
+  p.curv_region = c.curvature_region;
+  p.max_sharp = c.max_corner_sharp;
+  p.max_less_sharp = less_sharp;
+  p.max_flat = c.max_surface_flat;
+  p.less_flat_leaf = c.less_flat_filter_size;
+  p.curv_thr = c.surface_curvature_threshold;
+  fx.imu_history_size = std::max(fx.imu_history_size, std::max(200, c.imu_history_size));   // ensureCapacity only grows (CircularBuffer.h:53-70)
 }
 
 loamx_scanreg* loamx_scanreg_create(const loamx_scanreg_config* cfg) {
@@ -28,30 +55,23 @@ loamx_scanreg* loamx_scanreg_create(const loamx_scanreg_config* cfg) {
   guard([&]() {
     loamx_scanreg_config c;
     if (cfg) c = *cfg; else loamx_scanreg_default_config(&c);
-    // same validation as the reference's parameter parsing (ScanRegistration.cpp:49-138)
-    LX_REQUIRE(c.scan_period > 0.f, "scan_period must be positive");
-    LX_REQUIRE(c.n_feature_regions >= 1, "n_feature_regions must be >= 1");
-    LX_REQUIRE(c.curvature_region >= 1, "curvature_region must be >= 1");
-    LX_REQUIRE(c.max_corner_sharp >= 1, "max_corner_sharp must be >= 1");
-    LX_REQUIRE(c.max_surface_flat >= 1, "max_surface_flat must be >= 1");
-    LX_REQUIRE(c.less_flat_filter_size >= 0.001f, "less_flat_filter_size must be >= 0.001");
-    LX_REQUIRE(c.surface_curvature_threshold >= 0.001f, "surface_curvature_threshold must be >= 0.001");
     h = new loamx_scanreg(c.device);
-    FeatParams& p = h->fx.params;
-    p.scan_period = c.scan_period;
-    p.n_regions = c.n_feature_regions;
-    p.curv_region = c.curvature_region;
-    p.max_sharp = c.max_corner_sharp;
-    p.max_less_sharp = 10 * c.max_corner_sharp;   // RegistrationParams ctor, BasicScanRegistration.cpp:22
-    p.max_flat = c.max_surface_flat;
-    p.less_flat_leaf = c.less_flat_filter_size;
-    p.curv_thr = c.surface_curvature_threshold;
+    try { apply_scanreg_config(h->fx, c); } catch (...) { delete h; h = nullptr; throw; }
     return LOAMX_OK;
   });
   return h;
 }
 
 void loamx_scanreg_destroy(loamx_scanreg* h) { delete h; }
+
+int loamx_scanreg_configure(loamx_scanreg* h, const loamx_scanreg_config* cfg) {
+  return guard([&]() {
+    LX_REQUIRE(h && cfg, "NULL argument");
+    LX_REQUIRE(cfg->device == h->fx.device(), "configure() cannot move a handle to another device");
+    apply_scanreg_config(h->fx, *cfg);
+    return LOAMX_OK;
+  });
+}
 
 int loamx_scanreg_process(loamx_scanreg* h, const loamx_cloud* cloud, const uint32_t* ring_size, uint32_t n_rings,
                           loamx_cloud* sharp, loamx_cloud* less_sharp, loamx_cloud* flat, loamx_cloud* less_flat) {

@@ -25,6 +25,7 @@ class FeatureExtractor {
   ~FeatureExtractor();
   FeatParams params;
   hipStream_t stream() const { return st_; }
+  int device() const { return device_; }
 
   // stage nsw sweeps: cloud[s] = rings concatenated, ring_size[s][0..n_rings[s])
   void upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings);

@@ -185,7 +185,7 @@ class Pipeline {
       p.n_regions = fcfg.n_feature_regions;
       p.curv_region = fcfg.curvature_region;
       p.max_sharp = fcfg.max_corner_sharp;
-      p.max_less_sharp = 10 * fcfg.max_corner_sharp;
+      p.max_less_sharp = fcfg.max_corner_less_sharp == 0 ? 10 * fcfg.max_corner_sharp : fcfg.max_corner_less_sharp;
       p.max_flat = fcfg.max_surface_flat;
       p.less_flat_leaf = fcfg.less_flat_filter_size;
       p.curv_thr = fcfg.surface_curvature_threshold;
@@ -391,6 +391,7 @@ loamx_pipeline* loamx_pipeline_create(const loamx_scanreg_config* fcfg, const lo
     if (mcfg) m = *mcfg; else loamx_map_default_config(&m);
     LX_REQUIRE(n_streams >= 1 && n_streams <= 1024, "n_streams must be in [1, 1024]");
     LX_REQUIRE(f.device == m.device && o.device == m.device, "all three configurations must name the same device");
+    LX_REQUIRE(f.max_corner_less_sharp == 0 || f.max_corner_less_sharp >= f.max_corner_sharp, "max_corner_less_sharp must be >= max_corner_sharp");
     h = new loamx_pipeline(f, o, m, n_streams);
     return LOAMX_OK;
   });

@@ -23,7 +23,8 @@ class Cloud(C.Structure):
 class ScanRegConfig(C.Structure):
     _fields_ = [("scan_period", C.c_float), ("n_feature_regions", C.c_int), ("curvature_region", C.c_int),
                 ("max_corner_sharp", C.c_int), ("max_surface_flat", C.c_int), ("less_flat_filter_size", C.c_float),
-                ("surface_curvature_threshold", C.c_float), ("device", C.c_int)]
+                ("surface_curvature_threshold", C.c_float), ("device", C.c_int), ("max_corner_less_sharp", C.c_int),
+                ("imu_history_size", C.c_int)]
 
 
 class OdomConfig(C.Structure):
@@ -267,6 +268,13 @@ class ScanRegistration:
             self.h = None
 
     __del__ = close
+
+    def configure(self, **cfg):
+        """loamx_scanreg_configure: new parameters, the handle's IMU history and sweep state are kept"""
+        for k, v in cfg.items():
+            assert hasattr(self._c, k), k
+            setattr(self._c, k, v)
+        _check(lib().loamx_scanreg_configure(self.h, C.byref(self._c)))
 
     def process(self, points, ring_sizes, pcl_layout=False):
         pts = as_points(points)

@@ -56,13 +56,19 @@ int loamx_device_count(void) { return 0; }
 int loamx_abi_version(void) { return LOAMX_ABI_VERSION; }
 
 // ---- scan registration
-void loamx_scanreg_default_config(loamx_scanreg_config* c) { *c = loamx_scanreg_config{0.1f, 6, 5, 2, 4, 0.2f, 0.1f, 0}; }
-loamx_scanreg* loamx_scanreg_create(const loamx_scanreg_config* c) {
-  auto* h = new loamx_scanreg();
+void loamx_scanreg_default_config(loamx_scanreg_config* c) { *c = loamx_scanreg_config{0.1f, 6, 5, 2, 4, 0.2f, 0.1f, 0, 20, 200}; }
+int loamx_scanreg_configure(loamx_scanreg* h, const loamx_scanreg_config* c) {
   auto& k = h->s.cfg;
   k.scanPeriod = c->scan_period; k.nFeatureRegions = c->n_feature_regions; k.curvatureRegion = c->curvature_region;
-  k.maxCornerSharp = c->max_corner_sharp; k.maxCornerLessSharp = 10 * c->max_corner_sharp; k.maxSurfaceFlat = c->max_surface_flat;
+  k.maxCornerSharp = c->max_corner_sharp; k.maxSurfaceFlat = c->max_surface_flat;
+  k.maxCornerLessSharp = c->max_corner_less_sharp ? c->max_corner_less_sharp : 10 * c->max_corner_sharp;
+  k.imuHistorySize = c->imu_history_size;
   k.lessFlatFilterSize = c->less_flat_filter_size; k.surfaceCurvatureThreshold = c->surface_curvature_threshold;
+  return LOAMX_OK;
+}
+loamx_scanreg* loamx_scanreg_create(const loamx_scanreg_config* c) {
+  auto* h = new loamx_scanreg();
+  loamx_scanreg_configure(h, c);
   return h;
 }
 void loamx_scanreg_destroy(loamx_scanreg* h) { delete h; }

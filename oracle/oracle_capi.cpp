@@ -71,6 +71,12 @@ void orc_scanreg_config(void* h, float scanPeriod, int nFeatureRegions, int curv
   c.maxCornerSharp = maxCornerSharp; c.maxCornerLessSharp = 10 * maxCornerSharp; c.maxSurfaceFlat = maxSurfaceFlat;
   c.lessFlatFilterSize = lessFlatFilterSize; c.surfaceCurvatureThreshold = surfaceCurvatureThreshold;
 }
+// maxCornerLessSharp on its own (ScanRegistration.cpp:100-109); imuHistorySize (:59-66) — the history never shrinks below 200
+void orc_scanreg_config2(void* h, int maxCornerLessSharp, int imuHistorySize) {
+  auto* s = (ScanRegistration*)h;
+  s->cfg.maxCornerLessSharp = maxCornerLessSharp;
+  s->cfg.imuHistorySize = imuHistorySize;
+}
 // pts: all rings concatenated; ring_sizes[n_rings]
 void orc_scanreg_process(void* h, const float* pts, const int* ring_sizes, int n_rings) {
   std::vector<Cloud> rings(n_rings);

@@ -168,6 +168,7 @@ class ScanRegistration:
         orc.L.orc_scanreg_config(self.h, C.c_float(c["scanPeriod"]), c["nFeatureRegions"], c["curvatureRegion"],
                                  c["maxCornerSharp"], c["maxSurfaceFlat"], C.c_float(c["lessFlatFilterSize"]),
                                  C.c_float(c["surfaceCurvatureThreshold"]))
+        orc.L.orc_scanreg_config2(self.h, int(c.get("maxCornerLessSharp", 10 * c["maxCornerSharp"])), int(c.get("imuHistorySize", 200)))
 
     def __del__(self):
         self.o.L.orc_scanreg_destroy(self.h)
@@ -390,6 +391,8 @@ class RefScanRegistration:
         self.h = C.c_void_p(self._L.ref_sr_create(C.c_float(c["scanPeriod"]), c["imuHistorySize"], c["nFeatureRegions"], c["curvatureRegion"],
                                                   c["maxCornerSharp"], c["maxSurfaceFlat"], C.c_float(c["lessFlatFilterSize"]),
                                                   C.c_float(c["surfaceCurvatureThreshold"])))
+        if "maxCornerLessSharp" in c:      # parsed on its own by the node (ScanRegistration.cpp:100-109)
+            self._L.ref_sr_set_less_sharp(self.h, int(c["maxCornerLessSharp"]))
 
     def __del__(self):
         if getattr(self, "h", None):

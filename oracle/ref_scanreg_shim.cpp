@@ -23,6 +23,14 @@ void* ref_sr_create(float scanPeriod, int imuHistorySize, int nFeatureRegions, i
   return h;
 }
 void ref_sr_destroy(void* h) { delete (BasicScanRegistration*)h; }
+// what ScanRegistration::parseParams does for the "maxCornerLessSharp" parameter (ScanRegistration.cpp:100-109): the member is set
+// on its own and the object re-configured
+void ref_sr_set_less_sharp(void* h, int maxCornerLessSharp) {
+  auto* r = (BasicScanRegistration*)h;
+  RegistrationParams p = r->config();
+  p.maxCornerLessSharp = maxCornerLessSharp;
+  r->configure(p);
+}
 
 // updateIMUData(acc, newState)
 void ref_sr_update_imu(void* h, double stamp, float roll, float pitch, float yaw, float ax, float ay, float az) {

@@ -53,6 +53,20 @@ def test_nondefault_parameters(orc, small_world):
     _same(op.ScanRegistration(orc, **cfg).process(sw.points, sw.ring_sizes), g.process(sw.points, sw.ring_sizes))
 
 
+def test_max_corner_less_sharp_and_reconfigure(orc, small_world):
+    """RegistrationParams::maxCornerLessSharp is parsed on its own (ScanRegistration.cpp:100-109) and configure() on an existing
+    object keeps its state (BasicScanRegistration.cpp:49-53)"""
+    sw = synth.make_sweep(small_world, "VLP-16", np.zeros(6), np.zeros(6), seed=8, az_steps=900)
+    g = loamx.ScanRegistration(max_corner_sharp=3, max_corner_less_sharp=7)
+    _same(op.ScanRegistration(orc, maxCornerSharp=3, maxCornerLessSharp=7).process(sw.points, sw.ring_sizes), g.process(sw.points, sw.ring_sizes))
+    g.configure(max_corner_sharp=2, max_corner_less_sharp=0)           # 0 = 10 x max_corner_sharp, the constructor's rule (.cpp:22)
+    _same(op.ScanRegistration(orc).process(sw.points, sw.ring_sizes), g.process(sw.points, sw.ring_sizes))
+    with pytest.raises(loamx.LoamxError):                              # less-sharp limit below the sharp limit
+        loamx.ScanRegistration(max_corner_sharp=4, max_corner_less_sharp=3)
+    with pytest.raises(loamx.LoamxError):
+        loamx.ScanRegistration(imu_history_size=0)
+
+
 def test_pcl_layout_io(small_world):
     """32-byte pcl::PointXYZI records in and out give the same points as packed float4."""
     sw = synth.make_sweep(small_world, "VLP-16", np.zeros(6), np.zeros(6), seed=6, az_steps=600)

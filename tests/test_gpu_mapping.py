@@ -16,17 +16,28 @@ from loam_velodyne_amd import loamx, synth
 pytestmark = pytest.mark.gpu
 
 
-def _nn_set_distance(a, b):
-    """max over points of a of the distance to the nearest point of b (small clouds)."""
+def _assert_same_point_set(a, b, what, tol=2e-5, max_flips=4):
+    """Map insertion + per-cube voxel re-filtering from identical state is index work: the two clouds must hold the same
+    points (any order) within float rounding of the registered pose (<= 2e-5 m), up to a bounded number of voxel-boundary
+    flips (a point within 1e-6 of a 0.2 / 0.4 m voxel face may fall on the other side and change two centroids)."""
     from scipy.spatial import cKDTree
-    return float(cKDTree(b[:, :3]).query(a[:, :3])[0].max())
+    assert abs(len(a) - len(b)) <= max_flips, (what, len(a), len(b))
+    if len(a) == 0 or len(b) == 0:
+        return 0.0
+    ta, tb = cKDTree(a[:, :3]), cKDTree(b[:, :3])
+    dab, iab = tb.query(a[:, :3])
+    dba, _ = ta.query(b[:, :3])
+    assert int((dab > tol).sum()) <= max_flips and int((dba > tol).sum()) <= max_flips, (what, int((dab > tol).sum()), int((dba > tol).sum()))
+    ok = dab <= tol
+    assert np.abs(a[ok, 3] - b[iab[ok], 3]).max() < 1e-3, what       # the averaged intensity travels with the point
+    return float(dab[ok].max())
 
 
 def test_per_step_parity_from_identical_state(orc, small_world):
     n = 7
     poses = synth.trajectory(n)
     osr, ood, omp = op.ScanRegistration(orc), op.LaserOdometry(orc), op.LaserMapping(orc)
-    worst = 0.0
+    worst, worst_map, n_surround = 0.0, 0.0, 0
     for k in range(n):
         sw = synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=k, az_steps=1200)
         ood.set_features(osr.process(sw.points, sw.ring_sizes))
@@ -52,13 +63,17 @@ def test_per_step_parity_from_identical_state(orc, small_world):
         assert so["corner_from_map"] == sg["corner_from_map"] and so["surf_from_map"] == sg["surf_from_map"]
         assert so["corner_ds"] == sg["corner_ds"] and so["surf_ds"] == sg["surf_ds"] or k == 0
         assert np.abs(omp.cloud("full_res") - gfull).max() < 1e-3
-        # map contents after insertion + per-cube voxel re-filtering: same point sets up to voxel-boundary flips
+        # map contents after insertion (BasicLaserMapping.cpp:536-577) + per-cube voxel re-filtering (:580-593): the same point
+        # sets, point for point
         for name, which in (("corner_cubes", "corner"), ("surf_cubes", "surf")):
-            oc, gc = omp.cloud(name), g.cubes(which)
-            assert abs(len(oc) - len(gc)) <= max(2, len(oc) // 2000), (k, name, len(oc), len(gc))
-            if len(oc):
-                assert _nn_set_distance(gc, oc) < 0.45
-    assert worst < POSE_TOL
+            worst_map = max(worst_map, _assert_same_point_set(g.cubes(which), omp.cloud(name), (k, name)))
+        # createDownsizedMap (:242-264): the oracle publishes every fifth frame, a fresh handle on its first
+        if omp.has_fresh_map():
+            assert g.has_fresh_map()
+            n_surround += 1
+            worst_map = max(worst_map, _assert_same_point_set(g.surround(), omp.cloud("surround_ds"), (k, "surround_ds")))
+    assert worst < POSE_TOL and n_surround >= 2
+    print(f"worst pose difference {worst:.2e}, worst matched map-point distance {worst_map:.2e} over {n} steps")
 
 
 def test_golden_steps(orc):

@@ -84,7 +84,9 @@ needs_sr = pytest.mark.skipif(not op.RefScanRegistration.available(), reason="or
 @needs_sr
 @pytest.mark.parametrize("sensor,az,cfg", [("VLP-16", 900, {}), ("HDL-32", 700, {}), ("HDL-64E", 512, {}),
                                            ("VLP-16", 600, dict(nFeatureRegions=4, curvatureRegion=3, maxCornerSharp=3, maxSurfaceFlat=2,
-                                                                surfaceCurvatureThreshold=0.2))])
+                                                                surfaceCurvatureThreshold=0.2)),
+                                           ("VLP-16", 600, dict(maxCornerSharp=3, maxCornerLessSharp=7)),      # parsed on its own, ScanRegistration.cpp:100-109
+                                           ("HDL-32", 500, dict(maxCornerSharp=1, maxCornerLessSharp=40))])
 def test_feature_extraction_equals_the_reference(orc, small_world, sensor, az, cfg):
     """processScanlines / extractFeatures (BasicScanRegistration.cpp:28-46, :155-386) run by the reference's own code: sharp,
     less-sharp and flat picks identical point for point; the less-flat cloud identical too (its candidate set is the

@@ -199,6 +199,11 @@ int loamx_map_get_surround(loamx_map* h, loamx_cloud* out);
 int loamx_map_load_cubes(loamx_map* h, const loamx_cloud* corner, const loamx_cloud* surf);
 /* dump the whole map: which 0 = corner cubes, 1 = surf cubes */
 int loamx_map_get_cubes(loamx_map* h, int which, loamx_cloud* out);
+/* Map snapshot on disk (checkpointing a map, e.g. as the frozen map of the batched mode): the rolling map
+ * of both feature types in storage order, the cube window, the frame counters and the five transforms.  A handle restored with
+ * load continues bit for bit like the one that saved (same map filter sizes required).  File layout: mapping.hip, SnapshotHeader. */
+int loamx_map_save_snapshot(loamx_map* h, const char* path);
+int loamx_map_load_snapshot(loamx_map* h, const char* path);
 /* diagnostics of the last process(): iterations, rows selected, corner queries, surf queries, corner sub-map size,
  * surf sub-map size, degenerate flag, optimised flag */
 int loamx_map_get_stats(loamx_map* h, int stats[8]);

@@ -9,6 +9,7 @@
 #include <vector>
 #include <stdexcept>
 #include "../../include/loamx.h"
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 namespace loamx {
 
@@ -120,6 +121,15 @@ inline int unpack_cloud(const float4* src, uint32_t n, loamx_cloud* c) {
 }
 
 void select_device(int device);   // throws LOAMX_E_NOGPU
+
+// roctx range around a host-side stage (tracing): shows up in `rocprofv3 --marker-trace` next to the kernels the
+// stage enqueues; costs two calls into an unloaded tool library otherwise
+struct TraceRange {
+  explicit TraceRange(const char* name) { roctxRangePush(name); }
+  ~TraceRange() { roctxRangePop(); }
+  TraceRange(const TraceRange&) = delete;
+  TraceRange& operator=(const TraceRange&) = delete;
+};
 
 // HIP stream with a relative priority: +1 = highest the device offers, 0 = default, -1 = lowest.  The stages of the
 // pipeline run on streams of their own; the latency-critical ones (registration, odometry) outrank feature extraction,

@@ -706,6 +706,7 @@ int FeatureExtractor::download_cloud(uint32_t sweep, loamx_cloud* full, uint32_t
 }
 
 void FeatureExtractor::run_async() {
+  TraceRange trace_range("loamx:features:extract");
   LX_REQUIRE(nsw_ > 0, "run() before upload()");
   LX_HIP(hipSetDevice(device_));
   const int cr = params.curv_region;

@@ -11,6 +11,7 @@
 //   k_map_append / k_map_hist                   next map = rest ++ filtered; per-cube counts for the host directory
 // Host: closed-form pose prediction (:103-167), cube window + field-of-view selection (:300-500), transformUpdate.
 #include "registration.cuh"
+#include <algorithm>
 #include <deque>
 #include "host_math.h"
 #include "scan.cuh"
@@ -259,6 +260,8 @@ class Mapper {
   void load_cubes(const loamx_cloud* corner, const loamx_cloud* surf);
   int get_cubes(int which, loamx_cloud* out);
   int get_surround(loamx_cloud* out);
+  void save_snapshot(const char* path);
+  void load_snapshot(const char* path);
 
  private:
   void shift_counts(int axis, int dir);
@@ -322,6 +325,7 @@ void Mapper::ensure(TypeMap& t, uint32_t n_map_max, uint32_t n_in) {
 }
 
 int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res) {
+  TraceRange trace_range("loamx:mapping:process");
   check_cloud(corner_last, false);
   check_cloud(surf_last, false);
   if (full_res) check_cloud(full_res, false);
@@ -576,6 +580,86 @@ int Mapper::get_cubes(int which, loamx_cloud* out) {
   return unpack_cloud(tmp.data(), T.n, out);
 }
 
+// ---- map snapshot on disk: the rolling map (both feature types, in storage order — the order that
+// fixes the sub-map order of BasicLaserMapping.cpp:503-509), the cube window, the frame counters (:269-274, :245-249) and the
+// five transforms.  A handle restored from a snapshot continues bit for bit like the one that wrote it.
+// File: "LOAMXMAP" | u32 version = 1 | i32 cen[3] | i64 frame_count, map_frame_count | f32 leaf corner, surf |
+//       f32[6] x 5 (sum, incre, tobe, bef, aft) | u32 n_corner, n_surf | float4 corner[n_corner] | float4 surf[n_surf]
+namespace {
+struct SnapshotHeader {
+  char magic[8];
+  uint32_t version;
+  int32_t cen[3];
+  int64_t frame_count, map_frame_count;
+  float corner_leaf, surf_leaf;
+  float transforms[5][6];
+  uint32_t n[2];
+};
+}  // namespace
+
+void Mapper::save_snapshot(const char* path) {
+  LX_REQUIRE(path && *path, "NULL path");
+  LX_HIP(hipSetDevice(cfg.device));
+  LX_HIP(hipStreamSynchronize(reg.stream()));
+  SnapshotHeader h;
+  memcpy(h.magic, "LOAMXMAP", 8);
+  h.version = 1;
+  for (int k = 0; k < 3; k++) h.cen[k] = cen[k];
+  h.frame_count = frame_count;
+  h.map_frame_count = map_frame_count;
+  h.corner_leaf = cfg.corner_filter_size;
+  h.surf_leaf = cfg.surf_filter_size;
+  const HTwist* tw[5] = {&sum, &incre, &tobe, &bef, &aft};
+  for (int k = 0; k < 5; k++) tw[k]->get(h.transforms[k]);
+  for (int t = 0; t < 2; t++) h.n[t] = tm[t].n;
+  FILE* f = fopen(path, "wb");
+  if (!f) throw Error(LOAMX_E_INVALID, std::string("cannot open ") + path + " for writing");
+  bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+  for (int t = 0; t < 2 && ok; t++) {
+    std::vector<float4> tmp(tm[t].n);
+    if (tm[t].n) LX_HIP(hipMemcpy(tmp.data(), tm[t].pts[tm[t].cur].p, sizeof(float4) * tm[t].n, hipMemcpyDeviceToHost));
+    ok = tm[t].n == 0 || fwrite(tmp.data(), sizeof(float4), tm[t].n, f) == tm[t].n;
+  }
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) throw Error(LOAMX_E_INVALID, std::string("short write to ") + path);
+}
+
+void Mapper::load_snapshot(const char* path) {
+  LX_REQUIRE(path && *path, "NULL path");
+  FILE* f = fopen(path, "rb");
+  if (!f) throw Error(LOAMX_E_INVALID, std::string("cannot open ") + path);
+  SnapshotHeader h;
+  std::vector<float4> pts[2];
+  bool ok = fread(&h, sizeof(h), 1, f) == 1 && memcmp(h.magic, "LOAMXMAP", 8) == 0 && h.version == 1;
+  for (int t = 0; t < 2 && ok; t++) {
+    ok = h.n[t] < (1u << 30);
+    if (!ok) break;
+    pts[t].resize(h.n[t]);
+    ok = h.n[t] == 0 || fread(pts[t].data(), sizeof(float4), h.n[t], f) == h.n[t];
+  }
+  fclose(f);
+  if (!ok) throw Error(LOAMX_E_INVALID, std::string(path) + " is not a loamx map snapshot (version 1) or is truncated");
+  LX_REQUIRE(h.corner_leaf == cfg.corner_filter_size && h.surf_leaf == cfg.surf_filter_size,
+             "the snapshot was written with other map filter sizes than this handle's");
+  LX_HIP(hipSetDevice(cfg.device));
+  LX_HIP(hipStreamSynchronize(reg.stream()));
+  for (int k = 0; k < 3; k++) cen[k] = h.cen[k];
+  frame_count = (long)h.frame_count;
+  map_frame_count = (long)h.map_frame_count;
+  HTwist* tw[5] = {&sum, &incre, &tobe, &bef, &aft};
+  for (int k = 0; k < 5; k++) tw[k]->set(h.transforms[k]);
+  fresh_map = false;
+  n_surround = 0;
+  for (int t = 0; t < 2; t++) {
+    tm[t].n = 0;
+    std::fill(tm[t].cube_cnt.begin(), tm[t].cube_cnt.end(), 0u);
+  }
+  loamx_cloud c[2];
+  for (int t = 0; t < 2; t++) c[t] = loamx_cloud{pts[t].data(), (uint32_t)pts[t].size(), 16, 12, 0};
+  load_cubes(&c[0], &c[1]);   // by coordinate, against the restored window; storage order kept
+  LX_REQUIRE(tm[0].n == h.n[0] && tm[1].n == h.n[1], "snapshot points fall outside the cube window stored with them");
+}
+
 int Mapper::get_surround(loamx_cloud* out) {
   check_cloud(out, false);
   LX_HIP(hipSetDevice(cfg.device));
@@ -663,6 +747,12 @@ int loamx_map_load_cubes(loamx_map* h, const loamx_cloud* corner, const loamx_cl
 }
 int loamx_map_get_cubes(loamx_map* h, int which, loamx_cloud* out) {
   return guard([&]() { LX_REQUIRE(h && out, "NULL argument"); return h->m.get_cubes(which, out); });
+}
+int loamx_map_save_snapshot(loamx_map* h, const char* path) {
+  return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->m.save_snapshot(path); return LOAMX_OK; });
+}
+int loamx_map_load_snapshot(loamx_map* h, const char* path) {
+  return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->m.load_snapshot(path); return LOAMX_OK; });
 }
 int loamx_map_get_stats(loamx_map* h, int s[8]) {
   return guard([&]() {

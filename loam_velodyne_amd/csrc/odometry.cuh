@@ -116,6 +116,7 @@ class OdometryBatch {
   PinBuf<uint32_t> h_off_pin_;
   PinBuf<float4> h_stage_;
   DevBuf<float4> up_[4], tmp_cloud_;
+  uint32_t lm_slots_[2] = {0, 0};   // workgroups of k_odom_lm<1> / <2> the device holds at once (occupancy x CUs)
   hipEvent_t ev_tail_ = nullptr, ev_pose_ = nullptr;
   bool tail_pending_ = false;
   PinBuf<char> h_gather_;

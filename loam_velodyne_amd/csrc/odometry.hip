@@ -252,8 +252,9 @@ __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ pro
 // nine can).  Per iteration every workgroup reduces its rows to 28 double sums, publishes them (double-buffered by
 // iteration parity) and counts itself in on the stream's arrival counter; once all NB have arrived EVERY workgroup adds
 // the NB partial sums in workgroup order and solves — the same deterministic arithmetic everywhere, so all of them hold
-// the same new pose without a second exchange.  Workgroup 0 records the results.  NB x streams <= 16 x 64 workgroups
-// are all resident, so the spin cannot deadlock.
+// the same new pose without a second exchange.  Workgroup 0 records the results.  The spin needs every workgroup of the
+// launch resident: the host cuts a batch into launches of at most half the device's occupancy-derived capacity
+// (OdometryBatch::process).
 #ifdef LOAMX_PROF_LM
 #define LM_TS(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && iter == iter0 + 1) pb.part[32 * LX_NSUM + (k)] = (double)wall_clock64(); } while (0)
 #else
@@ -659,6 +660,7 @@ void OdometryBatch::to_end_device(uint32_t s, float4* pts, uint32_t n) {
 }
 
 void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
+  TraceRange trace_range("loamx:odometry");
   LX_HIP(hipSetDevice(device_));
   const uint32_t ns = n_streams(), K = 2 * ns;
   if (tail_pending_) {   // the previous call's re-projection / index build still reads the pinned staging buffers
@@ -763,10 +765,24 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
         const int nit = std::min(5, params.max_iterations - it0);
         hipLaunchKernelGGL(k_odom_corr, dim3(8 * (((max_sharp + 7) / 8 + (max_flat + 7) / 8 + 3) / 4), na), dim3(256), 0, st_, prob_.p, params);
         const uint32_t nb = std::min<uint32_t>(16u, (max_feat + OD_THREADS - 1) / OD_THREADS);
-        if (max_feat <= nb * OD_THREADS)
-          hipLaunchKernelGGL(k_odom_lm<1>, dim3(nb, na), dim3(OD_THREADS), 0, st_, prob_.p, params, it0, nit);
-        else
-          hipLaunchKernelGGL(k_odom_lm<2>, dim3(nb, na), dim3(OD_THREADS), 0, st_, prob_.p, params, it0, nit);
+        // k_odom_lm's workgroups of one stream spin on each other: everything a launch puts on the device must be resident
+        // at once.  The launch is cut into chunks of streams that fill at most half of what the device can hold (occupancy x
+        // CUs, queried once) — the registration and feature kernels of the other HIP streams share the CUs.
+        const bool two = max_feat > nb * OD_THREADS;
+        if (!lm_slots_[two]) {
+          int per_cu = 0;
+          if (two) LX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_odom_lm<2>, OD_THREADS, 0));
+          else LX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_odom_lm<1>, OD_THREADS, 0));
+          hipDeviceProp_t prop;
+          LX_HIP(hipGetDeviceProperties(&prop, device_));
+          lm_slots_[two] = (uint32_t)std::max(per_cu, 1) * (uint32_t)std::max(prop.multiProcessorCount, 1);
+        }
+        const uint32_t chunk = std::max<uint32_t>(1u, (lm_slots_[two] / 2) / nb);
+        for (uint32_t a0 = 0; a0 < na; a0 += chunk) {
+          const uint32_t nc = std::min(chunk, na - a0);
+          if (two) hipLaunchKernelGGL(k_odom_lm<2>, dim3(nb, nc), dim3(OD_THREADS), 0, st_, prob_.p + a0, params, it0, nit);
+          else hipLaunchKernelGGL(k_odom_lm<1>, dim3(nb, nc), dim3(OD_THREADS), 0, st_, prob_.p + a0, params, it0, nit);
+        }
       }
     }
     if (!max_feat) LX_HIP(hipMemcpyAsync(h_mirror_.p, prob_.p, sizeof(OdomProblem) * na, hipMemcpyDeviceToHost, st_));   // (no launch wrote the mirror)

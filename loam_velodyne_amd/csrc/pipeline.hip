@@ -155,6 +155,7 @@ class Pipeline {
   }
 
   void launch_features(uint32_t t) {
+    TraceRange trace_range("loamx:features");
     FeatureExtractor& F = *fx[t];
     const uint32_t ns = n_streams_, nring = F.total_rings();
     PinBuf<uint32_t>& hb = h_off3[t % 3];
@@ -250,6 +251,7 @@ class Pipeline {
   double trO[4] = {0, 0, 0, 0};
 
   int step(uint32_t t) {
+    TraceRange trace_range("loamx:pipeline:step");
     LX_REQUIRE(t < fx.size(), "step index beyond the staged sweeps");
     tr0 = std::chrono::steady_clock::now();
     double trM[6] = {0, 0, 0, 0, 0, 0};

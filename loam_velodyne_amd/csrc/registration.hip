@@ -1248,6 +1248,7 @@ static double host_us() {
 // many iterations as the previous call needed, looks at the flags (mirrored into pinned memory by the update step), and
 // stops launching once every sweep is done.
 void Registrar::run_iterations(bool trace, double& th2, double& th3) {
+  TraceRange trace_range("loamx:registration:gauss-newton");
   const uint32_t ns = n_sweeps_;
   struct ProfDump { std::function<void()> f; ~ProfDump() { if (f) f(); } } prof_dump;
   GnArgs a;
@@ -1318,6 +1319,7 @@ void Registrar::run_iterations(bool trace, double& th2, double& th3) {
 
 void Registrar::run_async() {
   LX_REQUIRE(n_sweeps_ > 0, "run() before upload()");
+  TraceRange trace_range("loamx:registration");
   static const bool trace = getenv("LOAMX_REG_TRACE") != nullptr;
   const double th0 = trace ? host_us() : 0.0;
   double th1 = 0, th2 = 0, th3 = 0;

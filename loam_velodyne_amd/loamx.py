@@ -457,6 +457,12 @@ class LaserMapping:
             _check(rc)
             return out[:c.count].copy()
 
+    def save_snapshot(self, path: str):
+        _check(lib().loamx_map_save_snapshot(self.h, path.encode()))
+
+    def load_snapshot(self, path: str):
+        _check(lib().loamx_map_load_snapshot(self.h, path.encode()))
+
     def surround(self):
         return self._get(lib().loamx_map_get_surround)
 

@@ -193,3 +193,44 @@ def test_imu_blend_in_transform_update(orc, small_world):
             roll_i = (blended[2] - 0.998 * plain[2]) / 0.002
             assert abs(pitch_i) < 0.035 and abs(roll_i) < 0.035 and abs(blended[0] - plain[0]) > 1e-7
             assert np.abs(blended[[1, 3, 4, 5]] - plain[[1, 3, 4, 5]]).max() < 1e-6
+
+
+def test_snapshot_restore_continues_bit_for_bit(orc, small_world, tmp_path):
+    """a map snapshot on disk; the restored handle continues exactly like the one that wrote it"""
+    n = 7
+    poses = synth.trajectory(n)
+    osr, ood = op.ScanRegistration(orc), op.LaserOdometry(orc)
+    g = loamx.LaserMapping()
+    steps = []
+    for k in range(n):
+        sw = synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=k, az_steps=900)
+        ood.set_features(osr.process(sw.points, sw.ring_sizes))
+        ood.process()
+        steps.append((ood.last_corner(), ood.last_surf(), ood.full_to_end(), ood.transform_sum))
+    path = str(tmp_path / "map.loamx")
+    for k in range(4):
+        g.update_odometry(steps[k][3])
+        g.process(*steps[k][:3])
+    g.save_snapshot(path)
+    assert os.path.getsize(path) > 16 * (len(g.cubes("corner")) + len(g.cubes("surf")))
+    r = loamx.LaserMapping()
+    r.load_snapshot(path)
+    for which in ("corner", "surf"):
+        assert np.array_equal(g.cubes(which), r.cubes(which))
+    for k in range(4, n):
+        outs = []
+        for h in (g, r):
+            h.update_odometry(steps[k][3])
+            rc, full = h.process(*steps[k][:3])
+            outs.append((rc, full, h.transform("aft"), h.transform("bef"), h.has_fresh_map(), h.cubes("corner"), h.cubes("surf"),
+                         h.surround() if h.has_fresh_map() else None))
+        a, b = outs
+        assert a[0] == b[0] and a[4] == b[4]
+        for i in (1, 2, 3, 5, 6):
+            assert np.array_equal(a[i], b[i]), (k, i)
+        if a[4]:
+            assert np.array_equal(a[7], b[7])
+    with pytest.raises(loamx.LoamxError):
+        loamx.LaserMapping(corner_filter_size=0.3).load_snapshot(path)          # other map filter sizes
+    with pytest.raises(loamx.LoamxError):
+        r.load_snapshot(str(tmp_path / "missing.loamx"))

@@ -320,6 +320,36 @@ int loamx_pipeline_set_timing(loamx_pipeline* h, int on);
 int loamx_pipeline_get_timing(loamx_pipeline* h, float stage_ms[4], float reg_ms[4], uint64_t counts[4]);
 void* loamx_pipeline_stream(loamx_pipeline* h);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, RCCL over xGMI.  The batched mode shards by independent sweeps — rank r of G
+ * registers sweeps [r*B/G, (r+1)*B/G) against a replica of the frozen map — so the data path has no collective.  The two
+ * exchanges are (1) the map epoch: ncclBroadcast of the two sub-map buffers, asynchronous, returning an event that
+ * loamx_{batch,pipeline}_stage_frozen_device takes as wait_event (the index build of epoch k+1 is ordered behind the broadcast
+ * on the device while epoch k's registrations run: double buffering), and (2) the results: ncclAllGather of
+ * n_local x (6 pose floats + iterations + flags) per rank.  The 128-byte id from loamx_dist_get_unique_id (rank 0) reaches the
+ * other processes by the host's own means (loam_velodyne_amd/launch.py uses a file).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct loamx_dist loamx_dist;
+#define LOAMX_DIST_ID_BYTES 128
+int loamx_dist_get_unique_id(unsigned char id[LOAMX_DIST_ID_BYTES]);
+loamx_dist* loamx_dist_create(const unsigned char id[LOAMX_DIST_ID_BYTES], int rank, int world_size, int device);
+void loamx_dist_destroy(loamx_dist* h);
+int loamx_dist_rank(const loamx_dist* h);
+int loamx_dist_world_size(const loamx_dist* h);
+/* this rank's contiguous share [begin, end) of a batch of `batch` sweeps */
+int loamx_dist_shard(const loamx_dist* h, uint32_t batch, uint32_t* begin, uint32_t* end);
+/* device buffers of packed float4 (x,y,z,intensity), the same sizes on every rank; in place (root's content reaches all).
+ * wait_event (may be NULL): hipEvent_t behind whatever fills the root's buffers; *done_event (may be NULL) receives a hipEvent_t
+ * owned by the handle, recorded behind the broadcast — valid until the next broadcast on this handle. */
+int loamx_dist_broadcast_map(loamx_dist* h, void* d_corner_xyzi, uint32_t n_corner, void* d_surf_xyzi, uint32_t n_surf, int root,
+                             void* wait_event, void** done_event);
+/* every rank contributes n_local records (poses6[n_local][6], iters_flags2[n_local][2], the latter may be NULL) and receives all
+ * world_size * n_local of them in rank order; blocking */
+int loamx_dist_allgather_results(loamx_dist* h, const float* poses6, const int* iters_flags2, uint32_t n_local, float* poses6_all,
+                                 int* iters_flags2_all);
+int loamx_dist_barrier(loamx_dist* h);
+void* loamx_dist_stream(loamx_dist* h);   /* hipStream_t of the collectives */
+
 #ifdef __cplusplus
 }
 #endif

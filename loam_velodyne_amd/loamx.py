@@ -586,3 +586,61 @@ class Pipeline:
     @property
     def stream(self) -> int:
         return int(lib().loamx_pipeline_stream(self.h) or 0)
+
+
+class Dist:
+    """loamx_dist_*: the multi-GPU exchanges of the batched mode over RCCL (one process per GPU)."""
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_ubyte * Dist.ID_BYTES)()
+        _check(lib().loamx_dist_get_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, unique_id: bytes, rank: int, world_size: int, device: int = 0):
+        assert len(unique_id) == self.ID_BYTES
+        L = lib()
+        L.loamx_dist_create.restype = C.c_void_p
+        L.loamx_dist_stream.restype = C.c_void_p
+        buf = (C.c_ubyte * self.ID_BYTES).from_buffer_copy(unique_id)
+        self.h = C.c_void_p(L.loamx_dist_create(buf, rank, world_size, device))
+        if not self.h:
+            raise LoamxError(E_INVALID, L.loamx_last_error().decode())
+        self.rank, self.world = rank, world_size
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().loamx_dist_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def shard(self, batch: int):
+        b, e = C.c_uint32(), C.c_uint32()
+        _check(lib().loamx_dist_shard(self.h, batch, C.byref(b), C.byref(e)))
+        return int(b.value), int(e.value)
+
+    def broadcast_map(self, d_corner_ptr: int, n_corner: int, d_surf_ptr: int, n_surf: int, root: int = 0, wait_event: int = 0) -> int:
+        """asynchronous; returns the raw hipEvent_t recorded behind the broadcast (for stage_frozen_device)"""
+        ev = C.c_void_p()
+        _check(lib().loamx_dist_broadcast_map(self.h, C.c_void_p(d_corner_ptr), n_corner, C.c_void_p(d_surf_ptr), n_surf, root,
+                                              C.c_void_p(wait_event or None), C.byref(ev)))
+        return int(ev.value or 0)
+
+    def allgather_results(self, poses6, iters_flags=None):
+        p = np.ascontiguousarray(poses6, np.float32).reshape(-1, 6)
+        n = len(p)
+        f = np.ascontiguousarray(iters_flags, np.int32).reshape(n, 2) if iters_flags is not None else None
+        pa = np.zeros((self.world * n, 6), np.float32)
+        fa = np.zeros((self.world * n, 2), np.int32)
+        _check(lib().loamx_dist_allgather_results(self.h, p.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p) if f is not None else None,
+                                                  n, pa.ctypes.data_as(C.c_void_p), fa.ctypes.data_as(C.c_void_p)))
+        return pa, fa
+
+    def barrier(self):
+        _check(lib().loamx_dist_barrier(self.h))
+
+    @property
+    def stream(self) -> int:
+        return int(lib().loamx_dist_stream(self.h) or 0)

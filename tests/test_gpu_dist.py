@@ -1,0 +1,37 @@
+"""GPU: loamx_dist_* (RCCL) — the two exchanges of the batched mode: map broadcast feeding the double-buffered
+index build through its event, and the all-gather of the results.  One rank on a one-GPU box; two ranks (one process per GPU,
+started by loam_velodyne_amd.launch) wherever two GPUs are visible."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from loam_velodyne_amd import launch, loamx
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
+
+
+def _run(nproc, tmp_path):
+    assert launch.main(["--nproc", str(nproc), WORKER, str(tmp_path), "gpu"]) == 0
+    return [np.load(tmp_path / f"rank{k}.npz") for k in range(nproc)]
+
+
+def test_one_rank(tmp_path):
+    (r,) = _run(1, tmp_path)
+    assert r["poses"].shape == (4, 6) and r["shard"].tolist() == [0, 4]
+    assert np.all(r["flags"][:, 0] >= 1) and np.all(r["flags"][:, 1] >= 50)          # iterations, rows selected
+    assert np.isfinite(r["poses"]).all()
+
+
+@pytest.mark.skipif(loamx.device_count() < 2, reason="needs two GPUs (one process per GPU)")
+def test_two_ranks_equal_one_rank(tmp_path):
+    (tmp_path / "one").mkdir()
+    (tmp_path / "two").mkdir()
+    one = _run(1, tmp_path / "one")[0]
+    two = _run(2, tmp_path / "two")
+    assert two[0]["shard"].tolist() == [0, 2] and two[1]["shard"].tolist() == [2, 4]
+    assert two[0]["map_sum"] == two[1]["map_sum"] == one["map_sum"]                  # the broadcast reached rank 1
+    for r in two:                                                                   # every rank holds all results, in batch order,
+        assert np.array_equal(r["poses"], one["poses"]) and np.array_equal(r["flags"], one["flags"])   # identical to the unsharded run

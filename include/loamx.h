@@ -301,6 +301,21 @@ int loamx_pipeline_set_state(loamx_pipeline* h, uint32_t stream, const float* tr
 /* stage n_steps sweeps per stream: sweep (t, s) = clouds[t * n_streams + s] (rings concatenated) */
 int loamx_pipeline_upload(loamx_pipeline* h, uint32_t n_steps, const loamx_cloud* clouds, const uint32_t* const* ring_size,
                           const uint32_t* n_rings);
+/* Streaming input (the PCIe-inclusive mode, SURVEY.md §8d "GPU timing"): instead of staging a whole run with
+ * loamx_pipeline_upload, hand over ONE step at a time, in order, without blocking — the copies go to a stream of their own
+ * (packed float4 clouds {stride 16, intensity at 12} straight from the caller's memory: pin it, e.g. hipHostRegister, and the
+ * transfer is a DMA that overlaps the kernels of the steps in flight; other layouts are repacked through pinned staging on
+ * the calling thread).  Up to four steps are in flight: stage_step(t) may be called once step(t - 4) has returned; the
+ * buffers of step t are read until step(t) has returned. */
+int loamx_pipeline_stage_step(loamx_pipeline* h, uint32_t step, const loamx_cloud* clouds, const uint32_t* const* ring_size,
+                              const uint32_t* n_rings);
+/* Asynchronous output: after enable (before the first step), download_step_async — called after loamx_pipeline_step(t) —
+ * starts copying the registered full-resolution clouds of step t (out[k] = k-th stream that was registered; packed float4
+ * records; count in = capacity, out = points) on a copy stream and returns; the registration alternates between two device
+ * buffers so the next step does not wait for the copy.  wait_downloads blocks until every started copy has landed. */
+int loamx_pipeline_enable_async_downloads(loamx_pipeline* h);
+int loamx_pipeline_download_step_async(loamx_pipeline* h, loamx_cloud* out, uint32_t n_out);
+int loamx_pipeline_wait_downloads(loamx_pipeline* h);
 /* run staged step t for every stream.  LOAMX_SKIPPED when no stream reached the registration stage (first sweeps) */
 int loamx_pipeline_step(loamx_pipeline* h, uint32_t step);
 /* stats8: odometry iterations, odometry rows, mapping iterations, mapping rows, corner queries, surf queries,

@@ -29,6 +29,11 @@ class FeatureExtractor {
 
   // stage nsw sweeps: cloud[s] = rings concatenated, ring_size[s][0..n_rings[s])
   void upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings);
+  // the same without blocking: every copy goes to `copy_stream` (packed float4 clouds straight from the caller's memory —
+  // pinned memory makes that a true DMA — other layouts through this object's pinned staging), `done` is recorded behind
+  // them; run_async() must be ordered behind `done`.  The caller's buffers are read until `done` has completed.
+  void upload_async(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings, hipStream_t copy_stream,
+                    hipEvent_t done);
   // one raw revolution in sensor axes / firing order (MultiScanRegistration::process): binned into rings on the device and,
   // with IMU data, de-skewed point by point (projectPointToStartOfSweep)
   void upload_raw(const void* raw_xyz, uint32_t count, uint32_t stride, float lower_deg, float upper_deg, uint32_t n_scan_rings);
@@ -79,7 +84,8 @@ class FeatureExtractor {
   PinBuf<ImuLast> h_imu_last_;
   void check_params_() const;
   void layout_(uint32_t nsw, const uint32_t* const* ring_size, const uint32_t* n_rings);
-  void allocate_();
+  void allocate_(hipStream_t table_stream = nullptr);
+  PinBuf<uint32_t> h_tab_;
   RawBinner binner_;
   DevBuf<float4> raw_;
   DevBuf<uint32_t> raw_ring_cnt_;

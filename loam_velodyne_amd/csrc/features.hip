@@ -485,6 +485,32 @@ void FeatureExtractor::check_params_() const {
 }
 
 // host bookkeeping of a batch: ring offsets, sweep bases, longest ring
+void FeatureExtractor::upload_async(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings,
+                                    hipStream_t copy_stream, hipEvent_t done) {
+  LX_REQUIRE(nsw >= 1 && clouds && ring_size && n_rings && copy_stream && done, "invalid sweep batch");
+  check_params_();
+  LX_HIP(hipSetDevice(device_));
+  bool packed = true;
+  for (uint32_t s = 0; s < nsw; s++) {
+    check_cloud(&clouds[s], false);
+    uint32_t sum = 0;
+    for (uint32_t r = 0; r < n_rings[s]; r++) sum += ring_size[s][r];
+    LX_REQUIRE(sum == clouds[s].count, "ring sizes do not add up to the cloud size");
+    packed = packed && clouds[s].stride == 16 && clouds[s].intensity_offset == 12;
+  }
+  layout_(nsw, ring_size, n_rings);
+  allocate_(copy_stream);
+  if (packed) {
+    for (uint32_t s = 0; s < nsw; s++)
+      if (clouds[s].count)
+        LX_HIP(hipMemcpyAsync(cloud_.p + h_pt_base_[s], clouds[s].data, sizeof(float4) * clouds[s].count, hipMemcpyHostToDevice, copy_stream));
+  } else {
+    h_cloud_.reserve(n_ + 1);
+    for (uint32_t s = 0; s < nsw; s++) pack_cloud(&clouds[s], h_cloud_.p + h_pt_base_[s]);
+    if (n_) LX_HIP(hipMemcpyAsync(cloud_.p, h_cloud_.p, sizeof(float4) * n_, hipMemcpyHostToDevice, copy_stream));
+  }
+  LX_HIP(hipEventRecord(done, copy_stream));
+}
 void FeatureExtractor::layout_(uint32_t nsw, const uint32_t* const* ring_size, const uint32_t* n_rings) {
   nsw_ = nsw;
   h_ring_off_.assign(1, 0);
@@ -511,7 +537,7 @@ void FeatureExtractor::layout_(uint32_t nsw, const uint32_t* const* ring_size, c
 }
 
 // device buffers for the laid-out batch + the small tables (the cloud itself is already in / copied to cloud_)
-void FeatureExtractor::allocate_() {
+void FeatureExtractor::allocate_(hipStream_t table_stream) {
   const uint32_t nsw = nsw_;
   cloud_.reserve(n_ + 1);
   curv_.reserve(n_ + 1);
@@ -534,9 +560,18 @@ void FeatureExtractor::allocate_() {
     out_off_[k].reserve(nsw + 2);
   }
   if (max_ring_len_ > 4096) vox_.reserve(n_ + 1, nring_);
-  LX_HIP(hipMemcpyAsync(ring_off_.p, h_ring_off_.data(), sizeof(uint32_t) * (nring_ + 1), hipMemcpyHostToDevice, st_));
-  LX_HIP(hipMemcpyAsync(ring_sweep_base_.p, h_ring_sweep_base_.data(), sizeof(uint32_t) * nring_, hipMemcpyHostToDevice, st_));
-  LX_HIP(hipMemcpyAsync(sweep_ring_base_.p, h_ring_base_.data(), sizeof(uint32_t) * (nsw + 1), hipMemcpyHostToDevice, st_));
+  // the three layout tables travel through pinned memory, so the copies never make the host wait for the stream
+  hipStream_t ts = table_stream ? table_stream : st_;
+  h_tab_.reserve((size_t)2 * nring_ + nsw + 8);
+  uint32_t* t0 = h_tab_.p;
+  uint32_t* t1 = t0 + nring_ + 1;
+  uint32_t* t2 = t1 + nring_;
+  memcpy(t0, h_ring_off_.data(), sizeof(uint32_t) * (nring_ + 1));
+  memcpy(t1, h_ring_sweep_base_.data(), sizeof(uint32_t) * nring_);
+  memcpy(t2, h_ring_base_.data(), sizeof(uint32_t) * (nsw + 1));
+  LX_HIP(hipMemcpyAsync(ring_off_.p, t0, sizeof(uint32_t) * (nring_ + 1), hipMemcpyHostToDevice, ts));
+  LX_HIP(hipMemcpyAsync(ring_sweep_base_.p, t1, sizeof(uint32_t) * nring_, hipMemcpyHostToDevice, ts));
+  LX_HIP(hipMemcpyAsync(sweep_ring_base_.p, t2, sizeof(uint32_t) * (nsw + 1), hipMemcpyHostToDevice, ts));
 }
 
 void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {

@@ -58,7 +58,21 @@ class Pipeline {
   uint32_t n_streams_;
   int device;
   std::vector<PipeStreamState> st;
-  std::vector<std::unique_ptr<FeatureExtractor>> fx;   // one staged batch per step
+  std::vector<std::unique_ptr<FeatureExtractor>> fx;   // one staged batch per step (upload) or a ring of RING slots (stage_step)
+  // Streaming input (loamx_pipeline_stage_step): step t lives in slot t % RING; steps t, t+1, t+2 may be in flight while t+3
+  // is being staged.  The copies run on a stream of their own; launch_features() orders the extraction behind their event.
+  static constexpr uint32_t RING = 4;
+  bool streaming = false;
+  uint32_t staged_hi = 0;                                // streaming: steps below this one have been staged
+  hipStream_t cstream = nullptr, dstream = nullptr;      // H2D staging / D2H of the registered clouds
+  hipEvent_t ev_stage[RING] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_reg_done = nullptr, ev_d2h[2] = {nullptr, nullptr};
+  bool d2h_pending[2] = {false, false};
+  uint32_t last_step = 0;
+  std::vector<uint32_t> last_full_off;                   // offsets of the registered clouds of the last step (k-th mapped stream)
+  FeatureExtractor& FX(uint32_t t) { return *fx[streaming ? t % RING : t]; }
+  char& LA(uint32_t t) { return launched[streaming ? t % RING : t]; }
+  uint32_t n_staged() const { return streaming ? staged_hi : (uint32_t)fx.size(); }
   // feature extraction of step t+1 is independent of odometry / registration of step t (in the reference they are
   // different ROS nodes): it runs on its own HIP stream, launched one step ahead, and overlaps with them
   hipStream_t fstream = nullptr;
@@ -151,13 +165,19 @@ class Pipeline {
     for (auto& a : evF) for (auto& e : a) if (e) (void)hipEventDestroy(e);
     for (auto& tm : tmO) tm.destroy();
     for (auto& tm : tmM) tm.destroy();
+    for (auto& e : ev_stage) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev_d2h) if (e) (void)hipEventDestroy(e);
+    if (ev_reg_done) (void)hipEventDestroy(ev_reg_done);
+    if (cstream) { (void)hipStreamSynchronize(cstream); (void)hipStreamDestroy(cstream); }
+    if (dstream) { (void)hipStreamSynchronize(dstream); (void)hipStreamDestroy(dstream); }
     if (fstream) (void)hipStreamDestroy(fstream);
   }
 
   void launch_features(uint32_t t) {
     TraceRange trace_range("loamx:features");
-    FeatureExtractor& F = *fx[t];
+    FeatureExtractor& F = FX(t);
     const uint32_t ns = n_streams_, nring = F.total_rings();
+    if (streaming) LX_HIP(hipStreamWaitEvent(fstream, ev_stage[t % RING], 0));   // this slot's H2D copies
     PinBuf<uint32_t>& hb = h_off3[t % 3];
     hb.reserve(3 * (ns + 1) + nring + 2);
     uint32_t* ho[3] = {hb.p, hb.p + (ns + 1), hb.p + 2 * (ns + 1)};
@@ -168,7 +188,7 @@ class Pipeline {
     for (int k = 0; k < 3; k++) LX_HIP(hipMemcpyAsync(ho[k], F.d_feat_off(k), sizeof(uint32_t) * (ns + 1), hipMemcpyDeviceToHost, fstream));
     LX_HIP(hipMemcpyAsync(hlf, F.d_less_flat_ring_off(), sizeof(uint32_t) * (nring + 1), hipMemcpyDeviceToHost, fstream));
     LX_HIP(hipEventRecord(evF[t % 3][1], fstream));
-    launched[t] = 1;
+    LA(t) = 1;
   }
 
   void upload(uint32_t n_steps, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
@@ -177,6 +197,8 @@ class Pipeline {
     if (!fstream) fstream = create_stream(-1);
     LX_HIP(hipStreamSynchronize(fstream));
     fx.clear();
+    streaming = false;
+    staged_hi = 0;
     launched.assign(n_steps, 0);
     odom_ready_step = -1;
     for (uint32_t t = 0; t < n_steps; t++) {
@@ -195,17 +217,88 @@ class Pipeline {
     }
   }
 
+  // Streaming input: stage ONE step (sweep s of the step = clouds[s]) without blocking; steps arrive in order.  Slot t % RING
+  // is free once step t - RING has been registered, which the caller's own order of calls guarantees (stage(t) after step(t - RING)).
+  void stage_step(uint32_t t, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
+    LX_REQUIRE(clouds && ring_size && n_rings, "invalid argument");
+    LX_HIP(hipSetDevice(device));
+    if (!streaming) {   // first use: switch to the ring of slots
+      LX_REQUIRE(t == 0, "streaming input starts at step 0");
+      if (!fstream) fstream = create_stream(-1);
+      LX_HIP(hipStreamSynchronize(fstream));
+      fx.clear();
+      for (uint32_t k = 0; k < RING; k++) {
+        auto f = std::make_unique<FeatureExtractor>(device, fstream);
+        FeatParams& p = f->params;
+        p.scan_period = fcfg.scan_period;
+        p.n_regions = fcfg.n_feature_regions;
+        p.curv_region = fcfg.curvature_region;
+        p.max_sharp = fcfg.max_corner_sharp;
+        p.max_less_sharp = fcfg.max_corner_less_sharp == 0 ? 10 * fcfg.max_corner_sharp : fcfg.max_corner_less_sharp;
+        p.max_flat = fcfg.max_surface_flat;
+        p.less_flat_leaf = fcfg.less_flat_filter_size;
+        p.curv_thr = fcfg.surface_curvature_threshold;
+        fx.push_back(std::move(f));
+      }
+      launched.assign(RING, 0);
+      if (!cstream) cstream = create_stream(0);
+      for (auto& e : ev_stage) if (!e) LX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      streaming = true;
+      staged_hi = 0;
+      odom_ready_step = -1;
+    }
+    LX_REQUIRE(t == staged_hi, "steps must be staged in order");
+    LX_REQUIRE(t < RING || last_step + RING > t, "stage_step(t) needs step(t - 4) to have run: only four steps can be in flight");
+    TraceRange trace_range("loamx:pipeline:stage_step");
+    fx[t % RING]->upload_async(n_streams_, clouds, ring_size, n_rings, cstream, ev_stage[t % RING]);
+    LA(t) = 0;
+    staged_hi = t + 1;
+  }
+
+  // Registered full-resolution clouds of the step that just ran -> caller memory, asynchronously on a copy stream (the next
+  // step's kernels do not wait for it: the registrar alternates between two full-resolution buffers).  Packed float4 records
+  // only (a DMA cannot re-stride); out[k] receives the k-th stream that was registered.
+  void download_step_async(loamx_cloud* out, uint32_t n_out) {
+    LX_REQUIRE(out, "NULL argument");
+    LX_REQUIRE(reg.double_buffer_full, "call loamx_pipeline_enable_async_downloads() before the first step");
+    LX_HIP(hipSetDevice(device));
+    const uint32_t nw = last_full_off.empty() ? 0u : (uint32_t)last_full_off.size() - 1;
+    LX_REQUIRE(n_out >= nw, "fewer output descriptors than registered streams");
+    if (!dstream) dstream = create_stream(0);
+    const int par = (int)((run_count + 1) & 1);   // the buffer the last run used
+    if (!ev_d2h[par]) LX_HIP(hipEventCreateWithFlags(&ev_d2h[par], hipEventDisableTiming));
+    LX_HIP(hipStreamWaitEvent(dstream, ev_reg_done, 0));
+    int rc_cap = LOAMX_OK;
+    for (uint32_t k = 0; k < nw; k++) {
+      check_cloud(&out[k], false);
+      LX_REQUIRE(out[k].stride == 16 && out[k].intensity_offset == 12, "asynchronous downloads need packed float4 records (stride 16, intensity at 12)");
+      const uint32_t n = last_full_off[k + 1] - last_full_off[k];
+      const uint32_t m = std::min(n, out[k].count);
+      if (m) LX_HIP(hipMemcpyAsync(out[k].data, reg.d_full_res() + last_full_off[k], sizeof(float4) * m, hipMemcpyDeviceToHost, dstream));
+      if (n > out[k].count) rc_cap = LOAMX_E_CAPACITY;
+      out[k].count = n;
+    }
+    LX_HIP(hipEventRecord(ev_d2h[par], dstream));
+    d2h_pending[par] = true;
+    if (rc_cap != LOAMX_OK) throw Error(LOAMX_E_CAPACITY, "an output cloud is smaller than the registered cloud (count fields hold the needed sizes)");
+  }
+  void wait_downloads() {
+    for (int par = 0; par < 2; par++)
+      if (d2h_pending[par]) LX_HIP(hipEventSynchronize(ev_d2h[par]));
+  }
+  uint64_t run_count = 0;   // registrations run so far (parity = which full-resolution buffer)
+
   // odometry of staged step t for every stream (needs its features); results go to st[s].next
   void run_odometry(uint32_t t) {
     const uint32_t ns = n_streams_;
-    FeatureExtractor& F = *fx[t];
-    if (!launched[t]) launch_features(t);
+    FeatureExtractor& F = FX(t);
+    if (!LA(t)) launch_features(t);
     uint32_t* hb = h_off3[t % 3].p;
     uint32_t* ho[3] = {hb, hb + (ns + 1), hb + 2 * (ns + 1)};
     uint32_t* hlf = hb + 3 * (ns + 1);
     LX_HIP(hipEventSynchronize(evF[t % 3][1]));
     trO[1] = tr_us();
-    launched[t] = 0;
+    LA(t) = 0;
     if (timing) LX_HIP(hipEventElapsedTime(&feat_ms[t % 3], evF[t % 3][0], evF[t % 3][1]));
     std::vector<OdomInput> in(ns);
     std::vector<int> rc(ns, 0);
@@ -252,7 +345,8 @@ class Pipeline {
 
   int step(uint32_t t) {
     TraceRange trace_range("loamx:pipeline:step");
-    LX_REQUIRE(t < fx.size(), "step index beyond the staged sweeps");
+    LX_REQUIRE(t < n_staged(), "step index beyond the staged sweeps");
+    LX_REQUIRE(!streaming || t + RING > staged_hi, "this step's slot has been re-staged already");
     tr0 = std::chrono::steady_clock::now();
     double trM[6] = {0, 0, 0, 0, 0, 0};
     LX_HIP(hipSetDevice(device));
@@ -260,24 +354,24 @@ class Pipeline {
     const uint32_t ns = n_streams_;
     // ---- this step's odometry: from the look-ahead of the previous call, or now
     if (odom_ready_step != (int)t) {
-      if (prefetch && t + 1 < fx.size() && !launched[t + 1]) { if (!launched[t]) launch_features(t); launch_features(t + 1); }
+      if (prefetch && t + 1 < n_staged() && !LA(t + 1)) { if (!LA(t)) launch_features(t); launch_features(t + 1); }
       run_odometry(t);
     }
     for (uint32_t s = 0; s < ns; s++) st[s].cur = st[s].next;
     odom_ready_step = -1;
-    FeatureExtractor& F = *fx[t];
+    FeatureExtractor& F = FX(t);
     const float f_ms = feat_ms[t % 3];
     // ---- look-ahead while M(t) runs: the odometry of step t+1 on the worker thread, started first (it is the longest
     // chain), and the features of step t+2, enqueued while this thread waits for M(t)'s first look at the flags.
     // (the re-projected "last" clouds of THIS sweep are produced at the tail of the odometry stream: order the
     // registrar's stream behind it before the odometry thread re-arms the event)
     if (hipEvent_t te = odom.tail_event()) LX_HIP(hipStreamWaitEvent(s_, te, 0));
-    const bool ahead = prefetch && t + 1 < fx.size();
+    const bool ahead = prefetch && t + 1 < n_staged();
     if (ahead) {
-      if (!launched[t + 1]) launch_features(t + 1);
+      if (!LA(t + 1)) launch_features(t + 1);
       kick(t + 1);
     }
-    bool f2_pending = ahead && t + 2 < fx.size() && !launched[t + 2];
+    bool f2_pending = ahead && t + 2 < n_staged() && !LA(t + 2);
     auto launch_f2 = [&]() {
       if (f2_pending) { f2_pending = false; launch_features(t + 2); }
     };
@@ -314,14 +408,26 @@ class Pipeline {
       if (nw) {
         // the full-resolution clouds are re-projected to the sweep end before they are registered (LaserOdometry.cpp:326):
         // one fused kernel writes them straight into the registrar's staging area
+        if (reg.double_buffer_full) {   // this run reuses the buffer of the run before last: its download must have finished
+          const int par = (int)(run_count & 1);
+          if (d2h_pending[par]) { LX_HIP(hipStreamWaitEvent(s_, ev_d2h[par], 0)); d2h_pending[par] = false; }
+        }
         float4* full_dst = reg.stage_full(nw, nfr.data());
         std::vector<uint32_t> foff(nw + 1, 0);
         for (uint32_t k = 0; k < nw; k++) foff[k + 1] = foff[k] + nfr[k];
+        last_full_off = foff;
+        run_count++;
         odom.to_end_gather(full_dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
         reg.upload_device(nw, cl.data(), ncl.data(), sl.data(), nsl.data(), nullptr, nullptr, guess.data());
         reg.on_first_wait = launch_f2;
         reg.run_async();
         reg.on_first_wait = nullptr;
+        if (reg.double_buffer_full) {
+          if (!ev_reg_done) LX_HIP(hipEventCreateWithFlags(&ev_reg_done, hipEventDisableTiming));
+          LX_HIP(hipEventRecord(ev_reg_done, s_));
+        }
+      } else {
+        last_full_off.clear();
       }
       launch_f2();
       if (timing) {
@@ -355,6 +461,7 @@ class Pipeline {
     // ---- join the look-ahead
     if (ahead) join_job();   // rethrows a failure of the odometry thread
     trM[3] = tr_us();
+    last_step = t;
     if (trace)
       fprintf(stderr, "[pipe t=%u] M-start %.0f  M-enqueued %.0f  M-downloaded %.0f  O-joined %.0f | O thread: start %.0f feat-ready %.0f process-done %.0f end %.0f\n", t,
               trM[0], trM[1], trM[2], trM[3], trO[0], trO[1], trO[2], trO[3]);
@@ -448,6 +555,18 @@ int loamx_pipeline_set_state(loamx_pipeline* h, uint32_t stream, const float* tr
 int loamx_pipeline_upload(loamx_pipeline* h, uint32_t n_steps, const loamx_cloud* clouds, const uint32_t* const* ring_size,
                           const uint32_t* n_rings) {
   return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->p.upload(n_steps, clouds, ring_size, n_rings); return LOAMX_OK; });
+}
+int loamx_pipeline_stage_step(loamx_pipeline* h, uint32_t step, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
+  return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->p.stage_step(step, clouds, ring_size, n_rings); return LOAMX_OK; });
+}
+int loamx_pipeline_enable_async_downloads(loamx_pipeline* h) {
+  return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->p.reg.double_buffer_full = true; return LOAMX_OK; });
+}
+int loamx_pipeline_download_step_async(loamx_pipeline* h, loamx_cloud* out, uint32_t n_out) {
+  return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->p.download_step_async(out, n_out); return LOAMX_OK; });
+}
+int loamx_pipeline_wait_downloads(loamx_pipeline* h) {
+  return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->p.wait_downloads(); return LOAMX_OK; });
 }
 int loamx_pipeline_step(loamx_pipeline* h, uint32_t step) {
   return guard([&]() { LX_REQUIRE(h, "NULL handle"); return h->p.step(step); });

@@ -94,6 +94,7 @@ class Registrar {
   void stage_submap_host(const loamx_cloud* corner, const loamx_cloud* surf);
   bool submap_staged() const { return next_staged_; }
   void swap_submap();
+  bool double_buffer_full = false;   // stage_full() alternates between two buffers (the pipeline's asynchronous downloads)
   bool defer_full = false;    // run_async() leaves the full-resolution clouds unregistered; finish_with_poses() does it
   void finish_with_poses(const float* poses6);
   std::function<void()> on_first_wait;   // early_exit: called once, right before run_async() first blocks on the flags
@@ -148,7 +149,7 @@ class Registrar {
   PinBuf<float4> h_in_, h_full_;
   std::vector<uint32_t> h_seg_off_, h_full_off_;
   PinBuf<float> h_guess_;
-  DevBuf<float4> in_, stack_, ds_pts_, full_;
+  DevBuf<float4> in_, stack_, ds_pts_, full_, full_alt_;
   DevBuf<uint32_t> seg_off_, full_off_, ds_off_;
   DevBuf<float> guess_;
   DevBuf<const float4*> src_ptrs_;

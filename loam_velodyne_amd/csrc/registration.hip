@@ -1182,6 +1182,10 @@ float4* Registrar::stage_full(uint32_t n_sweeps, const uint32_t* n_full) {
   h_full_off_.assign(n_sweeps + 1, 0);
   for (uint32_t s = 0; s < n_sweeps; s++) h_full_off_[s + 1] = h_full_off_[s] + n_full[s];
   n_full_ = h_full_off_[n_sweeps];
+  if (double_buffer_full) {   // the previous run's registered clouds stay readable (an asynchronous download may still be copying them)
+    std::swap(full_.p, full_alt_.p);
+    std::swap(full_.cap, full_alt_.cap);
+  }
   full_.reserve((size_t)n_full_ + 1);
   full_staged_ = true;
   return full_.p;

@@ -552,6 +552,34 @@ class Pipeline:
         _check(lib().loamx_pipeline_upload(self.h, n_steps, CA, RP, NR))
         self._sizes = [len(a) for a in pts]
 
+    def stage_step(self, t: int, sweeps_t):
+        """streaming input: stage step t (sweeps_t[s] = (points (N,4) float32 C-contiguous, ring_sizes)) without blocking.
+        The arrays must stay alive until step(t) has returned (kept referenced here); pinned memory makes the copy a DMA."""
+        ns = self.n_streams
+        assert len(sweeps_t) == ns
+        pts = [as_points(sweeps_t[s][0]) for s in range(ns)]
+        rings = [np.ascontiguousarray(sweeps_t[s][1], np.uint32) for s in range(ns)]
+        CA = (Cloud * ns)(*[cloud_of(a) for a in pts])
+        RP = (C.c_void_p * ns)(*[r.ctypes.data for r in rings])
+        NR = (C.c_uint32 * ns)(*[len(r) for r in rings])
+        _check(lib().loamx_pipeline_stage_step(self.h, t, CA, RP, NR))
+        if not hasattr(self, "_staged"):
+            self._staged = {}
+        self._staged[t % 8] = (pts, rings, CA, RP, NR)
+
+    def enable_async_downloads(self):
+        _check(lib().loamx_pipeline_enable_async_downloads(self.h))
+
+    def download_step_async(self, outs):
+        """outs: list of (N,4) float32 C-contiguous arrays (capacity); returns the point counts (the data is valid after wait_downloads())"""
+        CA = (Cloud * len(outs))(*[cloud_of(a) for a in outs])
+        _check(lib().loamx_pipeline_download_step_async(self.h, CA, len(outs)))
+        self._dl_keep = (outs, CA)
+        return [int(CA[k].count) for k in range(len(outs))]
+
+    def wait_downloads(self):
+        _check(lib().loamx_pipeline_wait_downloads(self.h))
+
     def step(self, t: int):
         return _check(lib().loamx_pipeline_step(self.h, t))
 

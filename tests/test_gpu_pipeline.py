@@ -166,3 +166,62 @@ def test_full_size_hdl64_pipeline_vs_oracle(orc):
         # sensor position at the end of the last sweep (LOAM with a 25 / 10 iteration budget, not a converged optimum)
         gt = synth.trajectory(T, start=starts[s])[T]
         assert np.abs(got[T - 1][s][2][3:] - gt[3:]).max() < 0.3
+
+
+def test_streaming_io_equals_staged_run(orc, small_world):
+    """loamx_pipeline_stage_step / download_step_async (the PCIe-inclusive mode): one step handed over at a time, at most four
+    in flight, registered clouds copied out asynchronously from alternating device buffers — bit-identical to the run that
+    staged everything up front, and the downloaded clouds are the ones download_full_res returns"""
+    ns, T = 2, 7
+    cm, sm = small_world.make_map(60000)
+    sweeps, starts = [[None] * ns for _ in range(T)], []
+    for s in range(ns):
+        poses = synth.trajectory(T, start=(1.5 * s, 0.0, 2.0 * s))
+        starts.append(np.array([0, 0, 0, 1.5 * s, 0, 2.0 * s], np.float32))
+        for t in range(T):
+            sw = synth.make_sweep(small_world, "VLP-16", poses[t], poses[t + 1], seed=30 * s + t, az_steps=900)
+            sweeps[t][s] = (np.ascontiguousarray(sw.points, np.float32), sw.ring_sizes)
+
+    def make():
+        p = loamx.Pipeline(ns)
+        p.set_frozen(cm, sm)
+        for s in range(ns):
+            p.set_state(s, aft=starts[s])
+        return p
+    a = make()
+    a.upload(sweeps)
+    ref, ref_full = [], []
+    for t in range(T):
+        rc = a.step(t)
+        ref.append([a.get(s) for s in range(ns)])
+        ref_full.append([a.download_full_res(k, len(sweeps[t][k][0])) for k in range(ns)] if rc == loamx.OK else None)
+    b = make()
+    b.enable_async_downloads()
+    for t in range(min(3, T)):
+        b.stage_step(t, sweeps[t])
+    outs = [[np.zeros((len(sweeps[0][k][0]) + 8, 4), np.float32) for k in range(ns)] for _ in range(2)]
+    pending = None
+    for t in range(T):
+        rc = b.step(t)
+        if t + 3 < T:
+            b.stage_step(t + 3, sweeps[t + 3])                       # slot (t + 3) % 4: free since step t - 1 has run
+        for s in range(ns):
+            got, want = b.get(s), ref[t][s]
+            for i in range(3):
+                assert np.array_equal(got[i], want[i]), (t, s, i)
+            assert got[3] == want[3]
+        if pending is not None:                                       # the previous step's clouds have had a whole step to land
+            b.wait_downloads()
+            pt, counts, bufs = pending
+            for k in range(ns):
+                assert counts[k] == len(ref_full[pt][k]) and np.array_equal(bufs[k][:counts[k]], ref_full[pt][k]), (pt, k)
+            pending = None
+        if rc == loamx.OK:
+            bufs = outs[t & 1]
+            pending = (t, b.download_step_async(bufs), bufs)
+    b.wait_downloads()
+    pt, counts, bufs = pending
+    for k in range(ns):
+        assert np.array_equal(bufs[k][:counts[k]], ref_full[pt][k])
+    with pytest.raises(loamx.LoamxError):                            # out of order
+        b.stage_step(T + 3, sweeps[0])

@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU)
     ap.add_argument("--handles", type=int, default=HANDLES_PER_GPU,
                     help="pipeline handles per GPU, each on its own HIP stream and host thread, sharing the streams evenly")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the second, PCIe-inclusive timed window")
     ap.add_argument("--mode", default="batched", choices=["batched", "live"],
                     help="live: sequential SLAM (BASELINE configs[1]: VLP-16, 200 k-pt live map, one sweep in flight, host clouds in / out)")
     args = ap.parse_args()
@@ -228,6 +229,20 @@ def main():
     sweeps_total = world * ns * K
     value = sweeps_total / elapsed
 
+    # ---- the same K steps once more with the PCIe inside the timed region (SURVEY.md §8d "GPU timing"): every step's sweeps
+    # are handed over from pinned host memory while earlier steps compute (loamx_pipeline_stage_step, three steps ahead) and
+    # every step's registered full-resolution clouds are copied back asynchronously (loamx_pipeline_download_step_async).  Never
+    # `value`: reported beside it.
+    pcie = None
+    if H == 1 and not args.no_pcie:
+        for p in pipes:   # free the resident run's HIP streams first: beyond 8 streams per process the runtime aliases busy streams onto
+            p.close()     # shared hardware queues and they serialise (GPU_MAX_HW_QUEUES above)
+        try:
+            pcie = pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps, starts, ns, W, K, dist, dev, lxdist)
+        except Exception as e:   # the device-resident figure above is the contract; a failure here must not lose it
+            pcie = {"error": repr(e)[:200]}
+
+
     if rank == 0:
         iters_map = np.mean([st["map_iterations"] for st in stats])
         iters_odom = np.mean([st["odom_iterations"] for st in stats])
@@ -270,6 +285,7 @@ def main():
                 "path_algorithmic_bytes_per_sweep": round(float(bytes_per_sweep), 1),
                 "path_hbm_frac": round(float(bytes_per_sweep * value / world / (HBM_PEAK_GBS * 1e9)), 6),
             },
+            "pcie_inclusive": pcie,
             "roofline": {
                 "kernel": "loamx::k_gn_iter",
                 "bound": "hbm",
@@ -368,6 +384,63 @@ def run_live(args):
                                "sample": f"{len(per)} sweeps of the same sequence, same initial map, oracle live-map process() (g++ -O3 -march=native, one thread)",
                                "seconds_per_sweep": _stats(per), "host_cores_available": os.cpu_count()}
     print(json.dumps(out), flush=True)
+
+
+def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps, starts, ns, W, K, dist, dev, lxdist):
+    """K timed steps with host <-> device traffic inside the timed region: H2D of each step's sweeps (pinned memory, a copy
+    stream, three steps ahead of the compute) and D2H of each step's registered clouds (asynchronous, alternating device buffers)."""
+    T = 1 + W + K
+    pinned = []
+    for t in range(T):
+        row = []
+        for s in range(ns):
+            pts = torch.from_numpy(np.ascontiguousarray(sweeps[t][s][0], np.float32)).pin_memory()
+            row.append((pts.numpy(), sweeps[t][s][1], pts))
+        pinned.append(row)
+    n_pts = len(sweeps[0][0][0])
+    outs = [[torch.empty((n_pts + 8, 4), dtype=torch.float32).pin_memory() for _ in range(ns)] for _ in range(2)]
+    p = loamx.Pipeline(ns, scanreg=dict(device=local_rank), odom=dict(device=local_rank), mapping=dict(device=local_rank))
+    p.set_frozen_device(map_t.data_ptr(), n_corner, map_t.data_ptr() + 16 * n_corner, n_surf)
+    for k in range(ns):
+        p.set_state(k, aft=starts[k])
+    p.enable_async_downloads()
+    for t in range(min(3, T)):
+        p.stage_step(t, [(a, r) for a, r, _ in pinned[t]])
+    t0 = None
+    mapped_pts = 0
+    for t in range(T):
+        if t == 1 + W:   # steady state: the pipeline is NOT drained here (steps t+1 .. t+3 are staged / in flight, as in production);
+            if dist is not None:   # the window ends with everything drained, so its cost is fully inside
+                dist.barrier()
+            t0 = time.perf_counter()
+        ta = time.perf_counter()
+        rc = p.step(t)
+        tb = time.perf_counter()
+        if t + 3 < T:
+            p.stage_step(t + 3, [(a, r) for a, r, _ in pinned[t + 3]])
+        tc = time.perf_counter()
+        if rc == loamx.OK:
+            counts = p.download_step_async([o.numpy() for o in outs[t & 1]])
+            if t >= 1 + W:
+                mapped_pts += sum(counts)
+        if os.environ.get("LOAMX_BENCH_TRACE"):
+            print(f"[pcie t={t}] step {(tb - ta) * 1e3:.3f} stage {(tc - tb) * 1e3:.3f} download {(time.perf_counter() - tc) * 1e3:.3f} ms", file=sys.stderr)
+    t_loop = time.perf_counter() - t0
+    p.wait_downloads()
+    t_wait = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if os.environ.get("LOAMX_BENCH_TRACE"):
+        print(f"[pcie] loop {t_loop * 1e3:.2f} ms, + wait_downloads {t_wait * 1e3:.2f}, + synchronize {elapsed * 1e3:.2f}", file=sys.stderr)
+    elapsed = lxdist.max_over_ranks(elapsed, dist, dev)
+    world = dist.get_world_size() if dist is not None else 1
+    return {
+        "value": round(world * ns * K / elapsed, 2), "unit": "sweeps/s", "ms_per_step": round(elapsed / K * 1e3, 4),
+        "h2d_bytes_per_step": int(ns * n_pts * 16), "d2h_bytes_per_step": int(mapped_pts * 16 // max(K, 1)),
+        "note": "same workload and steps as `value`, but every step's sweeps cross PCIe inside the timed region (pinned memory, copy stream, staged "
+                "three steps ahead) and every step's registered full-resolution clouds are copied back (asynchronous, alternating buffers); "
+                "steady-state window: not drained at its start, fully drained (downloads landed, device idle) at its end",
+    }
 
 
 def pmc_traffic():

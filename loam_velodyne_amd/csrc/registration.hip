@@ -1399,6 +1399,8 @@ void Registrar::sync() { LX_HIP(hipStreamSynchronize(st_)); }
 // final poses / statistics on the host: an early-exit run that saw every sweep converge already holds them (the update
 // step mirrors them into pinned memory), anything else is copied
 void Registrar::fetch_results() {
+  LX_HIP(hipStreamSynchronize(st_));
+  vox_.check();
   if (!mirrors_written_) {
     LX_HIP(hipMemcpyAsync(h_poses_.p, poses_.p, sizeof(Pose) * n_sweeps_, hipMemcpyDeviceToHost, st_));
     LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * n_sweeps_, hipMemcpyDeviceToHost, st_));

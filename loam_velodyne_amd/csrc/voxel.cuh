@@ -1,5 +1,5 @@
-// Segmented voxel-grid down-sampling (pcl::VoxelGrid semantics) on device: keys -> radix sort -> run heads ->
-// exclusive scan -> per-voxel float means in input order.  Used for the mapping stack clouds
+// Segmented voxel-grid down-sampling (pcl::VoxelGrid semantics) on device: keys -> stable radix sort -> run heads ->
+// their scan -> per-voxel float means in input order, all inside one persistent kernel (k_vox_ds, voxel.hip).  Used for the mapping stack clouds
 // (reference BasicLaserMapping.cpp:519-527), the per-ring less-flat clouds (BasicScanRegistration.cpp:246-252) and the
 // per-cube map re-filtering (BasicLaserMapping.cpp:580-593).
 //
@@ -7,12 +7,12 @@
 // segment = ascending (iz, iy, ix) = PCL's ascending voxel index; the mean covers x, y, z and intensity.  PCL's
 // unstable std::sort leaves the summation order inside a voxel unspecified; here it is input order (stable radix sort).
 #pragma once
+#include <algorithm>
 #include "common.h"
 #include "scan.cuh"
 
 namespace loamx {
 
-constexpr int VOX_SEG_SHIFT = 36;
 
 __device__ inline uint32_t vox_find_seg(const uint32_t* __restrict__ off, uint32_t nseg, uint32_t i) {
   uint32_t lo = 0, hi = nseg;   // off[lo] <= i < off[hi]
@@ -94,19 +94,18 @@ class VoxelPipeline {
   // the per-segment output offsets.  Slots with valid[i]==0 are ignored.
   void sort_reduce(const float4* pts, const uint8_t* valid, uint32_t n, const uint32_t* d_seg_off, uint32_t nseg, float4* out,
                    uint32_t* d_out_off, const uint32_t* d_seg_ids = nullptr);
-  // after sort_reduce: original slot index of the first point of output voxel v is first_slot()[v] (device)
-  const uint32_t* sorted_vals() const { return vals_sorted_.p; }
-  const uint32_t* head_flags() const { return head_.p; }
-  const uint32_t* head_scan() const { return head_scan_.p; }
+  // after the stream has been synchronised: throws if a grid barrier of the last launches timed out
+  void check();
 
  private:
   hipStream_t st_ = nullptr;
   DevBuf<int> ijk_, seg_minmax_;
-  DevBuf<unsigned long long> keys_, keys_sorted_;
-  DevBuf<uint32_t> vals_, vals_sorted_, head_, head_scan_, tile_sums_, scratch_;
+  DevBuf<unsigned long long> keys_[2];
+  DevBuf<uint32_t> vals_[2], zero_, tile_cnt_, head_scan_, tile_sums_, scratch_;   // zero_: barrier counter | digit histograms | tile status
+  size_t zero_words_ = 0;
   DevBuf<float4> gathered_;   // the points in sorted order
-  DevBuf<char> sort_tmp_;
-  size_t sort_tmp_bytes_ = 0;
+  PinBuf<uint32_t> h_err_;
+  uint32_t slots_ = 0;
 };
 
 }  // namespace loamx

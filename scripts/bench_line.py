@@ -1,5 +1,4 @@
-"""Condensed view of bench.py's JSON line (stdin)."""
+"""one-line summary of a bench.py JSON line on stdin (GPU probes): tag value ms_per_step stage times"""
 import json, sys
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(" ".join(sys.argv[1:]), "streams", d["config"]["streams_per_gpu"], "handles", d["config"]["handles_per_gpu"], "value", d["value"],
-      "ms/step", d["ms_per_step"], d["config"]["stage_ms_per_step"])
+print(sys.argv[1] if len(sys.argv) > 1 else "", d["value"], d["ms_per_step"], d["config"].get("stage_ms_per_step"), d.get("roofline", {}).get("avg_launch_us"), flush=True)

@@ -309,6 +309,17 @@ int loamx_pipeline_upload(loamx_pipeline* h, uint32_t n_steps, const loamx_cloud
  * buffers of step t are read until step(t) has returned. */
 int loamx_pipeline_stage_step(loamx_pipeline* h, uint32_t step, const loamx_cloud* clouds, const uint32_t* const* ring_size,
                               const uint32_t* n_rings);
+/* Raw input for the batched pipeline: step `step` as the sensors delivered it — raw_xyz[s] = one
+ * revolution of stream s, counts[s] records with x, y, z float32 at byte offsets 0 / 4 / 8, `stride` bytes apart, sensor axes,
+ * firing order (the /velodyne_points payload; MultiScanRegistration.cpp:160-238).  The payloads cross PCIe as they are (pin them
+ * for a DMA) and are re-strided, binned into rings and — for a stream with IMU data — de-skewed on the device; same ordering
+ * rules as loamx_pipeline_stage_step.  scan_time_sec[s] (may be NULL without IMU data) is the sweep's time stamp on the clock of
+ * loamx_pipeline_update_imu, which feeds stream s's IMU history exactly as loamx_scanreg_update_imu does (updateIMUData,
+ * BasicScanRegistration.cpp:82-98); the resulting imuTransform() of every sweep is plugged into that stream's odometry
+ * (BasicLaserOdometry::updateIMU).  The mapping-side roll / pitch blend of transformUpdate is not part of the frozen-map pipeline. */
+int loamx_pipeline_stage_step_raw(loamx_pipeline* h, uint32_t step, const void* const* raw_xyz, const uint32_t* counts, uint32_t stride,
+                                  const loamx_multiscan_mapper* mapper, const double* scan_time_sec);
+int loamx_pipeline_update_imu(loamx_pipeline* h, uint32_t stream, double stamp_sec, float roll, float pitch, float yaw, const float acc_xyz[3]);
 /* Asynchronous output: after enable (before the first step), download_step_async — called after loamx_pipeline_step(t) —
  * starts copying the registered full-resolution clouds of step t (out[k] = k-th stream that was registered; packed float4
  * records; count in = capacity, out = points) on a copy stream and returns; the registration alternates between two device

@@ -19,6 +19,38 @@ struct FeatParams {
   float curv_thr = 0.1f;
 };
 
+// The IMU state machine of BasicScanRegistration for ONE sensor stream, on the host (src/lib/BasicScanRegistration.cpp:55-152,
+// :258-281): history with accumulated position / velocity (updateIMUData :82-98), interpolation (interpolateIMUStateFor
+// :133-147), reset(scanTime) :55-79 and updateIMUTransform :258-281.  The per-point projection (projectPointToStartOfSweep
+// :101-131) runs on the device from a table this class fills (ingest.cuh ImuTable); the state the projection loop leaves behind
+// comes back as ImuLast.  Used by FeatureExtractor (single-sweep entry points) and, one per stream, by the batched pipeline.
+class ImuTracker {
+ public:
+  struct State {
+    double stamp = 0;
+    HAngle roll, pitch, yaw;
+    HVec3 position, velocity, acceleration;
+  };
+  int history_size = 200;                                   // max(200, RegistrationParams::imuHistorySize): the buffer never shrinks
+  void update(double stamp, float roll, float pitch, float yaw, const float acc[3]);   // updateIMUData :82-98
+  void set_scan_time(double t) { next_scan_time_ = t; }     // the scanTime argument of the next process call
+  void begin_sweep();                                       // reset(scanTime) + updateIMUTransform() around processScanlines
+  const float* imu_trans() const { return imu_trans_; }     // imuTransform(): 4 x (x, y, z)
+  uint32_t size() const { return (uint32_t)hist_.size(); }
+  // the table of the next projection loop: h_d[2 H] (dt, dstamp), h_f[9 H] (states); I gets everything but the device pointers
+  void fill_table(double* h_d, float* h_f, ImuTable& I) const;
+  void apply_last(const ImuLast& L);                        // _imuCur / _imuPositionShift / _imuIdx as the last kept point left them
+
+ private:
+  std::deque<State> hist_;
+  size_t idx_ = 0;
+  State start_, cur_;
+  HVec3 shift_;
+  double scan_time_ = 0, sweep_start_ = 0, next_scan_time_ = 0;
+  float imu_trans_[12] = {0};
+  void interpolate_for_(float rel_time, State& out);
+};
+
 class FeatureExtractor {
  public:
   FeatureExtractor(int device, hipStream_t shared_stream = nullptr);
@@ -34,14 +66,18 @@ class FeatureExtractor {
   // them; run_async() must be ordered behind `done`.  The caller's buffers are read until `done` has completed.
   void upload_async(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings, hipStream_t copy_stream,
                     hipEvent_t done);
+  // the same from DEVICE memory (e.g. the output of the raw-sweep binning): sweep s = d_src + src_off[s], rings concatenated;
+  // copies device-to-device on `copy_stream`, `done` recorded behind them
+  void upload_device(uint32_t nsw, const float4* d_src, const uint32_t* src_off, const uint32_t* const* ring_size, const uint32_t* n_rings,
+                     hipStream_t copy_stream, hipEvent_t done);
   // one raw revolution in sensor axes / firing order (MultiScanRegistration::process): binned into rings on the device and,
   // with IMU data, de-skewed point by point (projectPointToStartOfSweep)
   void upload_raw(const void* raw_xyz, uint32_t count, uint32_t stride, float lower_deg, float upper_deg, uint32_t n_scan_rings);
   // ---- IMU state machine of BasicScanRegistration (src/lib/BasicScanRegistration.cpp:55-152, :258-281); times in seconds
-  void update_imu_data(double stamp, float roll, float pitch, float yaw, const float acc[3]);   // updateIMUData :82-98
-  void set_scan_time(double t) { next_scan_time_ = t; }     // the scanTime argument of the next process call
-  void begin_sweep();                                       // reset(scanTime) + updateIMUTransform() around processScanlines
-  const float* imu_trans() const { return imu_trans_; }     // imuTransform(): 4 x (x, y, z)
+  void update_imu_data(double stamp, float roll, float pitch, float yaw, const float acc[3]) { imu_.history_size = imu_history_size; imu_.update(stamp, roll, pitch, yaw, acc); }
+  void set_scan_time(double t) { imu_.set_scan_time(t); }   // the scanTime argument of the next process call
+  void begin_sweep() { imu_.begin_sweep(); }                // reset(scanTime) + updateIMUTransform() around processScanlines
+  const float* imu_trans() const { return imu_.imu_trans(); }   // imuTransform(): 4 x (x, y, z)
   int imu_history_size = 200;                               // RegistrationParams::imuHistorySize
   int download_cloud(uint32_t sweep, loamx_cloud* full, uint32_t* ring_size_out);
   void run_async();
@@ -64,18 +100,7 @@ class FeatureExtractor {
   uint32_t total_rings() const { return nring_; }
 
  private:
-  struct ImuState {
-    double stamp = 0;
-    HAngle roll, pitch, yaw;
-    HVec3 position, velocity, acceleration;
-  };
-  std::deque<ImuState> imu_hist_;
-  size_t imu_idx_ = 0;
-  ImuState imu_start_, imu_cur_;
-  HVec3 imu_shift_;
-  double scan_time_ = 0, sweep_start_ = 0, next_scan_time_ = 0;
-  float imu_trans_[12] = {0};
-  void imu_interpolate_for_(float rel_time, ImuState& out);
+  ImuTracker imu_;
   DevBuf<double> imu_dt_, imu_dstamp_;
   DevBuf<float> imu_state_;
   DevBuf<ImuLast> imu_last_;

@@ -511,6 +511,19 @@ void FeatureExtractor::upload_async(uint32_t nsw, const loamx_cloud* clouds, con
   }
   LX_HIP(hipEventRecord(done, copy_stream));
 }
+void FeatureExtractor::upload_device(uint32_t nsw, const float4* d_src, const uint32_t* src_off, const uint32_t* const* ring_size,
+                                     const uint32_t* n_rings, hipStream_t copy_stream, hipEvent_t done) {
+  LX_REQUIRE(nsw >= 1 && d_src && src_off && ring_size && n_rings && copy_stream && done, "invalid sweep batch");
+  check_params_();
+  LX_HIP(hipSetDevice(device_));
+  layout_(nsw, ring_size, n_rings);
+  allocate_(copy_stream);
+  for (uint32_t s = 0; s < nsw; s++) {
+    const uint32_t cnt = h_pt_base_[s + 1] - h_pt_base_[s];
+    if (cnt) LX_HIP(hipMemcpyAsync(cloud_.p + h_pt_base_[s], d_src + src_off[s], sizeof(float4) * cnt, hipMemcpyDeviceToDevice, copy_stream));
+  }
+  LX_HIP(hipEventRecord(done, copy_stream));
+}
 void FeatureExtractor::layout_(uint32_t nsw, const uint32_t* const* ring_size, const uint32_t* n_rings) {
   nsw_ = nsw;
   h_ring_off_.assign(1, 0);
@@ -619,19 +632,11 @@ void FeatureExtractor::upload_raw(const void* raw_xyz, uint32_t count, uint32_t 
   // IMU de-skew (projectPointToStartOfSweep, :231): the state the PREVIOUS reset() left behind — the reference projects the
   // points of a sweep before processScanlines resets the state with this sweep's scan time
   ImuTable I;
-  const uint32_t H = (uint32_t)imu_hist_.size();
+  const uint32_t H = imu_.size();
   if (H) {
     h_imu_d_.reserve(2 * (size_t)H);
     h_imu_f_.reserve(9 * (size_t)H);
-    for (uint32_t j = 0; j < H; j++) {
-      const ImuState& s = imu_hist_[j];
-      h_imu_d_.p[j] = scan_time_ - s.stamp;
-      h_imu_d_.p[H + j] = j ? s.stamp - imu_hist_[j - 1].stamp : 1.0;
-      float* o = h_imu_f_.p + 9 * (size_t)j;
-      o[0] = s.roll.r; o[1] = s.pitch.r; o[2] = s.yaw.r;
-      o[3] = s.position.x; o[4] = s.position.y; o[5] = s.position.z;
-      o[6] = s.velocity.x; o[7] = s.velocity.y; o[8] = s.velocity.z;
-    }
+    imu_.fill_table(h_imu_d_.p, h_imu_f_.p, I);
     imu_dt_.reserve(2 * (size_t)H);
     imu_state_.reserve(9 * (size_t)H);
     imu_last_.reserve(1);
@@ -639,29 +644,15 @@ void FeatureExtractor::upload_raw(const void* raw_xyz, uint32_t count, uint32_t 
     LX_HIP(hipMemcpyAsync(imu_dt_.p, h_imu_d_.p, sizeof(double) * 2 * H, hipMemcpyHostToDevice, st_));
     LX_HIP(hipMemcpyAsync(imu_state_.p, h_imu_f_.p, sizeof(float) * 9 * H, hipMemcpyHostToDevice, st_));
     LX_HIP(hipMemsetAsync(imu_last_.p, 0, sizeof(ImuLast), st_));
-    I.H = H;
-    I.idx0 = (uint32_t)std::min(imu_idx_, (size_t)H - 1);
     I.dt = imu_dt_.p;
     I.dstamp = imu_dt_.p + H;
     I.state = imu_state_.p;
-    const HAngle* sa[3] = {&imu_start_.roll, &imu_start_.pitch, &imu_start_.yaw};
-    for (int k = 0; k < 3; k++) { I.start_c[k] = sa[k]->c; I.start_s[k] = sa[k]->s; }
-    I.start_pos[0] = imu_start_.position.x; I.start_pos[1] = imu_start_.position.y; I.start_pos[2] = imu_start_.position.z;
-    I.start_vel[0] = imu_start_.velocity.x; I.start_vel[1] = imu_start_.velocity.y; I.start_vel[2] = imu_start_.velocity.z;
-    I.rel_sweep_base = scan_time_ - sweep_start_;
   }
   binner_.run(raw_.p, count, M, params.scan_period, cloud_.p, raw_ring_cnt_.p, H ? &I : nullptr, H ? imu_last_.p : nullptr);
   LX_HIP(hipMemcpyAsync(h_raw_ring_cnt_.p, raw_ring_cnt_.p, sizeof(uint32_t) * n_scan_rings, hipMemcpyDeviceToHost, st_));
   if (H) LX_HIP(hipMemcpyAsync(h_imu_last_.p, imu_last_.p, sizeof(ImuLast), hipMemcpyDeviceToHost, st_));
   LX_HIP(hipStreamSynchronize(st_));
-  if (H && h_imu_last_.p->valid) {   // _imuCur / _imuPositionShift / _imuIdx as the last kept point left them
-    const ImuLast& L = *h_imu_last_.p;
-    imu_cur_.roll = HAngle(L.roll); imu_cur_.pitch = HAngle(L.pitch); imu_cur_.yaw = HAngle(L.yaw);
-    imu_cur_.position = {L.pos[0], L.pos[1], L.pos[2]};
-    imu_cur_.velocity = {L.vel[0], L.vel[1], L.vel[2]};
-    imu_shift_ = {L.shift[0], L.shift[1], L.shift[2]};
-    imu_idx_ = L.idx;
-  }
+  if (H && h_imu_last_.p->valid) imu_.apply_last(*h_imu_last_.p);
   begin_sweep();   // processScanlines: reset(scanTime) ... updateIMUTransform()
   const uint32_t* rs[1] = {h_raw_ring_cnt_.p};
   layout_(1, rs, &n_scan_rings);
@@ -670,33 +661,33 @@ void FeatureExtractor::upload_raw(const void* raw_xyz, uint32_t count, uint32_t 
 }
 
 // ---- IMU state machine (host): the reference keeps it in BasicScanRegistration; the per-point part runs in ingest.hip
-void FeatureExtractor::update_imu_data(double stamp, float roll, float pitch, float yaw, const float acc_in[3]) {
-  ImuState st;
+void ImuTracker::update(double stamp, float roll, float pitch, float yaw, const float acc_in[3]) {
+  State st;
   st.stamp = stamp; st.roll = HAngle(roll); st.pitch = HAngle(pitch); st.yaw = HAngle(yaw);
   st.acceleration = {acc_in[0], acc_in[1], acc_in[2]};
-  if (!imu_hist_.empty()) {   // accumulate IMU position and velocity over time (:84-95)
+  if (!hist_.empty()) {   // accumulate IMU position and velocity over time (:84-95)
     HVec3 acc = st.acceleration;
     h_rot_zxy(acc, st.roll, st.pitch, st.yaw);
-    const ImuState& prev = imu_hist_.back();
+    const State& prev = hist_.back();
     const float dt = (float)(stamp - prev.stamp);
     st.position = {prev.position.x + prev.velocity.x * dt + 0.5f * acc.x * dt * dt, prev.position.y + prev.velocity.y * dt + 0.5f * acc.y * dt * dt,
                    prev.position.z + prev.velocity.z * dt + 0.5f * acc.z * dt * dt};
     st.velocity = {prev.velocity.x + acc.x * dt, prev.velocity.y + acc.y * dt, prev.velocity.z + acc.z * dt};
   }
-  if (imu_hist_.size() >= (size_t)std::max(imu_history_size, 1)) imu_hist_.pop_front();   // CircularBuffer::push, CircularBuffer.h:111-119
-  imu_hist_.push_back(st);
+  if (hist_.size() >= (size_t)std::max(history_size, 1)) hist_.pop_front();   // CircularBuffer::push, CircularBuffer.h:111-119
+  hist_.push_back(st);
 }
 
-void FeatureExtractor::imu_interpolate_for_(float rel, ImuState& out) {   // interpolateIMUStateFor :133-147
-  double td = (scan_time_ - imu_hist_[imu_idx_].stamp) + rel;
-  while (imu_idx_ < imu_hist_.size() - 1 && td > 0) {
-    imu_idx_++;
-    td = (scan_time_ - imu_hist_[imu_idx_].stamp) + rel;
+void ImuTracker::interpolate_for_(float rel, State& out) {   // interpolateIMUStateFor :133-147
+  double td = (scan_time_ - hist_[idx_].stamp) + rel;
+  while (idx_ < hist_.size() - 1 && td > 0) {
+    idx_++;
+    td = (scan_time_ - hist_[idx_].stamp) + rel;
   }
-  if (imu_idx_ == 0 || td > 0) {
-    out = imu_hist_[imu_idx_];
+  if (idx_ == 0 || td > 0) {
+    out = hist_[idx_];
   } else {
-    const ImuState &a = imu_hist_[imu_idx_], &b = imu_hist_[imu_idx_ - 1];   // IMUState::interpolate(a, b, ratio), .h:107-131
+    const State &a = hist_[idx_], &b = hist_[idx_ - 1];   // IMUState::interpolate(a, b, ratio), .h:107-131
     const float ratio = (float)(-td / (a.stamp - b.stamp)), inv = 1 - ratio;
     out.roll = HAngle(a.roll.r * inv + b.roll.r * ratio);
     out.pitch = HAngle(a.pitch.r * inv + b.pitch.r * ratio);
@@ -710,19 +701,49 @@ void FeatureExtractor::imu_interpolate_for_(float rel, ImuState& out) {   // int
 
 // reset(scanTime) (:55-79) followed by updateIMUTransform() (:258-281): the latter only needs _imuStart (set by the reset) and
 // _imuCur / _imuPositionShift (left behind by the projection loop), so both are done up front
-void FeatureExtractor::begin_sweep() {
+void ImuTracker::begin_sweep() {
   scan_time_ = next_scan_time_;
-  imu_idx_ = 0;
-  if (!imu_hist_.empty()) imu_interpolate_for_(0.f, imu_start_);
+  idx_ = 0;
+  if (!hist_.empty()) interpolate_for_(0.f, start_);
   sweep_start_ = scan_time_;
-  imu_trans_[0] = imu_start_.pitch.r; imu_trans_[1] = imu_start_.yaw.r; imu_trans_[2] = imu_start_.roll.r;
-  imu_trans_[3] = imu_cur_.pitch.r; imu_trans_[4] = imu_cur_.yaw.r; imu_trans_[5] = imu_cur_.roll.r;
-  HVec3 sh = imu_shift_;
-  h_rot_yxz(sh, -imu_start_.yaw, -imu_start_.pitch, -imu_start_.roll);
+  imu_trans_[0] = start_.pitch.r; imu_trans_[1] = start_.yaw.r; imu_trans_[2] = start_.roll.r;
+  imu_trans_[3] = cur_.pitch.r; imu_trans_[4] = cur_.yaw.r; imu_trans_[5] = cur_.roll.r;
+  HVec3 sh = shift_;
+  h_rot_yxz(sh, -start_.yaw, -start_.pitch, -start_.roll);
   imu_trans_[6] = sh.x; imu_trans_[7] = sh.y; imu_trans_[8] = sh.z;
-  HVec3 v{imu_cur_.velocity.x - imu_start_.velocity.x, imu_cur_.velocity.y - imu_start_.velocity.y, imu_cur_.velocity.z - imu_start_.velocity.z};
-  h_rot_yxz(v, -imu_start_.yaw, -imu_start_.pitch, -imu_start_.roll);
+  HVec3 v{cur_.velocity.x - start_.velocity.x, cur_.velocity.y - start_.velocity.y, cur_.velocity.z - start_.velocity.z};
+  h_rot_yxz(v, -start_.yaw, -start_.pitch, -start_.roll);
   imu_trans_[9] = v.x; imu_trans_[10] = v.y; imu_trans_[11] = v.z;
+}
+
+void ImuTracker::fill_table(double* h_d, float* h_f, ImuTable& I) const {
+  // projectPointToStartOfSweep (:231) uses the state the PREVIOUS reset() left behind — the reference projects the points of a
+  // sweep before processScanlines resets the state with this sweep's scan time
+  const uint32_t H = (uint32_t)hist_.size();
+  for (uint32_t j = 0; j < H; j++) {
+    const State& s = hist_[j];
+    h_d[j] = scan_time_ - s.stamp;
+    h_d[H + j] = j ? s.stamp - hist_[j - 1].stamp : 1.0;
+    float* o = h_f + 9 * (size_t)j;
+    o[0] = s.roll.r; o[1] = s.pitch.r; o[2] = s.yaw.r;
+    o[3] = s.position.x; o[4] = s.position.y; o[5] = s.position.z;
+    o[6] = s.velocity.x; o[7] = s.velocity.y; o[8] = s.velocity.z;
+  }
+  I.H = H;
+  I.idx0 = H ? (uint32_t)std::min(idx_, (size_t)H - 1) : 0u;
+  const HAngle* sa[3] = {&start_.roll, &start_.pitch, &start_.yaw};
+  for (int k = 0; k < 3; k++) { I.start_c[k] = sa[k]->c; I.start_s[k] = sa[k]->s; }
+  I.start_pos[0] = start_.position.x; I.start_pos[1] = start_.position.y; I.start_pos[2] = start_.position.z;
+  I.start_vel[0] = start_.velocity.x; I.start_vel[1] = start_.velocity.y; I.start_vel[2] = start_.velocity.z;
+  I.rel_sweep_base = scan_time_ - sweep_start_;
+}
+
+void ImuTracker::apply_last(const ImuLast& L) {
+  cur_.roll = HAngle(L.roll); cur_.pitch = HAngle(L.pitch); cur_.yaw = HAngle(L.yaw);
+  cur_.position = {L.pos[0], L.pos[1], L.pos[2]};
+  cur_.velocity = {L.vel[0], L.vel[1], L.vel[2]};
+  shift_ = {L.shift[0], L.shift[1], L.shift[2]};
+  idx_ = L.idx;
 }
 
 // the (binned) input cloud of a sweep and its ring sizes

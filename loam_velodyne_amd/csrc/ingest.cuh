@@ -29,6 +29,9 @@ struct ImuLast {
   uint32_t idx, valid;
 };
 
+// device-side re-striding of a raw payload (x, y, z at 0 / 4 / 8 of every `stride` bytes) into float4 records
+void raw_unpack(const void* d_bytes, uint32_t stride, uint32_t n, float4* d_out, hipStream_t st);
+
 class RawBinner {
  public:
   static constexpr uint32_t MAX_RINGS = 256;

@@ -291,6 +291,18 @@ __global__ __launch_bounds__(256) void k_raw_scatter(const float4* __restrict__ 
 
 }  // namespace
 
+// raw records (x, y, z float32 at byte offsets 0 / 4 / 8, `stride` bytes apart) -> float4 (x, y, z, 0): the payload crosses PCIe as
+// it came and is re-strided on the device
+__global__ __launch_bounds__(256) void k_raw_unpack(const char* __restrict__ bytes, uint32_t stride, uint32_t n, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = (const float*)(bytes + (size_t)i * stride);
+  out[i] = make_float4(r[0], r[1], r[2], 0.f);
+}
+void raw_unpack(const void* d_bytes, uint32_t stride, uint32_t n, float4* d_out, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(k_raw_unpack, dim3((n + 255) / 256), dim3(256), 0, st, (const char*)d_bytes, stride, n, d_out);
+}
+
 void RawBinner::run(const float4* d_raw, uint32_t n, const MapperParams& m, float scan_period, float4* d_out, uint32_t* d_ring_cnt,
                     const ImuTable* imu, ImuLast* d_last) {
   LX_REQUIRE(m.n_rings >= 1 && m.n_rings <= MAX_RINGS, "n_scan_rings must be in [1, 256]");

@@ -38,7 +38,8 @@ struct PipeStreamState {
 class Pipeline {
  public:
   Pipeline(const loamx_scanreg_config& fc, const loamx_odom_config& oc, const loamx_map_config& mc, uint32_t n_streams)
-      : reg(mc.device, n_streams), odom(mc.device, n_streams, nullptr), fcfg(fc), n_streams_(n_streams), st(n_streams) {
+      : reg(mc.device, n_streams), odom(mc.device, n_streams, nullptr), fcfg(fc), n_streams_(n_streams), st(n_streams), imu(n_streams) {
+    for (auto& tr : imu) tr.history_size = std::max(200, fc.imu_history_size);
     reg.params.max_iterations = mc.max_iterations;
     reg.early_exit = true;   // step() blocks on M(t) anyway
     reg.params.delta_t_abort = mc.delta_t_abort;
@@ -70,6 +71,28 @@ class Pipeline {
   bool d2h_pending[2] = {false, false};
   uint32_t last_step = 0;
   std::vector<uint32_t> last_full_off;                   // offsets of the registered clouds of the last step (k-th mapped stream)
+  // Raw input (loamx_pipeline_stage_step_raw): per slot the payloads, their binned clouds and what the binning leaves behind
+  struct RawSlot {
+    bool raw = false, finalized = true;
+    std::vector<uint32_t> count, off;            // raw points per stream, their offsets in the slot's arrays
+    DevBuf<char> d_bytes;
+    DevBuf<float4> d_raw4, d_binned;
+    DevBuf<uint32_t> d_ring_cnt;                 // [stream][n_rings]
+    PinBuf<uint32_t> h_ring_cnt;
+    DevBuf<ImuLast> d_last;
+    PinBuf<ImuLast> h_last;
+    DevBuf<double> d_imu_d;
+    DevBuf<float> d_imu_f;
+    PinBuf<double> h_imu_d;
+    PinBuf<float> h_imu_f;
+    std::vector<uint32_t> imu_H;
+    std::vector<float> imu_trans;                // [stream][12], valid once finalized
+    hipEvent_t ev_ingest = nullptr;
+    uint32_t n_rings = 0;
+  };
+  RawSlot rawslot[RING];
+  std::vector<ImuTracker> imu;                   // one IMU state machine per stream
+  RawBinner binner;
   FeatureExtractor& FX(uint32_t t) { return *fx[streaming ? t % RING : t]; }
   char& LA(uint32_t t) { return launched[streaming ? t % RING : t]; }
   uint32_t n_staged() const { return streaming ? staged_hi : (uint32_t)fx.size(); }
@@ -166,6 +189,7 @@ class Pipeline {
     for (auto& tm : tmO) tm.destroy();
     for (auto& tm : tmM) tm.destroy();
     for (auto& e : ev_stage) if (e) (void)hipEventDestroy(e);
+    for (auto& r : rawslot) if (r.ev_ingest) (void)hipEventDestroy(r.ev_ingest);
     for (auto& e : ev_d2h) if (e) (void)hipEventDestroy(e);
     if (ev_reg_done) (void)hipEventDestroy(ev_reg_done);
     if (cstream) { (void)hipStreamSynchronize(cstream); (void)hipStreamDestroy(cstream); }
@@ -175,6 +199,7 @@ class Pipeline {
 
   void launch_features(uint32_t t) {
     TraceRange trace_range("loamx:features");
+    finalize_raw(t);
     FeatureExtractor& F = FX(t);
     const uint32_t ns = n_streams_, nring = F.total_rings();
     if (streaming) LX_HIP(hipStreamWaitEvent(fstream, ev_stage[t % RING], 0));   // this slot's H2D copies
@@ -217,11 +242,7 @@ class Pipeline {
     }
   }
 
-  // Streaming input: stage ONE step (sweep s of the step = clouds[s]) without blocking; steps arrive in order.  Slot t % RING
-  // is free once step t - RING has been registered, which the caller's own order of calls guarantees (stage(t) after step(t - RING)).
-  void stage_step(uint32_t t, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
-    LX_REQUIRE(clouds && ring_size && n_rings, "invalid argument");
-    LX_HIP(hipSetDevice(device));
+  void ensure_streaming_(uint32_t t) {
     if (!streaming) {   // first use: switch to the ring of slots
       LX_REQUIRE(t == 0, "streaming input starts at step 0");
       if (!fstream) fstream = create_stream(-1);
@@ -247,12 +268,125 @@ class Pipeline {
       staged_hi = 0;
       odom_ready_step = -1;
     }
+  }
+
+  // Streaming input: stage ONE step (sweep s of the step = clouds[s]) without blocking; steps arrive in order.  Slot t % RING
+  // is free once step t - RING has been registered, which the caller's own order of calls guarantees (stage(t) after step(t - RING)).
+  void stage_step(uint32_t t, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
+    LX_REQUIRE(clouds && ring_size && n_rings, "invalid argument");
+    LX_HIP(hipSetDevice(device));
+    ensure_streaming_(t);
     LX_REQUIRE(t == staged_hi, "steps must be staged in order");
     LX_REQUIRE(t < RING || last_step + RING > t, "stage_step(t) needs step(t - 4) to have run: only four steps can be in flight");
     TraceRange trace_range("loamx:pipeline:stage_step");
+    if (t > 0) finalize_raw(t - 1);
+    rawslot[t % RING].raw = false;
+    rawslot[t % RING].finalized = true;
     fx[t % RING]->upload_async(n_streams_, clouds, ring_size, n_rings, cstream, ev_stage[t % RING]);
     LA(t) = 0;
     staged_hi = t + 1;
+  }
+
+  // Raw input: step t as the sensor delivered it — per stream one revolution of (x, y, z) records in sensor axes and firing
+  // order (the /velodyne_points payload, MultiScanRegistration.cpp:160-238).  The payloads cross PCIe as they are and are
+  // re-strided, binned into rings and (with IMU data) de-skewed on the device, all on the copy stream; ring sizes and the IMU
+  // state the projection loop leaves behind come back through pinned memory and are consumed by finalize_raw().
+  void stage_step_raw(uint32_t t, const void* const* raw_xyz, const uint32_t* counts, uint32_t stride, const loamx_multiscan_mapper& mapper,
+                      const double* scan_time) {
+    LX_REQUIRE(raw_xyz && counts, "invalid argument");
+    LX_REQUIRE(stride >= 12 && stride % 4 == 0, "raw stride must be a multiple of 4 and at least 12");
+    LX_REQUIRE(mapper.n_scan_rings >= 1 && mapper.n_scan_rings <= RawBinner::MAX_RINGS, "n_scan_rings must be in [1, 256]");
+    LX_REQUIRE(mapper.upper_bound_deg != mapper.lower_bound_deg, "vertical bounds must differ");
+    LX_HIP(hipSetDevice(device));
+    ensure_streaming_(t);
+    LX_REQUIRE(t == staged_hi, "steps must be staged in order");
+    LX_REQUIRE(t < RING || last_step + RING > t, "stage_step_raw(t) needs step(t - 4) to have run: only four steps can be in flight");
+    TraceRange trace_range("loamx:pipeline:stage_step_raw");
+    if (t > 0) finalize_raw(t - 1);   // the IMU state machine advances sweep by sweep: this step's table needs the previous reset
+    const uint32_t ns = n_streams_, nr = mapper.n_scan_rings;
+    RawSlot& R = rawslot[t % RING];
+    R.raw = true;
+    R.finalized = false;
+    R.n_rings = nr;
+    R.count.assign(counts, counts + ns);
+    R.off.assign(ns + 1, 0);
+    for (uint32_t s = 0; s < ns; s++) {
+      LX_REQUIRE(raw_xyz[s] || counts[s] == 0, "NULL raw cloud");
+      R.off[s + 1] = R.off[s] + counts[s];
+    }
+    const uint32_t ntot = R.off[ns];
+    R.d_bytes.reserve((size_t)ntot * stride + 16);
+    R.d_raw4.reserve((size_t)ntot + 1);
+    R.d_binned.reserve((size_t)ntot + 1);
+    R.d_ring_cnt.reserve((size_t)ns * nr + 1);
+    R.h_ring_cnt.reserve((size_t)ns * nr + 1);
+    R.d_last.reserve(ns);
+    R.h_last.reserve(ns);
+    R.imu_H.assign(ns, 0);
+    R.imu_trans.assign((size_t)12 * ns, 0.f);
+    if (!R.ev_ingest) LX_HIP(hipEventCreateWithFlags(&R.ev_ingest, hipEventDisableTiming));
+    // IMU tables (one per stream with data), staged back to back
+    size_t Htot = 0;
+    for (uint32_t s = 0; s < ns; s++) { R.imu_H[s] = imu[s].size(); Htot += R.imu_H[s]; }
+    if (Htot) {
+      R.h_imu_d.reserve(2 * Htot); R.h_imu_f.reserve(9 * Htot); R.d_imu_d.reserve(2 * Htot); R.d_imu_f.reserve(9 * Htot);
+    }
+    MapperParams M;
+    M.lower = mapper.lower_bound_deg; M.upper = mapper.upper_bound_deg; M.n_rings = nr;
+    M.factor = (float)((int)nr - 1) / (mapper.upper_bound_deg - mapper.lower_bound_deg);   // MultiScanRegistration.cpp:41-50
+    binner.init(cstream);
+    LX_HIP(hipMemsetAsync(R.d_last.p, 0, sizeof(ImuLast) * ns, cstream));
+    size_t hbase = 0;
+    std::vector<ImuTable> tables(ns);
+    for (uint32_t s = 0; s < ns; s++) {
+      if (scan_time) imu[s].set_scan_time(scan_time[s]);
+      const uint32_t H = R.imu_H[s];
+      if (H) {
+        imu[s].fill_table(R.h_imu_d.p + 2 * hbase, R.h_imu_f.p + 9 * hbase, tables[s]);
+        tables[s].dt = R.d_imu_d.p + 2 * hbase;
+        tables[s].dstamp = R.d_imu_d.p + 2 * hbase + H;
+        tables[s].state = R.d_imu_f.p + 9 * hbase;
+        hbase += H;
+      }
+    }
+    if (Htot) {
+      LX_HIP(hipMemcpyAsync(R.d_imu_d.p, R.h_imu_d.p, sizeof(double) * 2 * Htot, hipMemcpyHostToDevice, cstream));
+      LX_HIP(hipMemcpyAsync(R.d_imu_f.p, R.h_imu_f.p, sizeof(float) * 9 * Htot, hipMemcpyHostToDevice, cstream));
+    }
+    for (uint32_t s = 0; s < ns; s++) {
+      const uint32_t n = counts[s];
+      if (n) LX_HIP(hipMemcpyAsync(R.d_bytes.p + (size_t)R.off[s] * stride, raw_xyz[s], (size_t)n * stride, hipMemcpyHostToDevice, cstream));
+      raw_unpack(R.d_bytes.p + (size_t)R.off[s] * stride, stride, n, R.d_raw4.p + R.off[s], cstream);
+      binner.run(R.d_raw4.p + R.off[s], n, M, fcfg.scan_period, R.d_binned.p + R.off[s], R.d_ring_cnt.p + (size_t)s * nr,
+                 R.imu_H[s] ? &tables[s] : nullptr, R.imu_H[s] ? R.d_last.p + s : nullptr);
+    }
+    LX_HIP(hipMemcpyAsync(R.h_ring_cnt.p, R.d_ring_cnt.p, sizeof(uint32_t) * ns * nr, hipMemcpyDeviceToHost, cstream));
+    LX_HIP(hipMemcpyAsync(R.h_last.p, R.d_last.p, sizeof(ImuLast) * ns, hipMemcpyDeviceToHost, cstream));
+    LX_HIP(hipEventRecord(R.ev_ingest, cstream));
+    LA(t) = 0;
+    staged_hi = t + 1;
+  }
+
+  // second half of a raw step's staging, once its binning has finished (long before it is needed in steady state): the IMU
+  // state machines take over what the projection loops left behind and are reset for the next sweep (processScanlines:
+  // reset(scanTime), updateIMUTransform), and the binned clouds are handed to the slot's feature extractor with their ring
+  // sizes.  Idempotent; called in step order from stage_step*(t + 1) and launch_features(t), whichever comes first.
+  void finalize_raw(uint32_t t) {
+    if (!streaming) return;
+    RawSlot& R = rawslot[t % RING];
+    if (!R.raw || R.finalized) return;
+    LX_HIP(hipEventSynchronize(R.ev_ingest));
+    const uint32_t ns = n_streams_, nr = R.n_rings;
+    std::vector<const uint32_t*> rs(ns);
+    std::vector<uint32_t> nrv(ns, nr);
+    for (uint32_t s = 0; s < ns; s++) {
+      if (R.imu_H[s] && R.h_last.p[s].valid) imu[s].apply_last(R.h_last.p[s]);
+      imu[s].begin_sweep();
+      memcpy(&R.imu_trans[12 * (size_t)s], imu[s].imu_trans(), sizeof(float) * 12);
+      rs[s] = R.h_ring_cnt.p + (size_t)s * nr;
+    }
+    fx[t % RING]->upload_device(ns, R.d_binned.p, R.off.data(), rs.data(), nrv.data(), cstream, ev_stage[t % RING]);
+    R.finalized = true;
   }
 
   // Registered full-resolution clouds of the step that just ran -> caller memory, asynchronously on a copy stream (the next
@@ -313,6 +447,8 @@ class Pipeline {
       tm.pending = false;
       LX_HIP(hipEventRecord(tm.a, odom.stream()));
     }
+    if (streaming && rawslot[t % RING].raw)   // imuTrans of this sweep (ScanRegistration publishes it with the clouds; LaserOdometry.cpp:239-248)
+      for (uint32_t s = 0; s < ns; s++) odom.update_imu(s, &rawslot[t % RING].imu_trans[12 * (size_t)s]);
     odom.process(in.data(), rc.data(), true);   // returns once the poses are known; clouds ready at odom.tail_event()
     trO[2] = tr_us();
     if (timing) {
@@ -558,6 +694,21 @@ int loamx_pipeline_upload(loamx_pipeline* h, uint32_t n_steps, const loamx_cloud
 }
 int loamx_pipeline_stage_step(loamx_pipeline* h, uint32_t step, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
   return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->p.stage_step(step, clouds, ring_size, n_rings); return LOAMX_OK; });
+}
+int loamx_pipeline_stage_step_raw(loamx_pipeline* h, uint32_t step, const void* const* raw_xyz, const uint32_t* counts, uint32_t stride,
+                                  const loamx_multiscan_mapper* mapper, const double* scan_time_sec) {
+  return guard([&]() {
+    LX_REQUIRE(h && mapper, "NULL argument");
+    h->p.stage_step_raw(step, raw_xyz, counts, stride, *mapper, scan_time_sec);
+    return LOAMX_OK;
+  });
+}
+int loamx_pipeline_update_imu(loamx_pipeline* h, uint32_t stream, double stamp_sec, float roll, float pitch, float yaw, const float acc_xyz[3]) {
+  return guard([&]() {
+    LX_REQUIRE(h && acc_xyz && stream < h->p.n_streams_, "invalid argument");
+    h->p.imu[stream].update(stamp_sec, roll, pitch, yaw, acc_xyz);
+    return LOAMX_OK;
+  });
 }
 int loamx_pipeline_enable_async_downloads(loamx_pipeline* h) {
   return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->p.reg.double_buffer_full = true; return LOAMX_OK; });

@@ -567,6 +567,29 @@ class Pipeline:
             self._staged = {}
         self._staged[t % 8] = (pts, rings, CA, RP, NR)
 
+    def stage_step_raw(self, t: int, raws, sensor="VLP-16", mapper=None, scan_times=None):
+        """streaming raw input: raws[s] = (N,3) float32 C-contiguous sensor-frame points in firing order (kept alive here)"""
+        ns = self.n_streams
+        assert len(raws) == ns
+        arrs = [np.ascontiguousarray(r, np.float32).reshape(-1, 3) for r in raws]
+        m = MultiScanMapper()
+        if mapper is None:
+            _check(lib().loamx_multiscan_mapper_preset(sensor.encode(), C.byref(m)))
+        else:
+            m.lower_bound_deg, m.upper_bound_deg, m.n_scan_rings = float(mapper[0]), float(mapper[1]), int(mapper[2])
+        PP = (C.c_void_p * ns)(*[a.ctypes.data if len(a) else None for a in arrs])
+        CN = (C.c_uint32 * ns)(*[len(a) for a in arrs])
+        st = (C.c_double * ns)(*[float(x) for x in scan_times]) if scan_times is not None else None
+        _check(lib().loamx_pipeline_stage_step_raw(self.h, t, PP, CN, 12, C.byref(m), st))
+        if not hasattr(self, "_staged"):
+            self._staged = {}
+        self._staged[t % 8] = (arrs, PP, CN, st)
+
+    def update_imu(self, stream: int, stamp, roll, pitch, yaw, acc):
+        a = np.ascontiguousarray(acc, np.float32)
+        _check(lib().loamx_pipeline_update_imu(self.h, stream, C.c_double(stamp), C.c_float(roll), C.c_float(pitch), C.c_float(yaw),
+                                               a.ctypes.data_as(C.c_void_p)))
+
     def enable_async_downloads(self):
         _check(lib().loamx_pipeline_enable_async_downloads(self.h))
 

@@ -225,3 +225,116 @@ def test_streaming_io_equals_staged_run(orc, small_world):
         assert np.array_equal(bufs[k][:counts[k]], ref_full[pt][k])
     with pytest.raises(loamx.LoamxError):                            # out of order
         b.stage_step(T + 3, sweeps[0])
+
+
+def _raw_run(small_world, T=6, with_imu=False, sensor="VLP-16", az=900):
+    """two streams of raw VLP-16 revolutions (a few NaN / zero returns), optional IMU messages for stream 0"""
+    ns = 2
+    raws, times = [[None] * ns for _ in range(T)], [[0.0] * ns for _ in range(T)]
+    starts = []
+    for s in range(ns):
+        poses = synth.trajectory(T, start=(1.5 * s, 0.0, 2.0 * s))
+        starts.append(np.array([0, 0, 0, 1.5 * s, 0, 2.0 * s], np.float32))
+        for t in range(T):
+            sw = synth.make_sweep(small_world, sensor, poses[t], poses[t + 1], seed=60 * s + t, az_steps=az)
+            raws[t][s] = synth.to_raw(sw, bad_every=41 + s)
+            times[t][s] = 0.1 * (t + 1)
+    imu_msgs = []
+    if with_imu:
+        t_imu = 0.0
+        while t_imu < 0.1 * (T + 1) + 0.05:
+            imu_msgs.append((t_imu, 0.004 * np.sin(3 * t_imu), 0.003 * np.cos(2 * t_imu), 0.05 * t_imu, (0.3 * np.sin(5 * t_imu), 0.05, -0.2 * np.cos(4 * t_imu))))
+            t_imu += 0.0031
+    return raws, times, starts, imu_msgs
+
+
+@pytest.mark.parametrize("sensor,az", [("VLP-16", 900), ("HDL-32", 700), ("HDL-64E", 512)])
+def test_raw_sweeps_into_the_pipeline_equal_binned_rings(orc, small_world, sensor, az):
+    """loamx_pipeline_stage_step_raw without IMU data: the step consumes /velodyne_points payloads; bit-identical to the run that is
+    fed the rings the single-sweep entry point bins (loamx_scanreg_process_raw) — i.e. to MultiScanRegistration.cpp:160-238 + the rest"""
+    T, ns = 5, 2
+    raws, _, starts, _ = _raw_run(small_world, T, sensor=sensor, az=az)
+    cm, sm = small_world.make_map(60000)
+
+    def make():
+        p = loamx.Pipeline(ns)
+        p.set_frozen(cm, sm)
+        for s in range(ns):
+            p.set_state(s, aft=starts[s])
+        return p
+    sr = loamx.ScanRegistration()
+    binned = [[None] * ns for _ in range(T)]
+    for t in range(T):
+        for s in range(ns):
+            g = sr.process_raw(raws[t][s], sensor)
+            binned[t][s] = (g["full"], g["ring_sizes"])
+            if t == 0:                                   # ... whose binning is the oracle's (= the reference's, tests/test_ref_pinning.py)
+                o_pts, o_rs = op.multiscan_bin(orc, raws[t][s], sensor)
+                assert np.array_equal(g["ring_sizes"], o_rs) and np.array_equal(g["full"][:, :3], o_pts[:, :3])
+    a = make()
+    a.upload(binned)
+    b = make()
+    for t in range(3):
+        b.stage_step_raw(t, raws[t], sensor)
+    for t in range(T):
+        ra, rb = a.step(t), b.step(t)
+        assert ra == rb
+        if t + 3 < T:
+            b.stage_step_raw(t + 3, raws[t + 3], sensor)
+        for s in range(ns):
+            ga, gb = a.get(s), b.get(s)
+            for i in range(3):
+                assert np.array_equal(ga[i], gb[i]), (t, s, i)
+            assert ga[3] == gb[3]
+
+
+def test_raw_sweeps_with_imu_feeds(orc, small_world):
+    """per-stream IMU feeds (loamx_pipeline_update_imu): stream 0 gets IMU messages, stream 1 none.  The de-skewed sweeps, the
+    imuTransform plugged into the odometry and the registration follow the oracle chain (ScanRegistration with IMU ->
+    LaserOdometry.updateIMU -> frozen-map registration) within the pose bar; stream 1 is untouched by its neighbour's IMU."""
+    T, ns = 6, 2
+    raws, times, starts, imu_msgs = _raw_run(small_world, T, with_imu=True)
+    cm, sm = small_world.make_map(60000)
+    p = loamx.Pipeline(ns)
+    p.set_frozen(cm, sm)
+    q = loamx.Pipeline(ns)                      # the same run without any IMU data
+    q.set_frozen(cm, sm)
+    for s in range(ns):
+        p.set_state(s, aft=starts[s])
+        q.set_state(s, aft=starts[s])
+    osr, ood, omp = op.ScanRegistration(orc), op.LaserOdometry(orc), op.LaserMapping(orc)
+    omp.set_frozen(cm, sm)
+    omp.set_transform("aft", starts[0])
+    # every IMU message is on both sides before the first sweep (the order in which messages and sweeps interleave changes what
+    # reset() can interpolate — ROS timing, not arithmetic — so the comparison fixes it; the 200-deep history wraps on both sides alike)
+    for m in imu_msgs:
+        p.update_imu(0, *m)
+        osr.update_imu(*m)
+    for t in range(3):
+        p.stage_step_raw(t, raws[t], "VLP-16", scan_times=times[t])
+        q.stage_step_raw(t, raws[t], "VLP-16", scan_times=times[t])
+    worst = 0.0
+    for t in range(T):
+        p.step(t)
+        q.step(t)
+        if t + 3 < T:
+            p.stage_step_raw(t + 3, raws[t + 3], "VLP-16", scan_times=times[t + 3])
+            q.stage_step_raw(t + 3, raws[t + 3], "VLP-16", scan_times=times[t + 3])
+        o = osr.process_raw(raws[t][0], times[t][0], "VLP-16")
+        ood.update_imu(o["imu_trans"])
+        ood.set_features(o)
+        ood.process()
+        if t > 0:
+            omp.set_transform("sum", ood.transform_sum)
+            pose = omp.register_frozen(ood.last_corner(), ood.last_surf(), omp.associate())
+            omp.set_transform("bef", ood.transform_sum)
+            omp.set_transform("aft", pose)
+        g0, g1, h1 = p.get(0), p.get(1), q.get(1)
+        worst = max(worst, float(np.abs(g0[1] - ood.transform_sum).max()))
+        assert np.abs(g0[1] - ood.transform_sum).max() < POSE_TOL, (t, g0[1], ood.transform_sum)
+        if t > 0:
+            assert np.abs(g0[2] - omp.transform("aft")).max() < POSE_TOL, t
+        for i in range(3):                                                         # the stream without IMU data is bit-identical
+            assert np.array_equal(g1[i], h1[i]), (t, i)
+    assert not np.array_equal(p.get(0)[1], q.get(0)[1])                            # ... and the IMU really acted on stream 0
+    print("worst odometry difference vs the oracle chain with IMU:", worst)

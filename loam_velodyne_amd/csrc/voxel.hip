@@ -104,7 +104,7 @@ __device__ inline void grid_barrier(GridSync& g) {
     const uint32_t target = g.epoch * gridDim.x;
     uint32_t spins = 0;
     while (__hip_atomic_load(g.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_s_sleep(32);   // ~1 us between polls: a hundred workgroups hammering one counter slow the L2 channel for everybody
       if (++spins > VDS_SPIN_LIMIT) { *g.err = 1u; sh_fail = 1; break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // acquire the other workgroups' writes
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_vox_ds(const VdsArgs A) {
           for (int u = 0; u < VDS_LOOK; u++) {
             uint32_t spins = 0;
             while (v[u] == 0u) {   // a predecessor that has not published yet
-              __builtin_amdgcn_s_sleep(2);
+              __builtin_amdgcn_s_sleep(16);
               v[u] = __hip_atomic_load(&st[(size_t)(t0 + u) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               if (++spins > VDS_SPIN_LIMIT) { *A.err = 1u; v[u] = 1u; }
             }

@@ -41,21 +41,21 @@ def main():
             h, m = sum(T[k].get('TCC_HIT_sum', [])), sum(T[k].get('TCC_MISS_sum', []))
             e['l2_hit_rate'] = round(h / (h + m), 4) if h + m else None
         kernels[k] = e
-    res = {'command': 'rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline'
+    res = {'command': 'rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-pcie'
                       '  (one pass per counter set: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum)',
            'units': 'FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3; fetch_bytes_corrected = 2 x FETCH_SIZE x 1024 '
                     '(MI355X_MICROARCH.md, HBM section: upper estimate for gather patterns)',
            'kernels': kernels}
-    kn = [k for k in kernels if 'k_knn5' in k]
-    if kn:
-        k = kn[0]
-        fr = kernels[k]['fetch_kib_max'] * 1024
-        wr = kernels[k]['write_kib_max'] * 1024
-        res['k_knn5_full_search_launch'] = {'fetch_bytes_raw': int(fr), 'fetch_bytes_corrected': int(2 * fr), 'write_bytes': int(wr),
-                                            'traffic_bytes': int(2 * fr + wr)}
+    for tag, key in (('k_gn_iter', 'k_gn_iter_full_launch'), ('k_knn5', 'k_knn5_full_search_launch'), ('k_vox_ds', 'k_vox_ds_launch')):
+        kn = [k for k in kernels if tag in k]
+        if kn:
+            k = kn[0]
+            fr = kernels[k]['fetch_kib_max'] * 1024
+            wr = kernels[k]['write_kib_max'] * 1024
+            res[key] = {'fetch_bytes_raw': int(fr), 'fetch_bytes_corrected': int(2 * fr), 'write_bytes': int(wr), 'traffic_bytes': int(2 * fr + wr)}
+            print(key, res[key])
     json.dump(res, open(out, 'w'), indent=1)
     print('wrote', out, 'kernels', len(kernels))
-    if kn: print(res['k_knn5_full_search_launch'])
 
 
 if __name__ == '__main__':

@@ -12,6 +12,7 @@
 //                  the de-skew chain rule, J^T J / J^T r reduced with wave shuffles (double accumulators), thread 0:
 //                  6x6 pivoted QR solve, degeneracy projector, update, convergence test.
 #include "odometry.cuh"
+#include <type_traits>
 
 namespace loamx {
 
@@ -260,8 +261,15 @@ __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ pro
 #else
 #define LM_TS(k) do { } while (0)
 #endif
+// 4 waves per SIMD (<= 128 VGPRs) and 36 KB of LDS: the persistent workgroups of a stream have to find room next to the wide
+// registration / feature kernels of the other HIP streams — at 226 VGPRs + 61 KB they waited for half-empty CUs
+#ifndef OD_LM_ATTR
+#define OD_LM_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"   // (the two-features-per-thread variant keeps 64 KB of LDS and cannot reach that occupancy)
 template <int OD_FPT>
-__global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict__ probs, OdomParams P, int iter0, int n_iters) {
+__global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* __restrict__ probs, OdomParams P, int iter0, int n_iters) {
   OdomProblem& pb = probs[blockIdx.y];
   if (pb.done) return;
   const unsigned NB = gridDim.x;
@@ -270,11 +278,16 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
   __shared__ float T[6];
   __shared__ float trig[6];
   __shared__ double red[8][LX_NSUM];
-  __shared__ double tr[LX_NSUM * OD_TR_STRIDE];
+  // one feature per thread (the usual case): the 28 products of a row are formed in float and go to LDS as floats — half the
+  // LDS and no 56-register double accumulator; the column sums convert to double exactly as before ((double)product, same order).
+  // Two features per thread: their two products are added in double first, so the table stays double.
+  using TrT = typename std::conditional<OD_FPT == 1, float, double>::type;
+  __shared__ TrT tr[LX_NSUM * OD_TR_STRIDE];
   __shared__ int sh_done, sh_degen;
   __shared__ float matP[36];
   __shared__ float ws[216];
   __shared__ double sums[LX_NSUM];
+  __shared__ double parts[16 * LX_NSUM];   // the partial sums of the stream's (<= 16) workgroups
   __shared__ float AtA[36], AtB[6], X[6], X2[6];
   if (tid < 6) T[tid] = pb.transform[tid];
   if (tid == 0) { sh_done = 0; sh_degen = pb.stats.degenerate; }
@@ -313,9 +326,11 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
     }
     __syncthreads();
     LM_TS(1);
-    double v[LX_NSUM];
+    double v[OD_FPT == 1 ? 1 : LX_NSUM];
+    float a1[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bb1 = 0.f;   // OD_FPT == 1: the row of this thread's feature (zeros when not selected)
+    bool sel1 = false;
 #pragma unroll
-    for (int k = 0; k < LX_NSUM; k++) v[k] = 0.0;
+    for (int k = 0; k < (OD_FPT == 1 ? 1 : LX_NSUM); k++) v[k] = 0.0;
 #pragma unroll
     for (int u = 0; u < OD_FPT; u++) {
       if (!fvalid[u]) continue;
@@ -381,29 +396,47 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
         a[4] = -(cry * srz + crz * srx * sry) * cx - crx * crz * cy - (sry * srz - cry * crz * srx) * cz;
         a[5] = crx * sry * cx - srx * cy - crx * cry * cz;
         const float bb = (float)(-0.05 * (double)ci);
-        int k = 0;
+        if (OD_FPT == 1) {
 #pragma unroll
-        for (int i = 0; i < 6; i++)
+          for (int i = 0; i < 6; i++) a1[i] = a[i];
+          bb1 = bb;
+          sel1 = true;
+        } else {
+          int k = 0;
 #pragma unroll
-          for (int j = i; j < 6; j++) v[k++] += (double)(a[i] * a[j]);
+          for (int i = 0; i < 6; i++)
 #pragma unroll
-        for (int i = 0; i < 6; i++) v[k++] += (double)(a[i] * bb);
-        v[k] += 1.0;
+            for (int j = i; j < 6; j++) v[k++] += (double)(a[i] * a[j]);
+#pragma unroll
+          for (int i = 0; i < 6; i++) v[k++] += (double)(a[i] * bb);
+          v[k] += 1.0;
+        }
       }
     }
     LM_TS(2);
     // transposed reduction through LDS (28 dependent 64-bit shuffle chains cost ~6 us; this is < 1 us): column c of the
     // 256 x 28 table is summed by 8 threads (rows g, g+8, ...), then the 8 strands in order — a fixed order, so the
     // sums are deterministic
+    if (OD_FPT == 1) {
+      int k = 0;
 #pragma unroll
-    for (int t = 0; t < LX_NSUM; t++) tr[t * OD_TR_STRIDE + tid] = v[t];
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++) tr[(k++) * OD_TR_STRIDE + tid] = (TrT)(a1[i] * a1[j]);
+#pragma unroll
+      for (int i = 0; i < 6; i++) tr[(k++) * OD_TR_STRIDE + tid] = (TrT)(a1[i] * bb1);
+      tr[k * OD_TR_STRIDE + tid] = (TrT)(sel1 ? 1.f : 0.f);
+    } else {
+#pragma unroll
+      for (int t = 0; t < LX_NSUM; t++) tr[t * OD_TR_STRIDE + tid] = (TrT)v[OD_FPT == 1 ? 0 : t];
+    }
     __syncthreads();
     if (tid < 8 * LX_NSUM) {
       const int c = tid % LX_NSUM, g = tid / LX_NSUM;
-      const double* col = tr + c * OD_TR_STRIDE + g;
+      const TrT* col = tr + c * OD_TR_STRIDE + g;
       double x = 0.0;
 #pragma unroll 8
-      for (int j = 0; j < OD_THREADS / 8; j++) x += col[8 * j];
+      for (int j = 0; j < OD_THREADS / 8; j++) x += (double)col[8 * j];
       red[g][c] = x;
     }
     __syncthreads();
@@ -431,11 +464,11 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
       __syncthreads();
       LM_TS(5);
       for (unsigned e = tid; e < NB * LX_NSUM; e += OD_THREADS)
-        tr[e] = __hip_atomic_load(&pb.part[((unsigned)iter & 1u) * 16u * LX_NSUM + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        parts[e] = __hip_atomic_load(&pb.part[((unsigned)iter & 1u) * 16u * LX_NSUM + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
       if (tid < LX_NSUM) {
         double x = 0.0;
-        for (unsigned b = 0; b < NB; b++) x += tr[b * LX_NSUM + tid];   // workgroup order: deterministic
+        for (unsigned b = 0; b < NB; b++) x += parts[b * LX_NSUM + tid];   // workgroup order: deterministic
         sums[tid] = x;
       }
       __syncthreads();
@@ -519,6 +552,8 @@ __global__ __launch_bounds__(OD_THREADS) void k_odom_lm(OdomProblem* __restrict_
     if (sh_done) break;
   }
 }
+
+#pragma clang diagnostic pop
 
 // transformToEnd (:57-87) of one point
 __device__ inline float4 to_end_point(float4 p, const ToEndParams& P) {

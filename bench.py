@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 STREAMS_PER_GPU = 8
+LAUNCH_TIMING_PERIOD = 4  # steps between two that carry HIP-event pairs around every k_gn_iter launch (roofline.achieved)
 HANDLES_PER_GPU = 1      # >1: split the streams over several pipeline handles driven from host threads (measured: no gain)
 SENSOR = "HDL-64E"
 MAP_POINTS = 1_000_000
@@ -171,6 +172,7 @@ def main():
     res_ms = 0.0
     res_launches = 0
     q_iters = 0
+    q_iters_timed = 0   # query-iterations of the steps whose launches carried event pairs
     queries = 0
     # double-buffered map epochs (off by default): epoch k+1 is broadcast and indexed in the background during epoch k
     # and swapped in before the first step of epoch k+1
@@ -207,14 +209,19 @@ def main():
                     ev = ev_map.cuda_event
                 for p in pipes:   # the index build waits for the event on the device; nothing blocks here
                     p.stage_frozen_device(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, ev)
+        sampled = (t - (1 + W)) % LAUNCH_TIMING_PERIOD == 0   # event pairs around the Gauss-Newton launches: every 4th step (they cost ~3 %)
+        for p in pipes:
+            p.set_timing(True, per_launch=sampled)
         run_step(t)
         for p in pipes:   # event read-back of the step that just finished (the step itself is synchronous)
             tm = p.timing()
             stage += np.array([tm["features_ms"], tm["odometry_ms"], tm["registration_ms"], tm["step_ms"]]) / H
-            res_ms += tm["residual_ms"]
-            res_launches += tm["residual_launches"]
             q_iters += tm["query_iterations"]
             queries += tm["queries"]
+            if sampled:
+                res_ms += tm["residual_ms"]
+                res_launches += tm["residual_launches"]
+                q_iters_timed += tm["query_iterations"]
     sync_all()
     elapsed = time.perf_counter() - t0
     elapsed = lxdist.max_over_ranks(elapsed, dist, dev)
@@ -251,7 +258,7 @@ def main():
         k_feat = 36 * synth.SENSORS[args.sensor][0]   # (2 sharp + 4 flat) x 6 regions per ring
         bytes_per_sweep = 32 * n_points + 16 * M / (ns * K) + 72 * (q_iters / max(ns * K, 1)) + 48 * iters_odom * k_feat
         avg_launch_ms = res_ms / max(res_launches, 1)
-        achieved = (72.0 * q_iters / max(res_launches, 1)) / (avg_launch_ms * 1e-3) / 1e9 if res_launches else 0.0
+        achieved = (72.0 * q_iters_timed / max(res_launches, 1)) / (avg_launch_ms * 1e-3) / 1e9 if res_launches else 0.0
         out = {
             "metric": "sweeps/sec (64-ring, 1M-pt map): feature extraction + odometry + scan-to-map registration",
             "value": round(value, 2),
@@ -301,7 +308,8 @@ def main():
                          "forms the 28 normal-equation sums and runs the 6x6 update step",
                 "avg_launch_us": round(avg_launch_ms * 1e3, 3),
                 "launches": res_launches,
-                "algorithmic_bytes_per_launch": round(72.0 * q_iters / max(res_launches, 1), 1),
+                "launch_sampling": f"HIP-event pairs around every k_gn_iter launch on every {LAUNCH_TIMING_PERIOD}th step of the timed region (the pairs cost ~3 % of a step)",
+                "algorithmic_bytes_per_launch": round(72.0 * q_iters_timed / max(res_launches, 1), 1),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

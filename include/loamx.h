@@ -340,6 +340,8 @@ int loamx_pipeline_download_full_res(loamx_pipeline* h, uint32_t slot, loamx_clo
  * identical; loamx_pipeline_get() always reports the sweep that was registered last.  Turn it off when per-stream
  * state is changed with loamx_pipeline_set_state() between steps. */
 int loamx_pipeline_set_lookahead(loamx_pipeline* h, int on);
+/* HIP-event timing of the stages: 0 off, 1 stage events + an event pair around every Gauss-Newton launch, 2 stage events only
+ * (the pairs cost ~3 % of a step: a caller that wants both the rate and the launch durations samples them, as bench.py does). */
 int loamx_pipeline_set_timing(loamx_pipeline* h, int on);
 /* stage_ms: features, odometry, registration, whole step (HIP events on the pipeline's stream);
  * reg_ms / counts as loamx_batch_get_timing */

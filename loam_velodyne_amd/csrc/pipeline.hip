@@ -751,7 +751,7 @@ int loamx_pipeline_set_timing(loamx_pipeline* h, int on) {
   return guard([&]() {
     LX_REQUIRE(h, "NULL handle");
     h->p.timing = on != 0;
-    h->p.reg.set_timing(on != 0);
+    h->p.reg.set_timing(on != 0, on != 2);
     return LOAMX_OK;
   });
 }

@@ -131,7 +131,7 @@ class Registrar {
 
   // parity hook (loamx_batch_knn_probe): exact 5-NN of n map-frame points in the corner (0) / surf (1) sub-map index
   void knn_probe(int which, const float* xyz, uint32_t n, uint32_t* idx5, float* d2_5);
-  void set_timing(bool on) { timing_ = on; }
+  void set_timing(bool on, bool per_launch = true) { timing_ = on; launch_timing_ = per_launch; }   // per_launch: event pairs around every Gauss-Newton launch
   void get_timing(float ms[4], uint64_t counts[4]);
   uint32_t n_sweeps() const { return n_sweeps_; }
   bool submap_sufficient() const { return corner_index.size() > 10 && surf_index.size() > 100; }
@@ -140,7 +140,7 @@ class Registrar {
   int device_;
   uint32_t max_sweeps_, n_sweeps_ = 0;
   hipStream_t st_ = nullptr;
-  bool timing_ = false, timed_run_ = false;
+  bool timing_ = false, timed_run_ = false, launch_timing_ = true;
 
   // owned copies of a host-provided sub-map
   DevBuf<float4> own_corner_, own_surf_;

@@ -1295,7 +1295,7 @@ void Registrar::run_iterations(bool trace, double& th2, double& th3) {
   while (it < params.max_iterations) {
     const int end = std::min(params.max_iterations, it + chunk);
     for (; it < end; it++) {
-      const bool tm = timing_ && n_res_launch_ < 64;
+      const bool tm = timing_ && launch_timing_ && n_res_launch_ < 64;
       if (tm) LX_HIP(hipEventRecord(ev_[2 + 2 * n_res_launch_], st_));
       a.iter = it;
       hipLaunchKernelGGL(k_gn_iter, grid, dim3(LX_RES_THREADS), 0, st_, a);

@@ -105,7 +105,7 @@ class VoxelPipeline {
   size_t zero_words_ = 0;
   DevBuf<float4> gathered_;   // the points in sorted order
   PinBuf<uint32_t> h_err_;
-  uint32_t slots_ = 0;
+  uint32_t slots_ = 0, slots_seg_ = 0;
 };
 
 }  // namespace loamx

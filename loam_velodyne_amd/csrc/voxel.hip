@@ -1,5 +1,6 @@
 // Segmented voxel-grid down-sampling kernels (see voxel.cuh).
 #include "voxel.cuh"
+#include <vector>
 
 namespace loamx {
 
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void k_vox_ijk(const float4* __restrict__ pts,
 // ----------------------------------------------------------------------------------------------------------------
 #ifdef LOAMX_PROF_VDS
 __device__ unsigned long long g_vds_ts[64];
+__device__ unsigned long long g_vds_arr[16][1024][2];   // per barrier, per workgroup: arrival, exit
 __device__ int g_vds_n;
 #define VDS_TS() do { if (blockIdx.x == 0 && threadIdx.x == 0) { int k_ = g_vds_n; if (k_ < 64) { g_vds_ts[k_] = wall_clock64(); g_vds_n = k_ + 1; } } } while (0)
 #else
@@ -60,6 +62,9 @@ __device__ int g_vds_n;
 constexpr int VDS_TILE = 2048;
 constexpr int VDS_LOOK = 32;          // predecessor counts fetched at once        // elements per tile (8 per thread)
 constexpr uint32_t VDS_SPIN_LIMIT = 1u << 20;
+constexpr int VDS_ROW = 256 + 64;     // words between two tiles' published counts: not a power of two, so that the rows a look-back
+                                      // fetches together fall on different memory channels
+
 
 struct VdsArgs {
   const float4* pts;
@@ -99,6 +104,9 @@ __device__ inline void grid_barrier(GridSync& g) {
   g.epoch++;
   if (threadIdx.x == 0) {
     sh_fail = 0;
+#ifdef LOAMX_PROF_VDS
+    if (g.epoch <= 16 && blockIdx.x < 1024) g_vds_arr[g.epoch - 1][blockIdx.x][0] = wall_clock64();
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // release this workgroup's writes
     atomicAdd(g.counter, 1u);
     const uint32_t target = g.epoch * gridDim.x;
@@ -108,6 +116,9 @@ __device__ inline void grid_barrier(GridSync& g) {
       if (++spins > VDS_SPIN_LIMIT) { *g.err = 1u; sh_fail = 1; break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // acquire the other workgroups' writes
+#ifdef LOAMX_PROF_VDS
+    if (g.epoch <= 16 && blockIdx.x < 1024) g_vds_arr[g.epoch - 1][blockIdx.x][1] = wall_clock64();
+#endif
   }
   __syncthreads();
   if (sh_fail) g.ok = false;
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(256) void k_vox_ds(const VdsArgs A) {
     const uint32_t* __restrict__ vsrc = A.vals[p & 1];
     unsigned long long* __restrict__ kdst = A.keys[(p & 1) ^ 1];
     uint32_t* __restrict__ vdst = A.vals[(p & 1) ^ 1];
-    uint32_t* st = A.status + (size_t)p * ntiles * 256;
+    uint32_t* st = A.status + (size_t)p * ntiles * VDS_ROW;
     {
       uint32_t tot;
       const uint32_t ex = block_excl_scan(A.gh[p * 256 + tid], s_scan, tot);
@@ -248,22 +259,23 @@ __global__ __launch_bounds__(256) void k_vox_ds(const VdsArgs A) {
         uint32_t run = 0;
 #pragma unroll
         for (int w = 0; w < 4; w++) { const uint32_t c = s_wcnt[w][tid]; s_wcnt[w][tid] = run; run += c; }
-        __hip_atomic_store(&st[(size_t)tile * 256 + tid], run + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&st[(size_t)tile * VDS_ROW + tid], run + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t excl = 0;
         for (uint32_t t0 = 0; t0 < tile; t0 += VDS_LOOK) {
           uint32_t v[VDS_LOOK];
+          uint32_t spins = 0;
+          for (;;) {   // the whole batch is re-fetched while any predecessor is unpublished: one round trip per retry, not per tile
+            bool pending = false;
 #pragma unroll
-          for (int u = 0; u < VDS_LOOK; u++) v[u] = (t0 + u < tile) ? __hip_atomic_load(&st[(size_t)(t0 + u) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+            for (int u = 0; u < VDS_LOOK; u++) v[u] = (t0 + u < tile) ? __hip_atomic_load(&st[(size_t)(t0 + u) * VDS_ROW + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
 #pragma unroll
-          for (int u = 0; u < VDS_LOOK; u++) {
-            uint32_t spins = 0;
-            while (v[u] == 0u) {   // a predecessor that has not published yet
-              __builtin_amdgcn_s_sleep(16);
-              v[u] = __hip_atomic_load(&st[(size_t)(t0 + u) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (++spins > VDS_SPIN_LIMIT) { *A.err = 1u; v[u] = 1u; }
-            }
-            excl += v[u] - 1u;
+            for (int u = 0; u < VDS_LOOK; u++) pending |= v[u] == 0u;
+            if (!pending) break;
+            if (++spins > VDS_SPIN_LIMIT) { *A.err = 1u; break; }
+            __builtin_amdgcn_s_sleep(4);
           }
+#pragma unroll
+          for (int u = 0; u < VDS_LOOK; u++) excl += v[u] ? v[u] - 1u : 0u;
         }
         s_toff[tid] = excl;
       }
@@ -402,6 +414,396 @@ __global__ __launch_bounds__(256) void k_vox_ds(const VdsArgs A) {
   VDS_TS();
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// k_vox_ds_seg: the same job for the common case of CONTIGUOUS segments (seg_off given, every slot valid, <= 256 segments:
+// the registration's stack clouds — sweep x {corner, surf}).  The input is already grouped by segment, so nothing has to be
+// sorted across segments: tiles never straddle a segment, the key is the linear voxel index alone (<= 31 bits, typically
+// 23-26 -> 3 passes of 9-bit digits instead of 4 of 8), digit histograms and bases are per segment, and a tile's look-back only
+// covers the earlier tiles of its own segment (<= 17 for a 33 k-point surf cloud instead of all 146 tiles of the batch).
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int VSEG_DB = 9, VSEG_NB = 1 << VSEG_DB, VSEG_ROW = VSEG_NB + 64;   // digit bits / bins
+constexpr int VSEG_MAXSEG = 256;
+constexpr int VSEG_IDX = 24;                         // low bits of a sort element: the point's position inside its segment
+constexpr int VSEG_MAXPASS = 4;                      // 31 bits / 9
+
+// Work distribution that does not depend on how many workgroups are resident.  In the first phase the tiles are CLAIMED from a
+// counter; a workgroup keeps the tiles it claimed for all later phases (it walks them through `link`), and a phase is complete
+// when its tiles are — not when every workgroup of the grid has arrived.  A workgroup the dispatcher has not started yet thus
+// owns nothing anybody waits for: several of these kernels run side by side on a process's streams and may together exceed the
+// device, where a classic grid barrier would let two half-resident launches wait for each other forever.  Look-backs stay safe
+// too: the claim counter is monotonic, so every tile below a claimed one belongs to a workgroup that is running, and tiles
+// publish before they look back.  The claim of the NEXT tile is issued before the current one is processed, so its round trip
+// is never exposed.
+struct TileSync {
+  uint32_t* next;   // tiles claimed (first phase)
+  uint32_t* done;   // [phase]  tiles completed
+  uint32_t* link;   // [tile]   the next tile of the same workgroup (VSEG_NONE: last)
+  uint32_t* err;
+  uint32_t ntiles;
+  uint32_t first;   // the workgroup's first tile
+  uint32_t seen;    // thread 0: done[phase] as read right after the workgroup's last completion
+  bool ok;
+};
+constexpr uint32_t VSEG_NONE = 0xffffffffu;
+
+// thread 0's view of the tile after `tile`: claimed (first phase) or read from the workgroup's list
+__device__ inline uint32_t tile_peek(const TileSync& g, uint32_t ph, uint32_t tile) {
+  if (threadIdx.x != 0) return VSEG_NONE;
+  if (ph == 0) {
+    const uint32_t c = atomicAdd(g.next, 1u);
+    return c < g.ntiles ? c : VSEG_NONE;
+  }
+  return g.link[tile];
+}
+// the workgroup finished `tile` of phase ph (nxt: thread 0's tile_peek, taken before the tile was processed)
+__device__ inline uint32_t tile_done(TileSync& g, uint32_t ph, uint32_t tile, uint32_t nxt, bool count) {
+  __shared__ uint32_t sh_tile;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (ph == 0) g.link[tile] = nxt;
+    if (count) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // ONE thread per workgroup fences (an agent-scope fence writes back whole caches here)
+      __hip_atomic_fetch_add(&g.done[ph], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (nxt == VSEG_NONE) g.seen = __hip_atomic_load(&g.done[ph], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    sh_tile = nxt;
+  }
+  __syncthreads();
+  return sh_tile;
+}
+// wait until every tile of phase ph is complete
+__device__ inline void phase_wait(TileSync& g, uint32_t ph) {
+  __shared__ int sh_fail;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sh_fail = 0;
+#ifdef LOAMX_PROF_VDS
+    if (ph < 15 && blockIdx.x < 1024) g_vds_arr[ph][blockIdx.x][0] = wall_clock64();
+#endif
+    uint32_t spins = 0;
+    while (g.seen < g.ntiles) {
+      g.seen = __hip_atomic_load(&g.done[ph], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g.seen >= g.ntiles) break;
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > VDS_SPIN_LIMIT) { *g.err = 1u; sh_fail = 1; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#ifdef LOAMX_PROF_VDS
+    if (ph < 15 && blockIdx.x < 1024) g_vds_arr[ph][blockIdx.x][1] = wall_clock64();
+#endif
+  }
+  __syncthreads();
+  if (sh_fail) g.ok = false;
+  g.seen = 0;
+}
+
+struct VsegArgs {
+  const float4* pts;
+  const uint32_t* seg_off;
+  const int* ijk;
+  const int* seg_minmax;
+  unsigned long long* keys[2];   // (voxel index << VSEG_IDX) | position inside the segment: one 8-byte element carries key and payload
+  uint32_t* gh;         // [nseg][VSEG_MAXPASS][VSEG_NB]  per-segment digit histograms (zero at launch)
+  uint32_t* status;     // [VSEG_MAXPASS][max_tiles][VSEG_NB]  (zero at launch)
+  uint32_t* tile_cnt;   // [max_tiles]  run heads of a tile + 1 once published (zero at launch)
+  uint32_t* link;       // [max_tiles]  TileSync's per-workgroup tile lists
+  uint32_t* barrier;
+  uint32_t* err;
+  float4* out;
+  uint32_t* out_off;    // [nseg + 1]
+  uint32_t n, nseg, max_tiles;
+};
+
+__global__ __launch_bounds__(256) void k_vox_ds_seg(const VsegArgs A) {
+  __shared__ uint32_t s_gh[VSEG_MAXPASS * VSEG_NB];
+  __shared__ uint32_t s_base[VSEG_NB];
+  __shared__ uint32_t s_toff[VSEG_NB];
+  __shared__ uint32_t s_wcnt[4][VSEG_NB];
+  __shared__ uint32_t s_tbase[VSEG_MAXSEG + 1];   // first tile of every segment; [nseg] = number of tiles
+  __shared__ uint32_t s_soff[VSEG_MAXSEG + 1];
+  __shared__ uint32_t s_scan[17];
+  __shared__ unsigned long long s_max;
+  __shared__ float4 s_pts[VDS_TILE + VDS_TILE / 8];   // phase H: the tile's points in sorted order (padded, see lp)
+  __shared__ uint32_t s_vox[VDS_TILE + VDS_TILE / 8];   //          and their voxel indices
+  __shared__ uint32_t s_prev;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const uint32_t n = A.n, nseg = A.nseg;
+#ifdef LOAMX_PROF_VDS
+  if (blockIdx.x == 0 && threadIdx.x == 0) g_vds_n = 0;
+#endif
+  VDS_TS();
+  uint32_t first_claim = 0;
+  if (tid == 0) first_claim = atomicAdd(&A.barrier[16], 1u);   // the workgroup's first tile: the round trip overlaps the set-up below
+  // ---- tiles per segment, B
+  if (tid == 0) s_max = 0ull;
+  {
+    const uint32_t a = tid < (int)nseg ? A.seg_off[tid] : n, b = tid < (int)nseg ? A.seg_off[tid + 1] : n;
+    if (tid < (int)nseg) s_soff[tid] = a;
+    if (tid == 0) s_soff[nseg] = n;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan((b - a + VDS_TILE - 1) / VDS_TILE, s_scan, tot);
+    if (tid < (int)nseg) s_tbase[tid] = ex;
+    if (tid == 0) s_tbase[nseg] = tot;
+  }
+  __syncthreads();
+  {
+    unsigned long long mx = 0ull;
+    if (tid < (int)nseg) {
+      const int* mm = A.seg_minmax + 6 * (size_t)tid;
+      if (mm[3] >= mm[0]) {
+        const long long dx = (long long)mm[3] - mm[0] + 1, dy = (long long)mm[4] - mm[1] + 1, dz = (long long)mm[5] - mm[2] + 1;
+        const bool pass = dx > 2147483647LL || dy > 2147483647LL || dx * dy > 2147483647LL || dz > 2147483647LL / (dx * dy) + 1 || dx * dy * dz > 2147483647LL;
+        mx = pass ? (unsigned long long)(s_soff[tid + 1] - s_soff[tid]) : (unsigned long long)(dx * dy * dz - 1);
+      }
+    }
+    atomicMax(&s_max, mx);
+  }
+  __syncthreads();
+  const uint32_t B = vds_bits(s_max);
+  const uint32_t P = (B + VSEG_DB - 1) / VSEG_DB ? (B + VSEG_DB - 1) / VSEG_DB : 1u;
+  const uint32_t ntiles = s_tbase[nseg];
+  if (tid == 0) s_prev = first_claim < ntiles ? first_claim : VSEG_NONE;
+  __syncthreads();
+  TileSync ts{A.barrier + 16, A.barrier, A.link, A.err, ntiles, s_prev, 0u, true};
+  uint32_t tile = ts.first;
+  auto seg_of_tile = [&](uint32_t t) {   // last segment whose first tile is <= t and that has tiles
+    uint32_t lo = 0, hi = nseg;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s_tbase[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+  };
+
+  // ---- keys + per-segment digit histograms of all passes
+  while (tile != VSEG_NONE) {
+    const uint32_t nxt = tile_peek(ts, 0, tile);
+    const uint32_t sg = seg_of_tile(tile);
+    const uint32_t beg = s_soff[sg] + (tile - s_tbase[sg]) * VDS_TILE, end = min(beg + (uint32_t)VDS_TILE, s_soff[sg + 1]);
+    for (uint32_t e = (uint32_t)tid; e < P * VSEG_NB; e += 256) s_gh[e] = 0u;
+    __syncthreads();
+    const int* mm = A.seg_minmax + 6 * (size_t)sg;
+    const long long dx = (long long)mm[3] - mm[0] + 1, dy = (long long)mm[4] - mm[1] + 1, dz = (long long)mm[5] - mm[2] + 1;
+    const bool pass = dx > 2147483647LL || dy > 2147483647LL || dx * dy > 2147483647LL || dz > 2147483647LL / (dx * dy) + 1 || dx * dy * dz > 2147483647LL;
+#pragma unroll
+    for (int j = 0; j < VDS_TILE / 256; j++) {
+      const uint32_t i = beg + (uint32_t)(j * 256 + tid);
+      if (i < end) {
+        unsigned long long key;
+        if (pass) key = (unsigned long long)(i - s_soff[sg]);
+        else key = (unsigned long long)((long long)(A.ijk[3 * (size_t)i] - mm[0]) + (long long)(A.ijk[3 * (size_t)i + 1] - mm[1]) * dx +
+                                        (long long)(A.ijk[3 * (size_t)i + 2] - mm[2]) * dx * dy);
+        A.keys[0][i] = (key << VSEG_IDX) | (unsigned long long)(i - s_soff[sg]);   // sort element: voxel index | position inside the segment
+        for (uint32_t p = 0; p < P; p++) atomicAdd(&s_gh[p * VSEG_NB + (uint32_t)((key >> (VSEG_DB * p)) & (VSEG_NB - 1))], 1u);
+      }
+    }
+    __syncthreads();
+    for (uint32_t e = (uint32_t)tid; e < P * VSEG_NB; e += 256)
+      if (s_gh[e]) atomicAdd(&A.gh[((size_t)sg * VSEG_MAXPASS) * VSEG_NB + e], s_gh[e]);
+    tile = tile_done(ts, 0, tile, nxt, true);
+  }
+  VDS_TS();
+  phase_wait(ts, 0);
+  VDS_TS();
+  if (!ts.ok) return;
+
+  // ---- the passes (one phase each, see k_vox_ds); thread t owns bins t and t + 256
+  for (uint32_t p = 0; p < P; p++) {
+    const uint32_t shift = VSEG_IDX + VSEG_DB * p;
+    const unsigned long long* __restrict__ ksrc = A.keys[p & 1];
+    unsigned long long* __restrict__ kdst = A.keys[(p & 1) ^ 1];
+    uint32_t* st = A.status + (size_t)p * A.max_tiles * VSEG_ROW;
+    uint32_t cur_seg = 0xffffffffu;
+    tile = ts.first;
+    while (tile != VSEG_NONE) {
+      const uint32_t nxt = tile_peek(ts, 1 + p, tile);
+      const uint32_t sg = seg_of_tile(tile);
+      const uint32_t sbeg = s_soff[sg];
+      const uint32_t beg = sbeg + (tile - s_tbase[sg]) * VDS_TILE, end = min(beg + (uint32_t)VDS_TILE, s_soff[sg + 1]);
+      __syncthreads();
+      if (sg != cur_seg) {   // the segment's digit bases: exclusive scan of its 512-bin histogram (two bins per thread)
+        cur_seg = sg;
+        const uint32_t* h = A.gh + ((size_t)sg * VSEG_MAXPASS + p) * VSEG_NB;
+        const uint32_t h0 = h[2 * tid], h1 = h[2 * tid + 1];
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(h0 + h1, s_scan, tot);
+        s_base[2 * tid] = ex;
+        s_base[2 * tid + 1] = ex + h0;
+      }
+#pragma unroll
+      for (int w = 0; w < 4; w++) { s_wcnt[w][tid] = 0u; s_wcnt[w][tid + 256] = 0u; }
+      __syncthreads();
+      unsigned long long key[8];
+      uint32_t rank[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t i = beg + (uint32_t)(wid * 512 + j * 64 + lane);
+        const bool in = i < end;
+        key[j] = in ? ksrc[i] : ~0ull;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t i = beg + (uint32_t)(wid * 512 + j * 64 + lane);
+        const bool in = i < end;
+        const uint32_t d = (uint32_t)((key[j] >> shift) & (VSEG_NB - 1));
+        unsigned long long m = __ballot(in);
+#pragma unroll
+        for (int b = 0; b < VSEG_DB; b++) {
+          const unsigned long long bal = __ballot((d >> b) & 1u);
+          m &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const unsigned long long below = m & ((1ull << lane) - 1ull);
+        const int leader = __builtin_ctzll(m | (1ull << 63));
+        uint32_t old = 0u;
+        if (in && lane == leader) {
+          old = s_wcnt[wid][d];
+          s_wcnt[wid][d] = old + (uint32_t)__popcll(m);
+        }
+        old = __shfl(old, leader, 64);
+        rank[j] = old + (uint32_t)__popcll(below);
+        __builtin_amdgcn_wave_barrier();
+      }
+      __syncthreads();
+#pragma unroll
+      for (int half = 0; half < 2; half++) {   // bins tid and tid + 256: wave prefix, publish, look back inside the segment
+        const uint32_t d = (uint32_t)tid + 256u * half;
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const uint32_t c = s_wcnt[w][d]; s_wcnt[w][d] = run; run += c; }
+        __hip_atomic_store(&st[(size_t)tile * VSEG_ROW + d], run + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        for (uint32_t t0 = s_tbase[sg]; t0 < tile; t0 += 16) {
+          uint32_t v[16];
+          uint32_t spins = 0;
+          for (;;) {   // see k_vox_ds: re-fetch the batch while any predecessor is unpublished
+            bool pending = false;
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = (t0 + u < tile) ? __hip_atomic_load(&st[(size_t)(t0 + u) * VSEG_ROW + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+#pragma unroll
+            for (int u = 0; u < 16; u++) pending |= v[u] == 0u;
+            if (!pending) break;
+            if (++spins > VDS_SPIN_LIMIT) { *A.err = 1u; break; }
+            __builtin_amdgcn_s_sleep(4);
+          }
+#pragma unroll
+          for (int u = 0; u < 16; u++) excl += v[u] ? v[u] - 1u : 0u;
+        }
+        s_toff[d] = excl;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const uint32_t i = beg + (uint32_t)(wid * 512 + j * 64 + lane);
+        if (i < end) {
+          const uint32_t d = (uint32_t)((key[j] >> shift) & (VSEG_NB - 1));
+          const uint32_t pos = sbeg + s_base[d] + s_toff[d] + s_wcnt[wid][d] + rank[j];
+          kdst[pos] = key[j];
+        }
+      }
+      tile = tile_done(ts, 1 + p, tile, nxt, true);
+    }
+    VDS_TS();
+    phase_wait(ts, 1 + p);
+    VDS_TS();
+    if (!ts.ok) return;
+  }
+  const unsigned long long* __restrict__ keys = A.keys[P & 1];
+
+  // ---- H: run heads, output positions and voxel means in one phase.  A tile stages its sorted elements' voxel indices and points
+  // in LDS, counts its run heads and publishes the count; the heads emitted by all earlier tiles come from a look-back over the
+  // published counts (as in the passes), so no grid barrier separates counting from emitting.  A mean is the sequential sum of the
+  // run in sorted order (the reference accumulates in that order): the walk reads LDS and only continues through global memory
+  // when a run crosses the tile's end.
+  constexpr unsigned long long IDX_MASK = (1ull << VSEG_IDX) - 1ull;
+  auto lp = [](uint32_t l) { return l + (l >> 3); };   // one pad slot per eight: a thread's eight consecutive elements start in distinct banks
+  tile = ts.first;
+  while (tile != VSEG_NONE) {
+    const uint32_t nxt = tile_peek(ts, 1 + P, tile);
+    const uint32_t sg = seg_of_tile(tile);
+    const uint32_t sbeg = s_soff[sg], send = s_soff[sg + 1];
+    const uint32_t beg = sbeg + (tile - s_tbase[sg]) * VDS_TILE, end = min(beg + (uint32_t)VDS_TILE, send);
+    const uint32_t tl = end - beg;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VDS_TILE / 256; j++) {
+      const uint32_t l = (uint32_t)(j * 256 + tid);
+      if (l < tl) {
+        const unsigned long long k = keys[beg + l];
+        s_vox[lp(l)] = (uint32_t)(k >> VSEG_IDX);
+        s_pts[lp(l)] = A.pts[sbeg + (uint32_t)(k & IDX_MASK)];
+      }
+    }
+    if (tid == 0) s_prev = beg > sbeg ? (uint32_t)(keys[beg - 1] >> VSEG_IDX) : 0xffffffffu;
+    __syncthreads();
+    const uint32_t l0 = (uint32_t)tid * 8;
+    bool head[8];
+    uint32_t cnt = 0;
+    uint32_t prev = l0 == 0 ? s_prev : (l0 <= tl ? s_vox[lp(l0 - 1)] : 0xffffffffu);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t l = l0 + j;
+      const uint32_t v = l < tl ? s_vox[lp(l)] : 0xffffffffu;
+      head[j] = l < tl && (beg + l == sbeg || v != prev);
+      cnt += head[j] ? 1u : 0u;
+      prev = v;
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(cnt, s_scan, tot);
+    if (tid == 0) __hip_atomic_store(&A.tile_cnt[tile], tot + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t part = 0;
+    for (uint32_t t = (uint32_t)tid; t < tile; t += 256) {
+      uint32_t v = __hip_atomic_load(&A.tile_cnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), spins = 0;
+      while (v == 0u) {
+        __builtin_amdgcn_s_sleep(4);
+        v = __hip_atomic_load(&A.tile_cnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > VDS_SPIN_LIMIT) { *A.err = 1u; v = 1u; }
+      }
+      part += v - 1u;
+    }
+    uint32_t base;
+    (void)block_excl_scan(part, s_scan, base);   // base = heads emitted by all earlier tiles
+    for (uint32_t s = (uint32_t)tid; s <= nseg; s += 256) {   // output offsets: a segment starts where its first tile starts (empty segments: where the next one does)
+      if (s_tbase[s] == tile) A.out_off[s] = base;
+      else if (tile + 1 == ntiles && s_tbase[s] == ntiles) A.out_off[s] = base + tot;
+    }
+    uint32_t pos = base + ex;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (head[j]) {
+        const uint32_t l = l0 + j;
+        const uint32_t v = s_vox[lp(l)];
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        uint32_t cntp = 0, e = l;
+        do {
+          const float4 q = s_pts[lp(e)];
+          sx += q.x; sy += q.y; sz += q.z; si += q.w;
+          cntp++;
+          e++;
+        } while (e < tl && s_vox[lp(e)] == v);
+        if (e == tl) {   // the run may continue in the segment's next tile
+          uint32_t g = end;
+          while (g < send) {
+            const unsigned long long k = keys[g];
+            if ((uint32_t)(k >> VSEG_IDX) != v) break;
+            const float4 q = A.pts[sbeg + (uint32_t)(k & IDX_MASK)];
+            sx += q.x; sy += q.y; sz += q.z; si += q.w;
+            cntp++;
+            g++;
+          }
+        }
+        const float c = (float)cntp;
+        A.out[pos] = make_float4(sx / c, sy / c, sz / c, si / c);
+        pos++;
+      }
+    }
+    tile = tile_done(ts, 1 + P, tile, nxt, false);   // nobody waits for the last phase
+  }
+  VDS_TS();
+#ifdef LOAMX_PROF_VDS
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_vds_arr[15][blockIdx.x][0] = wall_clock64();
+#endif
+}
+
 void VoxelPipeline::init(hipStream_t st) {
   st_ = st;
   tile_sums_.reserve(8192);
@@ -421,7 +823,7 @@ void VoxelPipeline::reserve(uint32_t n, uint32_t nseg) {
   uint32_t seg_bits = 0;
   while ((nseg >> seg_bits) != 0) seg_bits++;
   const uint32_t passes = (31u + seg_bits + 7u) / 8u;   // upper bound of the kernel's pass count (31 bits of voxel index + the segment)
-  zero_words_ = 64 + 8 * 256 + (size_t)passes * ntiles * 256;   // barrier | gh | status
+  zero_words_ = 64 + 8 * 256 + (size_t)passes * ntiles * VDS_ROW;   // barrier | gh | status
   zero_.reserve(zero_words_);
   tile_cnt_.reserve(ntiles + 2);
   head_scan_.reserve((size_t)n + 2);
@@ -455,6 +857,63 @@ void VoxelPipeline::sort_reduce(const float4* pts, const uint8_t* valid, uint32_
     hipDeviceProp_t prop;
     LX_HIP(hipGetDeviceProperties(&prop, dev));
     slots_ = (uint32_t)std::max(per_cu, 1) * (uint32_t)std::max(prop.multiProcessorCount, 1);
+  }
+  if (!valid && !d_seg_ids && nseg <= VSEG_MAXSEG && n < (1u << VSEG_IDX) && !getenv("LOAMX_VDS_GLOBAL")) {   // contiguous segments: sort inside each segment only
+    const uint32_t max_tiles = (n + VDS_TILE - 1) / VDS_TILE + nseg;
+    const size_t words = 64 + (size_t)nseg * VSEG_MAXPASS * VSEG_NB + (size_t)VSEG_MAXPASS * max_tiles * VSEG_ROW + max_tiles;
+    zero_.reserve(words + max_tiles);   // + the tile lists (no need to clear them)
+    VsegArgs a;
+    a.pts = pts; a.seg_off = d_seg_off; a.ijk = ijk_.p; a.seg_minmax = seg_minmax_.p;
+    a.keys[0] = keys_[0].p; a.keys[1] = keys_[1].p;
+    a.barrier = zero_.p; a.gh = zero_.p + 64; a.status = zero_.p + 64 + (size_t)nseg * VSEG_MAXPASS * VSEG_NB;
+    a.tile_cnt = a.status + (size_t)VSEG_MAXPASS * max_tiles * VSEG_ROW;
+    a.link = a.tile_cnt + max_tiles;
+    a.err = h_err_.p; a.out = out; a.out_off = d_out_off;
+    a.n = n; a.nseg = nseg; a.max_tiles = max_tiles;
+    LX_HIP(hipMemsetAsync(zero_.p, 0, sizeof(uint32_t) * words, st_));
+    if (!slots_seg_) {
+      int per_cu = 0, dev = 0;
+      LX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_vox_ds_seg, 256, 0));
+      LX_HIP(hipGetDevice(&dev));
+      hipDeviceProp_t prop;
+      LX_HIP(hipGetDeviceProperties(&prop, dev));
+      slots_seg_ = (uint32_t)std::max(per_cu, 1) * (uint32_t)std::max(prop.multiProcessorCount, 1);
+    }
+    uint32_t G = std::max<uint32_t>(1u, std::min<uint32_t>(max_tiles, slots_seg_));   // tiles are claimed, not dealt: residency is not a correctness condition
+    if (const char* e = getenv("LOAMX_VDS_WGS")) { const int v = atoi(e); if (v >= 1) G = std::min<uint32_t>(G, (uint32_t)v); }
+    hipLaunchKernelGGL(k_vox_ds_seg, dim3(G), dim3(256), 0, st_, a);
+    LX_HIP(hipGetLastError());
+#ifdef LOAMX_PROF_VDS
+    {
+      unsigned long long ts[64];
+      int cnt = 0;
+      LX_HIP(hipStreamSynchronize(st_));
+      LX_HIP(hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_vds_ts), sizeof(ts)));
+      LX_HIP(hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_vds_n), sizeof(cnt)));
+      {
+        static std::vector<unsigned long long> arr(16 * 1024 * 2);
+        LX_HIP(hipMemcpyFromSymbol(arr.data(), HIP_SYMBOL(g_vds_arr), sizeof(unsigned long long) * arr.size()));
+        for (int b = 0; b < 4; b++) {
+          unsigned long long a0 = ~0ull, a1 = 0, e0 = ~0ull, e1 = 0;
+          for (uint32_t w = 0; w < G && w < 1024; w++) {
+            const unsigned long long a_ = arr[((size_t)b * 1024 + w) * 2], e_ = arr[((size_t)b * 1024 + w) * 2 + 1];
+            a0 = std::min(a0, a_); a1 = std::max(a1, a_); e0 = std::min(e0, e_); e1 = std::max(e1, e_);
+          }
+          fprintf(stderr, "[barrier %d] arrivals spread %.1f us, last arrival -> first exit %.1f us, exits spread %.1f us\n", b, (a1 - a0) * 0.01, ((double)e0 - (double)a1) * 0.01, (e1 - e0) * 0.01);
+        }
+      }
+      fprintf(stderr, "[vox_ds_seg n=%u segs=%u G=%u] us (work | barrier wait):", n, nseg, G);
+      for (int k = 1; k < cnt; k++) fprintf(stderr, "%s%.1f", (k & 1) ? "  " : "|", (ts[k] - ts[k - 1]) * 0.01);
+      unsigned long long last = 0;
+      {
+        static std::vector<unsigned long long> arr(16 * 1024 * 2);
+        LX_HIP(hipMemcpyFromSymbol(arr.data(), HIP_SYMBOL(g_vds_arr), sizeof(unsigned long long) * arr.size()));
+        for (uint32_t w = 0; w < G && w < 1024; w++) last = std::max(last, arr[((size_t)15 * 1024 + w) * 2]);
+      }
+      fprintf(stderr, "  first workgroup %.1f, last %.1f\n", (ts[cnt - 1] - ts[0]) * 0.01, (last - ts[0]) * 0.01);
+    }
+#endif
+    return;
   }
   VdsArgs a;
   a.pts = pts; a.valid = valid; a.seg_off = d_seg_off; a.seg_ids = d_seg_ids; a.ijk = ijk_.p; a.seg_minmax = seg_minmax_.p;

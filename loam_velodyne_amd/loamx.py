@@ -623,8 +623,9 @@ class Pipeline:
     def set_lookahead(self, on: bool):
         _check(lib().loamx_pipeline_set_lookahead(self.h, 1 if on else 0))
 
-    def set_timing(self, on: bool):
-        _check(lib().loamx_pipeline_set_timing(self.h, 1 if on else 0))
+    def set_timing(self, on, per_launch: bool = True):
+        """on: stage events; per_launch: also an event pair around every Gauss-Newton launch (costs ~3 % of a step)."""
+        _check(lib().loamx_pipeline_set_timing(self.h, (1 if per_launch else 2) if on else 0))
 
     def timing(self):
         ms = (C.c_float * 4)()

@@ -175,69 +175,81 @@ __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ pro
   const int cscan = (int)last[closest].w;
   float d2 = 25.f, d3 = 25.f;
   int j2 = -1, j3 = -1, o2 = 0x7fffffff, o3 = 0x7fffffff;
-  // forward window (:262-279 / :378-403): 4 x 64 points are fetched per trip, then examined in scan order
-  for (int base = closest + 1; base < bound; base += 256) {
-    float4 q[4];
+  // forward window (:262-279 / :378-403) and backward window (:280-297 / :404-429), walked TOGETHER: per trip 4 x 64 points of
+  // each direction are fetched (8 loads in flight per lane), then examined in scan order; a direction stops at its first point
+  // beyond +-2.5 rings.  (d, order) minima make the result independent of the interleaving: forward candidates order before
+  // backward ones, as in the reference's two consecutive loops.
+  auto better = [](float d, int order, float dbest, int obest) { return d < dbest || (d == dbest && obest != 0x7fffffff && order < obest); };   // scan order decides ties (never admits d == 25)
+  int baseF = closest + 1, baseB = closest - 1;
+  bool stopF = baseF >= bound, stopB = baseB < 0;
+  while (!stopF || !stopB) {
+    float4 qf[4], qb[4];
+    if (!stopF) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int j = base + 64 * u + lane;
-      q[u] = j < bound ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    bool stop = false;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (stop) continue;
-      const int j = base + 64 * u + lane;
-      const bool in = j < bound;
-      const int ring = (int)q[u].w;
-      const bool brk = in && ((double)ring > (double)cscan + 2.5);
-      const unsigned long long mb = __ballot(brk);
-      const int fb = mb ? __builtin_ctzll(mb) : 64;
-      if (in && lane < fb) {
-        const float d = sqd(q[u], x, y, z);
-        const int order = j - (closest + 1);
-        if (corner) {
-          if (ring > cscan && d < d2) { d2 = d; j2 = j; o2 = order; }
-        } else {
-          if (ring <= cscan) { if (d < d2) { d2 = d; j2 = j; o2 = order; } }
-          else { if (d < d3) { d3 = d; j3 = j; o3 = order; } }
-        }
+      for (int u = 0; u < 4; u++) {
+        const int j = baseF + 64 * u + lane;
+        qf[u] = j < bound ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (mb) stop = true;
     }
-    if (stop) break;
-  }
-  // backward window (:280-297 / :404-429)
-  for (int base = closest - 1; base >= 0; base -= 256) {
-    float4 q[4];
+    if (!stopB) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int j = base - 64 * u - lane;
-      q[u] = j >= 0 ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    bool stop = false;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (stop) continue;
-      const int j = base - 64 * u - lane;
-      const bool in = j >= 0;
-      const int ring = (int)q[u].w;
-      const bool brk = in && ((double)ring < (double)cscan - 2.5);
-      const unsigned long long mb = __ballot(brk);
-      const int fb = mb ? __builtin_ctzll(mb) : 64;
-      if (in && lane < fb) {
-        const float d = sqd(q[u], x, y, z);
-        const int order = 0x40000000 + (closest - 1 - j);   // backward candidates come after all forward ones
-        if (corner) {
-          if (ring < cscan && d < d2) { d2 = d; j2 = j; o2 = order; }
-        } else {
-          if (ring >= cscan) { if (d < d2) { d2 = d; j2 = j; o2 = order; } }
-          else { if (d < d3) { d3 = d; j3 = j; o3 = order; } }
-        }
+      for (int u = 0; u < 4; u++) {
+        const int j = baseB - 64 * u - lane;
+        qb[u] = j >= 0 ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (mb) stop = true;
     }
-    if (stop) break;
+    if (!stopF) {
+      bool stop = false;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (stop) continue;
+        const int j = baseF + 64 * u + lane;
+        const bool in = j < bound;
+        const int ring = (int)qf[u].w;
+        const bool brk = in && ((double)ring > (double)cscan + 2.5);
+        const unsigned long long mb = __ballot(brk);
+        const int fb = mb ? __builtin_ctzll(mb) : 64;
+        if (in && lane < fb) {
+          const float d = sqd(qf[u], x, y, z);
+          const int order = j - (closest + 1);
+          if (corner) {
+            if (ring > cscan && better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; }
+          } else {
+            if (ring <= cscan) { if (better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; } }
+            else { if (better(d, order, d3, o3)) { d3 = d; j3 = j; o3 = order; } }
+          }
+        }
+        if (mb) stop = true;
+      }
+      baseF += 256;
+      stopF = stop || baseF >= bound;
+    }
+    if (!stopB) {
+      bool stop = false;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (stop) continue;
+        const int j = baseB - 64 * u - lane;
+        const bool in = j >= 0;
+        const int ring = (int)qb[u].w;
+        const bool brk = in && ((double)ring < (double)cscan - 2.5);
+        const unsigned long long mb = __ballot(brk);
+        const int fb = mb ? __builtin_ctzll(mb) : 64;
+        if (in && lane < fb) {
+          const float d = sqd(qb[u], x, y, z);
+          const int order = 0x40000000 + (closest - 1 - j);   // backward candidates come after all forward ones
+          if (corner) {
+            if (ring < cscan && better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; }
+          } else {
+            if (ring >= cscan) { if (better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; } }
+            else { if (better(d, order, d3, o3)) { d3 = d; j3 = j; o3 = order; } }
+          }
+        }
+        if (mb) stop = true;
+      }
+      baseB -= 256;
+      stopB = stop || baseB < 0;
+    }
   }
   wave_argmin(d2, j2, o2);
   if (!corner) wave_argmin(d3, j3, o3);

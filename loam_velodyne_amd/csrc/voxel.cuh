@@ -94,16 +94,15 @@ class VoxelPipeline {
   // the per-segment output offsets.  Slots with valid[i]==0 are ignored.
   void sort_reduce(const float4* pts, const uint8_t* valid, uint32_t n, const uint32_t* d_seg_off, uint32_t nseg, float4* out,
                    uint32_t* d_out_off, const uint32_t* d_seg_ids = nullptr);
-  // after the stream has been synchronised: throws if a grid barrier of the last launches timed out
+  // after the stream has been synchronised: throws if a wait inside the last launches timed out
   void check();
 
  private:
   hipStream_t st_ = nullptr;
   DevBuf<int> ijk_, seg_minmax_;
   DevBuf<unsigned long long> keys_[2];
-  DevBuf<uint32_t> vals_[2], zero_, tile_cnt_, head_scan_, tile_sums_, scratch_;   // zero_: barrier counter | digit histograms | tile status
-  size_t zero_words_ = 0;
-  DevBuf<float4> gathered_;   // the points in sorted order
+  DevBuf<uint32_t> vals_[2], zero_;   // zero_ (cleared before every launch): TileSync counters | digit histograms | tile status | tile head counts
+  size_t zero_words_ = 0, status_words_ = 0;
   PinBuf<uint32_t> h_err_;
   uint32_t slots_ = 0, slots_seg_ = 0;
 };

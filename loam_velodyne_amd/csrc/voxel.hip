@@ -41,15 +41,15 @@ __global__ __launch_bounds__(256) void k_vox_ijk(const float4* __restrict__ pts,
 // everything.  The sort is stable, so the points of a voxel stay in input order and the float means are accumulated in the
 // order of the reference's loop over a stably sorted index (PCL's std::sort leaves that order unspecified).
 //
-// grid = G workgroups of 256 threads, tiles of 2048 elements dealt round robin; phases are separated by a grid barrier
-// (arrival counter in HBM, agent scope; the launcher keeps G within half of what the device can hold, and a barrier that is
-// not passed within ~1 s raises the error word and ends the kernel instead of hanging the GPU).  Per pass:
-//   A  per-tile digit histograms (LDS atomics)                            -> hist[tile][256]
-//   B  one wave per digit scans its column over the tiles                 -> toff[tile][256], totals[256]
-//   C  every workgroup scans the 256 totals, ranks its tile's elements stably (per wave: 8 ballots give the lanes with the
-//      same digit; waves are chained through LDS) and scatters keys + values to the other buffer
-// then  H1 run heads per tile -> H2 scan of the tile counts -> H3 output position of every head, the voxel's mean (walking the
-// run in sorted = input order) -> H4 per-segment output offsets by binary search.
+// grid = G workgroups of 256 threads working on tiles of 2048 elements.  Tiles are claimed from a counter and a phase is complete
+// when its tiles are (TileSync below) — the launch does not rely on all of its workgroups being resident; a wait that is not
+// satisfied within ~1 s raises the error word and ends the kernel instead of hanging the GPU.  Phases:
+//   keys   key of every element + the digit histograms of ALL passes (the multiset of keys never changes)
+//   pass p every workgroup scans the 256 digit totals, ranks its tile's elements stably (per wave: 8 ballots give the lanes with
+//          the same digit; waves are chained through LDS), publishes the tile's digit counts, sums the counts of all earlier
+//          tiles (look-back, batches of independent loads) and scatters keys + values to the other buffer
+//   H      run heads, output positions (look-back over the tiles' head counts), voxel means walking each run in sorted = input
+//          order out of LDS, per-segment output offsets
 // ----------------------------------------------------------------------------------------------------------------
 #ifdef LOAMX_PROF_VDS
 __device__ unsigned long long g_vds_ts[64];
@@ -59,8 +59,8 @@ __device__ int g_vds_n;
 #else
 #define VDS_TS() do { } while (0)
 #endif
-constexpr int VDS_TILE = 2048;
-constexpr int VDS_LOOK = 32;          // predecessor counts fetched at once        // elements per tile (8 per thread)
+constexpr int VDS_TILE = 2048;        // elements per tile (8 per thread)
+constexpr int VDS_LOOK = 32;          // predecessor counts fetched at once
 constexpr uint32_t VDS_SPIN_LIMIT = 1u << 20;
 constexpr int VDS_ROW = 256 + 64;     // words between two tiles' published counts: not a power of two, so that the rows a look-back
                                       // fetches together fall on different memory channels
@@ -77,51 +77,84 @@ struct VdsArgs {
   uint32_t* vals[2];
   uint32_t* gh;         // [8][256]  global digit histograms of the passes (zero at launch)
   uint32_t* status;     // [passes][ntiles][256]  a tile's digit counts + 1 once published (zero at launch)
-  uint32_t* tile_cnt;   // [ntiles + 1]  heads per tile, then (in place) exclusive prefix; [ntiles] = total
-  uint32_t* head_scan;  // [n + 1]
-  float4* gathered;     // [n] the points in sorted order
-  uint32_t* barrier;    // arrival counter, zero at launch
+  uint32_t* tile_cnt;   // [ntiles]  run heads of a tile + 1 once published (zero at launch)
+  uint32_t* link;       // [ntiles]  TileSync's per-workgroup tile lists
+  uint32_t* barrier;    // TileSync counters (zero at launch): [0..15] tiles done per phase, [16] tiles claimed
   uint32_t* err;        // host-visible error word
   float4* out;
   uint32_t* out_off;    // [nseg + 1]
   uint32_t n, nseg, ntiles;
 };
 
-struct GridSync {
-  uint32_t* counter;
+// Work distribution that does not depend on how many workgroups are resident.  In the first phase the tiles are CLAIMED from a
+// counter; a workgroup keeps the tiles it claimed for all later phases (it walks them through `link`), and a phase is complete
+// when its tiles are — not when every workgroup of the grid has arrived.  A workgroup the dispatcher has not started yet thus
+// owns nothing anybody waits for: several of these kernels run side by side on a process's streams and may together exceed the
+// device, where a classic grid barrier would let two half-resident launches wait for each other forever.  Look-backs stay safe
+// too: the claim counter is monotonic, so every tile below a claimed one belongs to a workgroup that is running, and tiles
+// publish before they look back.  The claim of the NEXT tile is issued before the current one is processed, so its round trip
+// is never exposed.
+struct TileSync {
+  uint32_t* next;   // tiles claimed (first phase)
+  uint32_t* done;   // [phase]  tiles completed
+  uint32_t* link;   // [tile]   the next tile of the same workgroup (VSEG_NONE: last)
   uint32_t* err;
-  uint32_t epoch;
+  uint32_t ntiles;
+  uint32_t first;   // the workgroup's first tile
+  uint32_t seen;    // thread 0: done[phase] as read right after the workgroup's last completion
   bool ok;
 };
-// all threads of all workgroups call it the same number of times.  ONE thread per workgroup issues the release / acquire
-// fences: an agent-scope fence writes back / invalidates whole caches on this multi-XCD device, so hundreds of waves fencing
-// at every barrier (the first version) cost ~25 us per barrier; the workgroup barriers around it extend the ordering to the
-// other threads (their writes happen-before thread 0's release, their later reads happen-after its acquire; a workgroup lives
-// on one CU, whose L1 thread 0 invalidates).
-__device__ inline void grid_barrier(GridSync& g) {
+constexpr uint32_t VSEG_NONE = 0xffffffffu;
+
+// thread 0's view of the tile after `tile`: claimed (first phase) or read from the workgroup's list
+__device__ inline uint32_t tile_peek(const TileSync& g, uint32_t ph, uint32_t tile) {
+  if (threadIdx.x != 0) return VSEG_NONE;
+  if (ph == 0) {
+    const uint32_t c = atomicAdd(g.next, 1u);
+    return c < g.ntiles ? c : VSEG_NONE;
+  }
+  return g.link[tile];
+}
+// the workgroup finished `tile` of phase ph (nxt: thread 0's tile_peek, taken before the tile was processed)
+__device__ inline uint32_t tile_done(TileSync& g, uint32_t ph, uint32_t tile, uint32_t nxt, bool count) {
+  __shared__ uint32_t sh_tile;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (ph == 0) g.link[tile] = nxt;
+    if (count) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // ONE thread per workgroup fences (an agent-scope fence writes back whole caches here)
+      __hip_atomic_fetch_add(&g.done[ph], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (nxt == VSEG_NONE) g.seen = __hip_atomic_load(&g.done[ph], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    sh_tile = nxt;
+  }
+  __syncthreads();
+  return sh_tile;
+}
+// wait until every tile of phase ph is complete
+__device__ inline void phase_wait(TileSync& g, uint32_t ph) {
   __shared__ int sh_fail;
   __syncthreads();
-  g.epoch++;
   if (threadIdx.x == 0) {
     sh_fail = 0;
 #ifdef LOAMX_PROF_VDS
-    if (g.epoch <= 16 && blockIdx.x < 1024) g_vds_arr[g.epoch - 1][blockIdx.x][0] = wall_clock64();
+    if (ph < 15 && blockIdx.x < 1024) g_vds_arr[ph][blockIdx.x][0] = wall_clock64();
 #endif
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // release this workgroup's writes
-    atomicAdd(g.counter, 1u);
-    const uint32_t target = g.epoch * gridDim.x;
     uint32_t spins = 0;
-    while (__hip_atomic_load(g.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(32);   // ~1 us between polls: a hundred workgroups hammering one counter slow the L2 channel for everybody
+    while (g.seen < g.ntiles) {
+      g.seen = __hip_atomic_load(&g.done[ph], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (g.seen >= g.ntiles) break;
+      __builtin_amdgcn_s_sleep(8);
       if (++spins > VDS_SPIN_LIMIT) { *g.err = 1u; sh_fail = 1; break; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // acquire the other workgroups' writes
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #ifdef LOAMX_PROF_VDS
-    if (g.epoch <= 16 && blockIdx.x < 1024) g_vds_arr[g.epoch - 1][blockIdx.x][1] = wall_clock64();
+    if (ph < 15 && blockIdx.x < 1024) g_vds_arr[ph][blockIdx.x][1] = wall_clock64();
 #endif
   }
   __syncthreads();
   if (sh_fail) g.ok = false;
+  g.seen = 0;
 }
 
 __device__ inline uint32_t vds_bits(unsigned long long v) { return v ? 64u - (uint32_t)__builtin_clzll(v) : 0u; }
@@ -133,13 +166,18 @@ __global__ __launch_bounds__(256) void k_vox_ds(const VdsArgs A) {
   __shared__ uint32_t s_wcnt[4][256];
   __shared__ uint32_t s_scan[17];
   __shared__ unsigned long long s_max;
+  __shared__ float4 s_pts[VDS_TILE + VDS_TILE / 8];               // phase H: the tile's points in sorted order (padded, see lp)
+  __shared__ unsigned long long s_key[VDS_TILE + VDS_TILE / 8];   //          and their keys
+  __shared__ unsigned long long s_prevk;
+  __shared__ uint32_t s_first;
   const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const uint32_t n = A.n, nseg = A.nseg, ntiles = A.ntiles, G = gridDim.x;
-  GridSync gs{A.barrier, A.err, 0u, true};
+  const uint32_t n = A.n, nseg = A.nseg, ntiles = A.ntiles;
 #ifdef LOAMX_PROF_VDS
   if (blockIdx.x == 0 && threadIdx.x == 0) g_vds_n = 0;
 #endif
   VDS_TS();
+  uint32_t first_claim = 0;
+  if (tid == 0) first_claim = atomicAdd(&A.barrier[16], 1u);   // the workgroup's first tile: the round trip overlaps the set-up below
 
   // ---- B: bits of the largest linear voxel index of the batch (pass-through segments: of the largest point index)
   if (tid == 0) s_max = 0ull;
@@ -161,10 +199,15 @@ __global__ __launch_bounds__(256) void k_vox_ds(const VdsArgs A) {
   const uint32_t B = vds_bits(s_max);
   const uint32_t total_bits = B + vds_bits((unsigned long long)nseg);   // the pseudo-segment nseg must fit too
   const uint32_t P = (total_bits + 7) / 8 ? (total_bits + 7) / 8 : 1u;
+  if (tid == 0) s_first = first_claim < ntiles ? first_claim : VSEG_NONE;
+  __syncthreads();
+  TileSync ts{A.barrier + 16, A.barrier, A.link, A.err, ntiles, s_first, 0u, true};
+  uint32_t tile = ts.first;
 
   // ---- keys (into buffer 0) + the global digit histograms of ALL passes (the multiset of keys does not change from pass to
   // pass, so every pass's digit bases are known up front)
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += G) {
+  while (tile != VSEG_NONE) {
+    const uint32_t nxt = tile_peek(ts, 0, tile);
     for (uint32_t e = (uint32_t)tid; e < P * 256; e += 256) s_gh[e] = 0u;
     __syncthreads();
 #pragma unroll
@@ -193,17 +236,17 @@ __global__ __launch_bounds__(256) void k_vox_ds(const VdsArgs A) {
     __syncthreads();
     for (uint32_t e = (uint32_t)tid; e < P * 256; e += 256)
       if (s_gh[e]) atomicAdd(&A.gh[e], s_gh[e]);
-    __syncthreads();
+    tile = tile_done(ts, 0, tile, nxt, true);
   }
   VDS_TS();
-  grid_barrier(gs);
+  phase_wait(ts, 0);
   VDS_TS();
-  if (!gs.ok) return;
+  if (!ts.ok) return;
 
   // ---- the passes: ONE phase each.  Per tile: stable ranks (per wave: 8 ballots give the lanes with the same digit; waves
   // chained through LDS), the tile's digit counts published (count + 1, 0 = not there yet), the counts of all earlier tiles
   // summed — independent loads, re-polled while a predecessor has not published (tiles are taken in increasing order by
-  // resident workgroups, so every predecessor is being worked on) —, then the scatter to the other buffer.
+  // running workgroups, see TileSync, so every predecessor is being worked on) —, then the scatter to the other buffer.
   for (uint32_t p = 0; p < P; p++) {
     const uint32_t shift = 8 * p;
     const unsigned long long* __restrict__ ksrc = A.keys[p & 1];
@@ -216,7 +259,9 @@ __global__ __launch_bounds__(256) void k_vox_ds(const VdsArgs A) {
       const uint32_t ex = block_excl_scan(A.gh[p * 256 + tid], s_scan, tot);
       s_base[tid] = ex;
     }
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += G) {
+    tile = ts.first;
+    while (tile != VSEG_NONE) {
+      const uint32_t nxt = tile_peek(ts, 1 + p, tile);
       __syncthreads();
 #pragma unroll
       for (int w = 0; w < 4; w++) s_wcnt[w][tid] = 0u;
@@ -290,126 +335,104 @@ __global__ __launch_bounds__(256) void k_vox_ds(const VdsArgs A) {
           vdst[pos] = val[j];
         }
       }
+      tile = tile_done(ts, 1 + p, tile, nxt, true);
     }
     // (the next pass reads what this pass scattered)
     VDS_TS();
-    grid_barrier(gs);
+    phase_wait(ts, 1 + p);
     VDS_TS();
-    if (!gs.ok) return;
+    if (!ts.ok) return;
   }
   const unsigned long long* __restrict__ keys = A.keys[P & 1];
   const uint32_t* __restrict__ vals = A.vals[P & 1];
 
-  // ---- H1: run heads per tile (thread t owns 8 consecutive elements)
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += G) {
-    const uint32_t i0 = tile * VDS_TILE + (uint32_t)tid * 8;
-    uint32_t cnt = 0;
-    unsigned long long prev = (i0 > 0 && i0 <= n) ? keys[i0 - 1] : ~0ull;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const uint32_t i = i0 + j;
-      if (i < n) {
-        const unsigned long long k = keys[i];
-        if ((k >> B) < nseg && (i == 0 || k != prev)) cnt++;
-        prev = k;
-      }
-    }
-    uint32_t tot;
-    (void)block_excl_scan(cnt, s_scan, tot);
-    if (tid == 0) A.tile_cnt[tile] = tot;
-    // the points in sorted order (independent gathers, coalesced stores): H3 then walks its runs through contiguous memory
+  // ---- H: run heads, output positions, voxel means and segment offsets in one phase (see k_vox_ds_seg: the tile's sorted keys
+  // and points are staged in LDS, its head count is published and the heads of all earlier tiles come from a look-back).  A mean
+  // is the sequential sum of the run in sorted (= input) order; a run that crosses the tile's end continues through global memory.
+  // out_off[s] = voxels emitted before the first sorted element whose segment is >= s: written by the thread that owns that
+  // element (for every segment skipped at the boundary), the tail by the owner of the last element.
+  auto lp = [](uint32_t l) { return l + (l >> 3); };
+  tile = ts.first;
+  while (tile != VSEG_NONE) {
+    const uint32_t nxt = tile_peek(ts, 1 + P, tile);
+    const uint32_t beg = tile * VDS_TILE, end = min(beg + (uint32_t)VDS_TILE, n), tl = end - beg;
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < VDS_TILE / 256; j++) {
-      const uint32_t i = tile * VDS_TILE + (uint32_t)(j * 256 + tid);
-      if (i < n) A.gathered[i] = A.pts[vals[i]];
+      const uint32_t l = (uint32_t)(j * 256 + tid);
+      if (l < tl) {
+        s_key[lp(l)] = keys[beg + l];
+        s_pts[lp(l)] = A.pts[vals[beg + l]];
+      }
     }
-  }
-  VDS_TS();
-  grid_barrier(gs);
-  VDS_TS();
-  if (!gs.ok) return;
-  // ---- H2: exclusive scan of the tile counts (one wave of the first workgroup)
-  if (blockIdx.x == 0 && wid == 0) {
-    uint32_t running = 0;
-    for (uint32_t t0 = 0; t0 < ntiles; t0 += 64) {
-      const uint32_t t = t0 + (uint32_t)lane;
-      const uint32_t v = t < ntiles ? A.tile_cnt[t] : 0u;
-      const uint32_t inc = wave_incl_scan(v, lane);
-      if (t < ntiles) A.tile_cnt[t] = running + inc - v;
-      running += __shfl(inc, 63, 64);
-    }
-    if (lane == 0) { A.tile_cnt[ntiles] = running; A.head_scan[n] = running; }
-  }
-  VDS_TS();
-  grid_barrier(gs);
-  VDS_TS();
-  if (!gs.ok) return;
-  // ---- H3: output position of every element's voxel, the means
-  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += G) {
-    const uint32_t i0 = tile * VDS_TILE + (uint32_t)tid * 8;
+    if (tid == 0) s_prevk = beg > 0 ? keys[beg - 1] : ~0ull;
+    __syncthreads();
+    const uint32_t l0 = (uint32_t)tid * 8;
     unsigned long long k8[8];
     bool head[8];
     uint32_t cnt = 0;
-    unsigned long long prev = (i0 > 0 && i0 <= n) ? keys[i0 - 1] : ~0ull;
+    const unsigned long long prev0 = l0 == 0 ? s_prevk : (l0 <= tl ? s_key[lp(l0 - 1)] : ~0ull);
+    unsigned long long prev = prev0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const uint32_t i = i0 + j;
-      k8[j] = i < n ? keys[i] : ~0ull;
-      head[j] = i < n && (k8[j] >> B) < nseg && (i == 0 || k8[j] != prev);
+      const uint32_t l = l0 + j;
+      k8[j] = l < tl ? s_key[lp(l)] : ~0ull;
+      head[j] = l < tl && (k8[j] >> B) < nseg && (beg + l == 0 || k8[j] != prev);
       cnt += head[j] ? 1u : 0u;
       prev = k8[j];
     }
     uint32_t tot;
-    uint32_t pos = A.tile_cnt[tile] + block_excl_scan(cnt, s_scan, tot);
-    float4 g8[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) g8[j] = (i0 + j < n) ? A.gathered[i0 + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t ex = block_excl_scan(cnt, s_scan, tot);
+    if (tid == 0) __hip_atomic_store(&A.tile_cnt[tile], tot + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t part = 0;
+    for (uint32_t t = (uint32_t)tid; t < tile; t += 256) {
+      uint32_t v = __hip_atomic_load(&A.tile_cnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), spins = 0;
+      while (v == 0u) {
+        __builtin_amdgcn_s_sleep(4);
+        v = __hip_atomic_load(&A.tile_cnt[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > VDS_SPIN_LIMIT) { *A.err = 1u; v = 1u; }
+      }
+      part += v - 1u;
+    }
+    uint32_t base;
+    (void)block_excl_scan(part, s_scan, base);   // base = heads emitted by all earlier tiles
+    uint32_t pos = base + ex;
+    prev = prev0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const uint32_t i = i0 + j;
-      if (i < n) {
-        A.head_scan[i] = pos;
+      const uint32_t l = l0 + j;
+      if (l < tl) {
+        const uint32_t sg = (uint32_t)min(k8[j] >> B, (unsigned long long)nseg);
+        const uint32_t sp = beg + l == 0 ? 0u : (uint32_t)min(prev >> B, (unsigned long long)nseg) + 1u;   // first segment not yet given an offset
+        for (uint32_t q = sp; q <= sg; q++) A.out_off[q] = pos;   // (empty unless the segment changes here)
+        if (beg + l == n - 1)
+          for (uint32_t q = sg + 1; q <= nseg; q++) A.out_off[q] = pos + (head[j] ? 1u : 0u);
         if (head[j]) {
-          // float means of x, y, z, intensity over the run, in sorted (= input) order: first inside this thread's own eight
-          // elements (registers), then — a run that continues — from memory
           float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-          uint32_t cntp = 0;
-          bool open = true;
-#pragma unroll
-          for (int jj = 0; jj < 8; jj++) {
-            if (jj >= j && open) {
-              if (i0 + jj < n && k8[jj] == k8[j]) { sx += g8[jj].x; sy += g8[jj].y; sz += g8[jj].z; si += g8[jj].w; cntp++; }
-              else open = false;
-            }
-          }
-          if (open) {
-            uint32_t e = i0 + 8;
-            while (e < n && keys[e] == k8[j]) {
-              const float4 q = A.gathered[e];
+          uint32_t cntp = 0, e = l;
+          do {
+            const float4 q = s_pts[lp(e)];
+            sx += q.x; sy += q.y; sz += q.z; si += q.w;
+            cntp++;
+            e++;
+          } while (e < tl && s_key[lp(e)] == k8[j]);
+          if (e == tl) {   // the run may continue in the next tile
+            uint32_t g = end;
+            while (g < n && keys[g] == k8[j]) {
+              const float4 q = A.pts[vals[g]];
               sx += q.x; sy += q.y; sz += q.z; si += q.w;
               cntp++;
-              e++;
+              g++;
             }
           }
           const float c = (float)cntp;
           A.out[pos] = make_float4(sx / c, sy / c, sz / c, si / c);
           pos++;
         }
+        prev = k8[j];
       }
     }
-  }
-  VDS_TS();
-  grid_barrier(gs);
-  VDS_TS();
-  if (!gs.ok) return;
-  // ---- H4: out_off[s] = voxels emitted before segment s (first sorted slot whose segment >= s); out_off[nseg] = total
-  for (uint32_t sg = blockIdx.x * 256 + (uint32_t)tid; sg <= nseg; sg += G * 256) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if ((keys[mid] >> B) >= sg) hi = mid; else lo = mid + 1;
-    }
-    A.out_off[sg] = A.head_scan[lo];
+    tile = tile_done(ts, 1 + P, tile, nxt, false);   // nobody waits for the last phase
   }
   VDS_TS();
 }
@@ -425,77 +448,6 @@ constexpr int VSEG_DB = 9, VSEG_NB = 1 << VSEG_DB, VSEG_ROW = VSEG_NB + 64;   //
 constexpr int VSEG_MAXSEG = 256;
 constexpr int VSEG_IDX = 24;                         // low bits of a sort element: the point's position inside its segment
 constexpr int VSEG_MAXPASS = 4;                      // 31 bits / 9
-
-// Work distribution that does not depend on how many workgroups are resident.  In the first phase the tiles are CLAIMED from a
-// counter; a workgroup keeps the tiles it claimed for all later phases (it walks them through `link`), and a phase is complete
-// when its tiles are — not when every workgroup of the grid has arrived.  A workgroup the dispatcher has not started yet thus
-// owns nothing anybody waits for: several of these kernels run side by side on a process's streams and may together exceed the
-// device, where a classic grid barrier would let two half-resident launches wait for each other forever.  Look-backs stay safe
-// too: the claim counter is monotonic, so every tile below a claimed one belongs to a workgroup that is running, and tiles
-// publish before they look back.  The claim of the NEXT tile is issued before the current one is processed, so its round trip
-// is never exposed.
-struct TileSync {
-  uint32_t* next;   // tiles claimed (first phase)
-  uint32_t* done;   // [phase]  tiles completed
-  uint32_t* link;   // [tile]   the next tile of the same workgroup (VSEG_NONE: last)
-  uint32_t* err;
-  uint32_t ntiles;
-  uint32_t first;   // the workgroup's first tile
-  uint32_t seen;    // thread 0: done[phase] as read right after the workgroup's last completion
-  bool ok;
-};
-constexpr uint32_t VSEG_NONE = 0xffffffffu;
-
-// thread 0's view of the tile after `tile`: claimed (first phase) or read from the workgroup's list
-__device__ inline uint32_t tile_peek(const TileSync& g, uint32_t ph, uint32_t tile) {
-  if (threadIdx.x != 0) return VSEG_NONE;
-  if (ph == 0) {
-    const uint32_t c = atomicAdd(g.next, 1u);
-    return c < g.ntiles ? c : VSEG_NONE;
-  }
-  return g.link[tile];
-}
-// the workgroup finished `tile` of phase ph (nxt: thread 0's tile_peek, taken before the tile was processed)
-__device__ inline uint32_t tile_done(TileSync& g, uint32_t ph, uint32_t tile, uint32_t nxt, bool count) {
-  __shared__ uint32_t sh_tile;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (ph == 0) g.link[tile] = nxt;
-    if (count) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // ONE thread per workgroup fences (an agent-scope fence writes back whole caches here)
-      __hip_atomic_fetch_add(&g.done[ph], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (nxt == VSEG_NONE) g.seen = __hip_atomic_load(&g.done[ph], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    sh_tile = nxt;
-  }
-  __syncthreads();
-  return sh_tile;
-}
-// wait until every tile of phase ph is complete
-__device__ inline void phase_wait(TileSync& g, uint32_t ph) {
-  __shared__ int sh_fail;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    sh_fail = 0;
-#ifdef LOAMX_PROF_VDS
-    if (ph < 15 && blockIdx.x < 1024) g_vds_arr[ph][blockIdx.x][0] = wall_clock64();
-#endif
-    uint32_t spins = 0;
-    while (g.seen < g.ntiles) {
-      g.seen = __hip_atomic_load(&g.done[ph], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (g.seen >= g.ntiles) break;
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > VDS_SPIN_LIMIT) { *g.err = 1u; sh_fail = 1; break; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#ifdef LOAMX_PROF_VDS
-    if (ph < 15 && blockIdx.x < 1024) g_vds_arr[ph][blockIdx.x][1] = wall_clock64();
-#endif
-  }
-  __syncthreads();
-  if (sh_fail) g.ok = false;
-  g.seen = 0;
-}
 
 struct VsegArgs {
   const float4* pts;
@@ -806,8 +758,6 @@ __global__ __launch_bounds__(256) void k_vox_ds_seg(const VsegArgs A) {
 
 void VoxelPipeline::init(hipStream_t st) {
   st_ = st;
-  tile_sums_.reserve(8192);
-  scratch_.reserve(16);
 }
 
 void VoxelPipeline::reserve(uint32_t n, uint32_t nseg) {
@@ -823,11 +773,9 @@ void VoxelPipeline::reserve(uint32_t n, uint32_t nseg) {
   uint32_t seg_bits = 0;
   while ((nseg >> seg_bits) != 0) seg_bits++;
   const uint32_t passes = (31u + seg_bits + 7u) / 8u;   // upper bound of the kernel's pass count (31 bits of voxel index + the segment)
-  zero_words_ = 64 + 8 * 256 + (size_t)passes * ntiles * VDS_ROW;   // barrier | gh | status
-  zero_.reserve(zero_words_);
-  tile_cnt_.reserve(ntiles + 2);
-  head_scan_.reserve((size_t)n + 2);
-  gathered_.reserve((size_t)n + 1);
+  status_words_ = (size_t)passes * ntiles * VDS_ROW;
+  zero_words_ = 64 + 8 * 256 + status_words_ + ntiles;   // TileSync counters | gh | status | tile head counts
+  zero_.reserve(zero_words_ + ntiles);                                       // + the tile lists (not cleared)
   if (!h_err_.p) { h_err_.reserve(1); *h_err_.p = 0u; }
 }
 
@@ -850,7 +798,7 @@ void VoxelPipeline::sort_reduce(const float4* pts, const uint8_t* valid, uint32_
     return;
   }
   reserve(n, nseg);
-  if (!slots_) {   // workgroups of k_vox_ds the device can hold at once; the launch uses at most half of them (its barriers spin)
+  if (!slots_) {   // workgroups of k_vox_ds the device can hold at once; an upper bound of the useful grid size
     int per_cu = 0, dev = 0;
     LX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_vox_ds, 256, 0));
     LX_HIP(hipGetDevice(&dev));
@@ -918,12 +866,13 @@ void VoxelPipeline::sort_reduce(const float4* pts, const uint8_t* valid, uint32_
   VdsArgs a;
   a.pts = pts; a.valid = valid; a.seg_off = d_seg_off; a.seg_ids = d_seg_ids; a.ijk = ijk_.p; a.seg_minmax = seg_minmax_.p;
   a.keys[0] = keys_[0].p; a.keys[1] = keys_[1].p; a.vals[0] = vals_[0].p; a.vals[1] = vals_[1].p;
-  a.tile_cnt = tile_cnt_.p; a.head_scan = head_scan_.p; a.gathered = gathered_.p;
   a.err = h_err_.p; a.out = out; a.out_off = d_out_off;
   a.n = n; a.nseg = nseg; a.ntiles = (n + VDS_TILE - 1) / VDS_TILE;
   a.barrier = zero_.p; a.gh = zero_.p + 64; a.status = zero_.p + 64 + 8 * 256;
+  a.tile_cnt = a.status + status_words_;
+  a.link = zero_.p + zero_words_;
   LX_HIP(hipMemsetAsync(zero_.p, 0, sizeof(uint32_t) * zero_words_, st_));   // one block: barrier counter, digit histograms, tile status
-  uint32_t G = std::max<uint32_t>(1u, std::min<uint32_t>(a.ntiles, std::max<uint32_t>(slots_ / 2, 1u)));
+  uint32_t G = std::max<uint32_t>(1u, std::min<uint32_t>(a.ntiles, slots_));   // tiles are claimed: residency is not a correctness condition
   if (const char* e = getenv("LOAMX_VDS_WGS")) { const int v = atoi(e); if (v >= 1) G = std::min<uint32_t>(G, (uint32_t)v); }
   hipLaunchKernelGGL(k_vox_ds, dim3(G), dim3(256), 0, st_, a);
   LX_HIP(hipGetLastError());
@@ -945,7 +894,7 @@ void VoxelPipeline::sort_reduce(const float4* pts, const uint8_t* valid, uint32_
 void VoxelPipeline::check() {
   if (h_err_.p && *(volatile uint32_t*)h_err_.p) {
     *h_err_.p = 0u;
-    throw Error(LOAMX_E_HIP, "voxel grid: a grid barrier of k_vox_ds timed out (device over-subscribed?)");
+    throw Error(LOAMX_E_HIP, "voxel grid: a wait inside k_vox_ds timed out");
   }
 }
 

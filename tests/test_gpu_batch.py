@@ -60,6 +60,29 @@ def test_parity_vlp16_100k(orc):
         assert np.abs(got[:, :3] - want).max() < 2e-4 and np.array_equal(got[:, 3], fulls[k][:, 3])
 
 
+@pytest.mark.parametrize("env", [{"LOAMX_VDS_WGS": "3"}, {"LOAMX_VDS_WGS": "3", "LOAMX_VDS_GLOBAL": "1"}, {"LOAMX_VDS_GLOBAL": "1"}])
+def test_voxel_grid_does_not_depend_on_grid_size(orc, env, monkeypatch):
+    """The persistent voxel-grid kernels claim their tiles from a counter: with 3 workgroups instead of one per tile (what a
+    crowded device would leave resident) and through the general kernel the poses and the per-sweep statistics (down-sampled sizes, selected rows) are bit-identical."""
+    world = synth.World(half_extent=65.0)
+    cm, sm = world.make_map(100000)
+    cl, sl, guesses, _ = _inputs(orc, world, "VLP-16", 4, seed=5)
+
+    def run():
+        b = loamx.Batch(4)
+        b.set_frozen(cm, sm)
+        b.upload(cl, sl, guesses)
+        assert b.run() == loamx.OK
+        poses, stats = b.download()
+        return poses, stats
+
+    p0, s0 = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    p1, s1 = run()
+    assert np.array_equal(p0, p1) and np.array_equal(s0, s1)   # bit for bit: the voxel means feed every residual
+
+
 def test_full_size_hdl64_1m_map(orc):
     """BASELINE full size: HDL-64E sweeps against a 1M-point sub-map — oracle parity on 2 sweeps plus size-independent
     properties on a batch of 8 (batch-composition invariance, permutation equivariance, idempotence)."""

@@ -287,9 +287,10 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
 
 // ----------------------------------------------------------------------------------------------------------------
 // Per-ring pcl::VoxelGrid of the less-flat candidates (:246-252) in ONE workgroup per ring: the ring's candidates
-// (<= 4096) are compacted, keyed (voxel key << 12 | position, so equal voxels keep input order), bitonic-sorted in LDS,
-// and every voxel run is averaged by one thread in input order.  Same membership, order and float arithmetic as the
-// generic VoxelPipeline (which remains the fallback for longer rings); output goes to the ring's own slot range.
+// (<= 4096) are compacted, keyed (PCL's linear voxel index << 12 | position), sorted in LDS by a stable LSD radix sort on
+// the voxel index (8-bit digits, only as many passes as the index has bits — typically 3; the bitonic network this replaces
+// needed 66 stages), and every voxel run is averaged by one thread in input order.  Same membership, order and float
+// arithmetic as the generic VoxelPipeline (which remains the fallback for longer rings); output goes to the ring's own slots.
 // ----------------------------------------------------------------------------------------------------------------
 constexpr int LFV_THREADS = 1024;
 constexpr uint32_t LFV_MAX = 4096;
@@ -301,6 +302,8 @@ __global__ __launch_bounds__(LFV_THREADS) void k_feat_lf_voxel(const float4* __r
   unsigned long long* keys = (unsigned long long*)smem;   // P entries
   __shared__ uint32_t sc[17];
   __shared__ int mm[6];
+  __shared__ uint32_t s_wcnt[LFV_THREADS / 64][256];   // radix passes: per wave digit counts, then exclusive prefixes over the waves
+  __shared__ uint32_t s_base[256];
   const uint32_t r = blockIdx.x, tid = threadIdx.x;
   const uint32_t s0 = ring_off[r], len = ring_off[r + 1] - s0;
   if (tid < 3) mm[tid] = 2147483647;
@@ -320,17 +323,32 @@ __global__ __launch_bounds__(LFV_THREADS) void k_feat_lf_voxel(const float4* __r
   const uint32_t m = base;
   __syncthreads();
   // ---- voxel coordinates and their bounds
-  int ix = 0, iy = 0, iz = 0;
-  // (each thread handles candidates j = tid, tid + 256, ...; coordinates are recomputed when the key is formed)
-  for (uint32_t j = tid; j < m; j += LFV_THREADS) {
-    const float4 p = cloud[s0 + (uint32_t)keys[j]];
-    ix = (int)floorf(p.x * inv_leaf); iy = (int)floorf(p.y * inv_leaf); iz = (int)floorf(p.z * inv_leaf);
-    atomicMin(&mm[0], ix); atomicMin(&mm[1], iy); atomicMin(&mm[2], iz);
-    atomicMax(&mm[3], ix); atomicMax(&mm[4], iy); atomicMax(&mm[5], iz);
+  {   // per thread, then per wave (shuffles), then one LDS atomic per wave and bound: 2048 candidates hitting six LDS words
+      // one atomic at a time was the longest part of this kernel
+    int lo[3] = {2147483647, 2147483647, 2147483647}, hi[3] = {-2147483647 - 1, -2147483647 - 1, -2147483647 - 1};
+    for (uint32_t j = tid; j < m; j += LFV_THREADS) {
+      const float4 p = cloud[s0 + (uint32_t)keys[j]];
+      const int c[3] = {(int)floorf(p.x * inv_leaf), (int)floorf(p.y * inv_leaf), (int)floorf(p.z * inv_leaf)};
+#pragma unroll
+      for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], c[a]); hi[a] = max(hi[a], c[a]); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        lo[a] = min(lo[a], __shfl_xor(lo[a], off, 64));
+        hi[a] = max(hi[a], __shfl_xor(hi[a], off, 64));
+      }
+    }
+    if ((tid & 63u) == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) { atomicMin(&mm[a], lo[a]); atomicMax(&mm[3 + a], hi[a]); }
+    }
   }
   __syncthreads();
   const long long dx = (long long)mm[3] - mm[0] + 1, dy = (long long)mm[4] - mm[1] + 1, dz = (long long)mm[5] - mm[2] + 1;
-  const bool pass = m > 0 && (dx * dy * dz > 2147483647LL || dx > 4096 || dy > 4096 || dz > 4096);   // PCL: leaf too small
+  // PCL: "leaf size is too small" (more than INT_MAX voxels) -> the cloud passes through unfiltered
+  const bool pass = m > 0 && (dx > 2147483647LL || dy > 2147483647LL || dx * dy > 2147483647LL || dz > 2147483647LL / (dx * dy) + 1 || dx * dy * dz > 2147483647LL);
   for (uint32_t j = tid; j < m; j += LFV_THREADS) {
     const uint32_t li = (uint32_t)keys[j];
     unsigned long long k;
@@ -339,28 +357,79 @@ __global__ __launch_bounds__(LFV_THREADS) void k_feat_lf_voxel(const float4* __r
     } else {
       const float4 p = cloud[s0 + li];
       const int jx = (int)floorf(p.x * inv_leaf), jy = (int)floorf(p.y * inv_leaf), jz = (int)floorf(p.z * inv_leaf);
-      k = ((unsigned long long)(jz - mm[2]) << 24) | ((unsigned long long)(jy - mm[1]) << 12) | (unsigned long long)(jx - mm[0]);
+      k = (unsigned long long)((long long)(jx - mm[0]) + (long long)(jy - mm[1]) * dx + (long long)(jz - mm[2]) * dx * dy);
     }
-    keys[j] = (k << 12) | li;   // li < 4096: unique keys, equal voxels stay in input order
+    keys[j] = (k << 12) | li;   // li < 4096: unique elements; equal voxels are in input order and a stable sort keeps them so
   }
   __syncthreads();
-  // ---- bitonic sort of P keys (padding = ~0 sorts last).  Every thread owns one compare-exchange per stage (P/2 <= 1024
-  // pairs).  Stages whose partner distance is below 128 stay inside one wave's 128-key chunk and only need the wave's own
-  // LDS ordering; the workgroup barrier is kept for the 10 wide stages (it was 66 barriers before).
+  // ---- stable LSD radix sort on the voxel index.  Wave w owns the elements [w * per_wave, (w + 1) * per_wave) in slots of 64
+  // consecutive ones, so (wave, slot, lane) is the current order: per slot 8 ballots find the lanes with the same digit, the
+  // wave's running digit counts give the rank inside the wave, an exclusive prefix over the 16 waves and over the 256 digit
+  // totals the destination.  The second key buffer is the area that later holds the gathered points.
+  unsigned long long* kb[2] = {keys, (unsigned long long*)(smem + (size_t)P * 8)};
+  uint32_t npass = 0;
+  if (!pass && m > 1) {
+    const unsigned long long top = (unsigned long long)(dx * dy * dz - 1);
+    const uint32_t bits = top ? 64u - (uint32_t)__builtin_clzll(top) : 0u;
+    npass = (bits + 7u) / 8u;
+  }
   {
-    const uint32_t npairs = P >> 1;
-    for (uint32_t k2 = 2; k2 <= P; k2 <<= 1) {
-      for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-        for (uint32_t t = tid; t < npairs; t += LFV_THREADS) {
-          const uint32_t i = ((t / j2) * 2 * j2) + (t % j2), l = i + j2;
-          const unsigned long long a = keys[i], b = keys[l];
-          const bool up = (i & k2) == 0;
-          if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+    const uint32_t lane = tid & 63u, wid = tid >> 6;
+    const uint32_t per_wave = ((m + LFV_THREADS - 1) / LFV_THREADS) * 64u;   // <= 256
+    for (uint32_t ps = 0; ps < npass; ps++) {
+      const uint32_t shift = 12u + 8u * ps;
+      const unsigned long long* src = kb[ps & 1];
+      unsigned long long* dst = kb[(ps & 1) ^ 1];
+      for (uint32_t e = tid; e < (LFV_THREADS / 64) * 256; e += LFV_THREADS) (&s_wcnt[0][0])[e] = 0u;
+      __syncthreads();
+      unsigned long long key[4];
+      uint32_t rank[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t i = wid * per_wave + (uint32_t)j * 64u + lane;
+        const bool in = (uint32_t)j * 64u < per_wave && i < m;
+        key[j] = in ? src[i] : ~0ull;
+        const uint32_t d = (uint32_t)((key[j] >> shift) & 255ull);
+        unsigned long long mt = __ballot(in);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+          const unsigned long long bal = __ballot((d >> b) & 1u);
+          mt &= ((d >> b) & 1u) ? bal : ~bal;
         }
-        if (j2 >= 128 || (j2 >= 64 && npairs > LFV_THREADS)) __syncthreads();   // pairs t of a wave span keys [128w, 128w+128) when j2 <= 64
-        else wave_lds_sync();
+        const unsigned long long below = mt & ((1ull << lane) - 1ull);
+        const int leader = __builtin_ctzll(mt | (1ull << 63));
+        uint32_t old = 0u;
+        if (in && (int)lane == leader) {
+          old = s_wcnt[wid][d];
+          s_wcnt[wid][d] = old + (uint32_t)__popcll(mt);
+        }
+        old = __shfl(old, leader, 64);
+        rank[j] = old + (uint32_t)__popcll(below);
+        __builtin_amdgcn_wave_barrier();
       }
-      __syncthreads();   // (k2 changes the direction pattern; cheap relative to the stages saved)
+      __syncthreads();
+      uint32_t run = 0;
+      if (tid < 256) {
+#pragma unroll
+        for (int w = 0; w < LFV_THREADS / 64; w++) { const uint32_t c = s_wcnt[w][tid]; s_wcnt[w][tid] = run; run += c; }
+      }
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan(run, sc, tot);   // (threads >= 256 contribute 0 after the 256 digits)
+      if (tid < 256) s_base[tid] = ex;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t i = wid * per_wave + (uint32_t)j * 64u + lane;
+        if ((uint32_t)j * 64u < per_wave && i < m) {
+          const uint32_t d = (uint32_t)((key[j] >> shift) & 255ull);
+          dst[s_base[d] + s_wcnt[wid][d] + rank[j]] = key[j];
+        }
+      }
+      __syncthreads();
+    }
+    if (npass & 1u) {   // the result sits in the area the points are gathered into next
+      for (uint32_t j = tid; j < m; j += LFV_THREADS) keys[j] = kb[1][j];
+      __syncthreads();
     }
   }
   // ---- voxel heads -> output positions -> means.  The sorted points are first gathered into LDS (one parallel gather)

@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 STREAMS_PER_GPU = 8
-LAUNCH_TIMING_PERIOD = 4  # steps between two that carry HIP-event pairs around every k_gn_iter launch (roofline.achieved)
+TIMING_PERIOD = 4         # every 4th step of the timed region carries the HIP-event timing (stage chains, k_gn_iter launches)
 HANDLES_PER_GPU = 1      # >1: split the streams over several pipeline handles driven from host threads (measured: no gain)
 SENSOR = "HDL-64E"
 MAP_POINTS = 1_000_000
@@ -171,9 +171,10 @@ def main():
     stage = np.zeros(4)
     res_ms = 0.0
     res_launches = 0
-    q_iters = 0
-    q_iters_timed = 0   # query-iterations of the steps whose launches carried event pairs
-    queries = 0
+    q_iters_timed = 0   # query-iterations / queries of the sampled steps
+    queries_timed = 0
+    n_sampled = 0
+    in_step = 0.0       # wall time inside loamx_pipeline_step (the rest of the loop is this script)
     # double-buffered map epochs (off by default): epoch k+1 is broadcast and indexed in the background during epoch k
     # and swapped in before the first step of epoch k+1
     E = args.map_epoch_steps
@@ -209,19 +210,23 @@ def main():
                     ev = ev_map.cuda_event
                 for p in pipes:   # the index build waits for the event on the device; nothing blocks here
                     p.stage_frozen_device(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, ev)
-        sampled = (t - (1 + W)) % LAUNCH_TIMING_PERIOD == 0   # event pairs around the Gauss-Newton launches: every 4th step (they cost ~3 %)
+        # HIP-event timing (stage chains + a pair around every Gauss-Newton launch) on every 4th step only: the event pairs and
+        # their read-back (event synchronise, a statistics download) cost ~4 % of a step
+        sampled = (t - (1 + W)) % TIMING_PERIOD == 0
         for p in pipes:
-            p.set_timing(True, per_launch=sampled)
+            p.set_timing(sampled)
+        tc0 = time.perf_counter()
         run_step(t)
-        for p in pipes:   # event read-back of the step that just finished (the step itself is synchronous)
-            tm = p.timing()
-            stage += np.array([tm["features_ms"], tm["odometry_ms"], tm["registration_ms"], tm["step_ms"]]) / H
-            q_iters += tm["query_iterations"]
-            queries += tm["queries"]
-            if sampled:
+        in_step += time.perf_counter() - tc0
+        if sampled:
+            n_sampled += 1
+            for p in pipes:   # event read-back of the step that just finished (the step itself is synchronous)
+                tm = p.timing()
+                stage += np.array([tm["features_ms"], tm["odometry_ms"], tm["registration_ms"], tm["step_ms"]]) / H
                 res_ms += tm["residual_ms"]
                 res_launches += tm["residual_launches"]
                 q_iters_timed += tm["query_iterations"]
+                queries_timed += tm["queries"]
     sync_all()
     elapsed = time.perf_counter() - t0
     elapsed = lxdist.max_over_ranks(elapsed, dist, dev)
@@ -253,10 +258,11 @@ def main():
     if rank == 0:
         iters_map = np.mean([st["map_iterations"] for st in stats])
         iters_odom = np.mean([st["odom_iterations"] for st in stats])
-        q_per_sweep = queries / max(ns * K, 1)
+        S = max(n_sampled, 1)   # steps that carried the event timing
+        q_per_sweep = queries_timed / max(ns * S, 1)
         # BASELINE.md / SURVEY.md §8d algorithmic bytes per registered sweep (S = streams sharing the frozen map epoch)
         k_feat = 36 * synth.SENSORS[args.sensor][0]   # (2 sharp + 4 flat) x 6 regions per ring
-        bytes_per_sweep = 32 * n_points + 16 * M / (ns * K) + 72 * (q_iters / max(ns * K, 1)) + 48 * iters_odom * k_feat
+        bytes_per_sweep = 32 * n_points + 16 * M / (ns * K) + 72 * (q_iters_timed / max(ns * S, 1)) + 48 * iters_odom * k_feat
         avg_launch_ms = res_ms / max(res_launches, 1)
         achieved = (72.0 * q_iters_timed / max(res_launches, 1)) / (avg_launch_ms * 1e-3) / 1e9 if res_launches else 0.0
         out = {
@@ -282,8 +288,10 @@ def main():
                 "mean_map_iterations": round(float(iters_map), 2),
                 "mean_odom_iterations": round(float(iters_odom), 2),
                 "mean_queries_per_sweep": round(float(q_per_sweep), 1),
-                "stage_ms_per_step": {"features": round(stage[0] / K, 4), "odometry": round(stage[1] / K, 4),
-                                      "registration": round(stage[2] / K, 4), "gpu_step": round(stage[3] / K, 4)},
+                "stage_ms_per_step": {"features": round(stage[0] / S, 4), "odometry": round(stage[1] / S, 4),
+                                      "registration": round(stage[2] / S, 4), "gpu_step": round(stage[3] / S, 4)},
+                "ms_per_step_inside_step_call": round(in_step / K * 1e3, 4),
+                "stage_timing_sampling": f"HIP events on every {TIMING_PERIOD}th step of the timed region ({n_sampled} of {K} steps)",
                 "map_broadcast_ms": round(t_bcast * 1e3, 3),
                 "map_broadcast_via": bcast_via,
                 "map_epoch_steps": E,
@@ -308,7 +316,7 @@ def main():
                          "forms the 28 normal-equation sums and runs the 6x6 update step",
                 "avg_launch_us": round(avg_launch_ms * 1e3, 3),
                 "launches": res_launches,
-                "launch_sampling": f"HIP-event pairs around every k_gn_iter launch on every {LAUNCH_TIMING_PERIOD}th step of the timed region (the pairs cost ~3 % of a step)",
+                "launch_sampling": f"HIP-event pairs around every k_gn_iter launch on every {TIMING_PERIOD}th step of the timed region (the pairs and their read-back cost ~4 % of a step)",
                 "algorithmic_bytes_per_launch": round(72.0 * q_iters_timed / max(res_launches, 1), 1),
             },
         }

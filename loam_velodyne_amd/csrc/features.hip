@@ -99,6 +99,62 @@ __device__ inline void mark_as_picked(uint32_t scan_i, int cr, uint8_t* flags, c
   wave_lds_sync();
 }
 
+// One wave sorts up to 64 * KPL unique 64-bit keys (curvature bits << 32 | position) entirely in registers: element i of the
+// network lives in lane i / KPL, register i % KPL.  Compare-exchanges whose partner distance is below KPL stay inside the lane;
+// the others swap whole registers with the partner lane by shuffles — no LDS round trip and no fence per stage (the LDS version
+// this replaces spent 23 us of the ring's 48 us here).  The keys are unique, so any correct network yields the reference's
+// stable ascending order (:311-317); padding keys (~0) sort last.
+template <int KPL>
+__device__ inline void wave_sort_curvature(const float* __restrict__ c, uint32_t n, uint32_t* __restrict__ sorted, int lane) {
+  unsigned long long a[KPL];
+#pragma unroll
+  for (int r = 0; r < KPL; r++) {   // (initial placement is arbitrary for a sorting network: conflict-free reads)
+    const uint32_t e = (uint32_t)(r * 64 + lane);
+    a[r] = e < n ? ((unsigned long long)__float_as_uint(c[e]) << 32) | e : ~0ull;
+  }
+  constexpr uint32_t N = 64u * KPL;
+  // (k and the cross-lane j are run-time loop variables on purpose: fully unrolled, the 45-55 stages of five instantiations no longer
+  // fit the instruction cache and the kernel ran 1.5x slower than the LDS version; only the register indices have to be static)
+#pragma nounroll
+  for (uint32_t k = 2; k <= N; k <<= 1) {
+#pragma nounroll
+    for (uint32_t j = k >> 1; j >= (uint32_t)KPL; j >>= 1) {   // partner in another lane
+      const int pl = (int)(j / KPL);
+      const bool lower = (lane & pl) == 0;
+#pragma unroll
+      for (int r = 0; r < KPL; r++) {
+        const unsigned long long x = a[r];
+        const unsigned long long y = __shfl_xor(x, pl, 64);
+        const uint32_t i = (uint32_t)lane * KPL + (uint32_t)r;
+        const bool up = (i & k) == 0;           // the same for both ends of the pair (j < k)
+        const bool want_min = lower == up;
+        a[r] = want_min ? (x < y ? x : y) : (x < y ? y : x);
+      }
+    }
+#pragma unroll
+    for (int j = KPL / 2; j >= 1; j >>= 1) {   // partner in the same lane (static register indices)
+      if ((uint32_t)j <= (k >> 1)) {
+#pragma unroll
+        for (int r = 0; r < KPL; r++) {
+          if ((r & j) == 0) {
+            const uint32_t i = (uint32_t)lane * KPL + (uint32_t)r;
+            const bool up = (i & k) == 0;
+            const unsigned long long x = a[r], y = a[r | j];
+            const bool sw = (x > y) == up;
+            a[r] = sw ? y : x;
+            a[r | j] = sw ? x : y;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < KPL; r++) {
+    const uint32_t i = (uint32_t)lane * KPL + (uint32_t)r;
+    if (i < n) sorted[i] = (uint32_t)a[r];
+  }
+}
+
 #ifdef LOAMX_PROF_FEAT
 __device__ unsigned long long g_feat_ts[8];
 #define FT_TS(k) do { if (blockIdx.x == 100 && threadIdx.x == 0) g_feat_ts[k] = wall_clock64(); } while (0)
@@ -108,7 +164,8 @@ __device__ unsigned long long g_feat_ts[8];
 constexpr int FEAT_WAVES = 6;   // regions sorted concurrently per ring
 
 // one workgroup of FEAT_WAVES waves per ring.  Dynamic LDS: flags[flag_bytes] | gaps[flag_bytes] | per wave { c | sorted | label }[nmax]
-__global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
+// 5 waves per SIMD (<= 96 VGPRs): three 6-wave workgroups share a CU, and 512 rings on 256 CUs are not dealt two apiece
+__global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu(5))) void k_feat_ring(
     const float4* __restrict__ cloud, const uint32_t* __restrict__ ring_off, const uint32_t* __restrict__ ring_sweep_base, FeatParams P,
     const float* __restrict__ curv, const uint8_t* __restrict__ gflags, const uint8_t* __restrict__ ggap, uint32_t flag_bytes,
     uint32_t nmax, uint32_t sortP, float4* __restrict__ slotS,
@@ -165,9 +222,13 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) void k_feat_ring(
       FT_TS(1);
       // stable ascending order (:311-317): every wave sorts its own region with a bitonic network over unique 64-bit keys
       // (curvature bits << 32 | position: curvatures are sums of squares, so their bit patterns order like the values and
-      // equal curvatures keep their input order).  (The earlier rank sort — #smaller + #equal-before per element — was
-      // O(n^2) and took two thirds of this kernel.)
-      {
+      // equal curvatures keep their input order) — in registers for regions of up to 512 points, through LDS beyond that
+      // (16 keys per lane would cost the kernel its third workgroup per CU).
+      if (sortP == 64) wave_sort_curvature<1>(c, n, sorted, lane);
+      else if (sortP == 128) wave_sort_curvature<2>(c, n, sorted, lane);
+      else if (sortP == 256) wave_sort_curvature<4>(c, n, sorted, lane);
+      else if (sortP == 512) wave_sort_curvature<8>(c, n, sorted, lane);
+      else {
         unsigned long long* keys = (unsigned long long*)(wave_base + FEAT_WAVES * wave_bytes + (size_t)wid * sortP * 8);
         for (uint32_t e = lane; e < sortP; e += 64)
           keys[e] = e < n ? ((unsigned long long)__float_as_uint(c[e]) << 32) | e : ~0ull;
@@ -848,7 +909,7 @@ void FeatureExtractor::run_async() {
   uint32_t sortP = 64;   // bitonic sort size of one region
   while (sortP < nmax) sortP <<= 1;
   const size_t lds = ((2 * (size_t)flag_bytes + 4 * (size_t)(caps[0] + caps[1] + caps[2]) + 15) & ~(size_t)15) + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) +
-                     (size_t)FEAT_WAVES * sortP * 8 + 16;
+                     (sortP > 512 ? (size_t)FEAT_WAVES * sortP * 8 : 0) + 16;   // (regions of up to 512 points are sorted in registers)
   LX_REQUIRE(lds <= 160 * 1024, "scan ring too long for the LDS staging of k_feat_ring");
   if (lds > 64 * 1024)
     LX_HIP(hipFuncSetAttribute((const void*)k_feat_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -92,3 +92,37 @@ def test_mapping_too_few_rows(orc, small_world):
     g.process(lc, ls, full)
     assert o.stats()["optimized"] == 1 and o.stats()["sel"] < 50 and g.stats()["sel"] == o.stats()["sel"]
     assert np.abs(o.transform("aft") - g.transform("aft")).max() < 1e-6
+
+
+def test_nan_rows_through_the_odometry_solve(orc, small_world):
+    """Duplicated tripod points (the same corner on two adjacent rings of the previous cloud) make l12 = 0: the rows of those
+    features are NaN and — NaN != 0 — selected (BasicLaserOdometry.cpp:330-361).  The whole normal system is then non-finite.
+    The oracle's restatement of the column-pivoted QR answers zeros for it, the loop stops after one iteration and the seeded
+    motion estimate stands; the device has to take NaN through its reduction and its QR to the same end."""
+    poses = synth.trajectory(2)
+    sws = [synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=100 + k, az_steps=900) for k in range(2)]
+    sr = op.ScanRegistration(orc)
+    f0, f1 = sr.process(sws[0].points, sws[0].ring_sizes), sr.process(sws[1].points, sws[1].ring_sizes)
+    ls = f0["less_sharp"]
+    dup = ls.copy()
+    dup[:, 3] += 1.0
+    both = np.concatenate([ls, dup])
+    f0d = dict(f0)
+    f0d["less_sharp"] = both[np.argsort(np.floor(both[:, 3]), kind="stable")]
+    seed = np.float32([0.001, 0.002, -0.001, 0.05, 0.0, -0.3])
+    ood, god = op.LaserOdometry(orc), loamx.LaserOdometry()
+    ood.set_features(f0d)
+    ood.process()
+    god.process(f0d)
+    ood.set_features(f1)
+    ood.set_transform(seed)
+    ood.process()
+    god.set_transform(seed)
+    god.process(f1)
+    assert np.all(np.isfinite(god.transform)) and np.all(np.isfinite(god.transform_sum))
+    assert np.array_equal(ood.transform, god.transform)
+    assert np.abs(ood.transform_sum - god.transform_sum).max() < 1e-6
+    # (the row COUNT may differ by a row or two: original and duplicate are exactly equidistant, and which of the two a 1-NN search
+    # returns is a property of the search structure — the kd-tree's traversal order in the reference, the lowest index here)
+    assert ood.stats()["iterations"] == god.stats()["iterations"] == 1
+    assert abs(ood.stats()["sel"] - god.stats()["sel"]) <= 4

@@ -275,6 +275,10 @@ void* loamx_batch_stream(loamx_batch* h);
  * (distance, index).  Only neighbours closer than 1.05 m are searched for (the reference rejects a query whose fifth
  * neighbour is 1 m away or more, BasicLaserMapping.cpp:671, :760): missing entries are 0xffffffff / FLT_MAX. */
 int loamx_batch_knn_probe(loamx_batch* h, int which, const float* queries_xyz, uint32_t n, uint32_t* idx5, float* d2_5);
+/* Parity hook for the voxel-grid stage: the down-sampled stack clouds of one sweep of the last run (laserCloudCornerStackDS /
+ * laserCloudSurfStackDS, BasicLaserMapping.cpp:512-527 — the query points of the Gauss-Newton iterations, sensor frame, in
+ * pcl::VoxelGrid's output order).  count fields: capacity in, size out; LOAMX_E_CAPACITY when a cloud does not fit. */
+int loamx_batch_download_ds(loamx_batch* h, uint32_t sweep, loamx_cloud* corner_ds, loamx_cloud* surf_ds);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Streaming pipeline: n independent streams, each advancing one sweep per step through feature extraction ->

@@ -148,6 +148,17 @@ int loamx_batch_knn_probe(loamx_batch* h, int which, const float* queries_xyz, u
     return LOAMX_OK;
   });
 }
+int loamx_batch_download_ds(loamx_batch* h, uint32_t sweep, loamx_cloud* corner_ds, loamx_cloud* surf_ds) {
+  return guard([&]() {
+    LX_REQUIRE(h && corner_ds && surf_ds, "NULL argument");
+    check_cloud(corner_ds, false);
+    check_cloud(surf_ds, false);
+    std::vector<float4> c, s;
+    h->reg.download_ds(sweep, c, s);
+    const int rc = unpack_cloud(c.data(), (uint32_t)c.size(), corner_ds), rs = unpack_cloud(s.data(), (uint32_t)s.size(), surf_ds);
+    return rc != LOAMX_OK ? rc : rs;
+  });
+}
 void* loamx_batch_stream(loamx_batch* h) { return h ? (void*)h->reg.stream() : nullptr; }
 
 }  // extern "C"

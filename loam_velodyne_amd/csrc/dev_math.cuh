@@ -58,7 +58,7 @@ __host__ __device__ inline void to_be_mapped(const Pose& T, float& x, float& y, 
 
 // ---- symmetric 3x3 eigen-decomposition, cyclic Jacobi.  In: lower triangle a00,a10,a11,a20,a21,a22.
 // Out: eigenvalues ascending w0<=w1<=w2 and the unit eigenvector of the LARGEST one.
-__device__ inline void eig3_sym(float a00, float a10, float a11, float a20, float a21, float a22, float& w0, float& w1,
+__device__ __forceinline__ void eig3_sym(float a00, float a10, float a11, float a20, float a21, float a22, float& w0, float& w1,
                                 float& w2, float& vx, float& vy, float& vz) {
   float A[3][3] = {{a00, a10, a20}, {a10, a11, a21}, {a20, a21, a22}};
   float Q[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
@@ -117,8 +117,54 @@ __device__ inline void eig3_sym(float a00, float a10, float a11, float a20, floa
   vx = c2x; vy = c2y; vz = c2z;
 }
 
+// ---- the same decomposition in closed form, double precision: eigenvalues by the trigonometric solution of the characteristic
+// cubic, the eigenvector of the largest one as the best-conditioned cross product of two rows of A - w2 I.  No iteration: ~300
+// dependent instructions against the ~4000 of eight Jacobi sweeps (the single-lane latency of a corner tile, k_gn_iter).  The
+// reference's SelfAdjointEigenSolver<Matrix3f> (tridiagonal QL in float) and the Jacobi restatement above both approximate what
+// this computes to ~1e-15: the exact eigen-pairs of the float matrix, rounded to float at the end.  The vector is only defined
+// up to sign (the edge residual does not depend on it) and only used when w2 > 3 w1, where it is well conditioned.
+__device__ __forceinline__ void eig3_sym_direct(float a00f, float a10f, float a11f, float a20f, float a21f, float a22f, float& w0, float& w1,
+                                       float& w2, float& vx, float& vy, float& vz) {
+  const double a00 = a00f, a01 = a10f, a11 = a11f, a02 = a20f, a12 = a21f, a22 = a22f;
+  const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+  const double q = (a00 + a11 + a22) / 3.0;
+  const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+  const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
+  double e0, e1, e2;
+  if (!(p2 > 0.0)) {   // a multiple of the identity (or zero)
+    e0 = e1 = e2 = q;
+  } else {
+    const double p = sqrt(p2 / 6.0), ip = 1.0 / p;
+    const double c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
+    double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    const double phi = acos(r) / 3.0;
+    e2 = q + 2.0 * p * cos(phi);
+    e0 = q + 2.0 * p * cos(phi + 2.0943951023931954923);   // + 2 pi / 3
+    e1 = 3.0 * q - e2 - e0;
+  }
+  w0 = (float)e0; w1 = (float)e1; w2 = (float)e2;
+  // rows of A - e2 I
+  const double r0x = a00 - e2, r0y = a01, r0z = a02;
+  const double r1x = a01, r1y = a11 - e2, r1z = a12;
+  const double r2x = a02, r2y = a12, r2z = a22 - e2;
+  const double ax = r0y * r1z - r0z * r1y, ay = r0z * r1x - r0x * r1z, az = r0x * r1y - r0y * r1x;   // r0 x r1
+  const double bx = r0y * r2z - r0z * r2y, by = r0z * r2x - r0x * r2z, bz = r0x * r2y - r0y * r2x;   // r0 x r2
+  const double cx = r1y * r2z - r1z * r2y, cy = r1z * r2x - r1x * r2z, cz = r1x * r2y - r1y * r2x;   // r1 x r2
+  const double na = ax * ax + ay * ay + az * az, nb = bx * bx + by * by + bz * bz, nc = cx * cx + cy * cy + cz * cz;
+  double ux = ax, uy = ay, uz = az, nu = na;
+  if (nb > nu) { ux = bx; uy = by; uz = bz; nu = nb; }
+  if (nc > nu) { ux = cx; uy = cy; uz = cz; nu = nc; }
+  if (nu > 0.0) {
+    const double inv = 1.0 / sqrt(nu);
+    vx = (float)(ux * inv); vy = (float)(uy * inv); vz = (float)(uz * inv);
+  } else {
+    vx = 0.f; vy = 0.f; vz = 1.f;
+  }
+}
+
 // ---- column-pivoted Householder QR least squares, fully unrolled so A stays in registers.
-template <int M, int N> __device__ inline void qr_solve(float (&A)[M][N], float (&b)[M], float (&x)[N]) {
+template <int M, int N> __device__ __forceinline__ void qr_solve(float (&A)[M][N], float (&b)[M], float (&x)[N]) {
   int perm[N];
 #pragma unroll
   for (int c = 0; c < N; c++) perm[c] = c;
@@ -217,7 +263,7 @@ template <int M, int N> __device__ inline void qr_solve(float (&A)[M][N], float 
 // ---- 6x6 helpers for the once-per-iteration solve (one thread).  Work arrays live in a caller-provided LDS
 // workspace `ws` (>= 216 floats): dynamically indexed private arrays would be placed in scratch (global memory), whose
 // latency dominates a serial solve.
-__device__ inline void eig6_sym(const float* Ain, float* w, float* V, float* ws) {
+__device__ __forceinline__ void eig6_sym(const float* Ain, float* w, float* V, float* ws) {
   float* A = ws;        // 36
   float* Q = ws + 36;   // 36
   for (int r = 0; r < 6; r++)
@@ -275,7 +321,7 @@ __device__ inline void eig6_sym(const float* Ain, float* w, float* V, float* ws)
   }
 }
 
-__device__ inline bool inverse6(const float* Ain, float* inv, float* ws) {
+__device__ __forceinline__ bool inverse6(const float* Ain, float* inv, float* ws) {
   float* A = ws;   // 6 x 12
   for (int r = 0; r < 6; r++)
     for (int c = 0; c < 6; c++) {
@@ -308,7 +354,7 @@ __device__ inline bool inverse6(const float* Ain, float* inv, float* ws) {
 // AtA - thr*(1+1e-3)*I in double succeeds with pivots well above rounding noise.  When it holds the reference's loop
 // (BasicLaserMapping.cpp:883-897) zeroes nothing, isDegenerate stays false and matP is never used, so the 6x6
 // eigen-decomposition can be skipped; borderline and degenerate cases take the full path below.
-__device__ inline bool certainly_not_degenerate(const float* AtA, float thr) {
+__device__ __forceinline__ bool certainly_not_degenerate(const float* AtA, float thr) {
   double L[6][6];
   const double shift = (double)thr * 1.001;
   double scale = 0.0;
@@ -337,8 +383,13 @@ __device__ inline bool certainly_not_degenerate(const float* AtA, float thr) {
   return true;
 }
 
+__device__ __forceinline__ bool degeneracy_projector_full(const float* AtA, float thr, float* P, float* ws);
 __device__ __forceinline__ bool degeneracy_projector(const float* AtA, float thr, float* P, float* ws) {
   if (certainly_not_degenerate(AtA, thr)) return false;
+  return degeneracy_projector_full(AtA, thr, P, ws);
+}
+// the reference's computation itself (the caller has found no certificate)
+__device__ __forceinline__ bool degeneracy_projector_full(const float* AtA, float thr, float* P, float* ws) {
   float w[6];
   float* V = ws + 72;     // 36
   float* V2 = ws + 108;   // 36
@@ -376,9 +427,9 @@ __device__ __forceinline__ bool degeneracy_projector(const float* AtA, float thr
 // order, so the result is bit-identical — only the serial dependency chain shrinks.  Values travel between lanes with
 // v_readlane (a few cycles) instead of ds_bpermute (~60 cycles each on the critical path).
 // Must be called by ALL 64 lanes of wave 0 of the workgroup; AtA/AtB/X are in LDS or global memory.
-__device__ inline float lane_get(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
+__device__ __forceinline__ float lane_get(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
 
-__device__ inline void qr_solve6_coop(const float* AtA, const float* AtB, float* X) {
+__device__ __forceinline__ void qr_solve6_coop(const float* AtA, const float* AtB, float* X) {
   const int gl = (int)(threadIdx.x & 63);
   float a[6];
 #pragma unroll

@@ -5,6 +5,7 @@
 #include "common.h"
 #include "dev_math.cuh"
 #include "voxel.cuh"
+#include "voxbucket.cuh"
 
 namespace loamx {
 
@@ -155,9 +156,19 @@ class Registrar {
   DevBuf<const float4*> src_ptrs_;
   bool full_staged_ = false;
   VoxelPipeline vox_;
+  // the stack clouds' voxel grid normally takes the bucketed path (voxbucket.cuh); a run that gives up is repeated through the
+  // general kernel as soon as the host has synchronised with it (LOAMX_VOX_LEGACY=1 forces the general kernel)
+  VoxBucket vb_;
+  bool vb_disabled_ = false;   // LOAMX_VOX_LEGACY
+  bool jacobi_eig_ = false;    // LOAMX_EIG_JACOBI: the edge fit's eigen-decomposition by the oracle's Jacobi iteration instead of the closed form
+  bool vb_unchecked_ = false;  // the last run used the bucketed path and its fail word has not been looked at yet
+  void enqueue_front(bool legacy);   // k_pose_init + stack round trip + voxel grid
+  void enqueue_full(int mode);       // transformFullResToMap
+  bool full_enqueued_ = false;
+  void redo_if_bucket_path_failed(); // after a stream sync
   uint32_t n_in_ = 0, n_full_ = 0, max_q_per_sweep_ = 0;
   bool mirrors_written_ = false;      // h_poses_ / h_stats_ hold (after a stream sync) this run's final values
-  void run_iterations(bool trace, double& th2, double& th3);
+  bool run_iterations(bool trace, double& th2, double& th3);   // true: the bucketed voxel path gave up, run again
   void fetch_results();
   int pred_iters_ = 4;        // early_exit: iterations to enqueue before the first look at the done flags
 
@@ -179,6 +190,8 @@ class Registrar {
   hipEvent_t ev_build_ = nullptr, ev_swap_ = nullptr;
   bool next_staged_ = false, swapped_once_ = false;
   DevBuf<uint32_t> arrive_;   // per sweep: k_gn_iter workgroups that have delivered their tile sums
+  DevBuf<uint32_t> full_done_;   // per sweep: tag of the k_transform_full launch that registered its full-resolution cloud
+  uint32_t full_tag_ = 0;
   uint32_t nblk_ = 0;
 
   std::vector<hipEvent_t> ev_;   // timing events: [0]=run start, [1]=run end, then pairs per Gauss-Newton launch

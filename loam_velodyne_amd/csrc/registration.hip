@@ -376,10 +376,11 @@ __global__ __launch_bounds__(256) void k_stack(const float4* __restrict__ in, co
 // ----------------------------------------------------------------------------------------------------------------
 // (also resets the voxel bounds of the sweep's two segments: one launch less in front of k_stack)
 __global__ void k_pose_init(const float* __restrict__ guess, uint32_t ns, Pose* __restrict__ poses, SweepStats* __restrict__ stats,
-                            int* __restrict__ seg_minmax, uint32_t* __restrict__ ticket) {
+                            int* __restrict__ seg_minmax, uint32_t* __restrict__ ticket, uint32_t* __restrict__ full_done) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
   ticket[s] = 0u;   // k_gn_iter's per-sweep arrival counter
+  full_done[s] = 0u;
   for (int k = 0; k < 12; k++) seg_minmax[12 * s + k] = (k % 6) < 3 ? 2147483647 : (-2147483647 - 1);
   Pose T;
   pose_set_angles(T, guess[6 * s], guess[6 * s + 1], guess[6 * s + 2]);
@@ -408,7 +409,7 @@ constexpr float KNN_COVER2 = 1.05f * 1.05f * 0.9999f;   // every map point withi
 // Branch-free insertion into a lane's ascending top-6.  A candidate's rank key is (bits(d2) << 32) | original index:
 // d2 >= +0 and finite, so the unsigned order of the float bits is the order of the values and one 64-bit compare is the
 // strict (d2, index) order of a sequential scan.
-__device__ inline void knn_insert6(unsigned long long (&bk)[6], uint32_t (&bp)[6], unsigned long long key, uint32_t pos) {
+__device__ __forceinline__ void knn_insert6(unsigned long long (&bk)[6], uint32_t (&bp)[6], unsigned long long key, uint32_t pos) {
   bool lt[6];
 #pragma unroll
   for (int j = 0; j < 6; j++) lt[j] = key < bk[j];
@@ -424,7 +425,7 @@ constexpr unsigned long long KNN_NONE = 0x7f7fffffffffffffull;   // (FLT_MAX, 0x
 
 // pop the group's six best (destructive on the lane lists); every lane of the group ends up with the same winners
 template <int LPQ>
-__device__ inline void knn_pop6(unsigned long long (&bk)[6], uint32_t (&bp)[6], int gl, unsigned long long (&wk)[6], uint32_t (&win)[6]) {
+__device__ __forceinline__ void knn_pop6(unsigned long long (&bk)[6], uint32_t (&bp)[6], int gl, unsigned long long (&wk)[6], uint32_t (&win)[6]) {
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     unsigned long long key = bk[0];
@@ -455,8 +456,10 @@ struct Row {
   bool sel;
 };
 
-// corner query: BasicLaserMapping.cpp:667-751
-__device__ inline void corner_row(const Pose& T, const float4 po, const float4* __restrict__ pts, const uint32_t (&bp)[5], float& cx_,
+// corner query: BasicLaserMapping.cpp:667-751.  JACOBI: the 3x3 eigen-decomposition by the cyclic Jacobi iteration the oracle uses
+// for Eigen's solver (instruction for instruction) instead of the closed form (dev_math.cuh)
+template <bool JACOBI>
+__device__ __forceinline__ void corner_row(const Pose& T, const float4 po, const float4* __restrict__ pts, const uint32_t (&bp)[5], float& cx_,
                                   float& cy_, float& cz_, float& ci_, bool& sel) {
   sel = false;
   float x0 = po.x, y0 = po.y, z0 = po.z;
@@ -477,7 +480,8 @@ __device__ inline void corner_row(const Pose& T, const float4 po, const float4* 
   }
   a00 /= 5.0f; a10 /= 5.0f; a20 /= 5.0f; a11 /= 5.0f; a21 /= 5.0f; a22 /= 5.0f;
   float w0, w1, w2, ex, ey, ez;
-  eig3_sym(a00, a10, a11, a20, a21, a22, w0, w1, w2, ex, ey, ez);
+  if (JACOBI) eig3_sym(a00, a10, a11, a20, a21, a22, w0, w1, w2, ex, ey, ez);
+  else eig3_sym_direct(a00, a10, a11, a20, a21, a22, w0, w1, w2, ex, ey, ez);
   if (!(w2 > 3 * w1)) return;
   const float x1 = (float)(vx + 0.1 * ex), y1 = (float)(vy + 0.1 * ey), z1 = (float)(vz + 0.1 * ez);
   const float x2 = (float)(vx - 0.1 * ex), y2 = (float)(vy - 0.1 * ey), z2 = (float)(vz - 0.1 * ez);
@@ -498,7 +502,7 @@ __device__ inline void corner_row(const Pose& T, const float4 po, const float4* 
 }
 
 // surf query: BasicLaserMapping.cpp:756-816
-__device__ inline void surf_row(const Pose& T, const float4 po, const float4* __restrict__ pts, const uint32_t (&bp)[5], float& cx_,
+__device__ __forceinline__ void surf_row(const Pose& T, const float4 po, const float4* __restrict__ pts, const uint32_t (&bp)[5], float& cx_,
                                 float& cy_, float& cz_, float& ci_, bool& sel) {
   sel = false;
   float x0 = po.x, y0 = po.y, z0 = po.z;
@@ -538,7 +542,7 @@ __device__ unsigned long long g_solve_ts[16];
 #else
 #define SOLVE_TS(k) do { } while (0)
 #endif
-__device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_off, Pose* __restrict__ poses, SweepStats* __restrict__ stats,
+__device__ __forceinline__ void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_off, Pose* __restrict__ poses, SweepStats* __restrict__ stats,
                                    float* __restrict__ matP, const double* partials, uint32_t nblk, uint32_t nact, int iter,
                                    float delta_t_abort, float delta_r_abort, SweepStats* host_stats, Pose* host_poses) {
   __shared__ double gsum[LX_SOLVE_GROUPS][LX_NSUM];
@@ -547,6 +551,7 @@ __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_o
   __shared__ float AtA[36], AtB[6], X[6], X2[6], trig[6];
   __shared__ Pose sP;
   __shared__ SweepStats sSt;
+  __shared__ int s_cert;
   const int tid = (int)threadIdx.x;
   SOLVE_TS(0);
   if (tid == LX_RES_THREADS - 1) {   // (a lane of the last wave: the loads overlap with the partial sums below)
@@ -602,11 +607,12 @@ __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_o
   }
   SOLVE_TS(2);
   if (tid < 64) qr_solve6_coop(AtA, AtB, X);   // wave 0, all lanes
+  else if (tid == 64 && iter == 0) s_cert = certainly_not_degenerate(AtA, 100.f) ? 1 : 0;   // wave 1, meanwhile: the non-degeneracy certificate
   __syncthreads();
   SOLVE_TS(3);
   float* P = matP + 36 * s;
   if (tid == 0) {
-    if (iter == 0) sSt.degenerate = degeneracy_projector(AtA, 100.f, P, ws) ? 1 : 0;
+    if (iter == 0) sSt.degenerate = s_cert ? 0 : (degeneracy_projector_full(AtA, 100.f, P, ws) ? 1 : 0);
     if (sSt.degenerate) {
       for (int r = 0; r < 6; r++) X2[r] = X[r];
       for (int r = 0; r < 6; r++) {
@@ -695,7 +701,7 @@ __device__ inline void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_o
 // flat, strided scan of NR concatenated runs by the LPQ lanes of a group: lane gl takes candidates gl, gl + LPQ, ...
 // (adjacent lanes read adjacent points: a group's load covers one or two cache lines), MLP loads in flight per lane
 template <int NR, int MLP, int LPQ>
-__device__ inline void knn_scan_group(const float4* __restrict__ pts, const uint32_t (&beg)[NR], const uint32_t (&len)[NR], float qx, float qy,
+__device__ __forceinline__ void knn_scan_group(const float4* __restrict__ pts, const uint32_t (&beg)[NR], const uint32_t (&len)[NR], float qx, float qy,
                                       float qz, int gl, unsigned long long (&bk)[6], uint32_t (&bp)[6]) {
   uint32_t E[NR], O[NR];   // cumulative candidate count after run k; position = candidate number + O[k] inside run k
   uint32_t acc = 0;
@@ -732,7 +738,7 @@ __device__ inline void knn_scan_group(const float4* __restrict__ pts, const uint
 
 // distance (cell units) from coordinate f inside cell c to the neighbouring cell on side d (-1 / +1), shrunk by 1e-4
 // relative + 1e-5 so that rounding can only make the visit larger
-__device__ inline float knn_gap(float f, int c, int d) {
+__device__ __forceinline__ float knn_gap(float f, int c, int d) {
   const float v = d > 0 ? (float)(c + 1) - f : f - (float)c;
   const float w = v * 0.9999f - 1e-5f;
   return w > 0.f ? w : 0.f;
@@ -742,7 +748,7 @@ __device__ inline float knn_gap(float f, int c, int d) {
 // tab: the group's column of an LDS table [36][QB] (entry e of this group at tab[e * QB]).
 // out (all lanes): wk[0..5] ascending rank keys (KNN_NONE = empty), win[] = positions in the cell-sorted array
 template <int LPQ, int QB>
-__device__ inline void knn5_group(const GridDesc& g, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start, float qx, float qy,
+__device__ __forceinline__ void knn5_group(const GridDesc& g, const float4* __restrict__ pts, const uint32_t* __restrict__ cell_start, float qx, float qy,
                                   float qz, int gl, uint32_t* tab, unsigned long long (&wk)[6], uint32_t (&win)[6]) {
 #pragma unroll
   for (int j = 0; j < 6; j++) { wk[j] = KNN_NONE; win[j] = 0u; }
@@ -853,130 +859,16 @@ constexpr int GN_TILE = LX_RES_THREADS / KNN_LPQ;   // queries per workgroup
 #define GN_TS(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(LX_RES_THREADS) void k_gn_iter(const GnArgs A) {
-  constexpr int TRS = GN_TILE + 1;
-  __shared__ float tr[LX_NSUM * TRS];      // the tile's float products, transposed
-  __shared__ uint32_t s_tab[36 * GN_TILE];   // knn5_group's table staging, [entry][group]
-  __shared__ uint32_t s_nb[5 * GN_TILE];     // the winners' positions, [neighbour][query]
-  __shared__ double red[8][LX_NSUM];
-  __shared__ int sh_last;
-  const uint32_t s = blockIdx.y;
-  if (A.stats[s].done) return;
-  const int tid = (int)threadIdx.x;
-  const uint32_t q0 = A.ds_off[2 * s], qm = A.ds_off[2 * s + 1], q1 = A.ds_off[2 * s + 2];
-  const uint32_t tc = (qm - q0 + GN_TILE - 1) / GN_TILE, tsf = (q1 - qm + GN_TILE - 1) / GN_TILE;
-  const uint32_t ntiles = (tc + tsf) ? tc + tsf : 1u;   // (a sweep without queries still burns the iteration: one empty tile)
-  // XCD-aware order: workgroup b runs on XCD b % 8 — every XCD gets a contiguous eighth of the (voxel-ordered) corner tiles
-  // and a contiguous eighth of the surf tiles, the corner tiles first: their fit (a 3x3 Jacobi eigen solver per query) takes
-  // several times longer than the plane fit, so they start early and are spread over all XCDs
-  uint32_t tile;
-  {
-    const uint32_t x = blockIdx.x % 8, j = blockIdx.x / 8;
-    const uint32_t tsurf = ntiles - tc;   // (the empty tile of a sweep without queries counts as a surf tile)
-    const uint32_t c0 = x * tc / 8, c1 = (x + 1) * tc / 8, s0 = x * tsurf / 8, s1 = (x + 1) * tsurf / 8;
-    if (j < c1 - c0) tile = c0 + j;
-    else if (j - (c1 - c0) < s1 - s0) tile = tc + s0 + (j - (c1 - c0));
-    else return;
-  }
-  const bool corner = tile < tc;   // block-uniform
-  const uint32_t qbase = corner ? q0 + tile * GN_TILE : qm + (tile - tc) * GN_TILE;
-  const uint32_t qend = corner ? qm : q1;
-  GN_TS(0);
-  const Pose T = A.poses[s];
-  // ---- search: KNN_LPQ lanes per query
-  {
-    const int grp = tid / KNN_LPQ, gl = tid % KNN_LPQ;
-    const uint32_t q = qbase + (uint32_t)grp;
-    if (q < qend) {   // group-uniform
-      const float4 po = A.ds_pts[q];
-      float qx = po.x, qy = po.y, qz = po.z;
-      to_map(T, qx, qy, qz);
-      unsigned long long wk[6];
-      uint32_t win[6];
-      knn5_group<KNN_LPQ, GN_TILE>(corner ? *A.cdesc : *A.sdesc, corner ? A.cpts : A.spts, corner ? A.cstart : A.sstart, qx, qy, qz, gl, s_tab + grp, wk,
-                                   win);
-      if (gl == 0) {
-        const float d5 = wk[4] != KNN_NONE ? __uint_as_float((uint32_t)(wk[4] >> 32)) : FLT_MAX;
-#pragma unroll
-        for (int j = 0; j < 5; j++) s_nb[j * GN_TILE + grp] = (j == 4 && !(d5 < 1.0f)) ? 0xffffffffu : win[j];   // == pointSearchSqDis[4] < 1.0 (:671, :760)
-      }
-    }
-  }
-  __syncthreads();
-  GN_TS(1);
-  // ---- one lane per query (wave 0): edge / plane fit, weight, Jacobian row; float products into the transposed table
-  if (tid < GN_TILE) {
-    const uint32_t q = qbase + (uint32_t)tid;
-    float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bb = 0.f;
-    bool sel = false;
-    if (q < qend) {
-      const float4 po = A.ds_pts[q];
-      uint32_t bp[5];
-#pragma unroll
-      for (int j = 0; j < 5; j++) bp[j] = s_nb[j * GN_TILE + tid];
-      float cx, cy, cz, ci;
-      if (corner) corner_row(T, po, A.cpts, bp, cx, cy, cz, ci, sel);
-      else surf_row(T, po, A.spts, bp, cx, cy, cz, ci, sel);
-      if (sel) {
-        // Jacobian row, BasicLaserMapping.cpp:842-861
-        const float srx = T.srx, crx = T.crx, sry = T.sry, cry = T.cry, srz = T.srz, crz = T.crz;
-        a[0] = (crx * sry * srz * po.x + crx * crz * sry * po.y - srx * sry * po.z) * cx +
-               (-srx * srz * po.x - crz * srx * po.y - crx * po.z) * cy +
-               (crx * cry * srz * po.x + crx * cry * crz * po.y - cry * srx * po.z) * cz;
-        a[1] = ((cry * srx * srz - crz * sry) * po.x + (sry * srz + cry * crz * srx) * po.y + crx * cry * po.z) * cx +
-               ((-cry * crz - srx * sry * srz) * po.x + (cry * srz - crz * srx * sry) * po.y - crx * sry * po.z) * cz;
-        a[2] = ((crz * srx * sry - cry * srz) * po.x + (-cry * crz - srx * sry * srz) * po.y) * cx +
-               (crx * crz * po.x - crx * srz * po.y) * cy +
-               ((sry * srz + cry * crz * srx) * po.x + (crz * sry - cry * srx * srz) * po.y) * cz;
-        a[3] = cx; a[4] = cy; a[5] = cz;
-        bb = -ci;
-      }
-    }
-    // products in float (as Eigen's float A^T A forms them)
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-      for (int j = i; j < 6; j++) tr[(k++) * TRS + tid] = a[i] * a[j];
-#pragma unroll
-    for (int i = 0; i < 6; i++) tr[(k++) * TRS + tid] = a[i] * bb;
-    tr[k * TRS + tid] = sel ? 1.f : 0.f;
-  }
-  __syncthreads();
-  GN_TS(2);
-  // ---- accumulated in double in a fixed order: column c of the 64 x 28 table is summed by 8 threads (rows g, g + 8, ...),
-  // then the 8 strands in order
-  if (tid < 8 * LX_NSUM) {
-    const int c = tid % LX_NSUM, g8 = tid / LX_NSUM;
-    const float* col = tr + c * TRS + g8;
-    double x = 0.0;
-#pragma unroll
-    for (int j = 0; j < GN_TILE / 8; j++) x += (double)col[8 * j];
-    red[g8][c] = x;
-  }
-  __syncthreads();
-  if (tid < LX_NSUM) {
-    double x = 0.0;
-#pragma unroll
-    for (int w = 0; w < 8; w++) x += red[w][tid];
-    A.partials[((size_t)s * A.nblk + tile) * LX_NSUM + tid] = x;
-    __threadfence();   // release the tile sums before this workgroup is counted in
-  }
-  // ---- the last workgroup of the sweep to arrive runs the update
-  __syncthreads();
-  GN_TS(3);
-  if (tid == 0) {
-    const bool last = atomicAdd(&A.arrive[s], 1u) == ntiles - 1;
-    if (last) atomicExch(&A.arrive[s], 0u);   // ready for the next iteration (nobody else touches it before the next launch)
-    sh_last = last ? 1 : 0;
-  }
-  __syncthreads();
-  if (!sh_last) return;
-  __threadfence();   // acquire the other workgroups' tile sums
-  GN_TS(4);
-  solve_sweep(s, A.ds_off, A.poses, A.stats, A.matP, A.partials, A.nblk, ntiles, A.iter, A.delta_t_abort, A.delta_r_abort, A.host_stats, A.host_poses);
-  GN_TS(5);
-}
+#define GN_KERNEL k_gn_iter
+#define GN_JACOBI false
+#include "gn_iter_kernel.inc"
+#undef GN_KERNEL
+#undef GN_JACOBI
+#define GN_KERNEL k_gn_iter_jacobi
+#define GN_JACOBI true
+#include "gn_iter_kernel.inc"
+#undef GN_KERNEL
+#undef GN_JACOBI
 
 // debug / parity hook: the 5-NN search of k_gn_iter for arbitrary map-frame query points (loamx_batch_knn_probe)
 __global__ __launch_bounds__(256) void k_knn_probe(const float4* __restrict__ queries, uint32_t n, const GridDesc* __restrict__ desc,
@@ -999,11 +891,23 @@ __global__ __launch_bounds__(256) void k_knn_probe(const float4* __restrict__ qu
   }
 }
 
+// mode 0: every sweep.  mode 1 (enqueued together with the Gauss-Newton launches, before the host has seen their flags): only the
+// sweeps that have converged, marked in full_done with this launch's tag; mode 2 (after further iterations): the sweeps not marked yet.
+// skip_word / skip_value: a voxel stage that gave up leaves the clouds untouched for the repeated run.
 __global__ __launch_bounds__(256) void k_transform_full(float4* __restrict__ full, uint32_t n, const uint32_t* __restrict__ full_off,
-                                                        uint32_t ns, const Pose* __restrict__ poses) {
+                                                        uint32_t ns, const Pose* __restrict__ poses, const SweepStats* __restrict__ stats,
+                                                        uint32_t* __restrict__ full_done, int mode, uint32_t tag,
+                                                        const uint32_t* __restrict__ skip_word, uint32_t skip_value) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (skip_word && *skip_word == skip_value) return;
   const uint32_t s = vox_find_seg(full_off, ns, i);
+  if (mode == 1) {
+    if (!stats[s].done) return;
+    if (i == full_off[s]) full_done[s] = tag;
+  } else if (mode == 2) {
+    if (full_done[s] != 0u) return;   // (nothing writes full_done in this mode)
+  }
   const Pose T = poses[s];
   float4 p = full[i];
   to_map(T, p.x, p.y, p.z);
@@ -1038,6 +942,10 @@ Registrar::Registrar(int device, uint32_t max_sweeps) : device_(device), max_swe
   full_off_.reserve(max_sweeps + 2);
   ds_off_.reserve(2 * max_sweeps + 2);
   vox_.init(st_);
+  vb_.init(st_);
+  vb_disabled_ = getenv("LOAMX_VOX_LEGACY") != nullptr;
+  jacobi_eig_ = getenv("LOAMX_EIG_JACOBI") != nullptr;
+  full_done_.reserve(max_sweeps);
   h_stats_.reserve(max_sweeps);
   h_poses_.reserve(max_sweeps);
   ev_.resize(2 + 2 * 64);
@@ -1247,11 +1155,42 @@ static double host_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// transformFullResToMap (BasicLaserMapping.cpp:235-240); mode as in k_transform_full
+void Registrar::enqueue_full(int mode) {
+  if (!n_full_) return;
+  if (mode == 1 && ++full_tag_ == 0u) full_tag_ = 1u;
+  const uint32_t* skip = vb_unchecked_ ? vb_.d_fail_word() : nullptr;   // an unverified bucketed voxel stage may have given up
+  hipLaunchKernelGGL(k_transform_full, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, n_full_, d_full_off_, n_sweeps_, poses_.p,
+                     stats_.p, full_done_.p, mode, full_tag_, skip, vb_.epoch());
+}
+
+// k_pose_init + stack round trip + voxel grid of the stack clouds
+void Registrar::enqueue_front(bool legacy) {
+  const uint32_t ns = n_sweeps_, nseg = 2 * ns, n = n_in_;
+  hipLaunchKernelGGL(k_pose_init, dim3((ns + 63) / 64), dim3(64), 0, st_, d_guess_, ns, poses_.p, stats_.p, vox_.seg_minmax(), arrive_.p,
+                     full_done_.p);
+  if (n == 0) {
+    LX_HIP(hipMemsetAsync(ds_off_.p, 0, sizeof(uint32_t) * (nseg + 1), st_));
+    return;
+  }
+  if (legacy) {
+    const uint32_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_stack, dim3(nb), dim3(256), 0, st_, in_.p, d_src_, n, d_seg_off_, nseg, poses_.p, 1.0f / params.corner_leaf,
+                       1.0f / params.surf_leaf, stack_.p, vox_.ijk(), vox_.seg_minmax());
+    vox_.sort_reduce(stack_.p, nullptr, n, d_seg_off_, nseg, ds_pts_.p, ds_off_.p);
+  } else {
+    vb_.run(in_.p, d_src_, n, d_seg_off_, h_seg_off_.data(), nseg, poses_.p, 1.0f / params.corner_leaf, 1.0f / params.surf_leaf, stack_.p,
+            ds_pts_.p, ds_off_.p);
+  }
+}
+
 // The Gauss-Newton iterations: one k_gn_iter launch each.  Converged sweeps turn the remaining launches into no-ops on the
-// device (stats.done), which keeps run_async() free of host round trips.  A blocking caller (early_exit) instead enqueues as
-// many iterations as the previous call needed, looks at the flags (mirrored into pinned memory by the update step), and
-// stops launching once every sweep is done.
-void Registrar::run_iterations(bool trace, double& th2, double& th3) {
+// device (stats.done), which keeps run_async() free of host round trips.  A blocking caller (early_exit) enqueues one launch
+// more than the previous call needed (a launch over converged sweeps costs a few microseconds, a host round trip in the middle
+// of the chain ~90) together with the registration of the full-resolution clouds of the sweeps that converge within them, looks
+// at the flags (mirrored into pinned memory by the update step), and only goes on launching while some sweep is not done.
+// Returns true when the host, at its first look, finds that the bucketed voxel stage gave up: the caller runs again.
+bool Registrar::run_iterations(bool trace, double& th2, double& th3) {
   TraceRange trace_range("loamx:registration:gauss-newton");
   const uint32_t ns = n_sweeps_;
   struct ProfDump { std::function<void()> f; ~ProfDump() { if (f) f(); } } prof_dump;
@@ -1290,27 +1229,36 @@ void Registrar::run_iterations(bool trace, double& th2, double& th3) {
   };
 #endif   // per XCD: ceil(corner tiles / 8) + ceil(surf tiles / 8) workgroups at most
   int it = 0;
-  bool waited = false;
-  int chunk = early_exit ? std::min(std::max(pred_iters_, 2), params.max_iterations) : params.max_iterations;
-  while (it < params.max_iterations) {
-    const int end = std::min(params.max_iterations, it + chunk);
+  bool waited = false, spec_full = false, all_done = false;
+  const int maxit = params.max_iterations;
+  const bool want_full = n_full_ && !defer_full;
+  int chunk = early_exit ? std::min(std::max(pred_iters_ + 1, 2), maxit) : maxit;
+  while (it < maxit) {
+    const int end = std::min(maxit, it + chunk);
     for (; it < end; it++) {
       const bool tm = timing_ && launch_timing_ && n_res_launch_ < 64;
       if (tm) LX_HIP(hipEventRecord(ev_[2 + 2 * n_res_launch_], st_));
       a.iter = it;
-      hipLaunchKernelGGL(k_gn_iter, grid, dim3(LX_RES_THREADS), 0, st_, a);
+      if (jacobi_eig_) hipLaunchKernelGGL(k_gn_iter_jacobi, grid, dim3(LX_RES_THREADS), 0, st_, a);
+      else hipLaunchKernelGGL(k_gn_iter, grid, dim3(LX_RES_THREADS), 0, st_, a);
       if (tm) {
         LX_HIP(hipEventRecord(ev_[3 + 2 * n_res_launch_], st_));
         n_res_launch_++;
       }
     }
-    if (!early_exit || it >= params.max_iterations) break;
+    if (!early_exit) break;
+    if (!spec_full && want_full) { enqueue_full(1); spec_full = true; }
+    if (it >= maxit) break;
     if (trace && th2 == 0) th2 = host_us();
     if (on_first_wait && !waited) { waited = true; on_first_wait(); on_first_wait = nullptr; }   // host work that overlaps the wait
     if (trace && th3 == 0) th3 = host_us();
     LX_HIP(hipStreamSynchronize(st_));
-    bool all_done = true;
+    if (vb_unchecked_) {
+      vb_unchecked_ = false;
+      if (vb_.failed()) return true;
+    }
     int need = 0;
+    all_done = true;
     for (uint32_t k = 0; k < ns; k++) {
       all_done = all_done && h_stats_.p[k].done;
       need = std::max(need, h_stats_.p[k].iterations);
@@ -1319,6 +1267,12 @@ void Registrar::run_iterations(bool trace, double& th2, double& th3) {
     pred_iters_ = it + 1;
     chunk = 1;
   }
+  if (early_exit && want_full) {
+    if (!spec_full) enqueue_full(0);
+    else if (!all_done) enqueue_full(2);   // the sweeps that were not done when the first launch looked
+    full_enqueued_ = true;
+  }
+  return false;
 }
 
 void Registrar::run_async() {
@@ -1331,24 +1285,28 @@ void Registrar::run_async() {
   const uint32_t ns = n_sweeps_, nseg = 2 * ns, n = n_in_;
   if (timing_) LX_HIP(hipEventRecord(ev_[0], st_));
   n_res_launch_ = 0;
-  if (early_exit) memset(h_stats_.p, 0, sizeof(SweepStats) * ns);   // mirrors of sweeps that never reach an update stay "not done"
-  hipLaunchKernelGGL(k_pose_init, dim3((ns + 63) / 64), dim3(64), 0, st_, d_guess_, ns, poses_.p, stats_.p, vox_.seg_minmax(), arrive_.p);
-  if (n > 0) {
-    const uint32_t nb = (n + 255) / 256;
-    hipLaunchKernelGGL(k_stack, dim3(nb), dim3(256), 0, st_, in_.p, d_src_, n, d_seg_off_, nseg, poses_.p, 1.0f / params.corner_leaf,
-                       1.0f / params.surf_leaf, stack_.p, vox_.ijk(), vox_.seg_minmax());
-    vox_.sort_reduce(stack_.p, nullptr, n, d_seg_off_, nseg, ds_pts_.p, ds_off_.p);
-  } else {
-    LX_HIP(hipMemsetAsync(ds_off_.p, 0, sizeof(uint32_t) * (nseg + 1), st_));
+  const bool can_bucket = !vb_disabled_ && VoxBucket::fits(n, nseg);
+  for (int attempt = 0; attempt < 2; attempt++) {
+    const bool legacy = attempt == 1 || !can_bucket;
+    if (early_exit) memset(h_stats_.p, 0, sizeof(SweepStats) * ns);   // mirrors of sweeps that never reach an update stay "not done"
+    vb_unchecked_ = !legacy && n > 0;
+    full_enqueued_ = false;
+    enqueue_front(legacy);
+    if (trace) th1 = host_us();
+    mirrors_written_ = false;
+    bool again = false;
+    if (submap_sufficient() && n > 0) {   // BasicLaserMapping.cpp:628-629 guard
+      again = run_iterations(trace, th2, th3);
+      if (trace && th2 == 0) th2 = host_us();
+    }
+    if (!again && early_exit && vb_unchecked_) {   // a blocking caller goes on to use the voxel stage's output: look at its verdict now
+      LX_HIP(hipStreamSynchronize(st_));
+      vb_unchecked_ = false;
+      again = vb_.failed();
+    }
+    if (!again) break;
   }
-  if (trace) th1 = host_us();
-  mirrors_written_ = false;
-  if (submap_sufficient() && n > 0) {   // BasicLaserMapping.cpp:628-629 guard
-    run_iterations(trace, th2, th3);
-    if (trace && th2 == 0) th2 = host_us();
-  }
-  if (n_full_ && !defer_full)
-    hipLaunchKernelGGL(k_transform_full, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, n_full_, d_full_off_, ns, poses_.p);
+  if (n_full_ && !defer_full && !full_enqueued_) enqueue_full(0);
   if (timing_) { LX_HIP(hipEventRecord(ev_[1], st_)); timed_run_ = true; }
   LX_HIP(hipGetLastError());
   if (on_first_wait) on_first_wait();   // host work of the caller that overlaps the device work enqueued above
@@ -1356,6 +1314,19 @@ void Registrar::run_async() {
   if (trace)
     fprintf(stderr, "[reg] voxel stage enqueued %.0f us, first iterations enqueued %.0f, callback done %.0f, run_async returns %.0f\n", th1 - th0,
             th2 - th0, th3 - th0, host_us() - th0);
+}
+
+// after a stream synchronisation: a bucketed voxel stage that gave up left an empty query set (and the full-resolution clouds
+// untouched); run the sweeps again through the general kernel
+void Registrar::redo_if_bucket_path_failed() {
+  if (!vb_unchecked_) return;
+  vb_unchecked_ = false;
+  if (!vb_.failed()) return;
+  const bool keep = vb_disabled_;
+  vb_disabled_ = true;
+  try { run_async(); } catch (...) { vb_disabled_ = keep; throw; }
+  vb_disabled_ = keep;
+  LX_HIP(hipStreamSynchronize(st_));
 }
 
 // replace the device poses (6 floats per sweep) and register the full-resolution clouds with them — the tail of a
@@ -1367,8 +1338,7 @@ void Registrar::finish_with_poses(const float* poses6) {
   guess_.reserve((size_t)6 * ns + 8);
   LX_HIP(hipMemcpyAsync(guess_.p, h_guess_.p, sizeof(float) * 6 * ns, hipMemcpyHostToDevice, st_));
   hipLaunchKernelGGL(k_pose_set, dim3((ns + 63) / 64), dim3(64), 0, st_, guess_.p, ns, poses_.p);
-  if (n_full_)
-    hipLaunchKernelGGL(k_transform_full, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, n_full_, d_full_off_, ns, poses_.p);
+  enqueue_full(0);
   mirrors_written_ = false;   // the device poses were replaced
   LX_HIP(hipGetLastError());
 }
@@ -1401,6 +1371,8 @@ void Registrar::sync() { LX_HIP(hipStreamSynchronize(st_)); }
 void Registrar::fetch_results() {
   LX_HIP(hipStreamSynchronize(st_));
   vox_.check();
+  vb_.check();
+  redo_if_bucket_path_failed();
   if (!mirrors_written_) {
     LX_HIP(hipMemcpyAsync(h_poses_.p, poses_.p, sizeof(Pose) * n_sweeps_, hipMemcpyDeviceToHost, st_));
     LX_HIP(hipMemcpyAsync(h_stats_.p, stats_.p, sizeof(SweepStats) * n_sweeps_, hipMemcpyDeviceToHost, st_));
@@ -1434,6 +1406,7 @@ void Registrar::download(float* poses6, int* stats4) {
 int Registrar::download_full_res(uint32_t sweep, loamx_cloud* out) {
   LX_REQUIRE(sweep < n_sweeps_, "sweep index out of range");
   check_cloud(out, false);
+  fetch_results();
   const uint32_t a = h_full_off_[sweep], b = h_full_off_[sweep + 1];
   std::vector<float4> tmp(b - a);
   if (b > a) LX_HIP(hipMemcpyAsync(tmp.data(), full_.p + a, sizeof(float4) * (b - a), hipMemcpyDeviceToHost, st_));
@@ -1443,6 +1416,7 @@ int Registrar::download_full_res(uint32_t sweep, loamx_cloud* out) {
 
 void Registrar::download_ds(uint32_t sweep, std::vector<float4>& corner_ds, std::vector<float4>& surf_ds) {
   LX_REQUIRE(sweep < n_sweeps_, "sweep index out of range");
+  fetch_results();
   uint32_t off[3];
   LX_HIP(hipMemcpyAsync(off, ds_off_.p + 2 * sweep, sizeof(off), hipMemcpyDeviceToHost, st_));
   LX_HIP(hipStreamSynchronize(st_));

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libloamx.so")
+LIB_PATH = os.environ.get("LOAMX_LIB") or os.path.join(_HERE, "libloamx.so")   # LOAMX_LIB: a diagnostic build (time stamps inside kernels)
 
 OK, SKIPPED, E_INVALID, E_CAPACITY, E_HIP, E_NOGPU = 0, 1, -1, -2, -3, -4
 
@@ -179,6 +179,13 @@ class Batch:
         c = cloud_of(out)
         _check(lib().loamx_batch_download_full_res(self.h, sweep, C.byref(c)))
         return out[:c.count]
+
+    def download_ds(self, sweep: int, cap: int = 1 << 17):
+        """the down-sampled stack clouds (corner, surf) of one sweep of the last run — the Gauss-Newton query points"""
+        co, so = np.zeros((cap, 4), np.float32), np.zeros((cap, 4), np.float32)
+        cc, sc = cloud_of(co), cloud_of(so)
+        _check(lib().loamx_batch_download_ds(self.h, sweep, C.byref(cc), C.byref(sc)))
+        return co[:cc.count].copy(), so[:sc.count].copy()
 
     def knn_probe(self, which: int, queries_xyz):
         """the library's own 5-NN search for map-frame points: (indices into the cloud given to set_frozen, squared distances)"""

@@ -60,10 +60,13 @@ def test_parity_vlp16_100k(orc):
         assert np.abs(got[:, :3] - want).max() < 2e-4 and np.array_equal(got[:, 3], fulls[k][:, 3])
 
 
-@pytest.mark.parametrize("env", [{"LOAMX_VDS_WGS": "3"}, {"LOAMX_VDS_WGS": "3", "LOAMX_VDS_GLOBAL": "1"}, {"LOAMX_VDS_GLOBAL": "1"}])
+@pytest.mark.parametrize("env", [{"LOAMX_VOX_LEGACY": "1"}, {"LOAMX_VOX_LEGACY": "1", "LOAMX_VDS_WGS": "3"},
+                                 {"LOAMX_VOX_LEGACY": "1", "LOAMX_VDS_WGS": "3", "LOAMX_VDS_GLOBAL": "1"}, {"LOAMX_VOX_LEGACY": "1", "LOAMX_VDS_GLOBAL": "1"}])
 def test_voxel_grid_does_not_depend_on_grid_size(orc, env, monkeypatch):
-    """The persistent voxel-grid kernels claim their tiles from a counter: with 3 workgroups instead of one per tile (what a
-    crowded device would leave resident) and through the general kernel the poses and the per-sweep statistics (down-sampled sizes, selected rows) are bit-identical."""
+    """The stack clouds' voxel grid has three implementations: the bucketed path (default), the persistent segmented kernel and the
+    persistent general kernel (LOAMX_VOX_LEGACY / LOAMX_VDS_GLOBAL); the persistent ones claim their tiles from a counter, so they
+    may run with 3 workgroups instead of one per tile (what a crowded device would leave resident).  Poses and per-sweep
+    statistics (down-sampled sizes, selected rows) are bit-identical across all of them."""
     world = synth.World(half_extent=65.0)
     cm, sm = world.make_map(100000)
     cl, sl, guesses, _ = _inputs(orc, world, "VLP-16", 4, seed=5)

@@ -10,6 +10,7 @@ struct OdomParams {
   float scan_period = 0.1f;
   int max_iterations = 25;
   float delta_t_abort = 0.1f, delta_r_abort = 0.1f;
+  int window_scan = 0;   // LOAMX_ODOM_SCAN: always walk the +-2.5-ring windows point by point (the reference's loops) instead of searching them through the grid
 };
 
 struct OdomStats {
@@ -28,6 +29,10 @@ struct OdomProblem {
   const uint32_t* cell_table;      // concatenated cell tables
   const GridDescB* lc_desc;        // grid over last_corner
   const GridDescB* ls_desc;        // grid over last_surf
+  const uint32_t* lc_ring_first;   // last_corner / last_surf: first position with ring >= r (SubMapIndexBatch::ring_first)
+  const uint32_t* ls_ring_first;
+  const uint32_t* lc_flags;        // 0: the cloud is ring-ordered with ring ids in [0, 255] (SubMapIndexBatch::flags)
+  const uint32_t* ls_flags;
   int* ind;            // 5 ints per feature: corner (ind1, ind2, -, -, -) / surf (ind1, ind2, ind3, -, -)
   float transform[6];  // in: initial _transform, out: optimised
   OdomStats stats;
@@ -103,7 +108,7 @@ class OdometryBatch {
   bool own_stream_ = false;
   std::vector<OdomStream*> streams_;
   // clouds of all streams, concatenated: [corner_0 .. corner_{ns-1} | surf_0 .. surf_{ns-1}], offsets 2*ns+1
-  DevBuf<float4> cur_, last_;
+  DevBuf<float4> cur_, last_, prev_;   // being written | handed on by the last call | handed on by the call before (still read by its consumer)
   std::vector<uint32_t> h_cur_off_, h_last_off_;
   DevBuf<uint32_t> d_cur_off_;
   SubMapIndexBatch index_;
@@ -117,8 +122,8 @@ class OdometryBatch {
   PinBuf<float4> h_stage_;
   DevBuf<float4> up_[4], tmp_cloud_;
   uint32_t lm_slots_[2] = {0, 0};   // workgroups of k_odom_lm<1> / <2> the device holds at once (occupancy x CUs)
-  hipEvent_t ev_tail_ = nullptr, ev_pose_ = nullptr;
-  bool tail_pending_ = false;
+  hipEvent_t ev_tail_ = nullptr, ev_pose_ = nullptr, ev_up_ = nullptr;
+  bool tail_pending_ = false, up_pending_ = false;
   PinBuf<char> h_gather_;
   DevBuf<char> d_gather_;
 };

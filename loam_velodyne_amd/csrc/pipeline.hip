@@ -30,7 +30,7 @@ struct OdomPub {
 
 struct PipeStreamState {
   HTwist bef, aft, tobe, incre;   // mapping-side transforms (transformSum comes from the odometry stream)
-  OdomPub cur, next;              // odometry results of the step being registered / of the look-ahead step
+  OdomPub cur;                    // odometry results of the step being registered (the look-ahead's wait in Pipeline::ores)
   SweepStats map_stats = {0, 0, 0, 0, 0, 0, 0, 0};
   bool mapped = false;
 };
@@ -115,20 +115,30 @@ class Pipeline {
     }
     void destroy() { if (a) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); a = b = nullptr; } }
   };
-  LazyTimer tmO[2], tmM[2];   // by step parity
+  LazyTimer tmO[3], tmM[2];   // odometry: by step % 3 (the worker's), registration: by step parity
+  std::atomic<float> odom_ms{0.f};
   float feat_ms[3] = {0, 0, 0};
-  int odom_ready_step = -1;
+  int f_hi = -1;                       // features of steps <= f_hi have been launched (calling thread)
   float last_ms[4] = {0, 0, 0, 0};
   bool timing = false;
 
-  // the odometry look-ahead runs on a persistent host thread (it blocks on its Gauss-Newton results).  Hand-overs between
-  // the two threads happen every ~0.7 ms, so both sides spin briefly on an atomic before they fall back to the condition
-  // variable (a sleeping thread costs tens of microseconds to wake, on the critical path of every step)
+  // The odometry chain runs on a persistent host thread of its own and AHEAD of the registration: odometry O(k) only depends on
+  // O(k-1) and on the features F(k), never on a registration (separate ROS nodes in the reference), so the thread goes on to O(k+1)
+  // as soon as O(k) is done, up to two steps ahead of the step being registered — registration and odometry are both serial chains
+  // across steps and the slower of the two sets the pace, not their sum.  The calling thread launches the features (the only
+  // thread that does) and raises o_limit; the worker publishes o_done.  Results wait in a ring of three slots, the odometry's
+  // re-projected clouds in three rotating buffers (OdometryBatch), so step k's inputs stay valid while O(k+1), O(k+2) run.
+  // Hand-overs happen every ~0.4 ms, so both sides spin briefly before they fall back to the condition variable (a sleeping
+  // thread costs tens of microseconds to wake, on the critical path of every step).
+  std::vector<OdomPub> ores[3];        // [step % 3][stream]
+  hipEvent_t ev_otail[3] = {nullptr, nullptr, nullptr};   // recorded behind O(k)'s tail (re-projection + index build) on the odometry stream
   std::thread worker;
   std::mutex mu;
   std::condition_variable cv;
-  std::atomic<int> job{-1};
-  std::atomic<bool> job_done{true};
+  std::atomic<int> o_limit{-1};        // the worker may run steps <= o_limit (raised by the calling thread only)
+  std::atomic<int> o_done{-1};         // odometry of steps <= o_done is complete and published
+  std::atomic<bool> o_busy{false};
+  std::atomic<int> o_next{0};          // next step of the odometry chain (worker; the calling thread only while the worker is parked)
   bool quit = false;
   std::exception_ptr job_err;
   static bool spin_until(const std::function<bool()>& ready, double max_us) {
@@ -142,48 +152,64 @@ class Pipeline {
   void worker_main() {
     (void)hipSetDevice(device);
     for (;;) {
-      int t;
-      if (!spin_until([&] { return job.load(std::memory_order_acquire) >= 0; }, 400.0)) {
+      auto ready = [&] { return o_next.load(std::memory_order_acquire) <= o_limit.load(std::memory_order_acquire); };
+      if (!spin_until(ready, 400.0)) {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return job.load(std::memory_order_acquire) >= 0 || quit; });
+        cv.wait(lk, [&] { return ready() || quit; });
         if (quit) return;
       }
-      t = job.exchange(-1, std::memory_order_acq_rel);
-      if (t < 0) continue;
+      {
+        std::lock_guard<std::mutex> lk(mu);   // (o_busy and o_limit change under the mutex: park_odometry() relies on seeing them together)
+        if (!ready()) continue;
+        o_busy.store(true, std::memory_order_release);
+      }
       std::exception_ptr err;
-      try { trO[0] = tr_us(); run_odometry((uint32_t)t); trO[3] = tr_us(); } catch (...) { err = std::current_exception(); }
+      const int k = o_next.load(std::memory_order_acquire);
+      try { trO[0] = tr_us(); run_odometry((uint32_t)k); trO[3] = tr_us(); } catch (...) { err = std::current_exception(); }
       {
         std::lock_guard<std::mutex> lk(mu);
-        job_err = err;
-        job_done.store(true, std::memory_order_release);
+        if (err) { job_err = err; o_limit.store(-1, std::memory_order_release); }   // stop; the calling thread rethrows
+        else { o_next.store(k + 1, std::memory_order_release); o_done.store(k, std::memory_order_release); }
+        o_busy.store(false, std::memory_order_release);
       }
       cv.notify_all();
     }
   }
-  void kick(uint32_t t) {
+  // calling thread: allow the odometry chain to run up to step k
+  void allow_odometry(int k) {
+    if (k <= o_limit.load(std::memory_order_acquire)) return;
     if (!worker.joinable()) worker = std::thread([this] { worker_main(); });
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      job_done.store(false, std::memory_order_release);
-      job.store((int)t, std::memory_order_release);
-    }
+    { std::lock_guard<std::mutex> lk(mu); o_limit.store(k, std::memory_order_release); }
     cv.notify_all();
   }
-  void join_job() {
-    if (!spin_until([&] { return job_done.load(std::memory_order_acquire); }, 2000.0)) {
+  // calling thread: block until O(t) is published (rethrows a failure of the worker)
+  void wait_odometry(int t) {
+    auto ready = [&] { return o_done.load(std::memory_order_acquire) >= t || (!o_busy.load(std::memory_order_acquire) && o_limit.load(std::memory_order_acquire) < t); };
+    if (!spin_until(ready, 2000.0)) {
       std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk, [&] { return job_done.load(std::memory_order_acquire); });
+      cv.wait(lk, ready);
     }
     std::lock_guard<std::mutex> lk(mu);
     if (job_err) { std::exception_ptr e = job_err; job_err = nullptr; std::rethrow_exception(e); }
+    LX_REQUIRE(o_done.load() >= t, "internal: the odometry chain stopped before the requested step");
+  }
+  // calling thread: stop the look-ahead and wait until the worker is idle; the chain continues at step `next`
+  void park_odometry(int next) {
+    std::unique_lock<std::mutex> lk(mu);
+    o_limit.store(-1, std::memory_order_release);
+    cv.wait(lk, [&] { return !o_busy.load(std::memory_order_acquire); });
+    o_next.store(next, std::memory_order_release);
+    o_done.store(next - 1, std::memory_order_release);
+    job_err = nullptr;
   }
 
   ~Pipeline() {
     if (worker.joinable()) {
-      { std::lock_guard<std::mutex> lk(mu); quit = true; }
+      { std::lock_guard<std::mutex> lk(mu); quit = true; o_limit.store(-1, std::memory_order_release); }
       cv.notify_all();   // (the worker leaves its spin phase after 0.4 ms and then sees quit)
       worker.join();
     }
+    for (auto& e : ev_otail) if (e) (void)hipEventDestroy(e);
     fx.clear();
     for (auto& a : evF) for (auto& e : a) if (e) (void)hipEventDestroy(e);
     for (auto& tm : tmO) tm.destroy();
@@ -225,7 +251,8 @@ class Pipeline {
     streaming = false;
     staged_hi = 0;
     launched.assign(n_steps, 0);
-    odom_ready_step = -1;
+    park_odometry(0);
+    f_hi = -1;
     for (uint32_t t = 0; t < n_steps; t++) {
       auto f = std::make_unique<FeatureExtractor>(device, fstream);
       FeatParams& p = f->params;
@@ -266,7 +293,8 @@ class Pipeline {
       for (auto& e : ev_stage) if (!e) LX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       streaming = true;
       staged_hi = 0;
-      odom_ready_step = -1;
+      park_odometry(0);
+      f_hi = -1;
     }
   }
 
@@ -422,11 +450,11 @@ class Pipeline {
   }
   uint64_t run_count = 0;   // registrations run so far (parity = which full-resolution buffer)
 
-  // odometry of staged step t for every stream (needs its features); results go to st[s].next
+  // odometry of staged step t for every stream (needs its features, launched by the calling thread); results go to ores[t % 3]
   void run_odometry(uint32_t t) {
     const uint32_t ns = n_streams_;
     FeatureExtractor& F = FX(t);
-    if (!LA(t)) launch_features(t);
+    LX_REQUIRE(LA(t), "internal: odometry of a step whose features were not launched");
     uint32_t* hb = h_off3[t % 3].p;
     uint32_t* ho[3] = {hb, hb + (ns + 1), hb + 2 * (ns + 1)};
     uint32_t* hlf = hb + 3 * (ns + 1);
@@ -441,7 +469,7 @@ class Pipeline {
       in[s] = OdomInput{F.d_feat(0) + ho[0][s], ho[0][s + 1] - ho[0][s], F.d_feat(1) + ho[1][s], ho[1][s + 1] - ho[1][s],
                         F.d_feat(2) + ho[2][s], ho[2][s + 1] - ho[2][s], F.d_less_flat() + la, lb - la};
     }
-    LazyTimer& tm = tmO[t & 1];
+    LazyTimer& tm = tmO[t % 3];
     if (timing) {
       tm.create();
       tm.pending = false;
@@ -455,9 +483,16 @@ class Pipeline {
       LX_HIP(hipEventRecord(tm.b, odom.stream()));
       tm.pending = true;
     }
+    if (!ev_otail[t % 3]) LX_HIP(hipEventCreateWithFlags(&ev_otail[t % 3], hipEventDisableTiming));
+    LX_HIP(hipEventRecord(ev_otail[t % 3], odom.stream()));   // behind the tail that process() enqueued
+    if (timing) {   // (this thread's own timers: the elapsed time of an older step is taken once its events have completed)
+      for (auto& x : tmO) x.resolve();
+      odom_ms.store(tmO[(t + 2) % 3].pending ? tmO[(t + 1) % 3].ms : tmO[(t + 2) % 3].ms, std::memory_order_relaxed);
+    }
+    ores[t % 3].resize(ns);
     for (uint32_t s = 0; s < ns; s++) {
       OdomStream& O = odom.stream_state(s);
-      OdomPub& N = st[s].next;
+      OdomPub& N = ores[t % 3][s];
       N.transform = O.transform;
       N.transform_sum = O.transform_sum;
       N.stats = O.stats;
@@ -466,7 +501,6 @@ class Pipeline {
       N.last_surf = odom.d_last_surf(s); N.n_last_surf = O.n_last_surf;
       N.to_end = odom.to_end_params(s, true);
     }
-    odom_ready_step = (int)t;
   }
 
   // Software pipeline over consecutive steps (the stages are separate ROS nodes in the reference, so nothing in a later
@@ -488,28 +522,43 @@ class Pipeline {
     LX_HIP(hipSetDevice(device));
     hipStream_t s_ = reg.stream();
     const uint32_t ns = n_streams_;
-    // ---- this step's odometry: from the look-ahead of the previous call, or now
-    if (odom_ready_step != (int)t) {
-      if (prefetch && t + 1 < n_staged() && !LA(t + 1)) { if (!LA(t)) launch_features(t); launch_features(t + 1); }
-      run_odometry(t);
+    // ---- this step's odometry: published by the look-ahead (the normal case), or run now
+    const int ti = (int)t, last_staged = (int)n_staged() - 1;
+    if (ti > o_done.load(std::memory_order_acquire) && ti != o_next.load(std::memory_order_acquire)) {   // not the next step of the chain: it restarts here
+      park_odometry(ti);
+      f_hi = ti - 1;
     }
-    for (uint32_t s = 0; s < ns; s++) st[s].cur = st[s].next;
-    odom_ready_step = -1;
+    LX_REQUIRE(ti + 2 >= o_done.load(std::memory_order_acquire), "this step's odometry results have been overwritten: steps run in order");
+    auto launch_upto = [&](int k) {   // features of the steps up to k (launched by this thread only, in step order)
+      if (k > last_staged) k = last_staged;
+      while (f_hi < k) { ++f_hi; if (!LA((uint32_t)f_hi)) launch_features((uint32_t)f_hi); }
+    };
+    if (ti > o_done.load(std::memory_order_acquire)) {
+      launch_upto(prefetch ? ti + 1 : ti);
+      if (prefetch) {
+        allow_odometry(std::min(ti + 1, last_staged));
+        wait_odometry(ti);
+      } else {
+        if (o_limit.load(std::memory_order_acquire) >= 0) park_odometry(ti);   // the look-ahead was switched off: the chain goes on here
+        run_odometry(t);
+        o_next.store(ti + 1, std::memory_order_release);
+        o_done.store(ti, std::memory_order_release);
+      }
+    }
+    for (uint32_t s = 0; s < ns; s++) st[s].cur = ores[t % 3][s];
     FeatureExtractor& F = FX(t);
     const float f_ms = feat_ms[t % 3];
-    // ---- look-ahead while M(t) runs: the odometry of step t+1 on the worker thread, started first (it is the longest
-    // chain), and the features of step t+2, enqueued while this thread waits for M(t)'s first look at the flags.
-    // (the re-projected "last" clouds of THIS sweep are produced at the tail of the odometry stream: order the
-    // registrar's stream behind it before the odometry thread re-arms the event)
-    if (hipEvent_t te = odom.tail_event()) LX_HIP(hipStreamWaitEvent(s_, te, 0));
-    const bool ahead = prefetch && t + 1 < n_staged();
-    if (ahead) {
-      if (!LA(t + 1)) launch_features(t + 1);
-      kick(t + 1);
+    // the re-projected "last" clouds of THIS sweep are produced at the tail of the odometry stream
+    LX_HIP(hipStreamWaitEvent(s_, ev_otail[t % 3], 0));
+    // ---- look-ahead while M(t) runs: the odometry chain may go on to step t+1 now and — once M(t) is enqueued and the features
+    // of step t+2 are launched (while this thread waits for M(t)'s first look at the flags) — to step t+2
+    if (prefetch) {
+      launch_upto(ti + 1);
+      allow_odometry(std::min(ti + 1, last_staged));
     }
-    bool f2_pending = ahead && t + 2 < n_staged() && !LA(t + 2);
+    bool f2_pending = prefetch && ti + 2 <= last_staged;
     auto launch_f2 = [&]() {
-      if (f2_pending) { f2_pending = false; launch_features(t + 2); }
+      if (f2_pending) { f2_pending = false; launch_upto(ti + 2); allow_odometry(ti + 2); }
     };
     int ret = LOAMX_SKIPPED;
     try {
@@ -591,21 +640,17 @@ class Pipeline {
       }
       trM[2] = tr_us();
     } catch (...) {
-      if (ahead) { try { join_job(); } catch (...) {} }
       throw;
     }
-    // ---- join the look-ahead
-    if (ahead) join_job();   // rethrows a failure of the odometry thread
     trM[3] = tr_us();
     last_step = t;
     if (trace)
       fprintf(stderr, "[pipe t=%u] M-start %.0f  M-enqueued %.0f  M-downloaded %.0f  O-joined %.0f | O thread: start %.0f feat-ready %.0f process-done %.0f end %.0f\n", t,
               trM[0], trM[1], trM[2], trM[3], trO[0], trO[1], trO[2], trO[3]);
     if (timing) {
-      for (auto& x : tmO) x.resolve();
       for (auto& x : tmM) x.resolve();
       last_ms[0] = f_ms;               // on the feature stream (overlapped)
-      last_ms[1] = tmO[t & 1].ms;      // on the odometry stream (overlapped with the previous step's registration)
+      last_ms[1] = odom_ms.load(std::memory_order_relaxed);   // on the odometry stream (overlapped with the registrations)
       last_ms[2] = tmM[t & 1].pending ? tmM[(t + 1) & 1].ms : tmM[t & 1].ms;   // the previous step's while this one is in flight
       last_ms[3] = last_ms[2];
     }
@@ -680,9 +725,9 @@ int loamx_pipeline_set_state(loamx_pipeline* h, uint32_t stream, const float* tr
                              const float* aft) {
   return guard([&]() {
     LX_REQUIRE(h && stream < h->p.n_streams_, "invalid stream");
+    h->p.park_odometry(h->p.o_done.load() + 1);   // the odometry chain stops; the sweeps it has not processed yet start from the new state
     if (transform) h->p.odom.stream_state(stream).transform.set(transform);
     if (transform_sum) h->p.odom.stream_state(stream).transform_sum.set(transform_sum);
-    h->p.odom_ready_step = -1;   // any look-ahead was computed from the old state
     if (bef) h->p.st[stream].bef.set(bef);
     if (aft) h->p.st[stream].aft.set(aft);
     return LOAMX_OK;
@@ -743,6 +788,7 @@ int loamx_pipeline_download_full_res(loamx_pipeline* h, uint32_t slot, loamx_clo
 int loamx_pipeline_set_lookahead(loamx_pipeline* h, int on) {
   return guard([&]() {
     LX_REQUIRE(h, "NULL handle");
+    if (!on && h->p.prefetch) h->p.park_odometry(h->p.o_next.load());   // (the worker finishes the step it is in)
     h->p.prefetch = on != 0;
     return LOAMX_OK;
   });

@@ -164,9 +164,10 @@ void SubMapIndex::build(const float4* d_pts, uint32_t n) {
 // SubMapIndexBatch: the same counting-sort build for K clouds with one set of launches
 // scratch: [0] total cells + 1, [1] scan total, [2] total cells
 // ----------------------------------------------------------------------------------------------------------------
-__global__ void k_bb_init(uint32_t* enc, uint32_t K) {
+__global__ void k_bb_init(uint32_t* enc, uint32_t K, uint32_t* flags) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 6 * K) enc[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+  if (i < K) flags[i] = 0u;
 }
 // grid = (blocks, K)
 __global__ __launch_bounds__(256) void k_bb_bbox(const float4* __restrict__ pts, const uint32_t* __restrict__ off, uint32_t* __restrict__ enc) {
@@ -251,7 +252,7 @@ __device__ inline void wave_runs(uint32_t key, bool active, int& head_lane, int&
 
 __global__ __launch_bounds__(256) void k_bb_count(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off, uint32_t K,
                                                   const GridDescB* __restrict__ desc, uint32_t* __restrict__ cell_of,
-                                                  uint32_t* __restrict__ counts) {
+                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ ring_first, uint32_t* __restrict__ flags) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
   uint32_t c = 0;
@@ -263,6 +264,26 @@ __global__ __launch_bounds__(256) void k_bb_count(const float4* __restrict__ pts
     }
     const GridDescB d = desc[lo];
     const float4 p = pts[i];
+    {
+      // scan rings of the cloud (integer part of the intensity, BasicLaserOdometry.cpp:258): ring_first[r] = first position whose
+      // ring is >= r — what the +-2.5-ring windows of the correspondence search need when the cloud is ring-ordered (it is, as the
+      // scan registration emits it).  flags: 1 = some ring id decreases along the cloud, 2 = a ring id outside [0, 255].
+      const uint32_t a0 = off[lo], a1 = off[lo + 1];
+      const bool okr = p.w >= 0.f && p.w < 256.f;
+      const int ring = okr ? (int)p.w : 0;
+      int prev = -1;
+      if (i > a0) {
+        const float pw = pts[i - 1].w;
+        prev = (pw >= 0.f && pw < 256.f) ? (int)pw : 0;
+      }
+      uint32_t fl = okr ? 0u : 2u;
+      if (prev > ring) fl |= 1u;
+      if (fl) atomicOr(&flags[lo], fl);
+      uint32_t* tab = ring_first + (size_t)lo * LX_RINGTAB;
+      for (int q = prev + 1; q <= ring; q++) tab[q] = i - a0;
+      if (i == a1 - 1)
+        for (int q = ring + 1; q < LX_RINGTAB; q++) tab[q] = a1 - a0;
+    }
     int cx, cy, cz;
     cell_coords(d.g, p.x, p.y, p.z, cx, cy, cz);
     c = d.cell_base + ((uint32_t)cz * d.g.ny + cy) * d.g.nx + cx;
@@ -295,7 +316,9 @@ __global__ __launch_bounds__(256) void k_bb_scatter(const float4* __restrict__ p
   if (active && head == (int)__lane_id()) base = atomicAdd(&cursor[c], (uint32_t)len);
   base = __shfl(base, head, 64);
   if (!active) return;
-  p.w = __uint_as_float(i - off[lo]);   // index inside its own cloud
+  // position inside its own cloud (24 bits) | scan ring (8 bits; garbage-in when flags say the ring ids are unusable)
+  const uint32_t ring = (p.w >= 0.f && p.w < 256.f) ? (uint32_t)(int)p.w : 0u;
+  p.w = __uint_as_float((i - off[lo]) | (ring << 24));
   sorted[base + ((int)__lane_id() - head)] = p;
 }
 
@@ -310,7 +333,9 @@ void SubMapIndexBatch::init(hipStream_t st) {
 void SubMapIndexBatch::prepare(uint32_t K) {
   LX_REQUIRE(K >= 1 && K <= 4096, "too many clouds in one index batch");
   enc_.reserve((size_t)6 * K + 6);
-  hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K);
+  flags_.reserve(K + 1);
+  ring_first_.reserve((size_t)K * LX_RINGTAB);
+  hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K, flags_.p);
 }
 
 void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_t K, const uint32_t* d_off_ready, bool prepared) {
@@ -319,6 +344,8 @@ void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_
   d_off_.reserve(K + 2);
   d_desc_.reserve(K + 1);
   enc_.reserve((size_t)6 * K + 6);
+  flags_.reserve(K + 1);
+  ring_first_.reserve((size_t)K * LX_RINGTAB);
   const uint32_t* d_off = d_off_ready;   // the caller may already hold the offsets on the device
   if (!d_off) {
     h_off_pin_.reserve(K + 2);
@@ -330,14 +357,15 @@ void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_
   cell_of_.reserve((size_t)n + 1);
   cell_start_.reserve((size_t)LX_MAX_CELLS + 2);
   cursor_.reserve((size_t)LX_MAX_CELLS + 2);
-  if (!prepared) hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K);
+  if (!prepared) hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K, flags_.p);
   uint32_t max_len = 0;
   for (uint32_t c = 0; c < K; c++) max_len = std::max(max_len, h_off[c + 1] - h_off[c]);
+  LX_REQUIRE(max_len < (1u << 24), "a cloud of an index batch is limited to 16 Mi points");
   const uint32_t nbx = std::min<uint32_t>(std::max<uint32_t>((max_len + 255) / 256, 1u), 32u);
   hipLaunchKernelGGL(k_bb_bbox, dim3(nbx, K), dim3(256), 0, st_, d_pts, d_off, enc_.p);
   hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1), 0, st_, enc_.p, d_off, K, d_desc_.p, scratch_.p, LX_MAX_CELLS, cell_size);
   hipLaunchKernelGGL(k_zero_u32_dn, dim3(2048), dim3(256), 0, st_, cursor_.p, scratch_.p + 0);
-  if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, d_desc_.p, cell_of_.p, cursor_.p);
+  if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, d_desc_.p, cell_of_.p, cursor_.p, ring_first_.p, flags_.p);
   exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 2, scratch_.p + 1, LX_MAX_CELLS, st_, cursor_.p);
   if (n) hipLaunchKernelGGL(k_bb_scatter, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, cell_of_.p, cursor_.p, sorted_.p);
   LX_HIP(hipGetLastError());
@@ -1255,7 +1283,7 @@ bool Registrar::run_iterations(bool trace, double& th2, double& th3) {
     LX_HIP(hipStreamSynchronize(st_));
     if (vb_unchecked_) {
       vb_unchecked_ = false;
-      if (vb_.failed()) return true;
+      if (vb_.failed()) { note_bucket_give_up(); return true; }
     }
     int need = 0;
     all_done = true;
@@ -1303,6 +1331,7 @@ void Registrar::run_async() {
       LX_HIP(hipStreamSynchronize(st_));
       vb_unchecked_ = false;
       again = vb_.failed();
+      if (again) note_bucket_give_up();
     }
     if (!again) break;
   }
@@ -1316,12 +1345,19 @@ void Registrar::run_async() {
             th2 - th0, th3 - th0, host_us() - th0);
 }
 
+void Registrar::note_bucket_give_up() {
+  vb_give_ups_++;
+  static const bool trace = getenv("LOAMX_VB_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "[voxbucket] gave up (reason mask 0x%x, %u points, %u sweeps): repeating through the general kernel\n", vb_.why(), n_in_, n_sweeps_);
+}
+
 // after a stream synchronisation: a bucketed voxel stage that gave up left an empty query set (and the full-resolution clouds
 // untouched); run the sweeps again through the general kernel
 void Registrar::redo_if_bucket_path_failed() {
   if (!vb_unchecked_) return;
   vb_unchecked_ = false;
   if (!vb_.failed()) return;
+  note_bucket_give_up();
   const bool keep = vb_disabled_;
   vb_disabled_ = true;
   try { run_async(); } catch (...) { vb_disabled_ = keep; throw; }

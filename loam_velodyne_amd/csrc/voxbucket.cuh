@@ -59,6 +59,7 @@ class VoxBucket {
   // device word / value a later kernel of the same stream can test to skip work that would use the empty result
   const uint32_t* d_fail_word() const { return ctl_.p; }
   uint32_t epoch() const { return epoch_; }
+  uint32_t why() const;   // after failed(): bit mask of the give-up reasons (voxbucket.hip, vb_fail)
   void check();   // throws when a look-back wait timed out
   uint32_t last_buckets() const { return nb_; }
 
@@ -69,7 +70,7 @@ class VoxBucket {
   DevBuf<uint16_t> bin2bucket_;            // [nseg][VB_BINS]
   DevBuf<uint32_t> cnt_, heads_, ctl_;     // per bucket: points, run heads + 1 once published; ctl: [0] fail epoch, [1] claim counter
   DevBuf<unsigned long long> elems_;       // [buckets][VB_CAP]
-  PinBuf<uint32_t> h_fail_;                // [0] fail epoch (host-visible copy), [1] timeout
+  PinBuf<uint32_t> h_fail_;                // [0] fail epoch (host-visible copy), [1] timeout, [2..7] epoch of the last run that met reason r
   uint32_t epoch_ = 0, claim_base_ = 0, nb_ = 0;
   bool ctl_ready_ = false;
 };

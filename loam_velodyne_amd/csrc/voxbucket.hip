@@ -26,9 +26,13 @@ struct VbArgs {
 };
 
 __device__ inline uint32_t vb_bits(unsigned long long v) { return v ? 64u - (uint32_t)__builtin_clzll(v) : 0u; }
-__device__ inline void vb_fail(const VbArgs& A) {
+// reasons (h_fail[2 + reason] = epoch, for the diagnostics of VoxBucket::why()): 0 a coordinate without a voxel, 1 more buckets
+// than a segment may have, 2 padded box beyond INT_MAX voxels, 3 a histogram bin larger than a bucket takes, 4 a point outside
+// the predicted box, 5 a bucket over capacity
+__device__ inline void vb_fail(const VbArgs& A, int reason) {
   A.ctl[0] = A.epoch;      // (every writer stores the same value)
   A.h_fail[0] = A.epoch;
+  A.h_fail[2 + reason] = A.epoch;
 }
 // voxel coordinate of one axis exactly as pcl::VoxelGrid forms it: floor(v * inverse leaf), float arithmetic
 __device__ inline bool vb_voxel(float v, float inv, int& i) {
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(1024) void k_vb_plan(const VbArgs A) {
   }
   const uint32_t nbuckets = ns ? (ns + VB_T - 1) / VB_T : 1u;
   if (tid < 6) s_mm[tid] = tid < 3 ? 2147483647 : (-2147483647 - 1);
-  if (tid == 0) s_bad = nbuckets > (uint32_t)VB_MAXBUCK ? 1u : 0u;
+  if (tid == 0) s_bad = nbuckets > (uint32_t)VB_MAXBUCK ? 2u : 0u;   // bit 0: no voxel for a coordinate, bit 1: too many buckets, bit 2: a bin too large
   for (uint32_t e = (uint32_t)tid; e < (uint32_t)VB_BINS; e += 1024) s_hist[e] = 0u;
   for (uint32_t e = (uint32_t)tid; e < (uint32_t)VB_MAXBUCK; e += 1024) { s_first[e] = 0xffffffffu; s_last[e] = 0u; }
   __syncthreads();
@@ -74,12 +78,20 @@ __global__ __launch_bounds__(1024) void k_vb_plan(const VbArgs A) {
   {
     int mn[3] = {2147483647, 2147483647, 2147483647}, mx[3] = {-2147483647 - 1, -2147483647 - 1, -2147483647 - 1};
     bool bad = false;
-    for (uint32_t i = (uint32_t)tid; i < ns; i += 1024) {
-      const float4 p = pts[i];
-      int v[3];
-      if (!(vb_voxel(p.x, inv, v[0]) && vb_voxel(p.y, inv, v[1]) && vb_voxel(p.z, inv, v[2]))) { bad = true; continue; }
+    for (uint32_t i0 = (uint32_t)tid; i0 < ns; i0 += 8 * 1024) {   // eight loads in flight per thread: one workgroup walks a whole segment
+      float4 p[8];
 #pragma unroll
-      for (int a = 0; a < 3; a++) { mn[a] = v[a] < mn[a] ? v[a] : mn[a]; mx[a] = v[a] > mx[a] ? v[a] : mx[a]; }
+      for (int u = 0; u < 8; u++) {
+        const uint32_t i = i0 + (uint32_t)u * 1024u;
+        p[u] = pts[i < ns ? i : i0];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int v[3];
+        if (!(vb_voxel(p[u].x, inv, v[0]) && vb_voxel(p[u].y, inv, v[1]) && vb_voxel(p[u].z, inv, v[2]))) { bad = true; continue; }
+#pragma unroll
+        for (int a = 0; a < 3; a++) { mn[a] = v[a] < mn[a] ? v[a] : mn[a]; mx[a] = v[a] > mx[a] ? v[a] : mx[a]; }
+      }
     }
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(1024) void k_vb_plan(const VbArgs A) {
 #pragma unroll
       for (int a = 0; a < 3; a++) { atomicMin(&s_mm[a], mn[a]); atomicMax(&s_mm[3 + a], mx[a]); }
     }
-    if (bad) s_bad = 1u;
+    if (bad) atomicOr(&s_bad, 1u);
   }
   __syncthreads();
   VbSeg P;
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(1024) void k_vb_plan(const VbArgs A) {
   P.pos_bits = vb_bits(ns ? (unsigned long long)(ns - 1) : 0ull);
   if (P.pos_bits == 0) P.pos_bits = 1;
   unsigned long long nkeys = 1ull;
-  bool seg_bad = s_bad != 0u;   // block-uniform (every thread derives the same plan from the shared bounds)
+  bool seg_bad = s_bad != 0u, box_bad = false;   // block-uniform (every thread derives the same plan from the shared bounds)
   if (ns != 0 && !seg_bad) {
     unsigned long long d[3];
 #pragma unroll
@@ -113,7 +125,7 @@ __global__ __launch_bounds__(1024) void k_vb_plan(const VbArgs A) {
       P.dim[a] = (uint32_t)d[a];
     }
     // a padded box beyond INT_MAX voxels goes to the general kernel, which applies PCL's own (unpadded) pass-through test
-    if (d[0] * d[1] > 2147483647ull || d[0] * d[1] * d[2] > 2147483647ull) seg_bad = true;
+    if (d[0] * d[1] > 2147483647ull || d[0] * d[1] * d[2] > 2147483647ull) seg_bad = box_bad = true;
     else nkeys = d[0] * d[1] * d[2];
   }
   if (ns == 0 || seg_bad) {   // nothing can fall into an empty box: a point of a given-up segment raises the fail word again, harmlessly
@@ -127,12 +139,21 @@ __global__ __launch_bounds__(1024) void k_vb_plan(const VbArgs A) {
   __syncthreads();
   // ---- histogram of the predicted linear voxel indices
   if (!seg_bad) {
-    for (uint32_t i = (uint32_t)tid; i < ns; i += 1024) {
-      const float4 p = pts[i];
-      int v[3];
-      (void)vb_voxel(p.x, inv, v[0]); (void)vb_voxel(p.y, inv, v[1]); (void)vb_voxel(p.z, inv, v[2]);
-      const uint32_t key = (uint32_t)(v[0] - P.mn[0]) + ((uint32_t)(v[1] - P.mn[1]) + (uint32_t)(v[2] - P.mn[2]) * P.dim[1]) * P.dim[0];
-      atomicAdd(&s_hist[key >> P.shift], 1u);
+    for (uint32_t i0 = (uint32_t)tid; i0 < ns; i0 += 8 * 1024) {
+      float4 p[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t i = i0 + (uint32_t)u * 1024u;
+        p[u] = pts[i < ns ? i : i0];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (i0 + (uint32_t)u * 1024u >= ns) continue;
+        int v[3];
+        (void)vb_voxel(p[u].x, inv, v[0]); (void)vb_voxel(p[u].y, inv, v[1]); (void)vb_voxel(p[u].z, inv, v[2]);
+        const uint32_t key = (uint32_t)(v[0] - P.mn[0]) + ((uint32_t)(v[1] - P.mn[1]) + (uint32_t)(v[2] - P.mn[2]) * P.dim[1]) * P.dim[0];
+        atomicAdd(&s_hist[key >> P.shift], 1u);
+      }
     }
   }
   __syncthreads();
@@ -148,7 +169,7 @@ __global__ __launch_bounds__(1024) void k_vb_plan(const VbArgs A) {
       sum += h[k];
       big = big || h[k] > (uint32_t)VB_MAXBIN;
     }
-    if (big) s_bad = 1u;
+    if (big) atomicOr(&s_bad, 4u);
     uint32_t tot;
     uint32_t ex = block_excl_scan(sum, s_scan, tot);
     uint16_t* tab = A.bin2bucket + (size_t)seg * VB_BINS + BPT * tid;
@@ -173,7 +194,7 @@ __global__ __launch_bounds__(1024) void k_vb_plan(const VbArgs A) {
   }
   __syncthreads();
   const bool bad = seg_bad || s_bad != 0u;   // (s_bad: also a bin too large for a bucket)
-  if (bad && tid == 0) vb_fail(A);
+  if (bad && tid == 0) vb_fail(A, box_bad ? 2 : ((s_bad & 1u) ? 0 : ((s_bad & 2u) ? 1 : 3)));
   for (uint32_t k = (uint32_t)tid; k < nbuckets; k += 1024) {
     VbBucket B;
     B.seg = seg;
@@ -223,8 +244,8 @@ __global__ __launch_bounds__(256) void k_vb_stack(const VbArgs A) {
         r[a] = (uint32_t)d;
       }
     }
-    if (!ok) {   // outside the predicted box (or the plan gave the segment up: its box is 1 x 1 x 1 around nothing)
-      vb_fail(A);
+    if (!ok) {   // outside the predicted box (or the plan gave the segment up: its box is empty)
+      vb_fail(A, 4);
       act = false;
     } else {
       const uint32_t key = r[0] + (r[1] + r[2] * P.dim[1]) * P.dim[0];
@@ -247,7 +268,7 @@ __global__ __launch_bounds__(256) void k_vb_stack(const VbArgs A) {
   }
   if (act) {
     if (slot < (uint32_t)VB_CAP) A.elems[(size_t)g * VB_CAP + slot] = elem;
-    else vb_fail(A);
+    else vb_fail(A, 5);
   }
 }
 
@@ -452,8 +473,8 @@ void VoxBucket::run(const float4* in, const float4* const* d_src, uint32_t n, co
   elems_.reserve((size_t)nb * VB_CAP);
   if (!ctl_ready_) {
     ctl_.reserve(4);
-    h_fail_.reserve(4);
-    h_fail_.p[0] = h_fail_.p[1] = 0u;
+    h_fail_.reserve(8);
+    for (int k = 0; k < 8; k++) h_fail_.p[k] = 0u;
     LX_HIP(hipMemsetAsync(ctl_.p, 0, sizeof(uint32_t) * 4, st_));
     ctl_ready_ = true;
   }
@@ -469,6 +490,14 @@ void VoxBucket::run(const float4* in, const float4* const* d_src, uint32_t n, co
   hipLaunchKernelGGL(k_vb_reduce, dim3(nb), dim3(VB_THREADS), 0, st_, a);
   LX_HIP(hipGetLastError());
   claim_base_ += nb;   // (wraps together with the device counter)
+}
+
+// after failed(): which conditions the last run met (bit r = reason r of vb_fail)
+uint32_t VoxBucket::why() const {
+  uint32_t m = 0;
+  for (int r = 0; r < 6; r++)
+    if (((volatile uint32_t*)h_fail_.p)[2 + r] == epoch_) m |= 1u << r;
+  return m;
 }
 
 void VoxBucket::check() {

@@ -235,6 +235,122 @@ __device__ __forceinline__ void nn_window_wave(const GridDesc& g, const float4* 
   }
 }
 
+// Fast path of both searches: the 3x3x3 block of cells around the query holds every point within one cell edge h of it, so whenever
+// the answer is nearer than h (almost always: h = 2.1 m) one pass over the block decides the query.  The block is 9 rows of up to
+// three x-adjacent cells = 9 contiguous runs of the cell-sorted array; their 18 boundaries are fetched by 9 lanes in one trip, then
+// ALL lanes stride the concatenated runs with four loads in flight each — the shell walk of nn1_wave / nn_window_wave visits row
+// after row, one memory latency per row, and is kept for the queries this pass cannot decide.
+struct Block27 {
+  uint32_t O[9], E[9];   // run k holds the candidates [E[k-1], E[k]); position in the sorted array = candidate number + O[k]
+  uint32_t total;
+  float cover2;          // squared radius around the query that the block certainly contains (with a margin for rounding)
+};
+__device__ __forceinline__ void block27_setup(const GridDesc& g, const uint32_t* __restrict__ cell_start, float qx, float qy, float qz, int lane, Block27& B) {
+  const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+  uint32_t b = 0u, l = 0u;
+  // (a query far outside the grid has an empty block; the casts below then stay in range)
+  const bool near_grid = flx >= -2.f && flx <= (float)(g.nx + 1) && fly >= -2.f && fly <= (float)(g.ny + 1) && flz >= -2.f && flz <= (float)(g.nz + 1);
+  if (near_grid && lane < 9) {
+    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+    const int z = cz + lane / 3 - 1, y = cy + lane % 3 - 1;
+    int xa = cx - 1, xb = cx + 1;
+    if (xa < 0) xa = 0;
+    if (xb > g.nx - 1) xb = g.nx - 1;
+    if (z >= 0 && z < g.nz && y >= 0 && y < g.ny && xa <= xb) {
+      const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
+      b = cell_start[row + xa];
+      l = cell_start[row + xb + 1] - b;
+    }
+  }
+  uint32_t acc = 0u;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)b, k), lk = (uint32_t)__builtin_amdgcn_readlane((int)l, k);   // wave-uniform: scalar registers
+    B.O[k] = bk - acc;
+    acc += lk;
+    B.E[k] = acc;
+  }
+  B.total = acc;
+  const float h = 1.0f / g.inv_h;
+  B.cover2 = h * h * 0.999f;
+}
+__device__ __forceinline__ uint32_t block27_pos(const Block27& B, uint32_t c) {
+  uint32_t o = B.O[8];
+#pragma unroll
+  for (int k = 7; k >= 0; k--) o = c < B.E[k] ? B.O[k] : o;
+  return c + o;
+}
+// nearest point of the block (ties: lowest position in its cloud); returns its position or -1, d_out = its squared distance
+__device__ __forceinline__ int block27_nearest(const Block27& B, const float4* __restrict__ sorted, float qx, float qy, float qz, int lane, float& d_out) {
+  float lbest = 25.0f;
+  uint32_t lid = 0xffffffffu;
+  for (uint32_t c0 = (uint32_t)lane; c0 < B.total; c0 += 256) {
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t c = c0 + 64u * (uint32_t)u;
+      p[u] = sorted[c < B.total ? block27_pos(B, c) : block27_pos(B, c0)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (c0 + 64u * (uint32_t)u >= B.total) continue;
+      const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      const uint32_t id = __float_as_uint(p[u].w) & 0xffffffu;
+      if (d2 < lbest || (d2 == lbest && lid != 0xffffffffu && id < lid)) { lbest = d2; lid = id; }
+    }
+  }
+  float d = lbest;
+  int j = (int)lid, o_ = (int)lid;
+  if (lid == 0xffffffffu) { j = -1; o_ = 0x7fffffff; }
+  wave_argmin(d, j, o_);
+  d_out = d;
+  return (j >= 0 && d < 25.0f) ? j : -1;
+}
+// the window classes of nn_window_wave over the block; true when every class the feature needs is decided inside the covered radius
+__device__ __forceinline__ bool block27_window(const Block27& B, const float4* __restrict__ sorted, float qx, float qy, float qz, int lane, bool corner,
+                                               int closest, int cscan, int wlo, int whi, int& j2, int& j3) {
+  float l2 = 25.0f, l3 = 25.0f;
+  int lj2 = -1, lj3 = -1, lo2 = 0x7fffffff, lo3 = 0x7fffffff;
+  for (uint32_t c0 = (uint32_t)lane; c0 < B.total; c0 += 256) {
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t c = c0 + 64u * (uint32_t)u;
+      p[u] = sorted[c < B.total ? block27_pos(B, c) : block27_pos(B, c0)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (c0 + 64u * (uint32_t)u >= B.total) continue;
+      const uint32_t wb = __float_as_uint(p[u].w);
+      const int j = (int)(wb & 0xffffffu), ring = (int)(wb >> 24);
+      const bool fwd = j > closest;
+      if (j == closest || (fwd ? j >= whi : j < wlo)) continue;
+      const float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
+      const float d = dx * dx + dy * dy + dz * dz;
+      const int order = fwd ? j - (closest + 1) : 0x40000000 + (closest - 1 - j);
+      const bool other = fwd ? ring > cscan : ring < cscan;
+      if (corner) {
+        if (other && (d < l2 || (d == l2 && lo2 != 0x7fffffff && order < lo2))) { l2 = d; lj2 = j; lo2 = order; }
+      } else if (other) {
+        if (d < l3 || (d == l3 && lo3 != 0x7fffffff && order < lo3)) { l3 = d; lj3 = j; lo3 = order; }
+      } else {
+        if (d < l2 || (d == l2 && lo2 != 0x7fffffff && order < lo2)) { l2 = d; lj2 = j; lo2 = order; }
+      }
+    }
+  }
+  wave_argmin(l2, lj2, lo2);
+  const bool ok2 = lj2 >= 0 && l2 <= B.cover2;
+  bool ok3 = true;
+  if (!corner) {
+    wave_argmin(l3, lj3, lo3);
+    ok3 = lj3 >= 0 && l3 <= B.cover2;
+  }
+  j2 = lj2; j3 = lj3;
+  return ok2 && ok3;
+}
+
 // ---- phases A+B: correspondences of one feature by one wave: exact 1-NN, then the ring-window scans;
 // grid = (ceil(maxFeat/4), streams), 256 threads
 __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ probs, OdomParams P) {
@@ -263,7 +379,11 @@ __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ pro
   float x, y, z;
   transform_to_start(T, P.scan_period, pi, x, y, z);
   const GridDescB gd = corner ? *pb.lc_desc : *pb.ls_desc;
-  const int closest = nn1_wave(gd.g, pb.sorted, pb.cell_table + gd.cell_base, x, y, z, lane);
+  Block27 blk;
+  block27_setup(gd.g, pb.cell_table + gd.cell_base, x, y, z, lane, blk);
+  float dnear;
+  int closest = block27_nearest(blk, pb.sorted, x, y, z, lane, dnear);
+  if (!(closest >= 0 && dnear <= blk.cover2)) closest = nn1_wave(gd.g, pb.sorted, pb.cell_table + gd.cell_base, x, y, z, lane);   // not decided inside the block (wave-uniform)
   if (closest < 0) {   // wave-uniform
     if (lane == 0) { pb.ind[5 * f] = -1; pb.ind[5 * f + 1] = -1; pb.ind[5 * f + 2] = -1; }
     return;
@@ -279,7 +399,8 @@ __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ pro
     int whi = (int)rf[cscan + 3 < LX_RINGTAB - 1 ? cscan + 3 : LX_RINGTAB - 1];
     if (whi > bound) whi = bound;
     int j2, j3;
-    nn_window_wave(gd.g, pb.sorted, pb.cell_table + gd.cell_base, x, y, z, lane, corner, closest, cscan, wlo, whi, j2, j3);
+    if (!block27_window(blk, pb.sorted, x, y, z, lane, corner, closest, cscan, wlo, whi, j2, j3))   // (wave-uniform)
+      nn_window_wave(gd.g, pb.sorted, pb.cell_table + gd.cell_base, x, y, z, lane, corner, closest, cscan, wlo, whi, j2, j3);
     if (lane == 0) {
       pb.ind[5 * f] = closest;
       pb.ind[5 * f + 1] = j2;

@@ -164,10 +164,9 @@ void SubMapIndex::build(const float4* d_pts, uint32_t n) {
 // SubMapIndexBatch: the same counting-sort build for K clouds with one set of launches
 // scratch: [0] total cells + 1, [1] scan total, [2] total cells
 // ----------------------------------------------------------------------------------------------------------------
-__global__ void k_bb_init(uint32_t* enc, uint32_t K, uint32_t* flags) {
+__global__ void k_bb_init(uint32_t* enc, uint32_t K) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 6 * K) enc[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
-  if (i < K) flags[i] = 0u;
 }
 // grid = (blocks, K)
 __global__ __launch_bounds__(256) void k_bb_bbox(const float4* __restrict__ pts, const uint32_t* __restrict__ off, uint32_t* __restrict__ enc) {
@@ -204,10 +203,11 @@ __global__ __launch_bounds__(256) void k_bb_bbox(const float4* __restrict__ pts,
 }
 // one thread: grid descriptors, per-cloud cell budget, table bases
 __global__ void k_bb_setup(const uint32_t* __restrict__ enc, const uint32_t* __restrict__ off, uint32_t K, GridDescB* __restrict__ desc,
-                           uint32_t* __restrict__ scratch, uint32_t max_cells_total, float cell0) {
+                           uint32_t* __restrict__ scratch, uint32_t max_cells_total, float cell0, uint32_t* __restrict__ flags) {
   const uint32_t budget = max_cells_total / (K ? K : 1);
   uint32_t base = 0;
   for (uint32_t c = 0; c < K; c++) {
+    flags[c] = 0u;   // (the clouds' ring flags: k_bb_count raises them; the previous index's were in use until this build)
     GridDescB d;
     d.pt_base = off[c];
     d.cell_base = base;
@@ -335,7 +335,7 @@ void SubMapIndexBatch::prepare(uint32_t K) {
   enc_.reserve((size_t)6 * K + 6);
   flags_.reserve(K + 1);
   ring_first_.reserve((size_t)K * LX_RINGTAB);
-  hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K, flags_.p);
+  hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K);
 }
 
 void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_t K, const uint32_t* d_off_ready, bool prepared) {
@@ -357,13 +357,13 @@ void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_
   cell_of_.reserve((size_t)n + 1);
   cell_start_.reserve((size_t)LX_MAX_CELLS + 2);
   cursor_.reserve((size_t)LX_MAX_CELLS + 2);
-  if (!prepared) hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K, flags_.p);
+  if (!prepared) hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K);
   uint32_t max_len = 0;
   for (uint32_t c = 0; c < K; c++) max_len = std::max(max_len, h_off[c + 1] - h_off[c]);
   LX_REQUIRE(max_len < (1u << 24), "a cloud of an index batch is limited to 16 Mi points");
   const uint32_t nbx = std::min<uint32_t>(std::max<uint32_t>((max_len + 255) / 256, 1u), 32u);
   hipLaunchKernelGGL(k_bb_bbox, dim3(nbx, K), dim3(256), 0, st_, d_pts, d_off, enc_.p);
-  hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1), 0, st_, enc_.p, d_off, K, d_desc_.p, scratch_.p, LX_MAX_CELLS, cell_size);
+  hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1), 0, st_, enc_.p, d_off, K, d_desc_.p, scratch_.p, LX_MAX_CELLS, cell_size, flags_.p);
   hipLaunchKernelGGL(k_zero_u32_dn, dim3(2048), dim3(256), 0, st_, cursor_.p, scratch_.p + 0);
   if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, d_desc_.p, cell_of_.p, cursor_.p, ring_first_.p, flags_.p);
   exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 2, scratch_.p + 1, LX_MAX_CELLS, st_, cursor_.p);

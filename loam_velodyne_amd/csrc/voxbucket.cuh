@@ -1,10 +1,11 @@
 // Bucketed voxel-grid down-sampling of the registration's stack clouds (pcl::VoxelGrid semantics, BasicLaserMapping.cpp:512-527)
-// in three short launches — no phase barriers, no multi-pass global sort:
-//   k_vb_plan     one workgroup per segment (sweep x {corner, surf}), reads the UNtransformed feature points: a box padded by one
-//                 voxel, a 32 Ki-bin histogram of PCL's linear voxel index over that box, and from its prefix sums a partition of
-//                 the index range into buckets of ~VB_T points (contiguous index ranges, so the buckets of a segment in order are
-//                 its voxels in order).  The map -> sensor round trip that follows moves a point by a few 1e-5 m, i.e. almost never
-//                 across a voxel face, so the partition predicted here fits the transformed points up to a handful of strays.
+// in a handful of short launches — no phase barriers, no multi-pass global sort:
+//   plan          (k_vb_bounds, k_vb_hist, k_vb_scan: three small launches over the UNtransformed feature points of every segment
+//                 = sweep x {corner, surf}) a box padded by one voxel, a 32 Ki-bin histogram of PCL's linear voxel index over that
+//                 box, and from its prefix sums a partition of the index range into buckets of ~VB_T points (contiguous index
+//                 ranges, so the buckets of a segment in order are its voxels in order).  The map -> sensor round trip that follows
+//                 moves a point by a few 1e-5 m, i.e. almost never across a voxel face, so the partition predicted here fits the
+//                 transformed points up to a handful of strays.
 //   k_vb_stack    one thread per point: the round trip itself (:512-516), the exact voxel, its bucket (one table look-up) and a
 //                 slot in the bucket's fixed-capacity array (one atomic per run of equal buckets in a wave).
 //   k_vb_reduce   one workgroup per bucket: LSD radix sort of (voxel index, input position) entirely in LDS, run heads, output
@@ -20,9 +21,9 @@
 namespace loamx {
 
 #ifndef VB_CAP_LOG2
-#define VB_CAP_LOG2 11
+#define VB_CAP_LOG2 12
 #endif
-constexpr int VB_CAP = 1 << VB_CAP_LOG2;        // slots per bucket (2048: 56 KB of LDS per workgroup; 4096: 112 KB)
+constexpr int VB_CAP = 1 << VB_CAP_LOG2;        // slots per bucket (4096: a 512-thread workgroup with 41 KB of LDS)
 constexpr int VB_T = VB_CAP / 2;                // target points per bucket
 constexpr int VB_MAXBIN = VB_CAP - VB_T - 128;  // largest bin a bucket can take: T + MAXBIN + strays <= CAP
 constexpr int VB_BIN_BITS = 15;
@@ -68,6 +69,8 @@ class VoxBucket {
   DevBuf<VbSeg> segs_;
   DevBuf<VbBucket> buckets_;
   DevBuf<uint16_t> bin2bucket_;            // [nseg][VB_BINS]
+  DevBuf<int> mm_;                         // [nseg][6] voxel bounds of the untransformed points
+  DevBuf<uint32_t> hist_;                  // [nseg][VB_BINS]
   DevBuf<uint32_t> cnt_, heads_, ctl_;     // per bucket: points, run heads + 1 once published; ctl: [0] fail epoch, [1] claim counter
   DevBuf<unsigned long long> elems_;       // [buckets][VB_CAP]
   PinBuf<uint32_t> h_fail_;                // [0] fail epoch (host-visible copy), [1] timeout, [2..7] epoch of the last run that met reason r

@@ -11,164 +11,60 @@ struct VbArgs {
   const uint32_t* seg_off;      // [nseg + 1]
   const Pose* poses;            // per sweep (segment / 2)
   VbSeg* segs;
-  VbBucket* buckets;
-  uint16_t* bin2bucket;
-  int* mm;                      // [nseg][6] voxel bounds of the untransformed points (min x y z, max x y z)
-  uint32_t* hist;               // [nseg][VB_BINS], zero between runs (k_vb_scan clears what it has read)
+  unsigned long long* lo;       // per bucket: smallest voxel key
+  uint32_t* bseg;               // per bucket: segment
+  int* box;                     // [nseg][6]
   uint32_t* cnt;
   uint32_t* heads;
-  uint32_t* ctl;                // [0] fail epoch, [1] claim counter
+  uint32_t* ctl;                // [0] fail epoch
   uint32_t* h_fail;             // pinned: [0] fail epoch, [1] timeout, [2 + r] epoch of the last run that met reason r
-  unsigned long long* elems;
+  uint32_t* elems;
   float4* stack;
   float4* out;
   uint32_t* out_off;
-  uint32_t n, nseg, nb, epoch, claim_base;
+  uint32_t n, nseg, nb, epoch;
   float inv_even, inv_odd;
 };
 
 __device__ inline uint32_t vb_bits(unsigned long long v) { return v ? 64u - (uint32_t)__builtin_clzll(v) : 0u; }
-// reasons (h_fail[2 + reason] = epoch, for the diagnostics of VoxBucket::why()): 0 a coordinate without a voxel, 1 more buckets
-// than a segment may have, 2 padded box beyond INT_MAX voxels, 3 a histogram bin larger than a bucket takes, 4 a point outside
-// the predicted box, 5 a bucket over capacity
+// reasons (h_fail[2 + reason] = epoch, for the diagnostics of VoxBucket::why()): 0 a coordinate beyond +-2^20 voxels (or not finite),
+// 1 more buckets than a segment may have, 2 segment box beyond INT_MAX voxels (PCL passes the cloud through), 3 a bucket whose own
+// box needs more than 64 sort bits, 5 a bucket over capacity
 __device__ inline void vb_fail(const VbArgs& A, int reason) {
   A.ctl[0] = A.epoch;      // (every writer stores the same value)
   A.h_fail[0] = A.epoch;
   A.h_fail[2 + reason] = A.epoch;
 }
 // voxel coordinate of one axis exactly as pcl::VoxelGrid forms it: floor(v * inverse leaf), float arithmetic
+constexpr int VB_OFF = 1 << 20;
 __device__ inline bool vb_voxel(float v, float inv, int& i) {
   const float f = floorf(v * inv);
-  if (!(fabsf(f) < 1.0e9f)) return false;   // also catches NaN / inf
+  if (!(fabsf(f) < (float)VB_OFF)) return false;   // also catches NaN / inf
   i = (int)f;
   return true;
 }
-constexpr int VB_BAD = 2147483647;   // mm[seg][3] (max x) of a segment with a coordinate that has no voxel
-
-// the padded box of a segment and what follows from it; false: the segment cannot take the bucketed path (reason)
-__device__ inline bool vb_box(const int* __restrict__ mm, uint32_t ns, VbSeg& P, int& reason) {
-  P.pos_bits = vb_bits(ns ? (unsigned long long)(ns - 1) : 0ull);
-  if (P.pos_bits == 0) P.pos_bits = 1;
-  P.mn[0] = P.mn[1] = P.mn[2] = 0;
-  P.dim[0] = P.dim[1] = P.dim[2] = 0u;   // nothing falls into an empty box
-  P.shift = 0u;
-  P.bucket0 = P.nbuckets = 0u;
-  reason = -1;
-  if (ns == 0) return true;
-  if (mm[3] == VB_BAD || mm[3] < mm[0]) { reason = 0; return false; }
-  unsigned long long d[3];
-#pragma unroll
-  for (int a = 0; a < 3; a++) d[a] = (unsigned long long)((long long)mm[3 + a] - (long long)mm[a] + 3);   // one voxel of margin on every side
-  // a padded box beyond INT_MAX voxels goes to the general kernel, which applies PCL's own (unpadded) pass-through test
-  if (d[0] * d[1] > 2147483647ull || d[0] * d[1] * d[2] > 2147483647ull) { reason = 2; return false; }
-#pragma unroll
-  for (int a = 0; a < 3; a++) { P.mn[a] = mm[a] - 1; P.dim[a] = (uint32_t)d[a]; }
-  const uint32_t kb = vb_bits(d[0] * d[1] * d[2] - 1ull);
-  P.shift = kb > (uint32_t)VB_BIN_BITS ? kb - (uint32_t)VB_BIN_BITS : 0u;
-  return true;
+// voxel order = pcl::VoxelGrid's linear index order inside any box: (iz, iy, ix) lexicographically
+__device__ inline unsigned long long vb_key(int ix, int iy, int iz) {
+  return ((unsigned long long)(uint32_t)(iz + VB_OFF) << 42) | ((unsigned long long)(uint32_t)(iy + VB_OFF) << 21) | (unsigned long long)(uint32_t)(ix + VB_OFF);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
-// plan, step 1 — k_vb_bounds: voxel box of the untransformed points of every segment.  grid = (blocks, segments), 256 threads
+// k_vb_plan: grid = segments, VB_SAMPLE threads
 // ----------------------------------------------------------------------------------------------------------------
-__global__ void k_vb_bounds_init(int* mm, uint32_t nseg) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 6 * nseg) mm[i] = (i % 6) < 3 ? 2147483647 : (-2147483647 - 1);
-}
-__global__ __launch_bounds__(256) void k_vb_bounds(const VbArgs A) {
-  const uint32_t seg = blockIdx.y;
-  const uint32_t a0 = A.seg_off[seg], ns = A.seg_off[seg + 1] - a0;
-  if (blockIdx.x * 2048u >= ns) return;
-  const float4* __restrict__ pts = A.src ? A.src[seg] : A.in + a0;
-  const float inv = (seg & 1) ? A.inv_odd : A.inv_even;
-  int mn[3] = {2147483647, 2147483647, 2147483647}, mx[3] = {-2147483647 - 1, -2147483647 - 1, -2147483647 - 1};
-  bool bad = false;
-  for (uint32_t i0 = blockIdx.x * 2048u + threadIdx.x; i0 < ns; i0 += gridDim.x * 2048u) {
-    float4 p[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const uint32_t i = i0 + 256u * (uint32_t)u;
-      p[u] = pts[i < ns ? i : i0];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      int v[3];
-      if (!(vb_voxel(p[u].x, inv, v[0]) && vb_voxel(p[u].y, inv, v[1]) && vb_voxel(p[u].z, inv, v[2]))) { bad = true; continue; }
-#pragma unroll
-      for (int a = 0; a < 3; a++) { mn[a] = v[a] < mn[a] ? v[a] : mn[a]; mx[a] = v[a] > mx[a] ? v[a] : mx[a]; }
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-      const int lo = __shfl_xor(mn[a], d, 64), hi = __shfl_xor(mx[a], d, 64);
-      mn[a] = lo < mn[a] ? lo : mn[a];
-      mx[a] = hi > mx[a] ? hi : mx[a];
-    }
-  }
-  __shared__ int s_mm[4][6];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if (__any(bad)) mx[0] = VB_BAD;
-  if (lane == 0) {
-#pragma unroll
-    for (int a = 0; a < 3; a++) { s_mm[wid][a] = mn[a]; s_mm[wid][3 + a] = mx[a]; }
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    const int a = (int)threadIdx.x;
-    int v = s_mm[0][a];
-    for (int w = 1; w < 4; w++) v = a < 3 ? (s_mm[w][a] < v ? s_mm[w][a] : v) : (s_mm[w][a] > v ? s_mm[w][a] : v);
-    if (a < 3) atomicMin(&A.mm[6 * seg + a], v); else atomicMax(&A.mm[6 * seg + a], v);
-  }
-}
-
-// ----------------------------------------------------------------------------------------------------------------
-// plan, step 2 — k_vb_hist: histogram of the predicted linear voxel indices.  grid = (blocks, segments), 256 threads
-// ----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_vb_hist(const VbArgs A) {
-  const uint32_t seg = blockIdx.y;
-  const uint32_t a0 = A.seg_off[seg], ns = A.seg_off[seg + 1] - a0;
-  if (blockIdx.x * 2048u >= ns) return;
-  VbSeg P;
-  int reason;
-  if (!vb_box(A.mm + 6 * seg, ns, P, reason)) return;   // (k_vb_scan raises the fail word)
-  const float4* __restrict__ pts = A.src ? A.src[seg] : A.in + a0;
-  const float inv = (seg & 1) ? A.inv_odd : A.inv_even;
-  uint32_t* __restrict__ hist = A.hist + (size_t)seg * VB_BINS;
-  for (uint32_t i0 = blockIdx.x * 2048u + threadIdx.x; i0 < ns; i0 += gridDim.x * 2048u) {
-    float4 p[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const uint32_t i = i0 + 256u * (uint32_t)u;
-      p[u] = pts[i < ns ? i : i0];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      if (i0 + 256u * (uint32_t)u >= ns) continue;
-      int v[3];
-      (void)vb_voxel(p[u].x, inv, v[0]); (void)vb_voxel(p[u].y, inv, v[1]); (void)vb_voxel(p[u].z, inv, v[2]);
-      const uint32_t key = (uint32_t)(v[0] - P.mn[0]) + ((uint32_t)(v[1] - P.mn[1]) + (uint32_t)(v[2] - P.mn[2]) * P.dim[1]) * P.dim[0];
-      atomicAdd(&hist[key >> P.shift], 1u);
-    }
-  }
-}
-
-// ----------------------------------------------------------------------------------------------------------------
-// plan, step 3 — k_vb_scan: bins -> buckets.  grid = segments, 1024 threads (thread t owns VB_BINS / 1024 consecutive bins)
-// ----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_vb_scan(const VbArgs A) {
-  __shared__ uint32_t s_first[VB_MAXBUCK], s_last[VB_MAXBUCK];
+__global__ __launch_bounds__(VB_SAMPLE) void k_vb_plan(const VbArgs A) {
+  __shared__ unsigned long long s_key[VB_SAMPLE], s_sorted[VB_SAMPLE];
   __shared__ uint32_t s_scan[17];
   __shared__ uint32_t s_bad;
   const int tid = (int)threadIdx.x;
   const uint32_t seg = blockIdx.x;
-  const uint32_t ns = A.seg_off[seg + 1] - A.seg_off[seg];
+  const uint32_t a0 = A.seg_off[seg], ns = A.seg_off[seg + 1] - a0;
+  const float4* __restrict__ pts = A.src ? A.src[seg] : A.in + a0;
+  const float inv = (seg & 1) ? A.inv_odd : A.inv_even;
   // first bucket of this segment: every segment owns max(1, ceil(points / T)) buckets
   uint32_t bucket0;
   {
     uint32_t part = 0;
-    for (uint32_t s = (uint32_t)tid; s < seg; s += 1024) {
+    for (uint32_t s = (uint32_t)tid; s < seg; s += VB_SAMPLE) {
       const uint32_t m = A.seg_off[s + 1] - A.seg_off[s];
       part += m ? (m + VB_T - 1) / VB_T : 1u;
     }
@@ -177,89 +73,63 @@ __global__ __launch_bounds__(1024) void k_vb_scan(const VbArgs A) {
     bucket0 = tot;
   }
   const uint32_t nbuckets = ns ? (ns + VB_T - 1) / VB_T : 1u;
-  VbSeg P;
-  int reason;
-  const bool box_ok = vb_box(A.mm + 6 * seg, ns, P, reason);   // block-uniform (k_vb_hist counted this segment's points iff box_ok)
-  bool seg_bad = !box_ok;
-  if (!seg_bad && nbuckets > (uint32_t)VB_MAXBUCK) { seg_bad = true; reason = 1; }
-  if (seg_bad) P.dim[0] = P.dim[1] = P.dim[2] = 0u;   // a point of a given-up segment raises the fail word again, harmlessly
-  P.bucket0 = bucket0;
-  P.nbuckets = nbuckets;
-  unsigned long long nkeys = (unsigned long long)P.dim[0] * P.dim[1] * P.dim[2];
-  if (nkeys == 0ull) nkeys = 1ull;
-  const uint32_t nbins = (uint32_t)((nkeys - 1ull) >> P.shift) + 1u;   // <= VB_BINS
-  if (tid == 0) s_bad = 0u;
-  for (uint32_t e = (uint32_t)tid; e < (uint32_t)VB_MAXBUCK; e += 1024) { s_first[e] = 0xffffffffu; s_last[e] = 0u; }
+  const uint32_t m = ns < (uint32_t)VB_SAMPLE ? ns : (uint32_t)VB_SAMPLE;
+  if (tid == 0) s_bad = nbuckets > (uint32_t)VB_SAMPLE ? 2u : 0u;
   __syncthreads();
-  // bucket of a bin = exclusive prefix / T.  A bucket's index range covers every bin mapped to it, empty ones included: a stray
-  // may land in a bin the prediction left empty.
-  {
-    constexpr int BPT = VB_BINS / 1024;
-    uint32_t* __restrict__ hist = A.hist + (size_t)seg * VB_BINS + BPT * tid;
-    uint32_t h[BPT], sum = 0;
-    bool big = false;
-#pragma unroll
-    for (int k = 0; k < BPT; k++) {
-      h[k] = (box_ok && ns) ? hist[k] : 0u;
-      sum += h[k];
-      big = big || h[k] > (uint32_t)VB_MAXBIN;
+  unsigned long long key = ~0ull;
+  if (nbuckets > 1u && (uint32_t)tid < m) {   // (one bucket needs no splitter)
+    const float4 p = pts[(uint32_t)(((unsigned long long)tid * ns) / m)];
+    int v[3];
+    if (vb_voxel(p.x, inv, v[0]) && vb_voxel(p.y, inv, v[1]) && vb_voxel(p.z, inv, v[2])) key = vb_key(v[0], v[1], v[2]);
+    else atomicOr(&s_bad, 1u);
+  }
+  s_key[tid] = key;
+  __syncthreads();
+  if (nbuckets > 1u && (uint32_t)tid < m) {   // rank among the sample (ties by sample position): every thread scans the sample through LDS broadcasts
+    uint32_t r = 0;
+    for (uint32_t u = 0; u < m; u++) {
+      const unsigned long long k = s_key[u];
+      r += (k < key || (k == key && u < (uint32_t)tid)) ? 1u : 0u;
     }
-#pragma unroll
-    for (int k = 0; k < BPT; k++)
-      if (h[k]) hist[k] = 0u;   // ready for the next run
-    if (big) s_bad = 1u;
-    uint32_t tot;
-    uint32_t ex = block_excl_scan(sum, s_scan, tot);
-    uint16_t* tab = A.bin2bucket + (size_t)seg * VB_BINS + BPT * tid;
-    uint32_t run_b = 0xffffffffu, run_first = 0u, run_last = 0u;
-#pragma unroll
-    for (int k = 0; k < BPT; k++) {
-      const uint32_t bin = (uint32_t)(BPT * tid + k);
-      if (bin < nbins && !seg_bad) {
-        uint32_t b = ex / (uint32_t)VB_T;
-        if (b >= nbuckets) b = nbuckets - 1;   // empty bins behind the last point when the segment fills its buckets exactly
-        tab[k] = (uint16_t)b;
-        if (b != run_b) {
-          if (run_b != 0xffffffffu) { atomicMin(&s_first[run_b], run_first); atomicMax(&s_last[run_b], run_last); }
-          run_b = b;
-          run_first = bin;
-        }
-        run_last = bin;
-      }
-      ex += h[k];
-    }
-    if (run_b != 0xffffffffu) { atomicMin(&s_first[run_b], run_first); atomicMax(&s_last[run_b], run_last); }
+    s_sorted[r] = key;
   }
   __syncthreads();
-  if (!seg_bad && s_bad) { seg_bad = true; reason = 3; }
-  if (seg_bad && tid == 0) vb_fail(A, reason);
-  for (uint32_t k = (uint32_t)tid; k < nbuckets; k += 1024) {
-    VbBucket B;
-    B.seg = seg;
-    B.pad = 0u;
-    if (seg_bad || k >= (uint32_t)VB_MAXBUCK || s_first[k] == 0xffffffffu) { B.key_lo = 0u; B.key_bits = 1u; }
-    else {
-      B.key_lo = s_first[k] << P.shift;
-      const unsigned long long span = ((unsigned long long)(s_last[k] - s_first[k]) + 1ull) << P.shift;
-      B.key_bits = vb_bits(span - 1ull);
-      if (B.key_bits == 0u) B.key_bits = 1u;
-    }
-    A.buckets[bucket0 + k] = B;
+  const uint32_t bad = s_bad;
+  if (bad && tid == 0) vb_fail(A, (bad & 2u) ? 1 : 0);
+  for (uint32_t k = (uint32_t)tid; k < nbuckets && k < (uint32_t)VB_SAMPLE; k += VB_SAMPLE) {
+    A.lo[bucket0 + k] = (k == 0u || bad) ? 0ull : s_sorted[(uint32_t)(((unsigned long long)k * m) / nbuckets)];
+    A.bseg[bucket0 + k] = seg;
     A.cnt[bucket0 + k] = 0u;
     A.heads[bucket0 + k] = 0u;
   }
-  if (tid == 0) A.segs[seg] = P;
+  if (tid < 6) A.box[6 * seg + tid] = tid < 3 ? 2147483647 : (-2147483647 - 1);
+  if (tid == 0) {
+    VbSeg P;
+    P.bucket0 = bucket0;
+    P.nbuckets = bad ? 0u : nbuckets;   // a given-up segment takes no points (its points raise the fail word again, harmlessly)
+    P.pos_bits = vb_bits(ns ? (unsigned long long)(ns - 1) : 0ull);
+    if (P.pos_bits == 0) P.pos_bits = 1;
+    P.pad = 0u;
+    A.segs[seg] = P;
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
 // k_vb_stack: grid = ceil(n / 256), 256 threads
 // ----------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_vb_stack(const VbArgs A) {
+  __shared__ unsigned long long s_lo[64];   // the splitters of the segment of the workgroup's first point
+  __shared__ uint32_t s_tag[256], s_cnt[256], s_gbase[256];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = (int)(threadIdx.x & 63);
+  const uint32_t lead = vox_find_seg(A.seg_off, A.nseg, blockIdx.x * blockDim.x);
+  const VbSeg PL = A.segs[lead];
+  if (threadIdx.x < 64) s_lo[threadIdx.x] = threadIdx.x < PL.nbuckets ? A.lo[PL.bucket0 + threadIdx.x] : ~0ull;
+  s_tag[threadIdx.x] = 0xffffffffu;
+  s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
   bool act = i < A.n;
-  uint32_t g = 0u;
-  unsigned long long elem = 0ull;
+  uint32_t g = 0u, pos = 0u;
   if (act) {
     const uint32_t seg = vox_find_seg(A.seg_off, A.nseg, i);
     const uint32_t a0 = A.seg_off[seg];
@@ -269,36 +139,30 @@ __global__ __launch_bounds__(256) void k_vb_stack(const VbArgs A) {
     to_map(T, x, y, z);          // BasicLaserMapping.cpp:282-292 via :512-516
     to_be_mapped(T, x, y, z);
     A.stack[i] = make_float4(x, y, z, p.w);
-    const VbSeg P = A.segs[seg];
     const float inv = (seg & 1) ? A.inv_odd : A.inv_even;
     int v[3];
-    bool ok = vb_voxel(x, inv, v[0]) && vb_voxel(y, inv, v[1]) && vb_voxel(z, inv, v[2]);
-    uint32_t r[3] = {0u, 0u, 0u};
-    if (ok) {
-#pragma unroll
-      for (int a = 0; a < 3; a++) {
-        const long long d = (long long)v[a] - (long long)P.mn[a];
-        ok = ok && d >= 0 && d < (long long)P.dim[a];
-        r[a] = (uint32_t)d;
-      }
-    }
-    if (!ok) {   // outside the predicted box (or the plan gave the segment up: its box is empty)
-      vb_fail(A, 4);
+    const VbSeg P = seg == lead ? PL : A.segs[seg];
+    if (!(vb_voxel(x, inv, v[0]) && vb_voxel(y, inv, v[1]) && vb_voxel(z, inv, v[2])) || P.nbuckets == 0u) {
+      vb_fail(A, 0);
       act = false;
     } else {
-      const uint32_t key = r[0] + (r[1] + r[2] * P.dim[1]) * P.dim[0];
-      g = P.bucket0 + (uint32_t)A.bin2bucket[(size_t)seg * VB_BINS + (key >> P.shift)];
-      elem = ((unsigned long long)key << 24) | (unsigned long long)(i - a0);
+      const unsigned long long key = vb_key(v[0], v[1], v[2]);
+      // bucket = number of splitters (of buckets 1 ..) that are <= key
+      uint32_t lo = 0u, hi = P.nbuckets;   // splitter[lo] <= key < splitter[hi]  (splitter[0] = 0, splitter[nbuckets] = infinity)
+      if (seg == lead && P.nbuckets <= 64u) {
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (s_lo[mid] <= key) lo = mid; else hi = mid; }
+      } else {
+        const unsigned long long* __restrict__ sp = A.lo + P.bucket0;
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (sp[mid] <= key) lo = mid; else hi = mid; }
+      }
+      g = P.bucket0 + lo;
+      pos = i - a0;
     }
   }
   // Slots: the lanes of a wave that go to the same bucket are counted together, the waves of the workgroup meet in an LDS table
   // (256 entries, bucket % 256 with a tag: the buckets a workgroup touches are a few neighbours of one or two segments), and ONE
-  // thread per touched bucket bumps the global counter — hundreds of waves hammering ~150 counters serialise in L2 otherwise.
+  // thread per touched bucket bumps the global counter — hundreds of waves hammering ~150 counters serialise in memory otherwise.
   // A bucket that finds its table entry taken by another one goes to the global counter directly.
-  __shared__ uint32_t s_tag[256], s_cnt[256], s_gbase[256];
-  s_tag[threadIdx.x] = 0xffffffffu;
-  s_cnt[threadIdx.x] = 0u;
-  __syncthreads();
   unsigned long long rem = __ballot(act);
   uint32_t slot = 0u;      // rank inside the workgroup's share of the bucket (table path) or the final slot (direct path)
   bool direct = false;
@@ -323,7 +187,7 @@ __global__ __launch_bounds__(256) void k_vb_stack(const VbArgs A) {
   __syncthreads();
   if (act) {
     if (!direct) slot += s_gbase[g & 255u];
-    if (slot < (uint32_t)VB_CAP) A.elems[(size_t)g * VB_CAP + slot] = elem;
+    if (slot < (uint32_t)VB_CAP) A.elems[(size_t)g * VB_CAP + slot] = pos;
     else vb_fail(A, 5);
   }
 }
@@ -339,40 +203,99 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
   __shared__ uint32_t s_wcnt[VB_WAVES][256];
   __shared__ uint32_t s_base[256];
   __shared__ uint32_t s_scan[17];
-  __shared__ uint32_t s_bidx;
+  __shared__ int s_box[6];
   const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  // buckets are taken in the order the workgroups start, so everything a look-back waits for is already running
-  if (tid == 0) s_bidx = atomicAdd(&A.ctl[1], 1u) - A.claim_base;
-  __syncthreads();
-  const uint32_t b = s_bidx;
-  if (b >= A.nb) return;   // (cannot happen: the grid has exactly nb workgroups)
+  // workgroups start in index order, so everything a look-back waits for is already running (or done)
+  const uint32_t b = blockIdx.x;
   if (__hip_atomic_load(&A.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch) {   // given up: an empty, well-formed result
     if (b == 0)
       for (uint32_t s = (uint32_t)tid; s <= A.nseg; s += VB_THREADS) A.out_off[s] = 0u;
     return;
   }
-  const VbBucket bk = A.buckets[b];
+  const uint32_t seg = A.bseg[b];
   const uint32_t c = min(A.cnt[b], (uint32_t)VB_CAP);
-  const VbSeg P = A.segs[bk.seg];
-  const uint32_t sbeg = A.seg_off[bk.seg];
-  const unsigned long long* __restrict__ e = A.elems + (size_t)b * VB_CAP;
+  const VbSeg P = A.segs[seg];
+  const uint32_t sbeg = A.seg_off[seg];
+  const float inv = (seg & 1) ? A.inv_odd : A.inv_even;
+  const uint32_t* __restrict__ e = A.elems + (size_t)b * VB_CAP;
   const uint32_t pbits = P.pos_bits;
   const unsigned long long pmask = (1ull << pbits) - 1ull;
-  const uint32_t total_bits = bk.key_bits + pbits;
-  const uint32_t npass = (total_bits + 7u) / 8u;
-  // sort word: (linear voxel index - bucket base) << pos_bits | input position inside the segment — all distinct
+  if (tid < 6) s_box[tid] = tid < 3 ? 2147483647 : (-2147483647 - 1);
+  __syncthreads();
+  // ---- the elements' voxels (recomputed from the stack points: the same floor(x / leaf) k_vb_stack took) and the bucket's box
+  uint32_t pos8[8];
+  int vx[8], vy[8], vz[8];
+  {
+    float4 pt[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t i = (uint32_t)(wid * 512 + j * 64 + lane);
+      pos8[j] = i < c ? e[i] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t i = (uint32_t)(wid * 512 + j * 64 + lane);
+      pt[j] = i < c ? A.stack[sbeg + pos8[j]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int mn[3] = {2147483647, 2147483647, 2147483647}, mx[3] = {-2147483647 - 1, -2147483647 - 1, -2147483647 - 1};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t i = (uint32_t)(wid * 512 + j * 64 + lane);
+      vx[j] = vy[j] = vz[j] = 0;
+      if (i < c) {
+        (void)vb_voxel(pt[j].x, inv, vx[j]); (void)vb_voxel(pt[j].y, inv, vy[j]); (void)vb_voxel(pt[j].z, inv, vz[j]);
+        mn[0] = vx[j] < mn[0] ? vx[j] : mn[0]; mx[0] = vx[j] > mx[0] ? vx[j] : mx[0];
+        mn[1] = vy[j] < mn[1] ? vy[j] : mn[1]; mx[1] = vy[j] > mx[1] ? vy[j] : mx[1];
+        mn[2] = vz[j] < mn[2] ? vz[j] : mn[2]; mx[2] = vz[j] > mx[2] ? vz[j] : mx[2];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        const int lo = __shfl_xor(mn[a], d, 64), hi = __shfl_xor(mx[a], d, 64);
+        mn[a] = lo < mn[a] ? lo : mn[a];
+        mx[a] = hi > mx[a] ? hi : mx[a];
+      }
+    }
+    if (lane == 0 && (uint32_t)(wid * 512) < c) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) { atomicMin(&s_box[a], mn[a]); atomicMax(&s_box[3 + a], mx[a]); }
+    }
+  }
+  __syncthreads();
+  unsigned long long dimx = 1ull, dimy = 1ull, dimz = 1ull;
+  int bx0 = 0, by0 = 0, bz0 = 0;
+  if (c) {
+    bx0 = s_box[0]; by0 = s_box[1]; bz0 = s_box[2];
+    dimx = (unsigned long long)(s_box[3] - bx0 + 1); dimy = (unsigned long long)(s_box[4] - by0 + 1); dimz = (unsigned long long)(s_box[5] - bz0 + 1);
+    if (tid < 6) {   // the segment's box, for PCL's pass-through test by the last bucket (released by the fence in front of the head count)
+      if (tid < 3) atomicMin(&A.box[6 * seg + tid], s_box[tid]); else atomicMax(&A.box[6 * seg + tid], s_box[tid]);
+    }
+  }
+  const uint32_t key_bits = vb_bits(dimx * dimy * dimz - 1ull);   // each extent < 2^21
+  const uint32_t total_bits = (key_bits ? key_bits : 1u) + pbits;
+  if (total_bits > 63u) {   // (block-uniform) a box this sparse cannot be sorted on one word: give up
+    if (tid == 0) vb_fail(A, 3);
+  }
+  const uint32_t npass = total_bits > 63u ? 0u : (total_bits + 7u) / 8u;
+  // sort word: voxel index inside the bucket's box << pos_bits | input position inside the segment — all distinct
   unsigned long long w[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const uint32_t i = (uint32_t)(wid * 512 + j * 64 + lane);
-    if (i < c) {
-      const unsigned long long x = e[i];
-      w[j] = (((x >> 24) - (unsigned long long)bk.key_lo) << pbits) | (x & 0xffffffull);
-    } else {
-      w[j] = ~0ull;
-    }
+    const unsigned long long lin = (unsigned long long)(vx[j] - bx0) + dimx * ((unsigned long long)(vy[j] - by0) + dimy * (unsigned long long)(vz[j] - bz0));
+    w[j] = i < c ? ((lin << pbits) | (unsigned long long)pos8[j]) : ~0ull;
   }
   const bool wave_has = (uint32_t)(wid * 512) < c;   // wave-uniform: a wave whose slots are all beyond the end only keeps the barriers
+  if (npass == 0u) {   // (given up: keep the buffer defined)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t i = (uint32_t)(wid * 512 + j * 64 + lane);
+      if (i < c) s_w[i] = w[j];
+    }
+    __syncthreads();
+  }
   for (uint32_t p = 0; p < npass; p++) {
     const uint32_t shift = 8u * p;
     if (tid < 256) {
@@ -438,35 +361,38 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
       }
     }
   }
-  // (npass >= 1: s_w holds the sorted words.)  Every thread takes eight CONSECUTIVE sorted elements and fetches their points
-  // itself (eight independent gathers in flight); a voxel's mean is the sequential sum of its run in sorted = input order: the
-  // part of a run inside its head's thread comes out of registers, a run that goes on into the following threads' elements is
-  // continued through LDS (the words) and global memory (the points, just fetched by the neighbour: cache hits).
+  // s_w holds the sorted words.  Every thread takes eight CONSECUTIVE sorted elements and fetches their points itself (eight
+  // independent gathers in flight — cache hits, the bucket's points were read a moment ago); a voxel's mean is the sequential sum of
+  // its run in sorted = input order: the part of a run inside its head's thread comes out of registers, a run that goes on into the
+  // following threads' elements is continued through LDS (the words) and global memory (the points).
   if (tid == 0) s_w[c] = ~0ull;   // sentinel behind the last element
   __syncthreads();
   const uint32_t l0 = (uint32_t)tid * 8u;
-  uint32_t vox[8];
+  unsigned long long vox[8];
   float4 pt[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const uint32_t l = l0 + (uint32_t)j;
     const unsigned long long x = l < c ? s_w[l] : ~0ull;
-    vox[j] = l < c ? (uint32_t)(x >> pbits) : 0xffffffffu;
+    vox[j] = x >> pbits;   // (the sentinel's is larger than any index of the box)
     pt[j] = l < c ? A.stack[sbeg + (uint32_t)(x & pmask)] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   bool head[8];
   uint32_t nh = 0u;
-  uint32_t prev = (l0 == 0u || l0 > c) ? 0xffffffffu : (uint32_t)(s_w[l0 - 1u] >> pbits);
+  unsigned long long prev = (l0 == 0u || l0 > c) ? ~0ull : (s_w[l0 - 1u] >> pbits);
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const uint32_t l = l0 + (uint32_t)j;
-    head[j] = l < c && (l == 0u || vox[j] != prev);   // (a voxel never straddles two buckets: buckets are index ranges)
+    head[j] = l < c && (l == 0u || vox[j] != prev);   // (a voxel never straddles two buckets: buckets are ranges of the voxel order)
     nh += head[j] ? 1u : 0u;
     prev = vox[j];
   }
   uint32_t tot;
   const uint32_t ex = block_excl_scan(nh, s_scan, tot);
-  if (tid == 0) __hip_atomic_store(&A.heads[b], tot + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    __threadfence();   // the box atomics above are visible before the count is
+    __hip_atomic_store(&A.heads[b], tot + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   uint32_t part = 0u;
   for (uint32_t t = (uint32_t)tid; t < b; t += VB_THREADS) {
     uint32_t v = __hip_atomic_load(&A.heads[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), spins = 0u;
@@ -480,8 +406,20 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
   uint32_t base;
   (void)block_excl_scan(part, s_scan, base);   // voxels emitted by all earlier buckets
   if (tid == 0) {
-    if (P.bucket0 == b) A.out_off[bk.seg] = base;
+    if (P.bucket0 == b) A.out_off[seg] = base;
     if (b + 1u == A.nb) A.out_off[A.nseg] = base + tot;
+  }
+  if (b + 1u == A.nb) {   // the last bucket has seen every other bucket's count, hence every segment's final box: PCL's pass-through test
+    __threadfence();
+    for (uint32_t s = (uint32_t)tid; s < A.nseg; s += VB_THREADS) {
+      int bb[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) bb[k] = __hip_atomic_load(&A.box[6 * s + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (bb[3] >= bb[0]) {
+        const long long dx = (long long)bb[3] - bb[0] + 1, dy = (long long)bb[4] - bb[1] + 1, dz = (long long)bb[5] - bb[2] + 1;
+        if (dx * dy > 2147483647LL || dx * dy * dz > 2147483647LL) vb_fail(A, 2);   // (each extent < 2^21)
+      }
+    }
   }
   uint32_t pos = base + ex;
 #pragma unroll
@@ -500,7 +438,7 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
         uint32_t l = l0 + 8u;
         for (;;) {
           const unsigned long long x = s_w[l < c ? l : c];
-          if (l >= c || (uint32_t)(x >> pbits) != vox[j]) break;
+          if (l >= c || (x >> pbits) != vox[j]) break;
           const float4 t = A.stack[sbeg + (uint32_t)(x & pmask)];
           sx += t.x; sy += t.y; sz += t.z; si += t.w;
           cntp++;
@@ -518,53 +456,43 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
 void VoxBucket::run(const float4* in, const float4* const* d_src, uint32_t n, const uint32_t* d_seg_off, const uint32_t* h_seg_off, uint32_t nseg,
                     const Pose* d_poses, float inv_even, float inv_odd, float4* stack, float4* out, uint32_t* d_out_off) {
   LX_REQUIRE(fits(n, nseg), "internal: VoxBucket::run outside its limits");
-  uint32_t nb = 0, max_len = 0;
+  uint32_t nb = 0;
   for (uint32_t s = 0; s < nseg; s++) {
     const uint32_t m = h_seg_off[s + 1] - h_seg_off[s];
     nb += m ? (m + VB_T - 1) / VB_T : 1u;
-    max_len = std::max(max_len, m);
   }
   nb_ = nb;
   segs_.reserve(nseg);
-  buckets_.reserve(nb);
-  bin2bucket_.reserve((size_t)nseg * VB_BINS);
-  mm_.reserve((size_t)6 * nseg);
+  lo_.reserve(nb);
+  bseg_.reserve(nb);
+  box_.reserve((size_t)6 * nseg);
   cnt_.reserve(nb);
   heads_.reserve(nb);
   elems_.reserve((size_t)nb * VB_CAP);
-  if (hist_.cap < (size_t)nseg * VB_BINS) {   // (a fresh allocation: cleared once; k_vb_scan leaves it cleared)
-    hist_.reserve((size_t)nseg * VB_BINS);
-    LX_HIP(hipMemsetAsync(hist_.p, 0, sizeof(uint32_t) * hist_.cap, st_));
-  }
   if (!ctl_ready_) {
     ctl_.reserve(4);
-    h_fail_.reserve(8);
-    for (int k = 0; k < 8; k++) h_fail_.p[k] = 0u;
+    h_fail_.reserve(16);
+    for (int k = 0; k < 16; k++) h_fail_.p[k] = 0u;
     LX_HIP(hipMemsetAsync(ctl_.p, 0, sizeof(uint32_t) * 4, st_));
     ctl_ready_ = true;
   }
   if (++epoch_ == 0u) epoch_ = 1u;
   VbArgs a;
   a.in = in; a.src = d_src; a.seg_off = d_seg_off; a.poses = d_poses;
-  a.segs = segs_.p; a.buckets = buckets_.p; a.bin2bucket = bin2bucket_.p; a.mm = mm_.p; a.hist = hist_.p; a.cnt = cnt_.p; a.heads = heads_.p;
+  a.segs = segs_.p; a.lo = lo_.p; a.bseg = bseg_.p; a.box = box_.p; a.cnt = cnt_.p; a.heads = heads_.p;
   a.ctl = ctl_.p; a.h_fail = h_fail_.p; a.elems = elems_.p; a.stack = stack; a.out = out; a.out_off = d_out_off;
-  a.n = n; a.nseg = nseg; a.nb = nb; a.epoch = epoch_; a.claim_base = claim_base_;
+  a.n = n; a.nseg = nseg; a.nb = nb; a.epoch = epoch_;
   a.inv_even = inv_even; a.inv_odd = inv_odd;
-  const uint32_t bx = std::max(1u, std::min(16u, (max_len + 2047u) / 2048u));   // blocks per segment of the two passes over the points
-  hipLaunchKernelGGL(k_vb_bounds_init, dim3((6 * nseg + 255) / 256), dim3(256), 0, st_, mm_.p, nseg);
-  hipLaunchKernelGGL(k_vb_bounds, dim3(bx, nseg), dim3(256), 0, st_, a);
-  hipLaunchKernelGGL(k_vb_hist, dim3(bx, nseg), dim3(256), 0, st_, a);
-  hipLaunchKernelGGL(k_vb_scan, dim3(nseg), dim3(1024), 0, st_, a);
+  hipLaunchKernelGGL(k_vb_plan, dim3(nseg), dim3(VB_SAMPLE), 0, st_, a);
   hipLaunchKernelGGL(k_vb_stack, dim3((n + 255) / 256), dim3(256), 0, st_, a);
   hipLaunchKernelGGL(k_vb_reduce, dim3(nb), dim3(VB_THREADS), 0, st_, a);
   LX_HIP(hipGetLastError());
-  claim_base_ += nb;   // (wraps together with the device counter)
 }
 
 // after failed(): which conditions the last run met (bit r = reason r of vb_fail)
 uint32_t VoxBucket::why() const {
   uint32_t m = 0;
-  for (int r = 0; r < 6; r++)
+  for (int r = 0; r < 8; r++)
     if (((volatile uint32_t*)h_fail_.p)[2 + r] == epoch_) m |= 1u << r;
   return m;
 }

@@ -24,6 +24,7 @@ struct VbArgs {
   uint32_t* out_off;
   uint32_t n, nseg, nb, epoch;
   float inv_even, inv_odd;
+  unsigned long long* dbg;      // LOAMX_PROF_VB: per bucket 16 wall-clock stamps of k_vb_reduce
 };
 
 __device__ inline uint32_t vb_bits(unsigned long long v) { return v ? 64u - (uint32_t)__builtin_clzll(v) : 0u; }
@@ -196,6 +197,11 @@ __global__ __launch_bounds__(256) void k_vb_stack(const VbArgs A) {
 // k_vb_reduce: grid = buckets, VB_CAP / 8 threads, 8 elements per thread
 // ----------------------------------------------------------------------------------------------------------------
 constexpr uint32_t VB_SPIN_LIMIT = 1u << 20;
+#ifdef LOAMX_PROF_VB
+#define VB_TS(k) do { if (threadIdx.x == 0) A.dbg[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define VB_TS(k) do { } while (0)
+#endif
 constexpr int VB_THREADS = VB_CAP / 8, VB_WAVES = VB_THREADS / 64;
 
 __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
@@ -207,6 +213,7 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
   const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // workgroups start in index order, so everything a look-back waits for is already running (or done)
   const uint32_t b = blockIdx.x;
+  VB_TS(0);
   if (__hip_atomic_load(&A.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch) {   // given up: an empty, well-formed result
     if (b == 0)
       for (uint32_t s = (uint32_t)tid; s <= A.nseg; s += VB_THREADS) A.out_off[s] = 0u;
@@ -264,6 +271,7 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
     }
   }
   __syncthreads();
+  VB_TS(1);
   unsigned long long dimx = 1ull, dimy = 1ull, dimz = 1ull;
   int bx0 = 0, by0 = 0, bz0 = 0;
   if (c) {
@@ -298,6 +306,7 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
   }
   for (uint32_t p = 0; p < npass; p++) {
     const uint32_t shift = 8u * p;
+    VB_TS(2 + (p < 7u ? p : 7u));
     if (tid < 256) {
 #pragma unroll
       for (int k = 0; k < VB_WAVES; k++) s_wcnt[k][tid] = 0u;
@@ -365,6 +374,7 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
   // independent gathers in flight — cache hits, the bucket's points were read a moment ago); a voxel's mean is the sequential sum of
   // its run in sorted = input order: the part of a run inside its head's thread comes out of registers, a run that goes on into the
   // following threads' elements is continued through LDS (the words) and global memory (the points).
+  VB_TS(10);
   if (tid == 0) s_w[c] = ~0ull;   // sentinel behind the last element
   __syncthreads();
   const uint32_t l0 = (uint32_t)tid * 8u;
@@ -387,6 +397,7 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
     nh += head[j] ? 1u : 0u;
     prev = vox[j];
   }
+  VB_TS(11);
   uint32_t tot;
   const uint32_t ex = block_excl_scan(nh, s_scan, tot);
   if (tid == 0) {
@@ -403,6 +414,7 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
     }
     part += v - 1u;
   }
+  VB_TS(12);
   uint32_t base;
   (void)block_excl_scan(part, s_scan, base);   // voxels emitted by all earlier buckets
   if (tid == 0) {
@@ -450,6 +462,7 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
       pos++;
     }
   }
+  VB_TS(13);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -483,10 +496,32 @@ void VoxBucket::run(const float4* in, const float4* const* d_src, uint32_t n, co
   a.ctl = ctl_.p; a.h_fail = h_fail_.p; a.elems = elems_.p; a.stack = stack; a.out = out; a.out_off = d_out_off;
   a.n = n; a.nseg = nseg; a.nb = nb; a.epoch = epoch_;
   a.inv_even = inv_even; a.inv_odd = inv_odd;
+  a.dbg = nullptr;
+#ifdef LOAMX_PROF_VB
+  static DevBuf<unsigned long long> dbg;
+  dbg.reserve((size_t)nb * 16 + 16);
+  LX_HIP(hipMemsetAsync(dbg.p, 0, sizeof(unsigned long long) * ((size_t)nb * 16), st_));
+  a.dbg = dbg.p;
+#endif
   hipLaunchKernelGGL(k_vb_plan, dim3(nseg), dim3(VB_SAMPLE), 0, st_, a);
   hipLaunchKernelGGL(k_vb_stack, dim3((n + 255) / 256), dim3(256), 0, st_, a);
   hipLaunchKernelGGL(k_vb_reduce, dim3(nb), dim3(VB_THREADS), 0, st_, a);
   LX_HIP(hipGetLastError());
+#ifdef LOAMX_PROF_VB
+  {
+    std::vector<unsigned long long> h((size_t)nb * 16);
+    LX_HIP(hipStreamSynchronize(st_));
+    LX_HIP(hipMemcpy(h.data(), dbg.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (uint32_t b = 0; b < nb; b++) { if (h[16 * b]) t0 = std::min(t0, h[16 * b]); t1 = std::max(t1, h[16 * b + 13]); }
+    fprintf(stderr, "[k_vb_reduce %u buckets, %.1f us first start -> last end] bucket: start | box | passes ... | sorted | heads | look-back | end (us since first start)\n", nb, (t1 - t0) * 0.01);
+    for (uint32_t b : {0u, nb / 4, nb / 2, nb - 1}) {
+      fprintf(stderr, "  b%-4u", b);
+      for (int k = 0; k < 14; k++) if (h[16 * b + k]) fprintf(stderr, " %d:%.1f", k, (h[16 * b + k] - t0) * 0.01);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
 }
 
 // after failed(): which conditions the last run met (bit r = reason r of vb_fail)

@@ -3,9 +3,12 @@
 // The problem is small (<= 768 sharp + 1536 flat features against the previous sweep's <= ~60 k feature points) and
 // strictly iterative (<= 25 dependent Gauss-Newton steps), i.e. latency-bound.  Per group of 5 iterations, for all
 // streams of a batch at once:
-//   k_odom_corr    (:250-302, :368-435)  one thread per feature: transformToStart, exact 1-NN (5 m gate) in the previous cloud
-//                  through a uniform grid (3x3x3 block of cells, then expanding shells; replaces the kd-tree of :203-204 /
-//                  :662-663), then the +-2.5-ring windows as a second, predicated search of the same cells
+//   k_odom_corr    (:250-302, :368-435)  one wave per feature: transformToStart, exact 1-NN (5 m gate) in the previous cloud
+//                  through a uniform grid (3x3x3 block of cells with all lanes striding its nine runs, then — rarely — expanding
+//                  shells; replaces the kd-tree of :203-204 / :662-663), then the +-2.5-ring windows as a second, predicated
+//                  search of the same cells (LOAMX_ODOM_SCAN: the reference's point-by-point window loops instead)
+//                  (a one-thread-per-feature variant was built and measured: 2.6 ms per launch against ~50 us — every lane streaming
+//                  through its own cells defeats the memory pipeline; the wave-cooperative, coalesced walk stays)
 //   k_odom_lm      (:304-361, :437-481, :497-622)  one PERSISTENT workgroup per stream runs the 5 iterations without a
 //                  kernel boundary: thread per feature point-to-line / point-to-plane coefficients and Jacobian row with
 //                  the de-skew chain rule, J^T J / J^T r reduced with wave shuffles (double accumulators), thread 0:
@@ -43,201 +46,455 @@ __device__ inline float sqd(const float4& a, float x, float y, float z) {
   return dx * dx + dy * dy + dz * dz;
 }
 
-// ----------------------------------------------------------------------------------------------------------------
-// Correspondences (phases A+B of the reference's loop body): ONE THREAD per feature.
-//
-// The searches are small — a few hundred candidate points per feature once they go through the grid — and there are ~18 k
-// features per launch: a wave per feature (the first two rounds' design) spent most of its time in per-wave overhead (64 lanes
-// de-skewing the same point, cross-lane arg-min reductions, row-by-row latencies) and, above all, occupied 18 k wave slots per
-// launch on a device whose other two chains need them.  One lane per feature keeps everything in registers, needs ~300 waves per
-// launch, and every lane walks its own candidate runs with four independent loads in flight.
-//
-//   closest    exact nearest neighbour (d2 < 25, ties to the lowest position) in the previous cloud: first the 3x3x3 block of grid
-//              cells around the query (9 runs of the cell-sorted array; it holds every point within one cell edge h of the query, so
-//              an answer nearer than h is final), then — rarely — further shells of cells until the covered radius reaches the best
-//              distance or 5 m.
-//   windows    the +-2.5-ring windows of BasicLaserOdometry.cpp:262-297 (corner: the nearest point on ANOTHER ring) and :378-429
-//              (surf: the nearest on the SAME ring and the nearest on another ring).  In a ring-ordered cloud the two loops visit
-//              exactly the positions [ring_first[cscan - 2], closest) and (closest, min(ring_first[cscan + 3], bound)) — bound = the
-//              reference's forward limit, the CURRENT feature count — so the result is the arg-min of (distance, visiting order) over
-//              the points of that index range that pass the loops' ring tests: a nearest-neighbour query with a predicate, answered by
-//              the same block-then-shells search (a window holds ~3000 points, the cells that decide the query a few dozen).  Ties fall
-//              to the earlier position in visiting order (forward positions ascending, then backward positions descending), as in the
-//              sequential loops.  A cloud that is not ring-ordered (or has ring ids outside [0, 255]) takes the loops themselves.
-// ----------------------------------------------------------------------------------------------------------------
-struct CorrQuery {
-  float x, y, z;          // the de-skewed feature
-  bool corner;
-  int closest, cscan, wlo, whi;
-  // running minima: nearest (d1, id1) / window classes (d2, j2, o2), (d3, j3, o3)
-  float d1; uint32_t id1;
-  float d2, d3; int j2, j3, o2, o3;
-};
-// one candidate of the cell-sorted array, nearest-neighbour phase
-__device__ __forceinline__ void corr_visit_nn(CorrQuery& Q, const float4 p) {
-  const float dx = Q.x - p.x, dy = Q.y - p.y, dz = Q.z - p.z;
-  const float d = dx * dx + dy * dy + dz * dz;
-  const uint32_t id = __float_as_uint(p.w) & 0xffffffu;   // (the high byte carries the scan ring)
-  if (d < Q.d1 || (d == Q.d1 && Q.id1 != 0xffffffffu && id < Q.id1)) { Q.d1 = d; Q.id1 = id; }   // (d == 25 is never admitted)
-}
-// one candidate, window phase (the loops' ring tests :265-278, :283-296 / :381-402, :407-428)
-__device__ __forceinline__ void corr_visit_win(CorrQuery& Q, const float4 p) {
-  const uint32_t wb = __float_as_uint(p.w);
-  const int j = (int)(wb & 0xffffffu), ring = (int)(wb >> 24);
-  const bool fwd = j > Q.closest;
-  if (j == Q.closest || (fwd ? j >= Q.whi : j < Q.wlo)) return;
-  const float dx = p.x - Q.x, dy = p.y - Q.y, dz = p.z - Q.z;
-  const float d = dx * dx + dy * dy + dz * dz;
-  const int order = fwd ? j - (Q.closest + 1) : 0x40000000 + (Q.closest - 1 - j);
-  const bool other = fwd ? ring > Q.cscan : ring < Q.cscan;
-  if (Q.corner ? other : !other) {   // corner: a point of another ring; surf: a point of the closest point's own ring
-    if (d < Q.d2 || (d == Q.d2 && Q.j2 >= 0 && order < Q.o2)) { Q.d2 = d; Q.j2 = j; Q.o2 = order; }
-  } else if (!Q.corner) {            // surf: a point of another ring
-    if (d < Q.d3 || (d == Q.d3 && Q.j3 >= 0 && order < Q.o3)) { Q.d3 = d; Q.j3 = j; Q.o3 = order; }
-  }
-}
-template <bool WIN>
-__device__ __forceinline__ void corr_run(CorrQuery& Q, const float4* __restrict__ sorted, uint32_t beg, uint32_t end) {
-  uint32_t k = beg;
-  for (; k + 4 <= end; k += 4) {   // four independent loads in flight
-    const float4 p0 = sorted[k], p1 = sorted[k + 1], p2 = sorted[k + 2], p3 = sorted[k + 3];
-    if (WIN) { corr_visit_win(Q, p0); corr_visit_win(Q, p1); corr_visit_win(Q, p2); corr_visit_win(Q, p3); }
-    else { corr_visit_nn(Q, p0); corr_visit_nn(Q, p1); corr_visit_nn(Q, p2); corr_visit_nn(Q, p3); }
-  }
-  for (; k < end; k++) {
-    const float4 p = sorted[k];
-    if (WIN) corr_visit_win(Q, p); else corr_visit_nn(Q, p);
-  }
-}
-// radius (squared) that still matters to the phase: the worst of its unfinished minima
-template <bool WIN>
-__device__ __forceinline__ float corr_radius2(const CorrQuery& Q) {
-  if (!WIN) return Q.d1;
-  return Q.corner ? Q.d2 : (Q.d2 > Q.d3 ? Q.d2 : Q.d3);
-}
-// the search of one phase: block of 27 cells, then shells L = 2, 3, ... while the covered radius L * h is short of the radius that matters
-template <bool WIN>
-__device__ __forceinline__ void corr_search(CorrQuery& Q, const GridDesc& g, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start) {
-  const float h = 1.0f / g.inv_h;
-  const float fx = (Q.x - g.ox) * g.inv_h, fy = (Q.y - g.oy) * g.inv_h, fz = (Q.z - g.oz) * g.inv_h;
-  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-  // a query more than a few cells outside the grid has no point within 5 m (and the casts below stay in range)
-  const float reach = 5.0f * g.inv_h + 2.0f;
-  if (!(flx >= -reach && flx <= (float)g.nx + reach && fly >= -reach && fly <= (float)g.ny + reach && flz >= -reach && flz <= (float)g.nz + reach)) return;
-  const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
-  {   // ---- the 3x3x3 block: 9 rows of up to three x-adjacent cells = 9 contiguous runs; their 18 boundaries are fetched together
-    uint32_t rb[9], re[9];
-    int xa = cx - 1, xb = cx + 1;
-    if (xa < 0) xa = 0;
-    if (xb > g.nx - 1) xb = g.nx - 1;
+// wave-level arg-min of (d, order); every lane gets the winner
+__device__ inline void wave_argmin(float& d, int& j, int& order) {
 #pragma unroll
-    for (int r = 0; r < 9; r++) {
-      const int z = cz + r / 3 - 1, y = cy + r % 3 - 1;
-      rb[r] = re[r] = 0u;
-      if (z >= 0 && z < g.nz && y >= 0 && y < g.ny && xa <= xb) {
-        const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
-        rb[r] = cell_start[row + xa];
-        re[r] = cell_start[row + xb + 1];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 9; r++) corr_run<WIN>(Q, sorted, rb[r], re[r]);
-  }
-  // ---- further shells (rare): shell L adds the rows of the (2L+1)^2 square whose whole x-run is new (the square's border) and the
-  // two end cells of the inner rows.  Rows farther than the radius that matters are skipped (bounds shrunk by 1e-4 so rounding can
-  // only make the search visit more).
-  for (int L = 1;; L++) {
-    const float cover = (float)L * h, cover2 = cover * cover * 0.999f;
-    if (corr_radius2<WIN>(Q) <= cover2 || cover2 >= 25.0f) break;   // everything that could still improve the result lies inside the covered cube
-    const int M = L + 1;   // the shell to add
-    const float r2 = corr_radius2<WIN>(Q);
-    for (int dz = -M; dz <= M; dz++) {
-      const int z = cz + dz;
-      if (z < 0 || z >= g.nz) continue;
-      const float gz = dz == 0 ? 0.f : (dz > 0 ? ((float)z - fz) : (fz - (float)(z + 1))) * h;
-      for (int dy = -M; dy <= M; dy++) {
-        const int y = cy + dy;
-        if (y < 0 || y >= g.ny) continue;
-        const float gy = dy == 0 ? 0.f : (dy > 0 ? ((float)y - fy) : (fy - (float)(y + 1))) * h;
-        if ((gy * gy + gz * gz) * 0.9999f >= r2) continue;
-        const bool face = (dz == -M || dz == M || dy == -M || dy == M);
-        const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
-        if (face) {
-          int xa = cx - M, xb = cx + M;
-          if (xa < 0) xa = 0;
-          if (xb > g.nx - 1) xb = g.nx - 1;
-          if (xa <= xb) corr_run<WIN>(Q, sorted, cell_start[row + xa], cell_start[row + xb + 1]);
-        } else {
-          const int x0 = cx - M, x1 = cx + M;
-          if (x0 >= 0 && x0 <= g.nx - 1) corr_run<WIN>(Q, sorted, cell_start[row + x0], cell_start[row + x0 + 1]);
-          if (x1 >= 0 && x1 <= g.nx - 1) corr_run<WIN>(Q, sorted, cell_start[row + x1], cell_start[row + x1 + 1]);
-        }
-      }
-    }
+  for (int off = 32; off > 0; off >>= 1) {
+    const float od = __shfl_xor(d, off, 64);
+    const int oj = __shfl_xor(j, off, 64);
+    const int oo = __shfl_xor(order, off, 64);
+    if (od < d || (od == d && oo < order)) { d = od; j = oj; order = oo; }
   }
 }
 
-// grid = (ceil(max features / 256), streams), 256 threads
+// exact nearest neighbour (d2 < 25) searched by a WHOLE WAVE.  Per shell of grid cells: every lane first fetches the
+// cell range of "its" (y,z) row (all cell_start loads of the shell are in flight together), then the rows are walked
+// with the lanes striding over each row's contiguous candidate run; after every shell the lane minima are combined so
+// that pruning and termination stay wave-uniform.  A row is skipped when its (y,z) slab is already farther than the
+// best distance, and its x-run is clipped to the cells the best-distance ball can reach (bounds shrunk by a relative
+// 1e-4 so float rounding can only make the search visit MORE cells, never fewer).
+__device__ inline int nn1_wave(const GridDesc& g, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, float qx,
+                               float qy, float qz, int lane) {
+  float best = 25.0f;           // wave-uniform bound (only candidates with d2 < 25 are admissible)
+  float lbest = 25.0f;          // this lane's best
+  uint32_t lid = 0xffffffffu;
+  int best_id = -1;
+  const float h = 1.0f / g.inv_h;
+  const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+  for (int L = 0;; L++) {
+    const int side = 2 * L + 1, nrows = side * side;
+    for (int r0 = 0; r0 < nrows; r0 += 64) {
+      // ---- lane r: ranges of row r0 + lane
+      uint32_t b0 = 0, e0 = 0, b1 = 0, e1 = 0;
+      {
+        const int rr = r0 + lane;
+        if (rr < nrows) {
+          const int dz = rr / side - L, dy = rr % side - L;
+          const int z = cz + dz, y = cy + dy;
+          if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+            const float gz = dz == 0 ? 0.f : (dz > 0 ? ((float)z - fz) : (fz - (float)(z + 1))) * h;
+            const float gy = dy == 0 ? 0.f : (dy > 0 ? ((float)y - fy) : (fy - (float)(y + 1))) * h;
+            const float gyz = (gy * gy + gz * gz) * 0.9999f;
+            if (gyz < best) {
+              const float rx = sqrtf(best - gyz) * g.inv_h * 1.0001f + 1e-3f;
+              const int xlo = (int)floorf(fx - rx), xhi = (int)floorf(fx + rx);
+              const bool face = (dz == -L || dz == L || dy == -L || dy == L);
+              const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
+              // on a face row the whole x-run [cx-L, cx+L] is new; otherwise only its two end cells
+              int xa = cx - L, xb = face ? cx + L : cx - L;
+              if (xa < xlo) xa = xlo;
+              if (xb > xhi) xb = xhi;
+              if (xa < 0) xa = 0;
+              if (xb > g.nx - 1) xb = g.nx - 1;
+              if (xa <= xb) { b0 = cell_start[row + xa]; e0 = cell_start[row + xb + 1]; }
+              if (!face && L > 0) {
+                const int xc = cx + L;
+                if (xc >= xlo && xc <= xhi && xc >= 0 && xc <= g.nx - 1) { b1 = cell_start[row + xc]; e1 = cell_start[row + xc + 1]; }
+              }
+            }
+          }
+        }
+      }
+      // ---- walk the non-empty runs
+      unsigned long long todo = __ballot(e0 > b0 || e1 > b1);
+      while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t rb0 = __shfl(b0, src, 64), re0 = __shfl(e0, src, 64), rb1 = __shfl(b1, src, 64), re1 = __shfl(e1, src, 64);
+        for (int part = 0; part < 2; part++) {
+          const uint32_t beg = part ? rb1 : rb0, end = part ? re1 : re0;
+          for (uint32_t k = beg + lane; k < end; k += 64) {
+            const float4 p = sorted[k];
+            const float dx = qx - p.x, dy2 = qy - p.y, dz2 = qz - p.z;
+            const float d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
+            const uint32_t id = __float_as_uint(p.w) & 0xffffffu;   // (the high byte carries the scan ring)
+            if (d2 < lbest || (d2 == lbest && lid != 0xffffffffu && id < lid)) { lbest = d2; lid = id; }
+          }
+        }
+      }
+    }
+    // combine: smallest distance, ties to the lowest original index
+    float d = lbest;
+    int j = (int)lid, o_ = (int)lid;   // order key = original index (< 2^31)
+    if (lid == 0xffffffffu) { j = -1; o_ = 0x7fffffff; }
+    wave_argmin(d, j, o_);
+    if (j >= 0 && d < 25.0f) { best = d; best_id = j; }
+    const float cover = (float)L * h;
+    if (best <= cover * cover) break;
+    if (cover * cover >= 25.0f) break;
+  }
+  return best_id;
+}
+
+// The +-2.5-ring windows of BasicLaserOdometry.cpp:262-297 (corner: the nearest point on ANOTHER ring) and :378-429 (surf: the
+// nearest point on the SAME ring and the nearest on another ring) searched through the grid instead of point by point.  In a
+// ring-ordered cloud the two loops visit exactly the positions [ring_first[cscan - 2], closest) and (closest, min(ring_first[cscan + 3],
+// bound)) — bound = the reference's forward limit, the CURRENT feature count — so the result is the arg-min of (distance, visiting
+// order) over the points of that index range that pass the loops' ring tests: a nearest-neighbour query with a predicate, answered
+// exactly by the same shell search as nn1_wave (a window holds ~3000 points, the shells that decide the query ~200).  Both minima of
+// a surf feature are found in one traversal; a class is finished once its best distance lies inside the covered radius (or 5 m are
+// covered: the loops only accept d < 25).  Ties fall to the earlier position in visiting order (forward positions ascending, then
+// backward positions descending), as in the sequential loops.
+__device__ __forceinline__ void nn_window_wave(const GridDesc& g, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, float qx,
+                                              float qy, float qz, int lane, bool corner, int closest, int cscan, int wlo, int whi, int& j2, int& j3) {
+  float best2 = 25.0f, best3 = corner ? 0.0f : 25.0f;   // wave-uniform bounds
+  float l2 = 25.0f, l3 = 25.0f;                           // this lane's bests
+  int lj2 = -1, lj3 = -1, lo2 = 0x7fffffff, lo3 = 0x7fffffff;
+  j2 = -1; j3 = -1;
+  bool done2 = false, done3 = corner;
+  const float h = 1.0f / g.inv_h;
+  const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+  for (int L = 0;; L++) {
+    const float best = (done2 ? 0.f : best2) > (done3 ? 0.f : best3) ? (done2 ? 0.f : best2) : (done3 ? 0.f : best3);   // the radius that still matters
+    const int side = 2 * L + 1, nrows = side * side;
+    for (int r0 = 0; r0 < nrows; r0 += 64) {
+      uint32_t b0 = 0, e0 = 0, b1 = 0, e1 = 0;
+      {
+        const int rr = r0 + lane;
+        if (rr < nrows) {
+          const int dz = rr / side - L, dy = rr % side - L;
+          const int z = cz + dz, y = cy + dy;
+          if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+            const float gz = dz == 0 ? 0.f : (dz > 0 ? ((float)z - fz) : (fz - (float)(z + 1))) * h;
+            const float gy = dy == 0 ? 0.f : (dy > 0 ? ((float)y - fy) : (fy - (float)(y + 1))) * h;
+            const float gyz = (gy * gy + gz * gz) * 0.9999f;
+            if (gyz < best) {
+              const float rx = sqrtf(best - gyz) * g.inv_h * 1.0001f + 1e-3f;
+              const int xlo = (int)floorf(fx - rx), xhi = (int)floorf(fx + rx);
+              const bool face = (dz == -L || dz == L || dy == -L || dy == L);
+              const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
+              int xa = cx - L, xb = face ? cx + L : cx - L;
+              if (xa < xlo) xa = xlo;
+              if (xb > xhi) xb = xhi;
+              if (xa < 0) xa = 0;
+              if (xb > g.nx - 1) xb = g.nx - 1;
+              if (xa <= xb) { b0 = cell_start[row + xa]; e0 = cell_start[row + xb + 1]; }
+              if (!face && L > 0) {
+                const int xc = cx + L;
+                if (xc >= xlo && xc <= xhi && xc >= 0 && xc <= g.nx - 1) { b1 = cell_start[row + xc]; e1 = cell_start[row + xc + 1]; }
+              }
+            }
+          }
+        }
+      }
+      unsigned long long todo = __ballot(e0 > b0 || e1 > b1);
+      while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t rb0 = __shfl(b0, src, 64), re0 = __shfl(e0, src, 64), rb1 = __shfl(b1, src, 64), re1 = __shfl(e1, src, 64);
+        for (int part = 0; part < 2; part++) {
+          const uint32_t beg = part ? rb1 : rb0, end = part ? re1 : re0;
+          for (uint32_t k = beg + lane; k < end; k += 64) {
+            const float4 p = sorted[k];
+            const uint32_t wb = __float_as_uint(p.w);
+            const int j = (int)(wb & 0xffffffu), ring = (int)(wb >> 24);
+            const bool fwd = j > closest;
+            if (j == closest || (fwd ? j >= whi : j < wlo)) continue;
+            const float dx = p.x - qx, dy2 = p.y - qy, dz2 = p.z - qz;
+            const float d = dx * dx + dy2 * dy2 + dz2 * dz2;
+            const int order = fwd ? j - (closest + 1) : 0x40000000 + (closest - 1 - j);
+            // the loops' ring tests (:265-278, :283-296 / :381-402, :407-428)
+            const bool other = fwd ? ring > cscan : ring < cscan;
+            if (corner) {
+              if (other && (d < l2 || (d == l2 && lo2 != 0x7fffffff && order < lo2))) { l2 = d; lj2 = j; lo2 = order; }
+            } else if (other) {
+              if (d < l3 || (d == l3 && lo3 != 0x7fffffff && order < lo3)) { l3 = d; lj3 = j; lo3 = order; }
+            } else {
+              if (d < l2 || (d == l2 && lo2 != 0x7fffffff && order < lo2)) { l2 = d; lj2 = j; lo2 = order; }
+            }
+          }
+        }
+      }
+    }
+    const float cover = (float)L * h, cover2 = cover * cover;
+    if (!done2) {
+      float d = l2;
+      int j = lj2, o = lo2;
+      wave_argmin(d, j, o);
+      if (j >= 0 && d < 25.0f) { best2 = d; j2 = j; }
+      if (best2 <= cover2 || cover2 >= 25.0f) done2 = true;
+    }
+    if (!done3) {
+      float d = l3;
+      int j = lj3, o = lo3;
+      wave_argmin(d, j, o);
+      if (j >= 0 && d < 25.0f) { best3 = d; j3 = j; }
+      if (best3 <= cover2 || cover2 >= 25.0f) done3 = true;
+    }
+    if (done2 && done3) break;
+  }
+}
+
+// Fast path of both searches: the 3x3x3 block of cells around the query holds every point within one cell edge h of it, so whenever
+// the answer is nearer than h (almost always: h = 2.1 m) one pass over the block decides the query.  The block is 9 rows of up to
+// three x-adjacent cells = 9 contiguous runs of the cell-sorted array; their 18 boundaries are fetched by 9 lanes in one trip, then
+// ALL lanes stride the concatenated runs with four loads in flight each — the shell walk of nn1_wave / nn_window_wave visits row
+// after row, one memory latency per row, and is kept for the queries this pass cannot decide.
+// run k holds the candidates [E[k-1], E[k]); position in the sorted array = candidate number + O[k]; total = E[8];
+// cover2 = squared radius around the query that the block certainly contains (with a margin for rounding)
+__device__ __forceinline__ void block27_setup(const GridDesc& g, const uint32_t* __restrict__ cell_start, float qx, float qy, float qz, int lane,
+                                              uint32_t (&BO)[9], uint32_t (&BE)[9], float& cover2) {
+  const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+  uint32_t b = 0u, l = 0u;
+  // (a query far outside the grid has an empty block; the casts below then stay in range)
+  const bool near_grid = flx >= -2.f && flx <= (float)(g.nx + 1) && fly >= -2.f && fly <= (float)(g.ny + 1) && flz >= -2.f && flz <= (float)(g.nz + 1);
+  if (near_grid && lane < 9) {
+    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+    const int z = cz + lane / 3 - 1, y = cy + lane % 3 - 1;
+    int xa = cx - 1, xb = cx + 1;
+    if (xa < 0) xa = 0;
+    if (xb > g.nx - 1) xb = g.nx - 1;
+    if (z >= 0 && z < g.nz && y >= 0 && y < g.ny && xa <= xb) {
+      const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
+      b = cell_start[row + xa];
+      l = cell_start[row + xb + 1] - b;
+    }
+  }
+  uint32_t acc = 0u;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)b, k), lk = (uint32_t)__builtin_amdgcn_readlane((int)l, k);   // wave-uniform: scalar registers
+    BO[k] = bk - acc;
+    acc += lk;
+    BE[k] = acc;
+  }
+  const float h = 1.0f / g.inv_h;
+  cover2 = h * h * 0.999f;
+}
+__device__ __forceinline__ uint32_t block27_pos(const uint32_t (&BO)[9], const uint32_t (&BE)[9], uint32_t c) {
+  uint32_t o = BO[8];
+#pragma unroll
+  for (int k = 7; k >= 0; k--) o = c < BE[k] ? BO[k] : o;
+  return c + o;
+}
+// nearest point of the block (ties: lowest position in its cloud); returns its position or -1, d_out = its squared distance
+__device__ __forceinline__ int block27_nearest(const uint32_t (&BO)[9], const uint32_t (&BE)[9], const float4* __restrict__ sorted, float qx, float qy, float qz, int lane, float& d_out) {
+  float lbest = 25.0f;
+  uint32_t lid = 0xffffffffu;
+  const uint32_t total = BE[8];
+  for (uint32_t c0 = (uint32_t)lane; c0 < total; c0 += 256) {
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t c = c0 + 64u * (uint32_t)u;
+      p[u] = sorted[block27_pos(BO, BE, c < total ? c : c0)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (c0 + 64u * (uint32_t)u >= total) continue;
+      const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      const uint32_t id = __float_as_uint(p[u].w) & 0xffffffu;
+      if (d2 < lbest || (d2 == lbest && lid != 0xffffffffu && id < lid)) { lbest = d2; lid = id; }
+    }
+  }
+  float d = lbest;
+  int j = (int)lid, o_ = (int)lid;
+  if (lid == 0xffffffffu) { j = -1; o_ = 0x7fffffff; }
+  wave_argmin(d, j, o_);
+  d_out = d;
+  return (j >= 0 && d < 25.0f) ? j : -1;
+}
+// the window classes of nn_window_wave over the block; true when every class the feature needs is decided inside the covered radius
+__device__ __forceinline__ bool block27_window(const uint32_t (&BO)[9], const uint32_t (&BE)[9], float cover2, const float4* __restrict__ sorted, float qx, float qy,
+                                               float qz, int lane, bool corner, int closest, int cscan, int wlo, int whi, int& j2, int& j3) {
+  float l2 = 25.0f, l3 = 25.0f;
+  int lj2 = -1, lj3 = -1, lo2 = 0x7fffffff, lo3 = 0x7fffffff;
+  const uint32_t total = BE[8];
+  for (uint32_t c0 = (uint32_t)lane; c0 < total; c0 += 256) {
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t c = c0 + 64u * (uint32_t)u;
+      p[u] = sorted[block27_pos(BO, BE, c < total ? c : c0)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (c0 + 64u * (uint32_t)u >= total) continue;
+      const uint32_t wb = __float_as_uint(p[u].w);
+      const int j = (int)(wb & 0xffffffu), ring = (int)(wb >> 24);
+      const bool fwd = j > closest;
+      if (j == closest || (fwd ? j >= whi : j < wlo)) continue;
+      const float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
+      const float d = dx * dx + dy * dy + dz * dz;
+      const int order = fwd ? j - (closest + 1) : 0x40000000 + (closest - 1 - j);
+      const bool other = fwd ? ring > cscan : ring < cscan;
+      if (corner) {
+        if (other && (d < l2 || (d == l2 && lo2 != 0x7fffffff && order < lo2))) { l2 = d; lj2 = j; lo2 = order; }
+      } else if (other) {
+        if (d < l3 || (d == l3 && lo3 != 0x7fffffff && order < lo3)) { l3 = d; lj3 = j; lo3 = order; }
+      } else {
+        if (d < l2 || (d == l2 && lo2 != 0x7fffffff && order < lo2)) { l2 = d; lj2 = j; lo2 = order; }
+      }
+    }
+  }
+  wave_argmin(l2, lj2, lo2);
+  const bool ok2 = lj2 >= 0 && l2 <= cover2;
+  bool ok3 = true;
+  if (!corner) {
+    wave_argmin(l3, lj3, lo3);
+    ok3 = lj3 >= 0 && l3 <= cover2;
+  }
+  j2 = lj2; j3 = lj3;
+  return ok2 && ok3;
+}
+
+// ---- phases A+B: correspondences of one feature by one wave: exact 1-NN, then the ring-window scans;
+// grid = (ceil(maxFeat/4), streams), 256 threads
 __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ probs, OdomParams P) {
   OdomProblem& pb = probs[blockIdx.y];
   if (pb.done) return;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nSharp = (int)pb.n_sharp, nFlat = (int)pb.n_flat;
-  const int f = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (f >= nSharp + nFlat) return;
+  // XCD-aware order.  Workgroup b runs on XCD b % 8 (gridDim.x is a multiple of 8) and every XCD has a private L2.  Features
+  // are emitted ring after ring, so XCD x takes the x-th eighth of the sharp list and the x-th eighth of the flat list
+  // of every stream: its scan windows then cover a band of ~8+4 rings of the previous clouds instead of all 64, which
+  // fits its L2 for all streams at once (unordered, each L2 pulled every cloud from HBM: 8x the traffic).
+  int f;
+  {
+    const int x = (int)(blockIdx.x % 8), j = (int)(blockIdx.x / 8);
+    const int sS = (int)((long long)x * nSharp / 8), nS = (int)((long long)(x + 1) * nSharp / 8) - sS;
+    const int sF = (int)((long long)x * nFlat / 8), nF = (int)((long long)(x + 1) * nFlat / 8) - sF;
+    const int fl = 4 * j + wid;   // position in this XCD's list: its sharp features, then its flat features
+    if (fl >= nS + nF) return;
+    f = fl < nS ? sS + fl : nSharp + sF + (fl - nS);
+  }
   float T[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) T[k] = pb.transform[k];
-  CorrQuery Q;
-  Q.corner = f < nSharp;
-  const float4 pi = Q.corner ? pb.sharp[f] : pb.flat[f - nSharp];
-  transform_to_start(T, P.scan_period, pi, Q.x, Q.y, Q.z);
-  const GridDescB gd = Q.corner ? *pb.lc_desc : *pb.ls_desc;
-  const uint32_t* cell_start = pb.cell_table + gd.cell_base;
-  // ---- closest point (:250-258 / :368-376)
-  Q.d1 = 25.0f; Q.id1 = 0xffffffffu;
-  corr_search<false>(Q, gd.g, pb.sorted, cell_start);
-  if (Q.id1 == 0xffffffffu) {
-    pb.ind[5 * f] = -1; pb.ind[5 * f + 1] = -1; pb.ind[5 * f + 2] = -1;
+  const bool corner = f < nSharp;
+  const float4 pi = corner ? pb.sharp[f] : pb.flat[f - nSharp];
+  float x, y, z;
+  transform_to_start(T, P.scan_period, pi, x, y, z);
+  const GridDescB gd = corner ? *pb.lc_desc : *pb.ls_desc;
+  uint32_t BO[9], BE[9];
+  float cover2;
+  block27_setup(gd.g, pb.cell_table + gd.cell_base, x, y, z, lane, BO, BE, cover2);
+  float dnear;
+  int closest = block27_nearest(BO, BE, pb.sorted, x, y, z, lane, dnear);
+  if (!(closest >= 0 && dnear <= cover2)) closest = nn1_wave(gd.g, pb.sorted, pb.cell_table + gd.cell_base, x, y, z, lane);   // not decided inside the block (wave-uniform)
+  if (closest < 0) {   // wave-uniform
+    if (lane == 0) { pb.ind[5 * f] = -1; pb.ind[5 * f + 1] = -1; pb.ind[5 * f + 2] = -1; }
     return;
   }
-  const int closest = (int)Q.id1;
-  const float4* last = Q.corner ? pb.last_corner : pb.last_surf;
-  const int nLast = Q.corner ? (int)pb.n_last_corner : (int)pb.n_last_surf;
-  const int nCur = Q.corner ? nSharp : nFlat;
+  const float4* last = corner ? pb.last_corner : pb.last_surf;
+  const int nLast = corner ? (int)pb.n_last_corner : (int)pb.n_last_surf;
+  const int nCur = corner ? nSharp : nFlat;
   const int bound = nCur < nLast ? nCur : nLast;   // forward scans are bounded by the CURRENT feature count (:262, :378)
   const int cscan = (int)last[closest].w;
-  Q.closest = closest; Q.cscan = cscan;
-  Q.d2 = Q.d3 = 25.0f; Q.j2 = Q.j3 = -1; Q.o2 = Q.o3 = 0x7fffffff;
-  if (!P.window_scan && (Q.corner ? *pb.lc_flags : *pb.ls_flags) == 0u) {   // ring-ordered cloud: the windows are index ranges, searched through the grid
-    const uint32_t* rf = Q.corner ? pb.lc_ring_first : pb.ls_ring_first;
-    Q.wlo = (int)rf[cscan - 2 > 0 ? cscan - 2 : 0];
-    Q.whi = (int)rf[cscan + 3 < LX_RINGTAB - 1 ? cscan + 3 : LX_RINGTAB - 1];
-    if (Q.whi > bound) Q.whi = bound;
-    corr_search<true>(Q, gd.g, pb.sorted, cell_start);
-  } else {
-    // the reference's loops, point by point (any point order)
-    for (int j = closest + 1; j < bound; j++) {
-      const float4 q = last[j];
-      const int ring = (int)q.w;
-      if ((double)ring > (double)cscan + 2.5) break;
-      const float d = sqd(q, Q.x, Q.y, Q.z);
-      if (Q.corner) { if (ring > cscan && d < Q.d2) { Q.d2 = d; Q.j2 = j; } }
-      else if (ring <= cscan) { if (d < Q.d2) { Q.d2 = d; Q.j2 = j; } }
-      else { if (d < Q.d3) { Q.d3 = d; Q.j3 = j; } }
+  if (!P.window_scan && (corner ? *pb.lc_flags : *pb.ls_flags) == 0u) {   // ring-ordered cloud: the windows are index ranges, searched through the grid
+    const uint32_t* rf = corner ? pb.lc_ring_first : pb.ls_ring_first;
+    const int wlo = (int)rf[cscan - 2 > 0 ? cscan - 2 : 0];
+    int whi = (int)rf[cscan + 3 < LX_RINGTAB - 1 ? cscan + 3 : LX_RINGTAB - 1];
+    if (whi > bound) whi = bound;
+    int j2, j3;
+    if (!block27_window(BO, BE, cover2, pb.sorted, x, y, z, lane, corner, closest, cscan, wlo, whi, j2, j3))   // (wave-uniform)
+      nn_window_wave(gd.g, pb.sorted, pb.cell_table + gd.cell_base, x, y, z, lane, corner, closest, cscan, wlo, whi, j2, j3);
+    if (lane == 0) {
+      pb.ind[5 * f] = closest;
+      pb.ind[5 * f + 1] = j2;
+      pb.ind[5 * f + 2] = corner ? -1 : j3;
     }
-    for (int j = closest - 1; j >= 0; j--) {
-      const float4 q = last[j];
-      const int ring = (int)q.w;
-      if ((double)ring < (double)cscan - 2.5) break;
-      const float d = sqd(q, Q.x, Q.y, Q.z);
-      if (Q.corner) { if (ring < cscan && d < Q.d2) { Q.d2 = d; Q.j2 = j; } }
-      else if (ring >= cscan) { if (d < Q.d2) { Q.d2 = d; Q.j2 = j; } }
-      else { if (d < Q.d3) { Q.d3 = d; Q.j3 = j; } }
+    return;
+  }
+  float d2 = 25.f, d3 = 25.f;
+  int j2 = -1, j3 = -1, o2 = 0x7fffffff, o3 = 0x7fffffff;
+  // forward window (:262-279 / :378-403) and backward window (:280-297 / :404-429), walked TOGETHER: per trip 4 x 64 points of
+  // each direction are fetched (8 loads in flight per lane), then examined in scan order; a direction stops at its first point
+  // beyond +-2.5 rings.  (d, order) minima make the result independent of the interleaving: forward candidates order before
+  // backward ones, as in the reference's two consecutive loops.
+  auto better = [](float d, int order, float dbest, int obest) { return d < dbest || (d == dbest && obest != 0x7fffffff && order < obest); };   // scan order decides ties (never admits d == 25)
+  int baseF = closest + 1, baseB = closest - 1;
+  bool stopF = baseF >= bound, stopB = baseB < 0;
+  while (!stopF || !stopB) {
+    float4 qf[4], qb[4];
+    if (!stopF) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int j = baseF + 64 * u + lane;
+        qf[u] = j < bound ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (!stopB) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int j = baseB - 64 * u - lane;
+        qb[u] = j >= 0 ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (!stopF) {
+      bool stop = false;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (stop) continue;
+        const int j = baseF + 64 * u + lane;
+        const bool in = j < bound;
+        const int ring = (int)qf[u].w;
+        const bool brk = in && ((double)ring > (double)cscan + 2.5);
+        const unsigned long long mb = __ballot(brk);
+        const int fb = mb ? __builtin_ctzll(mb) : 64;
+        if (in && lane < fb) {
+          const float d = sqd(qf[u], x, y, z);
+          const int order = j - (closest + 1);
+          if (corner) {
+            if (ring > cscan && better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; }
+          } else {
+            if (ring <= cscan) { if (better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; } }
+            else { if (better(d, order, d3, o3)) { d3 = d; j3 = j; o3 = order; } }
+          }
+        }
+        if (mb) stop = true;
+      }
+      baseF += 256;
+      stopF = stop || baseF >= bound;
+    }
+    if (!stopB) {
+      bool stop = false;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (stop) continue;
+        const int j = baseB - 64 * u - lane;
+        const bool in = j >= 0;
+        const int ring = (int)qb[u].w;
+        const bool brk = in && ((double)ring < (double)cscan - 2.5);
+        const unsigned long long mb = __ballot(brk);
+        const int fb = mb ? __builtin_ctzll(mb) : 64;
+        if (in && lane < fb) {
+          const float d = sqd(qb[u], x, y, z);
+          const int order = 0x40000000 + (closest - 1 - j);   // backward candidates come after all forward ones
+          if (corner) {
+            if (ring < cscan && better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; }
+          } else {
+            if (ring >= cscan) { if (better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; } }
+            else { if (better(d, order, d3, o3)) { d3 = d; j3 = j; o3 = order; } }
+          }
+        }
+        if (mb) stop = true;
+      }
+      baseB -= 256;
+      stopB = stop || baseB < 0;
     }
   }
-  pb.ind[5 * f] = closest;
-  pb.ind[5 * f + 1] = Q.j2;
-  pb.ind[5 * f + 2] = Q.corner ? -1 : Q.j3;
+  wave_argmin(d2, j2, o2);
+  if (!corner) wave_argmin(d3, j3, o3);
+  if (lane == 0) {
+    pb.ind[5 * f] = closest;
+    pb.ind[5 * f + 1] = j2;
+    pb.ind[5 * f + 2] = corner ? -1 : j3;
+  }
 }
 
 // ---- phase C: iterations [iter0, iter0 + n_iters) of one stream in gridDim.x PERSISTENT workgroups (grid = NB x streams).
@@ -797,7 +1054,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
     if (max_feat) {
       for (int it0 = 0; it0 < params.max_iterations; it0 += 5) {
         const int nit = std::min(5, params.max_iterations - it0);
-        hipLaunchKernelGGL(k_odom_corr, dim3((max_feat + 255) / 256, na), dim3(256), 0, st_, prob_.p, params);
+        hipLaunchKernelGGL(k_odom_corr, dim3(8 * (((max_sharp + 7) / 8 + (max_flat + 7) / 8 + 3) / 4), na), dim3(256), 0, st_, prob_.p, params);
         const uint32_t nb = std::min<uint32_t>(16u, (max_feat + OD_THREADS - 1) / OD_THREADS);
         // k_odom_lm's workgroups of one stream spin on each other: everything a launch puts on the device must be resident
         // at once.  The launch is cut into chunks of streams that fill at most half of what the device can hold (occupancy x

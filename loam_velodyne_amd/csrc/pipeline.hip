@@ -119,6 +119,7 @@ class Pipeline {
   std::atomic<float> odom_ms{0.f};
   float feat_ms[3] = {0, 0, 0};
   int f_hi = -1;                       // features of steps <= f_hi have been launched (calling thread)
+  int ahead_depth = getenv("LOAMX_ODOM_AHEAD") ? atoi(getenv("LOAMX_ODOM_AHEAD")) : 2;   // steps the odometry chain may run ahead of the registration (diagnostic: 1)
   float last_ms[4] = {0, 0, 0, 0};
   bool timing = false;
 
@@ -558,7 +559,7 @@ class Pipeline {
     }
     bool f2_pending = prefetch && ti + 2 <= last_staged;
     auto launch_f2 = [&]() {
-      if (f2_pending) { f2_pending = false; launch_upto(ti + 2); allow_odometry(ti + 2); }
+      if (f2_pending) { f2_pending = false; launch_upto(ti + 2); if (ahead_depth >= 2) allow_odometry(ti + 2); }
     };
     int ret = LOAMX_SKIPPED;
     try {

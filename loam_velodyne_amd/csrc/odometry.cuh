@@ -10,7 +10,6 @@ struct OdomParams {
   float scan_period = 0.1f;
   int max_iterations = 25;
   float delta_t_abort = 0.1f, delta_r_abort = 0.1f;
-  int window_scan = 0;   // LOAMX_ODOM_SCAN: always walk the +-2.5-ring windows point by point (the reference's loops) instead of searching them through the grid
 };
 
 struct OdomStats {
@@ -29,10 +28,6 @@ struct OdomProblem {
   const uint32_t* cell_table;      // concatenated cell tables
   const GridDescB* lc_desc;        // grid over last_corner
   const GridDescB* ls_desc;        // grid over last_surf
-  const uint32_t* lc_ring_first;   // last_corner / last_surf: first position with ring >= r (SubMapIndexBatch::ring_first)
-  const uint32_t* ls_ring_first;
-  const uint32_t* lc_flags;        // 0: the cloud is ring-ordered with ring ids in [0, 255] (SubMapIndexBatch::flags)
-  const uint32_t* ls_flags;
   int* ind;            // 5 ints per feature: corner (ind1, ind2, -, -, -) / surf (ind1, ind2, ind3, -, -)
   float transform[6];  // in: initial _transform, out: optimised
   OdomStats stats;

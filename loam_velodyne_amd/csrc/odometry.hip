@@ -118,7 +118,7 @@ __device__ inline int nn1_wave(const GridDesc& g, const float4* __restrict__ sor
             const float4 p = sorted[k];
             const float dx = qx - p.x, dy2 = qy - p.y, dz2 = qz - p.z;
             const float d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
-            const uint32_t id = __float_as_uint(p.w) & 0xffffffu;   // (the high byte carries the scan ring)
+            const uint32_t id = __float_as_uint(p.w);
             if (d2 < lbest || (d2 == lbest && lid != 0xffffffffu && id < lid)) { lbest = d2; lid = id; }
           }
         }
@@ -135,221 +135,6 @@ __device__ inline int nn1_wave(const GridDesc& g, const float4* __restrict__ sor
     if (cover * cover >= 25.0f) break;
   }
   return best_id;
-}
-
-// The +-2.5-ring windows of BasicLaserOdometry.cpp:262-297 (corner: the nearest point on ANOTHER ring) and :378-429 (surf: the
-// nearest point on the SAME ring and the nearest on another ring) searched through the grid instead of point by point.  In a
-// ring-ordered cloud the two loops visit exactly the positions [ring_first[cscan - 2], closest) and (closest, min(ring_first[cscan + 3],
-// bound)) — bound = the reference's forward limit, the CURRENT feature count — so the result is the arg-min of (distance, visiting
-// order) over the points of that index range that pass the loops' ring tests: a nearest-neighbour query with a predicate, answered
-// exactly by the same shell search as nn1_wave (a window holds ~3000 points, the shells that decide the query ~200).  Both minima of
-// a surf feature are found in one traversal; a class is finished once its best distance lies inside the covered radius (or 5 m are
-// covered: the loops only accept d < 25).  Ties fall to the earlier position in visiting order (forward positions ascending, then
-// backward positions descending), as in the sequential loops.
-__device__ __forceinline__ void nn_window_wave(const GridDesc& g, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, float qx,
-                                              float qy, float qz, int lane, bool corner, int closest, int cscan, int wlo, int whi, int& j2, int& j3) {
-  float best2 = 25.0f, best3 = corner ? 0.0f : 25.0f;   // wave-uniform bounds
-  float l2 = 25.0f, l3 = 25.0f;                           // this lane's bests
-  int lj2 = -1, lj3 = -1, lo2 = 0x7fffffff, lo3 = 0x7fffffff;
-  j2 = -1; j3 = -1;
-  bool done2 = false, done3 = corner;
-  const float h = 1.0f / g.inv_h;
-  const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
-  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
-  for (int L = 0;; L++) {
-    const float best = (done2 ? 0.f : best2) > (done3 ? 0.f : best3) ? (done2 ? 0.f : best2) : (done3 ? 0.f : best3);   // the radius that still matters
-    const int side = 2 * L + 1, nrows = side * side;
-    for (int r0 = 0; r0 < nrows; r0 += 64) {
-      uint32_t b0 = 0, e0 = 0, b1 = 0, e1 = 0;
-      {
-        const int rr = r0 + lane;
-        if (rr < nrows) {
-          const int dz = rr / side - L, dy = rr % side - L;
-          const int z = cz + dz, y = cy + dy;
-          if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
-            const float gz = dz == 0 ? 0.f : (dz > 0 ? ((float)z - fz) : (fz - (float)(z + 1))) * h;
-            const float gy = dy == 0 ? 0.f : (dy > 0 ? ((float)y - fy) : (fy - (float)(y + 1))) * h;
-            const float gyz = (gy * gy + gz * gz) * 0.9999f;
-            if (gyz < best) {
-              const float rx = sqrtf(best - gyz) * g.inv_h * 1.0001f + 1e-3f;
-              const int xlo = (int)floorf(fx - rx), xhi = (int)floorf(fx + rx);
-              const bool face = (dz == -L || dz == L || dy == -L || dy == L);
-              const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
-              int xa = cx - L, xb = face ? cx + L : cx - L;
-              if (xa < xlo) xa = xlo;
-              if (xb > xhi) xb = xhi;
-              if (xa < 0) xa = 0;
-              if (xb > g.nx - 1) xb = g.nx - 1;
-              if (xa <= xb) { b0 = cell_start[row + xa]; e0 = cell_start[row + xb + 1]; }
-              if (!face && L > 0) {
-                const int xc = cx + L;
-                if (xc >= xlo && xc <= xhi && xc >= 0 && xc <= g.nx - 1) { b1 = cell_start[row + xc]; e1 = cell_start[row + xc + 1]; }
-              }
-            }
-          }
-        }
-      }
-      unsigned long long todo = __ballot(e0 > b0 || e1 > b1);
-      while (todo) {
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const uint32_t rb0 = __shfl(b0, src, 64), re0 = __shfl(e0, src, 64), rb1 = __shfl(b1, src, 64), re1 = __shfl(e1, src, 64);
-        for (int part = 0; part < 2; part++) {
-          const uint32_t beg = part ? rb1 : rb0, end = part ? re1 : re0;
-          for (uint32_t k = beg + lane; k < end; k += 64) {
-            const float4 p = sorted[k];
-            const uint32_t wb = __float_as_uint(p.w);
-            const int j = (int)(wb & 0xffffffu), ring = (int)(wb >> 24);
-            const bool fwd = j > closest;
-            if (j == closest || (fwd ? j >= whi : j < wlo)) continue;
-            const float dx = p.x - qx, dy2 = p.y - qy, dz2 = p.z - qz;
-            const float d = dx * dx + dy2 * dy2 + dz2 * dz2;
-            const int order = fwd ? j - (closest + 1) : 0x40000000 + (closest - 1 - j);
-            // the loops' ring tests (:265-278, :283-296 / :381-402, :407-428)
-            const bool other = fwd ? ring > cscan : ring < cscan;
-            if (corner) {
-              if (other && (d < l2 || (d == l2 && lo2 != 0x7fffffff && order < lo2))) { l2 = d; lj2 = j; lo2 = order; }
-            } else if (other) {
-              if (d < l3 || (d == l3 && lo3 != 0x7fffffff && order < lo3)) { l3 = d; lj3 = j; lo3 = order; }
-            } else {
-              if (d < l2 || (d == l2 && lo2 != 0x7fffffff && order < lo2)) { l2 = d; lj2 = j; lo2 = order; }
-            }
-          }
-        }
-      }
-    }
-    const float cover = (float)L * h, cover2 = cover * cover;
-    if (!done2) {
-      float d = l2;
-      int j = lj2, o = lo2;
-      wave_argmin(d, j, o);
-      if (j >= 0 && d < 25.0f) { best2 = d; j2 = j; }
-      if (best2 <= cover2 || cover2 >= 25.0f) done2 = true;
-    }
-    if (!done3) {
-      float d = l3;
-      int j = lj3, o = lo3;
-      wave_argmin(d, j, o);
-      if (j >= 0 && d < 25.0f) { best3 = d; j3 = j; }
-      if (best3 <= cover2 || cover2 >= 25.0f) done3 = true;
-    }
-    if (done2 && done3) break;
-  }
-}
-
-// Fast path of both searches: the 3x3x3 block of cells around the query holds every point within one cell edge h of it, so whenever
-// the answer is nearer than h (almost always: h = 2.1 m) one pass over the block decides the query.  The block is 9 rows of up to
-// three x-adjacent cells = 9 contiguous runs of the cell-sorted array; their 18 boundaries are fetched by 9 lanes in one trip, then
-// ALL lanes stride the concatenated runs with four loads in flight each — the shell walk of nn1_wave / nn_window_wave visits row
-// after row, one memory latency per row, and is kept for the queries this pass cannot decide.
-// run k holds the candidates [E[k-1], E[k]); position in the sorted array = candidate number + O[k]; total = E[8];
-// cover2 = squared radius around the query that the block certainly contains (with a margin for rounding)
-__device__ __forceinline__ void block27_setup(const GridDesc& g, const uint32_t* __restrict__ cell_start, float qx, float qy, float qz, int lane,
-                                              uint32_t (&BO)[9], uint32_t (&BE)[9], float& cover2) {
-  const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
-  const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
-  uint32_t b = 0u, l = 0u;
-  // (a query far outside the grid has an empty block; the casts below then stay in range)
-  const bool near_grid = flx >= -2.f && flx <= (float)(g.nx + 1) && fly >= -2.f && fly <= (float)(g.ny + 1) && flz >= -2.f && flz <= (float)(g.nz + 1);
-  if (near_grid && lane < 9) {
-    const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
-    const int z = cz + lane / 3 - 1, y = cy + lane % 3 - 1;
-    int xa = cx - 1, xb = cx + 1;
-    if (xa < 0) xa = 0;
-    if (xb > g.nx - 1) xb = g.nx - 1;
-    if (z >= 0 && z < g.nz && y >= 0 && y < g.ny && xa <= xb) {
-      const uint32_t row = ((uint32_t)z * g.ny + y) * g.nx;
-      b = cell_start[row + xa];
-      l = cell_start[row + xb + 1] - b;
-    }
-  }
-  uint32_t acc = 0u;
-#pragma unroll
-  for (int k = 0; k < 9; k++) {
-    const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)b, k), lk = (uint32_t)__builtin_amdgcn_readlane((int)l, k);   // wave-uniform: scalar registers
-    BO[k] = bk - acc;
-    acc += lk;
-    BE[k] = acc;
-  }
-  const float h = 1.0f / g.inv_h;
-  cover2 = h * h * 0.999f;
-}
-__device__ __forceinline__ uint32_t block27_pos(const uint32_t (&BO)[9], const uint32_t (&BE)[9], uint32_t c) {
-  uint32_t o = BO[8];
-#pragma unroll
-  for (int k = 7; k >= 0; k--) o = c < BE[k] ? BO[k] : o;
-  return c + o;
-}
-// nearest point of the block (ties: lowest position in its cloud); returns its position or -1, d_out = its squared distance
-__device__ __forceinline__ int block27_nearest(const uint32_t (&BO)[9], const uint32_t (&BE)[9], const float4* __restrict__ sorted, float qx, float qy, float qz, int lane, float& d_out) {
-  float lbest = 25.0f;
-  uint32_t lid = 0xffffffffu;
-  const uint32_t total = BE[8];
-  for (uint32_t c0 = (uint32_t)lane; c0 < total; c0 += 256) {
-    float4 p[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const uint32_t c = c0 + 64u * (uint32_t)u;
-      p[u] = sorted[block27_pos(BO, BE, c < total ? c : c0)];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (c0 + 64u * (uint32_t)u >= total) continue;
-      const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
-      const float d2 = dx * dx + dy * dy + dz * dz;
-      const uint32_t id = __float_as_uint(p[u].w) & 0xffffffu;
-      if (d2 < lbest || (d2 == lbest && lid != 0xffffffffu && id < lid)) { lbest = d2; lid = id; }
-    }
-  }
-  float d = lbest;
-  int j = (int)lid, o_ = (int)lid;
-  if (lid == 0xffffffffu) { j = -1; o_ = 0x7fffffff; }
-  wave_argmin(d, j, o_);
-  d_out = d;
-  return (j >= 0 && d < 25.0f) ? j : -1;
-}
-// the window classes of nn_window_wave over the block; true when every class the feature needs is decided inside the covered radius
-__device__ __forceinline__ bool block27_window(const uint32_t (&BO)[9], const uint32_t (&BE)[9], float cover2, const float4* __restrict__ sorted, float qx, float qy,
-                                               float qz, int lane, bool corner, int closest, int cscan, int wlo, int whi, int& j2, int& j3) {
-  float l2 = 25.0f, l3 = 25.0f;
-  int lj2 = -1, lj3 = -1, lo2 = 0x7fffffff, lo3 = 0x7fffffff;
-  const uint32_t total = BE[8];
-  for (uint32_t c0 = (uint32_t)lane; c0 < total; c0 += 256) {
-    float4 p[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const uint32_t c = c0 + 64u * (uint32_t)u;
-      p[u] = sorted[block27_pos(BO, BE, c < total ? c : c0)];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (c0 + 64u * (uint32_t)u >= total) continue;
-      const uint32_t wb = __float_as_uint(p[u].w);
-      const int j = (int)(wb & 0xffffffu), ring = (int)(wb >> 24);
-      const bool fwd = j > closest;
-      if (j == closest || (fwd ? j >= whi : j < wlo)) continue;
-      const float dx = p[u].x - qx, dy = p[u].y - qy, dz = p[u].z - qz;
-      const float d = dx * dx + dy * dy + dz * dz;
-      const int order = fwd ? j - (closest + 1) : 0x40000000 + (closest - 1 - j);
-      const bool other = fwd ? ring > cscan : ring < cscan;
-      if (corner) {
-        if (other && (d < l2 || (d == l2 && lo2 != 0x7fffffff && order < lo2))) { l2 = d; lj2 = j; lo2 = order; }
-      } else if (other) {
-        if (d < l3 || (d == l3 && lo3 != 0x7fffffff && order < lo3)) { l3 = d; lj3 = j; lo3 = order; }
-      } else {
-        if (d < l2 || (d == l2 && lo2 != 0x7fffffff && order < lo2)) { l2 = d; lj2 = j; lo2 = order; }
-      }
-    }
-  }
-  wave_argmin(l2, lj2, lo2);
-  const bool ok2 = lj2 >= 0 && l2 <= cover2;
-  bool ok3 = true;
-  if (!corner) {
-    wave_argmin(l3, lj3, lo3);
-    ok3 = lj3 >= 0 && l3 <= cover2;
-  }
-  j2 = lj2; j3 = lj3;
-  return ok2 && ok3;
 }
 
 // ---- phases A+B: correspondences of one feature by one wave: exact 1-NN, then the ring-window scans;
@@ -380,12 +165,7 @@ __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ pro
   float x, y, z;
   transform_to_start(T, P.scan_period, pi, x, y, z);
   const GridDescB gd = corner ? *pb.lc_desc : *pb.ls_desc;
-  uint32_t BO[9], BE[9];
-  float cover2;
-  block27_setup(gd.g, pb.cell_table + gd.cell_base, x, y, z, lane, BO, BE, cover2);
-  float dnear;
-  int closest = block27_nearest(BO, BE, pb.sorted, x, y, z, lane, dnear);
-  if (!(closest >= 0 && dnear <= cover2)) closest = nn1_wave(gd.g, pb.sorted, pb.cell_table + gd.cell_base, x, y, z, lane);   // not decided inside the block (wave-uniform)
+  const int closest = nn1_wave(gd.g, pb.sorted, pb.cell_table + gd.cell_base, x, y, z, lane);
   if (closest < 0) {   // wave-uniform
     if (lane == 0) { pb.ind[5 * f] = -1; pb.ind[5 * f + 1] = -1; pb.ind[5 * f + 2] = -1; }
     return;
@@ -395,21 +175,6 @@ __global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ pro
   const int nCur = corner ? nSharp : nFlat;
   const int bound = nCur < nLast ? nCur : nLast;   // forward scans are bounded by the CURRENT feature count (:262, :378)
   const int cscan = (int)last[closest].w;
-  if (!P.window_scan && (corner ? *pb.lc_flags : *pb.ls_flags) == 0u) {   // ring-ordered cloud: the windows are index ranges, searched through the grid
-    const uint32_t* rf = corner ? pb.lc_ring_first : pb.ls_ring_first;
-    const int wlo = (int)rf[cscan - 2 > 0 ? cscan - 2 : 0];
-    int whi = (int)rf[cscan + 3 < LX_RINGTAB - 1 ? cscan + 3 : LX_RINGTAB - 1];
-    if (whi > bound) whi = bound;
-    int j2, j3;
-    if (!block27_window(BO, BE, cover2, pb.sorted, x, y, z, lane, corner, closest, cscan, wlo, whi, j2, j3))   // (wave-uniform)
-      nn_window_wave(gd.g, pb.sorted, pb.cell_table + gd.cell_base, x, y, z, lane, corner, closest, cscan, wlo, whi, j2, j3);
-    if (lane == 0) {
-      pb.ind[5 * f] = closest;
-      pb.ind[5 * f + 1] = j2;
-      pb.ind[5 * f + 2] = corner ? -1 : j3;
-    }
-    return;
-  }
   float d2 = 25.f, d3 = 25.f;
   int j2 = -1, j3 = -1, o2 = 0x7fffffff, o3 = 0x7fffffff;
   // forward window (:262-279 / :378-403) and backward window (:280-297 / :404-429), walked TOGETHER: per trip 4 x 64 points of
@@ -893,7 +658,6 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
   index_.cell_size = 2.1f;
   if (const char* e = getenv("LOAMX_ODOM_CELL")) { const float v = (float)atof(e); if (v >= 0.25f && v <= 16.f) index_.cell_size = v; }
   index_.init(st_);
-  params.window_scan = getenv("LOAMX_ODOM_SCAN") ? 1 : 0;
   prob_.reserve(n_streams);
   h_mirror_.reserve(n_streams);
   part_.reserve((size_t)n_streams * OD_PART_STRIDE);
@@ -1019,8 +783,6 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       pb.cell_table = index_.cell_table();
       pb.lc_desc = index_.desc(s);
       pb.ls_desc = index_.desc(ns + s);
-      pb.lc_ring_first = index_.ring_first(s); pb.ls_ring_first = index_.ring_first(ns + s);
-      pb.lc_flags = index_.flags(s); pb.ls_flags = index_.flags(ns + s);
       pb.ind = ind_.p + ind_off[s];
       S.transform.get(pb.transform);
       pb.stats = {0, 0, 0, 0};

@@ -19,7 +19,6 @@ struct GridDesc {
 
 constexpr uint32_t LX_MAX_CELLS = 16u * 1024 * 1024 - 2048;   // scan limit (scan.cuh)
 constexpr int LX_RES_THREADS = 256;
-constexpr int LX_RINGTAB = 258;   // SubMapIndexBatch: ring_first entries per cloud
 constexpr int LX_NSUM = 28;   // 21 upper-triangular AtA + 6 AtB + row count
 
 class SubMapIndex {
@@ -63,14 +62,11 @@ class SubMapIndexBatch {
   const uint32_t* cell_start(uint32_t c) const { return cell_start_.p; }   // tables are addressed through desc(c)->cell_base
   const GridDescB* desc(uint32_t c) const { return d_desc_.p + c; }
   const uint32_t* cell_table() const { return cell_start_.p; }
-  // .w of a sorted point: position inside its own cloud (low 24 bits) | scan ring = integer part of its intensity (high 8 bits)
-  const uint32_t* ring_first(uint32_t c) const { return ring_first_.p + (size_t)c * LX_RINGTAB; }   // [r] = first position with ring >= r, r = 0 .. 256
-  const uint32_t* flags(uint32_t c) const { return flags_.p + c; }   // 0: ring ids in [0, 255] and non-decreasing along the cloud
 
  private:
   hipStream_t st_ = nullptr;
   DevBuf<float4> sorted_;
-  DevBuf<uint32_t> cell_of_, cell_start_, cursor_, tile_sums_, scratch_, d_off_, enc_, ring_first_, flags_;
+  DevBuf<uint32_t> cell_of_, cell_start_, cursor_, tile_sums_, scratch_, d_off_, enc_;
   DevBuf<GridDescB> d_desc_;
   PinBuf<uint32_t> h_off_pin_;
 };

@@ -203,11 +203,10 @@ __global__ __launch_bounds__(256) void k_bb_bbox(const float4* __restrict__ pts,
 }
 // one thread: grid descriptors, per-cloud cell budget, table bases
 __global__ void k_bb_setup(const uint32_t* __restrict__ enc, const uint32_t* __restrict__ off, uint32_t K, GridDescB* __restrict__ desc,
-                           uint32_t* __restrict__ scratch, uint32_t max_cells_total, float cell0, uint32_t* __restrict__ flags) {
+                           uint32_t* __restrict__ scratch, uint32_t max_cells_total, float cell0) {
   const uint32_t budget = max_cells_total / (K ? K : 1);
   uint32_t base = 0;
   for (uint32_t c = 0; c < K; c++) {
-    flags[c] = 0u;   // (the clouds' ring flags: k_bb_count raises them; the previous index's were in use until this build)
     GridDescB d;
     d.pt_base = off[c];
     d.cell_base = base;
@@ -252,7 +251,7 @@ __device__ inline void wave_runs(uint32_t key, bool active, int& head_lane, int&
 
 __global__ __launch_bounds__(256) void k_bb_count(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off, uint32_t K,
                                                   const GridDescB* __restrict__ desc, uint32_t* __restrict__ cell_of,
-                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ ring_first, uint32_t* __restrict__ flags) {
+                                                  uint32_t* __restrict__ counts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
   uint32_t c = 0;
@@ -264,26 +263,6 @@ __global__ __launch_bounds__(256) void k_bb_count(const float4* __restrict__ pts
     }
     const GridDescB d = desc[lo];
     const float4 p = pts[i];
-    {
-      // scan rings of the cloud (integer part of the intensity, BasicLaserOdometry.cpp:258): ring_first[r] = first position whose
-      // ring is >= r — what the +-2.5-ring windows of the correspondence search need when the cloud is ring-ordered (it is, as the
-      // scan registration emits it).  flags: 1 = some ring id decreases along the cloud, 2 = a ring id outside [0, 255].
-      const uint32_t a0 = off[lo], a1 = off[lo + 1];
-      const bool okr = p.w >= 0.f && p.w < 256.f;
-      const int ring = okr ? (int)p.w : 0;
-      int prev = -1;
-      if (i > a0) {
-        const float pw = pts[i - 1].w;
-        prev = (pw >= 0.f && pw < 256.f) ? (int)pw : 0;
-      }
-      uint32_t fl = okr ? 0u : 2u;
-      if (prev > ring) fl |= 1u;
-      if (fl) atomicOr(&flags[lo], fl);
-      uint32_t* tab = ring_first + (size_t)lo * LX_RINGTAB;
-      for (int q = prev + 1; q <= ring; q++) tab[q] = i - a0;
-      if (i == a1 - 1)
-        for (int q = ring + 1; q < LX_RINGTAB; q++) tab[q] = a1 - a0;
-    }
     int cx, cy, cz;
     cell_coords(d.g, p.x, p.y, p.z, cx, cy, cz);
     c = d.cell_base + ((uint32_t)cz * d.g.ny + cy) * d.g.nx + cx;
@@ -316,9 +295,7 @@ __global__ __launch_bounds__(256) void k_bb_scatter(const float4* __restrict__ p
   if (active && head == (int)__lane_id()) base = atomicAdd(&cursor[c], (uint32_t)len);
   base = __shfl(base, head, 64);
   if (!active) return;
-  // position inside its own cloud (24 bits) | scan ring (8 bits; garbage-in when flags say the ring ids are unusable)
-  const uint32_t ring = (p.w >= 0.f && p.w < 256.f) ? (uint32_t)(int)p.w : 0u;
-  p.w = __uint_as_float((i - off[lo]) | (ring << 24));
+  p.w = __uint_as_float(i - off[lo]);   // index inside its own cloud
   sorted[base + ((int)__lane_id() - head)] = p;
 }
 
@@ -333,8 +310,6 @@ void SubMapIndexBatch::init(hipStream_t st) {
 void SubMapIndexBatch::prepare(uint32_t K) {
   LX_REQUIRE(K >= 1 && K <= 4096, "too many clouds in one index batch");
   enc_.reserve((size_t)6 * K + 6);
-  flags_.reserve(K + 1);
-  ring_first_.reserve((size_t)K * LX_RINGTAB);
   hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K);
 }
 
@@ -344,8 +319,6 @@ void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_
   d_off_.reserve(K + 2);
   d_desc_.reserve(K + 1);
   enc_.reserve((size_t)6 * K + 6);
-  flags_.reserve(K + 1);
-  ring_first_.reserve((size_t)K * LX_RINGTAB);
   const uint32_t* d_off = d_off_ready;   // the caller may already hold the offsets on the device
   if (!d_off) {
     h_off_pin_.reserve(K + 2);
@@ -360,12 +333,11 @@ void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_
   if (!prepared) hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K);
   uint32_t max_len = 0;
   for (uint32_t c = 0; c < K; c++) max_len = std::max(max_len, h_off[c + 1] - h_off[c]);
-  LX_REQUIRE(max_len < (1u << 24), "a cloud of an index batch is limited to 16 Mi points");
   const uint32_t nbx = std::min<uint32_t>(std::max<uint32_t>((max_len + 255) / 256, 1u), 32u);
   hipLaunchKernelGGL(k_bb_bbox, dim3(nbx, K), dim3(256), 0, st_, d_pts, d_off, enc_.p);
-  hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1), 0, st_, enc_.p, d_off, K, d_desc_.p, scratch_.p, LX_MAX_CELLS, cell_size, flags_.p);
+  hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1), 0, st_, enc_.p, d_off, K, d_desc_.p, scratch_.p, LX_MAX_CELLS, cell_size);
   hipLaunchKernelGGL(k_zero_u32_dn, dim3(2048), dim3(256), 0, st_, cursor_.p, scratch_.p + 0);
-  if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, d_desc_.p, cell_of_.p, cursor_.p, ring_first_.p, flags_.p);
+  if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, d_desc_.p, cell_of_.p, cursor_.p);
   exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 2, scratch_.p + 1, LX_MAX_CELLS, st_, cursor_.p);
   if (n) hipLaunchKernelGGL(k_bb_scatter, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, cell_of_.p, cursor_.p, sorted_.p);
   LX_HIP(hipGetLastError());

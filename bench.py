@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--handles", type=int, default=HANDLES_PER_GPU,
                     help="pipeline handles per GPU, each on its own HIP stream and host thread, sharing the streams evenly")
     ap.add_argument("--no-pcie", action="store_true", help="skip the second, PCIe-inclusive timed window")
+    ap.add_argument("--repeat", type=int, default=5, help="repeat the timed window this many times (fresh handles, same sweeps): value_median / value_min / value_max; `value` is the first window")
+    ap.add_argument("--ab", default=None, help="diagnostic: ';'-separated environment variants ('A=1 B=2;C=3;' — empty = defaults) timed inside this process before the contract's window, one line each on stderr")
     ap.add_argument("--mode", default="batched", choices=["batched", "live"],
                     help="live: sequential SLAM (BASELINE configs[1]: VLP-16, 200 k-pt live map, one sweep in flight, host clouds in / out)")
     args = ap.parse_args()
@@ -138,25 +140,8 @@ def main():
     H = max(1, min(args.handles, ns))
     assert ns % H == 0, "--streams must be a multiple of --handles"
     per = ns // H
-    torch.cuda.synchronize()
-    pipes = []
-    for h in range(H):
-        p = loamx.Pipeline(per, scanreg=dict(device=local_rank), odom=dict(device=local_rank), mapping=dict(device=local_rank))
-        p.set_frozen_device(map_t.data_ptr(), n_corner, map_t.data_ptr() + 16 * n_corner, n_surf)
-        for k in range(per):
-            p.set_state(k, aft=starts[h * per + k])
-        p.upload([[sweeps[t][h * per + k] for k in range(per)] for t in range(T)])
-        p.set_timing(True)
-        pipes.append(p)
-
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=H)
-
-    def run_step(t):
-        if H == 1:
-            pipes[0].step(t)
-        else:
-            list(pool.map(lambda p: p.step(t), pipes))   # ctypes releases the GIL: the handles really run concurrently
 
     def sync_all():
         torch.cuda.synchronize()
@@ -164,72 +149,116 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up (includes every stream's initialising first sweep)
-    for t in range(1 + W):
-        run_step(t)
-    sync_all()
-    stage = np.zeros(4)
-    res_ms = 0.0
-    res_launches = 0
-    q_iters_timed = 0   # query-iterations / queries of the sampled steps
-    queries_timed = 0
-    n_sampled = 0
-    in_step = 0.0       # wall time inside loamx_pipeline_step (the rest of the loop is this script)
-    # double-buffered map epochs (off by default): epoch k+1 is broadcast and indexed in the background during epoch k
-    # and swapped in before the first step of epoch k+1
     E = args.map_epoch_steps
-    map_nexts = [torch.empty_like(map_t), torch.empty_like(map_t)] if E > 0 else None   # ping-pong: a buffer is rewritten only
-    # after a registration against the index built from it has been observed complete
-    ev_map = torch.cuda.Event() if E > 0 else None
-    if E > 0:   # one untimed stage + swap so that the second set of index buffers exists before the timed region
-        for p in pipes:
-            p.stage_frozen_device(map_t.data_ptr(), n_corner, map_t.data_ptr() + 16 * n_corner, n_surf)
+
+    def resident_window(keep_open=False):
+        """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize, all sweeps resident in HBM."""
         torch.cuda.synchronize()
-        for p in pipes:
-            p.swap_frozen()
+        pipes = []
+        for h in range(H):
+            p = loamx.Pipeline(per, scanreg=dict(device=local_rank), odom=dict(device=local_rank), mapping=dict(device=local_rank))
+            p.set_frozen_device(map_t.data_ptr(), n_corner, map_t.data_ptr() + 16 * n_corner, n_surf)
+            for k in range(per):
+                p.set_state(k, aft=starts[h * per + k])
+            p.upload([[sweeps[t][h * per + k] for k in range(per)] for t in range(T)])
+            p.set_timing(True)
+            pipes.append(p)
+
+        def run_step(t):
+            if H == 1:
+                pipes[0].step(t)
+            else:
+                list(pool.map(lambda p: p.step(t), pipes))   # ctypes releases the GIL: the handles really run concurrently
+
+        # ---- warm-up (includes every stream's initialising first sweep)
+        for t in range(1 + W):
+            run_step(t)
         sync_all()
-    n_epochs = 0
-    t0 = time.perf_counter()
-    for t in range(1 + W, T):
-        if E > 0:
-            k = (t - (1 + W)) % E
-            if k == 0:
-                for p in pipes:
-                    if p.swap_frozen():
-                        n_epochs += 1
-                map_next = map_nexts[((t - (1 + W)) // E) % 2]
-                if rank == 0:
-                    map_next.copy_(map_t, non_blocking=True)   # (the next epoch's map: same content, new buffer)
-                if ldist is not None:   # native: the broadcast waits for the copy's event, the index build for the broadcast's
-                    ev_map.record()
-                    ev = ldist.broadcast_map(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, root=0, wait_event=ev_map.cuda_event)
+        r = dict(stage=np.zeros(4), res_ms=0.0, res_launches=0, q_iters=0, queries=0, n_sampled=0, in_step=0.0, n_epochs=0)
+        # double-buffered map epochs (off by default): epoch k+1 is broadcast and indexed in the background during epoch k
+        # and swapped in before the first step of epoch k+1
+        map_nexts = [torch.empty_like(map_t), torch.empty_like(map_t)] if E > 0 else None   # ping-pong: a buffer is rewritten only
+        # after a registration against the index built from it has been observed complete
+        ev_map = torch.cuda.Event() if E > 0 else None
+        if E > 0:   # one untimed stage + swap so that the second set of index buffers exists before the timed region
+            for p in pipes:
+                p.stage_frozen_device(map_t.data_ptr(), n_corner, map_t.data_ptr() + 16 * n_corner, n_surf)
+            torch.cuda.synchronize()
+            for p in pipes:
+                p.swap_frozen()
+            sync_all()
+        t0 = time.perf_counter()
+        for t in range(1 + W, T):
+            if E > 0:
+                k = (t - (1 + W)) % E
+                if k == 0:
+                    for p in pipes:
+                        if p.swap_frozen():
+                            r["n_epochs"] += 1
+                    map_next = map_nexts[((t - (1 + W)) // E) % 2]
+                    if rank == 0:
+                        map_next.copy_(map_t, non_blocking=True)   # (the next epoch's map: same content, new buffer)
+                    if ldist is not None:   # native: the broadcast waits for the copy's event, the index build for the broadcast's
+                        ev_map.record()
+                        ev = ldist.broadcast_map(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, root=0, wait_event=ev_map.cuda_event)
+                    else:
+                        if dist is not None:
+                            dist.broadcast(map_next, src=0, async_op=True).wait()   # orders torch's stream behind RCCL's, not the host
+                        ev_map.record()
+                        ev = ev_map.cuda_event
+                    for p in pipes:   # the index build waits for the event on the device; nothing blocks here
+                        p.stage_frozen_device(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, ev)
+            # HIP-event timing (stage chains + a pair around every Gauss-Newton launch) on every 4th step only: the event pairs and
+            # their read-back (event synchronise, a statistics download) cost ~4 % of a step
+            sampled = (t - (1 + W)) % TIMING_PERIOD == 0
+            for p in pipes:
+                p.set_timing(sampled)
+            tc0 = time.perf_counter()
+            run_step(t)
+            r["in_step"] += time.perf_counter() - tc0
+            if sampled:
+                r["n_sampled"] += 1
+                for p in pipes:   # event read-back of the step that just finished (the step itself is synchronous)
+                    tm = p.timing()
+                    r["stage"] += np.array([tm["features_ms"], tm["odometry_ms"], tm["registration_ms"], tm["step_ms"]]) / H
+                    r["res_ms"] += tm["residual_ms"]
+                    r["res_launches"] += tm["residual_launches"]
+                    r["q_iters"] += tm["query_iterations"]
+                    r["queries"] += tm["queries"]
+        sync_all()
+        r["elapsed"] = lxdist.max_over_ranks(time.perf_counter() - t0, dist, dev)
+        r["pipes"] = pipes
+        if not keep_open:
+            for p in pipes:
+                p.close()
+            r["pipes"] = None
+        return r
+
+    # ---- diagnostic: environment variants inside one process (same data, same box): --ab "A=1;B=2 C=3;"
+    if args.ab is not None and world == 1:
+        for v in args.ab.split(";"):
+            kv = dict(x.split("=", 1) for x in v.split()) if v.strip() else {}
+            saved = {k: os.environ.get(k) for k in kv}
+            os.environ.update(kv)
+            vals = []
+            for _ in range(max(args.repeat, 1)):
+                w_ = resident_window()
+                vals.append(world * ns * K / w_["elapsed"])
+            st_ = w_["stage"] / max(w_["n_sampled"], 1)
+            print(f"[ab] {v.strip() or 'defaults':48s} sweeps/s median {np.median(vals):9.1f} min {min(vals):9.1f} max {max(vals):9.1f}  F {st_[0]:.3f} O {st_[1]:.3f} M {st_[2]:.3f}  "
+                  f"gn {w_['res_ms'] / max(w_['res_launches'], 1) * 1e3:.1f} us x {w_['res_launches']}", file=sys.stderr, flush=True)
+            for k, o in saved.items():
+                if o is None:
+                    os.environ.pop(k, None)
                 else:
-                    if dist is not None:
-                        dist.broadcast(map_next, src=0, async_op=True).wait()   # orders torch's stream behind RCCL's, not the host
-                    ev_map.record()
-                    ev = ev_map.cuda_event
-                for p in pipes:   # the index build waits for the event on the device; nothing blocks here
-                    p.stage_frozen_device(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, ev)
-        # HIP-event timing (stage chains + a pair around every Gauss-Newton launch) on every 4th step only: the event pairs and
-        # their read-back (event synchronise, a statistics download) cost ~4 % of a step
-        sampled = (t - (1 + W)) % TIMING_PERIOD == 0
-        for p in pipes:
-            p.set_timing(sampled)
-        tc0 = time.perf_counter()
-        run_step(t)
-        in_step += time.perf_counter() - tc0
-        if sampled:
-            n_sampled += 1
-            for p in pipes:   # event read-back of the step that just finished (the step itself is synchronous)
-                tm = p.timing()
-                stage += np.array([tm["features_ms"], tm["odometry_ms"], tm["registration_ms"], tm["step_ms"]]) / H
-                res_ms += tm["residual_ms"]
-                res_launches += tm["residual_launches"]
-                q_iters_timed += tm["query_iterations"]
-                queries_timed += tm["queries"]
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    elapsed = lxdist.max_over_ranks(elapsed, dist, dev)
+                    os.environ[k] = o
+
+    # ---- the contract's window: W warm-up steps, then exactly K timed steps
+    win = resident_window(keep_open=True)
+    pipes = win["pipes"]
+    elapsed = win["elapsed"]
+    stage, res_ms, res_launches, q_iters_timed, queries_timed, n_sampled, in_step, n_epochs = (
+        win["stage"], win["res_ms"], win["res_launches"], win["q_iters"], win["queries"], win["n_sampled"], win["in_step"], win["n_epochs"])
 
     # pose sanity of this rank's streams against ground truth (not the parity check — that is tests/)
     stats = [p.get(k)[3] for p in pipes for k in range(per)]
@@ -240,6 +269,12 @@ def main():
         n_results = len(allp)
     sweeps_total = world * ns * K
     value = sweeps_total / elapsed
+    for p in pipes:   # free the window's HIP streams: beyond 8 streams per process the runtime aliases busy streams onto shared
+        p.close()     # hardware queues and they serialise (GPU_MAX_HW_QUEUES above)
+    # run-to-run spread: the same window (same sweeps, fresh handles) repeated; `value` stays the first window's
+    repeats = [value]
+    for _ in range(max(args.repeat, 1) - 1):
+        repeats.append(sweeps_total / resident_window()["elapsed"])
 
     # ---- the same K steps once more with the PCIe inside the timed region (SURVEY.md §8d "GPU timing"): every step's sweeps
     # are handed over from pinned host memory while earlier steps compute (loamx_pipeline_stage_step, three steps ahead) and
@@ -247,8 +282,6 @@ def main():
     # `value`: reported beside it.
     pcie = None
     if H == 1 and not args.no_pcie:
-        for p in pipes:   # free the resident run's HIP streams first: beyond 8 streams per process the runtime aliases busy streams onto
-            p.close()     # shared hardware queues and they serialise (GPU_MAX_HW_QUEUES above)
         try:
             pcie = pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps, starts, ns, W, K, dist, dev, lxdist)
         except Exception as e:   # the device-resident figure above is the contract; a failure here must not lose it
@@ -273,6 +306,10 @@ def main():
             "steps": K,
             "warmup": W,
             "ms_per_step": round(elapsed / K * 1e3, 4),
+            "value_median": round(float(np.median(repeats)), 2),
+            "value_min": round(float(min(repeats)), 2),
+            "value_max": round(float(max(repeats)), 2),
+            "value_repeats": len(repeats),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -134,7 +134,20 @@ struct TraceRange {
 // HIP stream with a relative priority: +1 = highest the device offers, 0 = default, -1 = lowest.  The stages of the
 // pipeline run on streams of their own; the latency-critical ones (registration, odometry) outrank feature extraction,
 // whose wide kernels would otherwise delay their short dependent launches.
-inline hipStream_t create_stream(int rel_priority) {
+// cu_stride > 1 (diagnostic, LOAMX_FEAT_CU_STRIDE): a stream whose kernels only run on every cu_stride-th compute unit
+inline hipStream_t create_stream(int rel_priority, int cu_stride = 0) {
+  if (cu_stride > 1) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    LX_HIP(hipGetDevice(&dev));
+    LX_HIP(hipGetDeviceProperties(&prop, dev));
+    const int ncu = prop.multiProcessorCount;
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int i = 0; i < ncu; i += cu_stride) mask[(size_t)i / 32] |= 1u << (i % 32);
+    hipStream_t st = nullptr;
+    LX_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    return st;
+  }
   int lo = 0, hi = 0;   // numerically lower = higher priority
   LX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
   const int prio = rel_priority > 0 ? hi : (rel_priority < 0 ? lo : (lo + hi) / 2);

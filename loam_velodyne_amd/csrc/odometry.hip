@@ -139,7 +139,12 @@ __device__ inline int nn1_wave(const GridDesc& g, const float4* __restrict__ sor
 
 // ---- phases A+B: correspondences of one feature by one wave: exact 1-NN, then the ring-window scans;
 // grid = (ceil(maxFeat/4), streams), 256 threads
-__global__ __launch_bounds__(256) void k_odom_corr(OdomProblem* __restrict__ probs, OdomParams P) {
+#ifdef OD_CORR_WAVES
+#define OD_CORR_ATTR __attribute__((amdgpu_waves_per_eu(OD_CORR_WAVES, OD_CORR_WAVES)))
+#else
+#define OD_CORR_ATTR
+#endif
+__global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr(OdomProblem* __restrict__ probs, OdomParams P) {
   OdomProblem& pb = probs[blockIdx.y];
   if (pb.done) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;

@@ -859,6 +859,11 @@ constexpr int GN_TILE = LX_RES_THREADS / KNN_LPQ;   // queries per workgroup
 #define GN_TS(k) do { } while (0)
 #endif
 
+// waves per SIMD the register allocation of k_gn_iter aims at: 6 = 80 VGPRs without scratch (the compiler's own choice is 83 = 5 waves);
+// with 16 KB of LDS per workgroup six to seven 4-wave workgroups share a CU
+#ifndef GN_WAVES
+#define GN_WAVES 6
+#endif
 #define GN_KERNEL k_gn_iter
 #define GN_JACOBI false
 #include "gn_iter_kernel.inc"

@@ -265,7 +265,7 @@ def main():
     n_results = ns
     if ldist is not None:   # every rank ends up with every stream's final pose (ncclAllGather of 8 x 4 B per stream)
         aft = np.stack([p.get(k)[2] for p in pipes for k in range(per)])
-        allp, _ = ldist.allgather_results(aft, np.array([[st["map_iterations"], st["mapped"]] for st in stats], np.int32))
+        allp, _, _ = ldist.allgather_results(aft, np.array([[st["map_iterations"], st["mapped"]] for st in stats], np.int32), batch=world * ns)
         n_results = len(allp)
     sweeps_total = world * ns * K
     value = sweeps_total / elapsed
@@ -334,6 +334,7 @@ def main():
                 "map_epoch_steps": E,
                 "map_epochs_swapped": n_epochs,
                 "results_gathered": n_results,
+                "rccl_ranks": (ldist.comm_count() if ldist is not None else 1),   # what the RCCL communicator itself reports (ncclCommCount)
                 "path_algorithmic_bytes_per_sweep": round(float(bytes_per_sweep), 1),
                 "path_hbm_frac": round(float(bytes_per_sweep * value / world / (HBM_PEAK_GBS * 1e9)), 6),
             },

@@ -64,7 +64,7 @@ const char* loamx_last_error(void);
 /* number of visible HIP devices (0 if none / HIP unavailable); never fails */
 int loamx_device_count(void);
 /* ABI version of this header */
-#define LOAMX_ABI_VERSION 2
+#define LOAMX_ABI_VERSION 3
 int loamx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -375,10 +375,23 @@ int loamx_dist_shard(const loamx_dist* h, uint32_t batch, uint32_t* begin, uint3
  * owned by the handle, recorded behind the broadcast — valid until the next broadcast on this handle. */
 int loamx_dist_broadcast_map(loamx_dist* h, void* d_corner_xyzi, uint32_t n_corner, void* d_surf_xyzi, uint32_t n_surf, int root,
                              void* wait_event, void** done_event);
-/* every rank contributes n_local records (poses6[n_local][6], iters_flags2[n_local][2], the latter may be NULL) and receives all
- * world_size * n_local of them in rank order; blocking */
+/* every rank contributes ITS n_local records (poses6[n_local][6], iters_flags2[n_local][2], the latter may be NULL; n_local may
+ * differ between ranks and may be 0 — the shards of loamx_dist_shard are unequal whenever the batch does not divide by the world
+ * size) and receives the records of all ranks concatenated in rank order (sum of the counts = the batch); counts_all (may be NULL)
+ * receives the world_size record counts.  Every rank must call it; blocking. */
 int loamx_dist_allgather_results(loamx_dist* h, const float* poses6, const int* iters_flags2, uint32_t n_local, float* poses6_all,
-                                 int* iters_flags2_all);
+                                 int* iters_flags2_all, uint32_t* counts_all);
+/* ranks the RCCL communicator itself reports (ncclCommCount); -1 on error */
+int loamx_dist_comm_count(loamx_dist* h);
+/* The host side of the two rules above without a device or a communicator (for a host that brings its own transport; the
+ * library's own all-gather uses exactly these): the shard of a rank; the padded send block of a rank (n_pad records of
+ * LOAMX_DIST_RECORD_FLOATS floats = 6 pose floats + iterations + flags as raw ints, zero beyond n_local); and the inverse for the
+ * gathered blocks recv8[world_size][n_pad][...] given every rank's record count. */
+#define LOAMX_DIST_RECORD_FLOATS 8
+int loamx_dist_shard_of(int rank, int world_size, uint32_t batch, uint32_t* begin, uint32_t* end);
+int loamx_dist_pack_results(const float* poses6, const int* iters_flags2, uint32_t n_local, uint32_t n_pad, float* send8);
+int loamx_dist_unpack_results(const float* recv8, const uint32_t* counts, int world_size, uint32_t n_pad, float* poses6_all,
+                              int* iters_flags2_all);
 int loamx_dist_barrier(loamx_dist* h);
 void* loamx_dist_stream(loamx_dist* h);   /* hipStream_t of the collectives */
 

@@ -7,7 +7,8 @@
 //                  returning an event; loamx_{batch,pipeline}_stage_frozen_device orders its index build behind that event
 //                  on the device, so the broadcast of epoch k+1 overlaps the registrations of epoch k (double buffering,
 //                  BASELINE configs[4])
-//   results        ncclAllGather of n_local x (6 pose floats + iterations + flags) per rank — a few hundred bytes
+//   results        two ncclAllGathers: the ranks' record counts (shards are unequal whenever the batch does not divide by the
+//                  world size), then ceil(B / G) records of (6 pose floats + iterations + flags) per rank, padded — a few hundred bytes
 // xGMI is point to point (7 links x ~153 GB/s per GPU): a ring broadcast of the 16-32 MB map is per-link bound
 // (~0.1-0.2 ms); it is issued as ONE collective per buffer (no bucketing needed at this size).
 // One process per GPU; the 128-byte ncclUniqueId travels between the processes by the host's own means (a file, MPI,
@@ -35,6 +36,8 @@ struct loamx_dist {
   hipEvent_t ev_bcast = nullptr;
   DevBuf<float> d_send, d_recv;
   PinBuf<float> h_send, h_recv;
+  DevBuf<uint32_t> d_cnt;
+  PinBuf<uint32_t> h_cnt;
   ~loamx_dist() {
     if (comm) (void)ncclCommDestroy(comm);
     if (ev_bcast) (void)hipEventDestroy(ev_bcast);
@@ -81,10 +84,7 @@ int loamx_dist_world_size(const loamx_dist* h) { return h ? h->world : 0; }
 int loamx_dist_shard(const loamx_dist* h, uint32_t batch, uint32_t* begin, uint32_t* end) {
   return guard([&]() {
     LX_REQUIRE(h && begin && end, "NULL argument");
-    // GPU g of G takes sweeps [g*B/G, (g+1)*B/G)  (SURVEY.md §8e "Partitioning")
-    *begin = (uint32_t)((uint64_t)h->rank * batch / (uint64_t)h->world);
-    *end = (uint32_t)((uint64_t)(h->rank + 1) * batch / (uint64_t)h->world);
-    return LOAMX_OK;
+    return loamx_dist_shard_of(h->rank, h->world, batch, begin, end);
   });
 }
 
@@ -106,30 +106,89 @@ int loamx_dist_broadcast_map(loamx_dist* h, void* d_corner_xyzi, uint32_t n_corn
   });
 }
 
-int loamx_dist_allgather_results(loamx_dist* h, const float* poses6, const int* iters_flags2, uint32_t n_local, float* poses6_all,
-                                 int* iters_flags2_all) {
+// ---- host-side record layout of the result exchange (no device, no communicator: a host with its own transport — MPI, a socket —
+// uses the same three functions; tests/test_dist_cpu.py drives them over gloo)
+int loamx_dist_shard_of(int rank, int world_size, uint32_t batch, uint32_t* begin, uint32_t* end) {
   return guard([&]() {
-    LX_REQUIRE(h && poses6 && poses6_all, "NULL argument");
+    LX_REQUIRE(begin && end && world_size >= 1 && rank >= 0 && rank < world_size, "invalid argument");
+    // GPU g of G takes sweeps [g*B/G, (g+1)*B/G)  (SURVEY.md §8e "Partitioning")
+    *begin = (uint32_t)((uint64_t)rank * batch / (uint64_t)world_size);
+    *end = (uint32_t)((uint64_t)(rank + 1) * batch / (uint64_t)world_size);
+    return LOAMX_OK;
+  });
+}
+int loamx_dist_pack_results(const float* poses6, const int* iters_flags2, uint32_t n_local, uint32_t n_pad, float* send8) {
+  return guard([&]() {
+    LX_REQUIRE((poses6 || !n_local) && send8 && n_local <= n_pad, "invalid argument");
+    for (uint32_t i = 0; i < n_pad; i++) {
+      float* r = send8 + (size_t)LOAMX_DIST_RECORD_FLOATS * i;
+      if (i < n_local) {
+        memcpy(r, poses6 + 6 * (size_t)i, 6 * sizeof(float));
+        const int tail[2] = {iters_flags2 ? iters_flags2[2 * (size_t)i] : 0, iters_flags2 ? iters_flags2[2 * (size_t)i + 1] : 0};
+        memcpy(r + 6, tail, sizeof(tail));
+      } else {
+        memset(r, 0, LOAMX_DIST_RECORD_FLOATS * sizeof(float));   // padding of a shorter shard
+      }
+    }
+    return LOAMX_OK;
+  });
+}
+int loamx_dist_unpack_results(const float* recv8, const uint32_t* counts, int world_size, uint32_t n_pad, float* poses6_all, int* iters_flags2_all) {
+  return guard([&]() {
+    LX_REQUIRE(recv8 && counts && poses6_all && world_size >= 1, "invalid argument");
+    size_t o = 0;
+    for (int r = 0; r < world_size; r++) {
+      LX_REQUIRE(counts[r] <= n_pad, "a rank's record count exceeds the padded size");
+      for (uint32_t i = 0; i < counts[r]; i++, o++) {
+        const float* rec = recv8 + (size_t)LOAMX_DIST_RECORD_FLOATS * ((size_t)r * n_pad + i);
+        memcpy(poses6_all + 6 * o, rec, 6 * sizeof(float));
+        if (iters_flags2_all) memcpy(iters_flags2_all + 2 * o, rec + 6, 2 * sizeof(int));
+      }
+    }
+    return LOAMX_OK;
+  });
+}
+
+int loamx_dist_allgather_results(loamx_dist* h, const float* poses6, const int* iters_flags2, uint32_t n_local, float* poses6_all,
+                                 int* iters_flags2_all, uint32_t* counts_all) {
+  return guard([&]() {
+    LX_REQUIRE(h && (poses6 || !n_local) && poses6_all, "NULL argument");
     LX_HIP(hipSetDevice(h->device));
     TraceRange trace_range("loamx:dist:allgather_results");
-    const size_t rec = 8, nl = (size_t)n_local * rec, na = nl * (size_t)h->world;   // 6 pose floats + iterations + flags
-    if (!nl) return (int)LOAMX_OK;
+    const int G = h->world;
+    // 1. every rank's record count (shards differ by one whenever the batch does not divide by the world size; a rank with an
+    //    empty shard still takes part in both collectives)
+    h->h_cnt.reserve((size_t)G + 1); h->d_cnt.reserve((size_t)G + 1);
+    h->h_cnt.p[G] = n_local;
+    LX_HIP(hipMemcpyAsync(h->d_cnt.p + G, h->h_cnt.p + G, sizeof(uint32_t), hipMemcpyHostToDevice, h->st));
+    LX_NCCL(ncclAllGather(h->d_cnt.p + G, h->d_cnt.p, 1, ncclUint32, h->comm, h->st));
+    LX_HIP(hipMemcpyAsync(h->h_cnt.p, h->d_cnt.p, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, h->st));
+    LX_HIP(hipStreamSynchronize(h->st));
+    uint32_t n_pad = 0;
+    for (int r = 0; r < G; r++) n_pad = std::max(n_pad, h->h_cnt.p[r]);
+    if (counts_all) memcpy(counts_all, h->h_cnt.p, sizeof(uint32_t) * G);
+    if (!n_pad) return (int)LOAMX_OK;   // (every rank sees the same counts: all of them leave here)
+    // 2. the records, padded to the longest shard
+    const size_t nl = (size_t)n_pad * LOAMX_DIST_RECORD_FLOATS, na = nl * (size_t)G;
     h->h_send.reserve(nl); h->h_recv.reserve(na); h->d_send.reserve(nl); h->d_recv.reserve(na);
-    for (uint32_t i = 0; i < n_local; i++) {
-      memcpy(h->h_send.p + rec * i, poses6 + 6 * i, 6 * sizeof(float));
-      int tail[2] = {iters_flags2 ? iters_flags2[2 * i] : 0, iters_flags2 ? iters_flags2[2 * i + 1] : 0};
-      memcpy(h->h_send.p + rec * i + 6, tail, sizeof(tail));
-    }
+    int rc = loamx_dist_pack_results(poses6, iters_flags2, n_local, n_pad, h->h_send.p);
+    if (rc != LOAMX_OK) return rc;
     LX_HIP(hipMemcpyAsync(h->d_send.p, h->h_send.p, nl * sizeof(float), hipMemcpyHostToDevice, h->st));
     LX_NCCL(ncclAllGather(h->d_send.p, h->d_recv.p, nl, ncclFloat, h->comm, h->st));
     LX_HIP(hipMemcpyAsync(h->h_recv.p, h->d_recv.p, na * sizeof(float), hipMemcpyDeviceToHost, h->st));
     LX_HIP(hipStreamSynchronize(h->st));
-    for (size_t i = 0; i < (size_t)n_local * h->world; i++) {
-      memcpy(poses6_all + 6 * i, h->h_recv.p + rec * i, 6 * sizeof(float));
-      if (iters_flags2_all) memcpy(iters_flags2_all + 2 * i, h->h_recv.p + rec * i + 6, 2 * sizeof(int));
-    }
-    return (int)LOAMX_OK;
+    return loamx_dist_unpack_results(h->h_recv.p, h->h_cnt.p, G, n_pad, poses6_all, iters_flags2_all);
   });
+}
+
+int loamx_dist_comm_count(loamx_dist* h) {   // ranks the RCCL communicator itself reports (a scaling run proves RCCL saw N ranks)
+  int n = -1;
+  guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    LX_NCCL(ncclCommCount(h->comm, &n));
+    return LOAMX_OK;
+  });
+  return n;
 }
 
 int loamx_dist_barrier(loamx_dist* h) {

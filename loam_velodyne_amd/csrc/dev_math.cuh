@@ -168,13 +168,16 @@ template <int M, int N> __device__ __forceinline__ void qr_solve(float (&A)[M][N
   int perm[N];
 #pragma unroll
   for (int c = 0; c < N; c++) perm[c] = c;
+  // (maxima as Eigen's visitor finds them: seeded with the first coefficient, replaced on `value > current` only — a NaN in front
+  // survives, the threshold becomes NaN, no pivot is declared negligible and a non-finite system gets a non-finite solution)
   float maxnorm = 0.f;
 #pragma unroll
   for (int c = 0; c < N; c++) {
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < M; r++) s += A[r][c] * A[r][c];
-    maxnorm = fmaxf(maxnorm, sqrtf(s));
+    const float nrm = sqrtf(s);
+    maxnorm = (c == 0 || nrm > maxnorm) ? nrm : maxnorm;
   }
   const float eps = FLT_EPSILON;
   const float thr_helper = (maxnorm * eps) * (maxnorm * eps) / float(M);
@@ -182,13 +185,13 @@ template <int M, int N> __device__ __forceinline__ void qr_solve(float (&A)[M][N
 #pragma unroll
   for (int k = 0; k < N; k++) {
     int best = k;
-    float bestn = -1.f;
+    float bestn = 0.f;
 #pragma unroll
     for (int c = k; c < N; c++) {
       float s = 0.f;
 #pragma unroll
       for (int r = k; r < M; r++) s += A[r][c] * A[r][c];
-      if (s > bestn) { bestn = s; best = c; }
+      if (c == k || s > bestn) { bestn = s; best = c; }
     }
     if (nonzero == N && bestn < thr_helper * float(M - k)) nonzero = k;
 #pragma unroll
@@ -440,9 +443,12 @@ __device__ __forceinline__ void qr_solve6_coop(const float* AtA, const float* At
 #pragma unroll
   for (int r = 0; r < 6; r++) s0 += a[r] * a[r];
   const float nrm = gl < 6 ? sqrtf(s0) : 0.f;
-  float maxnorm = 0.f;
+  float maxnorm = lane_get(nrm, 0);   // (seeded with the first, replaced on `>` only: Eigen's visitor, see qr_solve)
 #pragma unroll
-  for (int c = 0; c < 6; c++) maxnorm = fmaxf(maxnorm, lane_get(nrm, c));
+  for (int c = 1; c < 6; c++) {
+    const float v = lane_get(nrm, c);
+    maxnorm = v > maxnorm ? v : maxnorm;
+  }
   const float thr_helper = (maxnorm * FLT_EPSILON) * (maxnorm * FLT_EPSILON) / 6.0f;
   int nonzero = 6;
 #pragma unroll
@@ -452,9 +458,9 @@ __device__ __forceinline__ void qr_solve6_coop(const float* AtA, const float* At
 #pragma unroll
     for (int r = k; r < 6; r++) s += a[r] * a[r];
     int best = k;
-    float bestn = -1.f;
+    float bestn = lane_get(s, k);
 #pragma unroll
-    for (int c = k; c < 6; c++) {
+    for (int c = k + 1; c < 6; c++) {
       const float sc = lane_get(s, c);
       if (sc > bestn) { bestn = sc; best = c; }
     }

@@ -950,7 +950,10 @@ void FeatureExtractor::run_async() {
   LX_HIP(hipGetLastError());
 }
 
-void FeatureExtractor::sync() { LX_HIP(hipStreamSynchronize(st_)); }
+void FeatureExtractor::sync() {
+  LX_HIP(hipStreamSynchronize(st_));
+  vox_.check();   // a timed-out wait inside the long-ring fallback's voxel kernel raises instead of passing garbage on
+}
 
 int FeatureExtractor::download(uint32_t sweep, loamx_cloud* sharp, loamx_cloud* less_sharp, loamx_cloud* flat, loamx_cloud* less_flat) {
   LX_REQUIRE(sweep < nsw_, "sweep index out of range");
@@ -961,6 +964,7 @@ int FeatureExtractor::download(uint32_t sweep, loamx_cloud* sharp, loamx_cloud* 
     LX_HIP(hipMemcpyAsync(ho[k], out_off_[k].p, sizeof(uint32_t) * (nsw_ + 1), hipMemcpyDeviceToHost, st_));
   LX_HIP(hipMemcpyAsync(hlf, lf_off_.p, sizeof(uint32_t) * (nring_ + 1), hipMemcpyDeviceToHost, st_));
   LX_HIP(hipStreamSynchronize(st_));
+  vox_.check();
   int rc = LOAMX_OK;
   loamx_cloud* outs[3] = {sharp, less_sharp, flat};
   std::vector<float4> tmp;

@@ -470,6 +470,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   float pose6[6];
   int stats4[4];
   reg.sync();   // the histogram / counter copies above
+  for (int t = 0; t < 2; t++) tm[t].vox.check();   // (a timed-out wait inside the per-cube voxel kernel must not corrupt the map silently)
   reg.download(pose6, stats4);
   LX_HIP(hipGetLastError());
   for (int t = 0; t < 2; t++) {
@@ -531,6 +532,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
       uint32_t off[2] = {0, 0};
       LX_HIP(hipMemcpyAsync(off, sur_off.p + 2, sizeof(off), hipMemcpyDeviceToHost, st));
       LX_HIP(hipStreamSynchronize(st));
+      sur_vox.check();
       n_surround = off[1];
     } else {
       n_surround = 0;
@@ -641,6 +643,12 @@ void Mapper::load_snapshot(const char* path) {
   if (!ok) throw Error(LOAMX_E_INVALID, std::string(path) + " is not a loamx map snapshot (version 1) or is truncated");
   LX_REQUIRE(h.corner_leaf == cfg.corner_filter_size && h.surf_leaf == cfg.surf_filter_size,
              "the snapshot was written with other map filter sizes than this handle's");
+  // every point must lie inside the cube window stored with it — checked before anything of the handle changes
+  for (int t = 0; t < 2; t++)
+    for (const float4& q : pts[t]) {
+      const int I = cube_abs(q.x) + h.cen[0], J = cube_abs(q.y) + h.cen[1], K = cube_abs(q.z) + h.cen[2];
+      LX_REQUIRE(I >= 0 && I < MW && J >= 0 && J < MH && K >= 0 && K < MD, "snapshot points fall outside the cube window stored with them");
+    }
   LX_HIP(hipSetDevice(cfg.device));
   LX_HIP(hipStreamSynchronize(reg.stream()));
   for (int k = 0; k < 3; k++) cen[k] = h.cen[k];

@@ -69,7 +69,7 @@ class Pipeline {
   hipEvent_t ev_stage[RING] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_reg_done = nullptr, ev_d2h[2] = {nullptr, nullptr};
   bool d2h_pending[2] = {false, false};
-  uint32_t last_step = 0;
+  long last_step = -1;                                    // the last step that has run (-1: none yet)
   std::vector<uint32_t> last_full_off;                   // offsets of the registered clouds of the last step (k-th mapped stream)
   // Raw input (loamx_pipeline_stage_step_raw): per slot the payloads, their binned clouds and what the binning leaves behind
   struct RawSlot {
@@ -251,6 +251,7 @@ class Pipeline {
     fx.clear();
     streaming = false;
     staged_hi = 0;
+    last_step = -1;
     launched.assign(n_steps, 0);
     park_odometry(0);
     f_hi = -1;
@@ -294,6 +295,7 @@ class Pipeline {
       for (auto& e : ev_stage) if (!e) LX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
       streaming = true;
       staged_hi = 0;
+      last_step = -1;
       park_odometry(0);
       f_hi = -1;
     }
@@ -306,7 +308,7 @@ class Pipeline {
     LX_HIP(hipSetDevice(device));
     ensure_streaming_(t);
     LX_REQUIRE(t == staged_hi, "steps must be staged in order");
-    LX_REQUIRE(t < RING || last_step + RING > t, "stage_step(t) needs step(t - 4) to have run: only four steps can be in flight");
+    LX_REQUIRE(t < RING || last_step + (long)RING >= (long)t, "stage_step(t) needs step(t - 4) to have run: only four steps can be in flight");
     TraceRange trace_range("loamx:pipeline:stage_step");
     if (t > 0) finalize_raw(t - 1);
     rawslot[t % RING].raw = false;
@@ -329,7 +331,7 @@ class Pipeline {
     LX_HIP(hipSetDevice(device));
     ensure_streaming_(t);
     LX_REQUIRE(t == staged_hi, "steps must be staged in order");
-    LX_REQUIRE(t < RING || last_step + RING > t, "stage_step_raw(t) needs step(t - 4) to have run: only four steps can be in flight");
+    LX_REQUIRE(t < RING || last_step + (long)RING >= (long)t, "stage_step_raw(t) needs step(t - 4) to have run: only four steps can be in flight");
     TraceRange trace_range("loamx:pipeline:stage_step_raw");
     if (t > 0) finalize_raw(t - 1);   // the IMU state machine advances sweep by sweep: this step's table needs the previous reset
     const uint32_t ns = n_streams_, nr = mapper.n_scan_rings;
@@ -517,7 +519,7 @@ class Pipeline {
   int step(uint32_t t) {
     TraceRange trace_range("loamx:pipeline:step");
     LX_REQUIRE(t < n_staged(), "step index beyond the staged sweeps");
-    LX_REQUIRE(!streaming || t + RING > staged_hi, "this step's slot has been re-staged already");
+    LX_REQUIRE(!streaming || t + RING >= staged_hi, "this step's slot has been re-staged already");   // (slot t % RING is rewritten by staging step t + RING)
     tr0 = std::chrono::steady_clock::now();
     double trM[6] = {0, 0, 0, 0, 0, 0};
     LX_HIP(hipSetDevice(device));
@@ -644,7 +646,7 @@ class Pipeline {
       throw;
     }
     trM[3] = tr_us();
-    last_step = t;
+    last_step = (long)t;
     if (trace)
       fprintf(stderr, "[pipe t=%u] M-start %.0f  M-enqueued %.0f  M-downloaded %.0f  O-joined %.0f | O thread: start %.0f feat-ready %.0f process-done %.0f end %.0f\n", t,
               trM[0], trM[1], trM[2], trM[3], trO[0], trO[1], trO[2], trO[3]);

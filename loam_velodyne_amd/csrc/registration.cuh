@@ -66,7 +66,7 @@ class SubMapIndexBatch {
  private:
   hipStream_t st_ = nullptr;
   DevBuf<float4> sorted_;
-  DevBuf<uint32_t> cell_of_, cell_start_, cursor_, tile_sums_, scratch_, d_off_, enc_;
+  DevBuf<uint32_t> cell_of_, rank_of_, cell_start_, cursor_, tile_sums_, scratch_, d_off_, enc_;   // cursor_: the cell counters (empty between builds)
   DevBuf<GridDescB> d_desc_;
   PinBuf<uint32_t> h_off_pin_;
 };

@@ -201,37 +201,48 @@ __global__ __launch_bounds__(256) void k_bb_bbox(const float4* __restrict__ pts,
     if (a < 3) atomicMin(&enc[6 * c + a], enc_f32(v)); else atomicMax(&enc[6 * c + a], enc_f32(v));
   }
 }
-// one thread: grid descriptors, per-cloud cell budget, table bases
-__global__ void k_bb_setup(const uint32_t* __restrict__ enc, const uint32_t* __restrict__ off, uint32_t K, GridDescB* __restrict__ desc,
-                           uint32_t* __restrict__ scratch, uint32_t max_cells_total, float cell0) {
+// one thread per cloud (one workgroup, K <= 4096 in rounds of 1024): grid descriptors within the per-cloud cell budget, table bases by a scan
+__global__ __launch_bounds__(1024) void k_bb_setup(const uint32_t* __restrict__ enc, const uint32_t* __restrict__ off, uint32_t K, GridDescB* __restrict__ desc,
+                                                   uint32_t* __restrict__ scratch, uint32_t max_cells_total, float cell0) {
+  __shared__ uint32_t lds[17];
   const uint32_t budget = max_cells_total / (K ? K : 1);
-  uint32_t base = 0;
-  for (uint32_t c = 0; c < K; c++) {
+  uint32_t carry = 0;
+  for (uint32_t c0 = 0; c0 < K; c0 += 1024) {
+    const uint32_t c = c0 + threadIdx.x;
     GridDescB d;
-    d.pt_base = off[c];
-    d.cell_base = base;
-    if (off[c + 1] == off[c]) {   // empty cloud: a 1-cell grid
-      d.g.ox = d.g.oy = d.g.oz = 0.f; d.g.inv_h = 1.f; d.g.nx = d.g.ny = d.g.nz = 1; d.g.ncell = 1;
-    } else {
-      float mn[3], mx[3];
-      for (int a = 0; a < 3; a++) { mn[a] = dec_f32(enc[6 * c + a]); mx[a] = dec_f32(enc[6 * c + 3 + a]); }
-      float h = cell0;
-      for (;;) {
-        d.g.inv_h = 1.0f / h;
-        d.g.ox = mn[0]; d.g.oy = mn[1]; d.g.oz = mn[2];
-        d.g.nx = (int)floorf((mx[0] - mn[0]) * d.g.inv_h) + 1;
-        d.g.ny = (int)floorf((mx[1] - mn[1]) * d.g.inv_h) + 1;
-        d.g.nz = (int)floorf((mx[2] - mn[2]) * d.g.inv_h) + 1;
-        const unsigned long long nc = (unsigned long long)d.g.nx * d.g.ny * d.g.nz;
-        if (nc <= budget) { d.g.ncell = (uint32_t)nc; break; }
-        h *= 1.25f;
+    d.g.ox = d.g.oy = d.g.oz = 0.f; d.g.inv_h = 1.f; d.g.nx = d.g.ny = d.g.nz = 1; d.g.ncell = 0;
+    d.pt_base = 0; d.cell_base = 0;
+    if (c < K) {
+      d.pt_base = off[c];
+      d.g.ncell = 1;   // an empty cloud: a 1-cell grid
+      if (off[c + 1] != off[c]) {
+        float mn[3], mx[3];
+        for (int a = 0; a < 3; a++) { mn[a] = dec_f32(enc[6 * c + a]); mx[a] = dec_f32(enc[6 * c + 3 + a]); }
+        float h = cell0;
+        for (;;) {
+          d.g.inv_h = 1.0f / h;
+          d.g.ox = mn[0]; d.g.oy = mn[1]; d.g.oz = mn[2];
+          d.g.nx = (int)floorf((mx[0] - mn[0]) * d.g.inv_h) + 1;
+          d.g.ny = (int)floorf((mx[1] - mn[1]) * d.g.inv_h) + 1;
+          d.g.nz = (int)floorf((mx[2] - mn[2]) * d.g.inv_h) + 1;
+          const unsigned long long nc = (unsigned long long)d.g.nx * d.g.ny * d.g.nz;
+          if (nc <= budget) { d.g.ncell = (uint32_t)nc; break; }
+          h *= 1.25f;
+        }
       }
     }
-    desc[c] = d;
-    base += d.g.ncell;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(c < K ? d.g.ncell : 0u, lds, tot);
+    if (c < K) {
+      d.cell_base = carry + ex;
+      desc[c] = d;
+    }
+    carry += tot;
   }
-  scratch[0] = base + 1;
-  scratch[2] = base;
+  if (threadIdx.x == 0) {
+    scratch[0] = carry + 1;
+    scratch[2] = carry;
+  }
 }
 // Points arrive in scan order, so neighbouring lanes mostly fall into the same cell: one atomic per RUN of equal cells
 // in a wave instead of one per point (64 lanes hammering two or three counters serialise in L2).
@@ -251,7 +262,7 @@ __device__ inline void wave_runs(uint32_t key, bool active, int& head_lane, int&
 
 __global__ __launch_bounds__(256) void k_bb_count(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off, uint32_t K,
                                                   const GridDescB* __restrict__ desc, uint32_t* __restrict__ cell_of,
-                                                  uint32_t* __restrict__ counts) {
+                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ rank_of) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
   uint32_t c = 0;
@@ -268,35 +279,28 @@ __global__ __launch_bounds__(256) void k_bb_count(const float4* __restrict__ pts
     c = d.cell_base + ((uint32_t)cz * d.g.ny + cy) * d.g.nx + cx;
     cell_of[i] = c;
   }
+  // the counter's value before a run's bump is where the run's points go inside their cell: the scatter needs no atomics of its own
   int head, len;
   wave_runs(c, active, head, len);
-  if (active && head == (int)__lane_id()) atomicAdd(&counts[c], (uint32_t)len);
+  uint32_t base = 0;
+  if (active && head == (int)__lane_id()) base = atomicAdd(&counts[c], (uint32_t)len);
+  base = __shfl(base, head, 64);
+  if (active) rank_of[i] = base + (uint32_t)((int)__lane_id() - head);
 }
 
 __global__ __launch_bounds__(256) void k_bb_scatter(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off, uint32_t K,
-                                                    const uint32_t* __restrict__ cell_of, uint32_t* __restrict__ cursor,
-                                                    float4* __restrict__ sorted) {
+                                                    const uint32_t* __restrict__ cell_of, const uint32_t* __restrict__ rank_of,
+                                                    const uint32_t* __restrict__ cell_start, float4* __restrict__ sorted) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = i < n;
-  uint32_t c = 0, lo = 0;
-  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (active) {
-    uint32_t hi = K;
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (off[mid] <= i) lo = mid; else hi = mid;
-    }
-    p = pts[i];
-    c = cell_of[i];
+  if (i >= n) return;
+  uint32_t lo = 0, hi = K;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= i) lo = mid; else hi = mid;
   }
-  int head, len;
-  wave_runs(c, active, head, len);   // one cursor bump per run of equal cells (see k_bb_count)
-  uint32_t base = 0;
-  if (active && head == (int)__lane_id()) base = atomicAdd(&cursor[c], (uint32_t)len);
-  base = __shfl(base, head, 64);
-  if (!active) return;
+  float4 p = pts[i];
   p.w = __uint_as_float(i - off[lo]);   // index inside its own cloud
-  sorted[base + ((int)__lane_id() - head)] = p;
+  sorted[cell_start[cell_of[i]] + rank_of[i]] = p;
 }
 
 void SubMapIndexBatch::init(hipStream_t st) {
@@ -328,18 +332,22 @@ void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_
   }
   sorted_.reserve((size_t)n + 1);
   cell_of_.reserve((size_t)n + 1);
+  rank_of_.reserve((size_t)n + 1);
   cell_start_.reserve((size_t)LX_MAX_CELLS + 2);
-  cursor_.reserve((size_t)LX_MAX_CELLS + 2);
+  if (!cursor_.p) {   // the cell counters: cleared once, kept clear by every build
+    cursor_.reserve((size_t)LX_MAX_CELLS + 2);
+    LX_HIP(hipMemsetAsync(cursor_.p, 0, sizeof(uint32_t) * cursor_.cap, st_));
+  }
   if (!prepared) hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K);
   uint32_t max_len = 0;
   for (uint32_t c = 0; c < K; c++) max_len = std::max(max_len, h_off[c + 1] - h_off[c]);
   const uint32_t nbx = std::min<uint32_t>(std::max<uint32_t>((max_len + 255) / 256, 1u), 32u);
   hipLaunchKernelGGL(k_bb_bbox, dim3(nbx, K), dim3(256), 0, st_, d_pts, d_off, enc_.p);
-  hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1), 0, st_, enc_.p, d_off, K, d_desc_.p, scratch_.p, LX_MAX_CELLS, cell_size);
-  hipLaunchKernelGGL(k_zero_u32_dn, dim3(2048), dim3(256), 0, st_, cursor_.p, scratch_.p + 0);
-  if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, d_desc_.p, cell_of_.p, cursor_.p);
-  exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 2, scratch_.p + 1, LX_MAX_CELLS, st_, cursor_.p);
-  if (n) hipLaunchKernelGGL(k_bb_scatter, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, cell_of_.p, cursor_.p, sorted_.p);
+  hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1024), 0, st_, enc_.p, d_off, K, d_desc_.p, scratch_.p, LX_MAX_CELLS, cell_size);
+  if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, d_desc_.p, cell_of_.p, cursor_.p, rank_of_.p);
+  // (the cell counters are cleared behind the scan: they are empty again when the next build starts)
+  exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 2, scratch_.p + 1, LX_MAX_CELLS, st_, nullptr, cursor_.p);
+  if (n) hipLaunchKernelGGL(k_bb_scatter, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, cell_of_.p, rank_of_.p, cell_start_.p, sorted_.p);
   LX_HIP(hipGetLastError());
 }
 
@@ -561,15 +569,15 @@ __device__ __forceinline__ void solve_sweep(uint32_t s, const uint32_t* __restri
   if (tid < LX_SOLVE_GROUPS * LX_NSUM) {
     const uint32_t g = (uint32_t)tid / LX_NSUM, t = (uint32_t)tid % LX_NSUM;
     double x = 0.0;
-    for (uint32_t b0 = g; b0 < nact; b0 += 8 * LX_SOLVE_GROUPS) {   // 8 loads in flight, added in tile order
-      double v[8];
+    for (uint32_t b0 = g; b0 < nact; b0 += 16 * LX_SOLVE_GROUPS) {   // 16 loads in flight, added in tile order
+      double v[16];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < 16; u++) {
         const uint32_t b = b0 + u * LX_SOLVE_GROUPS;
         v[u] = b < nact ? partials[((size_t)s * nblk + b) * LX_NSUM + t] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 8; u++)
+      for (int u = 0; u < 16; u++)
         if (b0 + u * LX_SOLVE_GROUPS < nact) x += v[u];
     }
     gsum[g][t] = x;

@@ -42,7 +42,8 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* lds /* >= 17 */
 // host launcher.  max_n bounds the launch; the real count is *d_n (<= max_n).  out needs max_n+1 entries and receives
 // out[n] = total; in may alias out.  tile_sums needs 8192 entries.
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, const uint32_t* d_n, uint32_t* d_total,
-                        uint32_t max_n, hipStream_t st, uint32_t* out2 = nullptr);   // out2: optional second copy of the result
+                        uint32_t max_n, hipStream_t st, uint32_t* out2 = nullptr,   // out2: optional second copy of the result
+                        uint32_t* zero_in = nullptr);   // zero_in (= in, when in != out): the input is cleared behind the scan
 
 // same with a host-known element count; scratch2 = two device words
 void exclusive_scan_u32_n(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, uint32_t* scratch2, uint32_t n, hipStream_t st);

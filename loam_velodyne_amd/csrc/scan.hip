@@ -4,8 +4,8 @@
 namespace loamx {
 
 // in may alias out
-__global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                    uint32_t* __restrict__ tile_sums, const uint32_t* __restrict__ d_n) {
+__global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t* in, uint32_t* __restrict__ out,
+                                                    uint32_t* __restrict__ tile_sums, const uint32_t* __restrict__ d_n, uint32_t* zero_in) {
   __shared__ uint32_t lds[17];
   const uint32_t n = *d_n;
   const uint32_t base = blockIdx.x * SCAN_TILE;
@@ -14,6 +14,11 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t* __restrict__
   const uint32_t i0 = base + threadIdx.x * 8;
 #pragma unroll
   for (int k = 0; k < 8; k++) v[k] = (i0 + k < n) ? in[i0 + k] : 0u;
+  if (zero_in) {   // the input is a histogram that its producer wants back empty (only entries that hold something are written)
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (i0 + k < n && v[k]) zero_in[i0 + k] = 0u;
+  }
   uint32_t s = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) { uint32_t t = v[k]; v[k] = s; s += t; }
@@ -70,9 +75,9 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, co
 }
 
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums /* >= 8192 */, const uint32_t* d_n,
-                               uint32_t* d_total, uint32_t max_n, hipStream_t st, uint32_t* out2) {
+                               uint32_t* d_total, uint32_t max_n, hipStream_t st, uint32_t* out2, uint32_t* zero_in) {
   const uint32_t ntiles = (max_n + SCAN_TILE - 1) / SCAN_TILE;
-  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, st, in, out, tile_sums, d_n);
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, st, in, out, tile_sums, d_n, zero_in);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums, d_n, d_total);
   hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, st, out, tile_sums, d_n, d_total, out2);
 }

@@ -62,9 +62,22 @@ def main(argv=None):
         env = dict(os.environ, LOAMX_RANK=str(r), LOAMX_WORLD_SIZE=str(a.nproc), LOAMX_LOCAL_RANK=str(r), LOAMX_ID_FILE=id_file)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, a.script, *a.args], env=env))
+    # any rank that ends badly (non-zero exit, or killed by a signal: negative return code) fails the job and takes the others
+    # down with it — a rank lost before or inside a collective would leave its peers, and this launcher, waiting forever
     rc = 0
-    for p in procs:
-        rc = max(rc, p.wait())
+    live = list(procs)
+    while live:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r if r > 0 else 128 - r   # (shell convention for signals)
+                for q in live:
+                    q.terminate()
+        if live:
+            time.sleep(0.02)
     if tmpdir:
         try:
             if os.path.exists(id_file):

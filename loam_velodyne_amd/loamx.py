@@ -647,6 +647,33 @@ class Pipeline:
         return int(lib().loamx_pipeline_stream(self.h) or 0)
 
 
+def dist_shard_of(rank: int, world: int, batch: int):
+    b, e = C.c_uint32(0), C.c_uint32(0)
+    _check(lib().loamx_dist_shard_of(rank, world, batch, C.byref(b), C.byref(e)))
+    return int(b.value), int(e.value)
+
+
+def dist_pack_results(poses6, iters_flags, n_pad: int) -> np.ndarray:
+    """a rank's padded send block of the result exchange (n_pad x 8 floats)"""
+    p = np.ascontiguousarray(poses6, np.float32).reshape(-1, 6)
+    f = np.ascontiguousarray(iters_flags, np.int32).reshape(len(p), 2) if iters_flags is not None else None
+    out = np.zeros((n_pad, 8), np.float32)
+    _check(lib().loamx_dist_pack_results(p.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p) if f is not None else None, len(p), n_pad,
+                                         out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def dist_unpack_results(recv, counts, n_pad: int):
+    """inverse of dist_pack_results for the gathered blocks recv[world][n_pad][8]"""
+    r = np.ascontiguousarray(recv, np.float32)
+    c = np.ascontiguousarray(counts, np.uint32)
+    tot = int(c.sum())
+    pa, fa = np.zeros((max(tot, 1), 6), np.float32), np.zeros((max(tot, 1), 2), np.int32)
+    _check(lib().loamx_dist_unpack_results(r.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), len(c), n_pad, pa.ctypes.data_as(C.c_void_p),
+                                           fa.ctypes.data_as(C.c_void_p)))
+    return pa[:tot], fa[:tot]
+
+
 class Dist:
     """loamx_dist_*: the multi-GPU exchanges of the batched mode over RCCL (one process per GPU)."""
     ID_BYTES = 128
@@ -687,15 +714,23 @@ class Dist:
                                               C.c_void_p(wait_event or None), C.byref(ev)))
         return int(ev.value or 0)
 
-    def allgather_results(self, poses6, iters_flags=None):
+    def allgather_results(self, poses6, iters_flags=None, batch=None):
+        """every rank's records in rank order; shards may be unequal (batch = total record count when known, else world x the
+        largest shard is reserved).  Returns (poses, flags, counts per rank)"""
         p = np.ascontiguousarray(poses6, np.float32).reshape(-1, 6)
         n = len(p)
         f = np.ascontiguousarray(iters_flags, np.int32).reshape(n, 2) if iters_flags is not None else None
-        pa = np.zeros((self.world * n, 6), np.float32)
-        fa = np.zeros((self.world * n, 2), np.int32)
+        cap = int(batch) if batch is not None else self.world * (n + 1)
+        pa = np.zeros((cap, 6), np.float32)
+        fa = np.zeros((cap, 2), np.int32)
+        cnt = np.zeros(self.world, np.uint32)
         _check(lib().loamx_dist_allgather_results(self.h, p.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p) if f is not None else None,
-                                                  n, pa.ctypes.data_as(C.c_void_p), fa.ctypes.data_as(C.c_void_p)))
-        return pa, fa
+                                                  n, pa.ctypes.data_as(C.c_void_p), fa.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
+        tot = int(cnt.sum())
+        return pa[:tot], fa[:tot], cnt
+
+    def comm_count(self) -> int:
+        return int(lib().loamx_dist_comm_count(self.h))
 
     def barrier(self):
         _check(lib().loamx_dist_barrier(self.h))

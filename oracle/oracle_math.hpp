@@ -180,11 +180,15 @@ template <int M, int N> inline void colpiv_qr_solve(const float* Ain, const floa
   }
   int perm[N];
   for (int c = 0; c < N; c++) perm[c] = c;
+  // (Eigen finds maxima with a visitor that is seeded with the FIRST coefficient and replaces it on `value > current` only — which
+  // matters for nothing but a non-finite system: a NaN in front survives every comparison, the threshold becomes NaN, no pivot is
+  // ever declared negligible and the solution comes out NaN, which is what BasicLaserOdometry.cpp:606-612 exists for)
   float maxnorm = 0.f;
   for (int c = 0; c < N; c++) {
     float s = 0.f;
     for (int r = 0; r < M; r++) s += A[r][c] * A[r][c];
-    maxnorm = std::max(maxnorm, std::sqrt(s));
+    const float nrm = std::sqrt(s);
+    if (c == 0 || nrm > maxnorm) maxnorm = nrm;
   }
   const float eps = std::numeric_limits<float>::epsilon();
   const float thr_helper = (maxnorm * eps) * (maxnorm * eps) / float(M);
@@ -192,11 +196,11 @@ template <int M, int N> inline void colpiv_qr_solve(const float* Ain, const floa
   float maxpivot = 0.f;
   for (int k = 0; k < N; k++) {
     int best = k;
-    float bestn = -1.f;
+    float bestn = 0.f;
     for (int c = k; c < N; c++) {
       float s = 0.f;
       for (int r = k; r < M; r++) s += A[r][c] * A[r][c];
-      if (s > bestn) {
+      if (c == k || s > bestn) {   // (seeded with the first remaining column, see above)
         bestn = s;
         best = c;
       }

@@ -34,7 +34,7 @@ import oracle_py as op  # noqa: E402
 
 d, rank, world, local = launch.rendezvous()
 torch.cuda.set_device(local)
-B = 4
+B = int(os.environ.get("LOAMX_TEST_BATCH", "4"))   # (5 with two ranks: shards of 2 and 3 sweeps)
 w = synth.World(half_extent=65.0)
 n_corner, n_surf = 10000, 90000
 map_t = torch.zeros((n_corner + n_surf, 4), dtype=torch.float32, device=f"cuda:{local}")
@@ -60,9 +60,13 @@ b0, b1 = d.shard(B)
 bt = loamx.Batch(max(b1 - b0, 1), device=local)
 bt.stage_frozen_device(map_t.data_ptr(), n_corner, map_t.data_ptr() + 16 * n_corner, n_surf, wait_event=ev)   # index build ordered behind the broadcast
 bt.swap_frozen()
-bt.upload(cl[b0:b1], sl[b0:b1], guesses[b0:b1])
-bt.run()
-poses, stats = bt.download()
-allp, allf = d.allgather_results(poses, np.stack([stats[:, 0], stats[:, 1]], 1))
+if b1 > b0:
+    bt.upload(cl[b0:b1], sl[b0:b1], guesses[b0:b1])
+    bt.run()
+    poses, stats = bt.download()
+else:                                      # more ranks than sweeps: an empty shard still takes part in the exchanges
+    poses, stats = np.zeros((0, 6), np.float32), np.zeros((0, 4), np.int32)
+allp, allf, counts = d.allgather_results(poses, np.stack([stats[:, 0], stats[:, 1]], 1), batch=B)
+assert int(counts.sum()) == B and d.comm_count() == world
 d.barrier()
 np.savez(os.path.join(out_dir, f"rank{rank}.npz"), poses=allp, flags=allf, shard=np.array([b0, b1]), map_sum=float(map_t.double().sum().item()))

@@ -13,8 +13,12 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def _run(nproc, tmp_path):
-    assert launch.main(["--nproc", str(nproc), WORKER, str(tmp_path), "gpu"]) == 0
+def _run(nproc, tmp_path, batch=4):
+    os.environ["LOAMX_TEST_BATCH"] = str(batch)
+    try:
+        assert launch.main(["--nproc", str(nproc), WORKER, str(tmp_path), "gpu"]) == 0
+    finally:
+        os.environ.pop("LOAMX_TEST_BATCH", None)
     return [np.load(tmp_path / f"rank{k}.npz") for k in range(nproc)]
 
 
@@ -35,3 +39,18 @@ def test_two_ranks_equal_one_rank(tmp_path):
     assert two[0]["map_sum"] == two[1]["map_sum"] == one["map_sum"]                  # the broadcast reached rank 1
     for r in two:                                                                   # every rank holds all results, in batch order,
         assert np.array_equal(r["poses"], one["poses"]) and np.array_equal(r["flags"], one["flags"])   # identical to the unsharded run
+
+
+@pytest.mark.skipif(loamx.device_count() < 2, reason="needs two GPUs (one process per GPU)")
+@pytest.mark.parametrize("batch,shards", [(5, [[0, 2], [2, 5]]), (1, [[0, 0], [0, 1]])])
+def test_two_ranks_unequal_shards(tmp_path, batch, shards):
+    """a batch that does not divide by the world size (and one smaller than it: an empty shard): the result exchange pads to the
+    longest shard, every rank takes part, and every rank ends up with the unsharded run's results in batch order"""
+    (tmp_path / "one").mkdir()
+    (tmp_path / "two").mkdir()
+    one = _run(1, tmp_path / "one", batch)[0]
+    two = _run(2, tmp_path / "two", batch)
+    assert [r["shard"].tolist() for r in two] == shards
+    for r in two:
+        assert r["poses"].shape == (batch, 6)
+        assert np.array_equal(r["poses"], one["poses"]) and np.array_equal(r["flags"], one["flags"])

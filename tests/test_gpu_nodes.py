@@ -3,7 +3,8 @@ ScanRegistration / LaserOdometry / LaserMapping / TransformMaintenance node sour
 the swapped MultiScanRegistration unit and libloamx.so (oracle/dropin_check.sh, built where /root/reference exists and shipped
 as a binary); oracle/_ref/libref_nodes.so holds the same node sources over the reference's own Basic* cores.  Both are fed the
 same /multi_scan_points and /imu/data messages through the same in-process bus, and every nav_msgs/Odometry they publish is
-compared: odometry to 1e-4, mapping (live rolling map, voxel-threshold feedback) and the fused pose to 2e-3."""
+compared: odometry to 1e-4, mapping (live rolling map, voxel-threshold feedback) and the fused pose to 2e-4
+(measured: 9e-5 / 3e-5)."""
 import os
 
 import numpy as np
@@ -40,7 +41,7 @@ def test_product_behind_the_reference_nodes(small_world, imu):
         for n in (ref, dev):
             n.push_cloud(raw, 1000 + ns // 10**9, ns % 10**9)
     worst = {}
-    for topic, tol in (("/laser_odom_to_init", 1e-4), ("/aft_mapped_to_init", 2e-3), ("/integrated_to_init", 2e-3)):
+    for topic, tol in (("/laser_odom_to_init", 1e-4), ("/aft_mapped_to_init", 2e-4), ("/integrated_to_init", 2e-4)):
         (sr, vr), (sd, vd) = ref.odometry(topic), dev.odometry(topic)
         assert np.array_equal(sr, sd), topic
         worst[topic] = float(np.abs(vr - vd).max())
@@ -59,7 +60,7 @@ def test_c_abi_composition_vs_the_reference_nodes(small_world):
         raw = synth.to_raw(sw, bad_every=89)
         ref.push_cloud(raw, 1000 + ns // 10**9, ns % 10**9)
         dev.push_cloud(raw, 1000 + (51 * k + 5) / 512)
-    for topic, tol in (("/laser_odom_to_init", 1e-4), ("/aft_mapped_to_init", 2e-3), ("/integrated_to_init", 2e-3)):
+    for topic, tol in (("/laser_odom_to_init", 1e-4), ("/aft_mapped_to_init", 2e-4), ("/integrated_to_init", 2e-4)):
         (sr, vr), (sd, vd) = ref.odometry(topic), dev.odometry(topic)
         assert np.array_equal(sr, sd), topic
         assert np.abs(vr - vd).max() < tol, (topic, float(np.abs(vr - vd).max()))

@@ -168,8 +168,10 @@ def test_full_size_hdl64_pipeline_vs_oracle(orc):
         assert np.abs(got[T - 1][s][2][3:] - gt[3:]).max() < 0.3
 
 
-def test_streaming_io_equals_staged_run(orc, small_world):
-    """loamx_pipeline_stage_step / download_step_async (the PCIe-inclusive mode): one step handed over at a time, at most four
+@pytest.mark.parametrize("ahead", [3, 4])
+def test_streaming_io_equals_staged_run(orc, small_world, ahead):
+    """(ahead = 4: the header's contract to the letter — four steps in flight, stage_step(t) right after step(t - 4))
+    loamx_pipeline_stage_step / download_step_async (the PCIe-inclusive mode): one step handed over at a time, at most four
     in flight, registered clouds copied out asynchronously from alternating device buffers — bit-identical to the run that
     staged everything up front, and the downloaded clouds are the ones download_full_res returns"""
     ns, T = 2, 7
@@ -197,14 +199,14 @@ def test_streaming_io_equals_staged_run(orc, small_world):
         ref_full.append([a.download_full_res(k, len(sweeps[t][k][0])) for k in range(ns)] if rc == loamx.OK else None)
     b = make()
     b.enable_async_downloads()
-    for t in range(min(3, T)):
+    for t in range(min(ahead, T)):
         b.stage_step(t, sweeps[t])
     outs = [[np.zeros((len(sweeps[0][k][0]) + 8, 4), np.float32) for k in range(ns)] for _ in range(2)]
     pending = None
     for t in range(T):
         rc = b.step(t)
-        if t + 3 < T:
-            b.stage_step(t + 3, sweeps[t + 3])                       # slot (t + 3) % 4: free since step t - 1 has run
+        if t + ahead < T:
+            b.stage_step(t + ahead, sweeps[t + ahead])               # ahead = 3: slot (t + 3) % 4, free since step t - 1 has run; 4: step t's own slot
         for s in range(ns):
             got, want = b.get(s), ref[t][s]
             for i in range(3):

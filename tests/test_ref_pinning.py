@@ -215,6 +215,40 @@ def test_odometry_from_a_poor_seed_equals_the_reference(orc, small_world):
     assert o.stats()["iterations"] > 10
 
 
+@needs_od
+def test_non_finite_system_takes_the_reset_branch(orc, small_world):
+    """BasicLaserOdometry.cpp:606-612.  Duplicated tripod points (the same corner on two adjacent rings of the previous cloud) make
+    l12 = 0: those features' rows are NaN and — NaN != 0 — selected (:330-361), the 6x6 system is NaN throughout, Eigen's pivoted
+    QR (maxima seeded with the first coefficient: a NaN survives, no pivot is declared negligible) answers NaN, and the reference
+    zeroes every non-finite transform component — in each of the first five iterations.  The oracle's
+    restatement of the QR follows those semantics; the reference's own translation unit (over the stand-in that forwards to it)
+    takes the branch."""
+    poses = synth.trajectory(2)
+    sws = [synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=100 + k, az_steps=900) for k in range(2)]   # (the input of tests/test_gpu_next.py)
+    sr = op.ScanRegistration(orc)
+    f0, f1 = sr.process(sws[0].points, sws[0].ring_sizes), sr.process(sws[1].points, sws[1].ring_sizes)
+    ls = f0["less_sharp"]
+    dup = ls.copy()
+    dup[:, 3] += 1.0
+    both = np.concatenate([ls, dup])
+    f0d = dict(f0)
+    f0d["less_sharp"] = both[np.argsort(np.floor(both[:, 3]), kind="stable")]
+    seed = np.float32([0.001, 0.002, -0.001, 0.05, 0.0, -0.3])
+    o, r, z = op.LaserOdometry(orc), op.RefLaserOdometry(), op.LaserOdometry(orc)
+    for od, start in ((o, seed), (r, seed), (z, np.zeros(6, np.float32))):
+        od.set_features(f0d)
+        od.process()
+        od.set_features(f1)
+        od.set_transform(start)
+        od.process()
+    assert np.array_equal(o.transform, r.transform) and np.array_equal(o.transform_sum, r.transform_sum)
+    # the seed was wiped in the first iteration: the run is the run that starts from zero.  (The distance weights that set in with
+    # the sixth iteration, :346-349, turn the infinite distances of the NaN rows into negative weights and deselect them, so the
+    # iterations after the fifth are ordinary ones.)
+    assert np.array_equal(o.transform, z.transform) and not np.array_equal(o.transform, seed)
+    assert 5 < o.stats()["iterations"] <= 25 and np.all(np.isfinite(o.transform))
+
+
 def _run_mapping(orc, world, sensor, az, n, cfg, offset=(0.0, 0.0, 0.0), imu=False):
     sr, od = op.ScanRegistration(orc), op.LaserOdometry(orc)
     o, r = op.LaserMapping(orc, **cfg), op.RefLaserMapping(**cfg)

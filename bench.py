@@ -81,6 +81,7 @@ def main():
         torch.cuda.set_device(local_rank)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
+    numa_node = bind_near_gpu(torch, local_rank)
 
     from loam_velodyne_amd import loamx, synth
     from loam_velodyne_amd import dist as lxdist
@@ -333,6 +334,7 @@ def main():
                 "map_broadcast_via": bcast_via,
                 "map_epoch_steps": E,
                 "map_epochs_swapped": n_epochs,
+                "numa_node_bound": numa_node,
                 "results_gathered": n_results,
                 "rccl_ranks": (ldist.comm_count() if ldist is not None else 1),   # what the RCCL communicator itself reports (ncclCommCount)
                 "path_algorithmic_bytes_per_sweep": round(float(bytes_per_sweep), 1),
@@ -385,8 +387,10 @@ def run_live(args):
     sweeps = [synth.make_sweep(world_model, sensor, poses[t], poses[t + 1], seed=500 + t) for t in range(T)]
     sr, od, mp = loamx.ScanRegistration(), loamx.LaserOdometry(), loamx.LaserMapping()
     mp.load_cubes(cm, sm)
+    mp.set_timing(True)
     stage = np.zeros(3)
     stats = []
+    gn_ms, gn_launches, gn_qi, reg_ms = 0.0, 0, 0, 0.0
     t0 = None
     for t in range(T):
         if t == 1 + W:
@@ -405,6 +409,8 @@ def run_live(args):
         if t >= 1 + W:
             stage += [b - a, c - b, d - c]
             stats.append(mp.stats())
+            tm = mp.timing()
+            gn_ms += tm["residual_ms"]; gn_launches += tm["residual_launches"]; gn_qi += tm["query_iterations"]; reg_ms += tm["run_ms"]
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     aft = mp.transform("aft")
@@ -418,8 +424,17 @@ def run_live(args):
                    "stage_ms_per_sweep": {"features": round(stage[0] / K * 1e3, 4), "odometry": round(stage[1] / K * 1e3, 4), "mapping": round(stage[2] / K * 1e3, 4)},
                    "mean_map_iterations": round(float(np.mean([s["iterations"] for s in stats])), 2),
                    "mean_submap_points": round(float(np.mean([s["corner_from_map"] + s["surf_from_map"] for s in stats])), 1),
+                   "registration_device_ms_per_sweep": round(reg_ms / K, 4),
                    "final_pose_error_vs_ground_truth_m": round(float(np.abs(aft[3:] - poses[T, 3:]).max()), 4)},
     }
+    avg_launch_ms = gn_ms / max(gn_launches, 1)
+    achieved = (72.0 * gn_qi / max(gn_launches, 1)) / (avg_launch_ms * 1e-3) / 1e9 if gn_launches else 0.0
+    out["roofline"] = {"kernel": "loamx::k_gn_iter", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                       "model": "72 B per query-iteration (12 B query + 5 x 12 B neighbours), S = 1 sweep per launch: one sweep's ~5 k queries "
+                                "cannot fill the device — the launch is latency (search ~10 us + fit + 6x6 update step), not bandwidth",
+                       "avg_launch_us": round(avg_launch_ms * 1e3, 3), "launches": gn_launches,
+                       "algorithmic_bytes_per_launch": round(72.0 * gn_qi / max(gn_launches, 1), 1)}
     if not args.no_cpu_baseline:
         import oracle_py as op
         orc = op.Oracle(fast=True)
@@ -438,6 +453,45 @@ def run_live(args):
                                "sample": f"{len(per)} sweeps of the same sequence, same initial map, oracle live-map process() (g++ -O3 -march=native, one thread)",
                                "seconds_per_sweep": _stats(per), "host_cores_available": os.cpu_count()}
     print(json.dumps(out), flush=True)
+
+
+def bind_near_gpu(torch, local_rank):
+    """Keep this process (and the pinned staging memory it first-touches) on the NUMA node of its GPU: on a two-socket host the
+    driver's box showed the PCIe-inclusive window 30 % below the resident one when the staging buffers sat on the far socket.
+    Returns the node, or None when the topology cannot be read."""
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        dom, bus, dev = getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", 0)
+        if bus is None:
+            return None
+        with open(f"/sys/bus/pci/devices/{dom:04x}:{bus:02x}:{dev:02x}.0/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            for part in f.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
+
+
+def copy_bandwidth(torch, dev, nbytes):
+    """what the box's PCIe link gives a pinned <-> device copy of one step's size (GB/s each way, best of 5)"""
+    h = torch.empty(nbytes // 4, dtype=torch.float32).pin_memory()
+    d = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    out = {}
+    for name, fn in (("h2d", lambda: d.copy_(h, non_blocking=True)), ("d2h", lambda: h.copy_(d, non_blocking=True))):
+        best = 0.0
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); b.synchronize()
+            best = max(best, nbytes / (a.elapsed_time(b) * 1e-3) / 1e9)
+        out[name] = round(best, 1)
+    return out
 
 
 def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps, starts, ns, W, K, dist, dev, lxdist):
@@ -488,9 +542,14 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
         print(f"[pcie] loop {t_loop * 1e3:.2f} ms, + wait_downloads {t_wait * 1e3:.2f}, + synchronize {elapsed * 1e3:.2f}", file=sys.stderr)
     elapsed = lxdist.max_over_ranks(elapsed, dist, dev)
     world = dist.get_world_size() if dist is not None else 1
+    bw = copy_bandwidth(torch, dev, int(ns * n_pts * 16))
+    h2d_b, d2h_b = int(ns * n_pts * 16), int(mapped_pts * 16 // max(K, 1))
     return {
         "value": round(world * ns * K / elapsed, 2), "unit": "sweeps/s", "ms_per_step": round(elapsed / K * 1e3, 4),
-        "h2d_bytes_per_step": int(ns * n_pts * 16), "d2h_bytes_per_step": int(mapped_pts * 16 // max(K, 1)),
+        "h2d_bytes_per_step": h2d_b, "d2h_bytes_per_step": d2h_b,
+        "link_gbps": bw,   # a pinned <-> device copy of one step's size on this box, each way
+        "h2d_ms_per_step": round(h2d_b / (bw["h2d"] * 1e9) * 1e3, 4), "d2h_ms_per_step": round(d2h_b / (bw["d2h"] * 1e9) * 1e3, 4),
+        "achieved_gbps_each_way": round(h2d_b / (elapsed / K) / 1e9, 2),
         "note": "same workload and steps as `value`, but every step's sweeps cross PCIe inside the timed region (pinned memory, copy stream, staged "
                 "three steps ahead) and every step's registered full-resolution clouds are copied back (asynchronous, alternating buffers); "
                 "steady-state window: not drained at its start, fully drained (downloads landed, device idle) at its end",

@@ -206,6 +206,10 @@ int loamx_map_save_snapshot(loamx_map* h, const char* path);
 int loamx_map_load_snapshot(loamx_map* h, const char* path);
 /* diagnostics of the last process(): iterations, rows selected, corner queries, surf queries, corner sub-map size,
  * surf sub-map size, degenerate flag, optimised flag */
+/* HIP-event timing of the registration inside the last process() (as loamx_batch_set_timing / loamx_batch_get_timing: ms[0] = the
+ * registration's device time, ms[1] = sum of the Gauss-Newton launches, counts[0] = launches, counts[1] = query-iterations) */
+int loamx_map_set_timing(loamx_map* h, int on);
+int loamx_map_get_timing(loamx_map* h, float ms[4], uint64_t counts[4]);
 int loamx_map_get_stats(loamx_map* h, int stats[8]);
 
 /* ------------------------------------------------------------------------------------------------------------

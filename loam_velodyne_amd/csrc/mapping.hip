@@ -246,9 +246,11 @@ class Mapper {
   }
   uint32_t last_sub[2] = {0, 0};
   TypeMap tm[2];
-  DevBuf<short> slot_lut;
-  DevBuf<uint8_t> sur_lut;
-  DevBuf<uint32_t> slot_tag;
+  DevBuf<char> d_tables;      // slot look-up table (short[MCUBES]) | surround flags (uint8[MCUBES]) | cube tags of the valid slots
+  PinBuf<char> h_tables;
+  const short* slot_lut_v = nullptr;
+  const uint8_t* sur_lut_v = nullptr;
+  const uint32_t* slot_tag_v = nullptr;
   // surround cloud
   DevBuf<float4> sur_in, sur_out;
   DevBuf<uint32_t> sur_flag, sur_scan, sur_off, sur_cnt, sur_tiles;
@@ -283,9 +285,6 @@ Mapper::Mapper(const loamx_map_config& c) : cfg(c), reg(c.device, 1) {
     tm[t].h_counters.reserve(16);
     tm[t].out_off.reserve(130);
   }
-  slot_lut.reserve(MCUBES);
-  sur_lut.reserve(MCUBES);
-  slot_tag.reserve(128);
   sur_vox.init(reg.stream());
   sur_off.reserve(4);
   sur_cnt.reserve(16);
@@ -387,10 +386,21 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   last_sub[0] = n_sub[0];
   last_sub[1] = n_sub[1];
 
-  LX_HIP(hipMemcpyAsync(slot_lut.p, lut.data(), sizeof(short) * MCUBES, hipMemcpyHostToDevice, st));
-  LX_HIP(hipMemcpyAsync(sur_lut.p, slut.data(), MCUBES, hipMemcpyHostToDevice, st));
-  LX_HIP(hipMemcpyAsync(slot_tag.p, stag.data(), sizeof(uint32_t) * stag.size(), hipMemcpyHostToDevice, st));
-  LX_HIP(hipStreamSynchronize(st));   // the host vectors above go out of scope
+  // the three tables travel as one block through pinned memory owned by this object (the previous call's copy has completed: every
+  // process() ends synchronised) — no host wait here
+  {
+    const size_t o_sur = sizeof(short) * MCUBES, o_tag = (o_sur + MCUBES + 3) & ~(size_t)3, bytes = o_tag + sizeof(uint32_t) * 128;
+    h_tables.reserve(bytes);
+    d_tables.reserve(bytes);
+    LX_REQUIRE(stag.size() <= 128, "internal: more than 125 valid cubes");
+    memcpy(h_tables.p, lut.data(), sizeof(short) * MCUBES);
+    memcpy(h_tables.p + o_sur, slut.data(), MCUBES);
+    memcpy(h_tables.p + o_tag, stag.data(), sizeof(uint32_t) * stag.size());
+    LX_HIP(hipMemcpyAsync(d_tables.p, h_tables.p, bytes, hipMemcpyHostToDevice, st));
+    slot_lut_v = (const short*)d_tables.p;
+    sur_lut_v = (const uint8_t*)(d_tables.p + o_sur);
+    slot_tag_v = (const uint32_t*)(d_tables.p + o_tag);
+  }
 
   MapWindow w;
   for (int a = 0; a < 3; a++) w.cen[a] = cen[a];
@@ -403,7 +413,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     const int cur = T.cur, nxt = 1 - cur;
     if (T.n) {
       const uint32_t nb = (T.n + 255) / 256;
-      hipLaunchKernelGGL(k_map_classify, dim3(nb), dim3(256), 0, st, T.tags[cur].p, T.n, w, slot_lut.p, T.fv.p, T.fr.p, T.seg.p);
+      hipLaunchKernelGGL(k_map_classify, dim3(nb), dim3(256), 0, st, T.tags[cur].p, T.n, w, slot_lut_v, T.fv.p, T.fr.p, T.seg.p);
       exclusive_scan_u32_n(T.fv.p, T.sv.p, T.tile_sums.p, T.counters.p + 0, T.n, st);
       exclusive_scan_u32_n(T.fr.p, T.sr.p, T.tile_sums.p, T.counters.p + 2, T.n, st);
       hipLaunchKernelGGL(k_map_partition, dim3(nb), dim3(256), 0, st, T.pts[cur].p, T.tags[cur].p, T.n, T.fv.p, T.sv.p, T.fr.p, T.sr.p,
@@ -417,7 +427,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   reg.set_submap_device(tm[0].sub.p, n_sub[0], tm[1].sub.p, n_sub[1], false);
   float g6[6];
   tobe.get(g6);
-  reg.upload(1, corner_last, surf_last, full_res, g6);
+  reg.upload(1, corner_last, surf_last, full_res, g6, false);
   reg.early_exit = true;   // process() is blocking
   const bool imu_blend = !imu_history.empty();
   reg.defer_full = imu_blend;
@@ -445,7 +455,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     if (n_slots) {
       const uint32_t nb = (n_slots + 255) / 256;
       hipLaunchKernelGGL(k_map_insert, dim3(nb), dim3(256), 0, st, reg.d_ds_points(), reg.d_ds_offsets(), t, n_slots, reg.d_poses(), w,
-                         slot_lut.p, n_old, T.fin.p, T.fin_seg.p, T.fin_valid.p, T.rest_flag.p, T.ins.p, T.ins_tags.p);
+                         slot_lut_v, n_old, T.fin.p, T.fin_seg.p, T.fin_valid.p, T.rest_flag.p, T.ins.p, T.ins_tags.p);
       exclusive_scan_u32_n(T.rest_flag.p, T.rest_scan.p, T.tile_sums.p, T.counters.p + 4, n_slots, st);
       hipLaunchKernelGGL(k_map_append_rest, dim3(nb), dim3(256), 0, st, T.ins.p, T.ins_tags.p, T.rest_flag.p, T.rest_scan.p, n_slots,
                          T.counters.p + 3, T.pts[nxt].p, T.tags[nxt].p);
@@ -457,7 +467,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     T.vox.compute_ijk(T.fin.p, T.fin_valid.p, n_fin, nullptr, nslots, inv, inv, T.fin_seg.p);
     T.vox.sort_reduce(T.fin.p, T.fin_valid.p, n_fin, nullptr, nslots, T.filt.p, T.out_off.p, T.fin_seg.p);
     const uint32_t max_f = n_fin ? n_fin : 1;
-    hipLaunchKernelGGL(k_map_append_filtered, dim3((max_f + 255) / 256), dim3(256), 0, st, T.filt.p, T.out_off.p, nslots, slot_tag.p,
+    hipLaunchKernelGGL(k_map_append_filtered, dim3((max_f + 255) / 256), dim3(256), 0, st, T.filt.p, T.out_off.p, nslots, slot_tag_v,
                        max_f, T.counters.p + 3, T.counters.p + 5, T.pts[nxt].p, T.tags[nxt].p, T.counters.p + 6);
     LX_HIP(hipMemsetAsync(T.hist.p, 0, sizeof(uint32_t) * MCUBES, st));
     const uint32_t max_new = T.n + n_slots + 1;
@@ -513,7 +523,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
       uint32_t* cnt = sur_cnt.p + 4 * t;   // [n, total]
       if (n) {
         const uint32_t nb = (n + 255) / 256;
-        hipLaunchKernelGGL(k_map_surround_flags, dim3(nb), dim3(256), 0, st, T.tags[T.cur].p, T.counters.p + 6, n, w, sur_lut.p, sur_flag.p);
+        hipLaunchKernelGGL(k_map_surround_flags, dim3(nb), dim3(256), 0, st, T.tags[T.cur].p, T.counters.p + 6, n, w, sur_lut_v, sur_flag.p);
         exclusive_scan_u32_n(sur_flag.p, sur_scan.p, sur_tiles.p, cnt, n, st);
         hipLaunchKernelGGL(k_map_compact, dim3(nb), dim3(256), 0, st, T.pts[T.cur].p, sur_flag.p, sur_scan.p, n, 0u,
                            t == 0 ? (const uint32_t*)nullptr : (const uint32_t*)(sur_cnt.p + 1), sur_in.p);
@@ -761,6 +771,12 @@ int loamx_map_save_snapshot(loamx_map* h, const char* path) {
 }
 int loamx_map_load_snapshot(loamx_map* h, const char* path) {
   return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->m.load_snapshot(path); return LOAMX_OK; });
+}
+int loamx_map_set_timing(loamx_map* h, int on) {
+  return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->m.reg.set_timing(on != 0); return LOAMX_OK; });
+}
+int loamx_map_get_timing(loamx_map* h, float ms[4], uint64_t counts[4]) {
+  return guard([&]() { LX_REQUIRE(h && ms && counts, "NULL argument"); h->m.reg.get_timing(ms, counts); return LOAMX_OK; });
 }
 int loamx_map_get_stats(loamx_map* h, int s[8]) {
   return guard([&]() {

@@ -108,7 +108,7 @@ class Registrar {
 
   // stage inputs (H2D, async on the stream)
   void upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const loamx_cloud* surf_last, const loamx_cloud* full_res,
-              const float* guess6);
+              const float* guess6, bool wait = true);
   // same with device-resident packed float4 inputs (copied device-to-device; async on the stream)
   void upload_device(uint32_t n_sweeps, const float4* const* corner_last, const uint32_t* n_corner, const float4* const* surf_last,
                      const uint32_t* n_surf, const float4* const* full_res, const uint32_t* n_full, const float* guess6);

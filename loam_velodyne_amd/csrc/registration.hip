@@ -1050,7 +1050,7 @@ void Registrar::swap_submap() {
 }
 
 void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const loamx_cloud* surf_last, const loamx_cloud* full_res,
-                       const float* guess6) {
+                       const float* guess6, bool wait) {
   LX_REQUIRE(n_sweeps >= 1 && n_sweeps <= max_sweeps_, "n_sweeps out of range for this handle");
   LX_REQUIRE(corner_last && surf_last && guess6, "NULL input");
   LX_HIP(hipSetDevice(device_));
@@ -1095,7 +1095,9 @@ void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const 
   d_guess_ = guess_.p; d_seg_off_ = seg_off_.p; d_full_off_ = full_off_.p; d_src_ = nullptr;
   nblk_ = max_q_per_sweep_ / GN_TILE + 2;   // >= ceil(corner / tile) + ceil(surf / tile) of every sweep
   partials_.reserve((size_t)n_sweeps * nblk_ * LX_NSUM);
-  LX_HIP(hipStreamSynchronize(st_));   // host staging buffers are reused by the caller after return
+  // the copies read this object's pinned staging, which the next upload() rewrites: a caller that does not synchronise with the
+  // stream before then (loamx_batch_upload twice in a row) needs the wait; Mapper::process always ends synchronised
+  if (wait) LX_HIP(hipStreamSynchronize(st_));
 }
 
 float4* Registrar::stage_full(uint32_t n_sweeps, const uint32_t* n_full) {

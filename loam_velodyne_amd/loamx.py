@@ -450,6 +450,15 @@ class LaserMapping:
         t = np.ascontiguousarray(t6, np.float32)
         _check(lib().loamx_map_set_transform(self.h, ("aft", "bef", "tobe", "sum").index(which), t.ctypes.data_as(C.c_void_p)))
 
+    def set_timing(self, on: bool):
+        _check(lib().loamx_map_set_timing(self.h, 1 if on else 0))
+
+    def timing(self):
+        ms = (C.c_float * 4)()
+        cnt = (C.c_uint64 * 4)()
+        _check(lib().loamx_map_get_timing(self.h, ms, cnt))
+        return dict(run_ms=ms[0], residual_ms=ms[1], residual_launches=int(cnt[0]), query_iterations=int(cnt[1]), queries=int(cnt[2]))
+
     def has_fresh_map(self):
         return bool(lib().loamx_map_has_fresh_map(self.h))
 

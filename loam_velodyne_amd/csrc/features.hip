@@ -631,9 +631,15 @@ void FeatureExtractor::upload_async(uint32_t nsw, const loamx_cloud* clouds, con
   layout_(nsw, ring_size, n_rings);
   allocate_(copy_stream);
   if (packed) {
-    for (uint32_t s = 0; s < nsw; s++)
-      if (clouds[s].count)
-        LX_HIP(hipMemcpyAsync(cloud_.p + h_pt_base_[s], clouds[s].data, sizeof(float4) * clouds[s].count, hipMemcpyHostToDevice, copy_stream));
+    // clouds that lie back to back in the caller's memory (one block per step) go over in ONE copy: a copy call costs ~5 us of host
+    // time, and the hand-over of a step must not take longer than the step
+    for (uint32_t s = 0; s < nsw;) {
+      uint32_t e = s + 1;
+      size_t cnt = clouds[s].count;
+      while (e < nsw && (const char*)clouds[e].data == (const char*)clouds[s].data + sizeof(float4) * cnt) cnt += clouds[e++].count;
+      if (cnt) LX_HIP(hipMemcpyAsync(cloud_.p + h_pt_base_[s], clouds[s].data, sizeof(float4) * cnt, hipMemcpyHostToDevice, copy_stream));
+      s = e;
+    }
   } else {
     h_cloud_.reserve(n_ + 1);
     for (uint32_t s = 0; s < nsw; s++) pack_cloud(&clouds[s], h_cloud_.p + h_pt_base_[s]);

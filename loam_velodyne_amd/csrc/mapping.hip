@@ -149,14 +149,23 @@ __global__ __launch_bounds__(256) void k_map_append_filtered(const float4* __res
   new_tags[base + v] = slot_tag[lo];
 }
 
+// per-cube point counts of the new map.  The map's points sit in a few dozen cubes: 200 k global atomics on those few counters
+// serialise (measured: 0.6 ms per launch); every workgroup counts in LDS first and adds each cube it touched once.
 __global__ __launch_bounds__(256) void k_map_hist(const uint32_t* __restrict__ tags, const uint32_t* __restrict__ d_n, uint32_t max_n,
                                                   MapWindow w, uint32_t* __restrict__ hist) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= *d_n || i >= max_n) return;
-  int ia, ja, ka;
-  unpack_tag(tags[i], ia, ja, ka);
-  const int I = ia + w.cen[0], J = ja + w.cen[1], K = ka + w.cen[2];
-  if (I >= 0 && I < MW && J >= 0 && J < MH && K >= 0 && K < MD) atomicAdd(&hist[I + MW * J + MW * MH * K], 1u);
+  __shared__ uint32_t s_hist[MCUBES];
+  for (int c = (int)threadIdx.x; c < MCUBES; c += 256) s_hist[c] = 0u;
+  __syncthreads();
+  const uint32_t n = min(*d_n, max_n);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    int ia, ja, ka;
+    unpack_tag(tags[i], ia, ja, ka);
+    const int I = ia + w.cen[0], J = ja + w.cen[1], K = ka + w.cen[2];
+    if (I >= 0 && I < MW && J >= 0 && J < MH && K >= 0 && K < MD) atomicAdd(&s_hist[I + MW * J + MW * MH * K], 1u);
+  }
+  __syncthreads();
+  for (int c = (int)threadIdx.x; c < MCUBES; c += 256)
+    if (s_hist[c]) atomicAdd(&hist[c], s_hist[c]);
 }
 
 // gather flags for the surround cloud (createDownsizedMap :251-257)
@@ -471,7 +480,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
                        max_f, T.counters.p + 3, T.counters.p + 5, T.pts[nxt].p, T.tags[nxt].p, T.counters.p + 6);
     LX_HIP(hipMemsetAsync(T.hist.p, 0, sizeof(uint32_t) * MCUBES, st));
     const uint32_t max_new = T.n + n_slots + 1;
-    hipLaunchKernelGGL(k_map_hist, dim3((max_new + 255) / 256), dim3(256), 0, st, T.tags[nxt].p, T.counters.p + 6, max_new, w, T.hist.p);
+    hipLaunchKernelGGL(k_map_hist, dim3(std::min<uint32_t>((max_new + 2047) / 2048, 256u)), dim3(256), 0, st, T.tags[nxt].p, T.counters.p + 6, max_new, w, T.hist.p);
     LX_HIP(hipMemcpyAsync(T.h_hist.p, T.hist.p, sizeof(uint32_t) * MCUBES, hipMemcpyDeviceToHost, st));
     LX_HIP(hipMemcpyAsync(T.h_counters.p, T.counters.p, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, st));
   }

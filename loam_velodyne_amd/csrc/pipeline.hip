@@ -64,12 +64,15 @@ class Pipeline {
   // is being staged.  The copies run on a stream of their own; launch_features() orders the extraction behind their event.
   static constexpr uint32_t RING = 4;
   bool streaming = false;
-  uint32_t staged_hi = 0;                                // streaming: steps below this one have been staged
+  // streaming: steps below staged_hi have been staged.  stage_step* may run on ONE other thread than step(): it publishes the slot
+  // (release) after everything of it is enqueued, step() reads the count once (acquire); the two never touch the same slot — the
+  // stager works on the slot of step t + RING - 1 at most while steps <= t + 2 are in flight
+  std::atomic<uint32_t> staged_hi{0};
   hipStream_t cstream = nullptr, dstream = nullptr;      // H2D staging / D2H of the registered clouds
   hipEvent_t ev_stage[RING] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_reg_done = nullptr, ev_d2h[2] = {nullptr, nullptr};
   bool d2h_pending[2] = {false, false};
-  long last_step = -1;                                    // the last step that has run (-1: none yet)
+  std::atomic<long> last_step{-1};                        // the last step that has run (-1: none yet)
   std::vector<uint32_t> last_full_off;                   // offsets of the registered clouds of the last step (k-th mapped stream)
   // Raw input (loamx_pipeline_stage_step_raw): per slot the payloads, their binned clouds and what the binning leaves behind
   struct RawSlot {
@@ -95,7 +98,7 @@ class Pipeline {
   RawBinner binner;
   FeatureExtractor& FX(uint32_t t) { return *fx[streaming ? t % RING : t]; }
   char& LA(uint32_t t) { return launched[streaming ? t % RING : t]; }
-  uint32_t n_staged() const { return streaming ? staged_hi : (uint32_t)fx.size(); }
+  uint32_t n_staged() const { return streaming ? staged_hi.load(std::memory_order_acquire) : (uint32_t)fx.size(); }
   // feature extraction of step t+1 is independent of odometry / registration of step t (in the reference they are
   // different ROS nodes): it runs on its own HIP stream, launched one step ahead, and overlaps with them
   hipStream_t fstream = nullptr;
@@ -307,15 +310,15 @@ class Pipeline {
     LX_REQUIRE(clouds && ring_size && n_rings, "invalid argument");
     LX_HIP(hipSetDevice(device));
     ensure_streaming_(t);
-    LX_REQUIRE(t == staged_hi, "steps must be staged in order");
-    LX_REQUIRE(t < RING || last_step + (long)RING >= (long)t, "stage_step(t) needs step(t - 4) to have run: only four steps can be in flight");
+    LX_REQUIRE(t == staged_hi.load(), "steps must be staged in order");
+    LX_REQUIRE(t < RING || last_step.load() + (long)RING >= (long)t, "stage_step(t) needs step(t - 4) to have run: only four steps can be in flight");
     TraceRange trace_range("loamx:pipeline:stage_step");
     if (t > 0) finalize_raw(t - 1);
     rawslot[t % RING].raw = false;
     rawslot[t % RING].finalized = true;
     fx[t % RING]->upload_async(n_streams_, clouds, ring_size, n_rings, cstream, ev_stage[t % RING]);
     LA(t) = 0;
-    staged_hi = t + 1;
+    staged_hi.store(t + 1, std::memory_order_release);
   }
 
   // Raw input: step t as the sensor delivered it — per stream one revolution of (x, y, z) records in sensor axes and firing
@@ -330,8 +333,8 @@ class Pipeline {
     LX_REQUIRE(mapper.upper_bound_deg != mapper.lower_bound_deg, "vertical bounds must differ");
     LX_HIP(hipSetDevice(device));
     ensure_streaming_(t);
-    LX_REQUIRE(t == staged_hi, "steps must be staged in order");
-    LX_REQUIRE(t < RING || last_step + (long)RING >= (long)t, "stage_step_raw(t) needs step(t - 4) to have run: only four steps can be in flight");
+    LX_REQUIRE(t == staged_hi.load(), "steps must be staged in order");
+    LX_REQUIRE(t < RING || last_step.load() + (long)RING >= (long)t, "stage_step_raw(t) needs step(t - 4) to have run: only four steps can be in flight");
     TraceRange trace_range("loamx:pipeline:stage_step_raw");
     if (t > 0) finalize_raw(t - 1);   // the IMU state machine advances sweep by sweep: this step's table needs the previous reset
     const uint32_t ns = n_streams_, nr = mapper.n_scan_rings;
@@ -395,7 +398,7 @@ class Pipeline {
     LX_HIP(hipMemcpyAsync(R.h_last.p, R.d_last.p, sizeof(ImuLast) * ns, hipMemcpyDeviceToHost, cstream));
     LX_HIP(hipEventRecord(R.ev_ingest, cstream));
     LA(t) = 0;
-    staged_hi = t + 1;
+    staged_hi.store(t + 1, std::memory_order_release);
   }
 
   // second half of a raw step's staging, once its binning has finished (long before it is needed in steady state): the IMU
@@ -437,11 +440,22 @@ class Pipeline {
     for (uint32_t k = 0; k < nw; k++) {
       check_cloud(&out[k], false);
       LX_REQUIRE(out[k].stride == 16 && out[k].intensity_offset == 12, "asynchronous downloads need packed float4 records (stride 16, intensity at 12)");
-      const uint32_t n = last_full_off[k + 1] - last_full_off[k];
-      const uint32_t m = std::min(n, out[k].count);
-      if (m) LX_HIP(hipMemcpyAsync(out[k].data, reg.d_full_res() + last_full_off[k], sizeof(float4) * m, hipMemcpyDeviceToHost, dstream));
-      if (n > out[k].count) rc_cap = LOAMX_E_CAPACITY;
-      out[k].count = n;
+    }
+    for (uint32_t k = 0; k < nw;) {   // destinations that lie back to back (and are filled exactly) share one copy, as in upload_async
+      uint32_t e = k;
+      size_t cnt = 0;
+      char* base = (char*)out[k].data;
+      do {
+        const uint32_t n = last_full_off[e + 1] - last_full_off[e];
+        const uint32_t m = std::min(n, out[e].count);
+        if (n > out[e].count) rc_cap = LOAMX_E_CAPACITY;
+        out[e].count = n;
+        cnt += m;
+        e++;
+        if (m != n) break;   // a truncated cloud ends the run
+      } while (e < nw && (char*)out[e].data == base + sizeof(float4) * cnt);
+      if (cnt) LX_HIP(hipMemcpyAsync(base, reg.d_full_res() + last_full_off[k], sizeof(float4) * cnt, hipMemcpyDeviceToHost, dstream));
+      k = e;
     }
     LX_HIP(hipEventRecord(ev_d2h[par], dstream));
     d2h_pending[par] = true;
@@ -519,7 +533,7 @@ class Pipeline {
   int step(uint32_t t) {
     TraceRange trace_range("loamx:pipeline:step");
     LX_REQUIRE(t < n_staged(), "step index beyond the staged sweeps");
-    LX_REQUIRE(!streaming || t + RING >= staged_hi, "this step's slot has been re-staged already");   // (slot t % RING is rewritten by staging step t + RING)
+    LX_REQUIRE(!streaming || t + RING >= staged_hi.load(), "this step's slot has been re-staged already");   // (slot t % RING is rewritten by staging step t + RING)
     tr0 = std::chrono::steady_clock::now();
     double trM[6] = {0, 0, 0, 0, 0, 0};
     LX_HIP(hipSetDevice(device));

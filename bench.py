@@ -516,9 +516,29 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
     for k in range(ns):
         p.set_state(k, aft=starts[k])
     p.enable_async_downloads()
+    # the C-ABI arguments of every hand-over are built once, ahead of the loop: inside it the second thread only makes the library
+    # call (which releases the GIL) — Python-level marshalling there would hold the GIL just when step() wants it back
+    import ctypes as C
+    L = loamx.lib()
+    stage_args = []
+    for t in range(T):
+        pts = [loamx.as_points(a) for a, _ in pinned[t][0]]
+        rings = [np.ascontiguousarray(r, np.uint32) for _, r in pinned[t][0]]
+        CA = (loamx.Cloud * ns)(*[loamx.cloud_of(a) for a in pts])
+        RP = (C.c_void_p * ns)(*[r.ctypes.data for r in rings])
+        NR = (C.c_uint32 * ns)(*[len(r) for r in rings])
+        stage_args.append((CA, RP, NR, pts, rings))
+    out_args = [(loamx.Cloud * ns)(*[loamx.cloud_of(a) for a in outs[k]]) for k in range(2)]
+
+    def stage(t):
+        CA, RP, NR, _, _ = stage_args[t]
+        rc_ = L.loamx_pipeline_stage_step(p.h, t, CA, RP, NR)
+        if rc_ < 0:
+            raise RuntimeError(L.loamx_last_error().decode())
+
     for t in range(min(3, T)):
-        p.stage_step(t, pinned[t][0])
-    stager = ThreadPoolExecutor(max_workers=1)   # stage_step(t + 3) runs beside step(t) (ctypes releases the GIL inside the library)
+        stage(t)
+    stager = ThreadPoolExecutor(max_workers=1)   # stage_step(t + 3) runs beside step(t)
     t0 = None
     mapped_pts = 0
     host = np.zeros(3)
@@ -528,16 +548,20 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
                 dist.barrier()
             t0 = time.perf_counter()
         ta = time.perf_counter()
-        fut = stager.submit(p.stage_step, t + 3, pinned[t + 3][0]) if t + 3 < T else None   # slot (t + 3) % 4: free since step t - 1 has run
+        fut = stager.submit(stage, t + 3) if t + 3 < T else None   # slot (t + 3) % 4: free since step t - 1 has run
         rc = p.step(t)
         tb = time.perf_counter()
         if fut is not None:
             fut.result()
         tc = time.perf_counter()
         if rc == loamx.OK:
-            counts = p.download_step_async(outs[t & 1])
+            CA = out_args[t & 1]
+            for k in range(ns):
+                CA[k].count = n_pts   # (capacity in, size out)
+            if L.loamx_pipeline_download_step_async(p.h, CA, ns) < 0:
+                raise RuntimeError(L.loamx_last_error().decode())
             if t >= 1 + W:
-                mapped_pts += sum(counts)
+                mapped_pts += sum(int(CA[k].count) for k in range(ns))
         if t >= 1 + W:
             host += [tb - ta, tc - tb, time.perf_counter() - tc]
     p.wait_downloads()

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <string>
@@ -134,6 +135,13 @@ struct TraceRange {
 // HIP stream with a relative priority: +1 = highest the device offers, 0 = default, -1 = lowest.  The stages of the
 // pipeline run on streams of their own; the latency-critical ones (registration, odometry) outrank feature extraction,
 // whose wide kernels would otherwise delay their short dependent launches.
+// env_priority (diagnostic): the stream priority a stage asked for can be overridden with LOAMX_PRIO_REG / _ODOM / _FEAT = -1, 0, 1
+inline int env_priority(const char* name, int dflt) {
+  const char* e = getenv(name);
+  if (!e) return dflt;
+  const int v = atoi(e);
+  return v > 0 ? 1 : (v < 0 ? -1 : 0);
+}
 // cu_stride > 1 (diagnostic, LOAMX_FEAT_CU_STRIDE): a stream whose kernels only run on every cu_stride-th compute unit
 inline hipStream_t create_stream(int rel_priority, int cu_stride = 0) {
   if (cu_stride > 1) {

@@ -282,9 +282,10 @@ __global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr(OdomProblem* __r
 #endif
 // 4 waves per SIMD (<= 128 VGPRs) and 36 KB of LDS: the persistent workgroups of a stream have to find room next to the wide
 // registration / feature kernels of the other HIP streams — at 226 VGPRs + 61 KB they waited for half-empty CUs
-#ifndef OD_LM_ATTR
-#define OD_LM_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef OD_LM_WAVES
+#define OD_LM_WAVES 4
 #endif
+#define OD_LM_ATTR __attribute__((amdgpu_waves_per_eu(OD_LM_WAVES, OD_LM_WAVES)))
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wpass-failed"   // (the two-features-per-thread variant keeps 64 KB of LDS and cannot reach that occupancy)
 template <int OD_FPT>
@@ -655,7 +656,7 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
   if (shared_stream) {
     st_ = shared_stream;
   } else {
-    st_ = create_stream(+1);
+    st_ = create_stream(env_priority("LOAMX_PRIO_ODOM", +1));
     own_stream_ = true;
   }
   for (uint32_t s = 0; s < n_streams; s++) streams_.push_back(new OdomStream());

@@ -350,7 +350,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": pmc_traffic(),
                 "traffic_note": "bytes of one launch with every sweep still iterating (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc "
-                                "passes of this command, profiles/r02_pmc_summary.json); achieved / avg_launch_us average over all timed "
+                                "passes of this command, profiles/r03_pmc_summary.json); achieved / avg_launch_us average over all timed "
                                 "launches incl. the short ones after most sweeps have converged",
                 "model": "72 B per query-iteration = 12 B query + 5 x 12 B neighbours (SURVEY.md §8d); the launch also fits edges / planes, "
                          "forms the 28 normal-equation sums and runs the 6x6 update step",
@@ -588,11 +588,11 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
 
 def pmc_traffic():
     """HBM bytes per full launch of the dominant kernel from the committed PMC passes of this same command
-    (profiles/r02_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs, FETCH_SIZE
+    (profiles/r03_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs, FETCH_SIZE
     doubled per MI355X_MICROARCH.md).  bench.py cannot run the profiler on itself, so the figure is read, not measured
     live; None when the file is missing."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")) as f:
             return json.load(f)["k_gn_iter_full_launch"]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         return None

@@ -11,7 +11,7 @@ cd /tmp
 for set in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "l2:TCC_HIT_sum TCC_MISS_sum"; do
   name=${set%%:*}; ctr=${set#*:}
   rm -rf /tmp/pmc_$name
-  timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$name -- python $root/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-pcie > $out/pmc_$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$name -- python $root/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-pcie --repeat 1 > $out/pmc_$name.log 2>&1
 done
 python $root/scripts/pmc_summary.py $out/pmc_summary.json /tmp/pmc_fetch /tmp/pmc_write /tmp/pmc_l2 > $out/pmc_summary.log 2>&1
 tail -5 $out/pmc_summary.log

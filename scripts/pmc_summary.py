@@ -41,12 +41,13 @@ def main():
             h, m = sum(T[k].get('TCC_HIT_sum', [])), sum(T[k].get('TCC_MISS_sum', []))
             e['l2_hit_rate'] = round(h / (h + m), 4) if h + m else None
         kernels[k] = e
-    res = {'command': 'rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-pcie'
+    res = {'command': 'rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-pcie --repeat 1'
                       '  (one pass per counter set: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum)',
            'units': 'FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3; fetch_bytes_corrected = 2 x FETCH_SIZE x 1024 '
                     '(MI355X_MICROARCH.md, HBM section: upper estimate for gather patterns)',
            'kernels': kernels}
-    for tag, key in (('k_gn_iter', 'k_gn_iter_full_launch'), ('k_knn5', 'k_knn5_full_search_launch'), ('k_vox_ds_seg', 'k_vox_ds_seg_launch'), ('k_feat_lf_voxel', 'k_feat_lf_voxel_launch'), ('k_odom_corr', 'k_odom_corr_launch')):
+    for tag, key in (('k_gn_iter', 'k_gn_iter_full_launch'), ('k_knn5', 'k_knn5_full_search_launch'), ('k_vox_ds_seg', 'k_vox_ds_seg_launch'), ('k_feat_lf_voxel', 'k_feat_lf_voxel_launch'), ('k_odom_corr', 'k_odom_corr_launch'), ('k_vb_reduce', 'k_vb_reduce_launch'),
+                     ('k_vb_stack', 'k_vb_stack_launch'), ('k_odom_lm', 'k_odom_lm_launch')):
         kn = [k for k in kernels if tag in k]
         if kn:
             k = kn[0]

@@ -1,5 +1,5 @@
 """GPU: the kNN contract (SURVEY.md §8 "kNN contract": nanoflann_pcl.h:140-152, nanoflann.hpp:115-139, :372-379) — the library's own
-neighbour search (loamx_batch_knn_probe runs knn5_lane, the device routine inside the Gauss-Newton kernel k_reg_gn) against
+neighbour search (loamx_batch_knn_probe runs knn5_group, the device routine inside the Gauss-Newton kernel k_gn_iter) against
   * the oracle's kd-tree (leaf 10, exact; pinned against the reference's nanoflann in tests/test_ref_pinning.py),
   * the reference's own nanoflann.hpp where oracle/_ref/libref_nanoflann.so was shipped,
   * brute force with the (distance, index) order.

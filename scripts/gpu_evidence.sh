@@ -18,7 +18,7 @@ for S in 1 2 4 16 32; do
   python -c "import json,sys; d=json.loads(open('$out/streams_$S.json').read().strip().splitlines()[-1]); print('streams', $S, d['value'], d['value_median'], d['ms_per_step'])"
 done
 cd /tmp; rm -rf /tmp/prof_copy
-timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/prof_copy -- python $root/bench.py --steps 8 --warmup 3 --no-cpu-baseline --repeat 1 > $out/pcie_traced.json 2> $out/pcie_traced.err
+LOAMX_PIPE_TRACE=1 timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/prof_copy -- python $root/bench.py --steps 8 --warmup 3 --no-cpu-baseline --repeat 1 > $out/pcie_traced.json 2> $out/pcie_traced.err
 mc=$(find /tmp/prof_copy -name '*memory_copy_trace.csv' | head -1)
 python - "$mc" > $out/pcie_copies.txt 2>&1 <<'PY'
 import csv, sys, collections
@@ -34,3 +34,5 @@ for k, v in agg.items():
     print(k, "copies >1MiB:", len(v), "mean MiB", round(b / len(v) / 2**20, 2), "mean us", round(t / len(v), 1), "GB/s", round(b / t / 1e3, 1))
 PY
 cat $out/pcie_copies.txt
+kt=$(find /tmp/prof_copy -name '*kernel_trace.csv' | head -1)
+gzip -c "$kt" > $out/pcie_kernel_trace.csv.gz; gzip -c "$mc" > $out/pcie_memory_copy_trace.csv.gz; ls -la $out | tail -30

@@ -56,6 +56,7 @@ def main():
                     help="pipeline handles per GPU, each on its own HIP stream and host thread, sharing the streams evenly")
     ap.add_argument("--no-pcie", action="store_true", help="skip the second, PCIe-inclusive timed window")
     ap.add_argument("--repeat", type=int, default=5, help="repeat the timed window this many times (fresh handles, same sweeps): value_median / value_min / value_max; `value` is the first window")
+    ap.add_argument("--ab-pcie", default=None, help="diagnostic: like --ab, but each variant runs the PCIe-inclusive window")
     ap.add_argument("--ab", default=None, help="diagnostic: ';'-separated environment variants ('A=1 B=2;C=3;' — empty = defaults) timed inside this process before the contract's window, one line each on stderr")
     ap.add_argument("--mode", default="batched", choices=["batched", "live"],
                     help="live: sequential SLAM (BASELINE configs[1]: VLP-16, 200 k-pt live map, one sweep in flight, host clouds in / out)")
@@ -254,6 +255,20 @@ def main():
                 else:
                     os.environ[k] = o
 
+    if args.ab_pcie is not None and world == 1:
+        for v in args.ab_pcie.split(";"):
+            kv = dict(x.split("=", 1) for x in v.split()) if v.strip() else {}
+            saved = {k: os.environ.get(k) for k in kv}
+            os.environ.update(kv)
+            rs = [pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps, starts, ns, W, K, dist, dev, lxdist) for _ in range(3)]
+            print(f"[ab-pcie] {v.strip() or 'defaults':48s} sweeps/s " + " ".join(f"{r['value']:9.1f}" for r in rs) + f"  inside_step {rs[-1]['host_ms_per_step']['inside_step']:.3f} ms",
+                  file=sys.stderr, flush=True)
+            for k, o in saved.items():
+                if o is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = o
+
     # ---- the contract's window: W warm-up steps, then exactly K timed steps
     win = resident_window(keep_open=True)
     pipes = win["pipes"]
@@ -284,7 +299,11 @@ def main():
     pcie = None
     if H == 1 and not args.no_pcie:
         try:
-            pcie = pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps, starts, ns, W, K, dist, dev, lxdist)
+            runs_ = [pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps, starts, ns, W, K, dist, dev, lxdist)
+                     for _ in range(3 if args.repeat > 1 else 1)]
+            runs_.sort(key=lambda r: r["value"])
+            pcie = dict(runs_[len(runs_) // 2])   # the median window, the others listed beside it
+            pcie["value_windows"] = [r["value"] for r in runs_]
         except Exception as e:   # the device-resident figure above is the contract; a failure here must not lose it
             pcie = {"error": repr(e)[:200]}
 
@@ -568,6 +587,7 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     elapsed = lxdist.max_over_ranks(elapsed, dist, dev)
+    n_direct, n_hip = p.download_counts()
     world = dist.get_world_size() if dist is not None else 1
     bw = copy_bandwidth(torch, dev, int(ns * n_pts * 16))
     h2d_b, d2h_b = int(ns * n_pts * 16), int(mapped_pts * 16 // max(K, 1))
@@ -578,6 +598,7 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
         "link_gbps": bw,   # a pinned <-> device copy of one step's size on this box, each way
         "h2d_ms_per_step": round(h2d_b / (bw["h2d"] * 1e9) * 1e3, 4), "d2h_ms_per_step": round(d2h_b / (bw["d2h"] * 1e9) * 1e3, 4),
         "achieved_gbps_each_way": round(h2d_b / (elapsed / K) / 1e9, 2),
+        "downloads": {"sdma_direct": n_direct, "hipMemcpyAsync": n_hip},
         "host_ms_per_step": {"inside_step": round(host[0] / K * 1e3, 4), "waiting_for_the_stager": round(host[1] / K * 1e3, 4), "download_call": round(host[2] / K * 1e3, 4)},
         "note": "same workload and steps as `value`, but every step's sweeps cross PCIe inside the timed region (one pinned block per step, copy "
                 "stream, staged three steps ahead by a second host thread) and every step's registered full-resolution clouds are copied back "

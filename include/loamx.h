@@ -331,10 +331,15 @@ int loamx_pipeline_update_imu(loamx_pipeline* h, uint32_t stream, double stamp_s
 /* Asynchronous output: after enable (before the first step), download_step_async — called after loamx_pipeline_step(t) —
  * starts copying the registered full-resolution clouds of step t (out[k] = k-th stream that was registered; packed float4
  * records; count in = capacity, out = points) on a copy stream and returns; the registration alternates between two device
- * buffers so the next step does not wait for the copy.  wait_downloads blocks until every started copy has landed. */
+ * buffers so the next step does not wait for the copy.  wait_downloads blocks until every started copy has landed.
+ * When the destination is pinned memory of the ROCm runtime's own (hipHostMalloc, torch's pinned tensors) the copy is handed to
+ * the GPU's SDMA engine directly; other host memory goes through hipMemcpyAsync on a copy stream (whose choice of engine may
+ * disturb kernels that write to host memory, see csrc/hostlink.cuh).  download_counts: [0] downloads issued the first way,
+ * [1] the second. */
 int loamx_pipeline_enable_async_downloads(loamx_pipeline* h);
 int loamx_pipeline_download_step_async(loamx_pipeline* h, loamx_cloud* out, uint32_t n_out);
 int loamx_pipeline_wait_downloads(loamx_pipeline* h);
+int loamx_pipeline_download_counts(loamx_pipeline* h, uint64_t counts[2]);
 /* run staged step t for every stream.  LOAMX_SKIPPED when no stream reached the registration stage (first sweeps) */
 int loamx_pipeline_step(loamx_pipeline* h, uint32_t step);
 /* stats8: odometry iterations, odometry rows, mapping iterations, mapping rows, corner queries, surf queries,

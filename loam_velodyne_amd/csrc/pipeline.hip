@@ -8,6 +8,7 @@
 #include "features.cuh"
 #include "odometry.cuh"
 #include "registration.cuh"
+#include "hostlink.cuh"
 #include <atomic>
 #include <functional>
 #include <chrono>
@@ -72,6 +73,8 @@ class Pipeline {
   hipEvent_t ev_stage[RING] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_reg_done = nullptr, ev_d2h[2] = {nullptr, nullptr};
   bool d2h_pending[2] = {false, false};
+  uint64_t downloads_direct = 0, downloads_hip = 0;      // asynchronous downloads issued to the SDMA engine directly / through hipMemcpyAsync
+  HostLinkDma hostlink;                                   // the same downloads on the SDMA engine directly (hostlink.cuh)
   std::atomic<long> last_step{-1};                        // the last step that has run (-1: none yet)
   std::vector<uint32_t> last_full_off;                   // offsets of the registered clouds of the last step (k-th mapped stream)
   // Raw input (loamx_pipeline_stage_step_raw): per slot the payloads, their binned clouds and what the binning leaves behind
@@ -432,15 +435,14 @@ class Pipeline {
     LX_HIP(hipSetDevice(device));
     const uint32_t nw = last_full_off.empty() ? 0u : (uint32_t)last_full_off.size() - 1;
     LX_REQUIRE(n_out >= nw, "fewer output descriptors than registered streams");
-    if (!dstream) dstream = create_stream(0);
     const int par = (int)((run_count + 1) & 1);   // the buffer the last run used
-    if (!ev_d2h[par]) LX_HIP(hipEventCreateWithFlags(&ev_d2h[par], hipEventDisableTiming));
-    LX_HIP(hipStreamWaitEvent(dstream, ev_reg_done, 0));
     int rc_cap = LOAMX_OK;
     for (uint32_t k = 0; k < nw; k++) {
       check_cloud(&out[k], false);
       LX_REQUIRE(out[k].stride == 16 && out[k].intensity_offset == 12, "asynchronous downloads need packed float4 records (stride 16, intensity at 12)");
     }
+    struct Run { char* dst; const char* src; size_t bytes; };
+    std::vector<Run> runs;
     for (uint32_t k = 0; k < nw;) {   // destinations that lie back to back (and are filled exactly) share one copy, as in upload_async
       uint32_t e = k;
       size_t cnt = 0;
@@ -454,16 +456,37 @@ class Pipeline {
         e++;
         if (m != n) break;   // a truncated cloud ends the run
       } while (e < nw && (char*)out[e].data == base + sizeof(float4) * cnt);
-      if (cnt) LX_HIP(hipMemcpyAsync(base, reg.d_full_res() + last_full_off[k], sizeof(float4) * cnt, hipMemcpyDeviceToHost, dstream));
+      if (cnt) runs.push_back(Run{base, (const char*)(reg.d_full_res() + last_full_off[k]), sizeof(float4) * cnt});
       k = e;
     }
-    LX_HIP(hipEventRecord(ev_d2h[par], dstream));
-    d2h_pending[par] = true;
+    // The copies go to the SDMA engine directly (hostlink.cuh: the HIP runtime may pick its blit kernel for them, which stalls
+    // every kernel that writes to host memory meanwhile) when source and destination are ROCr allocations; else through HIP.
+    static const bool via_hip = getenv("LOAMX_D2H_HIP") != nullptr;   // diagnostic: always hipMemcpyAsync
+    bool direct = !via_hip && !runs.empty();
+    for (const Run& r : runs) direct = direct && hostlink.can_copy(r.dst, r.src, r.bytes);
+    wait_download(par);   // (a caller that downloads the same step twice)
+    if (direct) {
+      if (ev_reg_done) LX_HIP(hipEventSynchronize(ev_reg_done));   // step() has returned: the registration is complete and its clouds are visible
+      hostlink.begin(par, (uint32_t)runs.size());
+      for (const Run& r : runs) hostlink.copy_d2h(par, r.dst, r.src, r.bytes);
+      downloads_direct++;
+    } else if (!runs.empty()) {
+      if (!dstream) dstream = create_stream(0);
+      if (!ev_d2h[par]) LX_HIP(hipEventCreateWithFlags(&ev_d2h[par], hipEventDisableTiming));
+      LX_HIP(hipStreamWaitEvent(dstream, ev_reg_done, 0));
+      for (const Run& r : runs) LX_HIP(hipMemcpyAsync(r.dst, r.src, r.bytes, hipMemcpyDeviceToHost, dstream));
+      LX_HIP(hipEventRecord(ev_d2h[par], dstream));
+      d2h_pending[par] = true;
+      downloads_hip++;
+    }
     if (rc_cap != LOAMX_OK) throw Error(LOAMX_E_CAPACITY, "an output cloud is smaller than the registered cloud (count fields hold the needed sizes)");
   }
+  void wait_download(int par) {
+    hostlink.wait(par);
+    if (d2h_pending[par]) { LX_HIP(hipEventSynchronize(ev_d2h[par])); d2h_pending[par] = false; }
+  }
   void wait_downloads() {
-    for (int par = 0; par < 2; par++)
-      if (d2h_pending[par]) LX_HIP(hipEventSynchronize(ev_d2h[par]));
+    for (int par = 0; par < 2; par++) wait_download(par);
   }
   uint64_t run_count = 0;   // registrations run so far (parity = which full-resolution buffer)
 
@@ -612,6 +635,7 @@ class Pipeline {
         // one fused kernel writes them straight into the registrar's staging area
         if (reg.double_buffer_full) {   // this run reuses the buffer of the run before last: its download must have finished
           const int par = (int)(run_count & 1);
+          hostlink.wait(par);   // (two steps old: landed long ago)
           if (d2h_pending[par]) { LX_HIP(hipStreamWaitEvent(s_, ev_d2h[par], 0)); d2h_pending[par] = false; }
         }
         float4* full_dst = reg.stage_full(nw, nfr.data());
@@ -777,6 +801,14 @@ int loamx_pipeline_enable_async_downloads(loamx_pipeline* h) {
 }
 int loamx_pipeline_download_step_async(loamx_pipeline* h, loamx_cloud* out, uint32_t n_out) {
   return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->p.download_step_async(out, n_out); return LOAMX_OK; });
+}
+int loamx_pipeline_download_counts(loamx_pipeline* h, uint64_t counts[2]) {
+  return guard([&]() {
+    LX_REQUIRE(h && counts, "NULL argument");
+    counts[0] = h->p.downloads_direct;
+    counts[1] = h->p.downloads_hip;
+    return LOAMX_OK;
+  });
 }
 int loamx_pipeline_wait_downloads(loamx_pipeline* h) {
   return guard([&]() { LX_REQUIRE(h, "NULL handle"); h->p.wait_downloads(); return LOAMX_OK; });

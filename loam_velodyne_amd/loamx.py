@@ -619,6 +619,12 @@ class Pipeline:
     def wait_downloads(self):
         _check(lib().loamx_pipeline_wait_downloads(self.h))
 
+    def download_counts(self):
+        """(downloads handed to the SDMA engine directly, downloads through hipMemcpyAsync)"""
+        c = (C.c_uint64 * 2)()
+        _check(lib().loamx_pipeline_download_counts(self.h, c))
+        return int(c[0]), int(c[1])
+
     def step(self, t: int):
         return _check(lib().loamx_pipeline_step(self.h, t))
 

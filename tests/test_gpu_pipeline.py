@@ -168,9 +168,10 @@ def test_full_size_hdl64_pipeline_vs_oracle(orc):
         assert np.abs(got[T - 1][s][2][3:] - gt[3:]).max() < 0.3
 
 
-@pytest.mark.parametrize("ahead", [3, 4])
-def test_streaming_io_equals_staged_run(orc, small_world, ahead):
-    """(ahead = 4: the header's contract to the letter — four steps in flight, stage_step(t) right after step(t - 4))
+@pytest.mark.parametrize("ahead,pinned", [(3, False), (4, False), (3, True)])
+def test_streaming_io_equals_staged_run(orc, small_world, ahead, pinned):
+    """(pinned: the destinations are pinned memory of the runtime's own, the downloads go to the SDMA engine directly — csrc/hostlink.cuh;
+    ahead = 4: the header's contract to the letter — four steps in flight, stage_step(t) right after step(t - 4))
     loamx_pipeline_stage_step / download_step_async (the PCIe-inclusive mode): one step handed over at a time, at most four
     in flight, registered clouds copied out asynchronously from alternating device buffers — bit-identical to the run that
     staged everything up front, and the downloaded clouds are the ones download_full_res returns"""
@@ -201,7 +202,17 @@ def test_streaming_io_equals_staged_run(orc, small_world, ahead):
     b.enable_async_downloads()
     for t in range(min(ahead, T)):
         b.stage_step(t, sweeps[t])
-    outs = [[np.zeros((len(sweeps[0][k][0]) + 8, 4), np.float32) for k in range(ns)] for _ in range(2)]
+    if pinned:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+
+        def pinned_array(rows):
+            ptr = C.c_void_p()
+            assert hip.hipHostMalloc(C.byref(ptr), C.c_size_t(rows * 16), C.c_uint(0)) == 0
+            return np.ctypeslib.as_array((C.c_float * (rows * 4)).from_address(ptr.value)).reshape(rows, 4)
+        outs = [[pinned_array(len(sweeps[0][k][0]) + 8) for k in range(ns)] for _ in range(2)]   # (left to the process' exit)
+    else:
+        outs = [[np.zeros((len(sweeps[0][k][0]) + 8, 4), np.float32) for k in range(ns)] for _ in range(2)]
     pending = None
     for t in range(T):
         rc = b.step(t)
@@ -225,6 +236,8 @@ def test_streaming_io_equals_staged_run(orc, small_world, ahead):
     pt, counts, bufs = pending
     for k in range(ns):
         assert np.array_equal(bufs[k][:counts[k]], ref_full[pt][k])
+    direct, via_hip = b.download_counts()
+    assert (direct == T - 1 and via_hip == 0) if pinned else (direct == 0 and via_hip == T - 1)
     with pytest.raises(loamx.LoamxError):                            # out of order
         b.stage_step(T + 3, sweeps[0])
 

@@ -438,7 +438,7 @@ def run_live(args):
         "value": round(K / elapsed, 2), "unit": "sweeps/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: {sensor} sweeps ({len(sweeps[0].points)} pts), {M}-pt LIVE map (updated, re-voxelised and re-indexed every sweep), "
+        "config": {"workload": f"BASELINE configs[{2 if sensor == 'HDL-32' else 1}]: {sensor} sweeps ({len(sweeps[0].points)} pts), {M}-pt LIVE map (updated, re-voxelised and re-indexed every sweep), "
                                "single-stream entry points with host clouds in / out (PCIe inside the timed region)",
                    "stage_ms_per_sweep": {"features": round(stage[0] / K * 1e3, 4), "odometry": round(stage[1] / K * 1e3, 4), "mapping": round(stage[2] / K * 1e3, 4)},
                    "mean_map_iterations": round(float(np.mean([s["iterations"] for s in stats])), 2),

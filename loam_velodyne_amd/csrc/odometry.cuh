@@ -105,15 +105,19 @@ class OdometryBatch {
   // clouds of all streams, concatenated: [corner_0 .. corner_{ns-1} | surf_0 .. surf_{ns-1}], offsets 2*ns+1
   DevBuf<float4> cur_, last_, prev_;   // being written | handed on by the last call | handed on by the call before (still read by its consumer)
   std::vector<uint32_t> h_cur_off_, h_last_off_;
-  DevBuf<uint32_t> d_cur_off_;
   SubMapIndexBatch index_;
   DevBuf<int> ind_;
-  DevBuf<OdomProblem> prob_;
   DevBuf<double> part_;
-  PinBuf<OdomProblem> h_prob_, h_mirror_;
-  DevBuf<ToEndParams> te_;
-  PinBuf<ToEndParams> h_te_;
-  PinBuf<uint32_t> h_off_pin_;
+  PinBuf<OdomProblem> h_mirror_;
+  // what a call sends up before its first kernel — the problems, the re-projection parameters, the cloud offsets — is ONE block in
+  // pinned memory and ONE copy (three copies were three ~7 us commands at the head of the odometry chain, the pipeline's longest)
+  template <class T> struct View { T* p = nullptr; };
+  DevBuf<char> up_dev_;
+  PinBuf<char> up_host_;
+  size_t up_bytes_ = 0;
+  View<OdomProblem> prob_, h_prob_;
+  View<ToEndParams> te_, h_te_;
+  View<uint32_t> d_cur_off_, h_off_pin_;
   PinBuf<float4> h_stage_;
   DevBuf<float4> up_[4], tmp_cloud_;
   uint32_t lm_slots_[2] = {0, 0};   // workgroups of k_odom_lm<1> / <2> the device holds at once (occupancy x CUs)

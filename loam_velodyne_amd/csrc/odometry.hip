@@ -617,22 +617,29 @@ __global__ void k_te_patch(const OdomProblem* __restrict__ probs, uint32_t na, T
 __global__ __launch_bounds__(256) void k_transform_to_end_batch(float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off,
                                                                 uint32_t K, uint32_t ns, const ToEndParams* __restrict__ params,
                                                                 const float4* __restrict__ src_c, const float4* __restrict__ src_s,
-                                                                uint32_t n_corner_all) {
+                                                                uint32_t n_corner_all, uint32_t* __restrict__ bounds) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t lo = 0, hi = K;
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (off[mid] <= i) lo = mid; else hi = mid;
+  const bool active = i < n;
+  uint32_t lo = 0;
+  float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    uint32_t hi = K;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    const ToEndParams P = params[lo % ns];
+    if (src_c) {
+      const float4 p = i < n_corner_all ? src_c[i] : src_s[i - n_corner_all];
+      q = P.enabled ? to_end_point(p, P) : p;
+      pts[i] = q;
+    } else {
+      q = pts[i];
+      if (P.enabled) { q = to_end_point(q, P); pts[i] = q; }
+    }
   }
-  const ToEndParams P = params[lo % ns];
-  if (src_c) {
-    const float4 p = i < n_corner_all ? src_c[i] : src_s[i - n_corner_all];
-    pts[i] = P.enabled ? to_end_point(p, P) : p;
-    return;
-  }
-  if (!P.enabled) return;
-  pts[i] = to_end_point(pts[i], P);
+  // the clouds are indexed next (SubMapIndexBatch): their bounds are gathered here, one launch and one pass over the points less
+  if (bounds) cloud_bounds_update(bounds, active, lo, q.x, q.y, q.z);
 }
 
 // segment k of dst = re-projected copy of src[k] with the parameters of stream sid[k]
@@ -664,14 +671,19 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
   index_.cell_size = 2.1f;
   if (const char* e = getenv("LOAMX_ODOM_CELL")) { const float v = (float)atof(e); if (v >= 0.25f && v <= 16.f) index_.cell_size = v; }
   index_.init(st_);
-  prob_.reserve(n_streams);
   h_mirror_.reserve(n_streams);
   part_.reserve((size_t)n_streams * OD_PART_STRIDE);
-  h_prob_.reserve(n_streams);
-  te_.reserve(n_streams);
-  h_te_.reserve(n_streams);
-  d_cur_off_.reserve(2 * n_streams + 2);
-  h_off_pin_.reserve(2 * n_streams + 2);
+  {
+    auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_te = up256(sizeof(OdomProblem) * n_streams), o_off = o_te + up256(sizeof(ToEndParams) * n_streams);
+    up_bytes_ = o_off + up256(sizeof(uint32_t) * (2 * (size_t)n_streams + 2));
+    up_dev_.reserve(up_bytes_);
+    up_host_.reserve(up_bytes_);
+    memset(up_host_.p, 0, up_bytes_);
+    prob_.p = (OdomProblem*)up_dev_.p; h_prob_.p = (OdomProblem*)up_host_.p;
+    te_.p = (ToEndParams*)(up_dev_.p + o_te); h_te_.p = (ToEndParams*)(up_host_.p + o_te);
+    d_cur_off_.p = (uint32_t*)(up_dev_.p + o_off); h_off_pin_.p = (uint32_t*)(up_host_.p + o_off);
+  }
   h_cur_off_.assign(2 * n_streams + 1, 0);
   h_last_off_.assign(2 * n_streams + 1, 0);
 }
@@ -810,11 +822,9 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   // parameters (those of the optimising streams are completed on the device, k_te_patch)
   for (uint32_t s = 0; s < ns; s++) h_te_.p[s] = to_end_params(s, rc[s] == LOAMX_OK);   // a first sweep is stored as it came (:200-201)
   memcpy(h_off_pin_.p, h_cur_off_.data(), sizeof(uint32_t) * (K + 1));
-  LX_HIP(hipMemcpyAsync(d_cur_off_.p, h_off_pin_.p, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st_));
-  LX_HIP(hipMemcpyAsync(te_.p, h_te_.p, sizeof(ToEndParams) * ns, hipMemcpyHostToDevice, st_));
-  index_.prepare(K);   // bounding-box accumulators of the NEXT index: reset here, far ahead of the tail
+  LX_HIP(hipMemcpyAsync(up_dev_.p, up_host_.p, up_bytes_, hipMemcpyHostToDevice, st_));   // problems + re-projection parameters + offsets
+  index_.prepare(K);   // bounding-box accumulators of the NEXT index (a launch only the first time: every build leaves them reset)
   const bool index_prepared = true;
-  if (na) LX_HIP(hipMemcpyAsync(prob_.p, h_prob_.p, sizeof(OdomProblem) * na, hipMemcpyHostToDevice, st_));
   if (!ev_up_) LX_HIP(hipEventCreateWithFlags(&ev_up_, hipEventDisableTiming));
   LX_HIP(hipEventRecord(ev_up_, st_));
   up_pending_ = true;
@@ -851,9 +861,10 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   }
   // ---- re-project to the sweep end (:651-652), hand over as "last" clouds and rebuild their index (:654-664): enqueued
   // right behind the iterations; the host only waits for the poses
+  static const bool fuse_bounds = !(getenv("LOAMX_BB_FUSED") && atoi(getenv("LOAMX_BB_FUSED")) == 0);   // diagnostic: 0 = separate k_bb_bbox launch
   if (n_all)
     hipLaunchKernelGGL(k_transform_to_end_batch, dim3((n_all + 255) / 256), dim3(256), 0, st_, cur_.p, n_all, d_cur_off_.p, K, ns, te_.p, src_c,
-                       src_s, n_corner_all);
+                       src_s, n_corner_all, fuse_bounds ? index_.d_bounds() : nullptr);
   // three rotating buffers: the clouds this call hands on stay untouched during the next two calls (a registration reads them
   // while the odometry chain is already one or two sweeps ahead — Pipeline)
   {
@@ -863,7 +874,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
     last_.p = p; last_.cap = c;
   }
   h_last_off_ = h_cur_off_;
-  index_.build(last_.p, h_last_off_.data(), K, d_cur_off_.p, index_prepared);
+  index_.build(last_.p, h_last_off_.data(), K, d_cur_off_.p, index_prepared, /*bounds_done=*/fuse_bounds && n_all > 0);
   if (!ev_tail_) LX_HIP(hipEventCreateWithFlags(&ev_tail_, hipEventDisableTiming));
   LX_HIP(hipEventRecord(ev_tail_, st_));
   tail_pending_ = true;

@@ -50,13 +50,56 @@ struct GridDescB {
   uint32_t cell_base;   // first entry of this cloud's cell table
   uint32_t pt_base;     // off[c]
 };
+// order-preserving float <-> uint32 (bounds accumulated with integer atomicMin / atomicMax)
+__device__ inline uint32_t enc_f32(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float dec_f32(uint32_t u) {
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __uint_as_float(u);
+}
+// Bounds accumulators: six words per cloud, each in a cache line of its own (BB_STRIDE words apart) — atomics on one line serialise
+// (~12 ns each, measured), and a producer kernel sends a few hundred per word.
+constexpr uint32_t BB_STRIDE = 32;
+__device__ __host__ inline uint32_t bb_word(uint32_t c, uint32_t a) { return (6u * c + a) * BB_STRIDE; }
+// A producer kernel folds its output points into the bounds of cloud c (SubMapIndexBatch::d_bounds) as it writes them: one
+// reduction per wave when the wave's points belong to one cloud (all but the few waves that straddle a boundary), six atomics per wave.
+// Every lane of the wave must call (inactive lanes with active = false).
+__device__ inline void cloud_bounds_update(uint32_t* __restrict__ enc, bool active, uint32_t c, float x, float y, float z) {
+  const unsigned long long m = __ballot(active);
+  if (!m) return;
+  const uint32_t c0 = (uint32_t)__shfl((int)c, __ffsll((long long)m) - 1, 64);
+  if (__ballot(active && c != c0) == 0ull) {
+    float mn[3] = {active ? x : FLT_MAX, active ? y : FLT_MAX, active ? z : FLT_MAX};
+    float mx[3] = {active ? x : -FLT_MAX, active ? y : -FLT_MAX, active ? z : -FLT_MAX};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        mn[a] = fminf(mn[a], __shfl_xor(mn[a], d, 64));
+        mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, 64));
+      }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) { atomicMin(&enc[bb_word(c0, a)], enc_f32(mn[a])); atomicMax(&enc[bb_word(c0, 3 + a)], enc_f32(mx[a])); }
+    }
+  } else if (active) {
+    atomicMin(&enc[bb_word(c, 0)], enc_f32(x)); atomicMin(&enc[bb_word(c, 1)], enc_f32(y)); atomicMin(&enc[bb_word(c, 2)], enc_f32(z));
+    atomicMax(&enc[bb_word(c, 3)], enc_f32(x)); atomicMax(&enc[bb_word(c, 4)], enc_f32(y)); atomicMax(&enc[bb_word(c, 5)], enc_f32(z));
+  }
+}
 class SubMapIndexBatch {
  public:
   void init(hipStream_t st);
   // d_pts: concatenated points; h_off: K+1 host offsets.  Asynchronous on the stream.
   // d_off_ready: the K+1 offsets already on the device (skips the upload); prepared: prepare(K) was enqueued earlier
-  void build(const float4* d_pts, const uint32_t* h_off, uint32_t K, const uint32_t* d_off_ready = nullptr, bool prepared = false);
+  // bounds_done: the kernel that produced d_pts has folded them into d_bounds() already (cloud_bounds_update; prepare(K) came first)
+  void build(const float4* d_pts, const uint32_t* h_off, uint32_t K, const uint32_t* d_off_ready = nullptr, bool prepared = false,
+             bool bounds_done = false);
   void prepare(uint32_t K);
+  uint32_t* d_bounds() const { return enc_.p; }
   float cell_size = 1.05f;   // initial cell edge (grown by 1.25x while the cell table would exceed its budget)
   const float4* sorted() const { return sorted_.p; }
   const uint32_t* cell_start(uint32_t c) const { return cell_start_.p; }   // tables are addressed through desc(c)->cell_base
@@ -66,6 +109,8 @@ class SubMapIndexBatch {
  private:
   hipStream_t st_ = nullptr;
   DevBuf<float4> sorted_;
+  void reset_bounds_(uint32_t K);
+  uint32_t enc_ready_ = 0;   // clouds whose bounds accumulators are known to be reset
   DevBuf<uint32_t> cell_of_, rank_of_, cell_start_, cursor_, tile_sums_, scratch_, d_off_, enc_;   // cursor_: the cell counters (empty between builds)
   DevBuf<GridDescB> d_desc_;
   PinBuf<uint32_t> h_off_pin_;

@@ -22,14 +22,6 @@ namespace loamx {
 // ----------------------------------------------------------------------------------------------------------------
 // small helpers
 // ----------------------------------------------------------------------------------------------------------------
-__device__ inline uint32_t enc_f32(float f) {
-  uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ inline float dec_f32(uint32_t u) {
-  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-  return __uint_as_float(u);
-}
 
 __global__ void k_init_bbox(uint32_t* scratch) {
   const uint32_t t = threadIdx.x;
@@ -166,7 +158,7 @@ void SubMapIndex::build(const float4* d_pts, uint32_t n) {
 // ----------------------------------------------------------------------------------------------------------------
 __global__ void k_bb_init(uint32_t* enc, uint32_t K) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 6 * K) enc[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+  if (i < 6 * K) enc[i * BB_STRIDE] = (i % 6) < 3 ? 0xffffffffu : 0u;
 }
 // grid = (blocks, K)
 __global__ __launch_bounds__(256) void k_bb_bbox(const float4* __restrict__ pts, const uint32_t* __restrict__ off, uint32_t* __restrict__ enc) {
@@ -198,11 +190,12 @@ __global__ __launch_bounds__(256) void k_bb_bbox(const float4* __restrict__ pts,
     const int a = threadIdx.x;
     float v = red[0][a];
     for (int w = 1; w < 4; w++) v = a < 3 ? fminf(v, red[w][a]) : fmaxf(v, red[w][a]);
-    if (a < 3) atomicMin(&enc[6 * c + a], enc_f32(v)); else atomicMax(&enc[6 * c + a], enc_f32(v));
+    if (a < 3) atomicMin(&enc[bb_word(c, a)], enc_f32(v)); else atomicMax(&enc[bb_word(c, a)], enc_f32(v));
   }
 }
 // one thread per cloud (one workgroup, K <= 4096 in rounds of 1024): grid descriptors within the per-cloud cell budget, table bases by a scan
-__global__ __launch_bounds__(1024) void k_bb_setup(const uint32_t* __restrict__ enc, const uint32_t* __restrict__ off, uint32_t K, GridDescB* __restrict__ desc,
+// (leaves the bounds accumulators reset for the next build: k_bb_init runs only when K grows)
+__global__ __launch_bounds__(1024) void k_bb_setup(uint32_t* __restrict__ enc, const uint32_t* __restrict__ off, uint32_t K, GridDescB* __restrict__ desc,
                                                    uint32_t* __restrict__ scratch, uint32_t max_cells_total, float cell0) {
   __shared__ uint32_t lds[17];
   const uint32_t budget = max_cells_total / (K ? K : 1);
@@ -217,7 +210,7 @@ __global__ __launch_bounds__(1024) void k_bb_setup(const uint32_t* __restrict__ 
       d.g.ncell = 1;   // an empty cloud: a 1-cell grid
       if (off[c + 1] != off[c]) {
         float mn[3], mx[3];
-        for (int a = 0; a < 3; a++) { mn[a] = dec_f32(enc[6 * c + a]); mx[a] = dec_f32(enc[6 * c + 3 + a]); }
+        for (int a = 0; a < 3; a++) { mn[a] = dec_f32(enc[bb_word(c, a)]); mx[a] = dec_f32(enc[bb_word(c, 3 + a)]); }
         float h = cell0;
         for (;;) {
           d.g.inv_h = 1.0f / h;
@@ -230,6 +223,8 @@ __global__ __launch_bounds__(1024) void k_bb_setup(const uint32_t* __restrict__ 
           h *= 1.25f;
         }
       }
+#pragma unroll
+      for (int a = 0; a < 6; a++) enc[bb_word(c, a)] = a < 3 ? 0xffffffffu : 0u;
     }
     uint32_t tot;
     const uint32_t ex = block_excl_scan(c < K ? d.g.ncell : 0u, lds, tot);
@@ -313,16 +308,21 @@ void SubMapIndexBatch::init(hipStream_t st) {
 // points depend on): build(..., prepared = true) then skips that launch
 void SubMapIndexBatch::prepare(uint32_t K) {
   LX_REQUIRE(K >= 1 && K <= 4096, "too many clouds in one index batch");
-  enc_.reserve((size_t)6 * K + 6);
-  hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K);
+  reset_bounds_(K);
+}
+void SubMapIndexBatch::reset_bounds_(uint32_t K) {
+  if (K <= enc_ready_) return;   // every build's k_bb_setup leaves the accumulators of its K clouds reset
+  const uint32_t cap = std::max<uint32_t>(K, 64u);
+  enc_.reserve(((size_t)6 * cap + 6) * BB_STRIDE);   // (growing discards the contents: all of it is initialised below)
+  hipLaunchKernelGGL(k_bb_init, dim3((6 * cap + 255) / 256), dim3(256), 0, st_, enc_.p, cap);
+  enc_ready_ = cap;
 }
 
-void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_t K, const uint32_t* d_off_ready, bool prepared) {
+void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_t K, const uint32_t* d_off_ready, bool prepared, bool bounds_done) {
   LX_REQUIRE(K >= 1 && K <= 4096, "too many clouds in one index batch");
   const uint32_t n = h_off[K];
   d_off_.reserve(K + 2);
   d_desc_.reserve(K + 1);
-  enc_.reserve((size_t)6 * K + 6);
   const uint32_t* d_off = d_off_ready;   // the caller may already hold the offsets on the device
   if (!d_off) {
     h_off_pin_.reserve(K + 2);
@@ -338,11 +338,12 @@ void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_
     cursor_.reserve((size_t)LX_MAX_CELLS + 2);
     LX_HIP(hipMemsetAsync(cursor_.p, 0, sizeof(uint32_t) * cursor_.cap, st_));
   }
-  if (!prepared) hipLaunchKernelGGL(k_bb_init, dim3((6 * K + 255) / 256), dim3(256), 0, st_, enc_.p, K);
+  (void)prepared;
+  reset_bounds_(K);
   uint32_t max_len = 0;
   for (uint32_t c = 0; c < K; c++) max_len = std::max(max_len, h_off[c + 1] - h_off[c]);
   const uint32_t nbx = std::min<uint32_t>(std::max<uint32_t>((max_len + 255) / 256, 1u), 32u);
-  hipLaunchKernelGGL(k_bb_bbox, dim3(nbx, K), dim3(256), 0, st_, d_pts, d_off, enc_.p);
+  if (!bounds_done) hipLaunchKernelGGL(k_bb_bbox, dim3(nbx, K), dim3(256), 0, st_, d_pts, d_off, enc_.p);
   hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1024), 0, st_, enc_.p, d_off, K, d_desc_.p, scratch_.p, LX_MAX_CELLS, cell_size);
   if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, d_desc_.p, cell_of_.p, cursor_.p, rank_of_.p);
   // (the cell counters are cleared behind the scan: they are empty again when the next build starts)

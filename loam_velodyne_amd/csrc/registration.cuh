@@ -63,14 +63,22 @@ __device__ inline float dec_f32(uint32_t u) {
 // (~12 ns each, measured), and a producer kernel sends a few hundred per word.
 constexpr uint32_t BB_STRIDE = 32;
 __device__ __host__ inline uint32_t bb_word(uint32_t c, uint32_t a) { return (6u * c + a) * BB_STRIDE; }
-// A producer kernel folds its output points into the bounds of cloud c (SubMapIndexBatch::d_bounds) as it writes them: one
-// reduction per wave when the wave's points belong to one cloud (all but the few waves that straddle a boundary), six atomics per wave.
-// Every lane of the wave must call (inactive lanes with active = false).
+// A producer kernel folds its output points into the bounds of cloud c (SubMapIndexBatch::d_bounds) as it writes them: reduced per wave
+// (shuffles) and per workgroup (LDS) when their points belong to one cloud — all but the few waves that straddle a boundary — so a
+// cloud's words see one atomic per workgroup.  EVERY thread of the workgroup must call (inactive ones with active = false);
+// workgroups of at most 1024 threads.
 __device__ inline void cloud_bounds_update(uint32_t* __restrict__ enc, bool active, uint32_t c, float x, float y, float z) {
+  constexpr uint32_t NONE = 0xffffffffu, MIXED = 0xfffffffeu;
+  __shared__ float s_red[16][6];
+  __shared__ uint32_t s_cloud[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (int)((blockDim.x + 63) >> 6);
   const unsigned long long m = __ballot(active);
-  if (!m) return;
-  const uint32_t c0 = (uint32_t)__shfl((int)c, __ffsll((long long)m) - 1, 64);
-  if (__ballot(active && c != c0) == 0ull) {
+  uint32_t wc = NONE;
+  if (m) {
+    const uint32_t c0 = (uint32_t)__shfl((int)c, __ffsll((long long)m) - 1, 64);
+    wc = __ballot(active && c != c0) == 0ull ? c0 : MIXED;
+  }
+  if (wc < MIXED) {
     float mn[3] = {active ? x : FLT_MAX, active ? y : FLT_MAX, active ? z : FLT_MAX};
     float mx[3] = {active ? x : -FLT_MAX, active ? y : -FLT_MAX, active ? z : -FLT_MAX};
 #pragma unroll
@@ -81,13 +89,29 @@ __device__ inline void cloud_bounds_update(uint32_t* __restrict__ enc, bool acti
         mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, 64));
       }
     }
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
 #pragma unroll
-      for (int a = 0; a < 3; a++) { atomicMin(&enc[bb_word(c0, a)], enc_f32(mn[a])); atomicMax(&enc[bb_word(c0, 3 + a)], enc_f32(mx[a])); }
+      for (int a = 0; a < 3; a++) { s_red[wid][a] = mn[a]; s_red[wid][3 + a] = mx[a]; }
     }
-  } else if (active) {
+  } else if (wc == MIXED && active) {   // a wave across a cloud boundary: every lane for itself
     atomicMin(&enc[bb_word(c, 0)], enc_f32(x)); atomicMin(&enc[bb_word(c, 1)], enc_f32(y)); atomicMin(&enc[bb_word(c, 2)], enc_f32(z));
     atomicMax(&enc[bb_word(c, 3)], enc_f32(x)); atomicMax(&enc[bb_word(c, 4)], enc_f32(y)); atomicMax(&enc[bb_word(c, 5)], enc_f32(z));
+  }
+  if (lane == 0) s_cloud[wid] = wc;
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = (int)threadIdx.x;
+    for (int w = 0; w < nw; w++) {
+      const uint32_t cw = s_cloud[w];
+      if (cw >= MIXED) continue;
+      bool first = true;
+      for (int v = 0; v < w; v++) first = first && s_cloud[v] != cw;
+      if (!first) continue;   // (combined with an earlier wave of the same cloud)
+      float r = s_red[w][a];
+      for (int u = w + 1; u < nw; u++)
+        if (s_cloud[u] == cw) r = a < 3 ? fminf(r, s_red[u][a]) : fmaxf(r, s_red[u][a]);
+      if (a < 3) atomicMin(&enc[bb_word(cw, a)], enc_f32(r)); else atomicMax(&enc[bb_word(cw, a)], enc_f32(r));
+    }
   }
 }
 class SubMapIndexBatch {

@@ -42,3 +42,16 @@ def small_world():
 def sorted_rows(a):
     a = np.asarray(a)
     return a[np.lexsort(a.T[::-1])]
+
+
+def collinear_previous_surf(f1):
+    """a previous less-flat cloud whose points all lie on ONE straight line through the current flat features (dyadic coordinates: the
+    differences, and with them every tripod's cross product, are exact zeros) — 24 points on each of the 16 rings, no two at the same
+    place, so no neighbour search meets a tie"""
+    fl = f1["flat"]
+    c0 = np.round(fl[len(fl) // 2, :3].astype(np.float64) * 4) / 4
+    rows = [[c0[0] + 0.5 * t, c0[1], c0[2] + 0.25 * t, r + 0.01 * k]
+            for r in range(16) for k in range(24) for t in [(-768 + 64 * k + r) / 256.0]]   # (distinct for every (ring, k))
+    line = np.array(rows, np.float32)
+    assert np.array_equal(line[:, :3].astype(np.float64), np.array(rows)[:, :3]) and len(np.unique(line[:, :3], axis=0)) == len(line)
+    return line

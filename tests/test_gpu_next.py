@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_py as op
-from conftest import POSE_TOL
+from conftest import POSE_TOL, collinear_previous_surf
 from loam_velodyne_amd import loamx, synth
 
 pytestmark = pytest.mark.gpu
@@ -136,3 +136,31 @@ def test_nan_rows_through_the_odometry_solve(orc, small_world):
     # search returns is a property of the search structure — the kd-tree's traversal order there, the lowest index here — and once
     # the NaN rows are deselected the two runs optimise over different tripods.  Both recover the motion:)
     assert np.abs(ood.transform - god.transform).max() < 0.05
+
+
+def test_reset_branch_device_equals_oracle(orc, small_world):
+    """The non-finite reset (BasicLaserOdometry.cpp:606-612) taken WITHOUT a distance tie, so that device and oracle can be compared
+    with each other: the previous surface cloud is a straight line (conftest.collinear_previous_surf — the
+    reference's own build takes the branch on the same input, ::test_reset_branch_through_collinear_tripods), every plane tripod is
+    collinear, its rows are NaN and selected in iterations 0-4, the transform is reset five times, then the edge rows carry the run."""
+    poses = synth.trajectory(2)
+    sws = [synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=100 + k, az_steps=900) for k in range(2)]
+    sr = op.ScanRegistration(orc)
+    f0, f1 = sr.process(sws[0].points, sws[0].ring_sizes), sr.process(sws[1].points, sws[1].ring_sizes)
+    f0d = dict(f0)
+    f0d["less_flat"] = collinear_previous_surf(f1)
+    seed = np.float32([0.001, 0.002, -0.001, 0.05, 0.0, -0.3])
+    ood, god, gzd = op.LaserOdometry(orc), loamx.LaserOdometry(), loamx.LaserOdometry()
+    ood.set_features(f0d)
+    ood.process()
+    ood.set_features(f1)
+    ood.set_transform(seed)
+    ood.process()
+    for g, start in ((god, seed), (gzd, np.zeros(6, np.float32))):
+        g.process(f0d)
+        g.set_transform(start)
+        g.process(f1)
+    assert np.array_equal(god.transform, gzd.transform) and not np.array_equal(god.transform, seed)   # reset taken on the device
+    assert np.all(np.isfinite(god.transform))
+    assert god.stats()["iterations"] == ood.stats()["iterations"] and god.stats()["sel"] == ood.stats()["sel"]
+    assert np.abs(ood.transform - god.transform).max() < 1e-5 and np.abs(ood.transform_sum - god.transform_sum).max() < 1e-5

@@ -11,6 +11,7 @@ import os
 import numpy as np
 import pytest
 
+import conftest
 import oracle_py as op
 from loam_velodyne_amd import loamx, synth
 
@@ -247,6 +248,31 @@ def test_non_finite_system_takes_the_reset_branch(orc, small_world):
     # iterations after the fifth are ordinary ones.)
     assert np.array_equal(o.transform, z.transform) and not np.array_equal(o.transform, seed)
     assert 5 < o.stats()["iterations"] <= 25 and np.all(np.isfinite(o.transform))
+
+
+@needs_od
+def test_reset_branch_through_collinear_tripods(orc, small_world):
+    """BasicLaserOdometry.cpp:606-612 once more, without any distance tie (the device can be compared on this one,
+    tests/test_gpu_next.py): the previous surface cloud is a straight line, so every plane tripod is collinear, its normal 0 / 0 = NaN
+    (:437-470), the rows selected while s = 1 (iterations 0-4), the system non-finite, the transform reset five times; from the sixth
+    iteration on the NaN weights deselect those rows and the edge rows alone carry the run."""
+    poses = synth.trajectory(2)
+    sws = [synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=100 + k, az_steps=900) for k in range(2)]
+    sr = op.ScanRegistration(orc)
+    f0, f1 = sr.process(sws[0].points, sws[0].ring_sizes), sr.process(sws[1].points, sws[1].ring_sizes)
+    f0d = dict(f0)
+    f0d["less_flat"] = conftest.collinear_previous_surf(f1)
+    seed = np.float32([0.001, 0.002, -0.001, 0.05, 0.0, -0.3])
+    o, r, z = op.LaserOdometry(orc), op.RefLaserOdometry(), op.LaserOdometry(orc)
+    for od, start in ((o, seed), (r, seed), (z, np.zeros(6, np.float32))):
+        od.set_features(f0d)
+        od.process()
+        od.set_features(f1)
+        od.set_transform(start)
+        od.process()
+    assert np.array_equal(o.transform, r.transform) and np.array_equal(o.transform_sum, r.transform_sum)
+    assert np.array_equal(o.transform, z.transform) and not np.array_equal(o.transform, seed)      # the seed was wiped: the reset was taken
+    assert o.stats()["iterations"] > 5 and o.stats()["sel"] >= 10 and np.all(np.isfinite(o.transform))
 
 
 def _run_mapping(orc, world, sensor, az, n, cfg, offset=(0.0, 0.0, 0.0), imu=False):

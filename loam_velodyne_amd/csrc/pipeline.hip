@@ -408,8 +408,10 @@ class Pipeline {
   // state machines take over what the projection loops left behind and are reset for the next sweep (processScanlines:
   // reset(scanTime), updateIMUTransform), and the binned clouds are handed to the slot's feature extractor with their ring
   // sizes.  Idempotent; called in step order from stage_step*(t + 1) and launch_features(t), whichever comes first.
+  std::mutex raw_mu;   // finalize_raw(t) is reached from the stager (stage_step*(t + 1)) and from the thread that launches the features of t
   void finalize_raw(uint32_t t) {
     if (!streaming) return;
+    std::lock_guard<std::mutex> lk(raw_mu);
     RawSlot& R = rawslot[t % RING];
     if (!R.raw || R.finalized) return;
     LX_HIP(hipEventSynchronize(R.ev_ingest));

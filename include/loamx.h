@@ -50,6 +50,7 @@ extern "C" {
 #define LOAMX_E_CAPACITY (-2)
 #define LOAMX_E_HIP (-3)
 #define LOAMX_E_NOGPU (-4)
+#define LOAMX_E_UNSUPPORTED (-5) /* an optional dependency was left out of this build (the multi-GPU exchanges without RCCL) */
 
 /* caller-owned cloud description (input or output) */
 typedef struct loamx_cloud {

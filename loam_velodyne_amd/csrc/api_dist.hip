@@ -14,8 +14,9 @@
 // One process per GPU; the 128-byte ncclUniqueId travels between the processes by the host's own means (a file, MPI,
 // a socket — loam_velodyne_amd/launch.py uses a file).
 #include "common.h"
-#include <rccl/rccl.h>
 #include <memory>
+#ifndef LOAMX_NO_RCCL
+#include <rccl/rccl.h>
 
 namespace loamx {
 #define LX_NCCL(expr)                                                                                                 \
@@ -26,6 +27,25 @@ namespace loamx {
                                             std::to_string(__LINE__) + ")");                                         \
   } while (0)
 }  // namespace loamx
+#else
+// make NO_RCCL=1 (a ROCm install without RCCL: the single-GPU drop-in needs none of it): the entry points below stay exported, the two
+// exchanges and the communicator answer LOAMX_E_UNSUPPORTED, the host-side layout functions (shard_of / pack / unpack) work as always.
+// The few RCCL names the code below mentions are declared here so that it reads the same in both builds (they do nothing).
+struct ncclUniqueId { char internal[LOAMX_DIST_ID_BYTES]; };
+typedef void* ncclComm_t;
+typedef int ncclResult_t;
+enum { ncclFloat = 0, ncclUint32 = 1, ncclSum = 0 };
+#define LX_NCCL(expr) do { (void)(expr); throw ::loamx::Error(LOAMX_E_UNSUPPORTED, "libloamx was built without RCCL (make NO_RCCL=1): " #expr); } while (0)
+static inline ncclResult_t ncclGetUniqueId(ncclUniqueId*) { return 1; }
+static inline ncclResult_t ncclCommInitRank(ncclComm_t*, int, ncclUniqueId, int) { return 1; }
+static inline ncclResult_t ncclCommDestroy(ncclComm_t) { return 0; }
+static inline ncclResult_t ncclCommCount(ncclComm_t, int*) { return 1; }
+static inline ncclResult_t ncclGroupStart() { return 1; }
+static inline ncclResult_t ncclGroupEnd() { return 1; }
+static inline ncclResult_t ncclBroadcast(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) { return 1; }
+static inline ncclResult_t ncclAllGather(const void*, void*, size_t, int, ncclComm_t, hipStream_t) { return 1; }
+static inline ncclResult_t ncclAllReduce(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) { return 1; }
+#endif
 
 using namespace loamx;
 

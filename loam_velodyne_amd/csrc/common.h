@@ -10,7 +10,9 @@
 #include <vector>
 #include <stdexcept>
 #include "../../include/loamx.h"
+#ifndef LOAMX_NO_ROCTX   // (make NO_ROCTX=1: a ROCm install without the rocprofiler SDK; the trace ranges become no-ops)
 #include <rocprofiler-sdk-roctx/roctx.h>
+#endif
 
 namespace loamx {
 
@@ -126,8 +128,12 @@ void select_device(int device);   // throws LOAMX_E_NOGPU
 // roctx range around a host-side stage (tracing): shows up in `rocprofv3 --marker-trace` next to the kernels the
 // stage enqueues; costs two calls into an unloaded tool library otherwise
 struct TraceRange {
+#ifndef LOAMX_NO_ROCTX
   explicit TraceRange(const char* name) { roctxRangePush(name); }
   ~TraceRange() { roctxRangePop(); }
+#else
+  explicit TraceRange(const char*) {}
+#endif
   TraceRange(const TraceRange&) = delete;
   TraceRange& operator=(const TraceRange&) = delete;
 };

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LOAMX_LIB") or os.path.join(_HERE, "libloamx.so")   # LOAMX_LIB: a diagnostic build (time stamps inside kernels)
 
-OK, SKIPPED, E_INVALID, E_CAPACITY, E_HIP, E_NOGPU = 0, 1, -1, -2, -3, -4
+OK, SKIPPED, E_INVALID, E_CAPACITY, E_HIP, E_NOGPU, E_UNSUPPORTED = 0, 1, -1, -2, -3, -4, -5
 
 
 class Cloud(C.Structure):

@@ -89,6 +89,13 @@ def main():
 
     ns, K, W = args.streams, args.steps, args.warmup
     T = 1 + W + K   # first sweep of a stream only initialises the odometry
+    # The library's look-ahead runs the odometry (and the features) of up to LOOK steps beyond the step being registered.  A window that
+    # ended with the last staged sweep would start with LOOK steps of look-ahead work already done and do none for the steps after it:
+    # K registrations but only K - LOOK odometry passes inside the timed region.  So LOOK more steps are staged than are run, and the
+    # window closes only when the look-ahead has drained (loamx_pipeline_drain_lookahead): what was done ahead before the window opens
+    # is done ahead, for the steps after it, before it closes — K passes of every stage inside, a steady-state window.
+    LOOK = 2
+    T_all = T + LOOK
     world_model = synth.World(half_extent=125.0)
 
     # ---- frozen map: generated on rank 0, broadcast over RCCL, adopted in place by the library
@@ -128,13 +135,13 @@ def main():
             bcast_via = "torch.distributed broadcast (native path failed: %s)" % repr(e)[:160]
 
     # ---- this rank's streams and staged sweeps (distinct trajectories per rank and stream)
-    sweeps = [[None] * ns for _ in range(T)]
+    sweeps = [[None] * ns for _ in range(T_all)]
     starts = []
     for s, gs in enumerate(lxdist.stream_ids(rank, world, ns)):
         start = lxdist.stream_start(gs)
-        poses = synth.trajectory(T, start=start)
+        poses = synth.trajectory(T_all, start=start)
         starts.append(np.array([0, 0, 0, start[0], start[1], start[2]], np.float32))
-        for t in range(T):
+        for t in range(T_all):
             sw = synth.make_sweep(world_model, args.sensor, poses[t], poses[t + 1], seed=1000 * gs + t)
             sweeps[t][s] = (sw.points, sw.ring_sizes)
     n_points = len(sweeps[0][0][0])
@@ -162,7 +169,7 @@ def main():
             p.set_frozen_device(map_t.data_ptr(), n_corner, map_t.data_ptr() + 16 * n_corner, n_surf)
             for k in range(per):
                 p.set_state(k, aft=starts[h * per + k])
-            p.upload([[sweeps[t][h * per + k] for k in range(per)] for t in range(T)])
+            p.upload([[sweeps[t][h * per + k] for k in range(per)] for t in range(T_all)])
             p.set_timing(True)
             pipes.append(p)
 
@@ -227,6 +234,8 @@ def main():
                     r["res_launches"] += tm["residual_launches"]
                     r["q_iters"] += tm["query_iterations"]
                     r["queries"] += tm["queries"]
+        for p in pipes:   # the look-ahead work for the LOOK steps after the window belongs inside it (see LOOK above)
+            p.drain_lookahead()
         sync_all()
         r["elapsed"] = lxdist.max_over_ranks(time.perf_counter() - t0, dist, dev)
         r["pipes"] = pipes
@@ -349,6 +358,9 @@ def main():
                                       "registration": round(stage[2] / S, 4), "gpu_step": round(stage[3] / S, 4)},
                 "ms_per_step_inside_step_call": round(in_step / K * 1e3, 4),
                 "stage_timing_sampling": f"HIP events on every {TIMING_PERIOD}th step of the timed region ({n_sampled} of {K} steps)",
+                "timed_window": f"steady state: {LOOK} more steps are staged than run and the window closes after loamx_pipeline_drain_lookahead + "
+                                "synchronize, so the look-ahead work done before it opens (odometry / features of the next steps) is matched by "
+                                f"the same work for the {LOOK} steps after it: K passes of every stage inside the timed region",
                 "map_broadcast_ms": round(t_bcast * 1e3, 3),
                 "map_broadcast_via": bcast_via,
                 "map_epoch_steps": E,
@@ -519,10 +531,11 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
     D2H of each step's registered clouds (asynchronous, alternating device buffers, one pinned block)."""
     from concurrent.futures import ThreadPoolExecutor
     T = 1 + W + K
+    T_all = min(len(sweeps), T + 2)   # staged beyond the last step that runs: the look-ahead's work stays inside the window (main(): LOOK)
     n_pts = len(sweeps[0][0][0])
-    assert all(len(sweeps[t][s][0]) == n_pts for t in range(T) for s in range(ns))
+    assert all(len(sweeps[t][s][0]) == n_pts for t in range(T_all) for s in range(ns))
     pinned = []
-    for t in range(T):   # the streams' clouds of a step lie back to back: the library hands the block over in one copy
+    for t in range(T_all):   # the streams' clouds of a step lie back to back: the library hands the block over in one copy
         blk = torch.empty((ns * n_pts, 4), dtype=torch.float32).pin_memory()
         for s in range(ns):
             blk[s * n_pts:(s + 1) * n_pts].copy_(torch.from_numpy(np.ascontiguousarray(sweeps[t][s][0], np.float32)))
@@ -540,7 +553,7 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
     import ctypes as C
     L = loamx.lib()
     stage_args = []
-    for t in range(T):
+    for t in range(T_all):
         pts = [loamx.as_points(a) for a, _ in pinned[t][0]]
         rings = [np.ascontiguousarray(r, np.uint32) for _, r in pinned[t][0]]
         CA = (loamx.Cloud * ns)(*[loamx.cloud_of(a) for a in pts])
@@ -555,7 +568,7 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
         if rc_ < 0:
             raise RuntimeError(L.loamx_last_error().decode())
 
-    for t in range(min(3, T)):
+    for t in range(min(3, T_all)):
         stage(t)
     stager = ThreadPoolExecutor(max_workers=1)   # stage_step(t + 3) runs beside step(t)
     t0 = None
@@ -567,7 +580,7 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
                 dist.barrier()
             t0 = time.perf_counter()
         ta = time.perf_counter()
-        fut = stager.submit(stage, t + 3) if t + 3 < T else None   # slot (t + 3) % 4: free since step t - 1 has run
+        fut = stager.submit(stage, t + 3) if t + 3 < T_all else None   # slot (t + 3) % 4: free since step t - 1 has run
         rc = p.step(t)
         tb = time.perf_counter()
         if fut is not None:
@@ -583,6 +596,7 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
                 mapped_pts += sum(int(CA[k].count) for k in range(ns))
         if t >= 1 + W:
             host += [tb - ta, tc - tb, time.perf_counter() - tc]
+    p.drain_lookahead()
     p.wait_downloads()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0

@@ -354,6 +354,11 @@ int loamx_pipeline_download_full_res(loamx_pipeline* h, uint32_t slot, loamx_clo
  * identical; loamx_pipeline_get() always reports the sweep that was registered last.  Turn it off when per-stream
  * state is changed with loamx_pipeline_set_state() between steps. */
 int loamx_pipeline_set_lookahead(loamx_pipeline* h, int on);
+/* Blocks until the look-ahead has finished every step it is currently allowed to run ahead (odometry of up to two steps beyond the
+ * last loamx_pipeline_step, their feature extraction) and everything of it is enqueued on the device; *last_odometry_step (may be NULL)
+ * receives the last step whose odometry is complete.  For a caller that wants a quiescent pipeline — a benchmark window that must
+ * contain the look-ahead work it profits from, a clean shutdown point — without switching the look-ahead off. */
+int loamx_pipeline_drain_lookahead(loamx_pipeline* h, int* last_odometry_step);
 /* HIP-event timing of the stages: 0 off, 1 stage events + an event pair around every Gauss-Newton launch, 2 stage events only
  * (the pairs cost ~3 % of a step: a caller that wants both the rate and the launch durations samples them, as bench.py does). */
 int loamx_pipeline_set_timing(loamx_pipeline* h, int on);

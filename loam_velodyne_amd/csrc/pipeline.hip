@@ -200,6 +200,13 @@ class Pipeline {
     if (job_err) { std::exception_ptr e = job_err; job_err = nullptr; std::rethrow_exception(e); }
     LX_REQUIRE(o_done.load() >= t, "internal: the odometry chain stopped before the requested step");
   }
+  // calling thread: block until the look-ahead has finished every step it has been allowed to run (its kernels are enqueued then:
+  // a device synchronisation afterwards covers them).  Returns the last step whose odometry is published, -1 if none.
+  int drain_lookahead() {
+    const int lim = o_limit.load(std::memory_order_acquire);
+    if (prefetch && lim >= 0 && worker.joinable()) wait_odometry(lim);
+    return o_done.load(std::memory_order_acquire);
+  }
   // calling thread: stop the look-ahead and wait until the worker is idle; the chain continues at step `next`
   void park_odometry(int next) {
     std::unique_lock<std::mutex> lk(mu);
@@ -841,6 +848,14 @@ int loamx_pipeline_set_lookahead(loamx_pipeline* h, int on) {
     LX_REQUIRE(h, "NULL handle");
     if (!on && h->p.prefetch) h->p.park_odometry(h->p.o_next.load());   // (the worker finishes the step it is in)
     h->p.prefetch = on != 0;
+    return LOAMX_OK;
+  });
+}
+int loamx_pipeline_drain_lookahead(loamx_pipeline* h, int* last_odometry_step) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    const int done = h->p.drain_lookahead();
+    if (last_odometry_step) *last_odometry_step = done;
     return LOAMX_OK;
   });
 }

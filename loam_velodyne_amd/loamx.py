@@ -645,6 +645,12 @@ class Pipeline:
     def set_lookahead(self, on: bool):
         _check(lib().loamx_pipeline_set_lookahead(self.h, 1 if on else 0))
 
+    def drain_lookahead(self):
+        """wait until the look-ahead has run as far as it may; returns the last step whose odometry is complete (-1: none)"""
+        last = C.c_int(-1)
+        _check(lib().loamx_pipeline_drain_lookahead(self.h, C.byref(last)))
+        return int(last.value)
+
     def set_timing(self, on, per_launch: bool = True):
         """on: stage events; per_launch: also an event pair around every Gauss-Newton launch (costs ~3 % of a step)."""
         _check(lib().loamx_pipeline_set_timing(self.h, (1 if per_launch else 2) if on else 0))

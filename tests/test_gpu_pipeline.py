@@ -78,6 +78,10 @@ def test_lookahead_is_transparent(small_world):
         out = []
         for t in range(T):
             rc = p.step(t)
+            if lookahead:   # the look-ahead runs up to two steps beyond the step that has returned — and no further
+                assert p.drain_lookahead() == min(t + 2, T - 1)
+            else:
+                assert p.drain_lookahead() == t
             out.append((rc, [p.get(s) for s in range(ns)]))
         return out
     a, b = run(True), run(False)

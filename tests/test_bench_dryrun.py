@@ -1,0 +1,191 @@
+"""CPU: bench.py's own control flow, run end to end over stand-ins for torch's device side and for the library handle — the resident
+window, its repeats, the PCIe-inclusive windows with the staging thread, the JSON line.  Nothing is measured here; the point is that the
+driver's command cannot die of a Python-level mistake (an index past the staged sweeps, a misspelt key) that only a GPU box would otherwise
+show.  What the stand-in pipeline checks on the way is the protocol bench.py promises: every step that runs was staged, steps run in order,
+the steady-state window stages two more steps than it runs and drains the look-ahead before it closes, a slot of the streaming ring is
+never re-staged while one of the four steps in flight still owns it."""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeTensor:
+    def __init__(self, a):
+        self.a = a
+
+    def copy_(self, other, non_blocking=False):
+        np.copyto(self.a, np.asarray(other.a if isinstance(other, FakeTensor) else other).reshape(self.a.shape))
+        return self
+
+    def pin_memory(self):
+        return self
+
+    def numpy(self):
+        return self.a
+
+    def cpu(self):
+        return self
+
+    def data_ptr(self):
+        return self.a.ctypes.data
+
+    def __getitem__(self, k):
+        return FakeTensor(self.a[k])
+
+    def __len__(self):
+        return len(self.a)
+
+
+def fake_torch():
+    t = types.ModuleType("torch")
+    t.float32, t.uint8, t.float64 = np.float32, np.uint8, np.float64
+    t.empty = lambda shape, dtype=np.float32, device=None: FakeTensor(np.zeros(shape, dtype))
+    t.zeros = t.empty
+    t.empty_like = lambda x: FakeTensor(np.zeros_like(x.a))
+    t.from_numpy = lambda a: FakeTensor(a)
+    t.frombuffer = lambda b, dtype=np.uint8: FakeTensor(np.frombuffer(b, dtype))
+    t.device = lambda kind, idx=0: ("device", kind, idx)
+
+    class Event:
+        def __init__(self, enable_timing=False):
+            self.cuda_event = 0
+
+        def record(self):
+            pass
+
+        def synchronize(self):
+            pass
+
+        def elapsed_time(self, other):
+            return 0.3
+
+    def no_props(idx):
+        raise RuntimeError("no device")
+    t.cuda = types.SimpleNamespace(set_device=lambda i: None, synchronize=lambda: None, Event=Event, get_device_properties=no_props)
+    return t
+
+
+class FakePipeline:
+    """the calls bench.py makes on loamx.Pipeline, with the ordering rules of include/loamx.h asserted"""
+    instances = []
+
+    def __init__(self, n_streams, **cfg):
+        self.ns, self.h = n_streams, id(self)
+        self.uploaded = 0           # steps staged up front (loamx_pipeline_upload)
+        self.staged = 0             # steps staged one at a time (loamx_pipeline_stage_step)
+        self.last = -1
+        self.drained_at = None
+        self.closed = False
+        self.async_dl = False
+        self.downloads = 0
+        FakePipeline.instances.append(self)
+
+    def set_frozen_device(self, *a):
+        pass
+
+    def set_state(self, k, aft=None):
+        assert 0 <= k < self.ns and aft is not None and len(aft) == 6
+
+    def upload(self, sweeps):
+        assert all(len(row) == self.ns for row in sweeps)
+        self.uploaded = len(sweeps)
+
+    def set_timing(self, on, per_launch=True):
+        pass
+
+    def enable_async_downloads(self):
+        self.async_dl = True
+
+    def step(self, t):
+        assert not self.closed and t == self.last + 1, "steps run in order"
+        assert t < max(self.uploaded, self.staged), "step beyond the staged sweeps"
+        self.last = t
+        return 1 if t == 0 else 0   # the first sweep of a stream only initialises the odometry
+
+    def drain_lookahead(self):
+        self.drained_at = self.last
+        return min(self.last + 2, max(self.uploaded, self.staged) - 1)
+
+    def timing(self):
+        return dict(features_ms=0.2, odometry_ms=0.5, registration_ms=0.4, step_ms=0.4, residual_ms=0.18, residual_launches=3,
+                    query_iterations=3 * 1000 * self.ns, queries=1000 * self.ns, run_ms=0.4)
+
+    def get(self, k):
+        z = np.zeros(6, np.float32)
+        return z, z, z, dict(map_iterations=3, mapped=1, odom_iterations=7, odom_sel=100, map_sel=500, corner_q=100, surf_q=900, degenerate=0)
+
+    def wait_downloads(self):
+        pass
+
+    def download_counts(self):
+        return self.downloads, 0
+
+    def close(self):
+        self.closed = True
+
+
+class FakeLib:
+    """the two C entry points bench.py calls directly in the PCIe window"""
+    def __init__(self, loamx):
+        self.loamx = loamx
+
+    def _pipe(self, h):
+        return next(p for p in FakePipeline.instances if p.h == h)
+
+    def loamx_pipeline_stage_step(self, h, t, clouds, rings, nrings):
+        p = self._pipe(h)
+        assert t == p.staged, "steps are staged in order"
+        assert t < 4 or p.last >= t - 4, "stage_step(t) needs step(t - 4) to have returned"
+        assert sum(int(x) for x in np.ctypeslib.as_array((np.ctypeslib.ctypes.c_uint32 * int(nrings[0])).from_address(rings[0]))) == clouds[0].count
+        p.staged = t + 1
+        return 0
+
+    def loamx_pipeline_download_step_async(self, h, clouds, n):
+        p = self._pipe(h)
+        assert p.async_dl and n == p.ns
+        p.downloads += 1
+        return 0
+
+    def loamx_last_error(self):
+        return b""
+
+
+@pytest.mark.parametrize("argv", [["--steps", "3", "--warmup", "1", "--streams", "2", "--sensor", "VLP-16", "--map-points", "2000", "--no-cpu-baseline",
+                                   "--repeat", "2"]])
+def test_bench_main_runs_over_stand_ins(monkeypatch, capsys, argv):
+    from loam_velodyne_amd import loamx
+    monkeypatch.setitem(sys.modules, "torch", fake_torch())
+    monkeypatch.setattr(loamx, "Pipeline", FakePipeline)
+    monkeypatch.setattr(loamx, "lib", lambda: FakeLib(loamx))
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    FakePipeline.instances.clear()
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    bench.main()
+    line = [l for l in capsys.readouterr().out.strip().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    K, W, ns = 3, 1, 2
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "value_median", "value_min", "value_max"):
+        assert key in out, key
+    assert out["steps"] == K and out["warmup"] == W and out["n_gpus"] == 1 and out["config"]["streams_per_gpu"] == ns
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert out["value_repeats"] == 2 and len(out["pcie_inclusive"]["value_windows"]) == 3
+    # the windows: every resident one staged K + 1 + W + 2 steps, ran 1 + W + K of them, and drained the look-ahead after its last step;
+    # the PCIe ones staged the same number one at a time
+    resident = [p for p in FakePipeline.instances if p.uploaded]
+    streaming = [p for p in FakePipeline.instances if p.staged]
+    assert len(resident) == 2 and len(streaming) == 3
+    for p in resident:
+        assert p.uploaded == 1 + W + K + 2 and p.last == W + K and p.drained_at == W + K and p.closed
+    for p in streaming:
+        assert p.staged == 1 + W + K + 2 and p.last == W + K and p.drained_at == W + K and p.downloads == W + K and p.closed

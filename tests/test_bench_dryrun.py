@@ -69,7 +69,56 @@ def fake_torch():
     def no_props(idx):
         raise RuntimeError("no device")
     t.cuda = types.SimpleNamespace(set_device=lambda i: None, synchronize=lambda: None, Event=Event, get_device_properties=no_props)
+
+    class Scalar(FakeTensor):
+        def item(self):
+            return self.a.reshape(-1)[0]
+    t.tensor = lambda v, dtype=np.float64, device=None: Scalar(np.array(v, dtype))
+    # torch.distributed as the driver's launcher sets it up (one process here plays rank 0 of a larger world)
+    d = types.ModuleType("torch.distributed")
+    d.world = 1
+    d.calls = []
+    d.init_process_group = lambda backend, rank=0, world_size=1, device_id=None: (d.calls.append("init"), setattr(d, "world", world_size))[0]
+    d.is_initialized = lambda: True
+    d.get_world_size = lambda: d.world
+    d.barrier = lambda: d.calls.append("barrier")
+    d.broadcast = lambda tensor, src=0, async_op=False: types.SimpleNamespace(wait=lambda: None)
+    d.all_reduce = lambda tensor, op=None: None
+    d.ReduceOp = types.SimpleNamespace(MAX="max")
+    d.destroy_process_group = lambda: d.calls.append("destroy")
+    t.distributed = d
     return t
+
+
+class FakeDist:
+    """loamx.Dist: the library's own RCCL communicator"""
+    ID_BYTES = 128
+    made = []
+
+    @staticmethod
+    def unique_id():
+        return bytes(range(128))
+
+    def __init__(self, uid, rank, world, device=0):
+        assert uid == bytes(range(128)) and 0 <= rank < world
+        self.rank, self.world, self.broadcasts = rank, world, 0
+        FakeDist.made.append(self)
+
+    def broadcast_map(self, d_corner, n_corner, d_surf, n_surf, root=0, wait_event=0):
+        assert d_surf == d_corner + 16 * n_corner and root == 0
+        self.broadcasts += 1
+        return 0
+
+    def barrier(self):
+        pass
+
+    def allgather_results(self, poses6, iters_flags=None, batch=None):
+        p = np.asarray(poses6, np.float32).reshape(-1, 6)
+        assert batch == self.world * len(p) and np.asarray(iters_flags).shape == (len(p), 2)
+        return np.tile(p, (self.world, 1)), np.tile(np.asarray(iters_flags, np.int32), (self.world, 1)), np.full(self.world, len(p), np.uint32)
+
+    def comm_count(self):
+        return self.world
 
 
 class FakePipeline:
@@ -189,3 +238,32 @@ def test_bench_main_runs_over_stand_ins(monkeypatch, capsys, argv):
         assert p.uploaded == 1 + W + K + 2 and p.last == W + K and p.drained_at == W + K and p.closed
     for p in streaming:
         assert p.staged == 1 + W + K + 2 and p.last == W + K and p.drained_at == W + K and p.downloads == W + K and p.closed
+
+
+def test_bench_main_as_rank_0_of_two(monkeypatch, capsys):
+    """the multi-GPU path of bench.py (process group, the library's own communicator for the map broadcast and the result gather,
+    max-over-ranks timing) — never executed on hardware so far: at least its Python must hold"""
+    from loam_velodyne_amd import loamx
+    ft = fake_torch()
+    monkeypatch.setitem(sys.modules, "torch", ft)
+    monkeypatch.setitem(sys.modules, "torch.distributed", ft.distributed)
+    monkeypatch.setattr(loamx, "Pipeline", FakePipeline)
+    monkeypatch.setattr(loamx, "Dist", FakeDist)
+    monkeypatch.setattr(loamx, "lib", lambda: FakeLib(loamx))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--streams", "2", "--sensor", "VLP-16", "--map-points", "2000",
+                                      "--repeat", "2"])
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    FakePipeline.instances.clear()
+    FakeDist.made.clear()
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    bench.main()
+    out = json.loads([l for l in capsys.readouterr().out.strip().splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and "cpu_baseline" not in out
+    assert out["config"]["rccl_ranks"] == 2 and out["config"]["results_gathered"] == 4 and "native" in out["config"]["map_broadcast_via"]
+    assert len(FakeDist.made) == 1 and FakeDist.made[0].broadcasts == 2          # (communicator warm-up + the timed broadcast)
+    assert ft.distributed.calls[0] == "init" and ft.distributed.calls[-1] == "destroy"
+    # value counts both ranks' sweeps over this rank's clock (the stand-in's max-over-ranks is the identity)
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 2 * 2) < 0.05 * 4

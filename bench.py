@@ -182,6 +182,8 @@ def main():
         # ---- warm-up (includes every stream's initialising first sweep)
         for t in range(1 + W):
             run_step(t)
+        for p in pipes:   # the window opens with the look-ahead exactly LOOK steps ahead — and closes the same way (below)
+            p.drain_lookahead()
         sync_all()
         r = dict(stage=np.zeros(4), res_ms=0.0, res_launches=0, q_iters=0, queries=0, n_sampled=0, in_step=0.0, n_epochs=0)
         # double-buffered map epochs (off by default): epoch k+1 is broadcast and indexed in the background during epoch k
@@ -358,9 +360,9 @@ def main():
                                       "registration": round(stage[2] / S, 4), "gpu_step": round(stage[3] / S, 4)},
                 "ms_per_step_inside_step_call": round(in_step / K * 1e3, 4),
                 "stage_timing_sampling": f"HIP events on every {TIMING_PERIOD}th step of the timed region ({n_sampled} of {K} steps)",
-                "timed_window": f"steady state: {LOOK} more steps are staged than run and the window closes after loamx_pipeline_drain_lookahead + "
-                                "synchronize, so the look-ahead work done before it opens (odometry / features of the next steps) is matched by "
-                                f"the same work for the {LOOK} steps after it: K passes of every stage inside the timed region",
+                "timed_window": f"steady state: {LOOK} more steps are staged than run; the window opens and closes after "
+                                "loamx_pipeline_drain_lookahead + synchronize, i.e. with the look-ahead exactly as far ahead at its end as at its "
+                                f"start ({LOOK} steps): K passes of every stage inside the timed region",
                 "map_broadcast_ms": round(t_bcast * 1e3, 3),
                 "map_broadcast_via": bcast_via,
                 "map_epoch_steps": E,
@@ -575,8 +577,9 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
     mapped_pts = 0
     host = np.zeros(3)
     for t in range(T):
-        if t == 1 + W:   # steady state: the pipeline is NOT drained here (steps t+1 .. t+3 are staged / in flight, as in production);
-            if dist is not None:   # the window ends with everything drained, so its cost is fully inside
+        if t == 1 + W:   # steady state: the pipeline is NOT emptied here (steps t .. t+2 are staged, the look-ahead has run as far as it
+            p.drain_lookahead()   # may, copies may be in flight — as in production); the window ends the same way plus everything landed,
+            if dist is not None:  # so the look-ahead work and the copies of exactly K steps are inside
                 dist.barrier()
             t0 = time.perf_counter()
         ta = time.perf_counter()

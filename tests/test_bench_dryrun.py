@@ -159,6 +159,8 @@ class FakePipeline:
         return 1 if t == 0 else 0   # the first sweep of a stream only initialises the odometry
 
     def drain_lookahead(self):
+        self.drains = getattr(self, "drains", [])
+        self.drains.append(self.last)
         self.drained_at = self.last
         return min(self.last + 2, max(self.uploaded, self.staged) - 1)
 
@@ -234,10 +236,10 @@ def test_bench_main_runs_over_stand_ins(monkeypatch, capsys, argv):
     resident = [p for p in FakePipeline.instances if p.uploaded]
     streaming = [p for p in FakePipeline.instances if p.staged]
     assert len(resident) == 2 and len(streaming) == 3
-    for p in resident:
-        assert p.uploaded == 1 + W + K + 2 and p.last == W + K and p.drained_at == W + K and p.closed
+    for p in resident:   # (drained when the window opens — after the last warm-up step — and before it closes)
+        assert p.uploaded == 1 + W + K + 2 and p.last == W + K and p.drains == [W, W + K] and p.closed
     for p in streaming:
-        assert p.staged == 1 + W + K + 2 and p.last == W + K and p.drained_at == W + K and p.downloads == W + K and p.closed
+        assert p.staged == 1 + W + K + 2 and p.last == W + K and p.drains == [W, W + K] and p.downloads == W + K and p.closed
 
 
 def test_bench_main_as_rank_0_of_two(monkeypatch, capsys):

@@ -137,20 +137,29 @@ def main():
     # ---- this rank's streams and staged sweeps (distinct trajectories per rank and stream)
     sweeps = [[None] * ns for _ in range(T_all)]
     starts = []
+    jobs = []
     for s, gs in enumerate(lxdist.stream_ids(rank, world, ns)):
         start = lxdist.stream_start(gs)
         poses = synth.trajectory(T_all, start=start)
         starts.append(np.array([0, 0, 0, start[0], start[1], start[2]], np.float32))
         for t in range(T_all):
-            sw = synth.make_sweep(world_model, args.sensor, poses[t], poses[t + 1], seed=1000 * gs + t)
-            sweeps[t][s] = (sw.points, sw.ring_sizes)
+            jobs.append((t, s, (125.0, args.sensor, poses[t], poses[t + 1], 1000 * gs + t)))
+    # ray casting is ~0.5 s per HDL-64E sweep on one core and the GPU box is leased by the minute: the (seeded, order-independent)
+    # sweeps are generated by worker processes — spawned, not forked: the HIP runtime is already up in this one
+    n_workers = max(1, min(int(os.environ.get("LOAMX_BENCH_WORKERS", "32")), (os.cpu_count() or 1) // max(world, 1), len(jobs)))
+    if n_workers > 1:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(max_workers=n_workers, mp_context=mp.get_context("spawn")) as ex:
+            made = list(ex.map(synth.make_sweep_job, [j[2] for j in jobs], chunksize=max(1, len(jobs) // (4 * n_workers))))
+    else:
+        made = [synth.make_sweep_job(j[2]) for j in jobs]
+    for (t, s, _), (pts, rs) in zip(jobs, made):
+        sweeps[t][s] = (pts, rs)
     n_points = len(sweeps[0][0][0])
 
-    H = max(1, min(args.handles, ns))
-    assert ns % H == 0, "--streams must be a multiple of --handles"
-    per = ns // H
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=H)
+    E = args.map_epoch_steps
 
     def sync_all():
         torch.cuda.synchronize()
@@ -158,10 +167,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    E = args.map_epoch_steps
-
     def resident_window(keep_open=False):
-        """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize, all sweeps resident in HBM."""
+        """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize, all sweeps resident in HBM.
+        With H > 1 pipeline handles (--handles / LOAMX_BENCH_HANDLES) the streams are dealt over H handles, each driven by a host thread
+        of its own that runs ITS K steps without waiting for the others between steps (the streams are independent; only the window's
+        two ends are common)."""
+        H = max(1, min(int(os.environ.get("LOAMX_BENCH_HANDLES", args.handles)), ns))
+        assert ns % H == 0, "--streams must be a multiple of --handles"
+        assert E == 0 or H == 1, "--map-epoch-steps runs with one handle"
+        per = ns // H
         torch.cuda.synchronize()
         pipes = []
         for h in range(H):
@@ -172,25 +186,68 @@ def main():
             p.upload([[sweeps[t][h * per + k] for k in range(per)] for t in range(T_all)])
             p.set_timing(True)
             pipes.append(p)
-
-        def run_step(t):
-            if H == 1:
-                pipes[0].step(t)
-            else:
-                list(pool.map(lambda p: p.step(t), pipes))   # ctypes releases the GIL: the handles really run concurrently
-
-        # ---- warm-up (includes every stream's initialising first sweep)
-        for t in range(1 + W):
-            run_step(t)
-        for p in pipes:   # the window opens with the look-ahead exactly LOOK steps ahead — and closes the same way (below)
-            p.drain_lookahead()
-        sync_all()
-        r = dict(stage=np.zeros(4), res_ms=0.0, res_launches=0, q_iters=0, queries=0, n_sampled=0, in_step=0.0, n_epochs=0)
+        r = dict(stage=np.zeros(4), res_ms=0.0, res_launches=0, q_iters=0, queries=0, n_sampled=0, in_step=0.0, n_epochs=0, handles=H, per=per)
+        racc = [dict(stage=np.zeros(4), res_ms=0.0, res_launches=0, q_iters=0, queries=0, n_sampled=0, in_step=0.0) for _ in range(H)]
         # double-buffered map epochs (off by default): epoch k+1 is broadcast and indexed in the background during epoch k
         # and swapped in before the first step of epoch k+1
         map_nexts = [torch.empty_like(map_t), torch.empty_like(map_t)] if E > 0 else None   # ping-pong: a buffer is rewritten only
         # after a registration against the index built from it has been observed complete
         ev_map = torch.cuda.Event() if E > 0 else None
+
+        def warm(h):   # warm-up (includes every stream's initialising first sweep); the window opens with the look-ahead exactly
+            p = pipes[h]                 # LOOK steps ahead — and closes the same way (below)
+            for t in range(1 + W):
+                p.step(t)
+            p.drain_lookahead()
+
+        def timed(h):
+            p, a = pipes[h], racc[h]
+            for t in range(1 + W, T):
+                if E > 0:
+                    k = (t - (1 + W)) % E
+                    if k == 0:
+                        if p.swap_frozen():
+                            r["n_epochs"] += 1
+                        map_next = map_nexts[((t - (1 + W)) // E) % 2]
+                        if rank == 0:
+                            map_next.copy_(map_t, non_blocking=True)   # (the next epoch's map: same content, new buffer)
+                        if ldist is not None:   # native: the broadcast waits for the copy's event, the index build for the broadcast's
+                            ev_map.record()
+                            ev = ldist.broadcast_map(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, root=0, wait_event=ev_map.cuda_event)
+                        else:
+                            if dist is not None:
+                                dist.broadcast(map_next, src=0, async_op=True).wait()   # orders torch's stream behind RCCL's, not the host
+                            ev_map.record()
+                            ev = ev_map.cuda_event
+                        # the index build waits for the event on the device; nothing blocks here
+                        p.stage_frozen_device(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, ev)
+                # HIP-event timing (stage chains + a pair around every Gauss-Newton launch) on every 4th step only: the event pairs and
+                # their read-back (event synchronise, a statistics download) cost ~4 % of a step
+                sampled = (t - (1 + W)) % TIMING_PERIOD == 0
+                p.set_timing(sampled)
+                tc0 = time.perf_counter()
+                p.step(t)
+                a["in_step"] += time.perf_counter() - tc0
+                if sampled:   # event read-back of the step that just finished (the step itself is synchronous)
+                    a["n_sampled"] += 1
+                    tm = p.timing()
+                    a["stage"] += np.array([tm["features_ms"], tm["odometry_ms"], tm["registration_ms"], tm["step_ms"]])
+                    a["res_ms"] += tm["residual_ms"]
+                    a["res_launches"] += tm["residual_launches"]
+                    a["q_iters"] += tm["query_iterations"]
+                    a["queries"] += tm["queries"]
+            p.drain_lookahead()   # the look-ahead work for the LOOK steps after the window belongs inside it (see LOOK above)
+
+        def on_all(fn):
+            if H == 1:
+                fn(0)
+            else:   # ctypes releases the GIL inside the library: the handles really run concurrently
+                for f in [pool.submit(fn, h) for h in range(H)]:
+                    f.result()
+
+        pool = ThreadPoolExecutor(max_workers=H) if H > 1 else None
+        on_all(warm)
+        sync_all()
         if E > 0:   # one untimed stage + swap so that the second set of index buffers exists before the timed region
             for p in pipes:
                 p.stage_frozen_device(map_t.data_ptr(), n_corner, map_t.data_ptr() + 16 * n_corner, n_surf)
@@ -199,47 +256,17 @@ def main():
                 p.swap_frozen()
             sync_all()
         t0 = time.perf_counter()
-        for t in range(1 + W, T):
-            if E > 0:
-                k = (t - (1 + W)) % E
-                if k == 0:
-                    for p in pipes:
-                        if p.swap_frozen():
-                            r["n_epochs"] += 1
-                    map_next = map_nexts[((t - (1 + W)) // E) % 2]
-                    if rank == 0:
-                        map_next.copy_(map_t, non_blocking=True)   # (the next epoch's map: same content, new buffer)
-                    if ldist is not None:   # native: the broadcast waits for the copy's event, the index build for the broadcast's
-                        ev_map.record()
-                        ev = ldist.broadcast_map(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, root=0, wait_event=ev_map.cuda_event)
-                    else:
-                        if dist is not None:
-                            dist.broadcast(map_next, src=0, async_op=True).wait()   # orders torch's stream behind RCCL's, not the host
-                        ev_map.record()
-                        ev = ev_map.cuda_event
-                    for p in pipes:   # the index build waits for the event on the device; nothing blocks here
-                        p.stage_frozen_device(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, ev)
-            # HIP-event timing (stage chains + a pair around every Gauss-Newton launch) on every 4th step only: the event pairs and
-            # their read-back (event synchronise, a statistics download) cost ~4 % of a step
-            sampled = (t - (1 + W)) % TIMING_PERIOD == 0
-            for p in pipes:
-                p.set_timing(sampled)
-            tc0 = time.perf_counter()
-            run_step(t)
-            r["in_step"] += time.perf_counter() - tc0
-            if sampled:
-                r["n_sampled"] += 1
-                for p in pipes:   # event read-back of the step that just finished (the step itself is synchronous)
-                    tm = p.timing()
-                    r["stage"] += np.array([tm["features_ms"], tm["odometry_ms"], tm["registration_ms"], tm["step_ms"]]) / H
-                    r["res_ms"] += tm["residual_ms"]
-                    r["res_launches"] += tm["residual_launches"]
-                    r["q_iters"] += tm["query_iterations"]
-                    r["queries"] += tm["queries"]
-        for p in pipes:   # the look-ahead work for the LOOK steps after the window belongs inside it (see LOOK above)
-            p.drain_lookahead()
+        on_all(timed)
         sync_all()
         r["elapsed"] = lxdist.max_over_ranks(time.perf_counter() - t0, dist, dev)
+        if pool is not None:
+            pool.shutdown()
+        for a in racc:   # stage times: mean over the handles (they run side by side); counts: summed
+            r["stage"] += a["stage"] / H
+            for k in ("res_ms", "res_launches", "q_iters", "queries"):
+                r[k] += a[k]
+        r["n_sampled"] = racc[0]["n_sampled"]
+        r["in_step"] = max(a["in_step"] for a in racc)
         r["pipes"] = pipes
         if not keep_open:
             for p in pipes:
@@ -283,6 +310,7 @@ def main():
     # ---- the contract's window: W warm-up steps, then exactly K timed steps
     win = resident_window(keep_open=True)
     pipes = win["pipes"]
+    H, per = win["handles"], win["per"]
     elapsed = win["elapsed"]
     stage, res_ms, res_launches, q_iters_timed, queries_timed, n_sampled, in_step, n_epochs = (
         win["stage"], win["res_ms"], win["res_launches"], win["q_iters"], win["queries"], win["n_sampled"], win["in_step"], win["n_epochs"])

@@ -38,6 +38,7 @@ struct OdomProblem {
   OdomProblem* host_mirror;   // pinned host copy that k_odom_lm fills with transform / stats / done (no D2H copy on the stream)
   unsigned ticket;        // k_odom_lm: workgroup arrivals since the problem was set up (per-stream barrier)
   double* part;           // k_odom_lm: [2][16][LX_NSUM] partial normal equations of the stream's workgroups
+  uint32_t* err_word;     // pinned host word raised when k_odom_lm's exchange times out (checked by the host after the pose event)
 };
 
 // one sweep's four feature clouds on the device.  less_sharp / less_flat of ALL streams must be contiguous in stream
@@ -109,6 +110,7 @@ class OdometryBatch {
   DevBuf<int> ind_;
   DevBuf<double> part_;
   PinBuf<OdomProblem> h_mirror_;
+  PinBuf<uint32_t> h_err_;
   // what a call sends up before its first kernel — the problems, the re-projection parameters, the cloud offsets — is ONE block in
   // pinned memory and ONE copy (three copies were three ~7 us commands at the head of the odometry chain, the pipeline's longest)
   template <class T> struct View { T* p = nullptr; };

@@ -303,14 +303,14 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
   // Two features per thread: their two products are added in double first, so the table stays double.
   using TrT = typename std::conditional<OD_FPT == 1, float, double>::type;
   __shared__ TrT tr[LX_NSUM * OD_TR_STRIDE];
-  __shared__ int sh_done, sh_degen;
+  __shared__ int sh_done, sh_degen, sh_abort;
   __shared__ float matP[36];
   __shared__ float ws[216];
   __shared__ double sums[LX_NSUM];
   __shared__ double parts[16 * LX_NSUM];   // the partial sums of the stream's (<= 16) workgroups
   __shared__ float AtA[36], AtB[6], X[6], X2[6];
   if (tid < 6) T[tid] = pb.transform[tid];
-  if (tid == 0) { sh_done = 0; sh_degen = pb.stats.degenerate; }
+  if (tid == 0) { sh_done = 0; sh_abort = 0; sh_degen = pb.stats.degenerate; }
   if (tid < 36) matP[tid] = pb.matP[tid];   // set at iteration 0 (an earlier launch when iter0 > 0)
   __syncthreads();
 
@@ -478,10 +478,26 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
       if (tid == 0) {
         atomicAdd(&pb.ticket, 1u);
         const unsigned target = NB * (unsigned)(iter + 1);   // the host zeroes the counter; every iteration adds NB
-        while (__hip_atomic_load(&pb.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        // The exchange needs every workgroup of the stream resident (the host's chunking arithmetic, OdometryBatch::process).  Should that
+        // ever not hold — a device shared with another process, more handles than the arithmetic knows of — the wait gives up after
+        // ~2 s of wall clock (100 MHz counter) and raises a host-visible error word instead of hanging the GPU (as VoxelPipeline's waits do)
+        const unsigned long long t_in = wall_clock64();
+        unsigned spins = 0;
+        while (__hip_atomic_load(&pb.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(1);
+          if ((++spins & 1023u) == 0u && wall_clock64() - t_in > 200000000ull) { sh_abort = 1; break; }
+        }
         __threadfence();   // acquire the other workgroups' partial sums
       }
       __syncthreads();
+      if (sh_abort) {   // block-uniform: this stream's launch is abandoned, later launches see `done`
+        if (tid == 0) {
+          pb.done = 1;
+          if (pb.err_word) __hip_atomic_store(pb.err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (pb.host_mirror) pb.host_mirror->done = -1;
+        }
+        return;
+      }
       LM_TS(5);
       for (unsigned e = tid; e < NB * LX_NSUM; e += OD_THREADS)
         parts[e] = __hip_atomic_load(&pb.part[((unsigned)iter & 1u) * 16u * LX_NSUM + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -672,6 +688,8 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
   if (const char* e = getenv("LOAMX_ODOM_CELL")) { const float v = (float)atof(e); if (v >= 0.25f && v <= 16.f) index_.cell_size = v; }
   index_.init(st_);
   h_mirror_.reserve(n_streams);
+  h_err_.reserve(16);
+  memset(h_err_.p, 0, 16 * sizeof(uint32_t));
   part_.reserve((size_t)n_streams * OD_PART_STRIDE);
   {
     auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -810,6 +828,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       pb.host_mirror = h_mirror_.p + active.size();
       pb.te_out = te_.p + s;
       pb.part = part_.p + (size_t)active.size() * OD_PART_STRIDE;
+      pb.err_word = h_err_.p;
       max_feat = std::max(max_feat, I.n_sharp + I.n_flat);
       max_sharp = std::max(max_sharp, I.n_sharp);
       max_flat = std::max(max_flat, I.n_flat);
@@ -880,6 +899,10 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   tail_pending_ = true;
   if (na) {
     LX_HIP(hipEventSynchronize(ev_pose_));
+    if (*(volatile uint32_t*)h_err_.p) {   // k_odom_lm's exchange timed out (its workgroups were not all resident)
+      *h_err_.p = 0u;
+      throw Error(LOAMX_E_HIP, "odometry: the exchange between a stream's k_odom_lm workgroups timed out (not all of them resident)");
+    }
 #ifdef LOAMX_PROF_LM
     {
       double ts[16];

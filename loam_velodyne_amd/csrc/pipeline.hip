@@ -39,7 +39,24 @@ struct PipeStreamState {
 class Pipeline {
  public:
   Pipeline(const loamx_scanreg_config& fc, const loamx_odom_config& oc, const loamx_map_config& mc, uint32_t n_streams)
-      : reg(mc.device, n_streams), odom(mc.device, n_streams, nullptr), fcfg(fc), n_streams_(n_streams), st(n_streams), imu(n_streams) {
+      : reg(mc.device, n_streams), fcfg(fc), n_streams_(n_streams), st(n_streams), imu(n_streams) {
+    // The odometry of the streams runs as G independent chains ("groups"), each with its own OdometryBatch, HIP stream and host thread:
+    // a stream whose sweep needs 25 iterations (BasicLaserOdometry.cpp:246 runs to maxIterations when the stop test at :613-620 never
+    // fires) delays only its own group, and the two steps of look-ahead absorb it — with ONE chain every step paid the launch pairs of
+    // the slowest of all streams (profiles/r03: 5.2 pairs per step for a mean of 7.1 iterations).
+    {
+      int g = (int)std::min<uint32_t>(n_streams, 4);
+      if (const char* e = getenv("LOAMX_ODOM_GROUPS")) g = atoi(e);
+      n_groups = (uint32_t)std::max(1, std::min(g, (int)std::min<uint32_t>(n_streams, MAX_GROUPS)));
+    }
+    for (uint32_t g = 0; g < n_groups; g++) {
+      chains.emplace_back(new OdomChain());
+      OdomChain& c = *chains.back();
+      c.s0 = (uint32_t)((uint64_t)g * n_streams / n_groups);
+      c.s1 = (uint32_t)((uint64_t)(g + 1) * n_streams / n_groups);
+      c.ob.reset(new OdometryBatch(mc.device, c.s1 - c.s0, nullptr));
+    }
+    for (auto& o : ores) o.resize(n_streams);
     for (auto& tr : imu) tr.history_size = std::max(200, fc.imu_history_size);
     reg.params.max_iterations = mc.max_iterations;
     reg.early_exit = true;   // step() blocks on M(t) anyway
@@ -47,15 +64,36 @@ class Pipeline {
     reg.params.delta_r_abort = mc.delta_r_abort;
     reg.params.corner_leaf = mc.corner_filter_size;
     reg.params.surf_leaf = mc.surf_filter_size;
-    odom.params.scan_period = oc.scan_period;
-    odom.params.max_iterations = oc.max_iterations;
-    odom.params.delta_t_abort = oc.delta_t_abort;
-    odom.params.delta_r_abort = oc.delta_r_abort;
+    for (auto& c : chains) {
+      c->ob->params.scan_period = oc.scan_period;
+      c->ob->params.max_iterations = oc.max_iterations;
+      c->ob->params.delta_t_abort = oc.delta_t_abort;
+      c->ob->params.delta_r_abort = oc.delta_r_abort;
+    }
     device = mc.device;
     if (getenv("LOAMX_NO_LOOKAHEAD")) prefetch = false;   // debugging / profiling: run the stages one after the other
   }
   Registrar reg;
-  OdometryBatch odom;
+  // one odometry chain: the streams [s0, s1), their batch object (own HIP stream), the host thread that drives it and its position
+  struct OdomChain {
+    uint32_t s0 = 0, s1 = 0;
+    std::unique_ptr<OdometryBatch> ob;
+    std::thread worker;
+    std::atomic<int> done{-1};           // odometry of steps <= done is complete and published
+    std::atomic<int> next{0};            // next step of this chain (its worker; the calling thread only while the workers are parked)
+    std::atomic<bool> busy{false};
+    hipEvent_t ev_tail[3] = {nullptr, nullptr, nullptr};   // recorded behind O(k)'s tail (re-projection + index build) on the chain's stream
+    hipEvent_t tm_a[3] = {nullptr, nullptr, nullptr}, tm_b[3] = {nullptr, nullptr, nullptr};   // chain timer of step k % 3 (this thread's own)
+    bool tm_pending[3] = {false, false, false};
+    std::atomic<float> ms{0.f};          // length of the chain's most recent timed pass on its HIP stream
+    double tr[4] = {0, 0, 0, 0};
+  };
+  static constexpr uint32_t MAX_GROUPS = 16;
+  uint32_t n_groups = 1;
+  std::vector<std::unique_ptr<OdomChain>> chains;
+  OdomChain& chain_of(uint32_t s) { uint32_t g = 0; while (g + 1 < n_groups && s >= chains[g]->s1) g++; return *chains[g]; }
+  OdometryBatch& OB(uint32_t s) { return *chain_of(s).ob; }
+  uint32_t LS(uint32_t s) { return s - chain_of(s).s0; }   // index of stream s inside its group
   loamx_scanreg_config fcfg;
   uint32_t n_streams_;
   int device;
@@ -121,33 +159,30 @@ class Pipeline {
     }
     void destroy() { if (a) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); a = b = nullptr; } }
   };
-  LazyTimer tmO[3], tmM[2];   // odometry: by step % 3 (the worker's), registration: by step parity
-  std::atomic<float> odom_ms{0.f};
+  LazyTimer tmM[2];   // registration: by step parity (the odometry chains keep their own timers, OdomChain)
   float feat_ms[3] = {0, 0, 0};
   int f_hi = -1;                       // features of steps <= f_hi have been launched (calling thread)
-  int ahead_depth = getenv("LOAMX_ODOM_AHEAD") ? atoi(getenv("LOAMX_ODOM_AHEAD")) : 2;   // steps the odometry chain may run ahead of the registration (diagnostic: 1)
+  int ahead_depth = getenv("LOAMX_ODOM_AHEAD") ? atoi(getenv("LOAMX_ODOM_AHEAD")) : 2;   // steps the odometry chains may run ahead of the registration (diagnostic: 1)
   float last_ms[4] = {0, 0, 0, 0};
-  bool timing = false;
+  std::atomic<bool> timing{false};
 
-  // The odometry chain runs on a persistent host thread of its own and AHEAD of the registration: odometry O(k) only depends on
-  // O(k-1) and on the features F(k), never on a registration (separate ROS nodes in the reference), so the thread goes on to O(k+1)
-  // as soon as O(k) is done, up to two steps ahead of the step being registered — registration and odometry are both serial chains
-  // across steps and the slower of the two sets the pace, not their sum.  The calling thread launches the features (the only
-  // thread that does) and raises o_limit; the worker publishes o_done.  Results wait in a ring of three slots, the odometry's
-  // re-projected clouds in three rotating buffers (OdometryBatch), so step k's inputs stay valid while O(k+1), O(k+2) run.
-  // Hand-overs happen every ~0.4 ms, so both sides spin briefly before they fall back to the condition variable (a sleeping
+  // The odometry chains run on persistent host threads of their own and AHEAD of the registration: odometry O(k) of a stream only
+  // depends on its O(k-1) and on the features F(k), never on a registration (separate ROS nodes in the reference) and never on another
+  // stream, so a chain goes on to O(k+1) as soon as its O(k) is done, up to two steps ahead of the step being registered —
+  // registration and odometry are serial chains across steps and the slowest sets the pace, not their sum.  The calling thread launches
+  // the features (the only thread that does) and raises o_limit; every chain publishes its own `done`.  Results wait in a ring of
+  // three slots, the re-projected clouds in three rotating buffers (OdometryBatch), so step k's inputs stay valid while O(k+1), O(k+2)
+  // run.  Hand-overs happen every ~0.4 ms, so both sides spin briefly before they fall back to the condition variable (a sleeping
   // thread costs tens of microseconds to wake, on the critical path of every step).
-  std::vector<OdomPub> ores[3];        // [step % 3][stream]
-  hipEvent_t ev_otail[3] = {nullptr, nullptr, nullptr};   // recorded behind O(k)'s tail (re-projection + index build) on the odometry stream
-  std::thread worker;
+  std::vector<OdomPub> ores[3];        // [step % 3][stream]; a chain writes its own streams only
   std::mutex mu;
   std::condition_variable cv;
-  std::atomic<int> o_limit{-1};        // the worker may run steps <= o_limit (raised by the calling thread only)
-  std::atomic<int> o_done{-1};         // odometry of steps <= o_done is complete and published
-  std::atomic<bool> o_busy{false};
-  std::atomic<int> o_next{0};          // next step of the odometry chain (worker; the calling thread only while the worker is parked)
+  std::atomic<int> o_limit{-1};        // the chains may run steps <= o_limit (raised by the calling thread only)
   bool quit = false;
   std::exception_ptr job_err;
+  int done_min() const { int m = INT32_MAX; for (auto& c : chains) m = std::min(m, c->done.load(std::memory_order_acquire)); return m; }
+  int done_max() const { int m = -1; for (auto& c : chains) m = std::max(m, c->done.load(std::memory_order_acquire)); return m; }
+  bool any_busy() const { for (auto& c : chains) if (c->busy.load(std::memory_order_acquire)) return true; return false; }
   static bool spin_until(const std::function<bool()>& ready, double max_us) {
     const auto t0 = std::chrono::steady_clock::now();
     while (!ready()) {
@@ -156,77 +191,95 @@ class Pipeline {
     }
     return true;
   }
-  void worker_main() {
+  void worker_main(OdomChain* cp) {
+    OdomChain& c = *cp;
     (void)hipSetDevice(device);
     for (;;) {
-      auto ready = [&] { return o_next.load(std::memory_order_acquire) <= o_limit.load(std::memory_order_acquire); };
+      auto ready = [&] { return c.next.load(std::memory_order_acquire) <= o_limit.load(std::memory_order_acquire); };
       if (!spin_until(ready, 400.0)) {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return ready() || quit; });
         if (quit) return;
       }
       {
-        std::lock_guard<std::mutex> lk(mu);   // (o_busy and o_limit change under the mutex: park_odometry() relies on seeing them together)
+        std::lock_guard<std::mutex> lk(mu);   // (busy and o_limit change under the mutex: park_odometry() relies on seeing them together)
+        if (quit) return;
         if (!ready()) continue;
-        o_busy.store(true, std::memory_order_release);
+        c.busy.store(true, std::memory_order_release);
       }
       std::exception_ptr err;
-      const int k = o_next.load(std::memory_order_acquire);
-      try { trO[0] = tr_us(); run_odometry((uint32_t)k); trO[3] = tr_us(); } catch (...) { err = std::current_exception(); }
+      const int k = c.next.load(std::memory_order_acquire);
+      try { c.tr[0] = tr_us(); run_odometry(c, (uint32_t)k); c.tr[3] = tr_us(); } catch (...) { err = std::current_exception(); }
       {
         std::lock_guard<std::mutex> lk(mu);
-        if (err) { job_err = err; o_limit.store(-1, std::memory_order_release); }   // stop; the calling thread rethrows
-        else { o_next.store(k + 1, std::memory_order_release); o_done.store(k, std::memory_order_release); }
-        o_busy.store(false, std::memory_order_release);
+        if (err) { if (!job_err) job_err = err; o_limit.store(-1, std::memory_order_release); }   // every chain stops; the calling thread rethrows
+        else { c.next.store(k + 1, std::memory_order_release); c.done.store(k, std::memory_order_release); }
+        c.busy.store(false, std::memory_order_release);
       }
       cv.notify_all();
     }
   }
-  // calling thread: allow the odometry chain to run up to step k
+  // calling thread: allow the odometry chains to run up to step k
   void allow_odometry(int k) {
     if (k <= o_limit.load(std::memory_order_acquire)) return;
-    if (!worker.joinable()) worker = std::thread([this] { worker_main(); });
+    for (auto& c : chains)
+      if (!c->worker.joinable()) { OdomChain* cp = c.get(); c->worker = std::thread([this, cp] { worker_main(cp); }); }
     { std::lock_guard<std::mutex> lk(mu); o_limit.store(k, std::memory_order_release); }
     cv.notify_all();
   }
-  // calling thread: block until O(t) is published (rethrows a failure of the worker)
+  // calling thread: block until O(t) of every chain is published (rethrows a failure of a worker)
   void wait_odometry(int t) {
-    auto ready = [&] { return o_done.load(std::memory_order_acquire) >= t || (!o_busy.load(std::memory_order_acquire) && o_limit.load(std::memory_order_acquire) < t); };
+    auto ready = [&] { return done_min() >= t || (!any_busy() && o_limit.load(std::memory_order_acquire) < t); };
     if (!spin_until(ready, 2000.0)) {
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, ready);
     }
     std::lock_guard<std::mutex> lk(mu);
     if (job_err) { std::exception_ptr e = job_err; job_err = nullptr; std::rethrow_exception(e); }
-    LX_REQUIRE(o_done.load() >= t, "internal: the odometry chain stopped before the requested step");
+    LX_REQUIRE(done_min() >= t, "internal: an odometry chain stopped before the requested step");
   }
   // calling thread: block until the look-ahead has finished every step it has been allowed to run (its kernels are enqueued then:
-  // a device synchronisation afterwards covers them).  Returns the last step whose odometry is published, -1 if none.
+  // a device synchronisation afterwards covers them).  Returns the last step whose odometry is published for every stream, -1 if none.
   int drain_lookahead() {
     const int lim = o_limit.load(std::memory_order_acquire);
-    if (prefetch && lim >= 0 && worker.joinable()) wait_odometry(lim);
-    return o_done.load(std::memory_order_acquire);
+    if (prefetch && lim >= 0 && chains[0]->worker.joinable()) wait_odometry(lim);
+    return done_min();
   }
-  // calling thread: stop the look-ahead and wait until the worker is idle; the chain continues at step `next`
-  void park_odometry(int next) {
+  // calling thread: stop the look-ahead and wait until every worker is idle.  restart >= 0: chains that have not reached that step
+  // continue there (the caller jumped); restart < 0: every chain continues where it IS — the positions are read AFTER the workers
+  // have gone idle, under the mutex (a position read before the wait is stale by the step a worker was inside: ADVICE.md round 3)
+  void park_odometry(int restart) {
     std::unique_lock<std::mutex> lk(mu);
     o_limit.store(-1, std::memory_order_release);
-    cv.wait(lk, [&] { return !o_busy.load(std::memory_order_acquire); });
-    o_next.store(next, std::memory_order_release);
-    o_done.store(next - 1, std::memory_order_release);
+    cv.wait(lk, [&] { return !any_busy(); });
+    if (restart >= 0)
+      for (auto& c : chains)
+        if (restart > c->done.load() && restart != c->next.load()) {
+          c->next.store(restart, std::memory_order_release);
+          c->done.store(restart - 1, std::memory_order_release);
+        }
+    job_err = nullptr;
+  }
+  // (upload / first use of the streaming ring: every chain starts over at step 0)
+  void reset_odometry() {
+    std::unique_lock<std::mutex> lk(mu);
+    o_limit.store(-1, std::memory_order_release);
+    cv.wait(lk, [&] { return !any_busy(); });
+    for (auto& c : chains) { c->next.store(0, std::memory_order_release); c->done.store(-1, std::memory_order_release); }
     job_err = nullptr;
   }
 
   ~Pipeline() {
-    if (worker.joinable()) {
-      { std::lock_guard<std::mutex> lk(mu); quit = true; o_limit.store(-1, std::memory_order_release); }
-      cv.notify_all();   // (the worker leaves its spin phase after 0.4 ms and then sees quit)
-      worker.join();
+    { std::lock_guard<std::mutex> lk(mu); quit = true; o_limit.store(-1, std::memory_order_release); }
+    cv.notify_all();   // (a worker leaves its spin phase after 0.4 ms and then sees quit)
+    for (auto& c : chains) if (c->worker.joinable()) c->worker.join();
+    for (auto& c : chains) {
+      for (auto& e : c->ev_tail) if (e) (void)hipEventDestroy(e);
+      for (auto& e : c->tm_a) if (e) (void)hipEventDestroy(e);
+      for (auto& e : c->tm_b) if (e) (void)hipEventDestroy(e);
     }
-    for (auto& e : ev_otail) if (e) (void)hipEventDestroy(e);
     fx.clear();
     for (auto& a : evF) for (auto& e : a) if (e) (void)hipEventDestroy(e);
-    for (auto& tm : tmO) tm.destroy();
     for (auto& tm : tmM) tm.destroy();
     for (auto& e : ev_stage) if (e) (void)hipEventDestroy(e);
     for (auto& r : rawslot) if (r.ev_ingest) (void)hipEventDestroy(r.ev_ingest);
@@ -266,7 +319,7 @@ class Pipeline {
     staged_hi = 0;
     last_step = -1;
     launched.assign(n_steps, 0);
-    park_odometry(0);
+    reset_odometry();
     f_hi = -1;
     for (uint32_t t = 0; t < n_steps; t++) {
       auto f = std::make_unique<FeatureExtractor>(device, fstream);
@@ -309,7 +362,7 @@ class Pipeline {
       streaming = true;
       staged_hi = 0;
       last_step = -1;
-      park_odometry(0);
+      reset_odometry();
       f_hi = -1;
     }
   }
@@ -499,59 +552,63 @@ class Pipeline {
   }
   uint64_t run_count = 0;   // registrations run so far (parity = which full-resolution buffer)
 
-  // odometry of staged step t for every stream (needs its features, launched by the calling thread); results go to ores[t % 3]
-  void run_odometry(uint32_t t) {
-    const uint32_t ns = n_streams_;
+  // odometry of staged step t for the streams of one chain (needs the step's features, launched by the calling thread); results go to
+  // ores[t % 3]
+  void run_odometry(OdomChain& c, uint32_t t) {
+    const uint32_t ns = n_streams_, ng = c.s1 - c.s0;
     FeatureExtractor& F = FX(t);
     LX_REQUIRE(LA(t), "internal: odometry of a step whose features were not launched");
+    OdometryBatch& odom = *c.ob;
     uint32_t* hb = h_off3[t % 3].p;
     uint32_t* ho[3] = {hb, hb + (ns + 1), hb + 2 * (ns + 1)};
     uint32_t* hlf = hb + 3 * (ns + 1);
     LX_HIP(hipEventSynchronize(evF[t % 3][1]));
-    trO[1] = tr_us();
-    LA(t) = 0;
-    if (timing) LX_HIP(hipEventElapsedTime(&feat_ms[t % 3], evF[t % 3][0], evF[t % 3][1]));
-    std::vector<OdomInput> in(ns);
-    std::vector<int> rc(ns, 0);
-    for (uint32_t s = 0; s < ns; s++) {
+    c.tr[1] = tr_us();
+    const bool timed = timing.load(std::memory_order_relaxed);   // latched: the caller flips the flag while this chain runs steps ahead
+    if (timed && c.s0 == 0) LX_HIP(hipEventElapsedTime(&feat_ms[t % 3], evF[t % 3][0], evF[t % 3][1]));
+    std::vector<OdomInput> in(ng);
+    std::vector<int> rc(ng, 0);
+    for (uint32_t s = c.s0; s < c.s1; s++) {
       const uint32_t la = hlf[F.ring_base(s)], lb = hlf[F.ring_base(s + 1)];
-      in[s] = OdomInput{F.d_feat(0) + ho[0][s], ho[0][s + 1] - ho[0][s], F.d_feat(1) + ho[1][s], ho[1][s + 1] - ho[1][s],
-                        F.d_feat(2) + ho[2][s], ho[2][s + 1] - ho[2][s], F.d_less_flat() + la, lb - la};
+      in[s - c.s0] = OdomInput{F.d_feat(0) + ho[0][s], ho[0][s + 1] - ho[0][s], F.d_feat(1) + ho[1][s], ho[1][s + 1] - ho[1][s],
+                               F.d_feat(2) + ho[2][s], ho[2][s + 1] - ho[2][s], F.d_less_flat() + la, lb - la};
     }
-    LazyTimer& tm = tmO[t % 3];
-    if (timing) {
-      tm.create();
-      tm.pending = false;
-      LX_HIP(hipEventRecord(tm.a, odom.stream()));
+    const int slot = (int)(t % 3);
+    if (timed) {   // this chain's own event pair for this step: both ends are recorded by this thread in this call
+      if (!c.tm_a[slot]) { LX_HIP(hipEventCreate(&c.tm_a[slot])); LX_HIP(hipEventCreate(&c.tm_b[slot])); }
+      c.tm_pending[slot] = false;
+      LX_HIP(hipEventRecord(c.tm_a[slot], odom.stream()));
     }
     if (streaming && rawslot[t % RING].raw)   // imuTrans of this sweep (ScanRegistration publishes it with the clouds; LaserOdometry.cpp:239-248)
-      for (uint32_t s = 0; s < ns; s++) odom.update_imu(s, &rawslot[t % RING].imu_trans[12 * (size_t)s]);
+      for (uint32_t s = c.s0; s < c.s1; s++) odom.update_imu(s - c.s0, &rawslot[t % RING].imu_trans[12 * (size_t)s]);
     odom.process(in.data(), rc.data(), true);   // returns once the poses are known; clouds ready at odom.tail_event()
-    trO[2] = tr_us();
-    if (timing) {
-      LX_HIP(hipEventRecord(tm.b, odom.stream()));
-      tm.pending = true;
+    c.tr[2] = tr_us();
+    if (!c.ev_tail[slot]) LX_HIP(hipEventCreateWithFlags(&c.ev_tail[slot], hipEventDisableTiming));
+    LX_HIP(hipEventRecord(c.ev_tail[slot], odom.stream()));   // behind the tail that process() enqueued
+    if (timed) {   // the chain of step t = everything process() enqueued, tail included
+      LX_HIP(hipEventRecord(c.tm_b[slot], odom.stream()));
+      c.tm_pending[slot] = true;
     }
-    if (!ev_otail[t % 3]) LX_HIP(hipEventCreateWithFlags(&ev_otail[t % 3], hipEventDisableTiming));
-    LX_HIP(hipEventRecord(ev_otail[t % 3], odom.stream()));   // behind the tail that process() enqueued
-    if (timing) {   // (this thread's own timers: the elapsed time of an older step is taken once its events have completed)
-      for (auto& x : tmO) x.resolve();
-      odom_ms.store(tmO[(t + 2) % 3].pending ? tmO[(t + 1) % 3].ms : tmO[(t + 2) % 3].ms, std::memory_order_relaxed);
-    }
-    ores[t % 3].resize(ns);
-    for (uint32_t s = 0; s < ns; s++) {
-      OdomStream& O = odom.stream_state(s);
-      OdomPub& N = ores[t % 3][s];
+    for (int k = 0; k < 3; k++)   // (the elapsed time of an older step is taken once its events have completed: measuring never waits)
+      if (c.tm_pending[k] && hipEventQuery(c.tm_b[k]) == hipSuccess) {
+        float ms = 0.f;
+        LX_HIP(hipEventElapsedTime(&ms, c.tm_a[k], c.tm_b[k]));
+        c.tm_pending[k] = false;
+        c.ms.store(ms, std::memory_order_relaxed);
+      }
+    for (uint32_t s = c.s0; s < c.s1; s++) {
+      const uint32_t l = s - c.s0;
+      OdomStream& O = odom.stream_state(l);
+      OdomPub& N = ores[slot][s];
       N.transform = O.transform;
       N.transform_sum = O.transform_sum;
       N.stats = O.stats;
-      N.rc = rc[s];
-      N.last_corner = odom.d_last_corner(s); N.n_last_corner = O.n_last_corner;
-      N.last_surf = odom.d_last_surf(s); N.n_last_surf = O.n_last_surf;
-      N.to_end = odom.to_end_params(s, true);
+      N.rc = rc[l];
+      N.last_corner = odom.d_last_corner(l); N.n_last_corner = O.n_last_corner;
+      N.last_surf = odom.d_last_surf(l); N.n_last_surf = O.n_last_surf;
+      N.to_end = odom.to_end_params(l, true);
     }
   }
-
   // Software pipeline over consecutive steps (the stages are separate ROS nodes in the reference, so nothing in a later
   // stage of step t feeds an earlier stage of step t+1):
   //   registration M(t) on the registrar's stream  ||  odometry O(t+1) on the odometry stream  ||  features F(t+2)
@@ -560,7 +617,6 @@ class Pipeline {
   bool trace = getenv("LOAMX_PIPE_TRACE") != nullptr;
   std::chrono::steady_clock::time_point tr0;
   double tr_us() const { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); }
-  double trO[4] = {0, 0, 0, 0};
 
   int step(uint32_t t) {
     TraceRange trace_range("loamx:pipeline:step");
@@ -573,32 +629,40 @@ class Pipeline {
     const uint32_t ns = n_streams_;
     // ---- this step's odometry: published by the look-ahead (the normal case), or run now
     const int ti = (int)t, last_staged = (int)n_staged() - 1;
-    if (ti > o_done.load(std::memory_order_acquire) && ti != o_next.load(std::memory_order_acquire)) {   // not the next step of the chain: it restarts here
-      park_odometry(ti);
-      f_hi = ti - 1;
+    {
+      bool jump = false;   // a chain for which this is neither a finished step nor its next one: the caller jumped, the chains restart here
+      for (auto& c : chains) jump = jump || (ti > c->done.load(std::memory_order_acquire) && ti != c->next.load(std::memory_order_acquire));
+      if (jump) {
+        park_odometry(ti);
+        f_hi = ti - 1;
+      }
     }
-    LX_REQUIRE(ti + 2 >= o_done.load(std::memory_order_acquire), "this step's odometry results have been overwritten: steps run in order");
+    LX_REQUIRE(ti + 2 >= done_max(), "this step's odometry results have been overwritten: steps run in order");
     auto launch_upto = [&](int k) {   // features of the steps up to k (launched by this thread only, in step order)
       if (k > last_staged) k = last_staged;
       while (f_hi < k) { ++f_hi; if (!LA((uint32_t)f_hi)) launch_features((uint32_t)f_hi); }
     };
-    if (ti > o_done.load(std::memory_order_acquire)) {
+    if (ti > done_min()) {
       launch_upto(prefetch ? ti + 1 : ti);
       if (prefetch) {
         allow_odometry(std::min(ti + 1, last_staged));
         wait_odometry(ti);
       } else {
-        if (o_limit.load(std::memory_order_acquire) >= 0) park_odometry(ti);   // the look-ahead was switched off: the chain goes on here
-        run_odometry(t);
-        o_next.store(ti + 1, std::memory_order_release);
-        o_done.store(ti, std::memory_order_release);
+        if (o_limit.load(std::memory_order_acquire) >= 0) park_odometry(-1);   // the look-ahead was switched off: the chains go on here
+        for (auto& c : chains)
+          if (ti > c->done.load(std::memory_order_acquire)) {
+            run_odometry(*c, t);
+            c->next.store(ti + 1, std::memory_order_release);
+            c->done.store(ti, std::memory_order_release);
+          }
       }
     }
+    LA(t) = 0;   // every chain has consumed the step's features (a restart at this step extracts them again: their offsets' slot is reused by step t + 3)
     for (uint32_t s = 0; s < ns; s++) st[s].cur = ores[t % 3][s];
     FeatureExtractor& F = FX(t);
     const float f_ms = feat_ms[t % 3];
-    // the re-projected "last" clouds of THIS sweep are produced at the tail of the odometry stream
-    LX_HIP(hipStreamWaitEvent(s_, ev_otail[t % 3], 0));
+    // the re-projected "last" clouds of THIS sweep are produced at the tails of the odometry chains
+    for (auto& c : chains) LX_HIP(hipStreamWaitEvent(s_, c->ev_tail[t % 3], 0));
     // ---- look-ahead while M(t) runs: the odometry chain may go on to step t+1 now and — once M(t) is enqueued and the features
     // of step t+2 are launched (while this thread waits for M(t)'s first look at the flags) — to step t+2
     if (prefetch) {
@@ -652,7 +716,7 @@ class Pipeline {
         for (uint32_t k = 0; k < nw; k++) foff[k + 1] = foff[k] + nfr[k];
         last_full_off = foff;
         run_count++;
-        odom.to_end_gather(full_dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
+        chains[0]->ob->to_end_gather(full_dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
         reg.upload_device(nw, cl.data(), ncl.data(), sl.data(), nsl.data(), nullptr, nullptr, guess.data());
         reg.on_first_wait = launch_f2;
         reg.run_async();
@@ -695,12 +759,16 @@ class Pipeline {
     trM[3] = tr_us();
     last_step = (long)t;
     if (trace)
-      fprintf(stderr, "[pipe t=%u] M-start %.0f  M-enqueued %.0f  M-downloaded %.0f  O-joined %.0f | O thread: start %.0f feat-ready %.0f process-done %.0f end %.0f\n", t,
-              trM[0], trM[1], trM[2], trM[3], trO[0], trO[1], trO[2], trO[3]);
+      fprintf(stderr, "[pipe t=%u] M-start %.0f  M-enqueued %.0f  M-downloaded %.0f  O-joined %.0f | O chain 0: start %.0f feat-ready %.0f process-done %.0f end %.0f\n", t,
+              trM[0], trM[1], trM[2], trM[3], chains[0]->tr[0], chains[0]->tr[1], chains[0]->tr[2], chains[0]->tr[3]);
     if (timing) {
       for (auto& x : tmM) x.resolve();
       last_ms[0] = f_ms;               // on the feature stream (overlapped)
-      last_ms[1] = odom_ms.load(std::memory_order_relaxed);   // on the odometry stream (overlapped with the registrations)
+      {   // the odometry chains (overlapped with the registrations): the longest chain's most recent timed pass
+        float m = 0.f;
+        for (auto& c : chains) m = std::max(m, c->ms.load(std::memory_order_relaxed));
+        last_ms[1] = m;
+      }
       last_ms[2] = tmM[t & 1].pending ? tmM[(t + 1) & 1].ms : tmM[t & 1].ms;   // the previous step's while this one is in flight
       last_ms[3] = last_ms[2];
     }
@@ -775,9 +843,9 @@ int loamx_pipeline_set_state(loamx_pipeline* h, uint32_t stream, const float* tr
                              const float* aft) {
   return guard([&]() {
     LX_REQUIRE(h && stream < h->p.n_streams_, "invalid stream");
-    h->p.park_odometry(h->p.o_done.load() + 1);   // the odometry chain stops; the sweeps it has not processed yet start from the new state
-    if (transform) h->p.odom.stream_state(stream).transform.set(transform);
-    if (transform_sum) h->p.odom.stream_state(stream).transform_sum.set(transform_sum);
+    h->p.park_odometry(-1);   // the odometry chains stop where they are; the sweeps they have not processed yet start from the new state
+    if (transform) h->p.OB(stream).stream_state(h->p.LS(stream)).transform.set(transform);
+    if (transform_sum) h->p.OB(stream).stream_state(h->p.LS(stream)).transform_sum.set(transform_sum);
     if (bef) h->p.st[stream].bef.set(bef);
     if (aft) h->p.st[stream].aft.set(aft);
     return LOAMX_OK;
@@ -846,7 +914,7 @@ int loamx_pipeline_download_full_res(loamx_pipeline* h, uint32_t slot, loamx_clo
 int loamx_pipeline_set_lookahead(loamx_pipeline* h, int on) {
   return guard([&]() {
     LX_REQUIRE(h, "NULL handle");
-    if (!on && h->p.prefetch) h->p.park_odometry(h->p.o_next.load());   // (the worker finishes the step it is in)
+    if (!on && h->p.prefetch) h->p.park_odometry(-1);   // (every worker finishes the step it is in; the chains continue from there)
     h->p.prefetch = on != 0;
     return LOAMX_OK;
   });

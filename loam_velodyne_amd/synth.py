@@ -197,6 +197,20 @@ def make_sweep(world: World, sensor: str, pose_start, pose_end, noise: float = 0
     return Sweep(pts, np.full(R, A, np.int32), pose_start.astype(np.float32), pose_end.astype(np.float32))
 
 
+_JOB_WORLDS = {}
+
+
+def make_sweep_job(job):
+    """(half_extent, sensor, pose_start, pose_end, seed) -> (points, ring_sizes): make_sweep for a worker process (bench.py generates
+    its sweeps in parallel); the world of a given extent is built once per process."""
+    half_extent, sensor, pose_start, pose_end, seed = job
+    w = _JOB_WORLDS.get(half_extent)
+    if w is None:
+        w = _JOB_WORLDS[half_extent] = World(half_extent=half_extent)
+    sw = make_sweep(w, sensor, pose_start, pose_end, seed=seed)
+    return sw.points, sw.ring_sizes
+
+
 def to_raw(sweep: Sweep, bad_every: int = 0) -> np.ndarray:
     """The sweep as a Velodyne driver delivers it (what MultiScanRegistration::process consumes): (N,3) float32 in SENSOR
     axes (x forward, y left, z up — the inverse of the remap at MultiScanRegistration.cpp:184-186) in firing order

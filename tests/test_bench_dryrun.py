@@ -209,8 +209,11 @@ class FakeLib:
 
 
 @pytest.mark.parametrize("argv", [["--steps", "3", "--warmup", "1", "--streams", "2", "--sensor", "VLP-16", "--map-points", "2000", "--no-cpu-baseline",
-                                   "--repeat", "2"]])
+                                   "--repeat", "2"],
+                                  ["--steps", "3", "--warmup", "1", "--streams", "2", "--sensor", "VLP-16", "--map-points", "2000", "--no-cpu-baseline",
+                                   "--repeat", "2", "--handles", "2"]])
 def test_bench_main_runs_over_stand_ins(monkeypatch, capsys, argv):
+    H = int(argv[argv.index("--handles") + 1]) if "--handles" in argv else 1
     from loam_velodyne_amd import loamx
     monkeypatch.setitem(sys.modules, "torch", fake_torch())
     monkeypatch.setattr(loamx, "Pipeline", FakePipeline)
@@ -230,12 +233,17 @@ def test_bench_main_runs_over_stand_ins(monkeypatch, capsys, argv):
         assert key in out, key
     assert out["steps"] == K and out["warmup"] == W and out["n_gpus"] == 1 and out["config"]["streams_per_gpu"] == ns
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
-    assert out["value_repeats"] == 2 and len(out["pcie_inclusive"]["value_windows"]) == 3
+    assert out["value_repeats"] == 2 and out["config"]["handles_per_gpu"] == H
+    if H == 1:
+        assert len(out["pcie_inclusive"]["value_windows"]) == 3
+    else:   # (the PCIe-inclusive window is a single-handle measurement)
+        assert out["pcie_inclusive"] is None
     # the windows: every resident one staged K + 1 + W + 2 steps, ran 1 + W + K of them, and drained the look-ahead after its last step;
     # the PCIe ones staged the same number one at a time
     resident = [p for p in FakePipeline.instances if p.uploaded]
     streaming = [p for p in FakePipeline.instances if p.staged]
-    assert len(resident) == 2 and len(streaming) == 3
+    assert len(resident) == 2 * H and len(streaming) == (3 if H == 1 else 0)
+    assert all(p.ns == ns // H for p in resident)   # the streams are dealt over the handles, each driven by its own host thread
     for p in resident:   # (drained when the window opens — after the last warm-up step — and before it closes)
         assert p.uploaded == 1 + W + K + 2 and p.last == W + K and p.drains == [W, W + K] and p.closed
     for p in streaming:

@@ -591,6 +591,8 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
 
 #pragma clang diagnostic pop
 
+__global__ void k_odom_noop(const OdomProblem* __restrict__ probs) { (void)probs; }
+
 // transformToEnd (:57-87) of one point
 __device__ inline float4 to_end_point(float4 p, const ToEndParams& P) {
   const float s = (1.f / P.scan_period) * (p.w - (float)(int)p.w);
@@ -872,6 +874,10 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
           else hipLaunchKernelGGL(k_odom_lm<1>, dim3(nb, nc), dim3(OD_THREADS), 0, st_, prob_.p + a0, params, it0, nit);
         }
       }
+    }
+    {   // diagnostic (LOAMX_ODOM_NOOPS=n): n empty launches behind the iterations — what a kernel boundary costs the OTHER chains
+      static const int noops = getenv("LOAMX_ODOM_NOOPS") ? atoi(getenv("LOAMX_ODOM_NOOPS")) : 0;
+      for (int k = 0; k < noops; k++) hipLaunchKernelGGL(k_odom_noop, dim3(1), dim3(64), 0, st_, prob_.p);
     }
     if (!max_feat) LX_HIP(hipMemcpyAsync(h_mirror_.p, prob_.p, sizeof(OdomProblem) * na, hipMemcpyDeviceToHost, st_));   // (no launch wrote the mirror)
     if (!ev_pose_) LX_HIP(hipEventCreateWithFlags(&ev_pose_, hipEventDisableTiming));

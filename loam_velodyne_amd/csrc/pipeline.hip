@@ -43,9 +43,11 @@ class Pipeline {
     // The odometry of the streams runs as G independent chains ("groups"), each with its own OdometryBatch, HIP stream and host thread:
     // a stream whose sweep needs 25 iterations (BasicLaserOdometry.cpp:246 runs to maxIterations when the stop test at :613-620 never
     // fires) delays only its own group, and the two steps of look-ahead absorb it — with ONE chain every step paid the launch pairs of
-    // the slowest of all streams (profiles/r03: 5.2 pairs per step for a mean of 7.1 iterations).
+    // the slowest of all streams (profiles/r03: 5.2 pairs per step for a mean of 7.1 iterations).  Default 2: measured on MI355X
+    // (profiles/r04_groups_ab.md) 1 -> 2 chains gains 8 %, but with 4 (six busy HIP streams in the process) EVERY chain slows down
+    // (registration 0.55 -> 0.88 ms, k_gn_iter 64 -> 93 us) and the step is 35 % slower than with one.
     {
-      int g = (int)std::min<uint32_t>(n_streams, 4);
+      int g = (int)std::min<uint32_t>(n_streams, 2);
       if (const char* e = getenv("LOAMX_ODOM_GROUPS")) g = atoi(e);
       n_groups = (uint32_t)std::max(1, std::min(g, (int)std::min<uint32_t>(n_streams, MAX_GROUPS)));
     }
@@ -66,7 +68,7 @@ class Pipeline {
     reg.params.surf_leaf = mc.surf_filter_size;
     for (auto& c : chains) {
       c->ob->params.scan_period = oc.scan_period;
-      c->ob->params.max_iterations = oc.max_iterations;
+      c->ob->params.max_iterations = getenv("LOAMX_ODOM_MAXIT") ? atoi(getenv("LOAMX_ODOM_MAXIT")) : oc.max_iterations;   // (diagnostic override)
       c->ob->params.delta_t_abort = oc.delta_t_abort;
       c->ob->params.delta_r_abort = oc.delta_r_abort;
     }
@@ -196,7 +198,8 @@ class Pipeline {
     (void)hipSetDevice(device);
     for (;;) {
       auto ready = [&] { return c.next.load(std::memory_order_acquire) <= o_limit.load(std::memory_order_acquire); };
-      if (!spin_until(ready, 400.0)) {
+      static const double spin_us = getenv("LOAMX_SPIN_US") ? atof(getenv("LOAMX_SPIN_US")) : 400.0;   // diagnostic
+      if (!spin_until(ready, spin_us)) {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return ready() || quit; });
         if (quit) return;
@@ -615,14 +618,16 @@ class Pipeline {
   // step(t) returns when M(t) is complete; O(t+1) / F(t+2) are look-ahead whose results are kept for the next call.
   // host-side timeline of one step (LOAMX_PIPE_TRACE=1): microseconds since step() entry
   bool trace = getenv("LOAMX_PIPE_TRACE") != nullptr;
-  std::chrono::steady_clock::time_point tr0;
+  std::chrono::steady_clock::time_point tr0, tr_exit = std::chrono::steady_clock::now();
   double tr_us() const { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count(); }
 
   int step(uint32_t t) {
     TraceRange trace_range("loamx:pipeline:step");
     LX_REQUIRE(t < n_staged(), "step index beyond the staged sweeps");
     LX_REQUIRE(!streaming || t + RING >= staged_hi.load(), "this step's slot has been re-staged already");   // (slot t % RING is rewritten by staging step t + RING)
-    tr0 = std::chrono::steady_clock::now();
+    const auto t_entry = std::chrono::steady_clock::now();
+    const double gap_us = std::chrono::duration<double, std::micro>(t_entry - tr_exit).count();   // the caller's time between two steps
+    tr0 = t_entry;
     double trM[6] = {0, 0, 0, 0, 0, 0};
     LX_HIP(hipSetDevice(device));
     hipStream_t s_ = reg.stream();
@@ -758,9 +763,13 @@ class Pipeline {
     }
     trM[3] = tr_us();
     last_step = (long)t;
-    if (trace)
-      fprintf(stderr, "[pipe t=%u] M-start %.0f  M-enqueued %.0f  M-downloaded %.0f  O-joined %.0f | O chain 0: start %.0f feat-ready %.0f process-done %.0f end %.0f\n", t,
-              trM[0], trM[1], trM[2], trM[3], chains[0]->tr[0], chains[0]->tr[1], chains[0]->tr[2], chains[0]->tr[3]);
+    tr_exit = std::chrono::steady_clock::now();
+    if (trace) {
+      fprintf(stderr, "[pipe t=%u] caller gap %.0f | M-start %.0f  M-enqueued %.0f  M-downloaded %.0f  O-joined %.0f |", t, gap_us, trM[0], trM[1], trM[2], trM[3]);
+      for (auto& c : chains)   // (each chain's most recent pass, whichever step that was: start, features ready, process() returned, end)
+        fprintf(stderr, " O[%u-%u): %.0f %.0f %.0f %.0f |", c->s0, c->s1, c->tr[0], c->tr[1], c->tr[2], c->tr[3]);
+      fprintf(stderr, "\n");
+    }
     if (timing) {
       for (auto& x : tmM) x.resolve();
       last_ms[0] = f_ms;               // on the feature stream (overlapped)

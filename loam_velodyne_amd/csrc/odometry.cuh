@@ -38,6 +38,9 @@ struct OdomProblem {
   OdomProblem* host_mirror;   // pinned host copy that k_odom_lm fills with transform / stats / done (no D2H copy on the stream)
   unsigned ticket;        // k_odom_lm: workgroup arrivals since the problem was set up (per-stream barrier)
   double* part;           // k_odom_lm: [2][16][LX_NSUM] partial normal equations of the stream's workgroups
+  const uint32_t* rf_corner;   // ring-first tables of last_corner / last_surf (k_odom_corr_lds: where to expect the ring windows — a hint)
+  const uint32_t* rf_surf;
+  uint32_t rf_epoch;
   uint32_t* err_word;     // pinned host word raised when k_odom_lm's exchange times out (checked by the host after the pose event)
 };
 
@@ -111,6 +114,8 @@ class OdometryBatch {
   DevBuf<double> part_;
   PinBuf<OdomProblem> h_mirror_;
   PinBuf<uint32_t> h_err_;
+  DevBuf<uint32_t> rf_;   // [2 * n_streams][OD_RF_N] ring-first tables of the clouds handed on by the last call (entries tagged with rf_epoch_)
+  uint32_t rf_epoch_ = 0;
   // what a call sends up before its first kernel — the problems, the re-projection parameters, the cloud offsets — is ONE block in
   // pinned memory and ONE copy (three copies were three ~7 us commands at the head of the odometry chain, the pipeline's longest)
   template <class T> struct View { T* p = nullptr; };

@@ -41,6 +41,9 @@ __device__ inline void transform_to_start(const float* T, float scan_period, con
   rot_y(x, z, cy, sy);
 }
 
+// cell-sorted copies of the previous clouds carry (ring << 24) | index inside the cloud in .w (k_bb_scatter with pack_ring); ring 255 = unknown
+constexpr uint32_t OD_IDX_MASK = 0xffffffu;
+
 __device__ inline float sqd(const float4& a, float x, float y, float z) {
   const float dx = a.x - x, dy = a.y - y, dz = a.z - z;
   return dx * dx + dy * dy + dz * dz;
@@ -63,16 +66,15 @@ __device__ inline void wave_argmin(float& d, int& j, int& order) {
 // that pruning and termination stay wave-uniform.  A row is skipped when its (y,z) slab is already farther than the
 // best distance, and its x-run is clipped to the cells the best-distance ball can reach (bounds shrunk by a relative
 // 1e-4 so float rounding can only make the search visit MORE cells, never fewer).
-__device__ inline int nn1_wave(const GridDesc& g, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, float qx,
-                               float qy, float qz, int lane) {
-  float best = 25.0f;           // wave-uniform bound (only candidates with d2 < 25 are admissible)
-  float lbest = 25.0f;          // this lane's best
-  uint32_t lid = 0xffffffffu;
-  int best_id = -1;
+// L0 / best / best_id: the shells below L0 have been searched already (nn1_wave_flat's 27-cell block) with this wave-uniform result
+__device__ inline int nn1_shells(const GridDesc& g, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, float qx,
+                                 float qy, float qz, int lane, int L0, float best, int best_id) {
+  float lbest = best;           // this lane's best (best: wave-uniform bound; only candidates with d2 < 25 are admissible)
+  uint32_t lid = best_id >= 0 ? (uint32_t)best_id : 0xffffffffu;
   const float h = 1.0f / g.inv_h;
   const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
   const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
-  for (int L = 0;; L++) {
+  for (int L = L0;; L++) {
     const int side = 2 * L + 1, nrows = side * side;
     for (int r0 = 0; r0 < nrows; r0 += 64) {
       // ---- lane r: ranges of row r0 + lane
@@ -118,7 +120,7 @@ __device__ inline int nn1_wave(const GridDesc& g, const float4* __restrict__ sor
             const float4 p = sorted[k];
             const float dx = qx - p.x, dy2 = qy - p.y, dz2 = qz - p.z;
             const float d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
-            const uint32_t id = __float_as_uint(p.w);
+            const uint32_t id = __float_as_uint(p.w) & OD_IDX_MASK;   // (the top byte carries the point's ring: SubMapIndexBatch::pack_ring)
             if (d2 < lbest || (d2 == lbest && lid != 0xffffffffu && id < lid)) { lbest = d2; lid = id; }
           }
         }
@@ -136,14 +138,319 @@ __device__ inline int nn1_wave(const GridDesc& g, const float4* __restrict__ sor
   }
   return best_id;
 }
+__device__ inline int nn1_wave(const GridDesc& g, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, float qx,
+                               float qy, float qz, int lane) {
+  return nn1_shells(g, sorted, cell_start, qx, qy, qz, lane, 0, 25.0f, -1);
+}
 
-// ---- phases A+B: correspondences of one feature by one wave: exact 1-NN, then the ring-window scans;
-// grid = (ceil(maxFeat/4), streams), 256 threads
+// ---- the 3x3x3 block of cells around a query, enumerated flat (round 4).  nn1_wave walks the rows of a shell one after the other, a
+// load latency each — ~10 of them before the 2.1 m shell is done.  Here: trip 1, the 18 boundaries of the block's 9 rows (a row's
+// three cells are one contiguous run of the cell-sorted array), one per lane; then the block's candidates numbered 0 .. total-1 across
+// the runs and dealt over the 64 lanes, 4 independent 16-byte loads in flight per lane.  The block contains the ball of radius h
+// around the query: a minimum below h^2 found in it is the minimum over the whole cloud.
 #ifdef OD_CORR_WAVES
 #define OD_CORR_ATTR __attribute__((amdgpu_waves_per_eu(OD_CORR_WAVES, OD_CORR_WAVES)))
 #else
 #define OD_CORR_ATTR
 #endif
+struct Block27 {
+  uint32_t E[9], O[9];   // cumulative candidate count after run r; position of candidate cc of run r = cc + O[r]
+  uint32_t total;
+};
+__device__ inline void block27_build(const GridDesc& g, const uint32_t* __restrict__ cell_start, float qx, float qy, float qz, int lane, Block27& B) {
+  const float fx = (qx - g.ox) * g.inv_h, fy = (qy - g.oy) * g.inv_h, fz = (qz - g.oz) * g.inv_h;
+  const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+  uint32_t v = 0u;
+  {
+    const int r = lane >> 1, z = cz + r / 3 - 1, y = cy + r % 3 - 1;
+    if (lane < 18 && z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+      int xx = (lane & 1) ? cx + 2 : cx - 1;   // run [cx - 1, cx + 1] = cell_start[cx - 1] .. cell_start[cx + 2], clamped onto the row
+      xx = xx < 0 ? 0 : (xx > g.nx ? g.nx : xx);
+      v = cell_start[((uint32_t)z * g.ny + y) * g.nx + xx];
+    }
+  }
+  uint32_t acc = 0;
+#pragma unroll
+  for (int r = 0; r < 9; r++) {
+    const uint32_t b = (uint32_t)__shfl((int)v, 2 * r, 64), e = (uint32_t)__shfl((int)v, 2 * r + 1, 64);
+    B.O[r] = b - acc;
+    acc += e > b ? e - b : 0u;
+    B.E[r] = acc;
+  }
+  B.total = acc;
+}
+// visit(point, valid): called for 4 candidates per lane and trip, every lane the same number of times (valid = false past the end)
+template <class F>
+__device__ inline void block27_scan(const Block27& B, const float4* __restrict__ sorted, int lane, F&& visit) {
+  for (uint32_t c0 = (uint32_t)lane; c0 < B.total; c0 += 4 * 64) {
+    uint32_t pos[4];
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t cc = c0 + 64u * u;
+      uint32_t o = B.O[8];
+#pragma unroll
+      for (int k = 7; k >= 0; k--) o = cc < B.E[k] ? B.O[k] : o;
+      pos[u] = cc < B.total ? cc + o : B.O[0];   // (O[0] = the first run's first slot: a valid address whenever total > 0)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) p[u] = sorted[pos[u]];
+#pragma unroll
+    for (int u = 0; u < 4; u++) visit(p[u], (c0 + 64u * u) < B.total);
+  }
+}
+// exact nearest neighbour (d2 < 25) = nn1_wave's result: the block first, and only when nothing lies within h of the query (rare) the
+// shells from 2 on.  w_out: the winner's packed .w (ring << 24 | index)
+__device__ inline int nn1_block(const GridDesc& g, const Block27& B, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start,
+                                float qx, float qy, float qz, int lane, uint32_t& w_out) {
+  float lbest = 25.0f;
+  uint32_t lw = 0xffffffffu;   // packed .w of this lane's best
+  block27_scan(B, sorted, lane, [&](const float4& p, bool valid) {
+    const float dx = qx - p.x, dy2 = qy - p.y, dz2 = qz - p.z;
+    const float d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
+    const uint32_t w = __float_as_uint(p.w);
+    if (valid && (d2 < lbest || (d2 == lbest && lw != 0xffffffffu && (w & OD_IDX_MASK) < (lw & OD_IDX_MASK)))) { lbest = d2; lw = w; }
+  });
+  float d = lbest;
+  int j = lw == 0xffffffffu ? -1 : (int)(lw & OD_IDX_MASK), o_ = lw == 0xffffffffu ? 0x7fffffff : (int)(lw & OD_IDX_MASK);
+  int ring = (int)(lw >> 24);
+  {   // wave arg-min of (d, index) carrying the ring along
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float od = __shfl_xor(d, off, 64);
+      const int oj = __shfl_xor(j, off, 64), oo = __shfl_xor(o_, off, 64), orr = __shfl_xor(ring, off, 64);
+      if (od < d || (od == d && oo < o_)) { d = od; j = oj; o_ = oo; ring = orr; }
+    }
+  }
+  const float h = 1.0f / g.inv_h;
+  if (j >= 0 && d < 25.0f && d <= h * h) { w_out = ((uint32_t)ring << 24) | (uint32_t)j; return j; }
+  const int id = nn1_shells(g, sorted, cell_start, qx, qy, qz, lane, 2, (j >= 0 && d < 25.0f) ? d : 25.0f, (j >= 0 && d < 25.0f) ? j : -1);
+  w_out = id == j ? (((uint32_t)ring << 24) | (uint32_t)j) : (0xff000000u | (uint32_t)(id < 0 ? 0 : id));   // (a shell winner's ring: unknown here)
+  return id;
+}
+
+// ---- correspondences, round 4: k_odom_corr's structure (one wave per feature, no LDS, XCD-aware feature order) with
+//   * the nearest neighbour from the flat 27-cell block (nn1_block: 3 dependent trips instead of ~10), its ring from the packed .w
+//     (no dependent load of last[closest].w), and
+//   * the +-2.5-ring windows searched THROUGH THE SAME BLOCK when that is the shorter way.  The reference walks every point of up to
+//     five rings (:262-297 / :378-429); the upper rings of an HDL-64E less-flat cloud hold ~2,000 points each (far walls: the 0.2 m
+//     voxel filter merges nothing there), so their features scanned ~6,000 points each and were the kernel's long pole (24 us against
+//     12 for a mid ring, in-kernel time stamps).  For a ring-ORDERED previous cloud — verified point by point by the re-projection
+//     kernel, not assumed — the walk's candidate set is {index < closest, ring >= cscan - 2} u {closest < index < bound, ring <= cscan + 2},
+//     so the nearest qualifying point can be looked up in the grid instead: the block's candidates (already in cache from the
+//     nearest-neighbour pass) are filtered by ring and index and ranked by (distance, scan order) exactly like the walk.  A slot's block
+//     minimum is final when it lies strictly inside the ball the block contains (d2 < h^2); otherwise — sparse ground rings 20-50 m out,
+//     whose neighbours are metres apart — the feature takes the walk, which is short exactly there.  The choice (walk length from the
+//     ring-first table against the block's candidate count) only decides speed; both ways give the same ind[] triple.
+// Measured and dropped on the way (profiles/r04_corr.md): the windows staged in LDS by 32- and 8-feature workgroups (5x less L2
+// traffic, no faster: the searches are latency chains, not bandwidth).
+constexpr int OD_RF_N = 320;           // ring-first table entries per cloud: rings 0..318 (ring ids < 256: loamx.h); entry 319 = epoch of the last UNORDERED version of the cloud
+#ifdef LOAMX_PROF_CORR
+__device__ unsigned long long g_corr_ts[3][16];   // [corner feature / flat mid / last flat][stamp]
+#define OC_TS(k) do { if (blockIdx.y == 0 && lane == 0 && ts_slot >= 0) g_corr_ts[ts_slot][k] = wall_clock64(); } while (0)
+#else
+#define OC_TS(k) do { } while (0)
+#endif
+__global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr_grid(OdomProblem* __restrict__ probs, OdomParams P) {
+  OdomProblem& pb = probs[blockIdx.y];
+  if (pb.done) return;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nSharp = (int)pb.n_sharp, nFlat = (int)pb.n_flat;
+  int f;
+  {   // XCD-aware order as in k_odom_corr: XCD x takes the x-th eighth of every stream's sharp and flat lists
+    const int x = (int)(blockIdx.x % 8), j = (int)(blockIdx.x / 8);
+    const int sS = (int)((long long)x * nSharp / 8), nS = (int)((long long)(x + 1) * nSharp / 8) - sS;
+    const int sF = (int)((long long)x * nFlat / 8), nF = (int)((long long)(x + 1) * nFlat / 8) - sF;
+    const int fl = 4 * j + wid;
+    if (fl >= nS + nF) return;
+    f = fl < nS ? sS + fl : nSharp + sF + (fl - nS);
+  }
+#ifdef LOAMX_PROF_CORR
+  const int ts_slot = f == nSharp / 2 ? 0 : f == nSharp + nFlat / 2 ? 1 : f == nSharp + nFlat - 1 ? 2 : -1;
+#endif
+  OC_TS(0);
+  float T[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) T[k] = pb.transform[k];
+  const bool corner = f < nSharp;
+  const float4 pi = corner ? pb.sharp[f] : pb.flat[f - nSharp];
+  const uint32_t* __restrict__ tbl = corner ? pb.rf_corner : pb.rf_surf;
+  // the ring-first entries around the feature's own ring (one per lane: rings rf - 8 .. rf + 55), asked for before the search needs them
+  const int e0 = max((int)pi.w - 8, 0);
+  uint32_t tv = 0u, unordered_epoch = 0u;
+  if (tbl) {
+    if (e0 + lane < OD_RF_N - 1) tv = tbl[e0 + lane];
+    unordered_epoch = tbl[OD_RF_N - 1];
+  }
+  float x, y, z;
+  transform_to_start(T, P.scan_period, pi, x, y, z);
+  const GridDescB gd = corner ? *pb.lc_desc : *pb.ls_desc;
+  const float4* __restrict__ sorted = pb.sorted;
+  const uint32_t* __restrict__ cell_start = pb.cell_table + gd.cell_base;
+  OC_TS(1);
+  Block27 B;
+  block27_build(gd.g, cell_start, x, y, z, lane, B);
+  OC_TS(2);
+  uint32_t wbest = 0u;
+  const int closest = nn1_block(gd.g, B, sorted, cell_start, x, y, z, lane, wbest);
+  OC_TS(3);
+  if (closest < 0) {   // wave-uniform
+    if (lane == 0) { pb.ind[5 * f] = -1; pb.ind[5 * f + 1] = -1; pb.ind[5 * f + 2] = -1; }
+    return;
+  }
+  const float4* last = corner ? pb.last_corner : pb.last_surf;
+  const int nLast = corner ? (int)pb.n_last_corner : (int)pb.n_last_surf;
+  const int nCur = corner ? nSharp : nFlat;
+  const int bound = nCur < nLast ? nCur : nLast;   // forward scans are bounded by the CURRENT feature count (:262, :378)
+  const int cscan = (wbest >> 24) != 255u ? (int)(wbest >> 24) : (int)last[closest].w;
+  float d2 = 25.f, d3 = 25.f;
+  int j2 = -1, j3 = -1, o2 = 0x7fffffff, o3 = 0x7fffffff;
+  auto better = [](float d, int order, float dbest, int obest) { return d < dbest || (d == dbest && obest != 0x7fffffff && order < obest); };   // scan order decides ties (never admits d == 25)
+
+  // ---- through the block?  Only for a cloud verified ring-ordered with all its rings < 255, and only when the walk would be longer
+  bool via_block = false;
+  if (tbl && unordered_epoch != pb.rf_epoch && cscan < 255 && B.total > 0u) {
+    const unsigned long long valid = __ballot(e0 + lane < OD_RF_N - 1 && (tv >> 24) == pb.rf_epoch);
+    auto first_from = [&](int ring) -> int {   // first index of the first ring >= `ring` with an entry (nLast: none among the 64 read)
+      const int k = ring - e0;
+      if (k >= 64) return nLast;
+      const unsigned long long m = k <= 0 ? valid : (valid >> k) << k;
+      if (!m) return nLast;
+      const int w = (int)((uint32_t)__shfl((int)tv, __builtin_ctzll(m), 64) & OD_IDX_MASK);
+      return w < nLast ? w : nLast;
+    };
+    if (cscan - 2 >= e0 || e0 == 0) {   // (the entries read cover the walk's rings)
+      const int wlo = min(first_from(cscan - 2), closest);
+      const int whi = closest + 1 < bound ? max(min(bound, first_from(cscan + 3)), closest + 1) : closest + 1;
+      const unsigned walk = (unsigned)(closest - wlo) + (unsigned)(whi - (closest + 1));
+      via_block = walk > B.total + 128u;
+    }
+  }
+  OC_TS(4);
+  if (via_block) {
+    block27_scan(B, sorted, lane, [&](const float4& p, bool ok) {
+      const uint32_t w = __float_as_uint(p.w);
+      const int j = (int)(w & OD_IDX_MASK), ring = (int)(w >> 24);
+      const float d = sqd(p, x, y, z);
+      if (ok && j > closest && j < bound && ring <= cscan + 2) {          // what the forward walk would examine
+        const int order = j - (closest + 1);
+        if (corner) {
+          if (ring > cscan && better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; }
+        } else {
+          if (ring <= cscan) { if (better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; } }
+          else { if (better(d, order, d3, o3)) { d3 = d; j3 = j; o3 = order; } }
+        }
+      } else if (ok && j < closest && ring >= cscan - 2) {                 // ... and the backward walk
+        const int order = 0x40000000 + (closest - 1 - j);
+        if (corner) {
+          if (ring < cscan && better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; }
+        } else {
+          if (ring >= cscan) { if (better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; } }
+          else { if (better(d, order, d3, o3)) { d3 = d; j3 = j; o3 = order; } }
+        }
+      }
+    });
+    wave_argmin(d2, j2, o2);
+    if (!corner) wave_argmin(d3, j3, o3);
+    const float h = 1.0f / gd.g.inv_h, h2 = h * h;
+    // final only strictly inside the ball the block contains; a slot without such a candidate sends the feature on the walk
+    via_block = d2 < h2 && (corner || d3 < h2);
+    if (!via_block) { d2 = d3 = 25.f; j2 = j3 = -1; o2 = o3 = 0x7fffffff; }
+  }
+  OC_TS(5);
+  if (!via_block) {
+    // forward window (:262-279 / :378-403) and backward window (:280-297 / :404-429), walked TOGETHER as in k_odom_corr
+    int baseF = closest + 1, baseB = closest - 1;
+    bool stopF = baseF >= bound, stopB = baseB < 0;
+    while (!stopF || !stopB) {
+      float4 qf[4], qb[4];
+      if (!stopF) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int j = baseF + 64 * u + lane;
+          qf[u] = j < bound ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      if (!stopB) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int j = baseB - 64 * u - lane;
+          qb[u] = j >= 0 ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      if (!stopF) {
+        bool stop = false;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (stop) continue;
+          const int j = baseF + 64 * u + lane;
+          const bool in = j < bound;
+          const int ring = (int)qf[u].w;
+          const bool brk = in && ((double)ring > (double)cscan + 2.5);
+          const unsigned long long mb = __ballot(brk);
+          const int fb = mb ? __builtin_ctzll(mb) : 64;
+          if (in && lane < fb) {
+            const float d = sqd(qf[u], x, y, z);
+            const int order = j - (closest + 1);
+            if (corner) {
+              if (ring > cscan && better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; }
+            } else {
+              if (ring <= cscan) { if (better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; } }
+              else { if (better(d, order, d3, o3)) { d3 = d; j3 = j; o3 = order; } }
+            }
+          }
+          if (mb) stop = true;
+        }
+        baseF += 256;
+        stopF = stop || baseF >= bound;
+      }
+      if (!stopB) {
+        bool stop = false;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (stop) continue;
+          const int j = baseB - 64 * u - lane;
+          const bool in = j >= 0;
+          const int ring = (int)qb[u].w;
+          const bool brk = in && ((double)ring < (double)cscan - 2.5);
+          const unsigned long long mb = __ballot(brk);
+          const int fb = mb ? __builtin_ctzll(mb) : 64;
+          if (in && lane < fb) {
+            const float d = sqd(qb[u], x, y, z);
+            const int order = 0x40000000 + (closest - 1 - j);   // backward candidates come after all forward ones
+            if (corner) {
+              if (ring < cscan && better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; }
+            } else {
+              if (ring >= cscan) { if (better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; } }
+              else { if (better(d, order, d3, o3)) { d3 = d; j3 = j; o3 = order; } }
+            }
+          }
+          if (mb) stop = true;
+        }
+        baseB -= 256;
+        stopB = stop || baseB < 0;
+      }
+    }
+    wave_argmin(d2, j2, o2);
+    if (!corner) wave_argmin(d3, j3, o3);
+  }
+  OC_TS(6);
+  if (lane == 0) {
+    pb.ind[5 * f] = closest;
+    pb.ind[5 * f + 1] = j2;
+    pb.ind[5 * f + 2] = corner ? -1 : j3;
+  }
+#ifdef LOAMX_PROF_CORR
+  if (blockIdx.y == 0 && lane == 0 && ts_slot >= 0) {
+    g_corr_ts[ts_slot][7] = wall_clock64();
+    g_corr_ts[ts_slot][8] = (unsigned long long)B.total; g_corr_ts[ts_slot][9] = (unsigned long long)via_block;
+    g_corr_ts[ts_slot][10] = (unsigned long long)closest; g_corr_ts[ts_slot][11] = (unsigned long long)cscan;
+  }
+#endif
+}
+
+// ---- phases A+B: correspondences of one feature by one wave: exact 1-NN, then the ring-window scans;
+// grid = (ceil(maxFeat/4), streams), 256 threads
 __global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr(OdomProblem* __restrict__ probs, OdomParams P) {
   OdomProblem& pb = probs[blockIdx.y];
   if (pb.done) return;
@@ -635,7 +942,8 @@ __global__ void k_te_patch(const OdomProblem* __restrict__ probs, uint32_t na, T
 __global__ __launch_bounds__(256) void k_transform_to_end_batch(float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off,
                                                                 uint32_t K, uint32_t ns, const ToEndParams* __restrict__ params,
                                                                 const float4* __restrict__ src_c, const float4* __restrict__ src_s,
-                                                                uint32_t n_corner_all, uint32_t* __restrict__ bounds) {
+                                                                uint32_t n_corner_all, uint32_t* __restrict__ bounds,
+                                                                uint32_t* __restrict__ ring_first, uint32_t rf_epoch) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
   uint32_t lo = 0;
@@ -655,6 +963,26 @@ __global__ __launch_bounds__(256) void k_transform_to_end_batch(float4* __restri
       q = pts[i];
       if (P.enabled) { q = to_end_point(q, P); pts[i] = q; }
     }
+  }
+  // ring-first table of every cloud (k_odom_corr_grid sizes a feature's ring-window walk by it — a hint): a point whose ring differs
+  // from its predecessor's inside the cloud is the first of its ring.  Entries carry the epoch, so the table is never cleared.  The
+  // same comparison VERIFIES that the cloud is ring-ordered with ring ids that fit the packed byte (what lets k_odom_corr_grid look a
+  // window up in the grid): one violation anywhere stamps the cloud's last entry with the epoch.
+  if (ring_first) {
+    const int ring = (int)q.w;
+    int prev = __shfl_up(ring, 1, 64);
+    const uint32_t plo = (uint32_t)__shfl_up((int)lo, 1, 64);
+    const bool first_in_cloud = active && i == off[lo];
+    if (active && !first_in_cloud && (threadIdx.x & 63) == 0) {   // the predecessor sits in another wave: read its ring from the source
+      const uint32_t ip = i - 1;
+      prev = (int)(src_c ? (ip < n_corner_all ? src_c[ip] : src_s[ip - n_corner_all]) : pts[ip]).w;   // (.w's integer part survives the re-projection)
+    } else if (active && plo != lo) {
+      prev = -1;
+    }
+    if (active && ring >= 0 && ring < OD_RF_N - 1 && (first_in_cloud || prev != ring))
+      ring_first[(size_t)lo * OD_RF_N + ring] = (rf_epoch << 24) | ((i - off[lo]) & OD_IDX_MASK);
+    if (active && (ring < 0 || ring >= 255 || (i - off[lo]) > OD_IDX_MASK || (!first_in_cloud && prev > ring)))
+      ring_first[(size_t)lo * OD_RF_N + OD_RF_N - 1] = rf_epoch;
   }
   // the clouds are indexed next (SubMapIndexBatch): their bounds are gathered here, one launch and one pass over the points less
   if (bounds) cloud_bounds_update(bounds, active, lo, q.x, q.y, q.z);
@@ -688,9 +1016,12 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
   // nn1_wave is exact for any cell size; coarser cells than the map index keep the cell tables (rebuilt every sweep) small
   index_.cell_size = 2.1f;
   if (const char* e = getenv("LOAMX_ODOM_CELL")) { const float v = (float)atof(e); if (v >= 0.25f && v <= 16.f) index_.cell_size = v; }
+  index_.pack_ring = true;   // k_odom_corr_grid filters a cell's points by ring
   index_.init(st_);
   h_mirror_.reserve(n_streams);
   h_err_.reserve(16);
+  rf_.reserve((size_t)2 * n_streams * OD_RF_N);
+  LX_HIP(hipMemsetAsync(rf_.p, 0, sizeof(uint32_t) * 2 * n_streams * OD_RF_N, st_));   // epoch 0 = no entry
   memset(h_err_.p, 0, 16 * sizeof(uint32_t));
   part_.reserve((size_t)n_streams * OD_PART_STRIDE);
   {
@@ -831,6 +1162,9 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       pb.te_out = te_.p + s;
       pb.part = part_.p + (size_t)active.size() * OD_PART_STRIDE;
       pb.err_word = h_err_.p;
+      pb.rf_corner = rf_.p + (size_t)s * OD_RF_N;
+      pb.rf_surf = rf_.p + (size_t)(ns + s) * OD_RF_N;
+      pb.rf_epoch = rf_epoch_;   // the table the previous call's re-projection left behind
       max_feat = std::max(max_feat, I.n_sharp + I.n_flat);
       max_sharp = std::max(max_sharp, I.n_sharp);
       max_flat = std::max(max_flat, I.n_flat);
@@ -853,7 +1187,11 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
     if (max_feat) {
       for (int it0 = 0; it0 < params.max_iterations; it0 += 5) {
         const int nit = std::min(5, params.max_iterations - it0);
-        hipLaunchKernelGGL(k_odom_corr, dim3(8 * (((max_sharp + 7) / 8 + (max_flat + 7) / 8 + 3) / 4), na), dim3(256), 0, st_, prob_.p, params);
+        static const bool corr_legacy = getenv("LOAMX_ODOM_CORR_LEGACY") != nullptr;   // A/B: the wave-per-feature kernel streaming its windows through L2
+        if (corr_legacy)
+          hipLaunchKernelGGL(k_odom_corr, dim3(8 * (((max_sharp + 7) / 8 + (max_flat + 7) / 8 + 3) / 4), na), dim3(256), 0, st_, prob_.p, params);
+        else
+          hipLaunchKernelGGL(k_odom_corr_grid, dim3(8 * (((max_sharp + 7) / 8 + (max_flat + 7) / 8 + 3) / 4), na), dim3(256), 0, st_, prob_.p, params);
         const uint32_t nb = std::min<uint32_t>(16u, (max_feat + OD_THREADS - 1) / OD_THREADS);
         // k_odom_lm's workgroups of one stream spin on each other: everything a launch puts on the device must be resident
         // at once.  The launch is cut into chunks of streams that fill at most half of what the device can hold (occupancy x
@@ -888,8 +1226,11 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   // right behind the iterations; the host only waits for the poses
   static const bool fuse_bounds = !(getenv("LOAMX_BB_FUSED") && atoi(getenv("LOAMX_BB_FUSED")) == 0);   // diagnostic: 0 = separate k_bb_bbox launch
   if (n_all)
+  {
+    if (++rf_epoch_ > 255u) rf_epoch_ = 1u;   // entries of this re-projection carry the new epoch; the problems of the NEXT call name it
     hipLaunchKernelGGL(k_transform_to_end_batch, dim3((n_all + 255) / 256), dim3(256), 0, st_, cur_.p, n_all, d_cur_off_.p, K, ns, te_.p, src_c,
-                       src_s, n_corner_all, fuse_bounds ? index_.d_bounds() : nullptr);
+                       src_s, n_corner_all, fuse_bounds ? index_.d_bounds() : nullptr, rf_.p, rf_epoch_);
+  }
   // three rotating buffers: the clouds this call hands on stay untouched during the next two calls (a registration reads them
   // while the odometry chain is already one or two sweeps ahead — Pipeline)
   {
@@ -909,6 +1250,17 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       *h_err_.p = 0u;
       throw Error(LOAMX_E_HIP, "odometry: the exchange between a stream's k_odom_lm workgroups timed out (not all of them resident)");
     }
+#ifdef LOAMX_PROF_CORR
+    {
+      unsigned long long ts[3][16];
+      LX_HIP(hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_corr_ts), sizeof(ts)));
+      for (int q = 0; q < 3; q++)
+        fprintf(stderr, "[corr ts %s, us since entry] feature+trig %.2f block table %.2f nn1 %.2f decision %.2f block windows %.2f walk %.2f end %.2f | block %llu pts, via block %llu, closest %lld cscan %lld\n",
+                q == 0 ? "corner" : q == 1 ? "flat mid" : "flat last", (ts[q][1] - ts[q][0]) * 0.01, (ts[q][2] - ts[q][0]) * 0.01, (ts[q][3] - ts[q][0]) * 0.01,
+                (ts[q][4] - ts[q][0]) * 0.01, (ts[q][5] - ts[q][0]) * 0.01, (ts[q][6] - ts[q][0]) * 0.01, (ts[q][7] - ts[q][0]) * 0.01, ts[q][8], ts[q][9],
+                (long long)ts[q][10], (long long)ts[q][11]);
+    }
+#endif
 #ifdef LOAMX_PROF_LM
     {
       double ts[16];

@@ -125,6 +125,7 @@ class SubMapIndexBatch {
   void prepare(uint32_t K);
   uint32_t* d_bounds() const { return enc_.p; }
   float cell_size = 1.05f;   // initial cell edge (grown by 1.25x while the cell table would exceed its budget)
+  bool pack_ring = false;    // .w of a sorted point = (ring << 24) | index inside its cloud, ring = (int) of the input's .w (255: does not fit)
   const float4* sorted() const { return sorted_.p; }
   const uint32_t* cell_start(uint32_t c) const { return cell_start_.p; }   // tables are addressed through desc(c)->cell_base
   const GridDescB* desc(uint32_t c) const { return d_desc_.p + c; }

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k_bb_count(const float4* __restrict__ pts
 
 __global__ __launch_bounds__(256) void k_bb_scatter(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off, uint32_t K,
                                                     const uint32_t* __restrict__ cell_of, const uint32_t* __restrict__ rank_of,
-                                                    const uint32_t* __restrict__ cell_start, float4* __restrict__ sorted) {
+                                                    const uint32_t* __restrict__ cell_start, float4* __restrict__ sorted, int pack_ring) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t lo = 0, hi = K;
@@ -294,7 +294,15 @@ __global__ __launch_bounds__(256) void k_bb_scatter(const float4* __restrict__ p
     if (off[mid] <= i) lo = mid; else hi = mid;
   }
   float4 p = pts[i];
-  p.w = __uint_as_float(i - off[lo]);   // index inside its own cloud
+  const uint32_t li = i - off[lo];      // index inside its own cloud
+  // pack_ring (the odometry's clouds: .w = ring id): the top byte carries the ring so that a search can filter by ring without a
+  // second gather; 255 = unknown (ring id or index too large for the packing — its user then falls back, odometry.hip)
+  uint32_t w = li;
+  if (pack_ring) {
+    const int ring = (int)p.w;
+    w = (li <= 0xffffffu && ring >= 0 && ring < 255) ? (((uint32_t)ring << 24) | li) : (0xff000000u | (li & 0xffffffu));
+  }
+  p.w = __uint_as_float(w);
   sorted[cell_start[cell_of[i]] + rank_of[i]] = p;
 }
 
@@ -348,7 +356,7 @@ void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_
   if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, d_desc_.p, cell_of_.p, cursor_.p, rank_of_.p);
   // (the cell counters are cleared behind the scan: they are empty again when the next build starts)
   exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 2, scratch_.p + 1, LX_MAX_CELLS, st_, nullptr, cursor_.p);
-  if (n) hipLaunchKernelGGL(k_bb_scatter, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, cell_of_.p, rank_of_.p, cell_start_.p, sorted_.p);
+  if (n) hipLaunchKernelGGL(k_bb_scatter, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, cell_of_.p, rank_of_.p, cell_start_.p, sorted_.p, pack_ring ? 1 : 0);
   LX_HIP(hipGetLastError());
 }
 

@@ -553,6 +553,9 @@ __device__ __forceinline__ void surf_row(const Pose& T, const float4 po, const f
 // (deterministic) reduction of the block partials — 9 groups of 28 threads each walk every 9th block, then the 9 group
 // sums are added in order — then wave 0 solves and thread 0 updates the pose
 constexpr int LX_SOLVE_GROUPS = 9;
+#ifndef LX_SOLVE_MLP
+#define LX_SOLVE_MLP 18
+#endif
 #ifdef LOAMX_PROF_GN
 __device__ unsigned long long g_solve_ts[16];
 #define SOLVE_TS(k) do { if (s == 0 && iter == 0 && threadIdx.x == 0) g_solve_ts[k] = wall_clock64(); } while (0)
@@ -578,15 +581,17 @@ __device__ __forceinline__ void solve_sweep(uint32_t s, const uint32_t* __restri
   if (tid < LX_SOLVE_GROUPS * LX_NSUM) {
     const uint32_t g = (uint32_t)tid / LX_NSUM, t = (uint32_t)tid % LX_NSUM;
     double x = 0.0;
-    for (uint32_t b0 = g; b0 < nact; b0 += 16 * LX_SOLVE_GROUPS) {   // 16 loads in flight, added in tile order
-      double v[16];
+    // 18 loads in flight, added in tile order: an HDL-64E sweep has ~300 tiles = 34 per thread — two memory round trips (the
+    // partials come from the other XCDs' workgroups: every trip is a miss, ~3 us) where 16 in flight made three
+    for (uint32_t b0 = g; b0 < nact; b0 += LX_SOLVE_MLP * LX_SOLVE_GROUPS) {
+      double v[LX_SOLVE_MLP];
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
+      for (int u = 0; u < LX_SOLVE_MLP; u++) {
         const uint32_t b = b0 + u * LX_SOLVE_GROUPS;
         v[u] = b < nact ? partials[((size_t)s * nblk + b) * LX_NSUM + t] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 16; u++)
+      for (int u = 0; u < LX_SOLVE_MLP; u++)
         if (b0 + u * LX_SOLVE_GROUPS < nact) x += v[u];
     }
     gsum[g][t] = x;

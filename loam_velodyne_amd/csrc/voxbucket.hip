@@ -205,7 +205,11 @@ constexpr uint32_t VB_SPIN_LIMIT = 1u << 20;
 constexpr int VB_THREADS = VB_CAP / 8, VB_WAVES = VB_THREADS / 64;
 
 __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
-  __shared__ unsigned long long s_w[VB_CAP + 1];   // the sort buffer (one: every thread holds its eight words in registers while a pass scatters)
+  // one buffer, used twice: the sort's words (8 B each; every thread holds its eight words in registers while a pass scatters), then —
+  // the words consumed — the bucket's points in sorted order (16 B each) for the voxel means
+  __shared__ float4 s_buf[VB_CAP + 1];
+  unsigned long long* s_w = (unsigned long long*)s_buf;
+  __shared__ uint32_t s_hbits[VB_CAP / 32 + 1];   // bit l: sorted element l starts a voxel
   __shared__ uint32_t s_wcnt[VB_WAVES][256];
   __shared__ uint32_t s_base[256];
   __shared__ uint32_t s_scan[17];
@@ -371,9 +375,11 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
     }
   }
   // s_w holds the sorted words.  Every thread takes eight CONSECUTIVE sorted elements and fetches their points itself (eight
-  // independent gathers in flight — cache hits, the bucket's points were read a moment ago); a voxel's mean is the sequential sum of
-  // its run in sorted = input order: the part of a run inside its head's thread comes out of registers, a run that goes on into the
-  // following threads' elements is continued through LDS (the words) and global memory (the points).
+  // independent gathers in flight); a voxel's mean is the sequential sum of its run in sorted = input order.  The points then go to
+  // LDS in sorted order (over the words, which are in registers by now) together with one head bit per element, so that a run which
+  // goes on beyond its head's own eight elements is continued from LDS.  (Round 3 continued through the words and global memory, one
+  // dependent gather per point: a voxel of ~100 points — dense ground next to the sensor — kept its thread, and with it the kernel,
+  // 40 us longer than every other bucket: in-kernel time stamps, profiles/r04_vb_reduce.md.)
   VB_TS(10);
   if (tid == 0) s_w[c] = ~0ull;   // sentinel behind the last element
   __syncthreads();
@@ -388,15 +394,22 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
     pt[j] = l < c ? A.stack[sbeg + (uint32_t)(x & pmask)] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   bool head[8];
-  uint32_t nh = 0u;
+  uint32_t nh = 0u, hb = 0u;
   unsigned long long prev = (l0 == 0u || l0 > c) ? ~0ull : (s_w[l0 - 1u] >> pbits);
 #pragma unroll
   for (int j = 0; j < 8; j++) {
     const uint32_t l = l0 + (uint32_t)j;
     head[j] = l < c && (l == 0u || vox[j] != prev);   // (a voxel never straddles two buckets: buckets are ranges of the voxel order)
     nh += head[j] ? 1u : 0u;
+    hb |= (head[j] || l >= c) ? (1u << j) : 0u;       // (elements behind the last one end every run)
     prev = vox[j];
   }
+  __syncthreads();   // every thread has read its words (and its predecessor's): the buffer changes hands
+#pragma unroll
+  for (int j = 0; j < 8; j++) s_buf[l0 + (uint32_t)j] = pt[j];
+  ((unsigned char*)s_hbits)[tid] = (unsigned char)hb;   // (little-endian bytes: bit l of the table = element l)
+  if (tid == 0) ((unsigned char*)s_hbits)[VB_THREADS] = 0xffu;
+  __syncthreads();
   VB_TS(11);
   uint32_t tot;
   const uint32_t ex = block_excl_scan(nh, s_scan, tot);
@@ -446,17 +459,24 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
         open = open && vox[q] == vox[j];
         if (open) { sx += pt[q].x; sy += pt[q].y; sz += pt[q].z; si += pt[q].w; cntp++; }
       }
-      if (open) {   // the run reaches the end of this thread's elements: it may go on
+      if (open) {   // the run reaches the end of this thread's elements: it goes on in LDS until the next head bit
         uint32_t l = l0 + 8u;
-        for (;;) {
-          const unsigned long long x = s_w[l < c ? l : c];
-          if (l >= c || (x >> pbits) != vox[j]) break;
-          const float4 t = A.stack[sbeg + (uint32_t)(x & pmask)];
-          sx += t.x; sy += t.y; sz += t.z; si += t.w;
-          cntp++;
-          l++;
+        while (open) {
+          const uint32_t hbyte = ((const unsigned char*)s_hbits)[l >> 3];   // (l is a multiple of 8: one byte = the next eight elements)
+          float4 ts[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) ts[q] = s_buf[min(l + (uint32_t)q, (uint32_t)VB_CAP)];
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            open = open && !((hbyte >> q) & 1u);
+            if (open) { sx += ts[q].x; sy += ts[q].y; sz += ts[q].z; si += ts[q].w; cntp++; }
+          }
+          l += 8u;
         }
       }
+#ifdef LOAMX_PROF_VB
+      atomicMax((unsigned long long*)&A.dbg[(size_t)blockIdx.x * 16 + 14], (unsigned long long)cntp);
+#endif
       const float cf = (float)cntp;
       A.out[pos] = make_float4(sx / cf, sy / cf, sz / cf, si / cf);
       pos++;
@@ -515,9 +535,12 @@ void VoxBucket::run(const float4* in, const float4* const* d_src, uint32_t n, co
     unsigned long long t0 = ~0ull, t1 = 0;
     for (uint32_t b = 0; b < nb; b++) { if (h[16 * b]) t0 = std::min(t0, h[16 * b]); t1 = std::max(t1, h[16 * b + 13]); }
     fprintf(stderr, "[k_vb_reduce %u buckets, %.1f us first start -> last end] bucket: start | box | passes ... | sorted | heads | look-back | end (us since first start)\n", nb, (t1 - t0) * 0.01);
-    for (uint32_t b : {0u, nb / 4, nb / 2, nb - 1}) {
+    uint32_t slow = 0;
+    for (uint32_t b = 0; b < nb; b++) if (h[16 * b + 13] > h[16 * slow + 13]) slow = b;
+    for (uint32_t b : {0u, nb / 4, nb / 2, nb - 1, slow}) {
       fprintf(stderr, "  b%-4u", b);
       for (int k = 0; k < 14; k++) if (h[16 * b + k]) fprintf(stderr, " %d:%.1f", k, (h[16 * b + k] - t0) * 0.01);
+      fprintf(stderr, " longest run %llu", h[16 * b + 14]);
       fprintf(stderr, "\n");
     }
   }

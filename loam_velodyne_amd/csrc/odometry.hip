@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr(OdomProblem* __r
 // launch resident: the host cuts a batch into launches of at most half the device's occupancy-derived capacity
 // (OdometryBatch::process).
 #ifdef LOAMX_PROF_LM
-#define LM_TS(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && iter == iter0 + 1) pb.part[32 * LX_NSUM + (k)] = (double)wall_clock64(); } while (0)
+#define LM_TS(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && iter == it_begin + 1) pb.part[32 * LX_NSUM + (k)] = (double)wall_clock64(); } while (0)
 #else
 #define LM_TS(k) do { } while (0)
 #endif
@@ -644,7 +644,10 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
     }
   }
 
-  for (int iter = iter0; iter < iter0 + n_iters; iter++) {
+  // iter0 < 0 (OdomEngine): every stream is at its own iteration — the launch continues where the problem says and stops at the cap
+  const int it_begin = iter0 >= 0 ? iter0 : pb.iter0;
+  const int it_end = iter0 >= 0 ? iter0 + n_iters : min(pb.iter0 + n_iters, P.max_iterations);
+  for (int iter = it_begin; iter < it_end; iter++) {
     // ---- phase C: residual rows + normal equations
     LM_TS(0);
     if (tid < 6) {   // sin/cos of the three angles, one per lane, double then rounded (see pose_set_angles)
@@ -871,7 +874,7 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
         if (sh_done) pb.done = 1;
         // results also go to the host-visible mirror once they are final for this launch: the host then needs no copy on
         // the stream, only the event behind the last launch
-        if (sh_done || iter == iter0 + n_iters - 1) {
+        if (sh_done || iter == it_end - 1) {
           // ... and into the re-projection parameters of the sweep's tail (transformToEnd with the optimised transform): the
           // tail is enqueued right behind the last launch, no host round trip and no extra kernel
           ToEndParams& P = *pb.te_out;
@@ -881,7 +884,7 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
             P.cT[k] = (float)cos((double)T[k]);
           }
         }
-        if (pb.host_mirror && (sh_done || iter == iter0 + n_iters - 1)) {
+        if (pb.host_mirror && (sh_done || iter == it_end - 1)) {
           OdomProblem* hm = pb.host_mirror;
           for (int r = 0; r < 6; r++) hm->transform[r] = T[r];
           hm->stats = pb.stats;
@@ -1047,16 +1050,41 @@ OdometryBatch::~OdometryBatch() {
   if (own_stream_ && st_) (void)hipStreamDestroy(st_);
 }
 
-void OdometryBatch::update_imu(uint32_t s, const float* t) {
-  OdomStream& S = *streams_[s];
+void odom_set_imu(OdomStream& S, const float* t);
+ToEndParams odom_to_end_params(const OdomStream& S, float scan_period, bool enabled);
+void odom_integrate_pose(OdomStream& S);
+
+void OdometryBatch::update_imu(uint32_t s, const float* t) { odom_set_imu(*streams_[s], t); }
+
+ToEndParams OdometryBatch::to_end_params(uint32_t s, bool enabled) const { return odom_to_end_params(*streams_[s], params.scan_period, enabled); }
+
+void OdometryBatch::to_end_device(uint32_t s, float4* pts, uint32_t n) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_transform_to_end, dim3((n + 255) / 256), dim3(256), 0, st_, pts, n, to_end_params(s, true));
+}
+
+// pose integration of one sweep (:626-649): transformSum <- transformSum (+) the sweep's optimised transform, with the IMU plug-in
+void odom_integrate_pose(OdomStream& S) {
+  HAngle rx, ry, rz;
+  accumulate_rotation(S.transform_sum.rot_x, S.transform_sum.rot_y, S.transform_sum.rot_z, -S.transform.rot_x,
+                      HAngle((float)(-S.transform.rot_y.r * 1.05)), -S.transform.rot_z, rx, ry, rz);
+  HVec3 v{S.transform.pos.x - S.imu_shift.x, S.transform.pos.y - S.imu_shift.y, (float)(S.transform.pos.z * 1.05 - S.imu_shift.z)};
+  h_rot_zxy(v, rz, rx, ry);
+  HVec3 trans{S.transform_sum.pos.x - v.x, S.transform_sum.pos.y - v.y, S.transform_sum.pos.z - v.z};
+  plugin_imu_rotation(rx, ry, rz, S.imu_pitch_start, S.imu_yaw_start, S.imu_roll_start, S.imu_pitch_end, S.imu_yaw_end,
+                      S.imu_roll_end, rx, ry, rz);
+  S.transform_sum.rot_x = rx; S.transform_sum.rot_y = ry; S.transform_sum.rot_z = rz;
+  S.transform_sum.pos = trans;
+}
+// the IMU quantities of a sweep (updateIMU, :182-197): 4 x (x, y, z) = pitch / yaw / roll start, end, shift from start, velocity from start
+void odom_set_imu(OdomStream& S, const float* t) {
   S.imu_pitch_start = HAngle(t[0]); S.imu_yaw_start = HAngle(t[1]); S.imu_roll_start = HAngle(t[2]);
   S.imu_pitch_end = HAngle(t[3]); S.imu_yaw_end = HAngle(t[4]); S.imu_roll_end = HAngle(t[5]);
   S.imu_shift = {t[6], t[7], t[8]};
   S.imu_velo = {t[9], t[10], t[11]};
 }
-
-ToEndParams OdometryBatch::to_end_params(uint32_t s, bool enabled) const {
-  const OdomStream& S = *streams_[s];
+// transformToEnd's parameters from a stream's host state (the transform's sin / cos as the host caches them, Angle.h)
+ToEndParams odom_to_end_params(const OdomStream& S, float scan_period, bool enabled) {
   ToEndParams P;
   S.transform.get(P.T);
   const HAngle* ta[3] = {&S.transform.rot_x, &S.transform.rot_y, &S.transform.rot_z};
@@ -1068,14 +1096,9 @@ ToEndParams OdometryBatch::to_end_params(uint32_t s, bool enabled) const {
     P.s_end[k] = ea[k]->s; P.c_end[k] = ea[k]->c;
   }
   P.shift[0] = S.imu_shift.x; P.shift[1] = S.imu_shift.y; P.shift[2] = S.imu_shift.z;
-  P.scan_period = params.scan_period;
+  P.scan_period = scan_period;
   P.enabled = enabled ? 1 : 0;
   return P;
-}
-
-void OdometryBatch::to_end_device(uint32_t s, float4* pts, uint32_t n) {
-  if (!n) return;
-  hipLaunchKernelGGL(k_transform_to_end, dim3((n + 255) / 256), dim3(256), 0, st_, pts, n, to_end_params(s, true));
 }
 
 void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
@@ -1282,18 +1305,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   // ---- pose integration (:626-649)
   for (uint32_t s = 0; s < ns; s++) {
     OdomStream& S = *streams_[s];
-    if (rc[s] == LOAMX_OK) {
-      HAngle rx, ry, rz;
-      accumulate_rotation(S.transform_sum.rot_x, S.transform_sum.rot_y, S.transform_sum.rot_z, -S.transform.rot_x,
-                          HAngle((float)(-S.transform.rot_y.r * 1.05)), -S.transform.rot_z, rx, ry, rz);
-      HVec3 v{S.transform.pos.x - S.imu_shift.x, S.transform.pos.y - S.imu_shift.y, (float)(S.transform.pos.z * 1.05 - S.imu_shift.z)};
-      h_rot_zxy(v, rz, rx, ry);
-      HVec3 trans{S.transform_sum.pos.x - v.x, S.transform_sum.pos.y - v.y, S.transform_sum.pos.z - v.z};
-      plugin_imu_rotation(rx, ry, rz, S.imu_pitch_start, S.imu_yaw_start, S.imu_roll_start, S.imu_pitch_end, S.imu_yaw_end,
-                          S.imu_roll_end, rx, ry, rz);
-      S.transform_sum.rot_x = rx; S.transform_sum.rot_y = ry; S.transform_sum.rot_z = rz;
-      S.transform_sum.pos = trans;
-    }
+    if (rc[s] == LOAMX_OK) odom_integrate_pose(S);
     S.inited = true;
     S.n_last_corner = in[s].n_less_sharp;
     S.n_last_surf = in[s].n_less_flat;
@@ -1385,5 +1397,7 @@ int OdometryBatch::transform_to_end_host(uint32_t s, loamx_cloud* cloud) {
   LX_HIP(hipStreamSynchronize(st_));
   return unpack_cloud(h_stage_.p, n, cloud);
 }
+
+#include "odom_engine.inc"
 
 }  // namespace loamx

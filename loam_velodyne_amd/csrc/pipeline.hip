@@ -46,7 +46,31 @@ class Pipeline {
     // the slowest of all streams (profiles/r03: 5.2 pairs per step for a mean of 7.1 iterations).  Default 2: measured on MI355X
     // (profiles/r04_groups_ab.md) 1 -> 2 chains gains 8 %, but with 4 (six busy HIP streams in the process) EVERY chain slows down
     // (registration 0.55 -> 0.88 ms, k_gn_iter 64 -> 93 us) and the step is 35 % slower than with one.
-    {
+    // Round 4, second step: the OdomEngine (odom_engine.inc) lets EVERY stream run at its own pace on one HIP stream (a per-stream state
+    // machine on the device, cycles of shared launches).  Bit-identical to the chains (tests/test_gpu_pipeline.py runs both), but NOT
+    // the default: on the bench workload the stragglers are persistent — a stream that needs 25 iterations needs them for five or six
+    // sweeps in a row — so the slowest stream still needs 57 launch pairs over the 20 timed steps (the lock-step chains of 4 streams:
+    // 60 and 71), and a cycle that serves streams in every phase (begin + correspondences + iterations + re-projection + three index
+    // launches = ~165 us) costs more than a chain's pair (~100 us): 11.2 k sweeps/s against the chains' 13.1 k
+    // (profiles/r04_odom_engine.md).  LOAMX_ODOM_ENGINE=1 selects it; LOAMX_ODOM_ENGINES = how many (default 2 x half the streams).
+    use_engine = getenv("LOAMX_ODOM_ENGINE") && atoi(getenv("LOAMX_ODOM_ENGINE")) != 0;
+    OdomParams op;
+    op.scan_period = oc.scan_period;
+    op.max_iterations = getenv("LOAMX_ODOM_MAXIT") ? atoi(getenv("LOAMX_ODOM_MAXIT")) : oc.max_iterations;   // (diagnostic override)
+    op.delta_t_abort = oc.delta_t_abort;
+    op.delta_r_abort = oc.delta_r_abort;
+    if (use_engine) {
+      n_groups = 0;
+      int ne = (int)std::min<uint32_t>(n_streams, 2);   // two engines of half the streams each overlap like two chains do (profiles/r04_groups_ab.md: up to four busy HIP streams)
+      if (const char* e = getenv("LOAMX_ODOM_ENGINES")) ne = std::max(1, std::min(atoi(e), (int)std::min<uint32_t>(n_streams, 8)));
+      for (int e = 0; e <= ne; e++) eng_s0.push_back((uint32_t)((uint64_t)e * n_streams / ne));
+      for (int e = 0; e < ne; e++) {
+        const uint32_t s0 = eng_s0[e], s1 = eng_s0[e + 1];
+        auto* x = new OdomEngine(mc.device, s1 - s0, op, [this, s0, s1](uint32_t t, OdomInput* in, float* imu, bool& has_imu) { return fetch_odom_inputs(t, s0, s1, in, imu, has_imu); });
+        if (e == 0) eng.reset(x); else engines_extra.emplace_back(x);
+      }
+      gather_util.reset(new OdometryBatch(mc.device, 1, nullptr));
+    } else {
       int g = (int)std::min<uint32_t>(n_streams, 2);
       if (const char* e = getenv("LOAMX_ODOM_GROUPS")) g = atoi(e);
       n_groups = (uint32_t)std::max(1, std::min(g, (int)std::min<uint32_t>(n_streams, MAX_GROUPS)));
@@ -66,12 +90,7 @@ class Pipeline {
     reg.params.delta_r_abort = mc.delta_r_abort;
     reg.params.corner_leaf = mc.corner_filter_size;
     reg.params.surf_leaf = mc.surf_filter_size;
-    for (auto& c : chains) {
-      c->ob->params.scan_period = oc.scan_period;
-      c->ob->params.max_iterations = getenv("LOAMX_ODOM_MAXIT") ? atoi(getenv("LOAMX_ODOM_MAXIT")) : oc.max_iterations;   // (diagnostic override)
-      c->ob->params.delta_t_abort = oc.delta_t_abort;
-      c->ob->params.delta_r_abort = oc.delta_r_abort;
-    }
+    for (auto& c : chains) c->ob->params = op;
     device = mc.device;
     if (getenv("LOAMX_NO_LOOKAHEAD")) prefetch = false;   // debugging / profiling: run the stages one after the other
   }
@@ -91,6 +110,14 @@ class Pipeline {
     double tr[4] = {0, 0, 0, 0};
   };
   static constexpr uint32_t MAX_GROUPS = 16;
+  bool use_engine = true;
+  std::unique_ptr<OdomEngine> eng;             // every stream at its own pace; else the chains below.  (eng = engines[0]: "an engine exists")
+  std::vector<std::unique_ptr<OdomEngine>> engines_extra;   // further engines: engine e owns the streams [eng_s0[e], eng_s0[e + 1])
+  std::vector<uint32_t> eng_s0;                // n_engines + 1 stream boundaries
+  uint32_t n_engines() const { return eng ? 1u + (uint32_t)engines_extra.size() : 0u; }
+  OdomEngine& E(uint32_t e) { return e == 0 ? *eng : *engines_extra[e - 1]; }
+  std::unique_ptr<OdometryBatch> gather_util;  // (to_end_gather's staging buffers when there are no chains)
+  std::atomic<int> f_pub{-1};                  // features of the steps <= f_pub have been launched (read by the engine's thread)
   uint32_t n_groups = 1;
   std::vector<std::unique_ptr<OdomChain>> chains;
   OdomChain& chain_of(uint32_t s) { uint32_t g = 0; while (g + 1 < n_groups && s >= chains[g]->s1) g++; return *chains[g]; }
@@ -224,6 +251,7 @@ class Pipeline {
   }
   // calling thread: allow the odometry chains to run up to step k
   void allow_odometry(int k) {
+    if (eng) { publish_features_upto(f_hi); for (uint32_t e = 0; e < n_engines(); e++) E(e).set_limit(k); return; }
     if (k <= o_limit.load(std::memory_order_acquire)) return;
     for (auto& c : chains)
       if (!c->worker.joinable()) { OdomChain* cp = c.get(); c->worker = std::thread([this, cp] { worker_main(cp); }); }
@@ -232,6 +260,19 @@ class Pipeline {
   }
   // calling thread: block until O(t) of every chain is published (rethrows a failure of a worker)
   void wait_odometry(int t) {
+    if (eng) {
+      for (uint32_t e = 0; e < n_engines(); e++) E(e).wait_step((uint32_t)t);
+      for (uint32_t s = 0; s < n_streams_; s++) {
+        uint32_t e = 0;
+        while (s >= eng_s0[e + 1]) e++;
+        const OdomStepResult& R = E(e).result((uint32_t)t, s - eng_s0[e]);
+        OdomPub& N = ores[t % 3][s];
+        N.transform = R.transform; N.transform_sum = R.transform_sum; N.stats = R.stats; N.rc = R.rc;
+        N.last_corner = R.last_corner; N.n_last_corner = R.n_last_corner; N.last_surf = R.last_surf; N.n_last_surf = R.n_last_surf;
+        N.to_end = R.to_end;
+      }
+      return;
+    }
     auto ready = [&] { return done_min() >= t || (!any_busy() && o_limit.load(std::memory_order_acquire) < t); };
     if (!spin_until(ready, 2000.0)) {
       std::unique_lock<std::mutex> lk(mu);
@@ -244,6 +285,14 @@ class Pipeline {
   // calling thread: block until the look-ahead has finished every step it has been allowed to run (its kernels are enqueued then:
   // a device synchronisation afterwards covers them).  Returns the last step whose odometry is published for every stream, -1 if none.
   int drain_lookahead() {
+    if (eng) {
+      int done = INT32_MAX;
+      for (uint32_t e = 0; e < n_engines(); e++) {
+        if (prefetch && E(e).limit() >= eng_first) E(e).wait_step((uint32_t)E(e).limit());
+        done = std::min(done, E(e).done_upto() - 1);
+      }
+      return done;
+    }
     const int lim = o_limit.load(std::memory_order_acquire);
     if (prefetch && lim >= 0 && chains[0]->worker.joinable()) wait_odometry(lim);
     return done_min();
@@ -252,6 +301,14 @@ class Pipeline {
   // continue there (the caller jumped); restart < 0: every chain continues where it IS — the positions are read AFTER the workers
   // have gone idle, under the mutex (a position read before the wait is stale by the step a worker was inside: ADVICE.md round 3)
   void park_odometry(int restart) {
+    if (eng) {
+      for (uint32_t e = 0; e < n_engines(); e++) {
+        if (restart >= 0) E(e).restart((uint32_t)restart, false);
+        else E(e).park();
+      }
+      if (restart >= 0) { eng_first = eng_expect = restart; f_pub.store(restart - 1, std::memory_order_release); }
+      return;
+    }
     std::unique_lock<std::mutex> lk(mu);
     o_limit.store(-1, std::memory_order_release);
     cv.wait(lk, [&] { return !any_busy(); });
@@ -264,7 +321,9 @@ class Pipeline {
     job_err = nullptr;
   }
   // (upload / first use of the streaming ring: every chain starts over at step 0)
+  int eng_first = 0, eng_expect = 0;   // first step of the engine's current run / the step the next step() call is expected to name
   void reset_odometry() {
+    if (eng) { for (uint32_t e = 0; e < n_engines(); e++) E(e).restart(0, false); eng_first = eng_expect = 0; f_pub.store(-1, std::memory_order_release); return; }
     std::unique_lock<std::mutex> lk(mu);
     o_limit.store(-1, std::memory_order_release);
     cv.wait(lk, [&] { return !any_busy(); });
@@ -273,6 +332,8 @@ class Pipeline {
   }
 
   ~Pipeline() {
+    engines_extra.clear();
+    eng.reset();   // (their threads read the feature extractors' buffers)
     { std::lock_guard<std::mutex> lk(mu); quit = true; o_limit.store(-1, std::memory_order_release); }
     cv.notify_all();   // (a worker leaves its spin phase after 0.4 ms and then sees quit)
     for (auto& c : chains) if (c->worker.joinable()) c->worker.join();
@@ -555,6 +616,28 @@ class Pipeline {
   }
   uint64_t run_count = 0;   // registrations run so far (parity = which full-resolution buffer)
 
+  // OdomEngine's input callback (its thread; must not block): the four feature clouds of every stream of step t once the step's
+  // features have been launched AND extracted
+  bool fetch_odom_inputs(uint32_t t, uint32_t s0, uint32_t s1, OdomInput* in, float* imu, bool& has_imu) {
+    if ((int)t > f_pub.load(std::memory_order_acquire)) return false;
+    if (hipEventQuery(evF[t % 3][1]) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const uint32_t ns = n_streams_;
+    FeatureExtractor& F = FX(t);
+    uint32_t* hb = h_off3[t % 3].p;
+    uint32_t* ho[3] = {hb, hb + (ns + 1), hb + 2 * (ns + 1)};
+    uint32_t* hlf = hb + 3 * (ns + 1);
+    if (s0 == 0 && timing.load(std::memory_order_relaxed)) (void)hipEventElapsedTime(&feat_ms[t % 3], evF[t % 3][0], evF[t % 3][1]);
+    for (uint32_t s = s0; s < s1; s++) {
+      const uint32_t la = hlf[F.ring_base(s)], lb = hlf[F.ring_base(s + 1)];
+      in[s - s0] = OdomInput{F.d_feat(0) + ho[0][s], ho[0][s + 1] - ho[0][s], F.d_feat(1) + ho[1][s], ho[1][s + 1] - ho[1][s],
+                             F.d_feat(2) + ho[2][s], ho[2][s + 1] - ho[2][s], F.d_less_flat() + la, lb - la};
+    }
+    has_imu = streaming && rawslot[t % RING].raw;   // imuTrans of this sweep (ScanRegistration publishes it with the clouds; LaserOdometry.cpp:239-248)
+    if (has_imu) memcpy(imu, rawslot[t % RING].imu_trans.data() + 12 * (size_t)s0, sizeof(float) * 12 * (s1 - s0));
+    return true;
+  }
+  void publish_features_upto(int k) { if (k > f_pub.load(std::memory_order_relaxed)) f_pub.store(k, std::memory_order_release); }
+
   // odometry of staged step t for the streams of one chain (needs the step's features, launched by the calling thread); results go to
   // ores[t % 3]
   void run_odometry(OdomChain& c, uint32_t t) {
@@ -634,20 +717,35 @@ class Pipeline {
     const uint32_t ns = n_streams_;
     // ---- this step's odometry: published by the look-ahead (the normal case), or run now
     const int ti = (int)t, last_staged = (int)n_staged() - 1;
-    {
+    if (eng) {
+      // the engine runs the steps in order from eng_first; a call that names neither the expected step nor one of the two before it
+      // (whose results are still in the ring) is a jump: every stream restarts there
+      if (!(ti == eng_expect || (ti < eng_expect && ti + 2 >= eng_expect && ti >= eng_first))) {
+        park_odometry(ti);
+        f_hi = ti - 1;
+      }
+    } else {
       bool jump = false;   // a chain for which this is neither a finished step nor its next one: the caller jumped, the chains restart here
       for (auto& c : chains) jump = jump || (ti > c->done.load(std::memory_order_acquire) && ti != c->next.load(std::memory_order_acquire));
       if (jump) {
         park_odometry(ti);
         f_hi = ti - 1;
       }
+      LX_REQUIRE(ti + 2 >= done_max(), "this step's odometry results have been overwritten: steps run in order");
     }
-    LX_REQUIRE(ti + 2 >= done_max(), "this step's odometry results have been overwritten: steps run in order");
     auto launch_upto = [&](int k) {   // features of the steps up to k (launched by this thread only, in step order)
       if (k > last_staged) k = last_staged;
       while (f_hi < k) { ++f_hi; if (!LA((uint32_t)f_hi)) launch_features((uint32_t)f_hi); }
+      if (eng) publish_features_upto(f_hi);
     };
-    if (ti > done_min()) {
+    if (eng) {
+      if (ti >= eng_expect) {
+        launch_upto(prefetch ? ti + 1 : ti);
+        allow_odometry(prefetch ? std::min(ti + 1, last_staged) : ti);
+      }
+      wait_odometry(ti);
+      eng_expect = std::max(eng_expect, ti + 1);
+    } else if (ti > done_min()) {
       launch_upto(prefetch ? ti + 1 : ti);
       if (prefetch) {
         allow_odometry(std::min(ti + 1, last_staged));
@@ -667,6 +765,7 @@ class Pipeline {
     FeatureExtractor& F = FX(t);
     const float f_ms = feat_ms[t % 3];
     // the re-projected "last" clouds of THIS sweep are produced at the tails of the odometry chains
+    for (uint32_t e = 0; e < n_engines(); e++) if (hipEvent_t ev = E(e).tail_event(t)) LX_HIP(hipStreamWaitEvent(s_, ev, 0));
     for (auto& c : chains) LX_HIP(hipStreamWaitEvent(s_, c->ev_tail[t % 3], 0));
     // ---- look-ahead while M(t) runs: the odometry chain may go on to step t+1 now and — once M(t) is enqueued and the features
     // of step t+2 are launched (while this thread waits for M(t)'s first look at the flags) — to step t+2
@@ -721,7 +820,7 @@ class Pipeline {
         for (uint32_t k = 0; k < nw; k++) foff[k + 1] = foff[k] + nfr[k];
         last_full_off = foff;
         run_count++;
-        chains[0]->ob->to_end_gather(full_dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
+        (eng ? gather_util.get() : chains[0]->ob.get())->to_end_gather(full_dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
         reg.upload_device(nw, cl.data(), ncl.data(), sl.data(), nsl.data(), nullptr, nullptr, guess.data());
         reg.on_first_wait = launch_f2;
         reg.run_async();
@@ -776,6 +875,7 @@ class Pipeline {
       {   // the odometry chains (overlapped with the registrations): the longest chain's most recent timed pass
         float m = 0.f;
         for (auto& c : chains) m = std::max(m, c->ms.load(std::memory_order_relaxed));
+        for (uint32_t e = 0; e < n_engines(); e++) m = std::max(m, E(e).busy_ms_per_step());   // device time of an engine's cycles per finished step
         last_ms[1] = m;
       }
       last_ms[2] = tmM[t & 1].pending ? tmM[(t + 1) & 1].ms : tmM[t & 1].ms;   // the previous step's while this one is in flight
@@ -853,8 +953,17 @@ int loamx_pipeline_set_state(loamx_pipeline* h, uint32_t stream, const float* tr
   return guard([&]() {
     LX_REQUIRE(h && stream < h->p.n_streams_, "invalid stream");
     h->p.park_odometry(-1);   // the odometry chains stop where they are; the sweeps they have not processed yet start from the new state
-    if (transform) h->p.OB(stream).stream_state(h->p.LS(stream)).transform.set(transform);
-    if (transform_sum) h->p.OB(stream).stream_state(h->p.LS(stream)).transform_sum.set(transform_sum);
+    if (h->p.eng) {
+      uint32_t e = 0;
+      while (stream >= h->p.eng_s0[e + 1]) e++;
+      OdomEngine& G = h->p.E(e);
+      const uint32_t l = stream - h->p.eng_s0[e];
+      if (transform) { G.stream_state(l).transform.set(transform); G.push_transform(l); }
+      if (transform_sum) G.stream_state(l).transform_sum.set(transform_sum);
+    } else {
+      if (transform) h->p.OB(stream).stream_state(h->p.LS(stream)).transform.set(transform);
+      if (transform_sum) h->p.OB(stream).stream_state(h->p.LS(stream)).transform_sum.set(transform_sum);
+    }
     if (bef) h->p.st[stream].bef.set(bef);
     if (aft) h->p.st[stream].aft.set(aft);
     return LOAMX_OK;
@@ -940,6 +1049,7 @@ int loamx_pipeline_set_timing(loamx_pipeline* h, int on) {
   return guard([&]() {
     LX_REQUIRE(h, "NULL handle");
     h->p.timing = on != 0;
+    for (uint32_t e = 0; e < h->p.n_engines(); e++) h->p.E(e).set_timing(on != 0);
     h->p.reg.set_timing(on != 0, on != 2);
     return LOAMX_OK;
   });

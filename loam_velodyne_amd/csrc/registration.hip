@@ -88,12 +88,6 @@ __global__ void k_grid_setup(uint32_t* __restrict__ scratch, GridDesc* __restric
   scratch[8] = g.ncell;
 }
 
-__device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-__device__ inline void cell_coords(const GridDesc& g, float x, float y, float z, int& cx, int& cy, int& cz) {
-  cx = clampi((int)floorf((x - g.ox) * g.inv_h), 0, g.nx - 1);
-  cy = clampi((int)floorf((y - g.oy) * g.inv_h), 0, g.ny - 1);
-  cz = clampi((int)floorf((z - g.oz) * g.inv_h), 0, g.nz - 1);
-}
 
 __global__ __launch_bounds__(256) void k_cell_count(const float4* __restrict__ pts, uint32_t n, const GridDesc* __restrict__ desc,
                                                     uint32_t* __restrict__ cell_of, uint32_t* __restrict__ counts) {
@@ -239,22 +233,6 @@ __global__ __launch_bounds__(1024) void k_bb_setup(uint32_t* __restrict__ enc, c
     scratch[2] = carry;
   }
 }
-// Points arrive in scan order, so neighbouring lanes mostly fall into the same cell: one atomic per RUN of equal cells
-// in a wave instead of one per point (64 lanes hammering two or three counters serialise in L2).
-// run_head_len: for the calling lane, the lane that starts its run and, if it is that lane, the run's length.
-__device__ inline void wave_runs(uint32_t key, bool active, int& head_lane, int& run_len) {
-  const int lane = (int)__lane_id();
-  const uint32_t prev = __shfl_up(key, 1, 64);
-  const unsigned long long act = __ballot(active);
-  const unsigned long long heads = __ballot(active && (lane == 0 || prev != key || !((act >> (lane > 0 ? lane - 1 : 0)) & 1ull)));
-  const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-  const unsigned long long below = heads & upto;
-  head_lane = below ? 63 - __builtin_clzll(below) : lane;
-  const unsigned long long stops = (heads | ~act) & ~upto;   // next head, or the first inactive lane
-  const int end = stops ? __builtin_ctzll(stops) : 64;
-  run_len = end - lane;   // meaningful on the head lane
-}
-
 __global__ __launch_bounds__(256) void k_bb_count(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off, uint32_t K,
                                                   const GridDescB* __restrict__ desc, uint32_t* __restrict__ cell_of,
                                                   uint32_t* __restrict__ counts, uint32_t* __restrict__ rank_of) {

@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--repeat", type=int, default=5, help="repeat the timed window this many times (fresh handles, same sweeps): value_median / value_min / value_max; `value` is the first window")
     ap.add_argument("--ab-pcie", default=None, help="diagnostic: like --ab, but each variant runs the PCIe-inclusive window")
     ap.add_argument("--ab", default=None, help="diagnostic: ';'-separated environment variants ('A=1 B=2;C=3;' — empty = defaults) timed inside this process before the contract's window, one line each on stderr")
+    ap.add_argument("--long-steps", type=int, default=0,
+                    help="N > 0: an additional window of N steps (needs N more staged sweeps per stream: ~1 s of host time per 50) reported as "
+                         "value_long — long enough for an external sampler (rocm-smi) to see the GPU busy")
     ap.add_argument("--mode", default="batched", choices=["batched", "live"],
                     help="live: sequential SLAM (BASELINE configs[1]: VLP-16, 200 k-pt live map, one sweep in flight, host clouds in / out)")
     args = ap.parse_args()
@@ -167,8 +170,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def resident_window(keep_open=False):
+    def resident_window(keep_open=False, collect=None):
         """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize, all sweeps resident in HBM.
+        collect: a list that receives, per step, the (odometry sum, mapped pose, iteration counts) of every stream — used by the
+        separate, untimed parity window only (it costs a few microseconds per stream and step).
         With H > 1 pipeline handles (--handles / LOAMX_BENCH_HANDLES) the streams are dealt over H handles, each driven by a host thread
         of its own that runs ITS K steps without waiting for the others between steps (the streams are independent; only the window's
         two ends are common)."""
@@ -194,10 +199,18 @@ def main():
         # after a registration against the index built from it has been observed complete
         ev_map = torch.cuda.Event() if E > 0 else None
 
+        def snapshot(h, t):
+            if collect is not None:
+                p = pipes[h]
+                for k in range(per):
+                    _, ts_, aft_, st_ = p.get(k)
+                    collect.append((t, h * per + k, ts_.copy(), aft_.copy(), st_["odom_iterations"], st_["map_iterations"]))
+
         def warm(h):   # warm-up (includes every stream's initialising first sweep); the window opens with the look-ahead exactly
             p = pipes[h]                 # LOOK steps ahead — and closes the same way (below)
             for t in range(1 + W):
                 p.step(t)
+                snapshot(h, t)
             p.drain_lookahead()
 
         def timed(h):
@@ -228,6 +241,7 @@ def main():
                 tc0 = time.perf_counter()
                 p.step(t)
                 a["in_step"] += time.perf_counter() - tc0
+                snapshot(h, t)
                 if sampled:   # event read-back of the step that just finished (the step itself is synchronous)
                     a["n_sampled"] += 1
                     tm = p.timing()
@@ -273,6 +287,32 @@ def main():
                 p.close()
             r["pipes"] = None
         return r
+
+    def long_window(N):
+        """value_long: the same protocol over N timed steps (N more sweeps per stream are generated and staged for it) — ~0.2 s of device
+        time, long enough for an external sampler to see the GPU busy."""
+        nonlocal sweeps, T, T_all, K
+        T_l = 1 + W + N + LOOK
+        jobs_l = []
+        for s_, gs in enumerate(lxdist.stream_ids(rank, world, ns)):
+            poses = synth.trajectory(T_l, start=lxdist.stream_start(gs))
+            for t in range(T_all, T_l):
+                jobs_l.append((t, s_, (125.0, args.sensor, poses[t], poses[t + 1], 1000 * gs + t)))
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(max_workers=n_workers, mp_context=mp.get_context("spawn")) as ex:
+            made_l = list(ex.map(synth.make_sweep_job, [j[2] for j in jobs_l], chunksize=max(1, len(jobs_l) // (4 * n_workers))))
+        keep = (sweeps, T, T_all, K)
+        sweeps = sweeps + [[None] * ns for _ in range(T_l - T_all)]
+        for (t, s_, _), (pts, rs) in zip(jobs_l, made_l):
+            sweeps[t][s_] = (pts, rs)
+        T, T_all, K = 1 + W + N, T_l, N
+        try:
+            w_ = resident_window()
+        finally:
+            sweeps, T, T_all, K = keep
+        return {"value": round(world * ns * N / w_["elapsed"], 2), "unit": "sweeps/s", "steps": N, "ms_per_step": round(w_["elapsed"] / N * 1e3, 4),
+                "seconds": round(w_["elapsed"], 4), "note": "same window protocol as `value` over a longer trajectory"}
 
     # ---- diagnostic: environment variants inside one process (same data, same box): --ab "A=1;B=2 C=3;"
     if args.ab is not None and world == 1:
@@ -330,6 +370,12 @@ def main():
     repeats = [value]
     for _ in range(max(args.repeat, 1) - 1):
         repeats.append(sweeps_total / resident_window()["elapsed"])
+
+    # ---- pose parity (BASELINE.json's metric, third part): one more window of the same steps, untimed, that records every stream's poses;
+    # cpu_baseline() runs the oracle chain over stream 0's sweeps from the same start and the two are compared below (bar: 1e-4 m / rad)
+    gpu_poses = []
+    if world == 1 and not args.no_cpu_baseline:
+        resident_window(collect=gpu_poses)
 
     # ---- the same K steps once more with the PCIe inside the timed region (SURVEY.md §8d "GPU timing"): every step's sweeps
     # are handed over from pinned host memory while earlier steps compute (loamx_pipeline_stage_step, three steps ahead) and
@@ -397,7 +443,9 @@ def main():
                 "map_epochs_swapped": n_epochs,
                 "numa_node_bound": numa_node,
                 "results_gathered": n_results,
-                "rccl_ranks": (ldist.comm_count() if ldist is not None else 1),   # what the RCCL communicator itself reports (ncclCommCount)
+                # what the RCCL communicator itself reports (ncclCommCount); 0 = a multi-rank run that fell back to torch.distributed for
+                # the map broadcast (map_broadcast_via says why): such a run must not be read as the native path
+                "rccl_ranks": (ldist.comm_count() if ldist is not None else (1 if world == 1 else 0)),
                 "path_algorithmic_bytes_per_sweep": round(float(bytes_per_sweep), 1),
                 "path_hbm_frac": round(float(bytes_per_sweep * value / world / (HBM_PEAK_GBS * 1e9)), 6),
             },
@@ -422,8 +470,17 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sweeps, starts, map_t)
+            orc_poses = []
+            out["cpu_baseline"] = cpu_baseline(sweeps, starts, map_t, poses_out=orc_poses)
+            out["pose_err_vs_oracle"] = pose_error(gpu_poses, orc_poses, stream=0)
+            if args.long_steps:
+                out["value_long"] = long_window(args.long_steps)
+        out["roofline_kernels"] = roofline_kernels(out["roofline"], ns)
         print(json.dumps(out), flush=True)
+        pe = out.get("pose_err_vs_oracle")
+        if pe and not pe.get("within_bar", True):   # a fast path whose poses differ from the reference's is not a result
+            print("bench.py: pose error against the oracle chain above the 1e-4 bar: %r" % pe, file=sys.stderr, flush=True)
+            sys.exit(3)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -652,11 +709,78 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
     }
 
 
+def pose_error(gpu_poses, orc_poses, stream=0):
+    """BASELINE.json metric part 3: the benchmarked path's poses against the oracle chain's (the CPU restatement of the reference, pinned
+    bit for bit against the reference's own translation units by tests/test_ref_pinning.py) on the same sweeps of one stream from the same
+    start: the mapped pose (transformAftMapped) and the accumulated odometry (transformSum) after every sweep.  Bar: 1e-4 m / 1e-4 rad."""
+    g = {t: (ts, aft, oi, mi) for (t, s, ts, aft, oi, mi) in gpu_poses if s == stream}
+    rows = []
+    for (t, ts_o, aft_o, oi_o, mi_o) in orc_poses:
+        if t in g and t >= 1:
+            ts_g, aft_g, oi_g, mi_g = g[t]
+            rows.append((np.abs(aft_g[3:] - aft_o[3:]).max(), np.abs(aft_g[:3] - aft_o[:3]).max(), np.abs(ts_g[3:] - ts_o[3:]).max(),
+                         np.abs(ts_g[:3] - ts_o[:3]).max(), int(oi_g == oi_o), int(mi_g == mi_o)))
+    if not rows:
+        return None
+    a = np.array(rows, float)
+    return {"stream": stream, "sweeps": len(rows),
+            "mapped_pose": {"max_m": float(a[:, 0].max()), "max_rad": float(a[:, 1].max()), "rmse_m": float(np.sqrt((a[:, 0] ** 2).mean())),
+                            "rmse_rad": float(np.sqrt((a[:, 1] ** 2).mean()))},
+            "odometry_sum": {"max_m": float(a[:, 2].max()), "max_rad": float(a[:, 3].max()), "rmse_m": float(np.sqrt((a[:, 2] ** 2).mean())),
+                             "rmse_rad": float(np.sqrt((a[:, 3] ** 2).mean()))},
+            "odometry_iterations_equal": int(a[:, 4].sum()), "mapping_iterations_equal": int(a[:, 5].sum()),
+            "bar": 1e-4, "within_bar": bool(a[:, :4].max() <= 1e-4),
+            "note": "per-sweep max |difference| of (x, y, z) and (rx, ry, rz) between the GPU pipeline (a separate, untimed window of the same "
+                    "steps) and the oracle chain run by cpu_baseline; the run exits with status 3 above the bar"}
+
+
+def roofline_kernels(main, ns):
+    """The other kernels on the critical chains next to the dominant one: algorithmic bytes per launch (SURVEY.md §8d models, stated per
+    kernel), average launch duration and HBM-side traffic from the COMMITTED rocprofv3 passes of this command (bench.py cannot profile
+    itself: profiles/r04_bench_kernel_stats.csv, profiles/r04_pmc_summary.json; None when a file is missing)."""
+    import csv
+    dur, pmc = {}, {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.csv")) as f:
+            for r in csv.DictReader(f):
+                dur[r["Name"].split("(")[0].replace("void ", "").strip()] = float(r["AverageNs"]) / 1e3
+    except (OSError, KeyError, ValueError):
+        pass
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_summary.json")) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        pass
+    feats = 36 * 64
+    models = [   # kernel, algorithmic bytes per launch of `ns` sweeps, model
+        ("loamx::k_odom_corr_grid", ns // 2 * feats * (12 + 16 * 64), "per feature: 12 B query + ~64 candidate points x 16 B (27-cell block or ring window), 4 streams per launch"),
+        ("loamx::k_odom_lm<1>", ns // 2 * feats * 48, "per feature 48 B (query + tripod) once per launch of up to 5 iterations, 4 streams per launch"),
+        ("loamx::k_vb_reduce", ns * 35000 * (16 + 8), "per stack point 16 B read + ~8 B of voxel means written"),
+        ("loamx::k_feat_ring", ns * 131072 * 8, "per sweep point ~8 B (curvature + flags)"),
+    ]
+    out = []
+    for name, nbytes, model in models:
+        us = next((v for k, v in dur.items() if k.startswith(name)), None)
+        tr = next((v.get("traffic_bytes") for k, v in pmc.items() if isinstance(v, dict) and name.split("::")[-1].split("<")[0] in k), None)
+        out.append({"kernel": name, "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_us": us,
+                    "achieved_gbs": (round(nbytes / (us * 1e-6) / 1e9, 2) if us else None),
+                    "frac": (round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6) if us else None), "traffic": tr, "model": model,
+                    "source": "profiles/r04_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command), profiles/r04_pmc_summary.json"})
+    return out
+
+
 def pmc_traffic():
     """HBM bytes per full launch of the dominant kernel from the committed PMC passes of this same command
     (profiles/r03_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs, FETCH_SIZE
     doubled per MI355X_MICROARCH.md).  bench.py cannot run the profiler on itself, so the figure is read, not measured
     live; None when the file is missing."""
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["k_gn_iter_full_launch"]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
     try:
         with open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")) as f:
             return json.load(f)["k_gn_iter_full_launch"]["traffic_bytes"]
@@ -669,7 +793,7 @@ def _stats(x):
     return {"median": round(float(np.median(x)), 5), "p95": round(float(np.percentile(x, 95)), 5), "mean": round(float(x.mean()), 5), "n": int(len(x))}
 
 
-def cpu_baseline(sweeps, starts, map_t, n_measure=20, n_warm=3, n_reference=6):
+def cpu_baseline(sweeps, starts, map_t, n_measure=20, n_warm=3, n_reference=6, poses_out=None):
     """SURVEY.md §8(d) "CPU baseline timing": the oracle (CPU restatement of the reference, g++ -O3 -march=native, every stage
     single-threaded like the reference's nodes) on stream 0 of the SAME workload — 3 warm-up sweeps, then up to 20 measured
     ones against the same frozen map; per-stage median and p95; sweeps/s as the serial sum (1 core) and as the slowest stage
@@ -703,6 +827,8 @@ def cpu_baseline(sweeps, starts, map_t, n_measure=20, n_warm=3, n_reference=6):
             omp.set_transform("bef", ood.transform_sum)
             omp.set_transform("aft", pose)
         d = time.perf_counter()
+        if poses_out is not None and t > 0:
+            poses_out.append((t, np.array(ood.transform_sum, np.float32), np.array(pose, np.float32), ood.stats()["iterations"], omp.stats()["iterations"]))
         if t > n_warm:
             st["features"].append(b - a); st["odometry"].append(c - b); st["registration"].append(d - c)
     per = np.array(st["features"]) + np.array(st["odometry"]) + np.array(st["registration"])

@@ -277,3 +277,27 @@ def test_bench_main_as_rank_0_of_two(monkeypatch, capsys):
     assert ft.distributed.calls[0] == "init" and ft.distributed.calls[-1] == "destroy"
     # value counts both ranks' sweeps over this rank's clock (the stand-in's max-over-ranks is the identity)
     assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 2 * 2) < 0.05 * 4
+
+
+def test_pose_error_and_roofline_kernels_helpers():
+    """bench.py's parity figure (BASELINE.json metric part 3) and the extra roofline rows, on synthetic inputs"""
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    rng = np.random.default_rng(0)
+    orc, gpu = [], []
+    for t in range(1, 8):
+        ts, aft = rng.normal(size=6).astype(np.float32), rng.normal(size=6).astype(np.float32)
+        orc.append((t, ts, aft, 6, 3))
+        for s in range(2):   # stream 1 is ignored
+            d = np.float32(2e-6 if s == 0 else 1.0)
+            gpu.append((t, s, ts + d, aft - d, 6, 3 if t != 4 else 4))
+    pe = bench.pose_error(gpu, orc, stream=0)
+    assert pe["sweeps"] == 7 and pe["within_bar"] and 1e-6 < pe["mapped_pose"]["max_m"] < 1e-5 and pe["odometry_iterations_equal"] == 7
+    assert pe["mapping_iterations_equal"] == 6   # (sweep 4 was made to differ)
+    gpu_bad = [(t, s, ts + np.float32(1e-3), aft, oi, mi) for (t, s, ts, aft, oi, mi) in gpu]
+    assert not bench.pose_error(gpu_bad, orc, stream=0)["within_bar"]
+    assert bench.pose_error([], orc) is None
+    rows = bench.roofline_kernels({"kernel": "loamx::k_gn_iter"}, 8)
+    assert {r["kernel"] for r in rows} >= {"loamx::k_odom_corr_grid", "loamx::k_odom_lm<1>", "loamx::k_vb_reduce", "loamx::k_feat_ring"}
+    for r in rows:
+        assert r["algorithmic_bytes_per_launch"] > 0 and set(r) >= {"avg_launch_us", "frac", "traffic", "model", "source"}

@@ -827,10 +827,24 @@ def cpu_baseline(sweeps, starts, map_t, n_measure=20, n_warm=3, n_reference=6, p
             omp.set_transform("bef", ood.transform_sum)
             omp.set_transform("aft", pose)
         d = time.perf_counter()
-        if poses_out is not None and t > 0:
-            poses_out.append((t, np.array(ood.transform_sum, np.float32), np.array(pose, np.float32), ood.stats()["iterations"], omp.stats()["iterations"]))
         if t > n_warm:
             st["features"].append(b - a); st["odometry"].append(c - b); st["registration"].append(d - c)
+    if poses_out is not None:
+        # the parity chain: the SAME sweeps through the oracle's parity build (liboracle.so: -O2 -ffp-contract=off, the build that is pinned
+        # bit for bit against the reference's translation units; the timed build above is -O3 -march=native and contracts FMAs)
+        orc_p = op.Oracle(fast=False)
+        psr, pod, pmp = op.ScanRegistration(orc_p), op.LaserOdometry(orc_p), op.LaserMapping(orc_p)
+        pmp.set_frozen(m[:n_corner], m[n_corner:])
+        pmp.set_transform("aft", starts[0])
+        for t in range(T):
+            pod.set_features(psr.process(*sweeps[t][0]))
+            pod.process()
+            if t > 0:
+                pmp.set_transform("sum", pod.transform_sum)
+                pose = pmp.register_frozen(pod.last_corner(), pod.last_surf(), pmp.associate())
+                pmp.set_transform("bef", pod.transform_sum)
+                pmp.set_transform("aft", pose)
+                poses_out.append((t, np.array(pod.transform_sum, np.float32), np.array(pose, np.float32), pod.stats()["iterations"], pmp.stats()["iterations"]))
     per = np.array(st["features"]) + np.array(st["odometry"]) + np.array(st["registration"])
     med = {k: float(np.median(v)) for k, v in st.items()}
     serial = 1.0 / float(np.median(per))

@@ -91,6 +91,48 @@ def test_lookahead_is_transparent(small_world):
             assert np.array_equal(tra, trb) and np.array_equal(tsa, tsb) and np.array_equal(afa, afb) and sta == stb
 
 
+@pytest.mark.parametrize("engine", [0, 1])
+def test_lookahead_toggled_and_state_set_mid_run(monkeypatch, small_world, engine):
+    """ADVICE.md (round 3): loamx_pipeline_set_lookahead(0) and loamx_pipeline_set_state in the MIDDLE of a run, right after step() has
+    returned and while the look-ahead is still working on the next steps, must leave the odometry chain where it really is — the old
+    code re-ran a step the worker had just finished (transformSum integrated twice).  A run with the look-ahead switched off after
+    step 2 and on again after step 4 equals the undisturbed run bit for bit; a set_state(aft=...) with the value the stream already
+    has changes nothing either.  Both odometry back ends (chains, OdomEngine)."""
+    monkeypatch.setenv("LOAMX_ODOM_ENGINE", str(engine))
+    cm, sm = small_world.make_map(40000)
+    T, ns = 8, 3
+    data = []
+    for s in range(ns):
+        poses = synth.trajectory(T, start=(1.0 * s, 0.0, 2.0 * s))
+        data.append([synth.make_sweep(small_world, "VLP-16", poses[t], poses[t + 1], seed=50 * s + t, az_steps=800) for t in range(T)])
+
+    def run(disturb):
+        p = loamx.Pipeline(ns)
+        p.set_frozen(cm, sm)
+        for s in range(ns):
+            p.set_state(s, aft=np.array([0, 0, 0, 1.0 * s, 0, 2.0 * s], np.float32))
+        p.upload([[(data[s][t].points, data[s][t].ring_sizes) for s in range(ns)] for t in range(T)])
+        out = []
+        for t in range(T):
+            p.step(t)
+            out.append([p.get(s) for s in range(ns)])
+            if disturb and t == 2:
+                p.set_lookahead(False)      # (the look-ahead is inside O(3) / O(4) right now)
+            if disturb and t == 4:
+                p.set_lookahead(True)
+            if disturb and t == 5:
+                for s in range(ns):
+                    p.set_state(s, aft=out[-1][s][2])   # the value it has: a no-op that parks the chain mid-flight
+        p.close()
+        return out
+    a, b = run(False), run(True)
+    for t in range(T):
+        for s in range(ns):
+            for x, y in zip(a[t][s][:3], b[t][s][:3]):
+                assert np.array_equal(x, y), (t, s)
+            assert a[t][s][3] == b[t][s][3], (t, s)
+
+
 def test_cpp_adapter_matches(orc, small_world, tmp_path):
     """The header-only C++ classes with the reference's member names (loam_velodyne_amd/adapter) drive the same library:
     scan registration -> odometry -> mapping exactly as the reference's node loop wires them."""
@@ -170,6 +212,83 @@ def test_full_size_hdl64_pipeline_vs_oracle(orc):
         # sensor position at the end of the last sweep (LOAM with a 25 / 10 iteration budget, not a converged optimum)
         gt = synth.trajectory(T, start=starts[s])[T]
         assert np.abs(got[T - 1][s][2][3:] - gt[3:]).max() < 0.3
+
+
+def _bench_scale_chain(args):
+    """worker process: the oracle chain of one stream over its sweeps (CPU) -> per sweep (transformSum, mapped pose, iteration counts)"""
+    s, start, cm, sm, sweeps = args
+    import oracle_py as op_
+    o = op_.Oracle()
+    osr, ood, omp = op_.ScanRegistration(o), op_.LaserOdometry(o), op_.LaserMapping(o)
+    omp.set_frozen(cm, sm)
+    omp.set_transform("aft", np.array([0, 0, 0, *start], np.float32))
+    out = []
+    for t, (pts, rs) in enumerate(sweeps):
+        ood.set_features(osr.process(pts, rs))
+        ood.process()
+        if t > 0:
+            omp.set_transform("sum", ood.transform_sum)
+            omp.register_frozen(ood.last_corner(), ood.last_surf(), omp.associate())
+        out.append((np.array(ood.transform_sum), np.array(omp.transform("aft")), ood.stats()["iterations"], omp.stats()["iterations"]))
+    return s, out
+
+
+@pytest.mark.parametrize("engine", [0, 1])
+def test_bench_scale_8_streams_vs_oracle(monkeypatch, engine):
+    """The BENCHMARKED shape (bench.py: 8 HDL-64E streams against the 1,000,000-point frozen map, look-ahead on, the bench's own
+    trajectories and seeds) for 11 sweeps per stream: every stream against its own oracle chain — accumulated odometry and mapped pose
+    within POSE_TOL after every sweep, odometry and mapping iteration counts equal.  engine = 1: the same through the decoupled
+    OdomEngine (LOAMX_ODOM_ENGINE=1), whose results must be the chains' bit for bit."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    from loam_velodyne_amd import dist as lxdist
+    monkeypatch.setenv("LOAMX_ODOM_ENGINE", str(engine))
+    NS, T = 8, 11
+    world = synth.World(half_extent=125.0)
+    cm, sm = world.make_map(1000000)
+    jobs, starts = [], []
+    for s, gs in enumerate(lxdist.stream_ids(0, 1, NS)):
+        start = lxdist.stream_start(gs)
+        starts.append(start)
+        poses = synth.trajectory(T, start=start)
+        jobs += [(125.0, "HDL-64E", poses[t], poses[t + 1], 1000 * gs + t) for t in range(T)]
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1), mp_context=mp.get_context("spawn")) as ex:
+        made = list(ex.map(synth.make_sweep_job, jobs, chunksize=4))
+        sweeps = [[made[s * T + t] for t in range(T)] for s in range(NS)]
+        chains = dict(ex.map(_bench_scale_chain, [(s, starts[s], cm, sm, sweeps[s]) for s in range(NS)]))
+    pipe = loamx.Pipeline(NS)
+    pipe.set_frozen(cm, sm)
+    for s in range(NS):
+        pipe.set_state(s, aft=np.array([0, 0, 0, *starts[s]], np.float32))
+    pipe.upload([[sweeps[s][t] for s in range(NS)] for t in range(T)])
+    got = []
+    for t in range(T):
+        assert pipe.step(t) == (loamx.SKIPPED if t == 0 else loamx.OK)
+        got.append([pipe.get(s) for s in range(NS)])
+    pipe.close()
+    worst = 0.0
+    for s in range(NS):
+        for t in range(T):
+            ts_o, aft_o, oi, mi = chains[s][t]
+            tr, ts, aft, st = got[t][s]
+            worst = max(worst, np.abs(ts - ts_o).max(), np.abs(aft - aft_o).max())
+            assert np.abs(ts - ts_o).max() < POSE_TOL and np.abs(aft - aft_o).max() < POSE_TOL, (s, t)
+            if t > 0:
+                assert st["odom_iterations"] == oi and st["map_iterations"] == mi, (s, t)
+    if engine:   # ... and the engine's poses ARE the chains': compare with a second run through them
+        monkeypatch.setenv("LOAMX_ODOM_ENGINE", "0")
+        q = loamx.Pipeline(NS)
+        q.set_frozen(cm, sm)
+        for s in range(NS):
+            q.set_state(s, aft=np.array([0, 0, 0, *starts[s]], np.float32))
+        q.upload([[sweeps[s][t] for s in range(NS)] for t in range(T)])
+        for t in range(T):
+            q.step(t)
+            for s in range(NS):
+                a, b = q.get(s), got[t][s]
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3], (s, t)
+        q.close()
+    print("bench-scale parity: worst |difference| %.2e over %d streams x %d sweeps" % (worst, NS, T))
 
 
 @pytest.mark.parametrize("ahead,pinned", [(3, False), (4, False), (3, True)])

@@ -528,4 +528,23 @@ __device__ __forceinline__ void qr_solve6_coop(const float* AtA, const float* At
   if (gl < 6) X[perm] = gl < nonzero ? y : 0.f;
 }
 
+// ---- exchange between workgroups without cache-wide fences (round 4).  __threadfence() on gfx950 is buffer_wbl2 sc1 + buffer_inv sc1:
+// it writes back and INVALIDATES the XCD's whole L2 — the L2 the other HIP streams' kernels are living in (k_gn_iter's map, the
+// odometry's clouds).  k_gn_iter executed it ~2,400 times per launch, k_odom_lm ~700.  What an exchange of a few dozen words needs is
+// much less: the producer stores its words with agent-scope (sc1, write-through) stores and waits for them to complete before it bumps
+// the arrival counter; the consumer reads them with agent-scope loads (which do not stop at the non-coherent L2).
+__device__ __forceinline__ void xchg_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void xchg_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // (gfx9: vmcnt counts stores too)
+// agent-scope load issued WITHOUT a wait: the compiler emits atomic loads one at a time (a wait behind each); n of these followed by
+// one xchg_loads_done() are n loads in flight
+__device__ __forceinline__ double xchg_load_nowait(const double* p) {
+  double v;
+  asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void xchg_loads_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// ... and every loaded value goes through this once, after xchg_loads_done(): it ties the value's uses behind the wait (the compiler
+// sees no dependence between the load statement's output and the wait statement otherwise)
+__device__ __forceinline__ void xchg_loaded(double& v) { asm volatile("" : "+v"(v)); }
+
 }  // namespace loamx

@@ -776,8 +776,8 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
 #pragma unroll
       for (int w = 0; w < 8; w++) x += red[w][tid];
       if (NB > 1) {
-        pb.part[(((unsigned)iter & 1u) * 16u + blockIdx.x) * LX_NSUM + tid] = x;
-        __threadfence();   // release the partial sums before this workgroup is counted in
+        xchg_store(&pb.part[(((unsigned)iter & 1u) * 16u + blockIdx.x) * LX_NSUM + tid], x);
+        xchg_stores_done();   // the partial sums are out (agent scope) before this workgroup is counted in — no cache-wide fence (dev_math.cuh)
       } else {
         sums[tid] = x;
       }
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
           __builtin_amdgcn_s_sleep(1);
           if ((++spins & 1023u) == 0u && wall_clock64() - t_in > 200000000ull) { sh_abort = 1; break; }
         }
-        __threadfence();   // acquire the other workgroups' partial sums
+        // (the other workgroups' partial sums are read with agent-scope loads below: nothing to invalidate)
       }
       __syncthreads();
       if (sh_abort) {   // block-uniform: this stream's launch is abandoned, later launches see `done`

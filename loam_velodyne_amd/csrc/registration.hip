@@ -559,18 +559,22 @@ __device__ __forceinline__ void solve_sweep(uint32_t s, const uint32_t* __restri
   if (tid < LX_SOLVE_GROUPS * LX_NSUM) {
     const uint32_t g = (uint32_t)tid / LX_NSUM, t = (uint32_t)tid % LX_NSUM;
     double x = 0.0;
-    // 18 loads in flight, added in tile order: an HDL-64E sweep has ~300 tiles = 34 per thread — two memory round trips (the
-    // partials come from the other XCDs' workgroups: every trip is a miss, ~3 us) where 16 in flight made three
+    // LX_SOLVE_MLP agent-scope loads in flight (the partials come from the other XCDs' workgroups; see dev_math.cuh "exchange"), added
+    // in tile order.  Unconditional loads with a clamped tile index: the conditional ones of round 3 were compiled into one branch +
+    // wait per load — 34 dependent round trips, 9-12 of solve_sweep's ~20 us (in-kernel time stamps)
     for (uint32_t b0 = g; b0 < nact; b0 += LX_SOLVE_MLP * LX_SOLVE_GROUPS) {
       double v[LX_SOLVE_MLP];
 #pragma unroll
       for (int u = 0; u < LX_SOLVE_MLP; u++) {
-        const uint32_t b = b0 + u * LX_SOLVE_GROUPS;
-        v[u] = b < nact ? partials[((size_t)s * nblk + b) * LX_NSUM + t] : 0.0;
+        const uint32_t b = min(b0 + u * LX_SOLVE_GROUPS, nact - 1u);
+        v[u] = xchg_load_nowait(&partials[((size_t)s * nblk + b) * LX_NSUM + t]);
       }
+      xchg_loads_done();
 #pragma unroll
-      for (int u = 0; u < LX_SOLVE_MLP; u++)
-        if (b0 + u * LX_SOLVE_GROUPS < nact) x += v[u];
+      for (int u = 0; u < LX_SOLVE_MLP; u++) {
+        xchg_loaded(v[u]);
+        x += (b0 + u * LX_SOLVE_GROUPS < nact) ? v[u] : 0.0;
+      }
     }
     gsum[g][t] = x;
   }

@@ -396,6 +396,12 @@ int loamx_dist_broadcast_map(loamx_dist* h, void* d_corner_xyzi, uint32_t n_corn
  * receives the world_size record counts.  Every rank must call it; blocking. */
 int loamx_dist_allgather_results(loamx_dist* h, const float* poses6, const int* iters_flags2, uint32_t n_local, float* poses6_all,
                                  int* iters_flags2_all, uint32_t* counts_all);
+/* the same with the capacity of the receive arrays stated (in records): LOAMX_E_CAPACITY — after both collectives, so that no rank
+ * is left waiting, and with counts_all filled — when the ranks' records do not fit; nothing is written beyond the capacity */
+int loamx_dist_allgather_results_cap(loamx_dist* h, const float* poses6, const int* iters_flags2, uint32_t n_local, float* poses6_all,
+                                     int* iters_flags2_all, uint32_t capacity_records, uint32_t* counts_all);
+/* only the first half: every rank's record count (for a caller that sizes its receive arrays by them).  Every rank must call it. */
+int loamx_dist_allgather_counts(loamx_dist* h, uint32_t n_local, uint32_t* counts_all);
 /* ranks the RCCL communicator itself reports (ncclCommCount); -1 on error */
 int loamx_dist_comm_count(loamx_dist* h);
 /* The host side of the two rules above without a device or a communicator (for a host that brings its own transport; the

@@ -169,8 +169,29 @@ int loamx_dist_unpack_results(const float* recv8, const uint32_t* counts, int wo
   });
 }
 
-int loamx_dist_allgather_results(loamx_dist* h, const float* poses6, const int* iters_flags2, uint32_t n_local, float* poses6_all,
-                                 int* iters_flags2_all, uint32_t* counts_all) {
+static int dist_gather_counts(loamx_dist* h, uint32_t n_local) {   // -> h->h_cnt.p[0 .. world)
+  const int G = h->world;
+  h->h_cnt.reserve((size_t)G + 1); h->d_cnt.reserve((size_t)G + 1);
+  h->h_cnt.p[G] = n_local;
+  LX_HIP(hipMemcpyAsync(h->d_cnt.p + G, h->h_cnt.p + G, sizeof(uint32_t), hipMemcpyHostToDevice, h->st));
+  LX_NCCL(ncclAllGather(h->d_cnt.p + G, h->d_cnt.p, 1, ncclUint32, h->comm, h->st));
+  LX_HIP(hipMemcpyAsync(h->h_cnt.p, h->d_cnt.p, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, h->st));
+  LX_HIP(hipStreamSynchronize(h->st));
+  return LOAMX_OK;
+}
+
+int loamx_dist_allgather_counts(loamx_dist* h, uint32_t n_local, uint32_t* counts_all) {
+  return guard([&]() {
+    LX_REQUIRE(h && counts_all, "NULL argument");
+    LX_HIP(hipSetDevice(h->device));
+    dist_gather_counts(h, n_local);
+    memcpy(counts_all, h->h_cnt.p, sizeof(uint32_t) * h->world);
+    return (int)LOAMX_OK;
+  });
+}
+
+int loamx_dist_allgather_results_cap(loamx_dist* h, const float* poses6, const int* iters_flags2, uint32_t n_local, float* poses6_all,
+                                     int* iters_flags2_all, uint32_t capacity_records, uint32_t* counts_all) {
   return guard([&]() {
     LX_REQUIRE(h && (poses6 || !n_local) && poses6_all, "NULL argument");
     LX_HIP(hipSetDevice(h->device));
@@ -178,14 +199,10 @@ int loamx_dist_allgather_results(loamx_dist* h, const float* poses6, const int* 
     const int G = h->world;
     // 1. every rank's record count (shards differ by one whenever the batch does not divide by the world size; a rank with an
     //    empty shard still takes part in both collectives)
-    h->h_cnt.reserve((size_t)G + 1); h->d_cnt.reserve((size_t)G + 1);
-    h->h_cnt.p[G] = n_local;
-    LX_HIP(hipMemcpyAsync(h->d_cnt.p + G, h->h_cnt.p + G, sizeof(uint32_t), hipMemcpyHostToDevice, h->st));
-    LX_NCCL(ncclAllGather(h->d_cnt.p + G, h->d_cnt.p, 1, ncclUint32, h->comm, h->st));
-    LX_HIP(hipMemcpyAsync(h->h_cnt.p, h->d_cnt.p, sizeof(uint32_t) * G, hipMemcpyDeviceToHost, h->st));
-    LX_HIP(hipStreamSynchronize(h->st));
+    dist_gather_counts(h, n_local);
     uint32_t n_pad = 0;
-    for (int r = 0; r < G; r++) n_pad = std::max(n_pad, h->h_cnt.p[r]);
+    unsigned long long total = 0;
+    for (int r = 0; r < G; r++) { n_pad = std::max(n_pad, h->h_cnt.p[r]); total += h->h_cnt.p[r]; }
     if (counts_all) memcpy(counts_all, h->h_cnt.p, sizeof(uint32_t) * G);
     if (!n_pad) return (int)LOAMX_OK;   // (every rank sees the same counts: all of them leave here)
     // 2. the records, padded to the longest shard
@@ -197,8 +214,15 @@ int loamx_dist_allgather_results(loamx_dist* h, const float* poses6, const int* 
     LX_NCCL(ncclAllGather(h->d_send.p, h->d_recv.p, nl, ncclFloat, h->comm, h->st));
     LX_HIP(hipMemcpyAsync(h->h_recv.p, h->d_recv.p, na * sizeof(float), hipMemcpyDeviceToHost, h->st));
     LX_HIP(hipStreamSynchronize(h->st));
+    // (the capacity is a LOCAL matter: it is checked after the collectives, so a rank with too small arrays fails alone)
+    if (total > capacity_records) throw Error(LOAMX_E_CAPACITY, "the ranks' records do not fit the receive arrays (counts_all holds the counts)");
     return loamx_dist_unpack_results(h->h_recv.p, h->h_cnt.p, G, n_pad, poses6_all, iters_flags2_all);
   });
+}
+
+int loamx_dist_allgather_results(loamx_dist* h, const float* poses6, const int* iters_flags2, uint32_t n_local, float* poses6_all,
+                                 int* iters_flags2_all, uint32_t* counts_all) {
+  return loamx_dist_allgather_results_cap(h, poses6, iters_flags2, n_local, poses6_all, iters_flags2_all, 0xffffffffu, counts_all);
 }
 
 int loamx_dist_comm_count(loamx_dist* h) {   // ranks the RCCL communicator itself reports (a scaling run proves RCCL saw N ranks)

@@ -42,6 +42,16 @@ class HostLinkDma {
     }
     hsa_signal_store_relaxed(sig_[slot], (hsa_signal_value_t)n);
     pending_[slot] = n > 0;
+    unissued_[slot] = n;
+  }
+  // A group that cannot be completed (a copy failed: the caller falls back to hipMemcpyAsync): the copies that were never issued are
+  // taken off the signal, the issued ones are waited for, the slot is free again.  (a failing copy used to leave
+  // the signal above zero for good and every later wait(slot) blocked for ever.)
+  void abandon(int slot) {
+    if (!pending_[slot]) return;
+    if (unissued_[slot]) hsa_signal_subtract_relaxed(sig_[slot], (hsa_signal_value_t)unissued_[slot]);
+    unissued_[slot] = 0;
+    try { wait(slot); } catch (...) { pending_[slot] = false; }
   }
   void copy_d2h(int slot, void* host_dst, const void* dev_src, size_t bytes) {
     hsa_agent_t g, c;
@@ -53,10 +63,11 @@ class HostLinkDma {
       if (st != HSA_STATUS_SUCCESS) engine_mask_ = 0;   // not available on this device: ROCr chooses from now on
     }
     if (st != HSA_STATUS_SUCCESS) st = hsa_amd_memory_async_copy(host_dst, c, dev_src, g, bytes, 0, nullptr, sig_[slot]);
-    if (st != HSA_STATUS_SUCCESS) {
-      hsa_signal_subtract_relaxed(sig_[slot], 1);   // (this copy will never complete the signal)
+    if (st != HSA_STATUS_SUCCESS) {   // this copy and the rest of its group will never complete the signal: see abandon()
+      abandon(slot);
       throw Error(LOAMX_E_HIP, "hsa_amd_memory_async_copy failed (" + std::to_string((int)st) + ")");
     }
+    if (unissued_[slot]) unissued_[slot]--;
   }
   uint32_t engine() const { return engine_mask_ == ~0u ? 0u : engine_mask_; }
   bool pending(int slot) const { return pending_[slot]; }
@@ -104,6 +115,7 @@ class HostLinkDma {
   uint32_t engine_mask_ = ~0u;
   hsa_signal_t sig_[SLOTS] = {};
   bool made_[SLOTS] = {false, false}, pending_[SLOTS] = {false, false};
+  uint32_t unissued_[SLOTS] = {0, 0};   // copies of the slot's group that have not been handed to ROCr yet
 };
 
 }  // namespace loamx

@@ -86,6 +86,7 @@ class Pipeline {
     for (auto& tr : imu) tr.history_size = std::max(200, fc.imu_history_size);
     reg.params.max_iterations = mc.max_iterations;
     reg.early_exit = true;   // step() blocks on M(t) anyway
+    reg.double_buffer_full = true;   // two full-resolution staging buffers: the next step's re-projected clouds are written while this step's are registered (prestage_gather)
     reg.params.delta_t_abort = mc.delta_t_abort;
     reg.params.delta_r_abort = mc.delta_r_abort;
     reg.params.corner_leaf = mc.corner_filter_size;
@@ -301,6 +302,7 @@ class Pipeline {
   // continue there (the caller jumped); restart < 0: every chain continues where it IS — the positions are read AFTER the workers
   // have gone idle, under the mutex (a position read before the wait is stale by the step a worker was inside: ADVICE.md round 3)
   void park_odometry(int restart) {
+    if (restart >= 0) pre_t = -1;   // (a pre-staged re-projection belongs to the run that is abandoned)
     if (eng) {
       for (uint32_t e = 0; e < n_engines(); e++) {
         if (restart >= 0) E(e).restart((uint32_t)restart, false);
@@ -593,10 +595,15 @@ class Pipeline {
     wait_download(par);   // (a caller that downloads the same step twice)
     if (direct) {
       if (ev_reg_done) LX_HIP(hipEventSynchronize(ev_reg_done));   // step() has returned: the registration is complete and its clouds are visible
-      hostlink.begin(par, (uint32_t)runs.size());
-      for (const Run& r : runs) hostlink.copy_d2h(par, r.dst, r.src, r.bytes);
-      downloads_direct++;
-    } else if (!runs.empty()) {
+      try {
+        hostlink.begin(par, (uint32_t)runs.size());
+        for (const Run& r : runs) hostlink.copy_d2h(par, r.dst, r.src, r.bytes);
+        downloads_direct++;
+      } catch (const Error&) {   // ROCr refused a copy: the slot has been freed (HostLinkDma::abandon); the whole group goes through HIP
+        direct = false;
+      }
+    }
+    if (!direct && !runs.empty()) {
       if (!dstream) dstream = create_stream(0);
       if (!ev_d2h[par]) LX_HIP(hipEventCreateWithFlags(&ev_d2h[par], hipEventDisableTiming));
       LX_HIP(hipStreamWaitEvent(dstream, ev_reg_done, 0));
@@ -695,6 +702,45 @@ class Pipeline {
       N.to_end = odom.to_end_params(l, true);
     }
   }
+  // Head of M(t+1) that does not depend on M(t): transformToEnd of the next step's full-resolution clouds (LaserOdometry.cpp:326) into
+  // the registrar's OTHER staging buffer, enqueued behind M(t)'s first Gauss-Newton launches while the host waits for them — as soon
+  // as the odometry of t+1 is known (it runs ahead).  step(t+1) then finds its clouds re-projected: one copy + one 12-25 us kernel less
+  // between two steps' registrations.  (The host waits for M(t) at an event recorded in front of this work: Registrar::run_iterations.)
+  int pre_t = -1;   // the step whose full-resolution clouds have been pre-staged
+  void prestage_gather(int tn, int last_staged, hipStream_t s_) {
+    static const bool off = getenv("LOAMX_NO_PRESTAGE") != nullptr;   // A/B
+    if (off || !prefetch || pre_t == tn || tn > last_staged || tn < 1) return;
+    const uint32_t ns = n_streams_;
+    if (eng) {
+      for (uint32_t e = 0; e < n_engines(); e++) if (E(e).done_upto() <= tn) return;
+      wait_odometry(tn);   // (done: integrates and copies the results, does not block)
+    } else if (done_min() < tn) {
+      return;
+    }
+    FeatureExtractor& F = FX((uint32_t)tn);
+    std::vector<const float4*> fsrc;
+    std::vector<uint32_t> nfr;
+    std::vector<ToEndParams> tep;
+    for (uint32_t s = 0; s < ns; s++) {
+      const OdomPub& N = ores[tn % 3][s];
+      if (N.rc != LOAMX_OK) continue;
+      fsrc.push_back(F.d_cloud() + F.point_base(s));
+      nfr.push_back(F.point_base(s + 1) - F.point_base(s));
+      tep.push_back(N.to_end);
+    }
+    const uint32_t nw = (uint32_t)fsrc.size();
+    if (!nw) return;
+    const int par = (int)(run_count & 1);   // the buffer the NEXT run uses: its last download (two runs ago) must have finished
+    hostlink.wait(par);
+    if (d2h_pending[par]) { LX_HIP(hipStreamWaitEvent(s_, ev_d2h[par], 0)); d2h_pending[par] = false; }
+    float4* dst = reg.stage_full_next(nw, nfr.data());
+    if (!dst) return;
+    std::vector<uint32_t> foff(nw + 1, 0);
+    for (uint32_t k = 0; k < nw; k++) foff[k + 1] = foff[k] + nfr[k];
+    (eng ? gather_util.get() : chains[0]->ob.get())->to_end_gather(dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
+    pre_t = tn;
+  }
+
   // Software pipeline over consecutive steps (the stages are separate ROS nodes in the reference, so nothing in a later
   // stage of step t feeds an earlier stage of step t+1):
   //   registration M(t) on the registrar's stream  ||  odometry O(t+1) on the odometry stream  ||  features F(t+2)
@@ -810,19 +856,23 @@ class Pipeline {
       if (nw) {
         // the full-resolution clouds are re-projected to the sweep end before they are registered (LaserOdometry.cpp:326):
         // one fused kernel writes them straight into the registrar's staging area
-        if (reg.double_buffer_full) {   // this run reuses the buffer of the run before last: its download must have finished
-          const int par = (int)(run_count & 1);
-          hostlink.wait(par);   // (two steps old: landed long ago)
-          if (d2h_pending[par]) { LX_HIP(hipStreamWaitEvent(s_, ev_d2h[par], 0)); d2h_pending[par] = false; }
-        }
-        float4* full_dst = reg.stage_full(nw, nfr.data());
         std::vector<uint32_t> foff(nw + 1, 0);
         for (uint32_t k = 0; k < nw; k++) foff[k + 1] = foff[k] + nfr[k];
+        const bool adopted = pre_t == ti && reg.adopt_full_next(nw, nfr.data());   // re-projected already, behind the previous step's first iterations
+        pre_t = -1;
+        if (!adopted) {
+          if (reg.double_buffer_full) {   // this run reuses the buffer of the run before last: its download must have finished
+            const int par = (int)(run_count & 1);
+            hostlink.wait(par);   // (two steps old: landed long ago)
+            if (d2h_pending[par]) { LX_HIP(hipStreamWaitEvent(s_, ev_d2h[par], 0)); d2h_pending[par] = false; }
+          }
+          float4* full_dst = reg.stage_full(nw, nfr.data());
+          (eng ? gather_util.get() : chains[0]->ob.get())->to_end_gather(full_dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
+        }
         last_full_off = foff;
         run_count++;
-        (eng ? gather_util.get() : chains[0]->ob.get())->to_end_gather(full_dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
         reg.upload_device(nw, cl.data(), ncl.data(), sl.data(), nsl.data(), nullptr, nullptr, guess.data());
-        reg.on_first_wait = launch_f2;
+        reg.on_first_wait = [&]() { launch_f2(); prestage_gather(ti + 1, last_staged, s_); };
         reg.run_async();
         reg.on_first_wait = nullptr;
         if (reg.double_buffer_full) {
@@ -833,6 +883,7 @@ class Pipeline {
         last_full_off.clear();
       }
       launch_f2();
+      if (nw) prestage_gather(ti + 1, last_staged, s_);   // (no-op when the first wait's callback did it)
       if (timing) {
         LX_HIP(hipEventRecord(tm.b, s_));
         tm.pending = true;

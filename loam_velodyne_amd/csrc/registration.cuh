@@ -208,6 +208,8 @@ class Registrar {
   // reserve the full-resolution staging area for the next upload_device() and return it: the caller fills
   // [full_offset(s), full_offset(s+1)) itself (e.g. with a fused re-projection kernel) and passes full_res = NULL
   float4* stage_full(uint32_t n_sweeps, const uint32_t* n_full);
+  float4* stage_full_next(uint32_t n_sweeps, const uint32_t* n_full);   // NULL: not possible now
+  bool adopt_full_next(uint32_t n_sweeps, const uint32_t* n_full);      // false: nothing (matching) was pre-staged
   // device-only: stack round trip + voxel DS + LM iterations (+ full-res registration)
   void run_async();
   void sync();
@@ -247,7 +249,9 @@ class Registrar {
   DevBuf<uint32_t> seg_off_, full_off_, ds_off_;
   DevBuf<float> guess_;
   DevBuf<const float4*> src_ptrs_;
-  bool full_staged_ = false;
+  bool full_staged_ = false, full_next_staged_ = false, results_final_ = false;
+  std::vector<uint32_t> next_full_off_;
+  hipEvent_t ev_look_ = nullptr;
   VoxelPipeline vox_;
   // the stack clouds' voxel grid normally takes the bucketed path (voxbucket.cuh); a run that gives up is repeated through the
   // general kernel as soon as the host has synchronised with it (LOAMX_VOX_LEGACY=1 forces the general kernel)

@@ -854,6 +854,8 @@ struct GnArgs {
   unsigned long long* dbg;   // LOAMX_PROF_GN: per workgroup of sweep 0: 8 wall-clock stamps
   int iter;
   float delta_t_abort, delta_r_abort;
+  const uint32_t* skip_word;   // a bucketed voxel stage that gave up (fail word == skip_value) left no valid query offsets: the launch does nothing
+  uint32_t skip_value;
 };
 
 constexpr int GN_TILE = LX_RES_THREADS / KNN_LPQ;   // queries per workgroup
@@ -965,6 +967,7 @@ Registrar::~Registrar() {
   for (auto& e : ev_) (void)hipEventDestroy(e);
   if (ev_build_) (void)hipEventDestroy(ev_build_);
   if (ev_swap_) (void)hipEventDestroy(ev_swap_);
+  if (ev_look_) (void)hipEventDestroy(ev_look_);
   if (st_build_) { (void)hipStreamSynchronize(st_build_); (void)hipStreamDestroy(st_build_); }
   if (st_) (void)hipStreamDestroy(st_);
 }
@@ -1098,6 +1101,7 @@ void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const 
 
 float4* Registrar::stage_full(uint32_t n_sweeps, const uint32_t* n_full) {
   LX_REQUIRE(n_sweeps >= 1 && n_sweeps <= max_sweeps_, "n_sweeps out of range for this handle");
+  full_next_staged_ = false;   // (a pre-staged buffer that was not adopted is simply dropped)
   h_full_off_.assign(n_sweeps + 1, 0);
   for (uint32_t s = 0; s < n_sweeps; s++) h_full_off_[s + 1] = h_full_off_[s] + n_full[s];
   n_full_ = h_full_off_[n_sweeps];
@@ -1108,6 +1112,31 @@ float4* Registrar::stage_full(uint32_t n_sweeps, const uint32_t* n_full) {
   full_.reserve((size_t)n_full_ + 1);
   full_staged_ = true;
   return full_.p;
+}
+
+// The staging area of the NEXT run while the current one is still in flight (the pipeline re-projects the next step's
+// full-resolution clouds into it behind the current step's first Gauss-Newton launches: that work does not depend on the
+// registration's poses).  Needs double_buffer_full.  adopt_full_next() makes it the current run's staging area.
+float4* Registrar::stage_full_next(uint32_t n_sweeps, const uint32_t* n_full) {
+  LX_REQUIRE(double_buffer_full, "internal: pre-staging needs the second full-resolution buffer");
+  LX_REQUIRE(n_sweeps >= 1 && n_sweeps <= max_sweeps_, "n_sweeps out of range for this handle");
+  next_full_off_.assign(n_sweeps + 1, 0);
+  for (uint32_t s = 0; s < n_sweeps; s++) next_full_off_[s + 1] = next_full_off_[s] + n_full[s];
+  if ((size_t)next_full_off_[n_sweeps] + 1 > full_alt_.cap) return nullptr;   // (growing would free a buffer a download may still read: the caller stages at the usual time)
+  full_next_staged_ = true;
+  return full_alt_.p;
+}
+bool Registrar::adopt_full_next(uint32_t n_sweeps, const uint32_t* n_full) {
+  if (!full_next_staged_ || next_full_off_.size() != n_sweeps + 1) { full_next_staged_ = false; return false; }
+  for (uint32_t s = 0; s < n_sweeps; s++)
+    if (next_full_off_[s + 1] - next_full_off_[s] != n_full[s]) { full_next_staged_ = false; return false; }
+  full_next_staged_ = false;
+  h_full_off_ = next_full_off_;
+  n_full_ = h_full_off_[n_sweeps];
+  std::swap(full_.p, full_alt_.p);
+  std::swap(full_.cap, full_alt_.cap);
+  full_staged_ = true;
+  return true;
 }
 
 void Registrar::upload_device(uint32_t n_sweeps, const float4* const* corner_last, const uint32_t* n_corner,
@@ -1214,6 +1243,8 @@ bool Registrar::run_iterations(bool trace, double& th2, double& th3) {
   a.nblk = nblk_; a.delta_t_abort = params.delta_t_abort; a.delta_r_abort = params.delta_r_abort;
   const dim3 grid(8 * ((nblk_ + 7) / 8 + 1), ns);
   a.dbg = nullptr;
+  a.skip_word = vb_unchecked_ ? vb_.d_fail_word() : nullptr;   // (offsets of a run that gave up part-way may be a mix)
+  a.skip_value = vb_.epoch();
 #ifdef LOAMX_PROF_GN
   static DevBuf<unsigned long long> dbg;
   dbg.reserve((size_t)nblk_ * 8 + 64);
@@ -1261,9 +1292,13 @@ bool Registrar::run_iterations(bool trace, double& th2, double& th3) {
     if (!spec_full && want_full) { enqueue_full(1); spec_full = true; }
     if (it >= maxit) break;
     if (trace && th2 == 0) th2 = host_us();
+    // the host waits for THIS point of the stream, not for the stream: the caller's on_first_wait may enqueue work of the next run
+    // behind it (the pipeline's pre-staged re-projection), which must not hold this run's results back
+    if (!ev_look_) LX_HIP(hipEventCreateWithFlags(&ev_look_, hipEventDisableTiming));
+    LX_HIP(hipEventRecord(ev_look_, st_));
     if (on_first_wait && !waited) { waited = true; on_first_wait(); on_first_wait = nullptr; }   // host work that overlaps the wait
     if (trace && th3 == 0) th3 = host_us();
-    LX_HIP(hipStreamSynchronize(st_));
+    LX_HIP(hipEventSynchronize(ev_look_));
     if (vb_unchecked_) {
       vb_unchecked_ = false;
       if (vb_.failed()) { note_bucket_give_up(); return true; }
@@ -1274,7 +1309,7 @@ bool Registrar::run_iterations(bool trace, double& th2, double& th3) {
       all_done = all_done && h_stats_.p[k].done;
       need = std::max(need, h_stats_.p[k].iterations);
     }
-    if (all_done) { pred_iters_ = need; mirrors_written_ = true; break; }   // poses / stats are final and on the host
+    if (all_done) { pred_iters_ = need; mirrors_written_ = true; results_final_ = spec_full || !want_full; break; }   // poses / stats are final and on the host (and the clouds registered by the speculative launch, which the event covers)
     pred_iters_ = it + 1;
     chunk = 1;
   }
@@ -1294,14 +1329,15 @@ void Registrar::run_async() {
   double th1 = 0, th2 = 0, th3 = 0;
   LX_HIP(hipSetDevice(device_));
   const uint32_t ns = n_sweeps_, nseg = 2 * ns, n = n_in_;
-  if (timing_) LX_HIP(hipEventRecord(ev_[0], st_));
-  n_res_launch_ = 0;
   const bool can_bucket = !vb_disabled_ && VoxBucket::fits(n, nseg);
   for (int attempt = 0; attempt < 2; attempt++) {
     const bool legacy = attempt == 1 || !can_bucket;
+    if (timing_) LX_HIP(hipEventRecord(ev_[0], st_));   // (per attempt: a run repeated through the general voxel kernel reports the attempt that counted — ADVICE.md round 3)
+    n_res_launch_ = 0;
     if (early_exit) memset(h_stats_.p, 0, sizeof(SweepStats) * ns);   // mirrors of sweeps that never reach an update stay "not done"
     vb_unchecked_ = !legacy && n > 0;
     full_enqueued_ = false;
+    results_final_ = false;
     enqueue_front(legacy);
     if (trace) th1 = host_us();
     mirrors_written_ = false;
@@ -1359,6 +1395,7 @@ void Registrar::finish_with_poses(const float* poses6) {
   hipLaunchKernelGGL(k_pose_set, dim3((ns + 63) / 64), dim3(64), 0, st_, guess_.p, ns, poses_.p);
   enqueue_full(0);
   mirrors_written_ = false;   // the device poses were replaced
+  results_final_ = false;     // ... and new device work was enqueued: the next fetch waits for the stream
   LX_HIP(hipGetLastError());
 }
 
@@ -1388,6 +1425,7 @@ void Registrar::sync() { LX_HIP(hipStreamSynchronize(st_)); }
 // final poses / statistics on the host: an early-exit run that saw every sweep converge already holds them (the update
 // step mirrors them into pinned memory), anything else is copied
 void Registrar::fetch_results() {
+  if (results_final_ && !vb_unchecked_) { vox_.check(); vb_.check(); return; }   // run_iterations saw everything complete at its event: no need to wait for what has been enqueued since
   LX_HIP(hipStreamSynchronize(st_));
   vox_.check();
   vb_.check();

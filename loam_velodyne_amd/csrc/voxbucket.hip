@@ -219,7 +219,11 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
   const uint32_t b = blockIdx.x;
   VB_TS(0);
   if (__hip_atomic_load(&A.ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.epoch) {   // given up: an empty, well-formed result
-    if (b == 0)
+    //  EVERY bucket publishes a count — a bucket that started before the give-up may be looking back at this one —
+    // and the offsets are zeroed by the first AND the last bucket: whichever buckets ran to the end before the fail word was raised
+    // may have written some, and the Gauss-Newton launches already enqueued behind this kernel read them
+    if (tid == 0) __hip_atomic_store(&A.heads[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b == 0 || b + 1u == A.nb)
       for (uint32_t s = (uint32_t)tid; s <= A.nseg; s += VB_THREADS) A.out_off[s] = 0u;
     return;
   }
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
   uint32_t tot;
   const uint32_t ex = block_excl_scan(nh, s_scan, tot);
   if (tid == 0) {
-    __threadfence();   // the box atomics above are visible before the count is
+    xchg_stores_done();   // the box atomics above (this wave's lanes 0-5) have been performed before the count is published; no cache-wide fence (dev_math.cuh)
     __hip_atomic_store(&A.heads[b], tot + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   uint32_t part = 0u;
@@ -435,7 +439,6 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
     if (b + 1u == A.nb) A.out_off[A.nseg] = base + tot;
   }
   if (b + 1u == A.nb) {   // the last bucket has seen every other bucket's count, hence every segment's final box: PCL's pass-through test
-    __threadfence();
     for (uint32_t s = (uint32_t)tid; s < A.nseg; s += VB_THREADS) {
       int bb[6];
 #pragma unroll

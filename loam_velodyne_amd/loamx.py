@@ -736,17 +736,23 @@ class Dist:
         return int(ev.value or 0)
 
     def allgather_results(self, poses6, iters_flags=None, batch=None):
-        """every rank's records in rank order; shards may be unequal (batch = total record count when known, else world x the
-        largest shard is reserved).  Returns (poses, flags, counts per rank)"""
+        """every rank's records in rank order; shards may be unequal, also empty.  batch = total record count when the caller knows
+        it; otherwise the counts are gathered first (loamx_dist_allgather_counts) and the receive arrays sized by them — a guess such as
+        world x (own count + 1) is too small as soon as shards differ by more than one.  The C call is told the
+        capacity either way and answers LOAMX_E_CAPACITY instead of writing beyond it.  Returns (poses, flags, counts per rank)"""
         p = np.ascontiguousarray(poses6, np.float32).reshape(-1, 6)
         n = len(p)
         f = np.ascontiguousarray(iters_flags, np.int32).reshape(n, 2) if iters_flags is not None else None
-        cap = int(batch) if batch is not None else self.world * (n + 1)
-        pa = np.zeros((cap, 6), np.float32)
-        fa = np.zeros((cap, 2), np.int32)
         cnt = np.zeros(self.world, np.uint32)
-        _check(lib().loamx_dist_allgather_results(self.h, p.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p) if f is not None else None,
-                                                  n, pa.ctypes.data_as(C.c_void_p), fa.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)))
+        if batch is None:
+            _check(lib().loamx_dist_allgather_counts(self.h, n, cnt.ctypes.data_as(C.c_void_p)))
+            cap = int(cnt.sum())
+        else:
+            cap = int(batch)
+        pa = np.zeros((max(cap, 1), 6), np.float32)
+        fa = np.zeros((max(cap, 1), 2), np.int32)
+        _check(lib().loamx_dist_allgather_results_cap(self.h, p.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p) if f is not None else None,
+                                                      n, pa.ctypes.data_as(C.c_void_p), fa.ctypes.data_as(C.c_void_p), cap, cnt.ctypes.data_as(C.c_void_p)))
         tot = int(cnt.sum())
         return pa[:tot], fa[:tot], cnt
 

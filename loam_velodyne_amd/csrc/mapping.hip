@@ -288,7 +288,8 @@ Mapper::Mapper(const loamx_map_config& c) : cfg(c), reg(c.device, 1) {
   for (int t = 0; t < 2; t++) {
     tm[t].vox.init(reg.stream());
     tm[t].counters.reserve(16);
-    tm[t].tile_sums.reserve(8192);
+    tm[t].tile_sums.reserve(SCAN_SCRATCH_WORDS);
+    LX_HIP(hipMemsetAsync(tm[t].tile_sums.p, 0, sizeof(uint32_t) * tm[t].tile_sums.cap, reg.stream()));
     tm[t].hist.reserve(MCUBES);
     tm[t].h_hist.reserve(MCUBES);
     tm[t].h_counters.reserve(16);
@@ -297,7 +298,8 @@ Mapper::Mapper(const loamx_map_config& c) : cfg(c), reg(c.device, 1) {
   sur_vox.init(reg.stream());
   sur_off.reserve(4);
   sur_cnt.reserve(16);
-  sur_tiles.reserve(8192);
+  sur_tiles.reserve(SCAN_SCRATCH_WORDS);
+  LX_HIP(hipMemsetAsync(sur_tiles.p, 0, sizeof(uint32_t) * sur_tiles.cap, reg.stream()));
 }
 
 // the reference's pointer-swap loops (:311-441) applied to the host count directory: contents move by one cube along

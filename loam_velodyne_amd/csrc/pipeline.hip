@@ -708,7 +708,7 @@ class Pipeline {
   // between two steps' registrations.  (The host waits for M(t) at an event recorded in front of this work: Registrar::run_iterations.)
   int pre_t = -1;   // the step whose full-resolution clouds have been pre-staged
   void prestage_gather(int tn, int last_staged, hipStream_t s_) {
-    static const bool off = getenv("LOAMX_NO_PRESTAGE") != nullptr;   // A/B
+    static const bool off = !(getenv("LOAMX_PRESTAGE") && atoi(getenv("LOAMX_PRESTAGE")) != 0);   // measured: no gain (15.44 k with, 15.51 k without; profiles/r04_ab.md) — the step is not bound by this copy + kernel; opt-in
     if (off || !prefetch || pre_t == tn || tn > last_staged || tn < 1) return;
     const uint32_t ns = n_streams_;
     if (eng) {

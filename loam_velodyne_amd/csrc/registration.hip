@@ -118,7 +118,8 @@ void SubMapIndex::init(hipStream_t st) {
   st_ = st;
   scratch_.reserve(16);
   d_desc_.reserve(1);
-  tile_sums_.reserve(8192);
+  tile_sums_.reserve(SCAN_SCRATCH_WORDS);
+  LX_HIP(hipMemsetAsync(tile_sums_.p, 0, sizeof(uint32_t) * tile_sums_.cap, st));
 }
 
 void SubMapIndex::swap(SubMapIndex& o) {
@@ -287,7 +288,8 @@ __global__ __launch_bounds__(256) void k_bb_scatter(const float4* __restrict__ p
 void SubMapIndexBatch::init(hipStream_t st) {
   st_ = st;
   scratch_.reserve(16);
-  tile_sums_.reserve(8192);
+  tile_sums_.reserve(SCAN_SCRATCH_WORDS);
+  LX_HIP(hipMemsetAsync(tile_sums_.p, 0, sizeof(uint32_t) * tile_sums_.cap, st));
 }
 
 // the bounding-box accumulators can be reset long before the points exist (e.g. ahead of the iterations whose result the
@@ -1425,10 +1427,11 @@ void Registrar::sync() { LX_HIP(hipStreamSynchronize(st_)); }
 // final poses / statistics on the host: an early-exit run that saw every sweep converge already holds them (the update
 // step mirrors them into pinned memory), anything else is copied
 void Registrar::fetch_results() {
-  if (results_final_ && !vb_unchecked_) { vox_.check(); vb_.check(); return; }   // run_iterations saw everything complete at its event: no need to wait for what has been enqueued since
+  if (results_final_ && !vb_unchecked_) { vox_.check(); vb_.check(); scan_check_errors(); return; }   // run_iterations saw everything complete at its event: no need to wait for what has been enqueued since
   LX_HIP(hipStreamSynchronize(st_));
   vox_.check();
   vb_.check();
+  scan_check_errors();
   redo_if_bucket_path_failed();
   if (!mirrors_written_) {
     LX_HIP(hipMemcpyAsync(h_poses_.p, poses_.p, sizeof(Pose) * n_sweeps_, hipMemcpyDeviceToHost, st_));

@@ -9,6 +9,9 @@ namespace loamx {
 
 constexpr int SCAN_TILE = 2048;
 constexpr uint32_t SCAN_MAX_N = 8192u * SCAN_TILE;
+// the scratch every scan call is handed ("tile_sums"): uint32 words, ZERO-FILLED ONCE by its owner — the one-launch scan keeps its
+// per-tile 64-bit words (epoch-tagged) in it, the three-launch scan its 8192 tile sums
+constexpr size_t SCAN_SCRATCH_WORDS = 2 * (8192 + 8);
 
 __device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
@@ -44,6 +47,22 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* lds /* >= 17 */
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, const uint32_t* d_n, uint32_t* d_total,
                         uint32_t max_n, hipStream_t st, uint32_t* out2 = nullptr,   // out2: optional second copy of the result
                         uint32_t* zero_in = nullptr);   // zero_in (= in, when in != out): the input is cleared behind the scan
+
+// ---- the same scan in ONE launch (round 4; the three-launch version above stays behind LOAMX_SCAN_3PASS=1 for A/B): chained tiles with a
+// decoupled look-back.  Tile b publishes its sum in a 64-bit word, walks back over the published sums / inclusive prefixes of the tiles
+// before it, publishes its own inclusive prefix and writes its slice.  The words carry the launch's epoch, so nothing is cleared between
+// launches; `state` (chained_scan_state_words() uint64 words) is zero-filled ONCE by its owner and may be shared by all scans of one HIP
+// stream.  Everything a tile needs from another one travels INSIDE those words: relaxed agent-scope atomics, no cache-wide fence
+// (dev_math.cuh "exchange").  Workgroups start in index order (as everywhere in this library where a workgroup waits for a
+// lower-numbered one); a predecessor that does not show up within ~1 s raises the process-wide error word (scan_check_errors()) instead
+// of hanging the device.  n_host != UINT32_MAX: the element count is this value and d_n is ignored (no k_scan_set_n launch).
+constexpr uint32_t CHAINED_SCAN_MAX_TILES = 8192;
+inline size_t chained_scan_state_words() { return (size_t)CHAINED_SCAN_MAX_TILES + 8; }
+void exclusive_scan_u32_chained(const uint32_t* in, uint32_t* out, unsigned long long* state, const uint32_t* d_n, uint32_t* d_total,
+                                uint32_t max_n, hipStream_t st, uint32_t* out2 = nullptr, uint32_t* zero_in = nullptr,
+                                uint32_t n_host = 0xffffffffu);
+void scan_check_errors();   // throws LOAMX_E_HIP when a chained scan gave up waiting (after a synchronisation point)
+bool scan_use_chained();    // !LOAMX_SCAN_3PASS
 
 // same with a host-known element count; scratch2 = two device words
 void exclusive_scan_u32_n(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, uint32_t* scratch2, uint32_t n, hipStream_t st);

@@ -325,7 +325,9 @@ int loamx_pipeline_stage_step(loamx_pipeline* h, uint32_t step, const loamx_clou
  * rules as loamx_pipeline_stage_step.  scan_time_sec[s] (may be NULL without IMU data) is the sweep's time stamp on the clock of
  * loamx_pipeline_update_imu, which feeds stream s's IMU history exactly as loamx_scanreg_update_imu does (updateIMUData,
  * BasicScanRegistration.cpp:82-98); the resulting imuTransform() of every sweep is plugged into that stream's odometry
- * (BasicLaserOdometry::updateIMU).  The mapping-side roll / pitch blend of transformUpdate is not part of the frozen-map pipeline. */
+ * (BasicLaserOdometry::updateIMU).  The same messages feed the stream's mapping-side history (LaserMapping's own subscription, 200
+ * deep): a sweep staged with a time stamp gets transformUpdate's roll / pitch blend (BasicLaserMapping.cpp:171-200) from the messages
+ * that had arrived when it was staged, before its full-resolution cloud is registered. */
 int loamx_pipeline_stage_step_raw(loamx_pipeline* h, uint32_t step, const void* const* raw_xyz, const uint32_t* counts, uint32_t stride,
                                   const loamx_multiscan_mapper* mapper, const double* scan_time_sec);
 int loamx_pipeline_update_imu(loamx_pipeline* h, uint32_t stream, double stamp_sec, float roll, float pitch, float yaw, const float acc_xyz[3]);

@@ -10,6 +10,7 @@
 #include "registration.cuh"
 #include "hostlink.cuh"
 #include <atomic>
+#include <deque>
 #include <functional>
 #include <chrono>
 #include <condition_variable>
@@ -39,7 +40,7 @@ struct PipeStreamState {
 class Pipeline {
  public:
   Pipeline(const loamx_scanreg_config& fc, const loamx_odom_config& oc, const loamx_map_config& mc, uint32_t n_streams)
-      : reg(mc.device, n_streams), fcfg(fc), n_streams_(n_streams), st(n_streams), imu(n_streams) {
+      : reg(mc.device, n_streams), fcfg(fc), n_streams_(n_streams), st(n_streams), imu(n_streams), map_imu(n_streams), map_imu_seq(n_streams, 0) {
     // The odometry of the streams runs as G independent chains ("groups"), each with its own OdometryBatch, HIP stream and host thread:
     // a stream whose sweep needs 25 iterations (BasicLaserOdometry.cpp:246 runs to maxIterations when the stop test at :613-620 never
     // fires) delays only its own group, and the two steps of look-ahead absorb it — with ONE chain every step paid the launch pairs of
@@ -161,11 +162,47 @@ class Pipeline {
     PinBuf<float> h_imu_f;
     std::vector<uint32_t> imu_H;
     std::vector<float> imu_trans;                // [stream][12], valid once finalized
+    std::vector<double> scan_time;               // [stream] the sweeps' time stamps (laserOdometryTime of the mapping-side blend); empty: none given
+    std::vector<uint64_t> map_imu_upto;          // [stream] mapping-side IMU messages that had arrived at staging time
     hipEvent_t ev_ingest = nullptr;
     uint32_t n_rings = 0;
   };
   RawSlot rawslot[RING];
   std::vector<ImuTracker> imu;                   // one IMU state machine per stream
+  // Mapping-side IMU history (LaserMapping's own /imu/data subscription: IMUState2 {stamp, roll, pitch}, 200 deep —
+  // BasicLaserMapping.cpp:602-605) per stream, for transformUpdate's roll / pitch blend (:171-200).  Messages are numbered: a sweep is
+  // blended with the messages that had arrived when it was STAGED (stage_step_raw), however far the staging runs ahead of its step.
+  struct MapImu { double stamp; float roll, pitch; uint64_t seq; };
+  std::vector<std::deque<MapImu>> map_imu;
+  std::vector<uint64_t> map_imu_seq;
+  std::mutex map_imu_mu;                         // (update_imu may come from the staging thread)
+  void map_imu_push(uint32_t s, double stamp, float roll, float pitch) {
+    std::lock_guard<std::mutex> lk(map_imu_mu);
+    if (map_imu[s].size() >= 200) map_imu[s].pop_front();
+    map_imu[s].push_back(MapImu{stamp, roll, pitch, map_imu_seq[s]++});
+  }
+  // the IMU part of transformUpdate (:173-200) for one stream's pose; false: no message had arrived when the sweep was staged
+  bool map_imu_blend(uint32_t s, uint64_t seq_limit, double odo_time, float scan_period, float* p6) {
+    std::lock_guard<std::mutex> lk(map_imu_mu);
+    const std::deque<MapImu>& Hq = map_imu[s];
+    size_t n = 0;
+    while (n < Hq.size() && Hq[n].seq < seq_limit) n++;
+    if (!n) return false;
+    size_t i = 0;
+    while (i < n - 1 && (odo_time - Hq[i].stamp) + scan_period > 0) i++;
+    float roll, pitch;
+    if (i == 0 || (odo_time - Hq[i].stamp) + scan_period > 0) {
+      roll = Hq[i].roll; pitch = Hq[i].pitch;   // scan time newer than the newest or older than the oldest IMU message
+    } else {
+      const float ratio = (float)(((Hq[i].stamp - odo_time) - scan_period) / (Hq[i].stamp - Hq[i - 1].stamp));
+      const float inv = 1 - ratio;
+      roll = Hq[i].roll * inv + Hq[i - 1].roll * ratio;
+      pitch = Hq[i].pitch * inv + Hq[i - 1].pitch * ratio;
+    }
+    p6[0] = (float)(0.998 * p6[0] + 0.002 * pitch);
+    p6[2] = (float)(0.998 * p6[2] + 0.002 * roll);
+    return true;
+  }
   RawBinner binner;
   FeatureExtractor& FX(uint32_t t) { return *fx[streaming ? t % RING : t]; }
   char& LA(uint32_t t) { return launched[streaming ? t % RING : t]; }
@@ -487,6 +524,11 @@ class Pipeline {
     R.h_last.reserve(ns);
     R.imu_H.assign(ns, 0);
     R.imu_trans.assign((size_t)12 * ns, 0.f);
+    if (scan_time) R.scan_time.assign(scan_time, scan_time + ns); else R.scan_time.clear();
+    {
+      std::lock_guard<std::mutex> lk(map_imu_mu);
+      R.map_imu_upto = map_imu_seq;
+    }
     if (!R.ev_ingest) LX_HIP(hipEventCreateWithFlags(&R.ev_ingest, hipEventDisableTiming));
     // IMU tables (one per stream with data), staged back to back
     size_t Htot = 0;
@@ -872,9 +914,25 @@ class Pipeline {
         last_full_off = foff;
         run_count++;
         reg.upload_device(nw, cl.data(), ncl.data(), sl.data(), nsl.data(), nullptr, nullptr, guess.data());
+        // transformUpdate's IMU blend (BasicLaserMapping.cpp:171-200) changes transformTobeMapped BEFORE the full-resolution cloud is
+        // registered (:235-240): a step with mapping-side IMU data for any of its streams registers its clouds after the blend
+        bool blend = false;
+        static const bool no_blend = getenv("LOAMX_NO_MAP_IMU_BLEND") != nullptr;   // (tests: what the poses would be without the blend)
+        if (!no_blend && streaming && rawslot[t % RING].raw && !rawslot[t % RING].scan_time.empty())
+          for (uint32_t k = 0; k < nw; k++) blend = blend || rawslot[t % RING].map_imu_upto[who[k]] > 0;
+        reg.defer_full = blend;
         reg.on_first_wait = [&]() { launch_f2(); prestage_gather(ti + 1, last_staged, s_); };
         reg.run_async();
         reg.on_first_wait = nullptr;
+        if (blend) {
+          std::vector<float> p6(6 * (size_t)nw);
+          reg.download(p6.data(), nullptr);
+          if (reg.submap_sufficient())   // (transformUpdate is only reached when the optimisation ran, :628-629)
+            for (uint32_t k = 0; k < nw; k++)
+              (void)map_imu_blend(who[k], rawslot[t % RING].map_imu_upto[who[k]], rawslot[t % RING].scan_time[who[k]], fcfg.scan_period, &p6[6 * (size_t)k]);
+          reg.finish_with_poses(p6.data());
+          reg.defer_full = false;
+        }
         if (reg.double_buffer_full) {
           if (!ev_reg_done) LX_HIP(hipEventCreateWithFlags(&ev_reg_done, hipEventDisableTiming));
           LX_HIP(hipEventRecord(ev_reg_done, s_));
@@ -1039,6 +1097,7 @@ int loamx_pipeline_update_imu(loamx_pipeline* h, uint32_t stream, double stamp_s
   return guard([&]() {
     LX_REQUIRE(h && acc_xyz && stream < h->p.n_streams_, "invalid argument");
     h->p.imu[stream].update(stamp_sec, roll, pitch, yaw, acc_xyz);
+    h->p.map_imu_push(stream, stamp_sec, roll, pitch);   // (the same topic feeds LaserMapping's history in the reference's node graph)
     return LOAMX_OK;
   });
 }

@@ -429,7 +429,9 @@ def test_raw_sweeps_into_the_pipeline_equal_binned_rings(orc, small_world, senso
 def test_raw_sweeps_with_imu_feeds(orc, small_world):
     """per-stream IMU feeds (loamx_pipeline_update_imu): stream 0 gets IMU messages, stream 1 none.  The de-skewed sweeps, the
     imuTransform plugged into the odometry and the registration follow the oracle chain (ScanRegistration with IMU ->
-    LaserOdometry.updateIMU -> frozen-map registration) within the pose bar; stream 1 is untouched by its neighbour's IMU."""
+    LaserOdometry.updateIMU -> frozen-map registration WITH transformUpdate's mapping-side roll / pitch blend,
+    BasicLaserMapping.cpp:171-200: the same messages feed LaserMapping's history on both sides) within the pose bar; stream 1 is
+    untouched by its neighbour's IMU."""
     T, ns = 6, 2
     raws, times, starts, imu_msgs = _raw_run(small_world, T, with_imu=True)
     cm, sm = small_world.make_map(60000)
@@ -448,10 +450,12 @@ def test_raw_sweeps_with_imu_feeds(orc, small_world):
     for m in imu_msgs:
         p.update_imu(0, *m)
         osr.update_imu(*m)
+        omp.update_imu(m[0], m[1], m[2])   # LaserMapping's own subscription to the same topic: IMUState2 {stamp, roll, pitch}
     for t in range(3):
         p.stage_step_raw(t, raws[t], "VLP-16", scan_times=times[t])
         q.stage_step_raw(t, raws[t], "VLP-16", scan_times=times[t])
     worst = 0.0
+    blended_any = False
     for t in range(T):
         p.step(t)
         q.step(t)
@@ -464,9 +468,12 @@ def test_raw_sweeps_with_imu_feeds(orc, small_world):
         ood.process()
         if t > 0:
             omp.set_transform("sum", ood.transform_sum)
-            pose = omp.register_frozen(ood.last_corner(), ood.last_surf(), omp.associate())
+            omp.set_time(times[t][0])          # laserOdometryTime of transformUpdate's blend (BasicLaserMapping.cpp:171-200)
+            guess = omp.associate()
+            pose = omp.register_frozen(ood.last_corner(), ood.last_surf(), guess)
             omp.set_transform("bef", ood.transform_sum)
             omp.set_transform("aft", pose)
+            blended_any = blended_any or bool(omp.stats()["optimized"])
         g0, g1, h1 = p.get(0), p.get(1), q.get(1)
         worst = max(worst, float(np.abs(g0[1] - ood.transform_sum).max()))
         assert np.abs(g0[1] - ood.transform_sum).max() < POSE_TOL, (t, g0[1], ood.transform_sum)
@@ -475,4 +482,22 @@ def test_raw_sweeps_with_imu_feeds(orc, small_world):
         for i in range(3):                                                         # the stream without IMU data is bit-identical
             assert np.array_equal(g1[i], h1[i]), (t, i)
     assert not np.array_equal(p.get(0)[1], q.get(0)[1])                            # ... and the IMU really acted on stream 0
+    assert blended_any   # (the mapping-side blend ran on the oracle's side: the mapped poses above include it)
+    # ... and the comparison can tell: the blend moves rot_x / rot_z by 0.2 % of (IMU angle - optimum) per sweep, a few 1e-6 rad here,
+    # so the blended run sits within 2e-6 of the oracle in the angles while a run with the blend switched off is visibly further away
+    import subprocess, sys, json
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_pipeline as tp; from loam_velodyne_amd import loamx, synth;"
+            "w = synth.World(half_extent=45.0); raws, times, starts, msgs = tp._raw_run(w, %d, with_imu=True); cm, sm = w.make_map(60000);"
+            "p = loamx.Pipeline(2); p.set_frozen(cm, sm); [p.set_state(s, aft=starts[s]) for s in range(2)]; [p.update_imu(0, *m) for m in msgs];"
+            "[p.stage_step_raw(t, raws[t], 'VLP-16', scan_times=times[t]) for t in range(3)];"
+            "[(p.step(t), (t + 3 < %d) and p.stage_step_raw(t + 3, raws[t + 3], 'VLP-16', scan_times=times[t + 3])) for t in range(%d)];"
+            "print(json.dumps([float(x) for x in p.get(0)[2]]))") % (ROOT, os.path.join(ROOT, "tests"), T, T, T)
+    env = dict(os.environ, LOAMX_NO_MAP_IMU_BLEND="1", PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    unblended = np.array(json.loads(out.stdout.strip().splitlines()[-1]), np.float32)
+    blended, truth = p.get(0)[2], omp.transform("aft")
+    assert np.abs(blended[[0, 2]] - truth[[0, 2]]).max() < 5e-7, (blended, truth)
+    assert np.abs(unblended[[0, 2]] - truth[[0, 2]]).max() > max(1e-6, 20 * np.abs(blended[[0, 2]] - truth[[0, 2]]).max()), (unblended, blended, truth)
     print("worst odometry difference vs the oracle chain with IMU:", worst)
+

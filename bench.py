@@ -97,7 +97,7 @@ def main():
     # K registrations but only K - LOOK odometry passes inside the timed region.  So LOOK more steps are staged than are run, and the
     # window closes only when the look-ahead has drained (loamx_pipeline_drain_lookahead): what was done ahead before the window opens
     # is done ahead, for the steps after it, before it closes — K passes of every stage inside, a steady-state window.
-    LOOK = 2
+    LOOK = int(os.environ.get("LOAMX_BENCH_LOOK", 6))   # = loamx_pipeline_lookahead_depth() of a staged batch (asserted when the pipeline exists)
     T_all = T + LOOK
     world_model = synth.World(half_extent=125.0)
 
@@ -190,6 +190,7 @@ def main():
                 p.set_state(k, aft=starts[h * per + k])
             p.upload([[sweeps[t][h * per + k] for k in range(per)] for t in range(T_all)])
             p.set_timing(True)
+            assert p.lookahead_depth() <= LOOK, "the window stages fewer steps beyond its last one than the look-ahead runs ahead"
             pipes.append(p)
         r = dict(stage=np.zeros(4), res_ms=0.0, res_launches=0, q_iters=0, queries=0, n_sampled=0, in_step=0.0, n_epochs=0, handles=H, per=per)
         racc = [dict(stage=np.zeros(4), res_ms=0.0, res_launches=0, q_iters=0, queries=0, n_sampled=0, in_step=0.0) for _ in range(H)]
@@ -212,6 +213,8 @@ def main():
                 p.step(t)
                 snapshot(h, t)
             p.drain_lookahead()
+
+        period = int(os.environ.get("LOAMX_BENCH_TIMING_PERIOD", TIMING_PERIOD))   # (diagnostic override: what the sampled steps cost)
 
         def timed(h):
             p, a = pipes[h], racc[h]
@@ -236,7 +239,7 @@ def main():
                         p.stage_frozen_device(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, ev)
                 # HIP-event timing (stage chains + a pair around every Gauss-Newton launch) on every 4th step only: the event pairs and
                 # their read-back (event synchronise, a statistics download) cost ~4 % of a step
-                sampled = (t - (1 + W)) % TIMING_PERIOD == 0
+                sampled = (t - (1 + W)) % period == 0
                 p.set_timing(sampled)
                 tc0 = time.perf_counter()
                 p.step(t)
@@ -424,6 +427,7 @@ def main():
                 "workload": f"{args.sensor} {synth.SENSORS[args.sensor][0]}x{synth.SENSORS[args.sensor][1]} sweeps ({n_points} pts), {M}-pt frozen sub-map, {ns} streams/GPU "
                             "(BASELINE configs[3]: batch 32 over 4 GPUs), full path per sweep",
                 "streams_per_gpu": ns,
+                "lookahead_depth": LOOK,
                 "handles_per_gpu": H,
                 "sweep_points": n_points,
                 "map_points": M,

@@ -351,13 +351,17 @@ int loamx_pipeline_get(loamx_pipeline* h, uint32_t stream, float* transform, flo
                        int* stats8);
 /* registered full-resolution cloud of the k-th stream that was registered in the last step */
 int loamx_pipeline_download_full_res(loamx_pipeline* h, uint32_t slot, loamx_cloud* out);
-/* Look-ahead (default on): while step t's registration runs, the odometry of step t+1 and the feature extraction of
- * step t+2 already execute on their own HIP streams (they are independent ROS nodes in the reference).  Results are
- * identical; loamx_pipeline_get() always reports the sweep that was registered last.  Turn it off when per-stream
- * state is changed with loamx_pipeline_set_state() between steps. */
+/* Look-ahead (default on): while step t's registration runs, the odometry and the feature extraction of the following staged
+ * steps already execute on their own HIP streams (they are independent ROS nodes in the reference) — up to
+ * loamx_pipeline_lookahead_depth() steps ahead.  Results are identical; loamx_pipeline_get() always reports the sweep that was
+ * registered last.  Turn it off when per-stream state is changed with loamx_pipeline_set_state() between steps. */
 int loamx_pipeline_set_lookahead(loamx_pipeline* h, int on);
-/* Blocks until the look-ahead has finished every step it is currently allowed to run ahead (odometry of up to two steps beyond the
- * last loamx_pipeline_step, their feature extraction) and everything of it is enqueued on the device; *last_odometry_step (may be NULL)
+/* How many steps beyond the one being registered the odometry may run: 0 with the look-ahead off, 6 for batches staged with
+ * loamx_pipeline_upload (a stream whose sweeps need every odometry iteration needs them for several sweeps in a row; the lead absorbs
+ * such a run), 2 for the streaming ring (loamx_pipeline_stage_step*: four slots). */
+int loamx_pipeline_lookahead_depth(loamx_pipeline* h);
+/* Blocks until the look-ahead has finished every step it is currently allowed to run ahead (odometry of up to
+ * loamx_pipeline_lookahead_depth() steps beyond the last loamx_pipeline_step, their feature extraction) and everything of it is enqueued on the device; *last_odometry_step (may be NULL)
  * receives the last step whose odometry is complete.  For a caller that wants a quiescent pipeline — a benchmark window that must
  * contain the look-ahead work it profits from, a clean shutdown point — without switching the look-ahead off. */
 int loamx_pipeline_drain_lookahead(loamx_pipeline* h, int* last_odometry_step);

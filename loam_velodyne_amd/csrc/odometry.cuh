@@ -93,6 +93,8 @@ class OdometryBatch {
   // defer_tail: return once the poses are known; the re-projected clouds / their index are ready at tail_event()
   void process(const OdomInput* in, int* rc, bool defer_tail = false);
   hipEvent_t tail_event() const { return tail_pending_ ? ev_tail_ : nullptr; }
+  // how many further process() calls the handed-on clouds (d_last_corner / d_last_surf) survive: 2 by default, up to MAX_KEEP
+  void set_keep(int n) { keep_ = n < 2 ? 2 : (n > MAX_KEEP ? MAX_KEEP : n); }
   // host-cloud convenience (single-stream handles)
   int process_host(const loamx_cloud* sharp, const loamx_cloud* less_sharp, const loamx_cloud* flat, const loamx_cloud* less_flat);
   int get_last_clouds(uint32_t s, loamx_cloud* corner, loamx_cloud* surf);
@@ -113,7 +115,10 @@ class OdometryBatch {
   bool own_stream_ = false;
   std::vector<OdomStream*> streams_;
   // clouds of all streams, concatenated: [corner_0 .. corner_{ns-1} | surf_0 .. surf_{ns-1}], offsets 2*ns+1
-  DevBuf<float4> cur_, last_, prev_;   // being written | handed on by the last call | handed on by the call before (still read by its consumer)
+  DevBuf<float4> cur_, last_;          // being written | handed on by the last call
+  static constexpr int MAX_KEEP = 16;
+  DevBuf<float4> older_[MAX_KEEP - 1];  // handed on by the calls before (still read by their consumers): older_[0] the most recent
+  int keep_ = 2;                       // clouds handed on stay valid during the next keep_ calls (set_keep)
   std::vector<uint32_t> h_cur_off_, h_last_off_;
   SubMapIndexBatch index_;
   DevBuf<int> ind_;

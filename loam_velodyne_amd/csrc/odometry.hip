@@ -1254,12 +1254,14 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
     hipLaunchKernelGGL(k_transform_to_end_batch, dim3((n_all + 255) / 256), dim3(256), 0, st_, cur_.p, n_all, d_cur_off_.p, K, ns, te_.p, src_c,
                        src_s, n_corner_all, fuse_bounds ? index_.d_bounds() : nullptr, rf_.p, rf_epoch_);
   }
-  // three rotating buffers: the clouds this call hands on stay untouched during the next two calls (a registration reads them
-  // while the odometry chain is already one or two sweeps ahead — Pipeline)
+  // rotating buffers: the clouds this call hands on stay untouched during the next keep_ calls (a registration reads them while the
+  // odometry chain is already that many sweeps ahead — Pipeline)
   {
     float4* p = cur_.p; size_t c = cur_.cap;
-    cur_.p = prev_.p; cur_.cap = prev_.cap;
-    prev_.p = last_.p; prev_.cap = last_.cap;
+    DevBuf<float4>& oldest = older_[keep_ - 2];
+    cur_.p = oldest.p; cur_.cap = oldest.cap;
+    for (int k = keep_ - 2; k > 0; k--) { older_[k].p = older_[k - 1].p; older_[k].cap = older_[k - 1].cap; }
+    older_[0].p = last_.p; older_[0].cap = last_.cap;
     last_.p = p; last_.cap = c;
   }
   h_last_off_ = h_cur_off_;

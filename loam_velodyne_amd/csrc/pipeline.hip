@@ -92,11 +92,14 @@ class Pipeline {
     reg.params.delta_r_abort = mc.delta_r_abort;
     reg.params.corner_leaf = mc.corner_filter_size;
     reg.params.surf_leaf = mc.surf_filter_size;
-    for (auto& c : chains) c->ob->params = op;
+    for (auto& c : chains) { c->ob->params = op; c->ob->set_keep(OR - 2); }
     device = mc.device;
     if (getenv("LOAMX_NO_LOOKAHEAD")) prefetch = false;   // debugging / profiling: run the stages one after the other
   }
   Registrar reg;
+  // Look-ahead rings: what a look-ahead step leaves behind for its registration (feature offsets, odometry results, events, timers)
+  // lives in slot step % OR, so the odometry may run up to OR - 2 steps ahead of the registration (ahead_depth below)
+  static constexpr int OR = 16;
   // one odometry chain: the streams [s0, s1), their batch object (own HIP stream), the host thread that drives it and its position
   struct OdomChain {
     uint32_t s0 = 0, s1 = 0;
@@ -105,9 +108,9 @@ class Pipeline {
     std::atomic<int> done{-1};           // odometry of steps <= done is complete and published
     std::atomic<int> next{0};            // next step of this chain (its worker; the calling thread only while the workers are parked)
     std::atomic<bool> busy{false};
-    hipEvent_t ev_tail[3] = {nullptr, nullptr, nullptr};   // recorded behind O(k)'s tail (re-projection + index build) on the chain's stream
-    hipEvent_t tm_a[3] = {nullptr, nullptr, nullptr}, tm_b[3] = {nullptr, nullptr, nullptr};   // chain timer of step k % 3 (this thread's own)
-    bool tm_pending[3] = {false, false, false};
+    hipEvent_t ev_tail[OR] = {};   // recorded behind O(k)'s tail (re-projection + index build) on the chain's stream
+    hipEvent_t tm_a[OR] = {}, tm_b[OR] = {};   // chain timer of step k % OR (this thread's own)
+    bool tm_pending[OR] = {};
     std::atomic<float> ms{0.f};          // length of the chain's most recent timed pass on its HIP stream
     double tr[4] = {0, 0, 0, 0};
   };
@@ -212,8 +215,8 @@ class Pipeline {
   hipStream_t fstream = nullptr;
   bool prefetch = true;
   std::vector<char> launched;
-  PinBuf<uint32_t> h_off3[3];
-  hipEvent_t evF[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  PinBuf<uint32_t> h_off3[OR];
+  hipEvent_t evF[OR][2] = {};
   // stage timers are read lazily (an elapsed time is taken once both events have completed) so that measuring never
   // makes the host wait for a stage
   struct LazyTimer {
@@ -227,21 +230,27 @@ class Pipeline {
     void destroy() { if (a) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); a = b = nullptr; } }
   };
   LazyTimer tmM[2];   // registration: by step parity (the odometry chains keep their own timers, OdomChain)
-  float feat_ms[3] = {0, 0, 0};
+  float feat_ms[OR] = {};
   int f_hi = -1;                       // features of steps <= f_hi have been launched (calling thread)
-  int ahead_depth = getenv("LOAMX_ODOM_AHEAD") ? atoi(getenv("LOAMX_ODOM_AHEAD")) : 2;   // steps the odometry chains may run ahead of the registration (diagnostic: 1)
+  // Steps the odometry chains may run ahead of the registration.  A stream that needs all 25 iterations needs them for five or six
+  // sweeps in a row (a chain then takes ~570 us per step against the registration's ~430): on average the chains keep up, and a deeper
+  // look-ahead lets them build the lead that such a run eats (depth 2: 15.6 k sweeps/s, 4: 16.6 k, 6: 16.9 k, 8 - 12: 16.4 - 16.6 k;
+  // profiles/r04_ab.md).  Staged batches (upload) only: the streaming
+  // ring holds RING = 4 slots, i.e. two steps of look-ahead; the engine keeps a result ring of its own (two steps as well).
+  int ahead_depth = std::max(1, std::min(getenv("LOAMX_ODOM_AHEAD") ? atoi(getenv("LOAMX_ODOM_AHEAD")) : 6, OR - 2));
+  int depth() const { return !prefetch ? 0 : ((streaming || eng) ? std::min(ahead_depth, 2) : ahead_depth); }
   float last_ms[4] = {0, 0, 0, 0};
   std::atomic<bool> timing{false};
 
   // The odometry chains run on persistent host threads of their own and AHEAD of the registration: odometry O(k) of a stream only
   // depends on its O(k-1) and on the features F(k), never on a registration (separate ROS nodes in the reference) and never on another
-  // stream, so a chain goes on to O(k+1) as soon as its O(k) is done, up to two steps ahead of the step being registered —
+  // stream, so a chain goes on to O(k+1) as soon as its O(k) is done, up to depth() steps ahead of the step being registered —
   // registration and odometry are serial chains across steps and the slowest sets the pace, not their sum.  The calling thread launches
   // the features (the only thread that does) and raises o_limit; every chain publishes its own `done`.  Results wait in a ring of
-  // three slots, the re-projected clouds in three rotating buffers (OdometryBatch), so step k's inputs stay valid while O(k+1), O(k+2)
-  // run.  Hand-overs happen every ~0.4 ms, so both sides spin briefly before they fall back to the condition variable (a sleeping
-  // thread costs tens of microseconds to wake, on the critical path of every step).
-  std::vector<OdomPub> ores[3];        // [step % 3][stream]; a chain writes its own streams only
+  // OR slots, the re-projected clouds in rotating buffers (OdometryBatch::set_keep), so step k's inputs stay valid while O(k+1) ...
+  // O(k+depth) run.  Hand-overs happen every ~0.4 ms, so both sides spin briefly before they fall back to the condition variable (a
+  // sleeping thread costs tens of microseconds to wake, on the critical path of every step).
+  std::vector<OdomPub> ores[OR];       // [step % OR][stream]; a chain writes its own streams only
   std::mutex mu;
   std::condition_variable cv;
   std::atomic<int> o_limit{-1};        // the chains may run steps <= o_limit (raised by the calling thread only)
@@ -304,7 +313,7 @@ class Pipeline {
         uint32_t e = 0;
         while (s >= eng_s0[e + 1]) e++;
         const OdomStepResult& R = E(e).result((uint32_t)t, s - eng_s0[e]);
-        OdomPub& N = ores[t % 3][s];
+        OdomPub& N = ores[t % OR][s];
         N.transform = R.transform; N.transform_sum = R.transform_sum; N.stats = R.stats; N.rc = R.rc;
         N.last_corner = R.last_corner; N.n_last_corner = R.n_last_corner; N.last_surf = R.last_surf; N.n_last_surf = R.n_last_surf;
         N.to_end = R.to_end;
@@ -399,16 +408,16 @@ class Pipeline {
     FeatureExtractor& F = FX(t);
     const uint32_t ns = n_streams_, nring = F.total_rings();
     if (streaming) LX_HIP(hipStreamWaitEvent(fstream, ev_stage[t % RING], 0));   // this slot's H2D copies
-    PinBuf<uint32_t>& hb = h_off3[t % 3];
+    PinBuf<uint32_t>& hb = h_off3[t % OR];
     hb.reserve(3 * (ns + 1) + nring + 2);
     uint32_t* ho[3] = {hb.p, hb.p + (ns + 1), hb.p + 2 * (ns + 1)};
     uint32_t* hlf = hb.p + 3 * (ns + 1);
-    for (auto& e : evF[t % 3]) if (!e) LX_HIP(hipEventCreate(&e));
-    LX_HIP(hipEventRecord(evF[t % 3][0], fstream));
+    for (auto& e : evF[t % OR]) if (!e) LX_HIP(hipEventCreate(&e));
+    LX_HIP(hipEventRecord(evF[t % OR][0], fstream));
     F.run_async();
     for (int k = 0; k < 3; k++) LX_HIP(hipMemcpyAsync(ho[k], F.d_feat_off(k), sizeof(uint32_t) * (ns + 1), hipMemcpyDeviceToHost, fstream));
     LX_HIP(hipMemcpyAsync(hlf, F.d_less_flat_ring_off(), sizeof(uint32_t) * (nring + 1), hipMemcpyDeviceToHost, fstream));
-    LX_HIP(hipEventRecord(evF[t % 3][1], fstream));
+    LX_HIP(hipEventRecord(evF[t % OR][1], fstream));
     LA(t) = 1;
   }
 
@@ -669,13 +678,13 @@ class Pipeline {
   // features have been launched AND extracted
   bool fetch_odom_inputs(uint32_t t, uint32_t s0, uint32_t s1, OdomInput* in, float* imu, bool& has_imu) {
     if ((int)t > f_pub.load(std::memory_order_acquire)) return false;
-    if (hipEventQuery(evF[t % 3][1]) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipEventQuery(evF[t % OR][1]) != hipSuccess) { (void)hipGetLastError(); return false; }
     const uint32_t ns = n_streams_;
     FeatureExtractor& F = FX(t);
-    uint32_t* hb = h_off3[t % 3].p;
+    uint32_t* hb = h_off3[t % OR].p;
     uint32_t* ho[3] = {hb, hb + (ns + 1), hb + 2 * (ns + 1)};
     uint32_t* hlf = hb + 3 * (ns + 1);
-    if (s0 == 0 && timing.load(std::memory_order_relaxed)) (void)hipEventElapsedTime(&feat_ms[t % 3], evF[t % 3][0], evF[t % 3][1]);
+    if (s0 == 0 && timing.load(std::memory_order_relaxed)) (void)hipEventElapsedTime(&feat_ms[t % OR], evF[t % OR][0], evF[t % OR][1]);
     for (uint32_t s = s0; s < s1; s++) {
       const uint32_t la = hlf[F.ring_base(s)], lb = hlf[F.ring_base(s + 1)];
       in[s - s0] = OdomInput{F.d_feat(0) + ho[0][s], ho[0][s + 1] - ho[0][s], F.d_feat(1) + ho[1][s], ho[1][s + 1] - ho[1][s],
@@ -688,19 +697,19 @@ class Pipeline {
   void publish_features_upto(int k) { if (k > f_pub.load(std::memory_order_relaxed)) f_pub.store(k, std::memory_order_release); }
 
   // odometry of staged step t for the streams of one chain (needs the step's features, launched by the calling thread); results go to
-  // ores[t % 3]
+  // ores[t % OR]
   void run_odometry(OdomChain& c, uint32_t t) {
     const uint32_t ns = n_streams_, ng = c.s1 - c.s0;
     FeatureExtractor& F = FX(t);
     LX_REQUIRE(LA(t), "internal: odometry of a step whose features were not launched");
     OdometryBatch& odom = *c.ob;
-    uint32_t* hb = h_off3[t % 3].p;
+    uint32_t* hb = h_off3[t % OR].p;
     uint32_t* ho[3] = {hb, hb + (ns + 1), hb + 2 * (ns + 1)};
     uint32_t* hlf = hb + 3 * (ns + 1);
-    LX_HIP(hipEventSynchronize(evF[t % 3][1]));
+    LX_HIP(hipEventSynchronize(evF[t % OR][1]));
     c.tr[1] = tr_us();
     const bool timed = timing.load(std::memory_order_relaxed);   // latched: the caller flips the flag while this chain runs steps ahead
-    if (timed && c.s0 == 0) LX_HIP(hipEventElapsedTime(&feat_ms[t % 3], evF[t % 3][0], evF[t % 3][1]));
+    if (timed && c.s0 == 0) LX_HIP(hipEventElapsedTime(&feat_ms[t % OR], evF[t % OR][0], evF[t % OR][1]));
     std::vector<OdomInput> in(ng);
     std::vector<int> rc(ng, 0);
     for (uint32_t s = c.s0; s < c.s1; s++) {
@@ -708,7 +717,7 @@ class Pipeline {
       in[s - c.s0] = OdomInput{F.d_feat(0) + ho[0][s], ho[0][s + 1] - ho[0][s], F.d_feat(1) + ho[1][s], ho[1][s + 1] - ho[1][s],
                                F.d_feat(2) + ho[2][s], ho[2][s + 1] - ho[2][s], F.d_less_flat() + la, lb - la};
     }
-    const int slot = (int)(t % 3);
+    const int slot = (int)(t % OR);
     if (timed) {   // this chain's own event pair for this step: both ends are recorded by this thread in this call
       if (!c.tm_a[slot]) { LX_HIP(hipEventCreate(&c.tm_a[slot])); LX_HIP(hipEventCreate(&c.tm_b[slot])); }
       c.tm_pending[slot] = false;
@@ -724,7 +733,7 @@ class Pipeline {
       LX_HIP(hipEventRecord(c.tm_b[slot], odom.stream()));
       c.tm_pending[slot] = true;
     }
-    for (int k = 0; k < 3; k++)   // (the elapsed time of an older step is taken once its events have completed: measuring never waits)
+    for (int k = 0; k < OR; k++)   // (the elapsed time of an older step is taken once its events have completed: measuring never waits)
       if (c.tm_pending[k] && hipEventQuery(c.tm_b[k]) == hipSuccess) {
         float ms = 0.f;
         LX_HIP(hipEventElapsedTime(&ms, c.tm_a[k], c.tm_b[k]));
@@ -764,7 +773,7 @@ class Pipeline {
     std::vector<uint32_t> nfr;
     std::vector<ToEndParams> tep;
     for (uint32_t s = 0; s < ns; s++) {
-      const OdomPub& N = ores[tn % 3][s];
+      const OdomPub& N = ores[tn % OR][s];
       if (N.rc != LOAMX_OK) continue;
       fsrc.push_back(F.d_cloud() + F.point_base(s));
       nfr.push_back(F.point_base(s + 1) - F.point_base(s));
@@ -819,7 +828,7 @@ class Pipeline {
         park_odometry(ti);
         f_hi = ti - 1;
       }
-      LX_REQUIRE(ti + 2 >= done_max(), "this step's odometry results have been overwritten: steps run in order");
+      LX_REQUIRE(ti + (OR - 2) >= done_max(), "this step's odometry results have been overwritten: steps run in order");
     }
     auto launch_upto = [&](int k) {   // features of the steps up to k (launched by this thread only, in step order)
       if (k > last_staged) k = last_staged;
@@ -849,21 +858,24 @@ class Pipeline {
       }
     }
     LA(t) = 0;   // every chain has consumed the step's features (a restart at this step extracts them again: their offsets' slot is reused by step t + 3)
-    for (uint32_t s = 0; s < ns; s++) st[s].cur = ores[t % 3][s];
+    for (uint32_t s = 0; s < ns; s++) st[s].cur = ores[t % OR][s];
     FeatureExtractor& F = FX(t);
-    const float f_ms = feat_ms[t % 3];
+    const float f_ms = feat_ms[t % OR];
     // the re-projected "last" clouds of THIS sweep are produced at the tails of the odometry chains
     for (uint32_t e = 0; e < n_engines(); e++) if (hipEvent_t ev = E(e).tail_event(t)) LX_HIP(hipStreamWaitEvent(s_, ev, 0));
-    for (auto& c : chains) LX_HIP(hipStreamWaitEvent(s_, c->ev_tail[t % 3], 0));
+    for (auto& c : chains) LX_HIP(hipStreamWaitEvent(s_, c->ev_tail[t % OR], 0));
     // ---- look-ahead while M(t) runs: the odometry chain may go on to step t+1 now and — once M(t) is enqueued and the features
     // of step t+2 are launched (while this thread waits for M(t)'s first look at the flags) — to step t+2
+    // (D steps of odometry look-ahead, FD >= 2 of features: in steady state the first two calls find nothing to do — the previous
+    // step's launch_f2 went that far — and the one new step of features / odometry is released by launch_f2, off M(t)'s critical path)
+    const int D = depth(), FD = std::max(D, 2);
     if (prefetch) {
-      launch_upto(ti + 1);
-      allow_odometry(std::min(ti + 1, last_staged));
+      launch_upto(ti + FD - 1);
+      allow_odometry(std::min(ti + std::min(D, FD - 1), last_staged));
     }
     bool f2_pending = prefetch && ti + 2 <= last_staged;
     auto launch_f2 = [&]() {
-      if (f2_pending) { f2_pending = false; launch_upto(ti + 2); if (ahead_depth >= 2) allow_odometry(ti + 2); }
+      if (f2_pending) { f2_pending = false; launch_upto(ti + FD); if (D >= 2) allow_odometry(std::min(ti + D, last_staged)); }
     };
     int ret = LOAMX_SKIPPED;
     try {
@@ -1172,6 +1184,7 @@ int loamx_pipeline_get_timing(loamx_pipeline* h, float stage_ms[4], float reg_ms
     return LOAMX_OK;
   });
 }
+int loamx_pipeline_lookahead_depth(loamx_pipeline* h) { return h ? h->p.depth() : 0; }
 void* loamx_pipeline_stream(loamx_pipeline* h) { return h ? (void*)h->p.reg.stream() : nullptr; }
 
 }  // extern "C"

@@ -168,6 +168,15 @@ struct SweepStats {
   int iterations, sel, corner_q, surf_q, degenerate, done, pad0, pad1;
 };
 
+// check word of the pinned (pose, statistics) mirror of one sweep: the host polls `done` while the kernel may still be
+// storing, and takes the pair only when the word it finds matches the words it read (SweepStats::pad1 of the mirror)
+__host__ __device__ inline int mirror_check_word(const SweepStats& st, const Pose& T) {
+  const unsigned* w = reinterpret_cast<const unsigned*>(&T);
+  unsigned x = 0x5bd1e995u ^ (unsigned)st.iterations ^ ((unsigned)st.sel << 8) ^ ((unsigned)st.degenerate << 30);
+  for (int i = 0; i < (int)(sizeof(Pose) / 4); i++) x = (x << 5 | x >> 27) ^ w[i];
+  return (int)x;
+}
+
 struct RegParams {
   int max_iterations = 10;
   float delta_t_abort = 0.05f, delta_r_abort = 0.05f;
@@ -268,6 +277,7 @@ class Registrar {
   uint32_t n_in_ = 0, n_full_ = 0, max_q_per_sweep_ = 0;
   bool mirrors_written_ = false;      // h_poses_ / h_stats_ hold (after a stream sync) this run's final values
   bool run_iterations(bool trace, double& th2, double& th3);   // true: the bucketed voxel path gave up, run again
+  bool wait_for_mirrors();
   void fetch_results();
   int pred_iters_ = 4;        // early_exit: iterations to enqueue before the first look at the done flags
 

@@ -13,6 +13,7 @@
 // HBM-bound gather work: no MFMA (the only dense contraction is 6x6).  Points are packed float4 so a neighbour is one
 // 16-byte load; queries are processed in voxel order, so the lanes of a wave walk the same few grid cells.
 #include "registration.cuh"
+#include <atomic>
 #include <chrono>
 #include "scan.cuh"
 #include "voxel.cuh"
@@ -542,6 +543,19 @@ __device__ unsigned long long g_solve_ts[16];
 #else
 #define SOLVE_TS(k) do { } while (0)
 #endif
+// pose and statistics of one sweep into the pinned mirrors, the `done` flag last (behind the other stores) and a check
+// word over what the host is about to read: Registrar::run_iterations polls these while later launches are still in flight
+__device__ __forceinline__ void mirror_to_host(SweepStats* hs, Pose* hp, const SweepStats& st, const Pose& T) {
+  SweepStats m = st;
+  m.done = 0;
+  m.pad1 = mirror_check_word(st, T);
+  *hp = T;
+  *hs = m;
+  if (!st.done) return;
+  xchg_stores_done();
+  __hip_atomic_store(&hs->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ void solve_sweep(uint32_t s, const uint32_t* __restrict__ ds_off, Pose* __restrict__ poses, SweepStats* __restrict__ stats,
                                    float* __restrict__ matP, const double* partials, uint32_t nblk, uint32_t nact, int iter,
                                    float delta_t_abort, float delta_r_abort, SweepStats* host_stats, Pose* host_poses) {
@@ -607,7 +621,7 @@ __device__ __forceinline__ void solve_sweep(uint32_t s, const uint32_t* __restri
       st.corner_q = (int)(ds_off[2 * s + 1] - ds_off[2 * s]);
       st.surf_q = (int)(ds_off[2 * s + 2] - ds_off[2 * s + 1]);
       stats[s] = st;
-      if (host_stats) { host_stats[s] = st; host_poses[s] = sP; }
+      if (host_stats) mirror_to_host(host_stats + s, host_poses + s, st, sP);
     }
     return;
   }
@@ -654,9 +668,9 @@ __device__ __forceinline__ void solve_sweep(uint32_t s, const uint32_t* __restri
   const float deltaT = (float)sqrt((double)t0 * t0 + (double)t1 * t1 + (double)t2 * t2);
   if (deltaR < delta_r_abort && deltaT < delta_t_abort) st.done = 1;
   stats[s] = st;
-  // mirror in host-visible (pinned, mapped) memory: a blocking caller reads flags and poses after a stream sync, without
-  // two more copies on the stream
-  if (host_stats) { host_stats[s] = st; host_poses[s] = T; }
+  // mirror in host-visible (pinned, mapped) memory: a blocking caller polls the flags and reads the poses without a
+  // stream sync and without two more copies on the stream
+  if (host_stats) mirror_to_host(host_stats + s, host_poses + s, st, T);
   SOLVE_TS(6);
 }
 
@@ -1232,6 +1246,37 @@ void Registrar::enqueue_front(bool legacy) {
 // of the chain ~90) together with the registration of the full-resolution clouds of the sweeps that converge within them, looks
 // at the flags (mirrored into pinned memory by the update step), and only goes on launching while some sweep is not done.
 // Returns true when the host, at its first look, finds that the bucketed voxel stage gave up: the caller runs again.
+// Blocks until every sweep's mirror says "done" (polled: the flags are written by the update step of the launch that
+// converged, ahead of the launches enqueued behind it) or until the stream reaches ev_look_.  Returns true when the flags
+// ended the wait.  A mirror counts only when its check word matches the pose / statistics words read after the flag.
+bool Registrar::wait_for_mirrors() {
+  const bool no_poll = getenv("LOAMX_NO_MIRROR_POLL") != nullptr;   // (diagnostic; read per call so that bench.py --ab can toggle it)
+  if (no_poll) { LX_HIP(hipEventSynchronize(ev_look_)); return false; }
+  const uint32_t ns = n_sweeps_;
+  const volatile SweepStats* hs = h_stats_.p;
+  for (unsigned spin = 0;; spin++) {
+    bool all = true;
+    for (uint32_t k = 0; k < ns && all; k++) all = hs[k].done != 0;
+    if (all) {
+      std::atomic_thread_fence(std::memory_order_acquire);
+      for (uint32_t k = 0; k < ns && all; k++) {
+        SweepStats st;
+        Pose T;
+        memcpy(&st, (const void*)&h_stats_.p[k], sizeof(st));
+        memcpy(&T, (const void*)&h_poses_.p[k], sizeof(T));
+        all = st.pad1 == mirror_check_word(st, T);
+      }
+      if (all) return true;
+    }
+    if ((spin & 15) == 15) {
+      const hipError_t q = hipEventQuery(ev_look_);
+      if (q == hipSuccess) return false;
+      if (q != hipErrorNotReady) LX_HIP(q);
+    }
+    __builtin_ia32_pause();
+  }
+}
+
 bool Registrar::run_iterations(bool trace, double& th2, double& th3) {
   TraceRange trace_range("loamx:registration:gauss-newton");
   const uint32_t ns = n_sweeps_;
@@ -1300,7 +1345,7 @@ bool Registrar::run_iterations(bool trace, double& th2, double& th3) {
     LX_HIP(hipEventRecord(ev_look_, st_));
     if (on_first_wait && !waited) { waited = true; on_first_wait(); on_first_wait = nullptr; }   // host work that overlaps the wait
     if (trace && th3 == 0) th3 = host_us();
-    LX_HIP(hipEventSynchronize(ev_look_));
+    const bool polled = wait_for_mirrors();
     if (vb_unchecked_) {
       vb_unchecked_ = false;
       if (vb_.failed()) { note_bucket_give_up(); return true; }
@@ -1311,7 +1356,9 @@ bool Registrar::run_iterations(bool trace, double& th2, double& th3) {
       all_done = all_done && h_stats_.p[k].done;
       need = std::max(need, h_stats_.p[k].iterations);
     }
-    if (all_done) { pred_iters_ = need; mirrors_written_ = true; results_final_ = spec_full || !want_full; break; }   // poses / stats are final and on the host (and the clouds registered by the speculative launch, which the event covers)
+    // poses / stats are final and on the host; the clouds registered by the speculative launch are behind them in the stream
+    // (every reader of the clouds goes through the stream or an event recorded on it), and so may be a converged launch or two
+    if (all_done) { pred_iters_ = need; mirrors_written_ = true; results_final_ = spec_full || !want_full; (void)polled; break; }
     pred_iters_ = it + 1;
     chunk = 1;
   }

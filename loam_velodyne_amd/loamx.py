@@ -645,6 +645,10 @@ class Pipeline:
     def set_lookahead(self, on: bool):
         _check(lib().loamx_pipeline_set_lookahead(self.h, 1 if on else 0))
 
+    def lookahead_depth(self) -> int:
+        """steps the odometry may run ahead of the registration (0: look-ahead off)"""
+        return int(lib().loamx_pipeline_lookahead_depth(self.h))
+
     def drain_lookahead(self):
         """wait until the look-ahead has run as far as it may; returns the last step whose odometry is complete (-1: none)"""
         last = C.c_int(-1)

@@ -1,0 +1,6 @@
+#!/bin/bash
+set -u
+root=$(pwd); out=$root/gpurun_out/r04_s42; mkdir -p $out
+export TMPDIR=/tmp
+timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pcie --ab ";LOAMX_ODOM_MAXIT=10;LOAMX_ODOM_MAXIT=10 LOAMX_PRESTAGE=1;LOAMX_ODOM_MAXIT=10 LOAMX_PRESTAGE=1 LOAMX_NO_MIRROR_POLL=1;LOAMX_ODOM_MAXIT=5 LOAMX_PRESTAGE=1;LOAMX_ODOM_MAXIT=5 LOAMX_PRESTAGE=1 LOAMX_BENCH_TIMING_PERIOD=1000" > $out/bench.json 2> $out/bench.err
+grep "\[ab\]" $out/bench.err | tail -12

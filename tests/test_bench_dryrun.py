@@ -162,7 +162,10 @@ class FakePipeline:
         self.drains = getattr(self, "drains", [])
         self.drains.append(self.last)
         self.drained_at = self.last
-        return min(self.last + 2, max(self.uploaded, self.staged) - 1)
+        return min(self.last + self.lookahead_depth(), max(self.uploaded, self.staged) - 1)
+
+    def lookahead_depth(self):
+        return 6 if self.uploaded else 2
 
     def timing(self):
         return dict(features_ms=0.2, odometry_ms=0.5, registration_ms=0.4, step_ms=0.4, residual_ms=0.18, residual_launches=3,
@@ -238,14 +241,14 @@ def test_bench_main_runs_over_stand_ins(monkeypatch, capsys, argv):
         assert len(out["pcie_inclusive"]["value_windows"]) == 3
     else:   # (the PCIe-inclusive window is a single-handle measurement)
         assert out["pcie_inclusive"] is None
-    # the windows: every resident one staged K + 1 + W + 2 steps, ran 1 + W + K of them, and drained the look-ahead after its last step;
-    # the PCIe ones staged the same number one at a time
+    # the windows: every resident one staged K + 1 + W + 6 steps (the staged batches' look-ahead depth), ran 1 + W + K of them, and drained
+    # the look-ahead after its last step; the PCIe ones staged K + 1 + W + 2 (the streaming ring's depth) one at a time
     resident = [p for p in FakePipeline.instances if p.uploaded]
     streaming = [p for p in FakePipeline.instances if p.staged]
     assert len(resident) == 2 * H and len(streaming) == (3 if H == 1 else 0)
     assert all(p.ns == ns // H for p in resident)   # the streams are dealt over the handles, each driven by its own host thread
     for p in resident:   # (drained when the window opens — after the last warm-up step — and before it closes)
-        assert p.uploaded == 1 + W + K + 2 and p.last == W + K and p.drains == [W, W + K] and p.closed
+        assert p.uploaded == 1 + W + K + 6 and p.last == W + K and p.drains == [W, W + K] and p.closed
     for p in streaming:
         assert p.staged == 1 + W + K + 2 and p.last == W + K and p.drains == [W, W + K] and p.downloads == W + K and p.closed
 

@@ -62,7 +62,7 @@ def test_lookahead_is_transparent(small_world):
     """The software pipeline across steps (registration t || odometry t+1 || features t+2 on separate HIP streams and a
     host thread) must not change any result: bit-identical to the strictly sequential execution."""
     cm, sm = small_world.make_map(40000)
-    T, ns = 5, 3
+    T, ns = 9, 3
     data = []
     for s in range(ns):
         poses = synth.trajectory(T, start=(1.0 * s, 0.0, 2.0 * s))
@@ -78,10 +78,11 @@ def test_lookahead_is_transparent(small_world):
         out = []
         for t in range(T):
             rc = p.step(t)
-            if lookahead:   # the look-ahead runs up to two steps beyond the step that has returned — and no further
-                assert p.drain_lookahead() == min(t + 2, T - 1)
+            if lookahead:   # the look-ahead runs up to lookahead_depth() steps beyond the step that has returned — and no further
+                assert p.lookahead_depth() == 6
+                assert p.drain_lookahead() == min(t + 6, T - 1)
             else:
-                assert p.drain_lookahead() == t
+                assert p.lookahead_depth() == 0 and p.drain_lookahead() == t
             out.append((rc, [p.get(s) for s in range(ns)]))
         return out
     a, b = run(True), run(False)

@@ -280,6 +280,10 @@ void* loamx_batch_stream(loamx_batch* h);
  * (distance, index).  Only neighbours closer than 1.05 m are searched for (the reference rejects a query whose fifth
  * neighbour is 1 m away or more, BasicLaserMapping.cpp:671, :760): missing entries are 0xffffffff / FLT_MAX. */
 int loamx_batch_knn_probe(loamx_batch* h, int which, const float* queries_xyz, uint32_t n, uint32_t* idx5, float* d2_5);
+/* Parity hook for the 6x6 solve of the update steps (colPivHouseholderQr().solve: BasicLaserMapping.cpp:867, BasicLaserOdometry.cpp:559):
+ * n systems ata[36 i .. ) x = atb[6 i .. ) through the wave-cooperative routine the kernels call (x_coop) and through the scalar
+ * routine it must equal bit for bit (x_scalar, one thread, the reference's order of operations). */
+int loamx_batch_qr6_probe(loamx_batch* h, const float* ata, const float* atb, uint32_t n, float* x_coop, float* x_scalar);
 /* Parity hook for the voxel-grid stage: the down-sampled stack clouds of one sweep of the last run (laserCloudCornerStackDS /
  * laserCloudSurfStackDS, BasicLaserMapping.cpp:512-527 — the query points of the Gauss-Newton iterations, sensor frame, in
  * pcl::VoxelGrid's output order).  count fields: capacity in, size out; LOAMX_E_CAPACITY when a cloud does not fit. */

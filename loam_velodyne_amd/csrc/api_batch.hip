@@ -148,6 +148,13 @@ int loamx_batch_knn_probe(loamx_batch* h, int which, const float* queries_xyz, u
     return LOAMX_OK;
   });
 }
+int loamx_batch_qr6_probe(loamx_batch* h, const float* ata, const float* atb, uint32_t n, float* x_coop, float* x_scalar) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    h->reg.qr6_probe(ata, atb, n, x_coop, x_scalar);
+    return LOAMX_OK;
+  });
+}
 int loamx_batch_download_ds(loamx_batch* h, uint32_t sweep, loamx_cloud* corner_ds, loamx_cloud* surf_ds) {
   return guard([&]() {
     LX_REQUIRE(h && corner_ds && surf_ds, "NULL argument");

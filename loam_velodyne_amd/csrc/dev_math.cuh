@@ -427,8 +427,8 @@ __device__ __forceinline__ bool degeneracy_projector_full(const float* AtA, floa
 
 // 6x6 column-pivoted Householder QR solve spread over the lanes of a wave: lane c < 6 owns COLUMN c of A, lane 6 owns the
 // right-hand side; every arithmetic operation is the one the scalar qr_solve<6,6> performs on that element, in the same
-// order, so the result is bit-identical — only the serial dependency chain shrinks.  Values travel between lanes with
-// v_readlane (a few cycles) instead of ds_bpermute (~60 cycles each on the critical path).
+// order, so the result is bit-identical (tests/test_gpu_parity_hooks: loamx_debug_qr6) — only the serial dependency chain shrinks.
+// Values travel between lanes with v_readlane (a few cycles) instead of ds_bpermute (~60 cycles each on the critical path).
 // Must be called by ALL 64 lanes of wave 0 of the workgroup; AtA/AtB/X are in LDS or global memory.
 __device__ __forceinline__ float lane_get(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
 
@@ -437,7 +437,11 @@ __device__ __forceinline__ void qr_solve6_coop(const float* AtA, const float* At
   float a[6];
 #pragma unroll
   for (int r = 0; r < 6; r++) a[r] = gl < 6 ? AtA[r * 6 + gl] : (gl == 6 ? AtB[r] : 0.f);
-  int perm = gl;   // lane c: original column index currently stored in this lane
+  // Columns never move between lanes: L[c] = the lane (= original column) that stands at POSITION c of the pivoted matrix.  A column
+  // swap is a swap of two entries of L — uniform integers — instead of twelve lane reads and selects, and everything a lane derives
+  // from its own column (remaining norm, Householder vector) is computed before the pivot is known, off the pivot search's chain.
+  int L[6] = {0, 1, 2, 3, 4, 5};
+  bool pivoted = false;   // this lane's column has been a pivot (its entries from the diagonal down are final)
   // largest initial column norm
   float s0 = 0.f;
 #pragma unroll
@@ -453,31 +457,10 @@ __device__ __forceinline__ void qr_solve6_coop(const float* AtA, const float* At
   int nonzero = 6;
 #pragma unroll
   for (int k = 0; k < 6; k++) {
-    // pivot: first column (from k upwards) with the largest remaining squared norm
-    float s = 0.f;
+    // every lane, for its own column: the remaining squared norm (rows k..5) and the Householder vector from row k
+    float s = 0.f, tail = 0.f;
 #pragma unroll
     for (int r = k; r < 6; r++) s += a[r] * a[r];
-    int best = k;
-    float bestn = lane_get(s, k);
-#pragma unroll
-    for (int c = k + 1; c < 6; c++) {
-      const float sc = lane_get(s, c);
-      if (sc > bestn) { bestn = sc; best = c; }
-    }
-    best = __builtin_amdgcn_readfirstlane(best);
-    if (nonzero == 6 && bestn < thr_helper * float(6 - k)) nonzero = k;
-    // swap columns k and best
-#pragma unroll
-    for (int r = 0; r < 6; r++) {
-      const float ak = lane_get(a[r], k), ab = lane_get(a[r], best);
-      a[r] = gl == k ? ab : (gl == best ? ak : a[r]);
-    }
-    {
-      const int pk = __builtin_amdgcn_readlane(perm, k), pb = __builtin_amdgcn_readlane(perm, best);
-      perm = gl == k ? pb : (gl == best ? pk : perm);
-    }
-    // Householder vector from column k (every lane computes one from its own column; lane k's is broadcast)
-    float tail = 0.f;
 #pragma unroll
     for (int r = k + 1; r < 6; r++) tail += a[r] * a[r];
     const float c0 = a[k];
@@ -495,15 +478,35 @@ __device__ __forceinline__ void qr_solve6_coop(const float* AtA, const float* At
       tau = (beta - c0) / beta;
     }
     v[k] = 1.f;
-    tau = lane_get(tau, k);
-    beta = lane_get(beta, k);
+    // pivot: first position (from k upwards) whose column has the largest remaining squared norm
+    int best = k;
+    float bestn = lane_get(s, L[k]);
 #pragma unroll
-    for (int r = k + 1; r < 6; r++) v[r] = lane_get(v[r], k);
-    if (gl == k) {
+    for (int c = k + 1; c < 6; c++) {
+      const float sc = lane_get(s, L[c]);
+      if (sc > bestn) { bestn = sc; best = c; }
+    }
+    best = __builtin_amdgcn_readfirstlane(best);
+    if (nonzero == 6 && bestn < thr_helper * float(6 - k)) nonzero = k;
+    {   // positions k and best change places
+      int lb = L[k];
+#pragma unroll
+      for (int c = k + 1; c < 6; c++) lb = best == c ? L[c] : lb;
+#pragma unroll
+      for (int c = k + 1; c < 6; c++) L[c] = best == c ? L[k] : L[c];
+      L[k] = __builtin_amdgcn_readfirstlane(lb);
+    }
+    const int pl = L[k];   // the pivot column's lane: its Householder vector is the step's
+    tau = lane_get(tau, pl);
+    beta = lane_get(beta, pl);
+#pragma unroll
+    for (int r = k + 1; r < 6; r++) v[r] = lane_get(v[r], pl);
+    if (gl == pl) {
+      pivoted = true;
       a[k] = beta;
 #pragma unroll
       for (int r = k + 1; r < 6; r++) a[r] = 0.f;
-    } else if (gl > k && gl <= 6) {   // remaining columns and the right-hand side
+    } else if (gl <= 6 && !pivoted) {   // remaining columns and the right-hand side
       float dot = 0.f;
 #pragma unroll
       for (int r = k; r < 6; r++) dot += v[r] * a[r];
@@ -512,20 +515,20 @@ __device__ __forceinline__ void qr_solve6_coop(const float* AtA, const float* At
       for (int r = k; r < 6; r++) a[r] -= dot * v[r];
     }
   }
-  // back substitution on the leading nonzero x nonzero block: y[k] ends up in lane k
+  // back substitution on the leading nonzero x nonzero block: y[k] ends up in the lane at position k
   float y = 0.f;
 #pragma unroll
   for (int k = 5; k >= 0; k--) {
     float sacc = lane_get(a[k], 6);   // b[k]
 #pragma unroll
     for (int c = k + 1; c < 6; c++) {
-      const float term = lane_get(a[k] * y, c);   // A[k][c] * y[c] from the lane owning column c
+      const float term = lane_get(a[k] * y, L[c]);   // A[k][c] * y[c] from the lane whose column stands at position c
       if (c < nonzero) sacc -= term;
     }
-    const float diag = lane_get(a[k], k);
-    if (gl == k && k < nonzero) y = sacc / diag;
+    const float diag = lane_get(a[k], L[k]);
+    if (gl == L[k] && k < nonzero) y = sacc / diag;
   }
-  if (gl < 6) X[perm] = gl < nonzero ? y : 0.f;
+  if (gl < 6) X[gl] = y;   // (a lane is its original column; positions >= nonzero never received a value: 0)
 }
 
 // ---- exchange between workgroups without cache-wide fences (round 4).  __threadfence() on gfx950 is buffer_wbl2 sc1 + buffer_inv sc1:

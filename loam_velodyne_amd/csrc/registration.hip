@@ -1469,6 +1469,42 @@ void Registrar::knn_probe(int which, const float* xyz, uint32_t n, uint32_t* idx
   LX_HIP(hipStreamSynchronize(st_));
 }
 
+// parity hook: the update steps' 6x6 solve, wave-cooperative (as the kernels run it) next to the scalar routine
+__global__ __launch_bounds__(64) void k_qr6_probe(const float* __restrict__ ata, const float* __restrict__ atb, uint32_t n, float* __restrict__ x_coop,
+                                                  float* __restrict__ x_scalar) {
+  __shared__ float A[36], B[6], X[6];
+  const uint32_t i = blockIdx.x;
+  const int tid = (int)threadIdx.x;
+  if (tid < 36) A[tid] = ata[36 * (size_t)i + tid];
+  if (tid < 6) { B[tid] = atb[6 * (size_t)i + tid]; X[tid] = 0.f; }
+  __syncthreads();
+  qr_solve6_coop(A, B, X);
+  __syncthreads();
+  if (tid < 6) x_coop[6 * (size_t)i + tid] = X[tid];
+  if (tid == 0) {
+    float M[6][6], b[6], x[6];
+    for (int r = 0; r < 6; r++) {
+      b[r] = B[r];
+      for (int c = 0; c < 6; c++) M[r][c] = A[r * 6 + c];
+    }
+    qr_solve<6, 6>(M, b, x);
+    for (int r = 0; r < 6; r++) x_scalar[6 * (size_t)i + r] = x[r];
+  }
+}
+void Registrar::qr6_probe(const float* ata, const float* atb, uint32_t n, float* x_coop, float* x_scalar) {
+  LX_REQUIRE(ata && atb && x_coop && x_scalar, "NULL argument");
+  LX_HIP(hipSetDevice(device_));
+  if (!n) return;
+  DevBuf<float> da, db, dx, dy;
+  da.reserve((size_t)36 * n); db.reserve((size_t)6 * n); dx.reserve((size_t)6 * n); dy.reserve((size_t)6 * n);
+  LX_HIP(hipMemcpyAsync(da.p, ata, sizeof(float) * 36 * n, hipMemcpyHostToDevice, st_));
+  LX_HIP(hipMemcpyAsync(db.p, atb, sizeof(float) * 6 * n, hipMemcpyHostToDevice, st_));
+  hipLaunchKernelGGL(k_qr6_probe, dim3(n), dim3(64), 0, st_, da.p, db.p, n, dx.p, dy.p);
+  LX_HIP(hipMemcpyAsync(x_coop, dx.p, sizeof(float) * 6 * n, hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipMemcpyAsync(x_scalar, dy.p, sizeof(float) * 6 * n, hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipStreamSynchronize(st_));
+}
+
 void Registrar::sync() { LX_HIP(hipStreamSynchronize(st_)); }
 
 // final poses / statistics on the host: an early-exit run that saw every sweep converge already holds them (the update

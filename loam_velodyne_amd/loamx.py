@@ -187,6 +187,16 @@ class Batch:
         _check(lib().loamx_batch_download_ds(self.h, sweep, C.byref(cc), C.byref(sc)))
         return co[:cc.count].copy(), so[:sc.count].copy()
 
+    def qr6_probe(self, ata, atb):
+        """parity hook: n 6x6 systems through the kernels' wave-cooperative solve and through the scalar routine -> (x_coop, x_scalar)"""
+        A = np.ascontiguousarray(ata, np.float32).reshape(-1, 36)
+        b = np.ascontiguousarray(atb, np.float32).reshape(-1, 6)
+        assert len(A) == len(b)
+        xc, xs = np.zeros_like(b), np.zeros_like(b)
+        _check(lib().loamx_batch_qr6_probe(self.h, A.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), len(A),
+                                           xc.ctypes.data_as(C.c_void_p), xs.ctypes.data_as(C.c_void_p)))
+        return xc, xs
+
     def knn_probe(self, which: int, queries_xyz):
         """the library's own 5-NN search for map-frame points: (indices into the cloud given to set_frozen, squared distances)"""
         q = np.ascontiguousarray(np.asarray(queries_xyz, np.float32)[:, :3])

@@ -537,7 +537,7 @@ def run_live(args):
     elapsed = time.perf_counter() - t0
     aft = mp.transform("aft")
     out = {
-        "metric": "sweeps/sec (sequential SLAM: 16-ring sweep, 200k-pt live map, one sweep in flight): feature extraction + odometry + mapping process()",
+        "metric": f"sweeps/sec (sequential SLAM: {sensor} sweep, {M // 1000}k-pt live map, one sweep in flight): feature extraction + odometry + mapping process()",
         "value": round(K / elapsed, 2), "unit": "sweeps/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",

@@ -103,6 +103,10 @@ inline void check_cloud(const loamx_cloud* c, bool allow_null_data = true) {
 }
 inline void pack_cloud(const loamx_cloud* c, float4* dst) {
   const char* src = (const char*)c->data;
+  if (c->stride == 16 && c->intensity_offset == 12) {   // x y z intensity records: the device layout itself
+    if (c->count) memcpy(dst, src, (size_t)c->count * 16);
+    return;
+  }
   for (uint32_t i = 0; i < c->count; i++) {
     const float* r = (const float*)(src + (size_t)i * c->stride);
     dst[i] = make_float4(r[0], r[1], r[2], *(const float*)((const char*)r + c->intensity_offset));
@@ -113,6 +117,11 @@ inline int unpack_cloud(const float4* src, uint32_t n, loamx_cloud* c) {
   uint32_t cap = c->count;
   uint32_t m = n < cap ? n : cap;
   char* dst = (char*)c->data;
+  if (c->stride == 16 && c->intensity_offset == 12) {
+    if (m) memcpy(dst, src, (size_t)m * 16);
+    c->count = n;
+    return n > cap ? LOAMX_E_CAPACITY : LOAMX_OK;
+  }
   for (uint32_t i = 0; i < m; i++) {
     float* r = (float*)(dst + (size_t)i * c->stride);
     r[0] = src[i].x; r[1] = src[i].y; r[2] = src[i].z;

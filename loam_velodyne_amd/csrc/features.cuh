@@ -134,6 +134,7 @@ class FeatureExtractor {
   DevBuf<uint32_t> lf_off_;
   VoxelPipeline vox_;
   PinBuf<uint32_t> h_off_;
+  PinBuf<float4> h_pack_;   // download(): [header | sharp | less sharp | flat | less flat] of one sweep, written by k_feat_pack_host
 };
 
 }  // namespace loamx

@@ -266,6 +266,13 @@ class Mapper {
   DevBuf<uint8_t> sur_valid;
   VoxelPipeline sur_vox;
   uint32_t n_surround = 0;
+  hipStream_t st2 = nullptr;                        // the corner map's update (the surf map's runs on the registration's stream)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  ~Mapper() {
+    if (st2) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+  }
 
   int process(const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res);
   void load_cubes(const loamx_cloud* corner, const loamx_cloud* surf);
@@ -285,8 +292,13 @@ Mapper::Mapper(const loamx_map_config& c) : cfg(c), reg(c.device, 1) {
   reg.params.delta_r_abort = c.delta_r_abort;
   reg.params.corner_leaf = c.corner_filter_size;
   reg.params.surf_leaf = c.surf_filter_size;
+  // the two feature types' map updates are independent: the corner map's runs on a stream of its own next to the surf map's
+  // (process(): forked behind the registration, joined before the results are read)
+  st2 = create_stream(0);
+  LX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  LX_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
   for (int t = 0; t < 2; t++) {
-    tm[t].vox.init(reg.stream());
+    tm[t].vox.init(t == 0 ? st2 : reg.stream());
     tm[t].counters.reserve(16);
     tm[t].tile_sums.reserve(SCAN_SCRATCH_WORDS);
     LX_HIP(hipMemsetAsync(tm[t].tile_sums.p, 0, sizeof(uint32_t) * tm[t].tile_sums.cap, reg.stream()));
@@ -417,10 +429,13 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   for (int a = 0; a < 3; a++) w.cen[a] = cen[a];
   const uint32_t n_in[2] = {corner_last->count, surf_last->count};
 
-  // ---- partition the map: sub-map | rest | dropped
+  // ---- partition the map: sub-map | rest | dropped (the two types side by side, as in the update below)
+  for (int t = 0; t < 2; t++) ensure(tm[t], tm[t].n + n_in[t] + 64, n_in[t]);
+  LX_HIP(hipEventRecord(ev_fork, reg.stream()));   // (behind the look-up tables' copy)
+  LX_HIP(hipStreamWaitEvent(st2, ev_fork, 0));
   for (int t = 0; t < 2; t++) {
     TypeMap& T = tm[t];
-    ensure(T, T.n + n_in[t] + 64, n_in[t]);
+    hipStream_t st = t == 0 ? st2 : reg.stream();
     const int cur = T.cur, nxt = 1 - cur;
     if (T.n) {
       const uint32_t nb = (T.n + 255) / 256;
@@ -433,9 +448,12 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
       LX_HIP(hipMemsetAsync(T.counters.p, 0, sizeof(uint32_t) * 4, st));
     }
   }
+  // ... and their grid indices (the corner sub-map's behind its partition on st2)
+  reg.set_submap_device_split(tm[0].sub.p, n_sub[0], st2, tm[1].sub.p, n_sub[1]);
+  LX_HIP(hipEventRecord(ev_join, st2));
+  LX_HIP(hipStreamWaitEvent(reg.stream(), ev_join, 0));
 
   // ---- registration against the sub-map (guard + iterations inside Registrar::run_async)
-  reg.set_submap_device(tm[0].sub.p, n_sub[0], tm[1].sub.p, n_sub[1], false);
   float g6[6];
   tobe.get(g6);
   reg.upload(1, corner_last, surf_last, full_res, g6, false);
@@ -453,9 +471,14 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     reg.finish_with_poses(p6);
   }
 
-  // ---- map insertion + per-cube re-filtering
+  if (full_res && full_res->count) reg.download_full_res_async(0);   // (lands while the map is updated)
+
+  // ---- map insertion + per-cube re-filtering: corners on st2, surfs on the registration's stream, side by side
+  LX_HIP(hipEventRecord(ev_fork, reg.stream()));
+  LX_HIP(hipStreamWaitEvent(st2, ev_fork, 0));
   for (int t = 0; t < 2; t++) {
     TypeMap& T = tm[t];
+    hipStream_t st = t == 0 ? st2 : reg.stream();
     const int nxt = 1 - T.cur;
     const uint32_t n_old = n_sub[t], n_slots = n_in[t], n_fin = n_old + n_slots;
     if (n_old) {
@@ -486,6 +509,8 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     LX_HIP(hipMemcpyAsync(T.h_hist.p, T.hist.p, sizeof(uint32_t) * MCUBES, hipMemcpyDeviceToHost, st));
     LX_HIP(hipMemcpyAsync(T.h_counters.p, T.counters.p, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, st));
   }
+  LX_HIP(hipEventRecord(ev_join, st2));
+  LX_HIP(hipStreamWaitEvent(reg.stream(), ev_join, 0));
 
   // ---- results
   float pose6[6];

@@ -1349,15 +1349,18 @@ int OdometryBatch::process_host(const loamx_cloud* sharp, const loamx_cloud* les
   LX_REQUIRE(n_streams() == 1, "process_host is the single-stream entry point");
   LX_HIP(hipSetDevice(device_));
   const loamx_cloud* cl[4] = {sharp, less_sharp, flat, less_flat};
+  // the four clouds go up back to back: one pinned block, one copy, no wait (process() orders everything behind it on the stream;
+  // the staging block is rewritten by the next call only, which starts after this one has synchronised)
+  size_t off[5] = {0, 0, 0, 0, 0};
   for (int k = 0; k < 4; k++) {
     check_cloud(cl[k], false);
-    h_stage_.reserve(cl[k]->count + 1);
-    up_[k].reserve(cl[k]->count + 1);
-    pack_cloud(cl[k], h_stage_.p);
-    if (cl[k]->count) LX_HIP(hipMemcpyAsync(up_[k].p, h_stage_.p, sizeof(float4) * cl[k]->count, hipMemcpyHostToDevice, st_));
-    LX_HIP(hipStreamSynchronize(st_));   // single staging buffer
+    off[k + 1] = off[k] + cl[k]->count;
   }
-  OdomInput in{up_[0].p, sharp->count, up_[1].p, less_sharp->count, up_[2].p, flat->count, up_[3].p, less_flat->count};
+  h_stage_.reserve(off[4] + 1);
+  up_[0].reserve(off[4] + 1);
+  for (int k = 0; k < 4; k++) pack_cloud(cl[k], h_stage_.p + off[k]);
+  if (off[4]) LX_HIP(hipMemcpyAsync(up_[0].p, h_stage_.p, sizeof(float4) * off[4], hipMemcpyHostToDevice, st_));
+  OdomInput in{up_[0].p, sharp->count, up_[0].p + off[1], less_sharp->count, up_[0].p + off[2], flat->count, up_[0].p + off[3], less_flat->count};
   int rc = LOAMX_OK;
   process(&in, &rc);
   return rc;
@@ -1365,22 +1368,22 @@ int OdometryBatch::process_host(const loamx_cloud* sharp, const loamx_cloud* les
 
 int OdometryBatch::get_last_clouds(uint32_t s, loamx_cloud* corner, loamx_cloud* surf) {
   LX_HIP(hipSetDevice(device_));
-  LX_HIP(hipStreamSynchronize(st_));
   OdomStream& S = *streams_[s];
   int rc = LOAMX_OK;
-  std::vector<float4> tmp;
+  if (corner) check_cloud(corner, false);
+  if (surf) check_cloud(surf, false);
+  // both clouds through pinned memory, one wait (copies into pageable memory are staged by the runtime, each with a wait of its own)
+  const uint32_t nc = corner ? S.n_last_corner : 0u, nsf = surf ? S.n_last_surf : 0u;
+  h_stage_.reserve((size_t)nc + nsf + 1);
+  if (nc) LX_HIP(hipMemcpyAsync(h_stage_.p, d_last_corner(s), sizeof(float4) * nc, hipMemcpyDeviceToHost, st_));
+  if (nsf) LX_HIP(hipMemcpyAsync(h_stage_.p + nc, d_last_surf(s), sizeof(float4) * nsf, hipMemcpyDeviceToHost, st_));
+  if (nc + nsf) LX_HIP(hipStreamSynchronize(st_));
   if (corner) {
-    check_cloud(corner, false);
-    tmp.resize(S.n_last_corner);
-    if (S.n_last_corner) LX_HIP(hipMemcpy(tmp.data(), d_last_corner(s), sizeof(float4) * S.n_last_corner, hipMemcpyDeviceToHost));
-    int r = unpack_cloud(tmp.data(), S.n_last_corner, corner);
+    const int r = unpack_cloud(h_stage_.p, nc, corner);
     if (r != LOAMX_OK) rc = r;
   }
   if (surf) {
-    check_cloud(surf, false);
-    tmp.resize(S.n_last_surf);
-    if (S.n_last_surf) LX_HIP(hipMemcpy(tmp.data(), d_last_surf(s), sizeof(float4) * S.n_last_surf, hipMemcpyDeviceToHost));
-    int r = unpack_cloud(tmp.data(), S.n_last_surf, surf);
+    const int r = unpack_cloud(h_stage_.p + nc, nsf, surf);
     if (r != LOAMX_OK) rc = r;
   }
   return rc;

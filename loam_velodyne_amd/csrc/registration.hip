@@ -1013,6 +1013,16 @@ void Registrar::set_submap_device(const float4* d_corner, uint32_t nc, const flo
   if (sync) LX_HIP(hipStreamSynchronize(st_));
 }
 
+// the two indices built side by side: the corner index on a stream of the caller's (ordered by the caller: the registration's stream
+// has to wait for what this enqueues there before run_async()), the surf index on the registration's stream
+void Registrar::set_submap_device_split(const float4* d_corner, uint32_t nc, hipStream_t corner_stream, const float4* d_surf, uint32_t ns) {
+  LX_HIP(hipSetDevice(device_));
+  corner_index.bind(corner_stream);
+  corner_index.build(d_corner, nc);
+  corner_index.bind(st_);
+  surf_index.build(d_surf, ns);
+}
+
 void Registrar::stage_submap_device(const float4* d_corner, uint32_t nc, const float4* d_surf, uint32_t ns, hipEvent_t wait_for) {
   LX_HIP(hipSetDevice(device_));
   if (!st_build_) {
@@ -1097,17 +1107,28 @@ void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const 
     pack_cloud(&surf_last[s], h_in_.p + h_seg_off_[2 * s + 1]);
   }
   LX_HIP(hipMemcpyAsync(in_.p, h_in_.p, sizeof(float4) * n_in_, hipMemcpyHostToDevice, st_));
-  LX_HIP(hipMemcpyAsync(seg_off_.p, h_seg_off_.data(), sizeof(uint32_t) * (2 * n_sweeps + 1), hipMemcpyHostToDevice, st_));
   if (n_full_) {
     h_full_.reserve(n_full_);
     full_.reserve(n_full_);
     for (uint32_t s = 0; s < n_sweeps; s++) pack_cloud(&full_res[s], h_full_.p + h_full_off_[s]);
     LX_HIP(hipMemcpyAsync(full_.p, h_full_.p, sizeof(float4) * n_full_, hipMemcpyHostToDevice, st_));
-    LX_HIP(hipMemcpyAsync(full_off_.p, h_full_off_.data(), sizeof(uint32_t) * (n_sweeps + 1), hipMemcpyHostToDevice, st_));
   }
-  memcpy(h_guess_.p, guess6, sizeof(float) * 6 * n_sweeps);
-  LX_HIP(hipMemcpyAsync(guess_.p, h_guess_.p, sizeof(float) * 6 * n_sweeps, hipMemcpyHostToDevice, st_));
-  d_guess_ = guess_.p; d_seg_off_ = seg_off_.p; d_full_off_ = full_off_.p; d_src_ = nullptr;
+  {   // guesses / offsets travel as ONE block through pinned memory owned by this object (as in upload_device; copies from the
+      // pageable vectors were staged by the runtime, one wait each)
+    const size_t nseg = 2 * (size_t)n_sweeps;
+    const size_t o_off = sizeof(float) * 6 * n_sweeps, o_full = o_off + sizeof(uint32_t) * (nseg + 1);
+    const size_t bytes = o_full + sizeof(uint32_t) * (n_sweeps + 1);
+    h_blob_.reserve(bytes + 16);
+    blob_.reserve(bytes + 16);
+    memcpy(h_blob_.p, guess6, sizeof(float) * 6 * n_sweeps);
+    memcpy(h_blob_.p + o_off, h_seg_off_.data(), sizeof(uint32_t) * (nseg + 1));
+    memcpy(h_blob_.p + o_full, h_full_off_.data(), sizeof(uint32_t) * (n_sweeps + 1));
+    LX_HIP(hipMemcpyAsync(blob_.p, h_blob_.p, bytes, hipMemcpyHostToDevice, st_));
+    d_guess_ = (const float*)blob_.p;
+    d_seg_off_ = (const uint32_t*)(blob_.p + o_off);
+    d_full_off_ = (const uint32_t*)(blob_.p + o_full);
+    d_src_ = nullptr;
+  }
   nblk_ = max_q_per_sweep_ / GN_TILE + 2;   // >= ceil(corner / tile) + ceil(surf / tile) of every sweep
   partials_.reserve((size_t)n_sweeps * nblk_ * LX_NSUM);
   // the copies read this object's pinned staging, which the next upload() rewrites: a caller that does not synchronise with the
@@ -1385,6 +1406,7 @@ void Registrar::run_async() {
     n_res_launch_ = 0;
     if (early_exit) memset(h_stats_.p, 0, sizeof(SweepStats) * ns);   // mirrors of sweeps that never reach an update stay "not done"
     vb_unchecked_ = !legacy && n > 0;
+    full_dl_sweep_ = -1;
     full_enqueued_ = false;
     results_final_ = false;
     enqueue_front(legacy);
@@ -1443,6 +1465,7 @@ void Registrar::finish_with_poses(const float* poses6) {
   LX_HIP(hipMemcpyAsync(guess_.p, h_guess_.p, sizeof(float) * 6 * ns, hipMemcpyHostToDevice, st_));
   hipLaunchKernelGGL(k_pose_set, dim3((ns + 63) / 64), dim3(64), 0, st_, guess_.p, ns, poses_.p);
   enqueue_full(0);
+  full_dl_sweep_ = -1;
   mirrors_written_ = false;   // the device poses were replaced
   results_final_ = false;     // ... and new device work was enqueued: the next fetch waits for the stream
   LX_HIP(hipGetLastError());
@@ -1546,15 +1569,29 @@ void Registrar::download(float* poses6, int* stats4) {
   }
 }
 
+// The registered full-resolution cloud of one sweep, asked for ahead of time: the copy into pinned memory is enqueued behind the
+// registration's last launch and overlaps whatever the caller enqueues next (Mapper: the map update); download_full_res() of the same
+// sweep then only waits for the stream and unpacks.
+void Registrar::download_full_res_async(uint32_t sweep) {
+  LX_REQUIRE(sweep < n_sweeps_, "sweep index out of range");
+  const uint32_t a = h_full_off_[sweep], b = h_full_off_[sweep + 1];
+  h_full_dl_.reserve((size_t)(b - a) + 1);
+  if (b > a) LX_HIP(hipMemcpyAsync(h_full_dl_.p, full_.p + a, sizeof(float4) * (b - a), hipMemcpyDeviceToHost, st_));
+  full_dl_sweep_ = (int)sweep;
+}
+
 int Registrar::download_full_res(uint32_t sweep, loamx_cloud* out) {
   LX_REQUIRE(sweep < n_sweeps_, "sweep index out of range");
   check_cloud(out, false);
   fetch_results();
   const uint32_t a = h_full_off_[sweep], b = h_full_off_[sweep + 1];
-  std::vector<float4> tmp(b - a);
-  if (b > a) LX_HIP(hipMemcpyAsync(tmp.data(), full_.p + a, sizeof(float4) * (b - a), hipMemcpyDeviceToHost, st_));
+  if (full_dl_sweep_ != (int)sweep) {   // not asked for ahead of time (or the clouds were registered again since): copy now
+    h_full_dl_.reserve((size_t)(b - a) + 1);   // (pinned: a copy into pageable memory is staged by the runtime)
+    if (b > a) LX_HIP(hipMemcpyAsync(h_full_dl_.p, full_.p + a, sizeof(float4) * (b - a), hipMemcpyDeviceToHost, st_));
+  }
+  full_dl_sweep_ = -1;
   LX_HIP(hipStreamSynchronize(st_));
-  return unpack_cloud(tmp.data(), b - a, out);
+  return unpack_cloud(h_full_dl_.p, b - a, out);
 }
 
 void Registrar::download_ds(uint32_t sweep, std::vector<float4>& corner_ds, std::vector<float4>& surf_ds) {

@@ -298,7 +298,11 @@ class ScanRegistration:
         rs = np.ascontiguousarray(ring_sizes, np.uint32)
         n = len(pts)
         width = 8 if pcl_layout else 4
-        outs = [np.zeros((max(n, 1), width), np.float32) for _ in range(4)]
+        key = (max(n, 1), width)
+        if getattr(self, "_out_key", None) != key:   # landing buffers are kept between calls (the results below are copies)
+            self._outs = [np.zeros(key, np.float32) for _ in range(4)]
+            self._out_key = key
+        outs = self._outs
         cl = [cloud_of(o) for o in outs]
         cin = cloud_of(pts)
         _check(lib().loamx_scanreg_process(self.h, C.byref(cin), rs.ctypes.data_as(C.c_void_p), len(rs), C.byref(cl[0]),

@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+root=$(pwd); out=$root/gpurun_out/r04_s48; mkdir -p $out
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1; echo "tests rc $?" >> $out/tests.log
+tail -8 $out/tests.log
+for i in 1 2; do timeout 300 python bench.py --mode live --steps 100 --warmup 10 --no-cpu-baseline > $out/live_$i.json 2> $out/live_$i.err; python -c "
+import json;d=json.load(open('$out/live_$i.json'));print(d['value'],d['ms_per_step'],d['config']['stage_ms_per_sweep'])"; done
+timeout 300 python bench.py --mode live --sensor HDL-32 --map-points 500000 --steps 60 --warmup 10 --no-cpu-baseline > $out/live_hdl32.json 2> $out/live_hdl32.err; python -c "
+import json;d=json.load(open('$out/live_hdl32.json'));print(d['metric']);print(d['value'],d['ms_per_step'],d['config']['stage_ms_per_sweep'])"

@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--long-steps", type=int, default=0,
                     help="N > 0: an additional window of N steps (needs N more staged sweeps per stream: ~1 s of host time per 50) reported as "
                          "value_long — long enough for an external sampler (rocm-smi) to see the GPU busy")
+    ap.add_argument("--no-live-nodes", action="store_true", help="live mode: skip the additional run with the three entry points as concurrent nodes")
     ap.add_argument("--mode", default="batched", choices=["batched", "live"],
                     help="live: sequential SLAM (BASELINE configs[1]: VLP-16, 200 k-pt live map, one sweep in flight, host clouds in / out)")
     args = ap.parse_args()
@@ -549,6 +550,62 @@ def run_live(args):
                    "registration_device_ms_per_sweep": round(reg_ms / K, 4),
                    "final_pose_error_vs_ground_truth_m": round(float(np.abs(aft[3:] - poses[T, 3:]).max()), 4)},
     }
+    # The same sweeps through the same three entry points, but run the way the reference runs them: three nodes, each consuming the
+    # messages of the one before it as they arrive (scanRegistration of sweep t+2 || laserOdometry of t+1 || laserMapping of t; queues
+    # of depth 2 between them).  Data flow and results are identical (asserted: the final pose equals the sequential run's bit for
+    # bit); `value` above stays the one-sweep-in-flight figure.
+    if not args.no_live_nodes:
+        import queue
+        import threading
+        sr2, od2, mp2 = loamx.ScanRegistration(), loamx.LaserOdometry(), loamx.LaserMapping()
+        mp2.load_cubes(cm, sm)
+        q1, q2 = queue.Queue(maxsize=2), queue.Queue(maxsize=2)
+        errs = []
+
+        def node_scanreg():
+            try:
+                for t in range(T):
+                    q1.put(sr2.process(sweeps[t].points, sweeps[t].ring_sizes))
+            except BaseException as e:   # noqa: BLE001 (reported by the main thread)
+                errs.append(e)
+            q1.put(None)
+
+        def node_odometry():
+            try:
+                while True:
+                    f = q1.get()
+                    if f is None:
+                        break
+                    od2.process(f)
+                    lc2, ls2 = od2.last_clouds()
+                    q2.put((lc2, ls2, od2.transform_to_end(f["full"]), od2.transform_sum))
+            except BaseException as e:   # noqa: BLE001
+                errs.append(e)
+            q2.put(None)
+
+        th = [threading.Thread(target=node_scanreg), threading.Thread(target=node_odometry)]
+        for x in th:
+            x.start()
+        tn0 = None
+        for t in range(T):
+            item = q2.get()
+            if item is None:
+                break
+            if t == 1 + W:
+                tn0 = time.perf_counter()
+            mp2.update_odometry(item[3])
+            mp2.process(item[0], item[1], item[2])
+        torch.cuda.synchronize()
+        tn1 = time.perf_counter()
+        for x in th:
+            x.join()
+        if errs:
+            raise errs[0]
+        aft2 = mp2.transform("aft")
+        assert np.array_equal(aft, aft2), f"three concurrent nodes and the sequential run disagree: {aft} vs {aft2}"
+        out["value_nodes_concurrent"] = round(K / (tn1 - tn0), 2)
+        out["config"]["nodes_concurrent"] = ("the same entry points as three concurrent nodes (threads; queues of depth 2), as the reference's scanRegistration / "
+                                             "laserOdometry / laserMapping run: throughput is set by the slowest node; final pose bit-identical to the sequential run")
     avg_launch_ms = gn_ms / max(gn_launches, 1)
     achieved = (72.0 * gn_qi / max(gn_launches, 1)) / (avg_launch_ms * 1e-3) / 1e9 if gn_launches else 0.0
     out["roofline"] = {"kernel": "loamx::k_gn_iter", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -81,8 +81,7 @@ int loamx_scanreg_process(loamx_scanreg* h, const loamx_cloud* cloud, const uint
     h->fx.begin_sweep();   // reset(scanTime) / updateIMUTransform() of processScanlines (identities without IMU data)
     h->fx.upload(1, cloud, rs, &n_rings);
     h->fx.run_async();
-    h->fx.sync();
-    return h->fx.download(0, sharp, less_sharp, flat, less_flat);
+    return h->fx.download(0, sharp, less_sharp, flat, less_flat);   // (one wait, behind the launch that packs the clouds into pinned memory)
   });
 }
 
@@ -109,7 +108,6 @@ int loamx_scanreg_process_raw(loamx_scanreg* h, const loamx_multiscan_mapper* ma
     LX_REQUIRE(mapper->n_scan_rings >= 2, "invalid number of scan rings (n < 2)");
     h->fx.upload_raw(raw_xyz, count, stride, mapper->lower_bound_deg, mapper->upper_bound_deg, mapper->n_scan_rings);
     h->fx.run_async();
-    h->fx.sync();
     int rc = h->fx.download_cloud(0, full, ring_size);
     const int rc2 = h->fx.download(0, sharp, less_sharp, flat, less_flat);
     return rc != LOAMX_OK ? rc : rc2;

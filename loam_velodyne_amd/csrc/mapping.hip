@@ -429,6 +429,14 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   for (int a = 0; a < 3; a++) w.cen[a] = cen[a];
   const uint32_t n_in[2] = {corner_last->count, surf_last->count};
 
+  // the sweep's clouds and the guess go up first: the copies run while this thread is still enqueuing the partition (the chain
+  // of short launches below is bound by the host's launch rate, not by the device)
+  {
+    float g6[6];
+    tobe.get(g6);
+    reg.upload(1, corner_last, surf_last, full_res, g6, false);
+  }
+
   // ---- partition the map: sub-map | rest | dropped (the two types side by side, as in the update below)
   for (int t = 0; t < 2; t++) ensure(tm[t], tm[t].n + n_in[t] + 64, n_in[t]);
   LX_HIP(hipEventRecord(ev_fork, reg.stream()));   // (behind the look-up tables' copy)
@@ -454,9 +462,6 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   LX_HIP(hipStreamWaitEvent(reg.stream(), ev_join, 0));
 
   // ---- registration against the sub-map (guard + iterations inside Registrar::run_async)
-  float g6[6];
-  tobe.get(g6);
-  reg.upload(1, corner_last, surf_last, full_res, g6, false);
   reg.early_exit = true;   // process() is blocking
   const bool imu_blend = !imu_history.empty();
   reg.defer_full = imu_blend;
@@ -476,7 +481,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   // ---- map insertion + per-cube re-filtering: corners on st2, surfs on the registration's stream, side by side
   LX_HIP(hipEventRecord(ev_fork, reg.stream()));
   LX_HIP(hipStreamWaitEvent(st2, ev_fork, 0));
-  for (int t = 0; t < 2; t++) {
+  for (int t = 1; t >= 0; t--) {   // (the surf map first: its chain is the longer one, and the host needs ~80 us to enqueue either)
     TypeMap& T = tm[t];
     hipStream_t st = t == 0 ? st2 : reg.stream();
     const int nxt = 1 - T.cur;

@@ -137,6 +137,8 @@ class OdometryBatch {
   View<ToEndParams> te_, h_te_;
   View<uint32_t> d_cur_off_, h_off_pin_;
   PinBuf<float4> h_stage_;
+  PinBuf<float4> h_last_dl_;     // process_host(): the clouds get_last_clouds() hands out, copied behind the tail
+  bool last_dl_valid_ = false;
   DevBuf<float4> up_[4], tmp_cloud_;
   uint32_t lm_slots_[2] = {0, 0};   // workgroups of k_odom_lm<1> / <2> the device holds at once (occupancy x CUs)
   hipEvent_t ev_tail_ = nullptr, ev_pose_ = nullptr, ev_up_ = nullptr;

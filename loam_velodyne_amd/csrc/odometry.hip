@@ -1362,7 +1362,15 @@ int OdometryBatch::process_host(const loamx_cloud* sharp, const loamx_cloud* les
   if (off[4]) LX_HIP(hipMemcpyAsync(up_[0].p, h_stage_.p, sizeof(float4) * off[4], hipMemcpyHostToDevice, st_));
   OdomInput in{up_[0].p, sharp->count, up_[0].p + off[1], less_sharp->count, up_[0].p + off[2], flat->count, up_[0].p + off[3], less_flat->count};
   int rc = LOAMX_OK;
-  process(&in, &rc);
+  last_dl_valid_ = false;
+  process(&in, &rc, /*defer_tail=*/true);   // returns with the pose; the re-projection / index build go on behind it
+  // what get_last_clouds() hands out is asked for now: the copy lands in pinned memory behind the tail while the caller is busy
+  // with the pose (ns = 1: the corner and the surf cloud lie back to back)
+  OdomStream& S = *streams_[0];
+  const uint32_t n = S.n_last_corner + S.n_last_surf;
+  h_last_dl_.reserve((size_t)n + 1);
+  if (n) LX_HIP(hipMemcpyAsync(h_last_dl_.p, d_last_corner(0), sizeof(float4) * n, hipMemcpyDeviceToHost, st_));
+  last_dl_valid_ = d_last_surf(0) == d_last_corner(0) + S.n_last_corner;
   return rc;
 }
 
@@ -1372,6 +1380,18 @@ int OdometryBatch::get_last_clouds(uint32_t s, loamx_cloud* corner, loamx_cloud*
   int rc = LOAMX_OK;
   if (corner) check_cloud(corner, false);
   if (surf) check_cloud(surf, false);
+  if (last_dl_valid_ && s == 0) {   // process_host() asked for them already
+    LX_HIP(hipStreamSynchronize(st_));
+    if (corner) {
+      const int r = unpack_cloud(h_last_dl_.p, S.n_last_corner, corner);
+      if (r != LOAMX_OK) rc = r;
+    }
+    if (surf) {
+      const int r = unpack_cloud(h_last_dl_.p + S.n_last_corner, S.n_last_surf, surf);
+      if (r != LOAMX_OK) rc = r;
+    }
+    return rc;
+  }
   // both clouds through pinned memory, one wait (copies into pageable memory are staged by the runtime, each with a wait of its own)
   const uint32_t nc = corner ? S.n_last_corner : 0u, nsf = surf ? S.n_last_surf : 0u;
   h_stage_.reserve((size_t)nc + nsf + 1);

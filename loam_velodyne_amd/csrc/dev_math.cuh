@@ -545,6 +545,22 @@ __device__ __forceinline__ double xchg_load_nowait(const double* p) {
   asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+// A double with a tag on both sides in ONE aligned 16-byte record, written by one store and read by one load: the reader takes the value
+// when BOTH tags are the one it waits for.  An aligned 16-byte access never leaves its cache line; should the memory system ever
+// split it, it splits at 8 bytes, and each half carries a tag — so a record with two matching tags holds both halves of the new
+// value.  The exchange then needs no separate flag, no counter and no wait on the producer's side (k_odom_lm).
+typedef unsigned xrec_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void xrec_store(xrec_t* p, double v, unsigned tag) {
+  xrec_t r;
+  r.x = tag; r.y = (unsigned)__double2loint(v); r.z = (unsigned)__double2hiint(v); r.w = tag;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
+}
+__device__ __forceinline__ xrec_t xrec_load(const xrec_t* p) {
+  xrec_t r;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ double xrec_value(const xrec_t& r) { return __hiloint2double((int)r.z, (int)r.y); }
 __device__ __forceinline__ void xchg_loads_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // ... and every loaded value goes through this once, after xchg_loads_done(): it ties the value's uses behind the wait (the compiler
 // sees no dependence between the load statement's output and the wait statement otherwise)

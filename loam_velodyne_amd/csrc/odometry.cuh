@@ -42,8 +42,9 @@ struct OdomProblem {
   int stream_id;          // index of the stream this problem belongs to
   ToEndParams* te_out;        // re-projection parameters of this stream (completed by k_odom_lm)
   OdomProblem* host_mirror;   // pinned host copy that k_odom_lm fills with transform / stats / done (no D2H copy on the stream)
-  unsigned ticket;        // k_odom_lm: workgroup arrivals since the problem was set up (per-stream barrier)
-  double* part;           // k_odom_lm: [2][16][LX_NSUM] partial normal equations of the stream's workgroups
+  unsigned ticket;        // (unused; kept zeroed)
+  unsigned xchg_epoch;    // k_odom_lm: number of this sweep (24 bits, never 0) in the tags of the records its workgroups exchange
+  double* part;           // k_odom_lm: [2][16][LX_NSUM] partial normal equations of the stream's workgroups, one tagged 16-byte record each
   const uint32_t* rf_corner;   // ring-first tables of last_corner / last_surf (k_odom_corr_lds: where to expect the ring windows — a hint)
   const uint32_t* rf_surf;
   uint32_t rf_epoch;
@@ -127,6 +128,7 @@ class OdometryBatch {
   PinBuf<uint32_t> h_err_;
   DevBuf<uint32_t> rf_;   // [2 * n_streams][OD_RF_N] ring-first tables of the clouds handed on by the last call (entries tagged with rf_epoch_)
   uint32_t rf_epoch_ = 0;
+  uint32_t xchg_epoch_ = 0;   // process() calls so far, 1 .. 2^24 - 1 (OdomProblem::xchg_epoch)
   // what a call sends up before its first kernel — the problems, the re-projection parameters, the cloud offsets — is ONE block in
   // pinned memory and ONE copy (three copies were three ~7 us commands at the head of the odometry chain, the pipeline's longest)
   template <class T> struct View { T* p = nullptr; };

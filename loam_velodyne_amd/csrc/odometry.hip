@@ -20,7 +20,8 @@ namespace loamx {
 
 constexpr int OD_THREADS = 256;
 constexpr int OD_TR_STRIDE = OD_THREADS + 2;        // k_odom_lm LDS transpose: row stride in doubles (bank spread)
-constexpr int OD_PART_STRIDE = 2 * 16 * LX_NSUM + 16;   // per stream: 2 x 16 workgroups' partial sums (+ 16 slots for LOAMX_PROF_LM timestamps)
+constexpr int OD_PART_STRIDE = 2 * (2 * 16 * LX_NSUM) + 16;   // per stream, in doubles: 2 x 16 workgroups' partial sums as 16-byte tagged records (+ 16 slots for LOAMX_PROF_LM timestamps)
+[[maybe_unused]] constexpr int OD_PART_TS = 2 * (2 * 16 * LX_NSUM);
 // k_odom_lm: up to 16 workgroups x 256 threads x 2 features per thread kept in registers = 8192 features per sweep
 
 // per-point de-skew angles (|a| << 1): float sincos (<= 2 ulp); the once-per-iteration pose trig stays in double
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr(OdomProblem* __r
 // launch resident: the host cuts a batch into launches of at most half the device's occupancy-derived capacity
 // (OdometryBatch::process).
 #ifdef LOAMX_PROF_LM
-#define LM_TS(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && iter == it_begin + 1) pb.part[32 * LX_NSUM + (k)] = (double)wall_clock64(); } while (0)
+#define LM_TS(k) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && iter == it_begin + 1) pb.part[OD_PART_TS + (k)] = (double)wall_clock64(); } while (0)
 #else
 #define LM_TS(k) do { } while (0)
 #endif
@@ -617,6 +618,7 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
   __shared__ double parts[16 * LX_NSUM];   // the partial sums of the stream's (<= 16) workgroups
   __shared__ float AtA[36], AtB[6], X[6], X2[6];
   if (tid < 6) T[tid] = pb.transform[tid];
+  const unsigned xtag = pb.xchg_epoch << 8;   // this sweep's number in the upper 24 bits of every record's tags
   if (tid == 0) { sh_done = 0; sh_abort = 0; sh_degen = pb.stats.degenerate; }
   if (tid < 36) matP[tid] = pb.matP[tid];   // set at iteration 0 (an earlier launch when iter0 > 0)
   __syncthreads();
@@ -776,28 +778,35 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
 #pragma unroll
       for (int w = 0; w < 8; w++) x += red[w][tid];
       if (NB > 1) {
-        xchg_store(&pb.part[(((unsigned)iter & 1u) * 16u + blockIdx.x) * LX_NSUM + tid], x);
-        xchg_stores_done();   // the partial sums are out (agent scope) before this workgroup is counted in — no cache-wide fence (dev_math.cuh)
+        // one tagged 16-byte record per sum, fire and forget: no wait for the store, no arrival counter (dev_math.cuh: xrec_store)
+        xrec_store(reinterpret_cast<xrec_t*>(pb.part) + (((unsigned)iter & 1u) * 16u + blockIdx.x) * LX_NSUM + tid, x, xtag | (unsigned)(iter + 1));
       } else {
         sums[tid] = x;
       }
     }
     if (NB > 1) {
-      __syncthreads();
       LM_TS(4);
-      if (tid == 0) {
-        atomicAdd(&pb.ticket, 1u);
-        const unsigned target = NB * (unsigned)(iter + 1);   // the host zeroes the counter; every iteration adds NB
-        // The exchange needs every workgroup of the stream resident (the host's chunking arithmetic, OdometryBatch::process).  Should that
-        // ever not hold — a device shared with another process, more handles than the arithmetic knows of — the wait gives up after
-        // ~2 s of wall clock (100 MHz counter) and raises a host-visible error word instead of hanging the GPU (as VoxelPipeline's waits do)
+      // Every thread polls the records it is going to add up — all NB workgroups' sums of this iteration (the buffer alternates with the
+      // iteration's parity: a workgroup overwrites a record only after every workgroup has published the NEXT iteration, i.e. has read
+      // this one).  A record counts when both of its tags name this sweep and this iteration (xtag: the sweep's number — records of
+      // earlier sweeps are still lying in the buffer).
+      // The exchange needs every workgroup of the stream resident (the host's chunking arithmetic, OdometryBatch::process).  Should that
+      // ever not hold — a device shared with another process, more handles than the arithmetic knows of — the wait gives up after
+      // ~2 s of wall clock (100 MHz counter) and raises a host-visible error word instead of hanging the GPU (as VoxelPipeline's waits do)
+      {
+        const unsigned want = xtag | (unsigned)(iter + 1);
+        const xrec_t* rec = reinterpret_cast<const xrec_t*>(pb.part) + ((unsigned)iter & 1u) * 16u * LX_NSUM;
         const unsigned long long t_in = wall_clock64();
-        unsigned spins = 0;
-        while (__hip_atomic_load(&pb.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          __builtin_amdgcn_s_sleep(1);
-          if ((++spins & 1023u) == 0u && wall_clock64() - t_in > 200000000ull) { sh_abort = 1; break; }
+        for (unsigned e = tid; e < NB * LX_NSUM; e += OD_THREADS) {
+          unsigned spins = 0;
+          xrec_t r = xrec_load(rec + e);
+          while (r.x != want || r.w != want) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0u && wall_clock64() - t_in > 200000000ull) { sh_abort = 1; break; }
+            r = xrec_load(rec + e);
+          }
+          parts[e] = xrec_value(r);
         }
-        // (the other workgroups' partial sums are read with agent-scope loads below: nothing to invalidate)
       }
       __syncthreads();
       if (sh_abort) {   // block-uniform: this stream's launch is abandoned, later launches see `done`
@@ -809,9 +818,6 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
         return;
       }
       LM_TS(5);
-      for (unsigned e = tid; e < NB * LX_NSUM; e += OD_THREADS)
-        parts[e] = __hip_atomic_load(&pb.part[((unsigned)iter & 1u) * 16u * LX_NSUM + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
       if (tid < LX_NSUM) {
         double x = 0.0;
         for (unsigned b = 0; b < NB; b++) x += parts[b * LX_NSUM + tid];   // workgroup order: deterministic
@@ -1027,6 +1033,7 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
   LX_HIP(hipMemsetAsync(rf_.p, 0, sizeof(uint32_t) * 2 * n_streams * OD_RF_N, st_));   // epoch 0 = no entry
   memset(h_err_.p, 0, 16 * sizeof(uint32_t));
   part_.reserve((size_t)n_streams * OD_PART_STRIDE);
+  LX_HIP(hipMemset(part_.p, 0, sizeof(double) * part_.cap));   // (tag 0 names no sweep)
   {
     auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t o_te = up256(sizeof(OdomProblem) * n_streams), o_off = o_te + up256(sizeof(ToEndParams) * n_streams);
@@ -1144,6 +1151,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   }
 
   // ---- problems of the streams that optimise this sweep
+  xchg_epoch_ = xchg_epoch_ % 0xffffffu + 1u;   // (the records of a stream keep its position among the active ones only by accident: the tag, not the place, says whose they are)
   std::vector<uint32_t> active;
   uint32_t max_feat = 0, max_sharp = 0, max_flat = 0, ind_total = 0;
   std::vector<uint32_t> ind_off(ns + 1, 0);
@@ -1180,6 +1188,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       pb.stats = {0, 0, 0, 0};
       pb.done = 0;
       pb.ticket = 0;
+      pb.xchg_epoch = xchg_epoch_;
       pb.stream_id = (int)s;
       pb.host_mirror = h_mirror_.p + active.size();
       pb.te_out = te_.p + s;
@@ -1289,7 +1298,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
 #ifdef LOAMX_PROF_LM
     {
       double ts[16];
-      LX_HIP(hipMemcpy(ts, part_.p + 32 * LX_NSUM, sizeof(ts), hipMemcpyDeviceToHost));
+      LX_HIP(hipMemcpy(ts, part_.p + OD_PART_TS, sizeof(ts), hipMemcpyDeviceToHost));
       fprintf(stderr, "[lm ts, 10ns ticks]");
       for (int k = 1; k < 10; k++) fprintf(stderr, " %d:%+.0f", k, ts[k] - ts[0]);
       fprintf(stderr, "\n");

@@ -382,7 +382,7 @@ def main():
         resident_window(collect=gpu_poses)
 
     # ---- the same K steps once more with the PCIe inside the timed region (SURVEY.md §8d "GPU timing"): every step's sweeps
-    # are handed over from pinned host memory while earlier steps compute (loamx_pipeline_stage_step, three steps ahead) and
+    # are handed over from pinned host memory while earlier steps compute (loamx_pipeline_stage_step, seven steps ahead) and
     # every step's registered full-resolution clouds are copied back asynchronously (loamx_pipeline_download_step_async).  Never
     # `value`: reported beside it.
     pcie = None
@@ -679,7 +679,8 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
     D2H of each step's registered clouds (asynchronous, alternating device buffers, one pinned block)."""
     from concurrent.futures import ThreadPoolExecutor
     T = 1 + W + K
-    T_all = min(len(sweeps), T + 2)   # staged beyond the last step that runs: the look-ahead's work stays inside the window (main(): LOOK)
+    AHEAD = 7                          # steps staged beyond the one being registered: the streaming ring's eight slots (look-ahead depth 6 + the one being staged)
+    T_all = min(len(sweeps), T + AHEAD - 1)   # staged beyond the last step that runs: the look-ahead's work stays inside the window (main(): LOOK)
     n_pts = len(sweeps[0][0][0])
     assert all(len(sweeps[t][s][0]) == n_pts for t in range(T_all) for s in range(ns))
     pinned = []
@@ -716,20 +717,21 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
         if rc_ < 0:
             raise RuntimeError(L.loamx_last_error().decode())
 
-    for t in range(min(3, T_all)):
+    for t in range(min(AHEAD, T_all)):
         stage(t)
-    stager = ThreadPoolExecutor(max_workers=1)   # stage_step(t + 3) runs beside step(t)
+    assert p.lookahead_depth() == AHEAD - 1, "the streaming ring's look-ahead depth changed: adapt AHEAD"
+    stager = ThreadPoolExecutor(max_workers=1)   # stage_step(t + AHEAD) runs beside step(t)
     t0 = None
     mapped_pts = 0
     host = np.zeros(3)
     for t in range(T):
-        if t == 1 + W:   # steady state: the pipeline is NOT emptied here (steps t .. t+2 are staged, the look-ahead has run as far as it
+        if t == 1 + W:   # steady state: the pipeline is NOT emptied here (steps t .. t+6 are staged, the look-ahead has run as far as it
             p.drain_lookahead()   # may, copies may be in flight — as in production); the window ends the same way plus everything landed,
             if dist is not None:  # so the look-ahead work and the copies of exactly K steps are inside
                 dist.barrier()
             t0 = time.perf_counter()
         ta = time.perf_counter()
-        fut = stager.submit(stage, t + 3) if t + 3 < T_all else None   # slot (t + 3) % 4: free since step t - 1 has run
+        fut = stager.submit(stage, t + AHEAD) if t + AHEAD < T_all else None   # slot (t + AHEAD) % 8: free since step t - 1 has run
         rc = p.step(t)
         tb = time.perf_counter()
         if fut is not None:
@@ -764,7 +766,7 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
         "downloads": {"sdma_direct": n_direct, "hipMemcpyAsync": n_hip},
         "host_ms_per_step": {"inside_step": round(host[0] / K * 1e3, 4), "waiting_for_the_stager": round(host[1] / K * 1e3, 4), "download_call": round(host[2] / K * 1e3, 4)},
         "note": "same workload and steps as `value`, but every step's sweeps cross PCIe inside the timed region (one pinned block per step, copy "
-                "stream, staged three steps ahead by a second host thread) and every step's registered full-resolution clouds are copied back "
+                "stream, staged seven steps ahead by a second host thread) and every step's registered full-resolution clouds are copied back "
                 "(asynchronous, alternating buffers); steady-state window: not drained at its start, fully drained (downloads landed, device "
                 "idle) at its end",
     }

@@ -318,7 +318,7 @@ int loamx_pipeline_upload(loamx_pipeline* h, uint32_t n_steps, const loamx_cloud
  * loamx_pipeline_upload, hand over ONE step at a time, in order, without blocking — the copies go to a stream of their own
  * (packed float4 clouds {stride 16, intensity at 12} straight from the caller's memory: pin it, e.g. hipHostRegister, and the
  * transfer is a DMA that overlaps the kernels of the steps in flight; other layouts are repacked through pinned staging on
- * the calling thread).  Up to four steps are in flight: stage_step(t) may be called once step(t - 4) has returned; the
+ * the calling thread).  Up to eight steps are in flight: stage_step(t) may be called once step(t - 8) has returned; the
  * buffers of step t are read until step(t) has returned. */
 int loamx_pipeline_stage_step(loamx_pipeline* h, uint32_t step, const loamx_cloud* clouds, const uint32_t* const* ring_size,
                               const uint32_t* n_rings);
@@ -362,7 +362,8 @@ int loamx_pipeline_download_full_res(loamx_pipeline* h, uint32_t slot, loamx_clo
 int loamx_pipeline_set_lookahead(loamx_pipeline* h, int on);
 /* How many steps beyond the one being registered the odometry may run: 0 with the look-ahead off, 6 for batches staged with
  * loamx_pipeline_upload (a stream whose sweeps need every odometry iteration needs them for several sweeps in a row; the lead absorbs
- * such a run), 2 for the streaming ring (loamx_pipeline_stage_step*: four slots). */
+ * such a run) and for the streaming ring (loamx_pipeline_stage_step*: eight slots, i.e. six steps beyond the one being registered
+ * and one more being staged). */
 int loamx_pipeline_lookahead_depth(loamx_pipeline* h);
 /* Blocks until the look-ahead has finished every step it is currently allowed to run ahead (odometry of up to
  * loamx_pipeline_lookahead_depth() steps beyond the last loamx_pipeline_step, their feature extraction) and everything of it is enqueued on the device; *last_odometry_step (may be NULL)

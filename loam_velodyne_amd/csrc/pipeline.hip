@@ -133,16 +133,16 @@ class Pipeline {
   int device;
   std::vector<PipeStreamState> st;
   std::vector<std::unique_ptr<FeatureExtractor>> fx;   // one staged batch per step (upload) or a ring of RING slots (stage_step)
-  // Streaming input (loamx_pipeline_stage_step): step t lives in slot t % RING; steps t, t+1, t+2 may be in flight while t+3
-  // is being staged.  The copies run on a stream of their own; launch_features() orders the extraction behind their event.
-  static constexpr uint32_t RING = 4;
+  // Streaming input (loamx_pipeline_stage_step): step t lives in slot t % RING; steps t .. t + RING - 2 may be in flight while
+  // t + RING - 1 is being staged.  The copies run on a stream of their own; launch_features() orders the extraction behind their event.
+  static constexpr uint32_t RING = 8;
   bool streaming = false;
   // streaming: steps below staged_hi have been staged.  stage_step* may run on ONE other thread than step(): it publishes the slot
   // (release) after everything of it is enqueued, step() reads the count once (acquire); the two never touch the same slot — the
-  // stager works on the slot of step t + RING - 1 at most while steps <= t + 2 are in flight
+  // stager works on the slot of step t + RING - 1 at most while steps <= t + RING - 2 are in flight
   std::atomic<uint32_t> staged_hi{0};
   hipStream_t cstream = nullptr, dstream = nullptr;      // H2D staging / D2H of the registered clouds
-  hipEvent_t ev_stage[RING] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_stage[RING] = {};
   hipEvent_t ev_reg_done = nullptr, ev_d2h[2] = {nullptr, nullptr};
   bool d2h_pending[2] = {false, false};
   uint64_t downloads_direct = 0, downloads_hip = 0;      // asynchronous downloads issued to the SDMA engine directly / through hipMemcpyAsync
@@ -235,10 +235,9 @@ class Pipeline {
   // Steps the odometry chains may run ahead of the registration.  A stream that needs all 25 iterations needs them for five or six
   // sweeps in a row (a chain then takes ~570 us per step against the registration's ~430): on average the chains keep up, and a deeper
   // look-ahead lets them build the lead that such a run eats (depth 2: 15.6 k sweeps/s, 4: 16.6 k, 6: 16.9 k, 8 - 12: 16.4 - 16.6 k;
-  // profiles/r04_ab.md).  Staged batches (upload) only: the streaming
-  // ring holds RING = 4 slots, i.e. two steps of look-ahead; the engine keeps a result ring of its own (two steps as well).
+  // profiles/r04_ab.md).  The streaming ring holds RING = 8 slots: the same six steps; the engine keeps a result ring of its own (two).
   int ahead_depth = std::max(1, std::min(getenv("LOAMX_ODOM_AHEAD") ? atoi(getenv("LOAMX_ODOM_AHEAD")) : 6, OR - 2));
-  int depth() const { return !prefetch ? 0 : ((streaming || eng) ? std::min(ahead_depth, 2) : ahead_depth); }
+  int depth() const { return !prefetch ? 0 : (eng ? std::min(ahead_depth, 2) : (streaming ? std::min(ahead_depth, (int)RING - 2) : ahead_depth)); }
   float last_ms[4] = {0, 0, 0, 0};
   std::atomic<bool> timing{false};
 
@@ -486,7 +485,7 @@ class Pipeline {
     LX_HIP(hipSetDevice(device));
     ensure_streaming_(t);
     LX_REQUIRE(t == staged_hi.load(), "steps must be staged in order");
-    LX_REQUIRE(t < RING || last_step.load() + (long)RING >= (long)t, "stage_step(t) needs step(t - 4) to have run: only four steps can be in flight");
+    LX_REQUIRE(t < RING || last_step.load() + (long)RING >= (long)t, "stage_step(t) needs step(t - 8) to have run: only eight steps can be in flight");
     TraceRange trace_range("loamx:pipeline:stage_step");
     if (t > 0) finalize_raw(t - 1);
     rawslot[t % RING].raw = false;
@@ -509,7 +508,7 @@ class Pipeline {
     LX_HIP(hipSetDevice(device));
     ensure_streaming_(t);
     LX_REQUIRE(t == staged_hi.load(), "steps must be staged in order");
-    LX_REQUIRE(t < RING || last_step.load() + (long)RING >= (long)t, "stage_step_raw(t) needs step(t - 4) to have run: only four steps can be in flight");
+    LX_REQUIRE(t < RING || last_step.load() + (long)RING >= (long)t, "stage_step_raw(t) needs step(t - 8) to have run: only eight steps can be in flight");
     TraceRange trace_range("loamx:pipeline:stage_step_raw");
     if (t > 0) finalize_raw(t - 1);   // the IMU state machine advances sweep by sweep: this step's table needs the previous reset
     const uint32_t ns = n_streams_, nr = mapper.n_scan_rings;

@@ -3,7 +3,7 @@ window, its repeats, the PCIe-inclusive windows with the staging thread, the JSO
 driver's command cannot die of a Python-level mistake (an index past the staged sweeps, a misspelt key) that only a GPU box would otherwise
 show.  What the stand-in pipeline checks on the way is the protocol bench.py promises: every step that runs was staged, steps run in order,
 the steady-state window stages two more steps than it runs and drains the look-ahead before it closes, a slot of the streaming ring is
-never re-staged while one of the four steps in flight still owns it."""
+never re-staged while one of the eight steps in flight still owns it."""
 import importlib
 import json
 import os
@@ -165,7 +165,7 @@ class FakePipeline:
         return min(self.last + self.lookahead_depth(), max(self.uploaded, self.staged) - 1)
 
     def lookahead_depth(self):
-        return 6 if self.uploaded else 2
+        return 6
 
     def timing(self):
         return dict(features_ms=0.2, odometry_ms=0.5, registration_ms=0.4, step_ms=0.4, residual_ms=0.18, residual_launches=3,
@@ -196,7 +196,7 @@ class FakeLib:
     def loamx_pipeline_stage_step(self, h, t, clouds, rings, nrings):
         p = self._pipe(h)
         assert t == p.staged, "steps are staged in order"
-        assert t < 4 or p.last >= t - 4, "stage_step(t) needs step(t - 4) to have returned"
+        assert t < 8 or p.last >= t - 8, "stage_step(t) needs step(t - 8) to have returned"
         assert sum(int(x) for x in np.ctypeslib.as_array((np.ctypeslib.ctypes.c_uint32 * int(nrings[0])).from_address(rings[0]))) == clouds[0].count
         p.staged = t + 1
         return 0
@@ -242,7 +242,7 @@ def test_bench_main_runs_over_stand_ins(monkeypatch, capsys, argv):
     else:   # (the PCIe-inclusive window is a single-handle measurement)
         assert out["pcie_inclusive"] is None
     # the windows: every resident one staged K + 1 + W + 6 steps (the staged batches' look-ahead depth), ran 1 + W + K of them, and drained
-    # the look-ahead after its last step; the PCIe ones staged K + 1 + W + 2 (the streaming ring's depth) one at a time
+    # the look-ahead after its last step; the PCIe ones staged the same number one at a time
     resident = [p for p in FakePipeline.instances if p.uploaded]
     streaming = [p for p in FakePipeline.instances if p.staged]
     assert len(resident) == 2 * H and len(streaming) == (3 if H == 1 else 0)
@@ -250,7 +250,7 @@ def test_bench_main_runs_over_stand_ins(monkeypatch, capsys, argv):
     for p in resident:   # (drained when the window opens — after the last warm-up step — and before it closes)
         assert p.uploaded == 1 + W + K + 6 and p.last == W + K and p.drains == [W, W + K] and p.closed
     for p in streaming:
-        assert p.staged == 1 + W + K + 2 and p.last == W + K and p.drains == [W, W + K] and p.downloads == W + K and p.closed
+        assert p.staged == 1 + W + K + 6 and p.last == W + K and p.drains == [W, W + K] and p.downloads == W + K and p.closed
 
 
 def test_bench_main_as_rank_0_of_two(monkeypatch, capsys):

@@ -185,6 +185,12 @@ void loamx_map_destroy(loamx_map* h);
 int loamx_map_update_odometry(loamx_map* h, const float transform_sum[6]);
 /* process(): corner_last / surf_last in, full_res registered in place (transformFullResToMap). */
 int loamx_map_process(loamx_map* h, const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res);
+/* The map side of process() alone — the merge step of a map epoch (collective 3): a sweep that was registered elsewhere
+ * (the batched pipeline, against a frozen copy of this map) is stacked, down-sized, inserted into the cubes with the GIVEN pose
+ * (rx, ry, rz, tx, ty, tz = its transformAftMapped) and the touched cubes are re-filtered, exactly as process() does after its
+ * optimisation (BasicLaserMapping.cpp:512-593); no optimisation runs.  loamx_map_get_cubes() afterwards is the next epoch's map
+ * (loamx_pipeline_stage_frozen_* / loamx_dist_broadcast_map). */
+int loamx_map_insert(loamx_map* h, const loamx_cloud* corner_last, const loamx_cloud* surf_last, const float pose6[6]);
 /* which: 0 transformAftMapped, 1 transformBefMapped, 2 transformTobeMapped, 3 transformSum */
 int loamx_map_get_transform(loamx_map* h, int which, float transform[6]);
 int loamx_map_set_transform(loamx_map* h, int which, const float transform[6]);
@@ -355,6 +361,10 @@ int loamx_pipeline_get(loamx_pipeline* h, uint32_t stream, float* transform, flo
                        int* stats8);
 /* registered full-resolution cloud of the k-th stream that was registered in the last step */
 int loamx_pipeline_download_full_res(loamx_pipeline* h, uint32_t slot, loamx_cloud* out);
+/* The re-projected less-sharp / less-flat clouds of one stream's sweep of the LAST step (laserCloudCornerLast / laserCloudSurfLast as the
+ * odometry hands them to the mapping, LaserOdometry.cpp:296-326): with the stream's transformAftMapped (loamx_pipeline_get) they are what
+ * loamx_map_insert needs to merge the sweep into the next epoch's map.  count fields: capacity in, size out. */
+int loamx_pipeline_download_last_clouds(loamx_pipeline* h, uint32_t stream, loamx_cloud* last_corner, loamx_cloud* last_surf);
 /* Look-ahead (default on): while step t's registration runs, the odometry and the feature extraction of the following staged
  * steps already execute on their own HIP streams (they are independent ROS nodes in the reference) — up to
  * loamx_pipeline_lookahead_depth() steps ahead.  Results are identical; loamx_pipeline_get() always reports the sweep that was

@@ -275,6 +275,11 @@ class Mapper {
   }
 
   int process(const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res);
+  // The map side of process() alone, for a sweep that has been registered elsewhere (the batched pipeline against a frozen map): stack,
+  // down-size, insert into the cubes with the GIVEN pose and re-filter the touched cubes (BasicLaserMapping.cpp:512-593) — the
+  // optimisation (:628-923) does not run, the pose is taken as transformTobeMapped.  The merge step of a map epoch.
+  int insert(const loamx_cloud* corner_last, const loamx_cloud* surf_last, const float pose6[6]);
+  const float* forced_pose = nullptr;   // (insert(): process() takes this as transformTobeMapped instead of transformAssociateToMap's)
   void load_cubes(const loamx_cloud* corner, const loamx_cloud* surf);
   int get_cubes(int which, loamx_cloud* out);
   int get_surround(loamx_cloud* out);
@@ -357,7 +362,8 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   if (frame_count < 1) return LOAMX_SKIPPED;   // _stackFrameNum = 1 (:269-274)
   frame_count = 0;
 
-  transform_associate_to_map(sum, bef, aft, incre, tobe);
+  if (forced_pose) tobe.set(forced_pose);
+  else transform_associate_to_map(sum, bef, aft, incre, tobe);
   const Pose guess = tobe.pose();
 
   // pointOnYAxis (:294-298)
@@ -547,7 +553,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   }
 
   // ---- createDownsizedMap (:242-264): every 5th processed frame
-  map_frame_count++;
+  if (!forced_pose) map_frame_count++;   // (insert() is not a processed frame: no surround cloud is due)
   fresh_map = false;
   if (map_frame_count >= 5) {
     map_frame_count = 0;
@@ -590,6 +596,18 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     }
     fresh_map = true;
   }
+  return rc;
+}
+
+int Mapper::insert(const loamx_cloud* corner_last, const loamx_cloud* surf_last, const float pose6[6]) {
+  const int keep_it = reg.params.max_iterations;
+  const long keep_fc = frame_count;
+  struct Restore { Mapper* m; int it; ~Restore() { m->reg.params.max_iterations = it; m->forced_pose = nullptr; } } restore{this, keep_it};
+  reg.params.max_iterations = 0;   // no Gauss-Newton launch: the registrar stacks and down-sizes with the pose it is given
+  forced_pose = pose6;
+  frame_count = 0;                 // (every call inserts: _stackFrameNum counts sweeps that go through process())
+  const int rc = process(corner_last, surf_last, nullptr);
+  frame_count = keep_fc;
   return rc;
 }
 
@@ -760,6 +778,12 @@ void loamx_map_destroy(loamx_map* h) { delete h; }
 
 int loamx_map_update_odometry(loamx_map* h, const float t[6]) {
   return guard([&]() { LX_REQUIRE(h && t, "NULL argument"); h->m.sum.set(t); return LOAMX_OK; });
+}
+int loamx_map_insert(loamx_map* h, const loamx_cloud* corner_last, const loamx_cloud* surf_last, const float pose6[6]) {
+  return guard([&]() {
+    LX_REQUIRE(h && corner_last && surf_last && pose6, "NULL argument");
+    return h->m.insert(corner_last, surf_last, pose6);
+  });
 }
 int loamx_map_process(loamx_map* h, const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res) {
   return guard([&]() {

@@ -1150,6 +1150,25 @@ int loamx_pipeline_get(loamx_pipeline* h, uint32_t stream, float* transform, flo
 int loamx_pipeline_download_full_res(loamx_pipeline* h, uint32_t slot, loamx_cloud* out) {
   return guard([&]() { LX_REQUIRE(h && out, "NULL argument"); return h->p.reg.download_full_res(slot, out); });
 }
+int loamx_pipeline_download_last_clouds(loamx_pipeline* h, uint32_t stream, loamx_cloud* last_corner, loamx_cloud* last_surf) {
+  return guard([&]() {
+    LX_REQUIRE(h && last_corner && last_surf, "NULL argument");
+    LX_REQUIRE(stream < h->p.n_streams_, "stream index out of range");
+    LX_REQUIRE(h->p.last_step.load() >= 0, "no step has run");
+    check_cloud(last_corner, false);
+    check_cloud(last_surf, false);
+    LX_HIP(hipSetDevice(h->p.device));
+    // (produced on the odometry chain's stream, behind the event the step's registration waited for: complete since step() returned;
+    // their buffer is rewritten only once the chain has gone on for more steps than the look-ahead allows before the next step())
+    const OdomPub& N = h->p.st[stream].cur;
+    std::vector<float4> tmp(std::max(N.n_last_corner, N.n_last_surf));
+    if (N.n_last_corner) LX_HIP(hipMemcpy(tmp.data(), N.last_corner, sizeof(float4) * N.n_last_corner, hipMemcpyDeviceToHost));
+    const int rc = unpack_cloud(tmp.data(), N.n_last_corner, last_corner);
+    if (N.n_last_surf) LX_HIP(hipMemcpy(tmp.data(), N.last_surf, sizeof(float4) * N.n_last_surf, hipMemcpyDeviceToHost));
+    const int rs = unpack_cloud(tmp.data(), N.n_last_surf, last_surf);
+    return rc != LOAMX_OK ? rc : rs;
+  });
+}
 int loamx_pipeline_set_lookahead(loamx_pipeline* h, int on) {
   return guard([&]() {
     LX_REQUIRE(h, "NULL handle");

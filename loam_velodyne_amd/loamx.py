@@ -455,6 +455,14 @@ class LaserMapping:
         rc = _check(lib().loamx_map_process(self.h, C.byref(cc), C.byref(sc), None))
         return rc, None
 
+    def insert(self, corner_last, surf_last, pose6):
+        """loamx_map_insert: the epoch merge step — stack, down-size and insert a sweep registered elsewhere with the given pose"""
+        c, s = as_points(corner_last), as_points(surf_last)
+        cc, sc = cloud_of(c), cloud_of(s)
+        p = np.ascontiguousarray(pose6, np.float32)
+        assert p.shape == (6,)
+        return _check(lib().loamx_map_insert(self.h, C.byref(cc), C.byref(sc), p.ctypes.data_as(C.c_void_p)))
+
     def transform(self, which="aft"):
         t = np.zeros(6, np.float32)
         _check(lib().loamx_map_get_transform(self.h, ("aft", "bef", "tobe", "sum").index(which), t.ctypes.data_as(C.c_void_p)))
@@ -655,6 +663,13 @@ class Pipeline:
         c = cloud_of(out)
         _check(lib().loamx_pipeline_download_full_res(self.h, slot, C.byref(c)))
         return out[:c.count]
+
+    def last_clouds(self, stream: int, capacity: int):
+        """loamx_pipeline_download_last_clouds: (corner_last, surf_last) of the stream's sweep of the last step"""
+        c, s = np.zeros((max(capacity, 1), 4), np.float32), np.zeros((max(capacity, 1), 4), np.float32)
+        cc, sc = cloud_of(c), cloud_of(s)
+        _check(lib().loamx_pipeline_download_last_clouds(self.h, stream, C.byref(cc), C.byref(sc)))
+        return c[:cc.count].copy(), s[:sc.count].copy()
 
     def set_lookahead(self, on: bool):
         _check(lib().loamx_pipeline_set_lookahead(self.h, 1 if on else 0))

@@ -286,3 +286,35 @@ def test_snapshot_restore_continues_bit_for_bit(orc, small_world, tmp_path):
         loamx.LaserMapping(corner_filter_size=0.3).load_snapshot(path)          # other map filter sizes
     with pytest.raises(loamx.LoamxError):
         r.load_snapshot(str(tmp_path / "missing.loamx"))
+
+
+def test_epoch_merge_insert_equals_the_map_side_of_process(orc, small_world):
+    """loamx_map_insert (the merge step of a map epoch): a sweep registered ELSEWHERE — here by the oracle's process(), in
+    production by the batched pipeline against a frozen copy of the map — is inserted with its final pose into a map that starts from
+    the same cubes.  What comes out must be the map the oracle's own process() leaves behind (BasicLaserMapping.cpp:512-593: stack,
+    down-size, insert, re-filter the touched cubes): the same point sets.  The one difference by construction: the stack's round trip
+    through the map frame (:279-292, :512-520) uses the final pose instead of the guess — a rounding-level change of the points that are
+    averaged (tolerance 5e-5 m at up to 45 m range, a few voxel-face flips)."""
+    n = 6
+    poses = synth.trajectory(n)
+    osr, ood, omp = op.ScanRegistration(orc), op.LaserOdometry(orc), op.LaserMapping(orc)
+    acc = loamx.LaserMapping()          # the epoch's accumulator: follows the oracle's map through inserts alone
+    worst, grew = 0.0, 0
+    for k in range(n):
+        sw = synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=40 + k, az_steps=1200)
+        ood.set_features(osr.process(sw.points, sw.ring_sizes))
+        ood.process()
+        lc, ls = ood.last_corner(), ood.last_surf()
+        if k == 0:
+            acc.load_cubes(omp.cloud("corner_cubes"), omp.cloud("surf_cubes"))
+        before = len(acc.cubes("corner")) + len(acc.cubes("surf"))
+        omp.set_inputs(lc, ls, ood.full_to_end(), ood.transform_sum)
+        assert omp.process()
+        assert acc.insert(lc, ls, omp.transform("aft")) == loamx.OK
+        for name, which in (("corner_cubes", "corner"), ("surf_cubes", "surf")):
+            worst = max(worst, _assert_same_point_set(acc.cubes(which), omp.cloud(name), (k, name), tol=5e-5, max_flips=8))
+        grew += int(len(acc.cubes("corner")) + len(acc.cubes("surf")) > before)
+        assert acc.stats()["iterations"] == 0          # nothing was optimised
+    assert grew >= n - 1
+    # a handle that went through process() itself holds the same map as the one that was only told the poses
+    print(f"epoch merge: worst matched map-point distance {worst:.2e} over {n} inserts")

@@ -292,14 +292,14 @@ def test_bench_scale_8_streams_vs_oracle(monkeypatch, engine):
     print("bench-scale parity: worst |difference| %.2e over %d streams x %d sweeps" % (worst, NS, T))
 
 
-@pytest.mark.parametrize("ahead,pinned", [(3, False), (4, False), (3, True)])
+@pytest.mark.parametrize("ahead,pinned", [(3, False), (8, False), (7, True)])
 def test_streaming_io_equals_staged_run(orc, small_world, ahead, pinned):
     """(pinned: the destinations are pinned memory of the runtime's own, the downloads go to the SDMA engine directly — csrc/hostlink.cuh;
-    ahead = 4: the header's contract to the letter — four steps in flight, stage_step(t) right after step(t - 4))
-    loamx_pipeline_stage_step / download_step_async (the PCIe-inclusive mode): one step handed over at a time, at most four
+    ahead = 8: the header's contract to the letter — eight steps in flight, stage_step(t) right after step(t - 8))
+    loamx_pipeline_stage_step / download_step_async (the PCIe-inclusive mode): one step handed over at a time, at most eight
     in flight, registered clouds copied out asynchronously from alternating device buffers — bit-identical to the run that
     staged everything up front, and the downloaded clouds are the ones download_full_res returns"""
-    ns, T = 2, 7
+    ns, T = 2, 12
     cm, sm = small_world.make_map(60000)
     sweeps, starts = [[None] * ns for _ in range(T)], []
     for s in range(ns):
@@ -341,7 +341,7 @@ def test_streaming_io_equals_staged_run(orc, small_world, ahead, pinned):
     for t in range(T):
         rc = b.step(t)
         if t + ahead < T:
-            b.stage_step(t + ahead, sweeps[t + ahead])               # ahead = 3: slot (t + 3) % 4, free since step t - 1 has run; 4: step t's own slot
+            b.stage_step(t + ahead, sweeps[t + ahead])               # ahead = 7: slot (t + 7) % 8, free since step t - 1 has run; 8: step t's own slot
         for s in range(ns):
             got, want = b.get(s), ref[t][s]
             for i in range(3):
@@ -502,3 +502,79 @@ def test_raw_sweeps_with_imu_feeds(orc, small_world):
     assert np.abs(unblended[[0, 2]] - truth[[0, 2]]).max() > max(1e-6, 20 * np.abs(blended[[0, 2]] - truth[[0, 2]]).max()), (unblended, blended, truth)
     print("worst odometry difference vs the oracle chain with IMU:", worst)
 
+
+
+def test_map_epoch_with_merge_step(orc, small_world):
+    """A whole map epoch, end to end (collective 3): the streams register N sweeps against a FROZEN map (epoch 0); their
+    sweeps are merged into the map on the side (loamx_pipeline_download_last_clouds + the stream's transformAftMapped ->
+    loamx_map_insert, the reference's own insertion + per-cube re-filtering, BasicLaserMapping.cpp:512-593); the merged map is staged,
+    indexed in the background and swapped in (epoch 1); the streams go on against it.
+      * epoch 0 is bit-identical to a run that never heard of epochs;
+      * the merged map holds every point the old one held (up to the re-filtering inside a voxel) plus the sweeps' points (the insertion
+        itself is pinned against the oracle's live mapping in tests/test_gpu_mapping.py::test_epoch_merge_insert_...);
+      * epoch 1's poses stay on the ground truth (the merged map is a valid map: same bound as epoch 0's)."""
+    ns, T, E0 = 2, 8, 4
+    cm, sm = small_world.make_map(60000)
+    data, gts, starts = [], [], []
+    for s in range(ns):
+        poses = synth.trajectory(T, start=(1.5 * s, 0.0, 2.0 * s))
+        gts.append(poses)
+        starts.append(np.array([0, 0, 0, 1.5 * s, 0, 2.0 * s], np.float32))
+        data.append([synth.make_sweep(small_world, "VLP-16", poses[t], poses[t + 1], seed=70 * s + t, az_steps=900) for t in range(T)])
+    batches = [[(data[s][t].points, data[s][t].ring_sizes) for s in range(ns)] for t in range(T)]
+
+    def make():
+        p = loamx.Pipeline(ns)
+        p.set_frozen(cm, sm)
+        for s in range(ns):
+            p.set_state(s, aft=starts[s])
+        p.upload(batches)
+        return p
+    plain = make()
+    ref = []
+    for t in range(T):
+        plain.step(t)
+        ref.append([plain.get(s) for s in range(ns)])
+    plain.close()
+
+    p = make()
+    acc = loamx.LaserMapping()                      # the epoch's accumulator starts from the frozen map
+    acc.load_cubes(cm, sm)
+    n0 = len(acc.cubes("corner")) + len(acc.cubes("surf"))
+    merged = 0
+    for t in range(E0):
+        p.step(t)
+        for s in range(ns):
+            got = p.get(s)
+            for i in range(3):
+                assert np.array_equal(got[i], ref[t][s][i]), (t, s, i)
+            if not got[3]["mapped"]:
+                continue
+            lc, ls = p.last_clouds(s, len(data[s][t].points))
+            assert len(lc) > 50 and len(ls) > 200
+            assert acc.insert(lc, ls, got[2]) == loamx.OK
+            merged += 1
+    assert merged == ns * (E0 - 1)
+    new_c, new_s = acc.cubes("corner"), acc.cubes("surf")
+    assert len(new_c) + len(new_s) > n0
+    # the old map's points are still there (re-filtering moves a centroid only inside its voxel: < a voxel diagonal)
+    from scipy.spatial import cKDTree
+    for old, new, leaf in ((cm, new_c, 0.2), (sm, new_s, 0.4)):
+        d, _ = cKDTree(new[:, :3]).query(np.asarray(old)[:, :3])
+        assert d.max() < leaf * 1.8, d.max()
+    # epoch 1: stage the merged map (indexed on the side), swap, go on
+    p.stage_frozen(new_c, new_s)
+    assert p.swap_frozen()
+    worst = 0.0
+    for t in range(E0, T):
+        assert p.step(t) == loamx.OK
+        for s in range(ns):
+            _, _, aft, st = p.get(s)
+            assert st["mapped"] and 1 <= st["map_iterations"] <= 10
+            err = np.abs(aft[3:] - gts[s][t + 1][3:]).max()
+            worst = max(worst, err)
+    ref_err = max(np.abs(ref[t][s][2][3:] - gts[s][t + 1][3:]).max() for t in range(E0, T) for s in range(ns))
+    assert worst < max(2 * ref_err, 0.05), (worst, ref_err)
+    p.close()
+    acc.close()
+    print(f"map epoch: {merged} sweeps merged, map {n0} -> {len(new_c) + len(new_s)} points; epoch-1 position error {worst:.4f} m (frozen epoch-0 map: {ref_err:.4f} m)")

@@ -58,9 +58,10 @@ def main():
     ap.add_argument("--repeat", type=int, default=5, help="repeat the timed window this many times (fresh handles, same sweeps): value_median / value_min / value_max; `value` is the first window")
     ap.add_argument("--ab-pcie", default=None, help="diagnostic: like --ab, but each variant runs the PCIe-inclusive window")
     ap.add_argument("--ab", default=None, help="diagnostic: ';'-separated environment variants ('A=1 B=2;C=3;' — empty = defaults) timed inside this process before the contract's window, one line each on stderr")
-    ap.add_argument("--long-steps", type=int, default=0,
-                    help="N > 0: an additional window of N steps (needs N more staged sweeps per stream: ~1 s of host time per 50) reported as "
-                         "value_long — long enough for an external sampler (rocm-smi) to see the GPU busy")
+    ap.add_argument("--long-steps", type=int, default=400,
+                    help="N > 0 (default 400; single rank, with the CPU baseline only): an additional window of N steps over a trajectory of its own, "
+                         "reported as value_long — ~0.2 s of device time, twice (timed, then once more for the iteration counts), so that an external "
+                         "sampler (rocm-smi) can see the GPU busy; costs ~60 s of host time for the sweeps; 0 = skip")
     ap.add_argument("--no-live-nodes", action="store_true", help="live mode: skip the additional run with the three entry points as concurrent nodes")
     ap.add_argument("--mode", default="batched", choices=["batched", "live"],
                     help="live: sequential SLAM (BASELINE configs[1]: VLP-16, 200 k-pt live map, one sweep in flight, host clouds in / out)")
@@ -293,30 +294,39 @@ def main():
         return r
 
     def long_window(N):
-        """value_long: the same protocol over N timed steps (N more sweeps per stream are generated and staged for it) — ~0.2 s of device
-        time, long enough for an external sampler to see the GPU busy."""
+        """value_long: the same protocol over N timed steps — ~0.2 s of device time, long enough for an external sampler to see the GPU
+        busy.  Its sweeps are generated for it: the short window's trajectory (1 m and 0.5 degrees per sweep, a circle of 115 m radius)
+        leaves the 250 m world after ~100 sweeps, so the long one turns tighter (1.43 degrees per sweep: a 40 m circle that stays inside
+        the map).  The iteration counts of the long window are reported with it — they, not the window length, are what makes its
+        sweeps cheaper or dearer than the short window's."""
         nonlocal sweeps, T, T_all, K
         T_l = 1 + W + N + LOOK
         jobs_l = []
         for s_, gs in enumerate(lxdist.stream_ids(rank, world, ns)):
-            poses = synth.trajectory(T_l, start=lxdist.stream_start(gs))
-            for t in range(T_all, T_l):
+            poses = synth.trajectory(T_l, yaw_step_deg=1.43, start=lxdist.stream_start(gs))
+            for t in range(T_l):
                 jobs_l.append((t, s_, (125.0, args.sensor, poses[t], poses[t + 1], 1000 * gs + t)))
         import multiprocessing as mp
         from concurrent.futures import ProcessPoolExecutor
         with ProcessPoolExecutor(max_workers=n_workers, mp_context=mp.get_context("spawn")) as ex:
             made_l = list(ex.map(synth.make_sweep_job, [j[2] for j in jobs_l], chunksize=max(1, len(jobs_l) // (4 * n_workers))))
         keep = (sweeps, T, T_all, K)
-        sweeps = sweeps + [[None] * ns for _ in range(T_l - T_all)]
+        sweeps = [[None] * ns for _ in range(T_l)]
         for (t, s_, _), (pts, rs) in zip(jobs_l, made_l):
             sweeps[t][s_] = (pts, rs)
         T, T_all, K = 1 + W + N, T_l, N
         try:
             w_ = resident_window()
+            per_step = []
+            resident_window(collect=per_step)   # (untimed: the iteration counts of every stream and step)
         finally:
             sweeps, T, T_all, K = keep
+        timed_rows = [r for r in per_step if r[0] >= 1 + W]
         return {"value": round(world * ns * N / w_["elapsed"], 2), "unit": "sweeps/s", "steps": N, "ms_per_step": round(w_["elapsed"] / N * 1e3, 4),
-                "seconds": round(w_["elapsed"], 4), "note": "same window protocol as `value` over a longer trajectory"}
+                "seconds": round(w_["elapsed"], 4),
+                "mean_odom_iterations": round(float(np.mean([r[4] for r in timed_rows])), 2), "mean_map_iterations": round(float(np.mean([r[5] for r in timed_rows])), 2),
+                "note": "same window protocol as `value` over a longer trajectory of its own (40 m circle inside the map; the short window's 115 m "
+                        "circle leaves the synthetic world after ~100 sweeps)"}
 
     # ---- diagnostic: environment variants inside one process (same data, same box): --ab "A=1;B=2 C=3;"
     if args.ab is not None and world == 1:
@@ -464,7 +474,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 6),
                 "traffic": pmc_traffic(),
                 "traffic_note": "bytes of one launch with every sweep still iterating (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc "
-                                "passes of this command, profiles/r03_pmc_summary.json); achieved / avg_launch_us average over all timed "
+                                "passes of this command, profiles/r04_pmc_summary.json); achieved / avg_launch_us average over all timed "
                                 "launches incl. the short ones after most sweeps have converged",
                 "model": "72 B per query-iteration = 12 B query + 5 x 12 B neighbours (SURVEY.md §8d); the launch also fits edges / planes, "
                          "forms the 28 normal-equation sums and runs the 6x6 update step",
@@ -838,7 +848,7 @@ def roofline_kernels(main, ns):
 
 def pmc_traffic():
     """HBM bytes per full launch of the dominant kernel from the committed PMC passes of this same command
-    (profiles/r03_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs, FETCH_SIZE
+    (profiles/r04_pmc_summary.json, else the previous round's: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs, FETCH_SIZE
     doubled per MI355X_MICROARCH.md).  bench.py cannot run the profiler on itself, so the figure is read, not measured
     live; None when the file is missing."""
     for name in ("r04_pmc_summary.json", "r03_pmc_summary.json"):
@@ -848,11 +858,6 @@ def pmc_traffic():
         except (OSError, KeyError, ValueError):
             continue
     return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")) as f:
-            return json.load(f)["k_gn_iter_full_launch"]["traffic_bytes"]
-    except (OSError, KeyError, ValueError):
-        return None
 
 
 def _stats(x):

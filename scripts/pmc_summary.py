@@ -46,7 +46,7 @@ def main():
            'units': 'FETCH_SIZE / WRITE_SIZE in KiB as reported by rocprofv3; fetch_bytes_corrected = 2 x FETCH_SIZE x 1024 '
                     '(MI355X_MICROARCH.md, HBM section: upper estimate for gather patterns)',
            'kernels': kernels}
-    for tag, key in (('k_gn_iter', 'k_gn_iter_full_launch'), ('k_knn5', 'k_knn5_full_search_launch'), ('k_vox_ds_seg', 'k_vox_ds_seg_launch'), ('k_feat_lf_voxel', 'k_feat_lf_voxel_launch'), ('k_odom_corr', 'k_odom_corr_launch'), ('k_vb_reduce', 'k_vb_reduce_launch'),
+    for tag, key in (('k_gn_iter', 'k_gn_iter_full_launch'), ('k_knn5', 'k_knn5_full_search_launch'), ('k_vox_ds_seg', 'k_vox_ds_seg_launch'), ('k_feat_lf_voxel', 'k_feat_lf_voxel_launch'), ('k_odom_corr_grid', 'k_odom_corr_grid_launch'), ('k_vb_reduce', 'k_vb_reduce_launch'), ('k_feat_ring', 'k_feat_ring_launch'),
                      ('k_vb_stack', 'k_vb_stack_launch'), ('k_odom_lm', 'k_odom_lm_launch')):
         kn = [k for k in kernels if tag in k]
         if kn:

@@ -7,8 +7,9 @@ tag=$1
 root=$(pwd); out=$root/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 ( timeout 900 python -m pytest tests -m gpu -q --timeout 300 2>&1 | tail -30 ) > $out/gpu_tests.log; tail -2 $out/gpu_tests.log
-timeout 600 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.json; echo
-SKIP_PLAIN_BENCH=1 scripts/gpu_profile.sh ${tag}_prof > /dev/null 2>&1; cp gpurun_out/${tag}_prof/kernel_stats.csv gpurun_out/${tag}_prof/kernels.txt gpurun_out/${tag}_prof/chain.txt $out/ 2>/dev/null
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 ) > $out/smoke.log; tail -1 $out/smoke.log
+timeout 900 python bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; tail -c 400 $out/bench.json; echo
+SKIP_PLAIN_BENCH=1 scripts/gpu_profile.sh ${tag}_prof > /dev/null 2>&1; cp gpurun_out/${tag}_prof/kernel_stats.csv gpurun_out/${tag}_prof/kernels.txt gpurun_out/${tag}_prof/chain.txt gpurun_out/${tag}_prof/chain_by_registration.txt $out/ 2>/dev/null
 scripts/gpu_pmc.sh ${tag}_pmc > $out/pmc.log 2>&1; cp gpurun_out/${tag}_pmc/pmc_summary.json $out/ 2>/dev/null; tail -3 $out/pmc.log
 LOAMX_NO_LOOKAHEAD=1 scripts/gpu_trace_raw.sh ${tag}_seq > /dev/null 2>&1; cp gpurun_out/${tag}_seq/summary.txt $out/sequential_summary.txt 2>/dev/null
 scripts/gpu_live_profile.sh ${tag}_live1 > $out/live_vlp16.log 2>&1; tail -c 300 gpurun_out/${tag}_live1/bench.json; echo

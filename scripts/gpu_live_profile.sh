@@ -11,5 +11,5 @@ kt=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
 cp "$ks" $out/kernel_stats.csv 2>/dev/null
 python $root/scripts/trace_summary.py "$kt" 150 > $out/summary.txt 2>&1
 cd $root
-timeout 300 python bench.py --mode live --steps 20 --warmup 3 "$@" > $out/bench.json 2> $out/bench.err
+timeout 600 python bench.py --mode live --steps 100 --warmup 10 "$@" > $out/bench.json 2> $out/bench.err
 tail -c 1500 $out/bench.json; echo; head -28 $out/summary.txt

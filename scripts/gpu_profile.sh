@@ -16,6 +16,7 @@ ks=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
 cp "$ks" $out/kernel_stats.csv 2>/dev/null
 python $root/scripts/prof_kernels.py "$kt" 40 > $out/kernels.txt 2>&1
 python $root/scripts/prof_chain.py "$kt" v > $out/chain.txt 2>&1
+python $root/scripts/prof_chain.py "$kt" v k_pose_init > $out/chain_by_registration.txt 2>&1   # (the window between two registrations' first kernels)
 cd $root
 if [ -z "${SKIP_PLAIN_BENCH:-}" ]; then
   timeout 300 python bench.py --steps 20 --warmup 5 "$@" > $out/bench.json 2> $out/bench.err

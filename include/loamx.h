@@ -65,7 +65,7 @@ const char* loamx_last_error(void);
 /* number of visible HIP devices (0 if none / HIP unavailable); never fails */
 int loamx_device_count(void);
 /* ABI version of this header */
-#define LOAMX_ABI_VERSION 3
+#define LOAMX_ABI_VERSION 4
 int loamx_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ def test_exports_every_declared_symbol():
     assert len(names) >= 50
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, f"declared in include/loamx.h but not exported: {missing}"
-    assert L.loamx_abi_version() == 3
+    assert L.loamx_abi_version() == 4
 
 
 def test_no_oracle_in_product():

@@ -725,9 +725,13 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
         stage_args.append((CA, RP, NR, pts, rings))
     out_args = [(loamx.Cloud * ns)(*[loamx.cloud_of(a) for a in outs[k]]) for k in range(2)]
 
+    stage_s = []
+
     def stage(t):
         CA, RP, NR, _, _ = stage_args[t]
+        ts0 = time.perf_counter()
         rc_ = L.loamx_pipeline_stage_step(p.h, t, CA, RP, NR)
+        stage_s.append(time.perf_counter() - ts0)
         if rc_ < 0:
             raise RuntimeError(L.loamx_last_error().decode())
 
@@ -765,6 +769,7 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
     p.wait_downloads()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     elapsed = lxdist.max_over_ranks(elapsed, dist, dev)
     n_direct, n_hip = p.download_counts()
     world = dist.get_world_size() if dist is not None else 1
@@ -778,7 +783,9 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
         "h2d_ms_per_step": round(h2d_b / (bw["h2d"] * 1e9) * 1e3, 4), "d2h_ms_per_step": round(d2h_b / (bw["d2h"] * 1e9) * 1e3, 4),
         "achieved_gbps_each_way": round(h2d_b / (elapsed / K) / 1e9, 2),
         "downloads": {"sdma_direct": n_direct, "hipMemcpyAsync": n_hip},
-        "host_ms_per_step": {"inside_step": round(host[0] / K * 1e3, 4), "waiting_for_the_stager": round(host[1] / K * 1e3, 4), "download_call": round(host[2] / K * 1e3, 4)},
+        "host_ms_per_step": {"inside_step": round(host[0] / K * 1e3, 4), "waiting_for_the_stager": round(host[1] / K * 1e3, 4), "download_call": round(host[2] / K * 1e3, 4),
+                             "stage_call_on_the_stager_thread": round(float(np.mean(stage_s[AHEAD:])) * 1e3, 4) if len(stage_s) > AHEAD else None,
+                             "window_close": round((elapsed_local - host.sum()) / K * 1e3, 4)},
         "note": "same workload and steps as `value`, but every step's sweeps cross PCIe inside the timed region (one pinned block per step, copy "
                 "stream, staged seven steps ahead by a second host thread) and every step's registered full-resolution clouds are copied back "
                 "(asynchronous, alternating buffers); steady-state window: not drained at its start, fully drained (downloads landed, device "

@@ -64,8 +64,10 @@ class FeatureExtractor {
   // the same without blocking: every copy goes to `copy_stream` (packed float4 clouds straight from the caller's memory —
   // pinned memory makes that a true DMA — other layouts through this object's pinned staging), `done` is recorded behind
   // them; run_async() must be ordered behind `done`.  The caller's buffers are read until `done` has completed.
+  // big_copy (optional): asked to carry each block copy itself (dst, src, bytes) — true: taken (the caller orders run_async() behind it by
+  // its own means), false: the copy goes to copy_stream as usual
   void upload_async(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings, hipStream_t copy_stream,
-                    hipEvent_t done);
+                    hipEvent_t done, const std::function<bool(void*, const void*, size_t)>& big_copy = nullptr);
   // the same from DEVICE memory (e.g. the output of the raw-sweep binning): sweep s = d_src + src_off[s], rings concatenated;
   // copies device-to-device on `copy_stream`, `done` recorded behind them
   void upload_device(uint32_t nsw, const float4* d_src, const uint32_t* src_off, const uint32_t* const* ring_size, const uint32_t* n_rings,

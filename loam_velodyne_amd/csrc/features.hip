@@ -616,7 +616,7 @@ void FeatureExtractor::check_params_() const {
 
 // host bookkeeping of a batch: ring offsets, sweep bases, longest ring
 void FeatureExtractor::upload_async(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings,
-                                    hipStream_t copy_stream, hipEvent_t done) {
+                                    hipStream_t copy_stream, hipEvent_t done, const std::function<bool(void*, const void*, size_t)>& big_copy) {
   LX_REQUIRE(nsw >= 1 && clouds && ring_size && n_rings && copy_stream && done, "invalid sweep batch");
   check_params_();
   LX_HIP(hipSetDevice(device_));
@@ -637,7 +637,8 @@ void FeatureExtractor::upload_async(uint32_t nsw, const loamx_cloud* clouds, con
       uint32_t e = s + 1;
       size_t cnt = clouds[s].count;
       while (e < nsw && (const char*)clouds[e].data == (const char*)clouds[s].data + sizeof(float4) * cnt) cnt += clouds[e++].count;
-      if (cnt) LX_HIP(hipMemcpyAsync(cloud_.p + h_pt_base_[s], clouds[s].data, sizeof(float4) * cnt, hipMemcpyHostToDevice, copy_stream));
+      if (cnt && !(big_copy && big_copy(cloud_.p + h_pt_base_[s], clouds[s].data, sizeof(float4) * cnt)))
+        LX_HIP(hipMemcpyAsync(cloud_.p + h_pt_base_[s], clouds[s].data, sizeof(float4) * cnt, hipMemcpyHostToDevice, copy_stream));
       s = e;
     }
   } else {

@@ -15,10 +15,9 @@
 
 namespace loamx {
 
-class HostLinkDma {
+template <int SLOTS> class HostLinkT {
  public:
-  static constexpr int SLOTS = 2;
-  ~HostLinkDma() {
+  ~HostLinkT() {
     for (int s = 0; s < SLOTS; s++) {
       if (!made_[s]) continue;
       try { wait(s); } catch (...) {}
@@ -69,6 +68,29 @@ class HostLinkDma {
     }
     if (unissued_[slot]) unissued_[slot]--;
   }
+  // ... and the other direction: pinned host -> device (the pipeline's staging copies; round 4).  A block copy that the HIP runtime
+  // carries on a stream of its own is a FIFTH busy HIP stream next to the four chains — and from five busy streams on every chain of the
+  // process slows down (profiles/r04_groups_ab.md; the odometry passes took 0.7-1.1 ms instead of 0.3-0.6 beside the staging stream).
+  // Issued through ROCr it is no HIP stream at all.  The engine is ROCr's own choice for this direction.
+  bool can_copy_h2d(void* dev_dst, const void* host_src, size_t bytes) {
+    if (!init_()) return false;
+    hsa_agent_t g, c;
+    return owner_(dev_dst, bytes, HSA_DEVICE_TYPE_GPU, &g) && owner_(host_src, bytes, HSA_DEVICE_TYPE_CPU, &c);
+  }
+  bool host_ok(const void* host, size_t bytes) {   // the host side alone (before the destination exists)
+    hsa_agent_t c;
+    return init_() && owner_(host, bytes, HSA_DEVICE_TYPE_CPU, &c);
+  }
+  void copy_h2d(int slot, void* dev_dst, const void* host_src, size_t bytes) {
+    hsa_agent_t g, c;
+    LX_REQUIRE(owner_(dev_dst, bytes, HSA_DEVICE_TYPE_GPU, &g) && owner_(host_src, bytes, HSA_DEVICE_TYPE_CPU, &c), "not ROCr-allocated memory");
+    const hsa_status_t st = hsa_amd_memory_async_copy(dev_dst, g, host_src, c, bytes, 0, nullptr, sig_[slot]);
+    if (st != HSA_STATUS_SUCCESS) {
+      abandon(slot);
+      throw Error(LOAMX_E_HIP, "hsa_amd_memory_async_copy (host -> device) failed (" + std::to_string((int)st) + ")");
+    }
+    if (unissued_[slot]) unissued_[slot]--;
+  }
   uint32_t engine() const { return engine_mask_ == ~0u ? 0u : engine_mask_; }
   bool pending(int slot) const { return pending_[slot]; }
   // blocks until every copy of the slot's group has landed (and is visible to the host)
@@ -114,8 +136,10 @@ class HostLinkDma {
   }
   uint32_t engine_mask_ = ~0u;
   hsa_signal_t sig_[SLOTS] = {};
-  bool made_[SLOTS] = {false, false}, pending_[SLOTS] = {false, false};
-  uint32_t unissued_[SLOTS] = {0, 0};   // copies of the slot's group that have not been handed to ROCr yet
+  bool made_[SLOTS] = {}, pending_[SLOTS] = {};
+  uint32_t unissued_[SLOTS] = {};   // copies of the slot's group that have not been handed to ROCr yet
 };
+using HostLinkDma = HostLinkT<2>;   // the downloads: two alternating buffers
+using HostLinkUp = HostLinkT<8>;    // the staging copies: one slot of the streaming ring each
 
 }  // namespace loamx

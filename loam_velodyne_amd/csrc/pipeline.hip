@@ -113,6 +113,7 @@ class Pipeline {
     bool tm_pending[OR] = {};
     std::atomic<float> ms{0.f};          // length of the chain's most recent timed pass on its HIP stream
     double tr[4] = {0, 0, 0, 0};
+    std::atomic<float> last_us{0.f};     // host time of the chain's most recent pass (LOAMX_PIPE_TRACE)
   };
   static constexpr uint32_t MAX_GROUPS = 16;
   bool use_engine = true;
@@ -147,6 +148,8 @@ class Pipeline {
   bool d2h_pending[2] = {false, false};
   uint64_t downloads_direct = 0, downloads_hip = 0;      // asynchronous downloads issued to the SDMA engine directly / through hipMemcpyAsync
   HostLinkDma hostlink;                                   // the same downloads on the SDMA engine directly (hostlink.cuh)
+  HostLinkUp uplink;                                      // ... and the staging copies of stage_step (slot = t % RING); LOAMX_H2D_DIRECT=0: through HIP
+  uint32_t up_runs[RING] = {};                            // block copies of the slot's step handed to uplink (0: none, the HIP copy stream carried them)
   std::atomic<long> last_step{-1};                        // the last step that has run (-1: none yet)
   std::vector<uint32_t> last_full_off;                   // offsets of the registered clouds of the last step (k-th mapped stream)
   // Raw input (loamx_pipeline_stage_step_raw): per slot the payloads, their binned clouds and what the binning leaves behind
@@ -285,7 +288,11 @@ class Pipeline {
       }
       std::exception_ptr err;
       const int k = c.next.load(std::memory_order_acquire);
-      try { c.tr[0] = tr_us(); run_odometry(c, (uint32_t)k); c.tr[3] = tr_us(); } catch (...) { err = std::current_exception(); }
+      try {
+        const auto tc0 = std::chrono::steady_clock::now();
+        c.tr[0] = tr_us(); run_odometry(c, (uint32_t)k); c.tr[3] = tr_us();
+        c.last_us.store((float)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tc0).count(), std::memory_order_relaxed);
+      } catch (...) { err = std::current_exception(); }
       {
         std::lock_guard<std::mutex> lk(mu);
         if (err) { if (!job_err) job_err = err; o_limit.store(-1, std::memory_order_release); }   // every chain stops; the calling thread rethrows
@@ -406,7 +413,10 @@ class Pipeline {
     finalize_raw(t);
     FeatureExtractor& F = FX(t);
     const uint32_t ns = n_streams_, nring = F.total_rings();
-    if (streaming) LX_HIP(hipStreamWaitEvent(fstream, ev_stage[t % RING], 0));   // this slot's H2D copies
+    if (streaming) {
+      LX_HIP(hipStreamWaitEvent(fstream, ev_stage[t % RING], 0));   // this slot's H2D copies (the tables; the sweeps too unless ROCr carried them)
+      if (up_runs[t % RING]) { uplink.wait((int)(t % RING)); up_runs[t % RING] = 0; }   // (issued a step or more ago)
+    }
     PinBuf<uint32_t>& hb = h_off3[t % OR];
     hb.reserve(3 * (ns + 1) + nring + 2);
     uint32_t* ho[3] = {hb.p, hb.p + (ns + 1), hb.p + 2 * (ns + 1)};
@@ -490,7 +500,42 @@ class Pipeline {
     if (t > 0) finalize_raw(t - 1);
     rawslot[t % RING].raw = false;
     rawslot[t % RING].finalized = true;
-    fx[t % RING]->upload_async(n_streams_, clouds, ring_size, n_rings, cstream, ev_stage[t % RING]);
+    // The sweeps' block copies go to ROCr directly when source and destination are the runtime's own allocations (hostlink.cuh: a copy
+    // stream of the HIP runtime would be a fifth busy HIP stream): the blocks are counted first (the group's size must be known when
+    // it begins), then issued; launch_features() waits for the slot's signal on the host — a whole step later.
+    static const bool direct = !(getenv("LOAMX_H2D_DIRECT") && atoi(getenv("LOAMX_H2D_DIRECT")) == 0);
+    const int slot = (int)(t % RING);
+    up_runs[slot] = 0;
+    uint32_t n_blocks = 0;
+    bool all_direct = direct;
+    if (direct) {   // (the runs of clouds that lie back to back, as upload_async forms them)
+      for (uint32_t s = 0; s < n_streams_ && all_direct;) {
+        all_direct = clouds[s].stride == 16 && clouds[s].intensity_offset == 12;
+        uint32_t e = s + 1;
+        size_t cnt = clouds[s].count;
+        while (all_direct && e < n_streams_ && (const char*)clouds[e].data == (const char*)clouds[s].data + sizeof(float4) * cnt) cnt += clouds[e++].count;
+        if (cnt) { n_blocks++; all_direct = all_direct && uplink.host_ok(clouds[s].data, sizeof(float4) * cnt); }
+        s = e;
+      }
+    }
+    if (all_direct && n_blocks) {
+      uplink.begin(slot, n_blocks);
+      uint32_t issued = 0;
+      try {
+        fx[slot]->upload_async(n_streams_, clouds, ring_size, n_rings, cstream, ev_stage[slot], [&](void* dst, const void* src, size_t bytes) {
+          if (!uplink.can_copy_h2d(dst, src, bytes)) throw Error(LOAMX_E_HIP, "internal: a staging block is not ROCr's memory after all");
+          uplink.copy_h2d(slot, dst, src, bytes);
+          issued++;
+          return true;
+        });
+      } catch (...) {
+        uplink.abandon(slot);
+        throw;
+      }
+      up_runs[slot] = issued;
+    } else {
+      fx[slot]->upload_async(n_streams_, clouds, ring_size, n_rings, cstream, ev_stage[slot]);
+    }
     LA(t) = 0;
     staged_hi.store(t + 1, std::memory_order_release);
   }
@@ -916,7 +961,9 @@ class Pipeline {
         if (!adopted) {
           if (reg.double_buffer_full) {   // this run reuses the buffer of the run before last: its download must have finished
             const int par = (int)(run_count & 1);
+            const double tw0 = trace ? tr_us() : 0.0;
             hostlink.wait(par);   // (two steps old: landed long ago)
+            if (trace) trM[4] = tr_us() - tw0;
             if (d2h_pending[par]) { LX_HIP(hipStreamWaitEvent(s_, ev_d2h[par], 0)); d2h_pending[par] = false; }
           }
           float4* full_dst = reg.stage_full(nw, nfr.data());
@@ -984,9 +1031,10 @@ class Pipeline {
     last_step = (long)t;
     tr_exit = std::chrono::steady_clock::now();
     if (trace) {
-      fprintf(stderr, "[pipe t=%u] caller gap %.0f | M-start %.0f  M-enqueued %.0f  M-downloaded %.0f  O-joined %.0f |", t, gap_us, trM[0], trM[1], trM[2], trM[3]);
+      fprintf(stderr, "[pipe t=%u] caller gap %.0f | M-start %.0f  M-enqueued %.0f  M-downloaded %.0f  O-joined %.0f  (download-wait %.0f) |", t, gap_us, trM[0], trM[1], trM[2], trM[3], trM[4]);
       for (auto& c : chains)   // (each chain's most recent pass, whichever step that was: start, features ready, process() returned, end)
-        fprintf(stderr, " O[%u-%u): %.0f %.0f %.0f %.0f |", c->s0, c->s1, c->tr[0], c->tr[1], c->tr[2], c->tr[3]);
+        fprintf(stderr, " O[%u-%u): %.0f %.0f %.0f %.0f done %d pass %.0f us |", c->s0, c->s1, c->tr[0], c->tr[1], c->tr[2], c->tr[3], c->done.load(), (double)c->last_us.load());
+      fprintf(stderr, " f_hi %d o_limit %d staged %u", f_hi, o_limit.load(), n_staged());
       fprintf(stderr, "\n");
     }
     if (timing) {

@@ -324,8 +324,6 @@ def test_streaming_io_equals_staged_run(orc, small_world, ahead, pinned):
         ref_full.append([a.download_full_res(k, len(sweeps[t][k][0])) for k in range(ns)] if rc == loamx.OK else None)
     b = make()
     b.enable_async_downloads()
-    for t in range(min(ahead, T)):
-        b.stage_step(t, sweeps[t])
     if pinned:
         import ctypes as C
         hip = C.CDLL("libamdhip64.so")
@@ -334,6 +332,21 @@ def test_streaming_io_equals_staged_run(orc, small_world, ahead, pinned):
             ptr = C.c_void_p()
             assert hip.hipHostMalloc(C.byref(ptr), C.c_size_t(rows * 16), C.c_uint(0)) == 0
             return np.ctypeslib.as_array((C.c_float * (rows * 4)).from_address(ptr.value)).reshape(rows, 4)
+        # ... and the sweeps come from pinned memory of the runtime's own, one block per step: the staging copies go through ROCr too
+        staged = []
+        for t in range(T):
+            blk = pinned_array(sum(len(sweeps[t][s][0]) for s in range(ns)))
+            row, views = 0, []
+            for s in range(ns):
+                n = len(sweeps[t][s][0])
+                blk[row:row + n] = sweeps[t][s][0]
+                views.append((blk[row:row + n], sweeps[t][s][1]))
+                row += n
+            staged.append(views)
+        sweeps = staged
+    for t in range(min(ahead, T)):
+        b.stage_step(t, sweeps[t])
+    if pinned:
         outs = [[pinned_array(len(sweeps[0][k][0]) + 8) for k in range(ns)] for _ in range(2)]   # (left to the process' exit)
     else:
         outs = [[np.zeros((len(sweeps[0][k][0]) + 8, 4), np.float32) for k in range(ns)] for _ in range(2)]

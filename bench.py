@@ -538,7 +538,7 @@ def run_live(args):
         full = od.transform_to_end(f["full"])
         c = time.perf_counter()
         mp.update_odometry(od.transform_sum)
-        mp.process(lc, ls, full)
+        mp.process(lc, ls, full, inplace=True)   # (full is transform_to_end's own array: registered where it lies, as the C entry point does)
         d = time.perf_counter()
         if t >= 1 + W:
             stage += [b - a, c - b, d - c]
@@ -608,7 +608,7 @@ def run_live(args):
             if t == 1 + W:
                 tn0 = time.perf_counter()
             mp2.update_odometry(item[3])
-            mp2.process(item[0], item[1], item[2])
+            mp2.process(item[0], item[1], item[2], inplace=True)
         torch.cuda.synchronize()
         tn1 = time.perf_counter()
         for x in th:

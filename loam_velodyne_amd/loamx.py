@@ -308,7 +308,7 @@ class ScanRegistration:
         _check(lib().loamx_scanreg_process(self.h, C.byref(cin), rs.ctypes.data_as(C.c_void_p), len(rs), C.byref(cl[0]),
                                            C.byref(cl[1]), C.byref(cl[2]), C.byref(cl[3])))
         res = {name: outs[k][:cl[k].count].copy() for k, name in enumerate(self.NAMES)}
-        res["full"] = pts[:, :4].copy() if pts.shape[1] == 4 else pts
+        res["full"] = pts   # laserCloud(): the input itself (binned rings already); read-only for the consumers here
         return res
 
     def update_imu(self, stamp, roll, pitch, yaw, acc):
@@ -444,11 +444,12 @@ class LaserMapping:
         """the laserOdometryTime argument of process()"""
         _check(lib().loamx_map_set_time(self.h, C.c_double(t)))
 
-    def process(self, corner_last, surf_last, full_res=None):
+    def process(self, corner_last, surf_last, full_res=None, inplace=False):
+        """inplace: register full_res where it lies (what the C entry point does) instead of in a copy"""
         c, s = as_points(corner_last), as_points(surf_last)
         cc, sc = cloud_of(c), cloud_of(s)
         if full_res is not None:
-            f = as_points(full_res).copy()
+            f = as_points(full_res) if inplace else as_points(full_res).copy()
             fc = cloud_of(f)
             rc = _check(lib().loamx_map_process(self.h, C.byref(cc), C.byref(sc), C.byref(fc)))
             return rc, f

@@ -99,6 +99,110 @@ __device__ inline void mark_as_picked(uint32_t scan_i, int cr, uint8_t* flags, c
   wave_lds_sync();
 }
 
+// The same, for a region whose picks run beside the other regions' (k_feat_ring): marks inside the wave's own region [r_lo, r_hi) go to
+// `flags`, marks beyond its end go to `fwd` (they matter to the NEXT region only), marks in front of its start are dropped — the
+// region before has made its picks before this one in the reference's order, so they can no longer change anything.
+__device__ inline void mark_as_picked_split(uint32_t scan_i, int cr, uint8_t* flags, uint8_t* fwd, const uint8_t* gaps, int lane, uint32_t r_lo,
+                                            uint32_t r_hi) {
+  bool brk = false;
+  if (lane < cr) brk = gaps[scan_i + lane] != 0;
+  else if (lane >= 32 && lane < 32 + cr) brk = gaps[scan_i - (lane - 32) - 1] != 0;
+  const unsigned long long m = __ballot(brk);
+  const uint32_t mf = (uint32_t)(m & 0xffffffffull), mb = (uint32_t)(m >> 32);
+  const int nf = mf ? __builtin_ctz(mf) : cr;
+  const int nb = mb ? __builtin_ctz(mb) : cr;
+  if (lane == 0) flags[scan_i] = 1;
+  if (lane < nf) {
+    const uint32_t t = scan_i + lane + 1;
+    if (t < r_hi) flags[t] = 1;
+    else fwd[t] = 1;
+  }
+  if (lane >= 32 && lane - 32 < nb) {
+    const uint32_t t = scan_i - (lane - 32) - 1;
+    if (t >= r_lo) flags[t] = 1;
+  }
+  wave_lds_sync();
+}
+
+// The order-dependent greedy picks of ONE region by one wave (BasicScanRegistration.cpp:197-235): corners from the largest curvature
+// down, then flat points from the smallest up; 64 lanes test the next 64 candidates in sorted order, a ballot finds the first
+// admissible one, its neighbours are suppressed before the next round.  The picks go to the region's own slots of the pick lists
+// (outS / outLS / outF) and their counts to cnt3[0..2].  fwd == nullptr: every mark goes to `flags` (the sequential walk over the regions).
+__device__ inline void region_picks(const FeatParams& P, int cr, uint32_t rn, uint32_t rgsp, uint32_t rscan, const float* rc, const uint32_t* rsorted,
+                                    int8_t* rlabel, uint8_t* flags, uint8_t* fwd, const uint8_t* gaps, uint32_t* outS, uint32_t* outLS, uint32_t* outF,
+                                    uint32_t* cnt3, int lane) {
+  const uint32_t r_lo = rscan, r_hi = rscan + rn;
+  uint32_t nS = 0, nLS = 0, nF = 0;
+  {
+    int picked = 0;
+    int pos = (int)rn;
+    while (pos > 0 && picked < P.max_less_sharp) {
+      const int kk = pos - 1 - lane;
+      const bool in = kk >= 0;
+      const uint32_t e = in ? rsorted[kk] : 0u;
+      const float ce = in ? rc[e] : 0.f;
+      const bool above = in && (ce > P.curv_thr);
+      const bool ok = above && flags[rscan + e] == 0;
+      const unsigned long long mok = __ballot(ok), mstop = __ballot(in && !above);
+      const int fo = mok ? __builtin_ctzll(mok) : 64, fs = mstop ? __builtin_ctzll(mstop) : 64;
+      if (fo < fs) {
+        const uint32_t pe = __shfl(e, fo, 64);
+        picked++;
+        if (lane == 0) {
+          if (picked <= P.max_sharp) {
+            rlabel[pe] = 2;
+            outS[nS] = rgsp + pe;
+          } else {
+            rlabel[pe] = 1;
+          }
+          outLS[nLS] = rgsp + pe;
+        }
+        if (picked <= P.max_sharp) nS++;
+        nLS++;
+        if (fwd) mark_as_picked_split(rscan + pe, cr, flags, fwd, gaps, lane, r_lo, r_hi);
+        else mark_as_picked(rscan + pe, cr, flags, gaps, lane);
+        pos = pos - 1 - fo;
+      } else if (fs < 64) {
+        break;   // sorted: nothing further exceeds the threshold
+      } else {
+        pos -= 64;
+      }
+    }
+  }
+  {
+    int picked = 0;
+    int pos = 0;
+    while (pos < (int)rn && picked < P.max_flat) {
+      const int kk = pos + lane;
+      const bool in = kk < (int)rn;
+      const uint32_t e = in ? rsorted[kk] : 0u;
+      const float ce = in ? rc[e] : 0.f;
+      const bool below = in && (ce < P.curv_thr);
+      const bool ok = below && flags[rscan + e] == 0;
+      const unsigned long long mok = __ballot(ok), mstop = __ballot(in && !below);
+      const int fo = mok ? __builtin_ctzll(mok) : 64, fs = mstop ? __builtin_ctzll(mstop) : 64;
+      if (fo < fs) {
+        const uint32_t pe = __shfl(e, fo, 64);
+        picked++;
+        if (lane == 0) {
+          rlabel[pe] = -1;
+          outF[nF] = rgsp + pe;
+        }
+        nF++;
+        if (fwd) mark_as_picked_split(rscan + pe, cr, flags, fwd, gaps, lane, r_lo, r_hi);
+        else mark_as_picked(rscan + pe, cr, flags, gaps, lane);
+        pos = pos + fo + 1;
+      } else if (fs < 64) {
+        break;
+      } else {
+        pos += 64;
+      }
+    }
+  }
+  if (lane == 0) { cnt3[0] = nS; cnt3[1] = nLS; cnt3[2] = nF; }
+  wave_lds_sync();
+}
+
 // One wave sorts up to 64 * KPL unique 64-bit keys (curvature bits << 32 | position) entirely in registers: element i of the
 // network lives in lane i / KPL, register i % KPL.  Compare-exchanges whose partner distance is below KPL stay inside the lane;
 // the others swap whole registers with the partner lane by shuffles — no LDS round trip and no fence per stage (the LDS version
@@ -174,13 +278,17 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint8_t* flags = (uint8_t*)smem;
   uint8_t* gaps = flags + flag_bytes;
-  // picked point indices (global); the points themselves are copied out after the sequential part
-  uint32_t* pickS = (uint32_t*)(smem + 2 * (size_t)flag_bytes);
+  uint8_t* fwd = gaps + flag_bytes;   // marks a region's picks leave BEYOND its end (they concern the next region only)
+  // picked point indices (global), region j's in its own slots [j * max, (j + 1) * max) of the three lists, compacted in region order
+  // at the end; the points themselves are copied out after that
+  uint32_t* pickS = (uint32_t*)(smem + 3 * (size_t)flag_bytes);
   uint32_t* pickLS = pickS + P.max_sharp * P.n_regions;
   uint32_t* pickF = pickLS + P.max_less_sharp * P.n_regions;
-  char* wave_base = smem + ((2 * (size_t)flag_bytes + 4 * (size_t)((P.max_sharp + P.max_less_sharp + P.max_flat) * P.n_regions) + 15) & ~(size_t)15);
+  char* wave_base = smem + ((3 * (size_t)flag_bytes + 4 * (size_t)((P.max_sharp + P.max_less_sharp + P.max_flat) * P.n_regions) + 15) & ~(size_t)15);
   const size_t wave_bytes = (size_t)nmax * 9;
   __shared__ uint32_t reg_n[FEAT_WAVES], reg_gsp[FEAT_WAVES], reg_scan[FEAT_WAVES], npick[3];
+  __shared__ uint32_t rcnt[64][3];    // picks per region (n_regions <= 64)
+  __shared__ int s_simple;
 
   const uint32_t r = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -196,6 +304,19 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu
     for (uint32_t k = tid; k < len; k += blockDim.x) {
       flags[k] = gflags[s0g + k];
       gaps[k] = k + 1 < len ? ggap[s0g + k] : 1;
+      fwd[k] = 0;
+    }
+    if (tid < 64) { rcnt[tid][0] = 0; rcnt[tid][1] = 0; rcnt[tid][2] = 0; }
+    if (tid == 0) {
+      // Regions side by side need every region to hold at least curv_region points: a pick's marks then reach into the NEXT region at
+      // most.  Shorter (or skipped) regions — rings of a few dozen points — take the sequential walk.
+      int simple = 1;
+      for (int j = 0; j < nreg; j++) {
+        const unsigned long long sp = ((s0 + cr) * (unsigned long long)(nreg - j) + (e0 - cr) * (unsigned long long)j) / nreg;
+        const unsigned long long ep = ((s0 + cr) * (unsigned long long)(nreg - 1 - j) + (e0 - cr) * (unsigned long long)(j + 1)) / nreg - 1;
+        if (!(ep > sp) || ep - sp + 1 < (unsigned long long)cr) simple = 0;
+      }
+      s_simple = simple;
     }
     float* c = (float*)(wave_base + wid * wave_bytes);
     uint32_t* sorted = (uint32_t*)(c + nmax);
@@ -248,82 +369,52 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu
       }
       __syncthreads();
       FT_TS(2);
-      // the order-dependent greedy picks: wave 0 walks the regions of this group in order
-      if (wid == 0) {
+      // The order-dependent greedy picks.  In the reference the regions of a ring are walked one after the other and a pick suppresses
+      // its +-curv_region neighbours in a flag array of the whole RING (:367-386) — so a region is not independent of the one before it:
+      // marks of picks near that region's end reach into this one's first points.  Nothing else couples them.  So every wave makes
+      // the picks of its own region at once, as if no such marks came in, and leaves the marks that go out beyond its end in `fwd`;
+      // then the boundaries are settled in order: a region is made again (by wave 0, with the incoming marks in place) exactly when one
+      // of the points it picked carries a mark of the — by then final — region before it.  An incoming mark on a point that was
+      // not picked cannot change anything: the walk skipped it or never reached it.  Bit-identical to the sequential walk
+      // (tests/test_gpu_features.py), which rings with regions shorter than curv_region still take.
+      if (s_simple) {
+        const uint32_t rn = reg_n[wid];
+        if (rn) {
+          if (wid == 0 && jb > 0)   // the previous group's last region is final: its marks come first
+            for (uint32_t e = lane; e < (uint32_t)cr && e < rn; e += 64) flags[reg_scan[0] + e] |= fwd[reg_scan[0] + e];
+          wave_lds_sync();
+          region_picks(P, cr, rn, reg_gsp[wid], reg_scan[wid], c, sorted, label, flags, fwd, gaps, pickS + (size_t)j * P.max_sharp,
+                       pickLS + (size_t)j * P.max_less_sharp, pickF + (size_t)j * P.max_flat, rcnt[j], lane);
+        }
+        __syncthreads();
+        if (wid == 0) {
+          for (int w = 1; w < FEAT_WAVES && jb + w < nreg; w++) {
+            const uint32_t rn2 = reg_n[w], rscan2 = reg_scan[w], rgsp2 = reg_gsp[w];
+            const float* rc = (const float*)(wave_base + w * wave_bytes);
+            const uint32_t* rsorted = (const uint32_t*)(rc + nmax);
+            int8_t* rlabel = (int8_t*)(rsorted + nmax);
+            const bool hit = lane < cr && (uint32_t)lane < rn2 && fwd[rscan2 + lane] != 0 && rlabel[lane] != 0;
+            if (__ballot(hit)) {   // one of its picks was not admissible: again, with the marks of the region before it in place
+              for (uint32_t e = lane; e < rn2; e += 64) {
+                flags[rscan2 + e] = gflags[s0g + rscan2 + e] | (e < (uint32_t)cr ? fwd[rscan2 + e] : (uint8_t)0);
+                rlabel[e] = 0;
+              }
+              for (uint32_t e = lane; e < (uint32_t)cr; e += 64) fwd[rscan2 + rn2 + e] = 0;   // (its own marks beyond its end: made anew)
+              wave_lds_sync();
+              region_picks(P, cr, rn2, rgsp2, rscan2, rc, rsorted, rlabel, flags, fwd, gaps, pickS + (size_t)(jb + w) * P.max_sharp,
+                           pickLS + (size_t)(jb + w) * P.max_less_sharp, pickF + (size_t)(jb + w) * P.max_flat, rcnt[jb + w], lane);
+            }
+          }
+        }
+      } else if (wid == 0) {
         for (int w = 0; w < FEAT_WAVES && jb + w < nreg; w++) {
-          const uint32_t rn = reg_n[w];
-          if (rn == 0) continue;
-          const uint32_t rgsp = reg_gsp[w], rscan = reg_scan[w];
+          const uint32_t rn2 = reg_n[w];
+          if (rn2 == 0) continue;
           const float* rc = (const float*)(wave_base + w * wave_bytes);
           const uint32_t* rsorted = (const uint32_t*)(rc + nmax);
           int8_t* rlabel = (int8_t*)(rsorted + nmax);
-          // corner picks from the largest curvature down (:197-217)
-          {
-            int picked = 0;
-            int pos = (int)rn;
-            while (pos > 0 && picked < P.max_less_sharp) {
-              const int kk = pos - 1 - lane;
-              const bool in = kk >= 0;
-              const uint32_t e = in ? rsorted[kk] : 0u;
-              const float ce = in ? rc[e] : 0.f;
-              const bool above = in && (ce > P.curv_thr);
-              const bool ok = above && flags[rscan + e] == 0;
-              const unsigned long long mok = __ballot(ok), mstop = __ballot(in && !above);
-              const int fo = mok ? __builtin_ctzll(mok) : 64, fs = mstop ? __builtin_ctzll(mstop) : 64;
-              if (fo < fs) {
-                const uint32_t pe = __shfl(e, fo, 64);
-                picked++;
-                if (lane == 0) {
-                  if (picked <= P.max_sharp) {
-                    rlabel[pe] = 2;
-                    pickS[nS] = rgsp + pe;
-                  } else {
-                    rlabel[pe] = 1;
-                  }
-                  pickLS[nLS] = rgsp + pe;
-                }
-                if (picked <= P.max_sharp) nS++;
-                nLS++;
-                mark_as_picked(rscan + pe, cr, flags, gaps, lane);
-                pos = pos - 1 - fo;
-              } else if (fs < 64) {
-                break;   // sorted: nothing further exceeds the threshold
-              } else {
-                pos -= 64;
-              }
-            }
-          }
-          // flat picks from the smallest curvature up (:220-235)
-          {
-            int picked = 0;
-            int pos = 0;
-            while (pos < (int)rn && picked < P.max_flat) {
-              const int kk = pos + lane;
-              const bool in = kk < (int)rn;
-              const uint32_t e = in ? rsorted[kk] : 0u;
-              const float ce = in ? rc[e] : 0.f;
-              const bool below = in && (ce < P.curv_thr);
-              const bool ok = below && flags[rscan + e] == 0;
-              const unsigned long long mok = __ballot(ok), mstop = __ballot(in && !below);
-              const int fo = mok ? __builtin_ctzll(mok) : 64, fs = mstop ? __builtin_ctzll(mstop) : 64;
-              if (fo < fs) {
-                const uint32_t pe = __shfl(e, fo, 64);
-                picked++;
-                if (lane == 0) {
-                  rlabel[pe] = -1;
-                  pickF[nF] = rgsp + pe;
-                }
-                nF++;
-                mark_as_picked(rscan + pe, cr, flags, gaps, lane);
-                pos = pos + fo + 1;
-              } else if (fs < 64) {
-                break;
-              } else {
-                pos += 64;
-              }
-            }
-          }
-          wave_lds_sync();
+          region_picks(P, cr, rn2, reg_gsp[w], reg_scan[w], rc, rsorted, rlabel, flags, nullptr, gaps, pickS + (size_t)(jb + w) * P.max_sharp,
+                       pickLS + (size_t)(jb + w) * P.max_less_sharp, pickF + (size_t)(jb + w) * P.max_flat, rcnt[jb + w], lane);
         }
       }
       __syncthreads();
@@ -332,6 +423,29 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu
       for (uint32_t e = lane; e < n; e += 64) lf_valid[gsp + e] = label[e] <= 0 ? 1 : 0;
       __syncthreads();
     }
+  }
+  // the regions' pick lists, one behind the other in region order (wave 0; a list only ever moves towards the front)
+  if (wid == 0 && len > 2u * cr + 1u) {
+    uint32_t* lists[3] = {pickS, pickLS, pickF};
+    const uint32_t per[3] = {(uint32_t)P.max_sharp, (uint32_t)P.max_less_sharp, (uint32_t)P.max_flat};
+    uint32_t tot[3] = {0, 0, 0};
+    for (int j = 0; j < nreg; j++) {
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const uint32_t cnt = rcnt[j][q], src = (uint32_t)j * per[q];
+        if (src != tot[q]) {
+          for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint32_t v = k < cnt ? lists[q][src + k] : 0u;
+            wave_lds_sync();
+            if (k < cnt) lists[q][tot[q] + k] = v;
+            wave_lds_sync();
+          }
+        }
+        tot[q] += cnt;
+      }
+    }
+    nS = tot[0]; nLS = tot[1]; nF = tot[2];
   }
   if (tid == 0) {
     cntS[r] = nS;
@@ -915,7 +1029,7 @@ void FeatureExtractor::run_async() {
   const uint32_t nmax = (max_ring_len_ / (uint32_t)params.n_regions + 8u + 15u) & ~15u;
   uint32_t sortP = 64;   // bitonic sort size of one region
   while (sortP < nmax) sortP <<= 1;
-  const size_t lds = ((2 * (size_t)flag_bytes + 4 * (size_t)(caps[0] + caps[1] + caps[2]) + 15) & ~(size_t)15) + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) +
+  const size_t lds = ((3 * (size_t)flag_bytes + 4 * (size_t)(caps[0] + caps[1] + caps[2]) + 15) & ~(size_t)15) + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) +
                      (sortP > 512 ? (size_t)FEAT_WAVES * sortP * 8 : 0) + 16;   // (regions of up to 512 points are sorted in registers)
   LX_REQUIRE(lds <= 160 * 1024, "scan ring too long for the LDS staging of k_feat_ring");
   if (lds > 64 * 1024)

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu
     const float* __restrict__ curv, const uint8_t* __restrict__ gflags, const uint8_t* __restrict__ ggap, uint32_t flag_bytes,
     uint32_t nmax, uint32_t sortP, float4* __restrict__ slotS,
     float4* __restrict__ slotLS, float4* __restrict__ slotF, uint32_t* __restrict__ cntS, uint32_t* __restrict__ cntLS,
-    uint32_t* __restrict__ cntF, uint8_t* __restrict__ lf_valid) {
+    uint32_t* __restrict__ cntF, uint8_t* __restrict__ lf_valid, int force_sequential) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint8_t* flags = (uint8_t*)smem;
   uint8_t* gaps = flags + flag_bytes;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu
         const unsigned long long ep = ((s0 + cr) * (unsigned long long)(nreg - 1 - j) + (e0 - cr) * (unsigned long long)(j + 1)) / nreg - 1;
         if (!(ep > sp) || ep - sp + 1 < (unsigned long long)cr) simple = 0;
       }
-      s_simple = simple;
+      s_simple = simple && !force_sequential;
     }
     float* c = (float*)(wave_base + wid * wave_bytes);
     uint32_t* sorted = (uint32_t*)(c + nmax);
@@ -1032,11 +1032,12 @@ void FeatureExtractor::run_async() {
   const size_t lds = ((3 * (size_t)flag_bytes + 4 * (size_t)(caps[0] + caps[1] + caps[2]) + 15) & ~(size_t)15) + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) +
                      (sortP > 512 ? (size_t)FEAT_WAVES * sortP * 8 : 0) + 16;   // (regions of up to 512 points are sorted in registers)
   LX_REQUIRE(lds <= 160 * 1024, "scan ring too long for the LDS staging of k_feat_ring");
+  static const bool force_seq = getenv("LOAMX_FEAT_SEQUENTIAL") && atoi(getenv("LOAMX_FEAT_SEQUENTIAL")) != 0;   // (diagnostic: the regions one after the other)
   if (lds > 64 * 1024)
     LX_HIP(hipFuncSetAttribute((const void*)k_feat_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_feat_ring, dim3(nring_), dim3(64 * FEAT_WAVES), lds, st_, cloud_.p, ring_off_.p, ring_sweep_base_.p, params, curv_.p,
                      flags_.p, gap_.p, flag_bytes, nmax, sortP, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p,
-                     lf_valid_.p);
+                     lf_valid_.p, force_seq ? 1 : 0);
   uint32_t* pre[3] = {slot_cnt_[0].p + nring_ + 1, slot_cnt_[1].p + nring_ + 1, slot_cnt_[2].p + nring_ + 1};
   hipLaunchKernelGGL(k_feat_prefix, dim3(3), dim3(1024), 0, st_, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p, nring_, pre[0], pre[1],
                      pre[2]);

@@ -53,6 +53,28 @@ def test_nondefault_parameters(orc, small_world):
     _same(op.ScanRegistration(orc, **cfg).process(sw.points, sw.ring_sizes), g.process(sw.points, sw.ring_sizes))
 
 
+@pytest.mark.parametrize("nreg,cr,sharp,flat,thr", [(8, 5, 2, 4, 0.1), (13, 5, 2, 4, 0.1), (6, 5, 6, 12, 0.1), (6, 8, 4, 8, 0.02), (7, 2, 3, 5, 0.5),
+                                                   (12, 6, 5, 9, 0.05)])
+def test_regions_side_by_side_equal_the_sequential_walk(orc, small_world, nreg, cr, sharp, flat, thr):
+    """k_feat_ring makes the picks of a ring's regions side by side and settles the marks that cross a region boundary afterwards
+    (markAsPicked writes into a flag array of the whole ring, BasicScanRegistration.cpp:367-386).  More regions than waves (several
+    groups, the last one partial), many picks per region and wide suppression windows make such crossings frequent; short rings whose
+    regions are smaller than the window take the sequential walk.  All of it bit-exact against the oracle's sequential loop."""
+    cfg = dict(nFeatureRegions=nreg, curvatureRegion=cr, maxCornerSharp=sharp, maxSurfaceFlat=flat, surfaceCurvatureThreshold=thr)
+    g = loamx.ScanRegistration(n_feature_regions=nreg, curvature_region=cr, max_corner_sharp=sharp, max_corner_less_sharp=0, max_surface_flat=flat,
+                               surface_curvature_threshold=thr)   # (0 = 10 x max_corner_sharp, the reference constructor's rule)
+    o = op.ScanRegistration(orc, **cfg)
+    for seed, sensor, az in ((21, "HDL-32", 1200), (22, "VLP-16", 400)):
+        sw = synth.make_sweep(small_world, sensor, np.zeros(6), np.zeros(6), seed=seed, az_steps=az)
+        _same(o.process(sw.points, sw.ring_sizes), g.process(sw.points, sw.ring_sizes))
+    # ragged rings: some long, some just long enough for the region formula, some with regions shorter than the window
+    sw = synth.make_sweep(small_world, "VLP-16", np.zeros(6), np.zeros(6), seed=23, az_steps=600)
+    pts = sw.points.reshape(16, 600, 4)
+    sizes = [600, 2 * cr + 2, 2 * cr + 1, nreg * cr + 2 * cr, nreg * cr + 2 * cr + 1, nreg * (cr - 1) + 2 * cr + 3, 97, 600, 45, 300, 0, 2 * cr + nreg, 599, 128, 64, 31]
+    cloud = np.concatenate([pts[r, :n] for r, n in enumerate(sizes)], 0)
+    _same(o.process(cloud, sizes), g.process(cloud, sizes))
+
+
 def test_max_corner_less_sharp_and_reconfigure(orc, small_world):
     """RegistrationParams::maxCornerLessSharp is parsed on its own (ScanRegistration.cpp:100-109) and configure() on an existing
     object keeps its state (BasicScanRegistration.cpp:49-53)"""

@@ -432,7 +432,8 @@ __device__ __forceinline__ bool degeneracy_projector_full(const float* AtA, floa
 // Must be called by ALL 64 lanes of wave 0 of the workgroup; AtA/AtB/X are in LDS or global memory.
 __device__ __forceinline__ float lane_get(float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); }
 
-__device__ __forceinline__ void qr_solve6_coop(const float* AtA, const float* AtB, float* X) {
+// qr_solve6_lanes: the solution stays in the lanes — lane c < 6 returns x[c], the others 0 (k_odom_lm goes on from there in registers)
+__device__ __forceinline__ float qr_solve6_lanes(const float* AtA, const float* AtB) {
   const int gl = (int)(threadIdx.x & 63);
   float a[6];
 #pragma unroll
@@ -528,7 +529,11 @@ __device__ __forceinline__ void qr_solve6_coop(const float* AtA, const float* At
     const float diag = lane_get(a[k], L[k]);
     if (gl == L[k] && k < nonzero) y = sacc / diag;
   }
-  if (gl < 6) X[gl] = y;   // (a lane is its original column; positions >= nonzero never received a value: 0)
+  return gl < 6 ? y : 0.f;   // (a lane is its original column; positions >= nonzero never received a value: 0)
+}
+__device__ __forceinline__ void qr_solve6_coop(const float* AtA, const float* AtB, float* X) {
+  const float y = qr_solve6_lanes(AtA, AtB);
+  if ((threadIdx.x & 63) < 6) X[threadIdx.x & 63] = y;
 }
 
 // ---- exchange between workgroups without cache-wide fences (round 4).  __threadfence() on gfx950 is buffer_wbl2 sc1 + buffer_inv sc1:

@@ -180,10 +180,18 @@ __device__ inline void block27_build(const GridDesc& g, const uint32_t* __restri
   }
   B.total = acc;
 }
-// visit(point, valid): called for 4 candidates per lane and trip, every lane the same number of times (valid = false past the end)
-template <class F>
-__device__ inline void block27_scan(const Block27& B, const float4* __restrict__ sorted, int lane, F&& visit) {
+// visit(point, valid): called for 4 candidates per lane and trip, every lane the same number of times (valid = false past the end).
+// The FIRST trip's first OD_BLK_CACHE points (candidates lane, lane + 64 — the whole block when it holds <= 128 points, the
+// usual case) are handed in and out through `first`: the nearest-neighbour pass loads them, the ring-window pass that follows takes them
+// from registers instead of going to the cache again (one dependent round trip less on every feature's chain).
+#ifndef OD_BLK_CACHE
+#define OD_BLK_CACHE 2   // points per lane kept from the first trip (0: none — every pass loads): 2 = blocks of <= 128 points, 8 VGPRs; with 4 the kernel drops from 6 to 5 waves per SIMD
+#endif
+struct Block27First { float4 p[OD_BLK_CACHE > 0 ? OD_BLK_CACHE : 1]; };
+template <bool LOAD_FIRST, class F>
+__device__ inline void block27_scan(const Block27& B, const float4* __restrict__ sorted, int lane, Block27First& first, F&& visit) {
   for (uint32_t c0 = (uint32_t)lane; c0 < B.total; c0 += 4 * 64) {
+    const bool first_trip = c0 == (uint32_t)lane;
     uint32_t pos[4];
     float4 p[4];
 #pragma unroll
@@ -194,8 +202,19 @@ __device__ inline void block27_scan(const Block27& B, const float4* __restrict__
       for (int k = 7; k >= 0; k--) o = cc < B.E[k] ? B.O[k] : o;
       pos[u] = cc < B.total ? cc + o : B.O[0];   // (O[0] = the first run's first slot: a valid address whenever total > 0)
     }
+    if (LOAD_FIRST || !first_trip) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) p[u] = sorted[pos[u]];
+      for (int u = 0; u < 4; u++) p[u] = sorted[pos[u]];
+      if (LOAD_FIRST && first_trip) {
+#pragma unroll
+        for (int u = 0; u < OD_BLK_CACHE; u++) first.p[u] = p[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = OD_BLK_CACHE; u < 4; u++) p[u] = sorted[pos[u]];
+#pragma unroll
+      for (int u = 0; u < OD_BLK_CACHE; u++) p[u] = first.p[u];
+    }
 #pragma unroll
     for (int u = 0; u < 4; u++) visit(p[u], (c0 + 64u * u) < B.total);
   }
@@ -203,10 +222,10 @@ __device__ inline void block27_scan(const Block27& B, const float4* __restrict__
 // exact nearest neighbour (d2 < 25) = nn1_wave's result: the block first, and only when nothing lies within h of the query (rare) the
 // shells from 2 on.  w_out: the winner's packed .w (ring << 24 | index)
 __device__ inline int nn1_block(const GridDesc& g, const Block27& B, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start,
-                                float qx, float qy, float qz, int lane, uint32_t& w_out) {
+                                float qx, float qy, float qz, int lane, uint32_t& w_out, Block27First& first) {
   float lbest = 25.0f;
   uint32_t lw = 0xffffffffu;   // packed .w of this lane's best
-  block27_scan(B, sorted, lane, [&](const float4& p, bool valid) {
+  block27_scan<true>(B, sorted, lane, first, [&](const float4& p, bool valid) {
     const float dx = qx - p.x, dy2 = qy - p.y, dz2 = qz - p.z;
     const float d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
     const uint32_t w = __float_as_uint(p.w);
@@ -293,7 +312,8 @@ __global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr_grid(OdomProblem
   block27_build(gd.g, cell_start, x, y, z, lane, B);
   OC_TS(2);
   uint32_t wbest = 0u;
-  const int closest = nn1_block(gd.g, B, sorted, cell_start, x, y, z, lane, wbest);
+  Block27First first;
+  const int closest = nn1_block(gd.g, B, sorted, cell_start, x, y, z, lane, wbest, first);
   OC_TS(3);
   if (closest < 0) {   // wave-uniform
     if (lane == 0) { pb.ind[5 * f] = -1; pb.ind[5 * f + 1] = -1; pb.ind[5 * f + 2] = -1; }
@@ -329,7 +349,7 @@ __global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr_grid(OdomProblem
   }
   OC_TS(4);
   if (via_block) {
-    block27_scan(B, sorted, lane, [&](const float4& p, bool ok) {
+    block27_scan<false>(B, sorted, lane, first, [&](const float4& p, bool ok) {
       const uint32_t w = __float_as_uint(p.w);
       const int j = (int)(w & OD_IDX_MASK), ring = (int)(w >> 24);
       const float d = sqd(p, x, y, z);
@@ -614,10 +634,14 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
   __shared__ int sh_done, sh_degen, sh_abort;
   __shared__ float matP[36];
   __shared__ float ws[216];
-  __shared__ double sums[LX_NSUM];
   __shared__ double parts[16 * LX_NSUM];   // the partial sums of the stream's (<= 16) workgroups
-  __shared__ float AtA[36], AtB[6], X[6], X2[6];
-  if (tid < 6) T[tid] = pb.transform[tid];
+  __shared__ float AtA[36], AtB[6];
+  if (tid < 6) {
+    T[tid] = pb.transform[tid];
+    // sin/cos of the three angles, one per lane, double then rounded (see pose_set_angles); later iterations get theirs from the update step
+    const double ang = (double)pb.transform[tid >> 1];
+    trig[tid] = (float)((tid & 1) ? cos(ang) : sin(ang));
+  }
   const unsigned xtag = pb.xchg_epoch << 8;   // this sweep's number in the upper 24 bits of every record's tags
   if (tid == 0) { sh_done = 0; sh_abort = 0; sh_degen = pb.stats.degenerate; }
   if (tid < 36) matP[tid] = pb.matP[tid];   // set at iteration 0 (an earlier launch when iter0 > 0)
@@ -652,11 +676,6 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
   for (int iter = it_begin; iter < it_end; iter++) {
     // ---- phase C: residual rows + normal equations
     LM_TS(0);
-    if (tid < 6) {   // sin/cos of the three angles, one per lane, double then rounded (see pose_set_angles)
-      const double ang = (double)T[tid >> 1];
-      trig[tid] = (float)((tid & 1) ? cos(ang) : sin(ang));
-    }
-    __syncthreads();
     LM_TS(1);
     double v[OD_FPT == 1 ? 1 : LX_NSUM];
     float a1[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bb1 = 0.f;   // OD_FPT == 1: the row of this thread's feature (zeros when not selected)
@@ -773,15 +792,13 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
     }
     __syncthreads();
     LM_TS(3);
+    double xs = 0.0;   // thread t < 28: sum t of the stream's normal equations (this workgroup's share first)
     if (tid < LX_NSUM) {
-      double x = 0.0;
 #pragma unroll
-      for (int w = 0; w < 8; w++) x += red[w][tid];
+      for (int w = 0; w < 8; w++) xs += red[w][tid];
       if (NB > 1) {
         // one tagged 16-byte record per sum, fire and forget: no wait for the store, no arrival counter (dev_math.cuh: xrec_store)
-        xrec_store(reinterpret_cast<xrec_t*>(pb.part) + (((unsigned)iter & 1u) * 16u + blockIdx.x) * LX_NSUM + tid, x, xtag | (unsigned)(iter + 1));
-      } else {
-        sums[tid] = x;
+        xrec_store(reinterpret_cast<xrec_t*>(pb.part) + (((unsigned)iter & 1u) * 16u + blockIdx.x) * LX_NSUM + tid, xs, xtag | (unsigned)(iter + 1));
       }
     }
     if (NB > 1) {
@@ -818,84 +835,96 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
         return;
       }
       LM_TS(5);
-      if (tid < LX_NSUM) {
-        double x = 0.0;
-        for (unsigned b = 0; b < NB; b++) x += parts[b * LX_NSUM + tid];   // workgroup order: deterministic
-        sums[tid] = x;
-      }
-      __syncthreads();
     }
-    if (tid < LX_NSUM) {
-      const double x = sums[tid];
+    // ---- wave 0 alone from here to the end of the iteration (no block-wide barrier in between): the NB partial sums in workgroup order
+    // -> normal equations -> 6x6 pivoted QR -> update, stop test and the NEXT iteration's sin/cos.  The update (:485-488, :561-612) runs on
+    // lanes 0..5, one pose component each, with the operations and their order as the reference's scalar loop has them.
+    if (tid < 64) {
+      if (NB > 1 && tid < LX_NSUM) {
+        xs = 0.0;
+        for (unsigned b = 0; b < NB; b++) xs += parts[b * LX_NSUM + tid];   // workgroup order: deterministic
+      }
       // scatter straight into the symmetric 6x6 / right-hand side (sum index t -> (i, j) of the upper triangle)
       if (tid < 21) {
         int i = 0, rem = tid;
         while (rem >= 6 - i) { rem -= 6 - i; i++; }
         const int j = i + rem;
-        AtA[i * 6 + j] = AtA[j * 6 + i] = (float)x;
+        AtA[i * 6 + j] = AtA[j * 6 + i] = (float)xs;
       } else if (tid < 27) {
-        AtB[tid - 21] = (float)x;
+        AtB[tid - 21] = (float)xs;
       }
-    }
-    __syncthreads();
-    const int sel = (int)sums[27];   // block-uniform
-    LM_TS(7);
-    if (tid == 0 && blockIdx.x == 0) {
-      pb.stats.iterations = iter + 1;
-      pb.stats.sel = sel;
-    }
-    if (sel >= 10 && tid < 64) qr_solve6_coop(AtA, AtB, X);   // wave 0, all lanes (:559)
-    __syncthreads();
-    LM_TS(8);
-    if (tid == 0) {
-      if (sel >= 10) {   // :485-488
+      const int sel = (int)__hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xs), 27), __builtin_amdgcn_readlane(__double2loint(xs), 27));   // wave-uniform
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (the solve's lanes read what other lanes of this wave have just written to LDS)
+      LM_TS(7);
+      float xl = 0.f;      // lane r < 6: X[r]
+      int done_now = 0;
+      if (sel >= 10) {     // :485-488
+        xl = qr_solve6_lanes(AtA, AtB);   // all lanes (:559)
+        LM_TS(8);
         if (iter == 0) {
-          sh_degen = degeneracy_projector(AtA, 10.f, matP, ws) ? 1 : 0;
-          if (blockIdx.x == 0) {
-            pb.stats.degenerate = sh_degen;
-            for (int k = 0; k < 36; k++) pb.matP[k] = matP[k];
-          }
+          if (tid == 0) sh_degen = degeneracy_projector(AtA, 10.f, matP, ws) ? 1 : 0;
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+          if (blockIdx.x == 0 && tid < 36) pb.matP[tid] = matP[tid];
         }
-        if (sh_degen) {
-          for (int r = 0; r < 6; r++) X2[r] = X[r];
-          for (int r = 0; r < 6; r++) {
-            float acc = 0.f;
-            for (int c = 0; c < 6; c++) acc += matP[r * 6 + c] * X2[c];
-            X[r] = acc;
-          }
+        const int degen = sh_degen;
+        if (degen) {       // X = matP * X2, row r on lane r (:591-593)
+          const int r = tid < 6 ? tid : 5;
+          float acc = 0.f;
+#pragma unroll
+          for (int c = 0; c < 6; c++) acc += matP[r * 6 + c] * lane_get(xl, c);
+          xl = acc;
         }
-        for (int r = 0; r < 6; r++) {
-          float nv = T[r] + X[r];
-          if (!isfinite(nv)) nv = 0.f;   // :606-612
-          T[r] = nv;
-        }
-        const float d0 = (float)(X[0] * 180.0 / M_PI), d1 = (float)(X[1] * 180.0 / M_PI), d2 = (float)(X[2] * 180.0 / M_PI);
+        float x6[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) x6[k] = lane_get(xl, k);
+        const float d0 = (float)(x6[0] * 180.0 / M_PI), d1 = (float)(x6[1] * 180.0 / M_PI), d2 = (float)(x6[2] * 180.0 / M_PI);
         const float deltaR = (float)sqrt((double)d0 * d0 + (double)d1 * d1 + (double)d2 * d2);
-        const float t0 = X[3] * 100, t1 = X[4] * 100, t2 = X[5] * 100;
+        const float t0 = x6[3] * 100, t1 = x6[4] * 100, t2 = x6[5] * 100;
         const float deltaT = (float)sqrt((double)t0 * t0 + (double)t1 * t1 + (double)t2 * t2);
-        if (deltaR < P.delta_r_abort && deltaT < P.delta_t_abort) sh_done = 1;
+        done_now = (deltaR < P.delta_r_abort && deltaT < P.delta_t_abort) ? 1 : 0;
       }
+      // the new pose component of lane r < 6 (unchanged when the solve was skipped) and, on lanes 0..5, sin / cos of the three angles
+      // for the next iteration's rows — and for the re-projection parameters, should this be the sweep's last iteration
+      float tl = T[tid < 6 ? tid : 5];
+      if (sel >= 10) {
+        float nv = tl + xl;
+        if (!isfinite(nv)) nv = 0.f;   // :606-612
+        tl = nv;
+      }
+      const float a0 = lane_get(tl, 0), a1 = lane_get(tl, 1), a2 = lane_get(tl, 2);
+      const double ang = (double)((tid >> 1) == 0 ? a0 : ((tid >> 1) == 1 ? a1 : a2));
+      const float tg = (float)((tid & 1) ? cos(ang) : sin(ang));
+      if (tid < 6) { T[tid] = tl; trig[tid] = tg; }
+      if (tid == 0 && done_now) sh_done = 1;
       if (blockIdx.x == 0) {
-        for (int r = 0; r < 6; r++) pb.transform[r] = T[r];
-        if (sh_done) pb.done = 1;
-        // results also go to the host-visible mirror once they are final for this launch: the host then needs no copy on
-        // the stream, only the event behind the last launch
-        if (sh_done || iter == it_end - 1) {
-          // ... and into the re-projection parameters of the sweep's tail (transformToEnd with the optimised transform): the
-          // tail is enqueued right behind the last launch, no host round trip and no extra kernel
-          ToEndParams& P = *pb.te_out;
-          for (int k = 0; k < 6; k++) P.T[k] = T[k];
-          for (int k = 0; k < 3; k++) {   // the host caches sin/cos of a float angle (Angle.h); double-then-round is within an ulp of it
-            P.sT[k] = (float)sin((double)T[k]);
-            P.cT[k] = (float)cos((double)T[k]);
-          }
+        const bool final_now = done_now || iter == it_end - 1;
+        if (tid < 6) pb.transform[tid] = tl;
+        if (tid == 0) {
+          pb.stats.iterations = iter + 1;
+          pb.stats.sel = sel;
+          if (iter == 0 && sel >= 10) pb.stats.degenerate = sh_degen;
+          if (done_now) pb.done = 1;
         }
-        if (pb.host_mirror && (sh_done || iter == it_end - 1)) {
-          OdomProblem* hm = pb.host_mirror;
-          for (int r = 0; r < 6; r++) hm->transform[r] = T[r];
-          hm->stats = pb.stats;
-          hm->stats.iterations = iter + 1;
-          hm->done = sh_done;
+        // results also go to the host-visible mirror once they are final for this launch: the host then needs no copy on the stream,
+        // only the event behind the last launch — and into the re-projection parameters of the sweep's tail (transformToEnd with the
+        // optimised transform): the tail is enqueued right behind the last launch, no host round trip and no extra kernel
+        if (final_now) {
+          ToEndParams& Pe = *pb.te_out;
+          if (tid < 6) {
+            Pe.T[tid] = tl;
+            // (the host caches sin/cos of a float angle (Angle.h); double-then-round is within an ulp of it)
+            if (tid & 1) Pe.cT[tid >> 1] = tg; else Pe.sT[tid >> 1] = tg;
+          }
+          if (pb.host_mirror) {
+            OdomProblem* hm = pb.host_mirror;
+            if (tid < 6) hm->transform[tid] = tl;
+            if (tid == 0) {
+              OdomStats stt;
+              stt.iterations = iter + 1; stt.sel = sel; stt.frame = pb.stats.frame; stt.degenerate = sh_degen;
+              hm->stats = stt;
+              hm->done = done_now;
+            }
+          }
         }
       }
       LM_TS(9);

@@ -23,9 +23,13 @@
  *    intensity_offset 16}; a packed float4 is {16, 12}.  Outputs are written with the same description.
  *  - Poses are float[6] = rot_x (pitch), rot_y (yaw), rot_z (roll), x, y, z in the LOAM camera frame, rotation order
  *    R = Ry*Rx*Rz (reference src/lib/math_utils.h:212-238).
- *  - Point coordinates handed to loamx_scanreg_process, loamx_odom_* and loamx_map_* must be finite.  The reference's own pipeline
- *    guarantees that (MultiScanRegistration.cpp:187-191 drops non-finite returns — and so does loamx_scanreg_process_raw); its
- *    pcl::removeNaNFromPointCloud calls in the odometry (BasicLaserOdometry.cpp:230, :252) are therefore not reproduced.
+ *  - Point coordinates handed to loamx_scanreg_process, loamx_odom_*, loamx_map_* and staged into a pipeline must be finite.  The
+ *    reference's own pipeline guarantees that (MultiScanRegistration.cpp:187-191 drops non-finite returns — and so does
+ *    loamx_scanreg_process_raw / loamx_pipeline_stage_step_raw); its pcl::removeNaNFromPointCloud calls in the odometry
+ *    (BasicLaserOdometry.cpp:230, :252) are safeguards that never fire there.  Here a violation is an ERROR, not a silent drop: the
+ *    call (for a pipeline: the step that first uses the sweep) returns LOAMX_E_INVALID — binned rings are checked on the device while
+ *    the curvature pass reads them, feature clouds on the host while they are packed; full-resolution clouds that are only
+ *    transformed (loamx_map_process full_res) are not checked.
  *  - Return value: 0 = processed, 1 = skipped (mirrors the reference's `false` / silent guards), < 0 = error;
  *    loamx_last_error() gives the text for the calling thread's last failing call.  No exception or abort crosses
  *    the ABI.
@@ -65,8 +69,12 @@ const char* loamx_last_error(void);
 /* number of visible HIP devices (0 if none / HIP unavailable); never fails */
 int loamx_device_count(void);
 /* ABI version of this header */
-#define LOAMX_ABI_VERSION 4
+#define LOAMX_ABI_VERSION 5
 int loamx_abi_version(void);
+/* How this library was built, as "key=value;..." (static storage): abi=<n>; diag=0|1 (1: made with EXTRA=-DLOAMX_DIAG — the only kind of
+ * build that reads the diagnostic LOAMX_* environment switches, some of which change results; a product library ignores them);
+ * rccl=0|1; roctx=0|1.  A harness records it next to its measurements. */
+const char* loamx_build_info(void);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Feature extraction  (BasicScanRegistration, IMU-less path)
@@ -137,7 +145,7 @@ typedef struct loamx_odom loamx_odom;
 
 typedef struct loamx_odom_config {
   float scan_period;  /* 0.1  */
-  int max_iterations; /* 25   */
+  int max_iterations; /* 25; 1 .. 255 */
   float delta_t_abort; /* 0.1 */
   float delta_r_abort; /* 0.1 */
   int device;
@@ -188,7 +196,9 @@ int loamx_map_process(loamx_map* h, const loamx_cloud* corner_last, const loamx_
 /* The map side of process() alone — the merge step of a map epoch (collective 3): a sweep that was registered elsewhere
  * (the batched pipeline, against a frozen copy of this map) is stacked, down-sized, inserted into the cubes with the GIVEN pose
  * (rx, ry, rz, tx, ty, tz = its transformAftMapped) and the touched cubes are re-filtered, exactly as process() does after its
- * optimisation (BasicLaserMapping.cpp:512-593); no optimisation runs.  loamx_map_get_cubes() afterwards is the next epoch's map
+ * optimisation (BasicLaserMapping.cpp:512-593); no optimisation runs, and the pose is inserted AS GIVEN — no IMU blend is applied to it even
+ * when the handle holds IMU history (a pipeline pose has had its blend), and the handle's own transforms (Tobe / Bef / AftMapped), frame
+ * counter and iteration limit are as before the call, also after an error.  loamx_map_get_cubes() afterwards is the next epoch's map
  * (loamx_pipeline_stage_frozen_* / loamx_dist_broadcast_map). */
 int loamx_map_insert(loamx_map* h, const loamx_cloud* corner_last, const loamx_cloud* surf_last, const float pose6[6]);
 /* which: 0 transformAftMapped, 1 transformBefMapped, 2 transformTobeMapped, 3 transformSum */
@@ -290,6 +300,11 @@ int loamx_batch_knn_probe(loamx_batch* h, int which, const float* queries_xyz, u
  * n systems ata[36 i .. ) x = atb[6 i .. ) through the wave-cooperative routine the kernels call (x_coop) and through the scalar
  * routine it must equal bit for bit (x_scalar, one thread, the reference's order of operations). */
 int loamx_batch_qr6_probe(loamx_batch* h, const float* ata, const float* atb, uint32_t n, float* x_coop, float* x_scalar);
+/* Stress probe of the exchange between the workgroups of one odometry stream (tagged 16-byte records written by one agent-scope store,
+ * accepted by the reader when both tags match): `pairs` producer / consumer workgroup pairs on different XCDs, `rounds` versions per
+ * record.  out4 = {accepted reads, torn reads (tags differ: the reader polls again), INCONSISTENT accepted reads (must be 0: the
+ * property the exchange rests on), consumer threads that gave up waiting (must be 0)}. */
+int loamx_batch_xrec_stress(loamx_batch* h, uint32_t pairs, uint32_t rounds, uint64_t out4[4]);
 /* Parity hook for the voxel-grid stage: the down-sampled stack clouds of one sweep of the last run (laserCloudCornerStackDS /
  * laserCloudSurfStackDS, BasicLaserMapping.cpp:512-527 — the query points of the Gauss-Newton iterations, sensor frame, in
  * pcl::VoxelGrid's output order).  count fields: capacity in, size out; LOAMX_E_CAPACITY when a cloud does not fit. */
@@ -386,6 +401,14 @@ int loamx_pipeline_set_timing(loamx_pipeline* h, int on);
 /* stage_ms: features, odometry, registration, whole step (HIP events on the pipeline's stream);
  * reg_ms / counts as loamx_batch_get_timing */
 int loamx_pipeline_get_timing(loamx_pipeline* h, float stage_ms[4], float reg_ms[4], uint64_t counts[4]);
+/* The odometry chains' launch pairs (k_odom_corr_grid + k_odom_lm, BasicLaserOdometry.cpp:246-622 in groups of five iterations), timed
+ * with HIP events on the chains' own streams while loamx_pipeline_set_timing(h, 1) is on; running totals over all chains since the handle
+ * was created (never waits: a call whose events have not completed is counted later).
+ * ms4 = {k_odom_lm launches that iterated, k_odom_lm launches over converged streams, k_odom_corr_grid likewise x 2};
+ * counts7 = {lm launches that iterated, lm no-op launches, iterations (slowest stream of each launch, summed), corr launches that
+ * searched, corr no-op launches, algorithmic bytes of the iterating lm launches (48 B x features of the streams still iterating),
+ * features searched by the corr launches}. */
+int loamx_pipeline_get_odom_launch_timing(loamx_pipeline* h, double ms4[4], uint64_t counts7[7]);
 void* loamx_pipeline_stream(loamx_pipeline* h);
 
 /* ------------------------------------------------------------------------------------------------------------

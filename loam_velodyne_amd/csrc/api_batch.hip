@@ -155,6 +155,15 @@ int loamx_batch_qr6_probe(loamx_batch* h, const float* ata, const float* atb, ui
     return LOAMX_OK;
   });
 }
+int loamx_batch_xrec_stress(loamx_batch* h, uint32_t pairs, uint32_t rounds, uint64_t out4[4]) {
+  return guard([&]() {
+    LX_REQUIRE(h && out4, "NULL argument");
+    unsigned long long o[4] = {0, 0, 0, 0};
+    h->reg.xrec_stress(pairs, rounds, o);
+    for (int k = 0; k < 4; k++) out4[k] = (uint64_t)o[k];
+    return LOAMX_OK;
+  });
+}
 int loamx_batch_download_ds(loamx_batch* h, uint32_t sweep, loamx_cloud* corner_ds, loamx_cloud* surf_ds) {
   return guard([&]() {
     LX_REQUIRE(h && corner_ds && surf_ds, "NULL argument");

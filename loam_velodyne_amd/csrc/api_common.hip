@@ -24,4 +24,25 @@ int loamx_device_count(void) {
   return n;
 }
 int loamx_abi_version(void) { return LOAMX_ABI_VERSION; }
+#define LX_STR2(x) #x
+#define LX_STR(x) LX_STR2(x)
+const char* loamx_build_info(void) {
+  return "abi=" LX_STR(LOAMX_ABI_VERSION)
+#ifdef LOAMX_DIAG
+         ";diag=1"
+#else
+         ";diag=0"
+#endif
+#ifdef LOAMX_NO_RCCL
+         ";rccl=0"
+#else
+         ";rccl=1"
+#endif
+#ifdef LOAMX_NO_ROCTX
+         ";roctx=0"
+#else
+         ";roctx=1"
+#endif
+      ;
+}
 }

@@ -26,7 +26,7 @@ loamx_odom* loamx_odom_create(const loamx_odom_config* cfg) {
     if (cfg) c = *cfg; else loamx_odom_default_config(&c);
     // same validation as LaserOdometry::setup (LaserOdometry.cpp:70-138)
     LX_REQUIRE(c.scan_period > 0.f, "scan_period must be positive");
-    LX_REQUIRE(c.max_iterations >= 1, "max_iterations must be >= 1");
+    LX_REQUIRE(c.max_iterations >= 1 && c.max_iterations <= 255, "max_iterations must be in [1, 255]");   // (k_odom_lm tags its exchange records with iteration + 1 in 8 bits)
     LX_REQUIRE(c.delta_t_abort > 0.f && c.delta_r_abort > 0.f, "abort thresholds must be positive");
     h = new loamx_odom(c.device);
     h->od.params.scan_period = c.scan_period;

@@ -101,6 +101,12 @@ inline void check_cloud(const loamx_cloud* c, bool allow_null_data = true) {
              "cloud intensity_offset must be 4-aligned, >= 12 and inside the record");
   LX_REQUIRE(allow_null_data || c->data != nullptr || c->count == 0, "cloud data is NULL");
 }
+// true when every x, y, z of n packed points is finite (x * 0 is NaN for NaN and +-Inf, 0 otherwise: a loop the compiler vectorises)
+inline bool packed_all_finite(const float4* p, size_t n) {
+  float acc = 0.f;
+  for (size_t i = 0; i < n; i++) acc += p[i].x * 0.f + p[i].y * 0.f + p[i].z * 0.f;
+  return acc == 0.f;
+}
 inline void pack_cloud(const loamx_cloud* c, float4* dst) {
   const char* src = (const char*)c->data;
   if (c->stride == 16 && c->intensity_offset == 12) {   // x y z intensity records: the device layout itself
@@ -147,12 +153,22 @@ struct TraceRange {
   TraceRange& operator=(const TraceRange&) = delete;
 };
 
+// Diagnostic switches — timing experiments, A/B runs of retired code paths, anything that changes RESULTS (LOAMX_ODOM_MAXIT,
+// LOAMX_NO_MAP_IMU_BLEND, LOAMX_EIG_JACOBI ...) — exist only in a build made with `make EXTRA=-DLOAMX_DIAG`; the product library does
+// not read them (loamx_build_info() says which kind a library is).  What the product does read from the environment is listed in
+// tracing (LOAMX_*_TRACE), transport selection and the look-ahead / chain tuning knobs, none of which changes a result.
+#ifdef LOAMX_DIAG
+inline const char* diag_env(const char* name) { return getenv(name); }
+#else
+inline const char* diag_env(const char*) { return nullptr; }
+#endif
+
 // HIP stream with a relative priority: +1 = highest the device offers, 0 = default, -1 = lowest.  The stages of the
 // pipeline run on streams of their own; the latency-critical ones (registration, odometry) outrank feature extraction,
 // whose wide kernels would otherwise delay their short dependent launches.
 // env_priority (diagnostic): the stream priority a stage asked for can be overridden with LOAMX_PRIO_REG / _ODOM / _FEAT = -1, 0, 1
 inline int env_priority(const char* name, int dflt) {
-  const char* e = getenv(name);
+  const char* e = diag_env(name);
   if (!e) return dflt;
   const int v = atoi(e);
   return v > 0 ? 1 : (v < 0 ? -1 : 0);

@@ -84,6 +84,8 @@ class FeatureExtractor {
   int download_cloud(uint32_t sweep, loamx_cloud* full, uint32_t* ring_size_out);
   void run_async();
   void sync();
+  // after a synchronisation point behind run_async(): throws LOAMX_E_INVALID when k_feat_point met a non-finite coordinate (and clears the mark)
+  void check_finite_input();
   // host copies of one sweep's outputs (after sync); any pointer may be NULL
   int download(uint32_t sweep, loamx_cloud* sharp, loamx_cloud* less_sharp, loamx_cloud* flat, loamx_cloud* less_flat);
 
@@ -136,6 +138,7 @@ class FeatureExtractor {
   DevBuf<uint32_t> lf_off_;
   VoxelPipeline vox_;
   PinBuf<uint32_t> h_off_;
+  PinBuf<uint32_t> h_bad_;   // pinned word raised by k_feat_point on a non-finite input coordinate
   PinBuf<float4> h_pack_;   // download(): [header | sharp | less sharp | flat | less flat] of one sweep, written by k_feat_pack_host
 };
 

@@ -26,13 +26,21 @@ __device__ inline float sqdiff3w(const float4& a, const float4& b, float wb) {
 
 // grid = (ceil(max_ring_len/256), nring)
 __global__ __launch_bounds__(256) void k_feat_point(const float4* __restrict__ cloud, const uint32_t* __restrict__ ring_off, int cr,
-                                                    float* __restrict__ curv, uint8_t* __restrict__ flags, uint8_t* __restrict__ gap) {
+                                                    float* __restrict__ curv, uint8_t* __restrict__ flags, uint8_t* __restrict__ gap,
+                                                    uint32_t* __restrict__ bad_word) {
   const uint32_t r = blockIdx.y;
   const uint32_t s0 = ring_off[r], e1 = ring_off[r + 1];
   const uint32_t len = e1 - s0;
+  const uint32_t i = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+  // Binned rings are finite by contract (the reference drops NaN / Inf points where it bins, MultiScanRegistration.cpp:187-196, and so
+  // does loamx_scanreg_process_raw); a caller that breaks the contract is told (LOAMX_E_INVALID at the call's synchronisation point)
+  // instead of getting a pose that went through NaN arithmetic: every point of every ring is looked at here anyway
+  if (i < e1) {
+    const float4 q = cloud[i];
+    if (!(isfinite(q.x) && isfinite(q.y) && isfinite(q.z))) __hip_atomic_store(bad_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (len <= 2u * cr + 1u) return;
   const uint32_t e0 = e1 - 1;
-  const uint32_t i = s0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (i > e0) return;
   // gap[i]: the step to the next point exceeds markAsPicked's 0.05 m^2 limit (:372, :380) — precomputed so that the
   // sequential picking loop never waits on global memory
@@ -715,6 +723,15 @@ FeatureExtractor::FeatureExtractor(int device, hipStream_t shared_stream) : devi
     own_stream_ = true;
   }
   vox_.init(st_);
+  h_bad_.reserve(16);
+  h_bad_.p[0] = 0u;
+}
+
+void FeatureExtractor::check_finite_input() {
+  if (*(volatile uint32_t*)h_bad_.p) {
+    *h_bad_.p = 0u;
+    throw Error(LOAMX_E_INVALID, "a sweep holds non-finite coordinates (binned rings must be finite: BasicLaserOdometry.cpp:230 / MultiScanRegistration.cpp:187-196 drop such points before this stage)");
+  }
 }
 
 FeatureExtractor::~FeatureExtractor() {
@@ -1021,7 +1038,7 @@ void FeatureExtractor::run_async() {
   LX_HIP(hipMemsetAsync(lf_valid_.p, 0, n_ + 1, st_));
   if (n_ && max_ring_len_) {
     hipLaunchKernelGGL(k_feat_point, dim3((max_ring_len_ + 255) / 256, nring_), dim3(256), 0, st_, cloud_.p, ring_off_.p, cr, curv_.p,
-                       flags_.p, gap_.p);
+                       flags_.p, gap_.p, h_bad_.p);
   }
   const uint32_t caps[3] = {(uint32_t)(params.max_sharp * params.n_regions), (uint32_t)(params.max_less_sharp * params.n_regions),
                             (uint32_t)(params.max_flat * params.n_regions)};
@@ -1032,7 +1049,7 @@ void FeatureExtractor::run_async() {
   const size_t lds = ((3 * (size_t)flag_bytes + 4 * (size_t)(caps[0] + caps[1] + caps[2]) + 15) & ~(size_t)15) + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) +
                      (sortP > 512 ? (size_t)FEAT_WAVES * sortP * 8 : 0) + 16;   // (regions of up to 512 points are sorted in registers)
   LX_REQUIRE(lds <= 160 * 1024, "scan ring too long for the LDS staging of k_feat_ring");
-  static const bool force_seq = getenv("LOAMX_FEAT_SEQUENTIAL") && atoi(getenv("LOAMX_FEAT_SEQUENTIAL")) != 0;   // (diagnostic: the regions one after the other)
+  static const bool force_seq = diag_env("LOAMX_FEAT_SEQUENTIAL") && atoi(diag_env("LOAMX_FEAT_SEQUENTIAL")) != 0;   // (diagnostic: the regions one after the other)
   if (lds > 64 * 1024)
     LX_HIP(hipFuncSetAttribute((const void*)k_feat_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_feat_ring, dim3(nring_), dim3(64 * FEAT_WAVES), lds, st_, cloud_.p, ring_off_.p, ring_sweep_base_.p, params, curv_.p,
@@ -1075,6 +1092,7 @@ void FeatureExtractor::run_async() {
 void FeatureExtractor::sync() {
   LX_HIP(hipStreamSynchronize(st_));
   vox_.check();   // a timed-out wait inside the long-ring fallback's voxel kernel raises instead of passing garbage on
+  check_finite_input();
 }
 
 // The four feature clouds of one sweep, written back to back into pinned (device-mapped) memory by ONE launch, sizes in a header in
@@ -1116,6 +1134,7 @@ int FeatureExtractor::download(uint32_t sweep, loamx_cloud* sharp, loamx_cloud* 
                      h_pack_.p);
   LX_HIP(hipStreamSynchronize(st_));
   vox_.check();
+  check_finite_input();
   const uint32_t* hdr = reinterpret_cast<const uint32_t*>(h_pack_.p);
   LX_REQUIRE(hdr[0] != 0xffffffffu, "internal: the feature clouds of a sweep exceed four times its points");
   int rc = LOAMX_OK;

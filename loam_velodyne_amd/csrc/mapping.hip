@@ -469,7 +469,8 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
 
   // ---- registration against the sub-map (guard + iterations inside Registrar::run_async)
   reg.early_exit = true;   // process() is blocking
-  const bool imu_blend = !imu_history.empty();
+  // (insert(): the caller's pose goes into the map verbatim — a pipeline pose has had its IMU blend already)
+  const bool imu_blend = !imu_history.empty() && !forced_pose;
   reg.defer_full = imu_blend;
   reg.run_async();
   last_optimized = reg.submap_sufficient();
@@ -600,15 +601,20 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
 }
 
 int Mapper::insert(const loamx_cloud* corner_last, const loamx_cloud* surf_last, const float pose6[6]) {
-  const int keep_it = reg.params.max_iterations;
-  const long keep_fc = frame_count;
-  struct Restore { Mapper* m; int it; ~Restore() { m->reg.params.max_iterations = it; m->forced_pose = nullptr; } } restore{this, keep_it};
+  // process() with zero Gauss-Newton launches and a forced pose: the map side alone (:512-593).  Everything of the handle that is NOT
+  // the map is put back when the call ends, also when it throws: the iteration limit, the frame counter (an insertion is not a
+  // processed frame) and the transforms — the handle's transformTobeMapped / BefMapped / AftMapped belong to its own process() calls
+  struct Restore {
+    Mapper* m; int it; long fc; HTwist tobe, bef, aft; bool opt;
+    ~Restore() {
+      m->reg.params.max_iterations = it; m->forced_pose = nullptr; m->frame_count = fc;
+      m->tobe = tobe; m->bef = bef; m->aft = aft; m->last_optimized = opt;
+    }
+  } restore{this, reg.params.max_iterations, frame_count, tobe, bef, aft, last_optimized};
   reg.params.max_iterations = 0;   // no Gauss-Newton launch: the registrar stacks and down-sizes with the pose it is given
   forced_pose = pose6;
   frame_count = 0;                 // (every call inserts: _stackFrameNum counts sweeps that go through process())
-  const int rc = process(corner_last, surf_last, nullptr);
-  frame_count = keep_fc;
-  return rc;
+  return process(corner_last, surf_last, nullptr);
 }
 
 void Mapper::load_cubes(const loamx_cloud* corner, const loamx_cloud* surf) {

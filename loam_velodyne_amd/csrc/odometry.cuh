@@ -37,7 +37,6 @@ struct OdomProblem {
   float transform[6];  // in: initial _transform, out: optimised
   OdomStats stats;
   int done;
-  int iter0;           // OdomEngine: iterations of this sweep done before the launch (k_odom_lm with iter0 < 0)
   float matP[36];
   int stream_id;          // index of the stream this problem belongs to
   ToEndParams* te_out;        // re-projection parameters of this stream (completed by k_odom_lm)
@@ -106,6 +105,17 @@ class OdometryBatch {
   void to_end_gather(float4* dst, const uint32_t* h_off, const float4* const* src, const ToEndParams* seg_params, uint32_t K,
                      hipStream_t stream);
   ToEndParams to_end_params(uint32_t s, bool enabled) const;
+  // Launch timing (measurement only; bench.py's roofline / latency model of the odometry pair): while on, every process() call brackets
+  // its k_odom_corr_grid and k_odom_lm launches with HIP events on this object's stream; the elapsed times are taken lazily, once a
+  // call's events have completed, and added up together with what the host knows of every launch afterwards: how many iterations its
+  // slowest stream ran in it (0: a launch over converged streams) and the algorithmic bytes of the streams that were still iterating.
+  struct LaunchTotals {
+    double lm_ms = 0, lm_noop_ms = 0, corr_ms = 0, corr_noop_ms = 0;   // launches that iterated / that found every stream converged
+    uint64_t lm_launches = 0, lm_noop_launches = 0, lm_iterations = 0, corr_launches = 0, corr_noop_launches = 0;
+    uint64_t lm_bytes = 0, corr_features = 0;                          // 48 B x features of the iterating streams; features searched
+  };
+  void set_launch_timing(bool on) { launch_timing_.store(on, std::memory_order_relaxed); }
+  LaunchTotals launch_totals();   // resolves what has completed and returns the running totals (never waits)
   // device views of the re-projected clouds handed on to mapping
   const float4* d_last_corner(uint32_t s) const { return last_.p + h_last_off_[s]; }
   const float4* d_last_surf(uint32_t s) const { return last_.p + h_last_off_[n_streams() + s]; }
@@ -147,100 +157,22 @@ class OdometryBatch {
   bool tail_pending_ = false, up_pending_ = false;
   PinBuf<char> h_gather_;
   DevBuf<char> d_gather_;
+  // launch timing: a small ring of per-call event sets
+  static constexpr int LT_RING = 8, LT_MAXP = 8;   // calls in flight, launch pairs per call
+  struct LtCall {
+    hipEvent_t ev[3 * LT_MAXP] = {};   // pair k: before corr, between corr and lm, behind lm
+    int pairs = 0;
+    bool pending = false;
+    int iters[LT_MAXP] = {};           // iterations of the slowest stream in pair k's k_odom_lm launch
+    uint64_t bytes[LT_MAXP] = {}, feats[LT_MAXP] = {};
+  };
+  LtCall lt_[LT_RING];
+  int lt_next_ = 0;
+  std::atomic<bool> launch_timing_{false};
+  std::mutex lt_mu_;   // (the totals are read by the calling thread while a chain's worker thread is inside process())
+  LaunchTotals lt_tot_;
+  void lt_resolve_();
 };
 
-
-// ---- the pipeline's odometry with every stream at its own pace (odom_engine.inc)
-struct OeArgs;
-struct OeSlot;
-struct OeResult;
-struct OeStream;
-// what a finished (stream, step) hands on to the registration of the same sweep
-struct OdomStepResult {
-  HTwist transform, transform_sum;
-  OdomStats stats = {0, 0, 0, 0};
-  int rc = LOAMX_SKIPPED;
-  const float4* last_corner = nullptr; uint32_t n_last_corner = 0;
-  const float4* last_surf = nullptr; uint32_t n_last_surf = 0;
-  ToEndParams to_end;
-};
-class OdomEngine {
- public:
-  // fetch(step, in[n_streams], imu[12 * n_streams], has_imu): the inputs of a step if its features exist (false: not yet; must not block).
-  // Called from the engine's own thread.
-  using Fetch = std::function<bool(uint32_t step, OdomInput* in, float* imu, bool& has_imu)>;
-  OdomEngine(int device, uint32_t n_streams, const OdomParams& params, Fetch fetch);
-  ~OdomEngine();
-  uint32_t n_streams() const { return ns_; }
-  hipStream_t stream() const { return st_; }
-  // --- calling thread
-  void set_limit(int step);                 // the streams may run steps <= step (never lowered by this call)
-  int limit() const { return limit_.load(std::memory_order_acquire); }
-  void wait_step(uint32_t step);            // until every stream has finished `step`: its results are integrated and kept for result()
-  const OdomStepResult& result(uint32_t step, uint32_t s) const { return res_[step % 4][s]; }
-  hipEvent_t tail_event(uint32_t step);     // recorded behind the launches that produced `step`'s re-projected clouds (after wait_step)
-  int done_upto() const { return done_all_.load(std::memory_order_acquire); }   // every stream has finished the steps below this
-  // stop where the streams are (every published step is finished first); positions and carried transforms stay
-  void park();
-  // start over at step `first` (park + forget the staged steps; stream states stay unless reset_state)
-  void restart(uint32_t first, bool reset_state);
-  OdomStream& stream_state(uint32_t s) { return hs_[s]; }   // (after park())
-  void push_transform(uint32_t s);          // the host state's transform -> the device (after park())
-  float busy_ms_per_step();                 // device time of the cycles since the last call / steps finished since then (timing only)
-  void set_timing(bool on) { timing_.store(on, std::memory_order_relaxed); }
-  OdomParams params;
-
- private:
-  void pump();
-  void enqueue_cycle();
-  bool publish_next();
-  void harvest();
-  void check_error();
-  int device_;
-  uint32_t ns_;
-  hipStream_t st_ = nullptr;
-  Fetch fetch_;
-  std::thread th_;
-  std::mutex mu_;
-  std::condition_variable cv_;
-  bool quit_ = false, parked_ = true, hold_ = false, held_ = false;
-  std::exception_ptr err_;
-  std::atomic<int> limit_{-1};
-  std::atomic<int> done_all_{0};            // steps [first_, done_all_) are finished by every stream (engine thread writes)
-  std::atomic<bool> idle_{true};            // the engine thread has nothing in flight and nothing to do
-  uint32_t first_ = 0;                      // first step of the current run
-  uint32_t published_ = 0;                  // steps < published_ have been handed to the device
-  uint32_t cycles_ = 0;                     // cycles enqueued
-  std::atomic<uint32_t> cycles_done_{0};    // cycles whose last launch has completed (engine thread, by event query)
-  std::vector<uint32_t> done_s_;            // per stream: steps < done_s_[s] are finished (engine thread)
-  std::vector<uint32_t> max_sharp_, max_flat_;   // per slot of the ring: the largest feature counts of the step
-  uint32_t integrated_ = 0;                 // steps < integrated_ have been integrated into hs_ (calling thread)
-  std::vector<OdomStream> hs_;              // host state per stream (transform, transformSum, IMU terms of the sweep being integrated)
-  std::vector<float> imu_cur_;              // [ns][12] the latest IMU terms per stream (a step without an IMU message keeps them)
-  std::vector<std::vector<float>> imu_step_;   // [4][ns * 12] the terms each staged step was published with
-  std::vector<std::vector<char>> init_step_;   // [4][ns] the step was the stream's first (initialising) sweep
-  std::vector<char> started_;               // per stream: its first sweep has been published
-  std::vector<OdomStepResult> res_[4];
-  // device
-  uint32_t cap_c_ = 0, cap_s_ = 0;
-  DevBuf<char> d_state_;                    // OeStream[ns] | OdomProblem[ns] | OeSlot[ns * 4] | GridDescB[2 ns]
-  DevBuf<float4> slab_, sorted_;
-  DevBuf<uint32_t> cell_start_, cell_cnt_, cell_loc_, seg_tot_, cell_of_, rank_of_, rf_, bounds_;
-  DevBuf<int> ind_;
-  DevBuf<double> part_;
-  PinBuf<char> h_pin_;                      // OeResult[4][ns] | cycles_done | err word | slot staging [4][ns]
-  OeStream* d_st_ = nullptr; OdomProblem* d_prob_ = nullptr; OeSlot* d_slots_ = nullptr; GridDescB* d_desc_ = nullptr;
-  OeResult* h_results_ = nullptr; volatile uint32_t* h_cycles_done_ = nullptr; uint32_t* h_err_ = nullptr; OeSlot* h_slots_ = nullptr;
-  static constexpr int EVR = 16;
-  hipEvent_t ev_cycle_[EVR] = {};           // recorded behind cycle c's last launch (c % EVR)
-  hipEvent_t ev_t0_[EVR] = {};              // ... and in front of its first (timing)
-  bool ev_timed_[EVR] = {};
-  std::vector<uint32_t> res_cycle_[4];      // [step % 4][s] the cycle that produced the result
-  std::atomic<bool> timing_{false};
-  double busy_ms_ = 0.0; uint32_t busy_from_ = 0; uint32_t timed_upto_ = 0;
-  uint32_t lm_chunk_ = 0, nb_ = 9;
-  void ensure_capacity(uint32_t cap_c, uint32_t cap_s);
-  void fill_args(OeArgs& A);
-};
 
 }  // namespace loamx

@@ -139,11 +139,6 @@ __device__ inline int nn1_shells(const GridDesc& g, const float4* __restrict__ s
   }
   return best_id;
 }
-__device__ inline int nn1_wave(const GridDesc& g, const float4* __restrict__ sorted, const uint32_t* __restrict__ cell_start, float qx,
-                               float qy, float qz, int lane) {
-  return nn1_shells(g, sorted, cell_start, qx, qy, qz, lane, 0, 25.0f, -1);
-}
-
 // ---- the 3x3x3 block of cells around a query, enumerated flat (round 4).  nn1_wave walks the rows of a shell one after the other, a
 // load latency each — ~10 of them before the 2.1 m shell is done.  Here: trip 1, the 18 boundaries of the block's 9 rows (a row's
 // three cells are one contiguous run of the cell-sorted array), one per lane; then the block's candidates numbered 0 .. total-1 across
@@ -470,131 +465,6 @@ __global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr_grid(OdomProblem
 #endif
 }
 
-// ---- phases A+B: correspondences of one feature by one wave: exact 1-NN, then the ring-window scans;
-// grid = (ceil(maxFeat/4), streams), 256 threads
-__global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr(OdomProblem* __restrict__ probs, OdomParams P) {
-  OdomProblem& pb = probs[blockIdx.y];
-  if (pb.done) return;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int nSharp = (int)pb.n_sharp, nFlat = (int)pb.n_flat;
-  // XCD-aware order.  Workgroup b runs on XCD b % 8 (gridDim.x is a multiple of 8) and every XCD has a private L2.  Features
-  // are emitted ring after ring, so XCD x takes the x-th eighth of the sharp list and the x-th eighth of the flat list
-  // of every stream: its scan windows then cover a band of ~8+4 rings of the previous clouds instead of all 64, which
-  // fits its L2 for all streams at once (unordered, each L2 pulled every cloud from HBM: 8x the traffic).
-  int f;
-  {
-    const int x = (int)(blockIdx.x % 8), j = (int)(blockIdx.x / 8);
-    const int sS = (int)((long long)x * nSharp / 8), nS = (int)((long long)(x + 1) * nSharp / 8) - sS;
-    const int sF = (int)((long long)x * nFlat / 8), nF = (int)((long long)(x + 1) * nFlat / 8) - sF;
-    const int fl = 4 * j + wid;   // position in this XCD's list: its sharp features, then its flat features
-    if (fl >= nS + nF) return;
-    f = fl < nS ? sS + fl : nSharp + sF + (fl - nS);
-  }
-  float T[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) T[k] = pb.transform[k];
-  const bool corner = f < nSharp;
-  const float4 pi = corner ? pb.sharp[f] : pb.flat[f - nSharp];
-  float x, y, z;
-  transform_to_start(T, P.scan_period, pi, x, y, z);
-  const GridDescB gd = corner ? *pb.lc_desc : *pb.ls_desc;
-  const int closest = nn1_wave(gd.g, pb.sorted, pb.cell_table + gd.cell_base, x, y, z, lane);
-  if (closest < 0) {   // wave-uniform
-    if (lane == 0) { pb.ind[5 * f] = -1; pb.ind[5 * f + 1] = -1; pb.ind[5 * f + 2] = -1; }
-    return;
-  }
-  const float4* last = corner ? pb.last_corner : pb.last_surf;
-  const int nLast = corner ? (int)pb.n_last_corner : (int)pb.n_last_surf;
-  const int nCur = corner ? nSharp : nFlat;
-  const int bound = nCur < nLast ? nCur : nLast;   // forward scans are bounded by the CURRENT feature count (:262, :378)
-  const int cscan = (int)last[closest].w;
-  float d2 = 25.f, d3 = 25.f;
-  int j2 = -1, j3 = -1, o2 = 0x7fffffff, o3 = 0x7fffffff;
-  // forward window (:262-279 / :378-403) and backward window (:280-297 / :404-429), walked TOGETHER: per trip 4 x 64 points of
-  // each direction are fetched (8 loads in flight per lane), then examined in scan order; a direction stops at its first point
-  // beyond +-2.5 rings.  (d, order) minima make the result independent of the interleaving: forward candidates order before
-  // backward ones, as in the reference's two consecutive loops.
-  auto better = [](float d, int order, float dbest, int obest) { return d < dbest || (d == dbest && obest != 0x7fffffff && order < obest); };   // scan order decides ties (never admits d == 25)
-  int baseF = closest + 1, baseB = closest - 1;
-  bool stopF = baseF >= bound, stopB = baseB < 0;
-  while (!stopF || !stopB) {
-    float4 qf[4], qb[4];
-    if (!stopF) {
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int j = baseF + 64 * u + lane;
-        qf[u] = j < bound ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    if (!stopB) {
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int j = baseB - 64 * u - lane;
-        qb[u] = j >= 0 ? last[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    if (!stopF) {
-      bool stop = false;
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        if (stop) continue;
-        const int j = baseF + 64 * u + lane;
-        const bool in = j < bound;
-        const int ring = (int)qf[u].w;
-        const bool brk = in && ((double)ring > (double)cscan + 2.5);
-        const unsigned long long mb = __ballot(brk);
-        const int fb = mb ? __builtin_ctzll(mb) : 64;
-        if (in && lane < fb) {
-          const float d = sqd(qf[u], x, y, z);
-          const int order = j - (closest + 1);
-          if (corner) {
-            if (ring > cscan && better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; }
-          } else {
-            if (ring <= cscan) { if (better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; } }
-            else { if (better(d, order, d3, o3)) { d3 = d; j3 = j; o3 = order; } }
-          }
-        }
-        if (mb) stop = true;
-      }
-      baseF += 256;
-      stopF = stop || baseF >= bound;
-    }
-    if (!stopB) {
-      bool stop = false;
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        if (stop) continue;
-        const int j = baseB - 64 * u - lane;
-        const bool in = j >= 0;
-        const int ring = (int)qb[u].w;
-        const bool brk = in && ((double)ring < (double)cscan - 2.5);
-        const unsigned long long mb = __ballot(brk);
-        const int fb = mb ? __builtin_ctzll(mb) : 64;
-        if (in && lane < fb) {
-          const float d = sqd(qb[u], x, y, z);
-          const int order = 0x40000000 + (closest - 1 - j);   // backward candidates come after all forward ones
-          if (corner) {
-            if (ring < cscan && better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; }
-          } else {
-            if (ring >= cscan) { if (better(d, order, d2, o2)) { d2 = d; j2 = j; o2 = order; } }
-            else { if (better(d, order, d3, o3)) { d3 = d; j3 = j; o3 = order; } }
-          }
-        }
-        if (mb) stop = true;
-      }
-      baseB -= 256;
-      stopB = stop || baseB < 0;
-    }
-  }
-  wave_argmin(d2, j2, o2);
-  if (!corner) wave_argmin(d3, j3, o3);
-  if (lane == 0) {
-    pb.ind[5 * f] = closest;
-    pb.ind[5 * f + 1] = j2;
-    pb.ind[5 * f + 2] = corner ? -1 : j3;
-  }
-}
-
 // ---- phase C: iterations [iter0, iter0 + n_iters) of one stream in gridDim.x PERSISTENT workgroups (grid = NB x streams).
 // The features of a stream are dealt out over its NB workgroups (one CU cannot evaluate 2304 rows in less than ~16 us,
 // nine can).  Per iteration every workgroup reduces its rows to 28 double sums, publishes them (double-buffered by
@@ -670,9 +540,7 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
     }
   }
 
-  // iter0 < 0 (OdomEngine): every stream is at its own iteration — the launch continues where the problem says and stops at the cap
-  const int it_begin = iter0 >= 0 ? iter0 : pb.iter0;
-  const int it_end = iter0 >= 0 ? iter0 + n_iters : min(pb.iter0 + n_iters, P.max_iterations);
+  const int it_begin = iter0, it_end = iter0 + n_iters;
   for (int iter = it_begin; iter < it_end; iter++) {
     // ---- phase C: residual rows + normal equations
     LM_TS(0);
@@ -936,8 +804,6 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
 
 #pragma clang diagnostic pop
 
-__global__ void k_odom_noop(const OdomProblem* __restrict__ probs) { (void)probs; }
-
 // transformToEnd (:57-87) of one point
 __device__ inline float4 to_end_point(float4 p, const ToEndParams& P) {
   const float s = (1.f / P.scan_period) * (p.w - (float)(int)p.w);
@@ -1083,7 +949,32 @@ OdometryBatch::~OdometryBatch() {
   if (ev_up_) (void)hipEventDestroy(ev_up_);
   if (ev_pose_) (void)hipEventDestroy(ev_pose_);
   for (auto* p : streams_) delete p;
+  for (auto& c : lt_) for (auto& e : c.ev) if (e) (void)hipEventDestroy(e);
   if (own_stream_ && st_) (void)hipStreamDestroy(st_);
+}
+
+void OdometryBatch::lt_resolve_() {
+  for (auto& c : lt_) {
+    if (!c.pending || !c.pairs) continue;
+    if (hipEventQuery(c.ev[3 * (c.pairs - 1) + 2]) != hipSuccess) { (void)hipGetLastError(); continue; }
+    for (int k = 0; k < c.pairs; k++) {
+      float a = 0.f, b = 0.f;
+      if (hipEventElapsedTime(&a, c.ev[3 * k], c.ev[3 * k + 1]) != hipSuccess || hipEventElapsedTime(&b, c.ev[3 * k + 1], c.ev[3 * k + 2]) != hipSuccess) { (void)hipGetLastError(); continue; }
+      if (c.iters[k] > 0) {
+        lt_tot_.corr_ms += a; lt_tot_.corr_launches++; lt_tot_.corr_features += c.feats[k];
+        lt_tot_.lm_ms += b; lt_tot_.lm_launches++; lt_tot_.lm_iterations += (uint64_t)c.iters[k]; lt_tot_.lm_bytes += c.bytes[k];
+      } else {
+        lt_tot_.corr_noop_ms += a; lt_tot_.corr_noop_launches++;
+        lt_tot_.lm_noop_ms += b; lt_tot_.lm_noop_launches++;
+      }
+    }
+    c.pending = false;
+  }
+}
+OdometryBatch::LaunchTotals OdometryBatch::launch_totals() {
+  std::lock_guard<std::mutex> lk(lt_mu_);
+  lt_resolve_();
+  return lt_tot_;
 }
 
 void odom_set_imu(OdomStream& S, const float* t);
@@ -1244,15 +1135,24 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   if (!ev_up_) LX_HIP(hipEventCreateWithFlags(&ev_up_, hipEventDisableTiming));
   LX_HIP(hipEventRecord(ev_up_, st_));
   up_pending_ = true;
+  LtCall* lt = nullptr;
+  if (launch_timing_.load(std::memory_order_relaxed) && na && max_feat) {
+    std::lock_guard<std::mutex> lk(lt_mu_);
+    lt_resolve_();
+    LtCall& c = lt_[lt_next_ % LT_RING];
+    if (!c.pending) { lt = &c; lt_next_++; c.pairs = 0; }   // (a call whose slot is still in flight goes untimed)
+  }
   if (na) {
     if (max_feat) {
       for (int it0 = 0; it0 < params.max_iterations; it0 += 5) {
         const int nit = std::min(5, params.max_iterations - it0);
-        static const bool corr_legacy = getenv("LOAMX_ODOM_CORR_LEGACY") != nullptr;   // A/B: the wave-per-feature kernel streaming its windows through L2
-        if (corr_legacy)
-          hipLaunchKernelGGL(k_odom_corr, dim3(8 * (((max_sharp + 7) / 8 + (max_flat + 7) / 8 + 3) / 4), na), dim3(256), 0, st_, prob_.p, params);
-        else
-          hipLaunchKernelGGL(k_odom_corr_grid, dim3(8 * (((max_sharp + 7) / 8 + (max_flat + 7) / 8 + 3) / 4), na), dim3(256), 0, st_, prob_.p, params);
+        const int lk = lt && lt->pairs < LT_MAXP ? lt->pairs : -1;
+        if (lk >= 0) {
+          for (int e = 0; e < 3; e++) if (!lt->ev[3 * lk + e]) LX_HIP(hipEventCreate(&lt->ev[3 * lk + e]));
+          LX_HIP(hipEventRecord(lt->ev[3 * lk], st_));
+        }
+        hipLaunchKernelGGL(k_odom_corr_grid, dim3(8 * (((max_sharp + 7) / 8 + (max_flat + 7) / 8 + 3) / 4), na), dim3(256), 0, st_, prob_.p, params);
+        if (lk >= 0) LX_HIP(hipEventRecord(lt->ev[3 * lk + 1], st_));
         const uint32_t nb = std::min<uint32_t>(16u, (max_feat + OD_THREADS - 1) / OD_THREADS);
         // k_odom_lm's workgroups of one stream spin on each other: everything a launch puts on the device must be resident
         // at once.  The launch is cut into chunks of streams that fill at most half of what the device can hold (occupancy x
@@ -1272,11 +1172,8 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
           if (two) hipLaunchKernelGGL(k_odom_lm<2>, dim3(nb, nc), dim3(OD_THREADS), 0, st_, prob_.p + a0, params, it0, nit);
           else hipLaunchKernelGGL(k_odom_lm<1>, dim3(nb, nc), dim3(OD_THREADS), 0, st_, prob_.p + a0, params, it0, nit);
         }
+        if (lk >= 0) { LX_HIP(hipEventRecord(lt->ev[3 * lk + 2], st_)); lt->pairs = lk + 1; }
       }
-    }
-    {   // diagnostic (LOAMX_ODOM_NOOPS=n): n empty launches behind the iterations — what a kernel boundary costs the OTHER chains
-      static const int noops = getenv("LOAMX_ODOM_NOOPS") ? atoi(getenv("LOAMX_ODOM_NOOPS")) : 0;
-      for (int k = 0; k < noops; k++) hipLaunchKernelGGL(k_odom_noop, dim3(1), dim3(64), 0, st_, prob_.p);
     }
     if (!max_feat) LX_HIP(hipMemcpyAsync(h_mirror_.p, prob_.p, sizeof(OdomProblem) * na, hipMemcpyDeviceToHost, st_));   // (no launch wrote the mirror)
     if (!ev_pose_) LX_HIP(hipEventCreateWithFlags(&ev_pose_, hipEventDisableTiming));
@@ -1285,7 +1182,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   }
   // ---- re-project to the sweep end (:651-652), hand over as "last" clouds and rebuild their index (:654-664): enqueued
   // right behind the iterations; the host only waits for the poses
-  static const bool fuse_bounds = !(getenv("LOAMX_BB_FUSED") && atoi(getenv("LOAMX_BB_FUSED")) == 0);   // diagnostic: 0 = separate k_bb_bbox launch
+  static const bool fuse_bounds = !(diag_env("LOAMX_BB_FUSED") && atoi(diag_env("LOAMX_BB_FUSED")) == 0);   // diagnostic: 0 = separate k_bb_bbox launch
   if (n_all)
   {
     if (++rf_epoch_ > 255u) rf_epoch_ = 1u;   // entries of this re-projection carry the new epoch; the problems of the NEXT call name it
@@ -1340,6 +1237,21 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       S.stats.iterations = h_mirror_.p[a].stats.iterations;
       S.stats.sel = h_mirror_.p[a].stats.sel;
       S.stats.degenerate = h_mirror_.p[a].stats.degenerate;
+    }
+    if (lt) {   // what every timed launch did, now that the iteration counts are known
+      std::lock_guard<std::mutex> lk(lt_mu_);
+      for (int k = 0; k < lt->pairs; k++) {
+        lt->iters[k] = 0; lt->bytes[k] = 0; lt->feats[k] = 0;
+        for (uint32_t a = 0; a < na; a++) {
+          const int it = h_mirror_.p[a].stats.iterations - 5 * k;
+          if (it <= 0) continue;
+          const uint64_t nf = (uint64_t)in[active[a]].n_sharp + in[active[a]].n_flat;
+          lt->iters[k] = std::max(lt->iters[k], std::min(it, 5));
+          lt->bytes[k] += 48ull * nf;
+          lt->feats[k] += nf;
+        }
+      }
+      lt->pending = true;
     }
   }
   // ---- pose integration (:626-649)
@@ -1397,6 +1309,9 @@ int OdometryBatch::process_host(const loamx_cloud* sharp, const loamx_cloud* les
   h_stage_.reserve(off[4] + 1);
   up_[0].reserve(off[4] + 1);
   for (int k = 0; k < 4; k++) pack_cloud(cl[k], h_stage_.p + off[k]);
+  // feature clouds are finite by contract (BasicLaserOdometry.cpp:230, :252 strip NaN points as a safeguard; the registration stage
+  // never produces them): a caller that hands over NaN / Inf coordinates is told instead of getting a pose through NaN arithmetic
+  if (!packed_all_finite(h_stage_.p, off[4])) throw Error(LOAMX_E_INVALID, "a feature cloud holds non-finite coordinates");
   if (off[4]) LX_HIP(hipMemcpyAsync(up_[0].p, h_stage_.p, sizeof(float4) * off[4], hipMemcpyHostToDevice, st_));
   OdomInput in{up_[0].p, sharp->count, up_[0].p + off[1], less_sharp->count, up_[0].p + off[2], flat->count, up_[0].p + off[3], less_flat->count};
   int rc = LOAMX_OK;
@@ -1460,7 +1375,5 @@ int OdometryBatch::transform_to_end_host(uint32_t s, loamx_cloud* cloud) {
   LX_HIP(hipStreamSynchronize(st_));
   return unpack_cloud(h_stage_.p, n, cloud);
 }
-
-#include "odom_engine.inc"
 
 }  // namespace loamx

@@ -47,31 +47,16 @@ class Pipeline {
     // the slowest of all streams (profiles/r03: 5.2 pairs per step for a mean of 7.1 iterations).  Default 2: measured on MI355X
     // (profiles/r04_groups_ab.md) 1 -> 2 chains gains 8 %, but with 4 (six busy HIP streams in the process) EVERY chain slows down
     // (registration 0.55 -> 0.88 ms, k_gn_iter 64 -> 93 us) and the step is 35 % slower than with one.
-    // Round 4, second step: the OdomEngine (odom_engine.inc) lets EVERY stream run at its own pace on one HIP stream (a per-stream state
-    // machine on the device, cycles of shared launches).  Bit-identical to the chains (tests/test_gpu_pipeline.py runs both), but NOT
-    // the default: on the bench workload the stragglers are persistent — a stream that needs 25 iterations needs them for five or six
-    // sweeps in a row — so the slowest stream still needs 57 launch pairs over the 20 timed steps (the lock-step chains of 4 streams:
-    // 60 and 71), and a cycle that serves streams in every phase (begin + correspondences + iterations + re-projection + three index
-    // launches = ~165 us) costs more than a chain's pair (~100 us): 11.2 k sweeps/s against the chains' 13.1 k
-    // (profiles/r04_odom_engine.md).  LOAMX_ODOM_ENGINE=1 selects it; LOAMX_ODOM_ENGINES = how many (default 2 x half the streams).
-    use_engine = getenv("LOAMX_ODOM_ENGINE") && atoi(getenv("LOAMX_ODOM_ENGINE")) != 0;
+    // Round 4 / 5, measured and removed: an engine that let EVERY stream run at its own pace inside shared launches (a per-stream state
+    // machine on the device).  Bit-identical, but slower on the bench workload even with six steps of look-ahead and its thread off
+    // the runtime's locks (16.3 k sweeps/s against the chains' 17.9 k, profiles/r05_ab.md): the code is in the history (odom_engine.inc).
     OdomParams op;
     op.scan_period = oc.scan_period;
-    op.max_iterations = getenv("LOAMX_ODOM_MAXIT") ? atoi(getenv("LOAMX_ODOM_MAXIT")) : oc.max_iterations;   // (diagnostic override)
+    op.max_iterations = diag_env("LOAMX_ODOM_MAXIT") ? atoi(diag_env("LOAMX_ODOM_MAXIT")) : oc.max_iterations;   // (diagnostic override, LOAMX_DIAG builds only)
+    if (op.max_iterations < 1 || op.max_iterations > 255) throw Error(LOAMX_E_INVALID, "odometry max_iterations must be in [1, 255]");   // (k_odom_lm tags its exchange records with iteration + 1 in 8 bits)
     op.delta_t_abort = oc.delta_t_abort;
     op.delta_r_abort = oc.delta_r_abort;
-    if (use_engine) {
-      n_groups = 0;
-      int ne = (int)std::min<uint32_t>(n_streams, 2);   // two engines of half the streams each overlap like two chains do (profiles/r04_groups_ab.md: up to four busy HIP streams)
-      if (const char* e = getenv("LOAMX_ODOM_ENGINES")) ne = std::max(1, std::min(atoi(e), (int)std::min<uint32_t>(n_streams, 8)));
-      for (int e = 0; e <= ne; e++) eng_s0.push_back((uint32_t)((uint64_t)e * n_streams / ne));
-      for (int e = 0; e < ne; e++) {
-        const uint32_t s0 = eng_s0[e], s1 = eng_s0[e + 1];
-        auto* x = new OdomEngine(mc.device, s1 - s0, op, [this, s0, s1](uint32_t t, OdomInput* in, float* imu, bool& has_imu) { return fetch_odom_inputs(t, s0, s1, in, imu, has_imu); });
-        if (e == 0) eng.reset(x); else engines_extra.emplace_back(x);
-      }
-      gather_util.reset(new OdometryBatch(mc.device, 1, nullptr));
-    } else {
+    {
       int g = (int)std::min<uint32_t>(n_streams, 2);
       if (const char* e = getenv("LOAMX_ODOM_GROUPS")) g = atoi(e);
       n_groups = (uint32_t)std::max(1, std::min(g, (int)std::min<uint32_t>(n_streams, MAX_GROUPS)));
@@ -116,14 +101,6 @@ class Pipeline {
     std::atomic<float> last_us{0.f};     // host time of the chain's most recent pass (LOAMX_PIPE_TRACE)
   };
   static constexpr uint32_t MAX_GROUPS = 16;
-  bool use_engine = true;
-  std::unique_ptr<OdomEngine> eng;             // every stream at its own pace; else the chains below.  (eng = engines[0]: "an engine exists")
-  std::vector<std::unique_ptr<OdomEngine>> engines_extra;   // further engines: engine e owns the streams [eng_s0[e], eng_s0[e + 1])
-  std::vector<uint32_t> eng_s0;                // n_engines + 1 stream boundaries
-  uint32_t n_engines() const { return eng ? 1u + (uint32_t)engines_extra.size() : 0u; }
-  OdomEngine& E(uint32_t e) { return e == 0 ? *eng : *engines_extra[e - 1]; }
-  std::unique_ptr<OdometryBatch> gather_util;  // (to_end_gather's staging buffers when there are no chains)
-  std::atomic<int> f_pub{-1};                  // features of the steps <= f_pub have been launched (read by the engine's thread)
   uint32_t n_groups = 1;
   std::vector<std::unique_ptr<OdomChain>> chains;
   OdomChain& chain_of(uint32_t s) { uint32_t g = 0; while (g + 1 < n_groups && s >= chains[g]->s1) g++; return *chains[g]; }
@@ -238,9 +215,9 @@ class Pipeline {
   // Steps the odometry chains may run ahead of the registration.  A stream that needs all 25 iterations needs them for five or six
   // sweeps in a row (a chain then takes ~570 us per step against the registration's ~430): on average the chains keep up, and a deeper
   // look-ahead lets them build the lead that such a run eats (depth 2: 15.6 k sweeps/s, 4: 16.6 k, 6: 16.9 k, 8 - 12: 16.4 - 16.6 k;
-  // profiles/r04_ab.md).  The streaming ring holds RING = 8 slots: the same six steps; the engine keeps a result ring of its own (two).
+  // profiles/r04_ab.md).  The streaming ring holds RING = 8 slots: the same six steps.
   int ahead_depth = std::max(1, std::min(getenv("LOAMX_ODOM_AHEAD") ? atoi(getenv("LOAMX_ODOM_AHEAD")) : 6, OR - 2));
-  int depth() const { return !prefetch ? 0 : (eng ? std::min(ahead_depth, 2) : (streaming ? std::min(ahead_depth, (int)RING - 2) : ahead_depth)); }
+  int depth() const { return !prefetch ? 0 : (streaming ? std::min(ahead_depth, (int)RING - 2) : ahead_depth); }
   float last_ms[4] = {0, 0, 0, 0};
   std::atomic<bool> timing{false};
 
@@ -274,7 +251,7 @@ class Pipeline {
     (void)hipSetDevice(device);
     for (;;) {
       auto ready = [&] { return c.next.load(std::memory_order_acquire) <= o_limit.load(std::memory_order_acquire); };
-      static const double spin_us = getenv("LOAMX_SPIN_US") ? atof(getenv("LOAMX_SPIN_US")) : 400.0;   // diagnostic
+      static const double spin_us = diag_env("LOAMX_SPIN_US") ? atof(diag_env("LOAMX_SPIN_US")) : 400.0;   // diagnostic
       if (!spin_until(ready, spin_us)) {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return ready() || quit; });
@@ -304,7 +281,6 @@ class Pipeline {
   }
   // calling thread: allow the odometry chains to run up to step k
   void allow_odometry(int k) {
-    if (eng) { publish_features_upto(f_hi); for (uint32_t e = 0; e < n_engines(); e++) E(e).set_limit(k); return; }
     if (k <= o_limit.load(std::memory_order_acquire)) return;
     for (auto& c : chains)
       if (!c->worker.joinable()) { OdomChain* cp = c.get(); c->worker = std::thread([this, cp] { worker_main(cp); }); }
@@ -313,19 +289,6 @@ class Pipeline {
   }
   // calling thread: block until O(t) of every chain is published (rethrows a failure of a worker)
   void wait_odometry(int t) {
-    if (eng) {
-      for (uint32_t e = 0; e < n_engines(); e++) E(e).wait_step((uint32_t)t);
-      for (uint32_t s = 0; s < n_streams_; s++) {
-        uint32_t e = 0;
-        while (s >= eng_s0[e + 1]) e++;
-        const OdomStepResult& R = E(e).result((uint32_t)t, s - eng_s0[e]);
-        OdomPub& N = ores[t % OR][s];
-        N.transform = R.transform; N.transform_sum = R.transform_sum; N.stats = R.stats; N.rc = R.rc;
-        N.last_corner = R.last_corner; N.n_last_corner = R.n_last_corner; N.last_surf = R.last_surf; N.n_last_surf = R.n_last_surf;
-        N.to_end = R.to_end;
-      }
-      return;
-    }
     auto ready = [&] { return done_min() >= t || (!any_busy() && o_limit.load(std::memory_order_acquire) < t); };
     if (!spin_until(ready, 2000.0)) {
       std::unique_lock<std::mutex> lk(mu);
@@ -338,14 +301,6 @@ class Pipeline {
   // calling thread: block until the look-ahead has finished every step it has been allowed to run (its kernels are enqueued then:
   // a device synchronisation afterwards covers them).  Returns the last step whose odometry is published for every stream, -1 if none.
   int drain_lookahead() {
-    if (eng) {
-      int done = INT32_MAX;
-      for (uint32_t e = 0; e < n_engines(); e++) {
-        if (prefetch && E(e).limit() >= eng_first) E(e).wait_step((uint32_t)E(e).limit());
-        done = std::min(done, E(e).done_upto() - 1);
-      }
-      return done;
-    }
     const int lim = o_limit.load(std::memory_order_acquire);
     if (prefetch && lim >= 0 && chains[0]->worker.joinable()) wait_odometry(lim);
     return done_min();
@@ -355,14 +310,6 @@ class Pipeline {
   // have gone idle, under the mutex (a position read before the wait is stale by the step a worker was inside: ADVICE.md round 3)
   void park_odometry(int restart) {
     if (restart >= 0) pre_t = -1;   // (a pre-staged re-projection belongs to the run that is abandoned)
-    if (eng) {
-      for (uint32_t e = 0; e < n_engines(); e++) {
-        if (restart >= 0) E(e).restart((uint32_t)restart, false);
-        else E(e).park();
-      }
-      if (restart >= 0) { eng_first = eng_expect = restart; f_pub.store(restart - 1, std::memory_order_release); }
-      return;
-    }
     std::unique_lock<std::mutex> lk(mu);
     o_limit.store(-1, std::memory_order_release);
     cv.wait(lk, [&] { return !any_busy(); });
@@ -375,9 +322,7 @@ class Pipeline {
     job_err = nullptr;
   }
   // (upload / first use of the streaming ring: every chain starts over at step 0)
-  int eng_first = 0, eng_expect = 0;   // first step of the engine's current run / the step the next step() call is expected to name
   void reset_odometry() {
-    if (eng) { for (uint32_t e = 0; e < n_engines(); e++) E(e).restart(0, false); eng_first = eng_expect = 0; f_pub.store(-1, std::memory_order_release); return; }
     std::unique_lock<std::mutex> lk(mu);
     o_limit.store(-1, std::memory_order_release);
     cv.wait(lk, [&] { return !any_busy(); });
@@ -386,8 +331,6 @@ class Pipeline {
   }
 
   ~Pipeline() {
-    engines_extra.clear();
-    eng.reset();   // (their threads read the feature extractors' buffers)
     { std::lock_guard<std::mutex> lk(mu); quit = true; o_limit.store(-1, std::memory_order_release); }
     cv.notify_all();   // (a worker leaves its spin phase after 0.4 ms and then sees quit)
     for (auto& c : chains) if (c->worker.joinable()) c->worker.join();
@@ -433,7 +376,7 @@ class Pipeline {
   void upload(uint32_t n_steps, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
     LX_REQUIRE(n_steps >= 1 && clouds && ring_size && n_rings, "invalid argument");
     LX_HIP(hipSetDevice(device));
-    if (!fstream) fstream = create_stream(env_priority("LOAMX_PRIO_FEAT", -1), getenv("LOAMX_FEAT_CU_STRIDE") ? atoi(getenv("LOAMX_FEAT_CU_STRIDE")) : 0);
+    if (!fstream) fstream = create_stream(env_priority("LOAMX_PRIO_FEAT", -1), diag_env("LOAMX_FEAT_CU_STRIDE") ? atoi(diag_env("LOAMX_FEAT_CU_STRIDE")) : 0);
     LX_HIP(hipStreamSynchronize(fstream));
     fx.clear();
     streaming = false;
@@ -461,7 +404,7 @@ class Pipeline {
   void ensure_streaming_(uint32_t t) {
     if (!streaming) {   // first use: switch to the ring of slots
       LX_REQUIRE(t == 0, "streaming input starts at step 0");
-      if (!fstream) fstream = create_stream(env_priority("LOAMX_PRIO_FEAT", -1), getenv("LOAMX_FEAT_CU_STRIDE") ? atoi(getenv("LOAMX_FEAT_CU_STRIDE")) : 0);
+      if (!fstream) fstream = create_stream(env_priority("LOAMX_PRIO_FEAT", -1), diag_env("LOAMX_FEAT_CU_STRIDE") ? atoi(diag_env("LOAMX_FEAT_CU_STRIDE")) : 0);
       LX_HIP(hipStreamSynchronize(fstream));
       fx.clear();
       for (uint32_t k = 0; k < RING; k++) {
@@ -718,28 +661,6 @@ class Pipeline {
   }
   uint64_t run_count = 0;   // registrations run so far (parity = which full-resolution buffer)
 
-  // OdomEngine's input callback (its thread; must not block): the four feature clouds of every stream of step t once the step's
-  // features have been launched AND extracted
-  bool fetch_odom_inputs(uint32_t t, uint32_t s0, uint32_t s1, OdomInput* in, float* imu, bool& has_imu) {
-    if ((int)t > f_pub.load(std::memory_order_acquire)) return false;
-    if (hipEventQuery(evF[t % OR][1]) != hipSuccess) { (void)hipGetLastError(); return false; }
-    const uint32_t ns = n_streams_;
-    FeatureExtractor& F = FX(t);
-    uint32_t* hb = h_off3[t % OR].p;
-    uint32_t* ho[3] = {hb, hb + (ns + 1), hb + 2 * (ns + 1)};
-    uint32_t* hlf = hb + 3 * (ns + 1);
-    if (s0 == 0 && timing.load(std::memory_order_relaxed)) (void)hipEventElapsedTime(&feat_ms[t % OR], evF[t % OR][0], evF[t % OR][1]);
-    for (uint32_t s = s0; s < s1; s++) {
-      const uint32_t la = hlf[F.ring_base(s)], lb = hlf[F.ring_base(s + 1)];
-      in[s - s0] = OdomInput{F.d_feat(0) + ho[0][s], ho[0][s + 1] - ho[0][s], F.d_feat(1) + ho[1][s], ho[1][s + 1] - ho[1][s],
-                             F.d_feat(2) + ho[2][s], ho[2][s + 1] - ho[2][s], F.d_less_flat() + la, lb - la};
-    }
-    has_imu = streaming && rawslot[t % RING].raw;   // imuTrans of this sweep (ScanRegistration publishes it with the clouds; LaserOdometry.cpp:239-248)
-    if (has_imu) memcpy(imu, rawslot[t % RING].imu_trans.data() + 12 * (size_t)s0, sizeof(float) * 12 * (s1 - s0));
-    return true;
-  }
-  void publish_features_upto(int k) { if (k > f_pub.load(std::memory_order_relaxed)) f_pub.store(k, std::memory_order_release); }
-
   // odometry of staged step t for the streams of one chain (needs the step's features, launched by the calling thread); results go to
   // ores[t % OR]
   void run_odometry(OdomChain& c, uint32_t t) {
@@ -751,6 +672,7 @@ class Pipeline {
     uint32_t* ho[3] = {hb, hb + (ns + 1), hb + 2 * (ns + 1)};
     uint32_t* hlf = hb + 3 * (ns + 1);
     LX_HIP(hipEventSynchronize(evF[t % OR][1]));
+    F.check_finite_input();   // (LOAMX_E_INVALID out of step(): a staged sweep with NaN / Inf coordinates)
     c.tr[1] = tr_us();
     const bool timed = timing.load(std::memory_order_relaxed);   // latched: the caller flips the flag while this chain runs steps ahead
     if (timed && c.s0 == 0) LX_HIP(hipEventElapsedTime(&feat_ms[t % OR], evF[t % OR][0], evF[t % OR][1]));
@@ -803,15 +725,10 @@ class Pipeline {
   // between two steps' registrations.  (The host waits for M(t) at an event recorded in front of this work: Registrar::run_iterations.)
   int pre_t = -1;   // the step whose full-resolution clouds have been pre-staged
   void prestage_gather(int tn, int last_staged, hipStream_t s_) {
-    static const bool off = !(getenv("LOAMX_PRESTAGE") && atoi(getenv("LOAMX_PRESTAGE")) != 0);   // measured: no gain (15.44 k with, 15.51 k without; profiles/r04_ab.md) — the step is not bound by this copy + kernel; opt-in
+    static const bool off = !(diag_env("LOAMX_PRESTAGE") && atoi(diag_env("LOAMX_PRESTAGE")) != 0);   // measured: no gain (15.44 k with, 15.51 k without; profiles/r04_ab.md) — the step is not bound by this copy + kernel; opt-in
     if (off || !prefetch || pre_t == tn || tn > last_staged || tn < 1) return;
     const uint32_t ns = n_streams_;
-    if (eng) {
-      for (uint32_t e = 0; e < n_engines(); e++) if (E(e).done_upto() <= tn) return;
-      wait_odometry(tn);   // (done: integrates and copies the results, does not block)
-    } else if (done_min() < tn) {
-      return;
-    }
+    if (done_min() < tn) return;
     FeatureExtractor& F = FX((uint32_t)tn);
     std::vector<const float4*> fsrc;
     std::vector<uint32_t> nfr;
@@ -832,7 +749,7 @@ class Pipeline {
     if (!dst) return;
     std::vector<uint32_t> foff(nw + 1, 0);
     for (uint32_t k = 0; k < nw; k++) foff[k + 1] = foff[k] + nfr[k];
-    (eng ? gather_util.get() : chains[0]->ob.get())->to_end_gather(dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
+    chains[0]->ob->to_end_gather(dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
     pre_t = tn;
   }
 
@@ -858,14 +775,7 @@ class Pipeline {
     const uint32_t ns = n_streams_;
     // ---- this step's odometry: published by the look-ahead (the normal case), or run now
     const int ti = (int)t, last_staged = (int)n_staged() - 1;
-    if (eng) {
-      // the engine runs the steps in order from eng_first; a call that names neither the expected step nor one of the two before it
-      // (whose results are still in the ring) is a jump: every stream restarts there
-      if (!(ti == eng_expect || (ti < eng_expect && ti + 2 >= eng_expect && ti >= eng_first))) {
-        park_odometry(ti);
-        f_hi = ti - 1;
-      }
-    } else {
+    {
       bool jump = false;   // a chain for which this is neither a finished step nor its next one: the caller jumped, the chains restart here
       for (auto& c : chains) jump = jump || (ti > c->done.load(std::memory_order_acquire) && ti != c->next.load(std::memory_order_acquire));
       if (jump) {
@@ -877,16 +787,8 @@ class Pipeline {
     auto launch_upto = [&](int k) {   // features of the steps up to k (launched by this thread only, in step order)
       if (k > last_staged) k = last_staged;
       while (f_hi < k) { ++f_hi; if (!LA((uint32_t)f_hi)) launch_features((uint32_t)f_hi); }
-      if (eng) publish_features_upto(f_hi);
     };
-    if (eng) {
-      if (ti >= eng_expect) {
-        launch_upto(prefetch ? ti + 1 : ti);
-        allow_odometry(prefetch ? std::min(ti + 1, last_staged) : ti);
-      }
-      wait_odometry(ti);
-      eng_expect = std::max(eng_expect, ti + 1);
-    } else if (ti > done_min()) {
+    if (ti > done_min()) {
       launch_upto(prefetch ? ti + 1 : ti);
       if (prefetch) {
         allow_odometry(std::min(ti + 1, last_staged));
@@ -906,7 +808,6 @@ class Pipeline {
     FeatureExtractor& F = FX(t);
     const float f_ms = feat_ms[t % OR];
     // the re-projected "last" clouds of THIS sweep are produced at the tails of the odometry chains
-    for (uint32_t e = 0; e < n_engines(); e++) if (hipEvent_t ev = E(e).tail_event(t)) LX_HIP(hipStreamWaitEvent(s_, ev, 0));
     for (auto& c : chains) LX_HIP(hipStreamWaitEvent(s_, c->ev_tail[t % OR], 0));
     // ---- look-ahead while M(t) runs: the odometry chain may go on to step t+1 now and — once M(t) is enqueued and the features
     // of step t+2 are launched (while this thread waits for M(t)'s first look at the flags) — to step t+2
@@ -967,7 +868,7 @@ class Pipeline {
             if (d2h_pending[par]) { LX_HIP(hipStreamWaitEvent(s_, ev_d2h[par], 0)); d2h_pending[par] = false; }
           }
           float4* full_dst = reg.stage_full(nw, nfr.data());
-          (eng ? gather_util.get() : chains[0]->ob.get())->to_end_gather(full_dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
+          chains[0]->ob->to_end_gather(full_dst, foff.data(), fsrc.data(), tep.data(), nw, s_);
         }
         last_full_off = foff;
         run_count++;
@@ -975,7 +876,7 @@ class Pipeline {
         // transformUpdate's IMU blend (BasicLaserMapping.cpp:171-200) changes transformTobeMapped BEFORE the full-resolution cloud is
         // registered (:235-240): a step with mapping-side IMU data for any of its streams registers its clouds after the blend
         bool blend = false;
-        static const bool no_blend = getenv("LOAMX_NO_MAP_IMU_BLEND") != nullptr;   // (tests: what the poses would be without the blend)
+        static const bool no_blend = diag_env("LOAMX_NO_MAP_IMU_BLEND") != nullptr;   // (tests: what the poses would be without the blend)
         if (!no_blend && streaming && rawslot[t % RING].raw && !rawslot[t % RING].scan_time.empty())
           for (uint32_t k = 0; k < nw; k++) blend = blend || rawslot[t % RING].map_imu_upto[who[k]] > 0;
         reg.defer_full = blend;
@@ -1043,7 +944,6 @@ class Pipeline {
       {   // the odometry chains (overlapped with the registrations): the longest chain's most recent timed pass
         float m = 0.f;
         for (auto& c : chains) m = std::max(m, c->ms.load(std::memory_order_relaxed));
-        for (uint32_t e = 0; e < n_engines(); e++) m = std::max(m, E(e).busy_ms_per_step());   // device time of an engine's cycles per finished step
         last_ms[1] = m;
       }
       last_ms[2] = tmM[t & 1].pending ? tmM[(t + 1) & 1].ms : tmM[t & 1].ms;   // the previous step's while this one is in flight
@@ -1121,17 +1021,8 @@ int loamx_pipeline_set_state(loamx_pipeline* h, uint32_t stream, const float* tr
   return guard([&]() {
     LX_REQUIRE(h && stream < h->p.n_streams_, "invalid stream");
     h->p.park_odometry(-1);   // the odometry chains stop where they are; the sweeps they have not processed yet start from the new state
-    if (h->p.eng) {
-      uint32_t e = 0;
-      while (stream >= h->p.eng_s0[e + 1]) e++;
-      OdomEngine& G = h->p.E(e);
-      const uint32_t l = stream - h->p.eng_s0[e];
-      if (transform) { G.stream_state(l).transform.set(transform); G.push_transform(l); }
-      if (transform_sum) G.stream_state(l).transform_sum.set(transform_sum);
-    } else {
-      if (transform) h->p.OB(stream).stream_state(h->p.LS(stream)).transform.set(transform);
-      if (transform_sum) h->p.OB(stream).stream_state(h->p.LS(stream)).transform_sum.set(transform_sum);
-    }
+    if (transform) h->p.OB(stream).stream_state(h->p.LS(stream)).transform.set(transform);
+    if (transform_sum) h->p.OB(stream).stream_state(h->p.LS(stream)).transform_sum.set(transform_sum);
     if (bef) h->p.st[stream].bef.set(bef);
     if (aft) h->p.st[stream].aft.set(aft);
     return LOAMX_OK;
@@ -1237,8 +1128,22 @@ int loamx_pipeline_set_timing(loamx_pipeline* h, int on) {
   return guard([&]() {
     LX_REQUIRE(h, "NULL handle");
     h->p.timing = on != 0;
-    for (uint32_t e = 0; e < h->p.n_engines(); e++) h->p.E(e).set_timing(on != 0);
     h->p.reg.set_timing(on != 0, on != 2);
+    for (auto& c : h->p.chains) c->ob->set_launch_timing(on != 0 && on != 2);
+    return LOAMX_OK;
+  });
+}
+int loamx_pipeline_get_odom_launch_timing(loamx_pipeline* h, double ms4[4], uint64_t counts7[7]) {
+  return guard([&]() {
+    LX_REQUIRE(h && ms4 && counts7, "NULL argument");
+    for (int k = 0; k < 4; k++) ms4[k] = 0.0;
+    for (int k = 0; k < 7; k++) counts7[k] = 0;
+    for (auto& c : h->p.chains) {
+      const OdometryBatch::LaunchTotals t = c->ob->launch_totals();
+      ms4[0] += t.lm_ms; ms4[1] += t.lm_noop_ms; ms4[2] += t.corr_ms; ms4[3] += t.corr_noop_ms;
+      counts7[0] += t.lm_launches; counts7[1] += t.lm_noop_launches; counts7[2] += t.lm_iterations; counts7[3] += t.corr_launches;
+      counts7[4] += t.corr_noop_launches; counts7[5] += t.lm_bytes; counts7[6] += t.corr_features;
+    }
     return LOAMX_OK;
   });
 }

@@ -239,6 +239,7 @@ class Registrar {
   // parity hook (loamx_batch_knn_probe): exact 5-NN of n map-frame points in the corner (0) / surf (1) sub-map index
   void knn_probe(int which, const float* xyz, uint32_t n, uint32_t* idx5, float* d2_5);
   void qr6_probe(const float* ata, const float* atb, uint32_t n, float* x_coop, float* x_scalar);
+  void xrec_stress(uint32_t pairs, uint32_t rounds, unsigned long long out4[4]);
   void set_timing(bool on, bool per_launch = true) { timing_ = on; launch_timing_ = per_launch; }   // per_launch: event pairs around every Gauss-Newton launch
   void get_timing(float ms[4], uint64_t counts[4]);
   uint32_t n_sweeps() const { return n_sweeps_; }

@@ -891,11 +891,13 @@ constexpr int GN_TILE = LX_RES_THREADS / KNN_LPQ;   // queries per workgroup
 #include "gn_iter_kernel.inc"
 #undef GN_KERNEL
 #undef GN_JACOBI
+#ifdef LOAMX_DIAG   // the oracle's cyclic Jacobi in the edge fit (bit-faithful, slower): a diagnostic build's LOAMX_EIG_JACOBI=1 selects it
 #define GN_KERNEL k_gn_iter_jacobi
 #define GN_JACOBI true
 #include "gn_iter_kernel.inc"
 #undef GN_KERNEL
 #undef GN_JACOBI
+#endif
 
 // debug / parity hook: the 5-NN search of k_gn_iter for arbitrary map-frame query points (loamx_batch_knn_probe)
 __global__ __launch_bounds__(256) void k_knn_probe(const float4* __restrict__ queries, uint32_t n, const GridDesc* __restrict__ desc,
@@ -971,7 +973,7 @@ Registrar::Registrar(int device, uint32_t max_sweeps) : device_(device), max_swe
   vox_.init(st_);
   vb_.init(st_);
   vb_disabled_ = getenv("LOAMX_VOX_LEGACY") != nullptr;
-  jacobi_eig_ = getenv("LOAMX_EIG_JACOBI") != nullptr;
+  jacobi_eig_ = diag_env("LOAMX_EIG_JACOBI") != nullptr;
   full_done_.reserve(max_sweeps);
   h_stats_.reserve(max_sweeps);
   h_poses_.reserve(max_sweeps);
@@ -1106,6 +1108,8 @@ void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const 
     pack_cloud(&corner_last[s], h_in_.p + h_seg_off_[2 * s]);
     pack_cloud(&surf_last[s], h_in_.p + h_seg_off_[2 * s + 1]);
   }
+  // (the feature clouds of the registration are finite by contract, as the odometry's: common.h packed_all_finite)
+  if (!packed_all_finite(h_in_.p, n_in_)) throw Error(LOAMX_E_INVALID, "a feature cloud holds non-finite coordinates");
   LX_HIP(hipMemcpyAsync(in_.p, h_in_.p, sizeof(float4) * n_in_, hipMemcpyHostToDevice, st_));
   if (n_full_) {
     h_full_.reserve(n_full_);
@@ -1271,7 +1275,7 @@ void Registrar::enqueue_front(bool legacy) {
 // converged, ahead of the launches enqueued behind it) or until the stream reaches ev_look_.  Returns true when the flags
 // ended the wait.  A mirror counts only when its check word matches the pose / statistics words read after the flag.
 bool Registrar::wait_for_mirrors() {
-  const bool no_poll = getenv("LOAMX_NO_MIRROR_POLL") != nullptr;   // (diagnostic; read per call so that bench.py --ab can toggle it)
+  const bool no_poll = diag_env("LOAMX_NO_MIRROR_POLL") != nullptr;   // (diagnostic; read per call so that bench.py --ab can toggle it)
   if (no_poll) { LX_HIP(hipEventSynchronize(ev_look_)); return false; }
   const uint32_t ns = n_sweeps_;
   const volatile SweepStats* hs = h_stats_.p;
@@ -1349,8 +1353,11 @@ bool Registrar::run_iterations(bool trace, double& th2, double& th3) {
       const bool tm = timing_ && launch_timing_ && n_res_launch_ < 64;
       if (tm) LX_HIP(hipEventRecord(ev_[2 + 2 * n_res_launch_], st_));
       a.iter = it;
+#ifdef LOAMX_DIAG
       if (jacobi_eig_) hipLaunchKernelGGL(k_gn_iter_jacobi, grid, dim3(LX_RES_THREADS), 0, st_, a);
-      else hipLaunchKernelGGL(k_gn_iter, grid, dim3(LX_RES_THREADS), 0, st_, a);
+      else
+#endif
+      hipLaunchKernelGGL(k_gn_iter, grid, dim3(LX_RES_THREADS), 0, st_, a);
       if (tm) {
         LX_HIP(hipEventRecord(ev_[3 + 2 * n_res_launch_], st_));
         n_res_launch_++;
@@ -1525,6 +1532,56 @@ void Registrar::qr6_probe(const float* ata, const float* atb, uint32_t n, float*
   hipLaunchKernelGGL(k_qr6_probe, dim3(n), dim3(64), 0, st_, da.p, db.p, n, dx.p, dy.p);
   LX_HIP(hipMemcpyAsync(x_coop, dx.p, sizeof(float) * 6 * n, hipMemcpyDeviceToHost, st_));
   LX_HIP(hipMemcpyAsync(x_scalar, dy.p, sizeof(float) * 6 * n, hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipStreamSynchronize(st_));
+}
+
+// Stress probe of the exchange primitive k_odom_lm rests on (dev_math.cuh: xrec_store / xrec_load).  The assumption: an aligned 16-byte
+// agent-scope store is observed whole or split at 8 bytes, never finer, so a record read with BOTH tags equal to k holds both halves
+// of value k.  Workgroup pairs (2 p, 2 p + 1) — consecutive workgroups run on different XCDs — hammer shared records: thread t of the
+// producer writes versions 1 .. rounds of record (p, t) back to back, thread t of the consumer reads the record as fast as it can until
+// it has seen the last version.  Counted: accepted reads (tags equal), torn reads (tags differ: harmless, the reader would poll again)
+// and — the property itself — accepted reads whose value is not the one its tag names.  out[0..3] = accepted, torn, inconsistent, timed-out threads
+__device__ __forceinline__ double xrec_probe_value(unsigned k) {
+  return __hiloint2double((int)(k * 2654435761u ^ 0x5bd1e995u), (int)(~k * 40503u + 0x9e3779b9u));
+}
+__global__ __launch_bounds__(64) void k_xrec_stress(xrec_t* __restrict__ rec, unsigned rounds, unsigned long long* __restrict__ out) {
+  const unsigned p = blockIdx.x >> 1, t = threadIdx.x;
+  xrec_t* r = rec + (size_t)p * 64 + t;
+  if ((blockIdx.x & 1u) == 0u) {
+    for (unsigned k = 1; k <= rounds; k++) xrec_store(r, xrec_probe_value(k), k);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+  unsigned long long acc = 0, torn = 0, bad = 0, late = 0;
+  const unsigned long long t0 = wall_clock64();
+  unsigned last = 0, polls = 0;
+  while (last != rounds) {
+    const xrec_t v = xrec_load(r);
+    if (v.x == v.w) {
+      if (v.x != 0u) {
+        acc++;
+        const double want = xrec_probe_value(v.x);
+        if (__double2hiint(xrec_value(v)) != __double2hiint(want) || __double2loint(xrec_value(v)) != __double2loint(want)) bad++;
+        last = v.x;
+      }
+    } else {
+      torn++;
+    }
+    if ((++polls & 4095u) == 0u && wall_clock64() - t0 > 300000000ull) { late = 1; break; }   // ~3 s: the producer never became resident
+  }
+  atomicAdd(&out[0], acc); atomicAdd(&out[1], torn); atomicAdd(&out[2], bad); atomicAdd(&out[3], late);
+}
+void Registrar::xrec_stress(uint32_t pairs, uint32_t rounds, unsigned long long out4[4]) {
+  LX_REQUIRE(out4 && pairs >= 1 && pairs <= 512 && rounds >= 1, "invalid argument");
+  LX_HIP(hipSetDevice(device_));
+  DevBuf<xrec_t> rec;
+  DevBuf<unsigned long long> out;
+  rec.reserve((size_t)pairs * 64);
+  out.reserve(4);
+  LX_HIP(hipMemsetAsync(rec.p, 0, sizeof(xrec_t) * pairs * 64, st_));
+  LX_HIP(hipMemsetAsync(out.p, 0, sizeof(unsigned long long) * 4, st_));
+  hipLaunchKernelGGL(k_xrec_stress, dim3(2 * pairs), dim3(64), 0, st_, rec.p, rounds, out.p);
+  LX_HIP(hipMemcpyAsync(out4, out.p, sizeof(unsigned long long) * 4, hipMemcpyDeviceToHost, st_));
   LX_HIP(hipStreamSynchronize(st_));
 }
 

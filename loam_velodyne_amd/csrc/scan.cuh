@@ -1,6 +1,5 @@
-// Device-wide exclusive scan of uint32 with the element count read from device memory (no host sync).
-// Three launches: tile scan (2048 elements / 256-thread block), scan of tile sums (one 1024-thread block, up to
-// 8192 tiles = 16 Mi elements), uniform add.  wave64 shuffles for the intra-wave step.
+// Device-wide exclusive scan of uint32 with the element count read from device memory (no host sync): one launch, tiles of 2048
+// elements per 256-thread block chained by a decoupled look-back, up to 8192 tiles = 16 Mi elements.  wave64 shuffles inside a wave.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -10,7 +9,7 @@ namespace loamx {
 constexpr int SCAN_TILE = 2048;
 constexpr uint32_t SCAN_MAX_N = 8192u * SCAN_TILE;
 // the scratch every scan call is handed ("tile_sums"): uint32 words, ZERO-FILLED ONCE by its owner — the one-launch scan keeps its
-// per-tile 64-bit words (epoch-tagged) in it, the three-launch scan its 8192 tile sums
+// per-tile 64-bit words (epoch-tagged) in it
 constexpr size_t SCAN_SCRATCH_WORDS = 2 * (8192 + 8);
 
 __device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
@@ -48,8 +47,7 @@ void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, 
                         uint32_t max_n, hipStream_t st, uint32_t* out2 = nullptr,   // out2: optional second copy of the result
                         uint32_t* zero_in = nullptr);   // zero_in (= in, when in != out): the input is cleared behind the scan
 
-// ---- the same scan in ONE launch (round 4; the three-launch version above stays behind LOAMX_SCAN_3PASS=1 for A/B): chained tiles with a
-// decoupled look-back.  Tile b publishes its sum in a 64-bit word, walks back over the published sums / inclusive prefixes of the tiles
+// ---- the scan itself (round 4; the three-launch version it replaced is in the history): chained tiles with a decoupled look-back.  Tile b publishes its sum in a 64-bit word, walks back over the published sums / inclusive prefixes of the tiles
 // before it, publishes its own inclusive prefix and writes its slice.  The words carry the launch's epoch, so nothing is cleared between
 // launches; `state` (chained_scan_state_words() uint64 words) is zero-filled ONCE by its owner and may be shared by all scans of one HIP
 // stream.  Everything a tile needs from another one travels INSIDE those words: relaxed agent-scope atomics, no cache-wide fence
@@ -62,7 +60,6 @@ void exclusive_scan_u32_chained(const uint32_t* in, uint32_t* out, unsigned long
                                 uint32_t max_n, hipStream_t st, uint32_t* out2 = nullptr, uint32_t* zero_in = nullptr,
                                 uint32_t n_host = 0xffffffffu);
 void scan_check_errors();   // throws LOAMX_E_HIP when a chained scan gave up waiting (after a synchronisation point)
-bool scan_use_chained();    // !LOAMX_SCAN_3PASS
 
 // same with a host-known element count; scratch2 = two device words
 void exclusive_scan_u32_n(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, uint32_t* scratch2, uint32_t n, hipStream_t st);

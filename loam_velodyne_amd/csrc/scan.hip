@@ -1,90 +1,15 @@
 // Device-wide exclusive scan kernels (see scan.cuh).
 #include "scan.cuh"
 #include "common.h"
+#include <mutex>
+#include <unordered_map>
 
 namespace loamx {
 
-// in may alias out
-__global__ __launch_bounds__(256) void k_scan_tiles(const uint32_t* in, uint32_t* __restrict__ out,
-                                                    uint32_t* __restrict__ tile_sums, const uint32_t* __restrict__ d_n, uint32_t* zero_in) {
-  __shared__ uint32_t lds[17];
-  const uint32_t n = *d_n;
-  const uint32_t base = blockIdx.x * SCAN_TILE;
-  if (base >= n) return;
-  uint32_t v[8];
-  const uint32_t i0 = base + threadIdx.x * 8;
-#pragma unroll
-  for (int k = 0; k < 8; k++) v[k] = (i0 + k < n) ? in[i0 + k] : 0u;
-  if (zero_in) {   // the input is a histogram that its producer wants back empty (only entries that hold something are written)
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-      if (i0 + k < n && v[k]) zero_in[i0 + k] = 0u;
-  }
-  uint32_t s = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) { uint32_t t = v[k]; v[k] = s; s += t; }
-  uint32_t total;
-  uint32_t off = block_excl_scan(s, lds, total);
-#pragma unroll
-  for (int k = 0; k < 8; k++)
-    if (i0 + k < n) out[i0 + k] = v[k] + off;
-  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
-}
-
-// one block of 1024 threads; writes exclusive tile offsets in place and the grand total to *d_total
-__global__ __launch_bounds__(1024) void k_scan_sums(uint32_t* __restrict__ tile_sums, const uint32_t* __restrict__ d_n,
-                                                    uint32_t* __restrict__ d_total) {
-  __shared__ uint32_t lds[17];
-  const uint32_t n = *d_n;
-  const uint32_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-  uint32_t v[8];
-  const uint32_t i0 = threadIdx.x * 8;
-#pragma unroll
-  for (int k = 0; k < 8; k++) v[k] = (i0 + k < ntiles) ? tile_sums[i0 + k] : 0u;
-  uint32_t s = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) { uint32_t t = v[k]; v[k] = s; s += t; }
-  uint32_t total;
-  uint32_t off = block_excl_scan(s, lds, total);
-#pragma unroll
-  for (int k = 0; k < 8; k++)
-    if (i0 + k < ntiles) tile_sums[i0 + k] = v[k] + off;
-  if (threadIdx.x == 0 && d_total) *d_total = total;
-}
-
-// out[i] += tile offset; also writes out[n] = total (so out is a proper "starts" array of n+1 entries)
-// out2 (optional): a second copy of the result (counting sorts keep one as the table and consume the other as cursors)
-__global__ __launch_bounds__(256) void k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ tile_sums,
-                                                  const uint32_t* __restrict__ d_n, const uint32_t* __restrict__ d_total,
-                                                  uint32_t* __restrict__ out2) {
-  const uint32_t n = *d_n;
-  const uint32_t base = blockIdx.x * SCAN_TILE;
-  if (base >= n) return;
-  const uint32_t off = tile_sums[blockIdx.x];
-  const uint32_t i0 = base + threadIdx.x * 8;
-#pragma unroll
-  for (int k = 0; k < 8; k++)
-    if (i0 + k < n) {
-      const uint32_t v = out[i0 + k] + off;
-      out[i0 + k] = v;
-      if (out2) out2[i0 + k] = v;
-    }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    out[n] = *d_total;
-    if (out2) out2[n] = *d_total;
-  }
-}
-
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums /* SCAN_SCRATCH_WORDS, zero-filled once */, const uint32_t* d_n,
                                uint32_t* d_total, uint32_t max_n, hipStream_t st, uint32_t* out2, uint32_t* zero_in) {
-  if (scan_use_chained()) {   // one launch (the scratch doubles as the chained scan's state: 64-bit words)
-    exclusive_scan_u32_chained(in, out, (unsigned long long*)tile_sums, d_n, d_total, max_n, st, out2, zero_in);
-    return;
-  }
-  const uint32_t ntiles = (max_n + SCAN_TILE - 1) / SCAN_TILE;
-  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(256), 0, st, in, out, tile_sums, d_n, zero_in);
-  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums, d_n, d_total);
-  hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(256), 0, st, out, tile_sums, d_n, d_total, out2);
+  // one launch (the scratch holds the chained scan's state: 64-bit words)
+  exclusive_scan_u32_chained(in, out, (unsigned long long*)tile_sums, d_n, d_total, max_n, st, out2, zero_in);
 }
 
 // ---- one-launch variant (see scan.cuh) ---------------------------------------------------------------------------------------------
@@ -98,7 +23,13 @@ __global__ __launch_bounds__(256) void k_scan_chained(const uint32_t* in, uint32
                                                       uint32_t* __restrict__ out2, uint32_t* zero_in, uint32_t* __restrict__ err_flag) {
   __shared__ uint32_t lds[17];
   __shared__ uint32_t s_excl;
-  const uint32_t n = n_host != 0xffffffffu ? n_host : *d_n;
+  uint32_t n = n_host != 0xffffffffu ? n_host : *d_n;
+  // a count beyond what this launch's grid covers (a caller's bound that was too small) is cut to the grid: every tile that counts
+  // exists, the launch ends and leaves the state usable (the raised error word tells the host; out[] is then incomplete)
+  if ((unsigned long long)n > (unsigned long long)gridDim.x * SCAN_TILE) {
+    n = gridDim.x * (uint32_t)SCAN_TILE;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && err_flag) *err_flag = 1u;
+  }
   const uint32_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   const uint32_t b = blockIdx.x;
   if (b >= ntiles && !(n == 0 && b == 0)) return;   // (nobody waits for a tile beyond the data)
@@ -198,24 +129,31 @@ void scan_check_errors() {
   uint32_t* p = scan_err_word();
   if (p && *(volatile uint32_t*)p) { *p = 0u; throw Error(LOAMX_E_HIP, "a chained scan gave up waiting for an earlier tile"); }
 }
-bool scan_use_chained() { static const bool on = getenv("LOAMX_SCAN_3PASS") == nullptr; return on; }
 
 void exclusive_scan_u32_chained(const uint32_t* in, uint32_t* out, unsigned long long* state, const uint32_t* d_n, uint32_t* d_total,
                                 uint32_t max_n, hipStream_t st, uint32_t* out2, uint32_t* zero_in, uint32_t n_host) {
   const uint32_t bound = n_host != 0xffffffffu ? n_host : max_n;
   const uint32_t ntiles = (bound + SCAN_TILE - 1) / SCAN_TILE;
+  // The tiles' words carry a 30-bit epoch and are never cleared: after 2^30 launches on one state buffer (hours of live operation) a word
+  // of a tile that has not been written since the epoch's previous life would pass for current.  The host counts the launches per state
+  // buffer and clears the buffer on the stream before the epoch comes round (the kernel continues at epoch 1 from a zeroed state).
+  {
+    static std::mutex mu;
+    static std::unordered_map<const void*, uint32_t> launches;
+    bool clear = false;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      uint32_t& k = launches[state];
+      if (++k >= (1u << 30) - 8u) { k = 0; clear = true; }
+    }
+    if (clear) LX_HIP(hipMemsetAsync(state, 0, sizeof(unsigned long long) * chained_scan_state_words(), st));
+  }
   hipLaunchKernelGGL(k_scan_chained, dim3(ntiles ? ntiles : 1u), dim3(256), 0, st, in, out, state, d_n, n_host, d_total, out2, zero_in, scan_err_word());
 }
 
-__global__ void k_scan_set_n(uint32_t* p, uint32_t v) { *p = v; }
-
 void exclusive_scan_u32_n(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, uint32_t* scratch2, uint32_t n, hipStream_t st) {
-  if (scan_use_chained()) {   // one launch instead of four: the count travels as a kernel argument
-    exclusive_scan_u32_chained(in, out, (unsigned long long*)tile_sums, nullptr, scratch2 + 1, n, st, nullptr, nullptr, n);
-    return;
-  }
-  hipLaunchKernelGGL(k_scan_set_n, dim3(1), dim3(1), 0, st, scratch2, n);
-  exclusive_scan_u32(in, out, tile_sums, scratch2, scratch2 + 1, n, st);
+  // the count travels as a kernel argument
+  exclusive_scan_u32_chained(in, out, (unsigned long long*)tile_sums, nullptr, scratch2 + 1, n, st, nullptr, nullptr, n);
 }
 
 }  // namespace loamx

@@ -56,6 +56,8 @@ def lib():
                                     "(no CPU fallback exists)")
         L = C.CDLL(LIB_PATH)
         L.loamx_last_error.restype = C.c_char_p
+        if hasattr(L, "loamx_build_info"):
+            L.loamx_build_info.restype = C.c_char_p
         for n in ("loamx_scanreg_create", "loamx_odom_create", "loamx_map_create", "loamx_batch_create",
                   "loamx_batch_stream"):
             if hasattr(L, n):
@@ -72,6 +74,11 @@ def _check(rc):
 
 def device_count() -> int:
     return int(lib().loamx_device_count())
+
+
+def build_info() -> dict:
+    """loamx_build_info() as a dict: abi, diag (1: a diagnostic build that reads the result-changing LOAMX_* switches), rccl, roctx."""
+    return dict(kv.split("=", 1) for kv in lib().loamx_build_info().decode().split(";") if kv)
 
 
 def as_points(a) -> np.ndarray:
@@ -197,6 +204,12 @@ class Batch:
                                            xc.ctypes.data_as(C.c_void_p), xs.ctypes.data_as(C.c_void_p)))
         return xc, xs
 
+    def xrec_stress(self, pairs: int = 64, rounds: int = 20000):
+        """stress probe of k_odom_lm's tagged-record exchange -> dict(accepted, torn, inconsistent, timed_out)"""
+        out = (C.c_uint64 * 4)()
+        _check(lib().loamx_batch_xrec_stress(self.h, pairs, rounds, out))
+        return dict(accepted=int(out[0]), torn=int(out[1]), inconsistent=int(out[2]), timed_out=int(out[3]))
+
     def knn_probe(self, which: int, queries_xyz):
         """the library's own 5-NN search for map-frame points: (indices into the cloud given to set_frozen, squared distances)"""
         q = np.ascontiguousarray(np.asarray(queries_xyz, np.float32)[:, :3])
@@ -308,7 +321,8 @@ class ScanRegistration:
         _check(lib().loamx_scanreg_process(self.h, C.byref(cin), rs.ctypes.data_as(C.c_void_p), len(rs), C.byref(cl[0]),
                                            C.byref(cl[1]), C.byref(cl[2]), C.byref(cl[3])))
         res = {name: outs[k][:cl[k].count].copy() for k, name in enumerate(self.NAMES)}
-        res["full"] = pts   # laserCloud(): the input itself (binned rings already); read-only for the consumers here
+        res["full"] = pts   # laserCloud(): THE CALLER'S ARRAY, not a copy (binned rings already): a consumer that registers it in place
+        # (LaserMapping.process(inplace=True)) rewrites the caller's sweep — pass a copy where the sweep is needed again
         return res
 
     def update_imu(self, stamp, roll, pitch, yaw, acc):
@@ -697,6 +711,15 @@ class Pipeline:
         return dict(features_ms=ms[0], odometry_ms=ms[1], registration_ms=ms[2], step_ms=ms[3], reg_run_ms=rms[0],
                     residual_ms=rms[1], residual_launches=int(cnt[0]), query_iterations=int(cnt[1]), queries=int(cnt[2]))
 
+    def odom_launch_timing(self):
+        """running totals of the odometry chains' timed launch pairs (loamx_pipeline_get_odom_launch_timing)"""
+        ms = (C.c_double * 4)()
+        cnt = (C.c_uint64 * 7)()
+        _check(lib().loamx_pipeline_get_odom_launch_timing(self.h, ms, cnt))
+        return dict(lm_ms=ms[0], lm_noop_ms=ms[1], corr_ms=ms[2], corr_noop_ms=ms[3], lm_launches=int(cnt[0]), lm_noop_launches=int(cnt[1]),
+                    lm_iterations=int(cnt[2]), corr_launches=int(cnt[3]), corr_noop_launches=int(cnt[4]), lm_bytes=int(cnt[5]),
+                    corr_features=int(cnt[6]))
+
     @property
     def stream(self) -> int:
         return int(lib().loamx_pipeline_stream(self.h) or 0)
@@ -770,19 +793,19 @@ class Dist:
         return int(ev.value or 0)
 
     def allgather_results(self, poses6, iters_flags=None, batch=None):
-        """every rank's records in rank order; shards may be unequal, also empty.  batch = total record count when the caller knows
-        it; otherwise the counts are gathered first (loamx_dist_allgather_counts) and the receive arrays sized by them — a guess such as
-        world x (own count + 1) is too small as soon as shards differ by more than one.  The C call is told the
+        """every rank's records in rank order; shards may be unequal, also empty.  The counts are gathered first
+        (loamx_dist_allgather_counts) and the receive arrays sized by them; batch (optional) = the total the caller expects.  The C call is told the
         capacity either way and answers LOAMX_E_CAPACITY instead of writing beyond it.  Returns (poses, flags, counts per rank)"""
         p = np.ascontiguousarray(poses6, np.float32).reshape(-1, 6)
         n = len(p)
         f = np.ascontiguousarray(iters_flags, np.int32).reshape(n, 2) if iters_flags is not None else None
         cnt = np.zeros(self.world, np.uint32)
-        if batch is None:
-            _check(lib().loamx_dist_allgather_counts(self.h, n, cnt.ctypes.data_as(C.c_void_p)))
-            cap = int(cnt.sum())
-        else:
-            cap = int(batch)
+        # the counts are ALWAYS gathered: whether a rank passes `batch` must not decide which collectives it takes part in (ranks that
+        # disagreed would hang in mismatched collectives, ADVICE.md round 4); `batch` is only checked against them
+        _check(lib().loamx_dist_allgather_counts(self.h, n, cnt.ctypes.data_as(C.c_void_p)))
+        cap = int(cnt.sum())
+        if batch is not None and int(batch) != cap:
+            raise ValueError(f"allgather_results: batch = {batch} but the ranks hold {cap} records")
         pa = np.zeros((max(cap, 1), 6), np.float32)
         fa = np.zeros((max(cap, 1), 2), np.int32)
         _check(lib().loamx_dist_allgather_results_cap(self.h, p.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p) if f is not None else None,

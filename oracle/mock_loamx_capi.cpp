@@ -54,6 +54,7 @@ extern "C" {
 const char* loamx_last_error(void) { return "oracle-backed test double"; }
 int loamx_device_count(void) { return 0; }
 int loamx_abi_version(void) { return LOAMX_ABI_VERSION; }
+const char* loamx_build_info(void) { return "abi=5;diag=0;rccl=0;roctx=0;mock=1"; }
 
 // ---- scan registration
 void loamx_scanreg_default_config(loamx_scanreg_config* c) { *c = loamx_scanreg_config{0.1f, 6, 5, 2, 4, 0.2f, 0.1f, 0, 20, 200}; }

@@ -116,3 +116,29 @@ def test_error_behaviour(small_world):
     cs = loamx.cloud_of(small)
     rc = loamx.lib().loamx_scanreg_process(g.h, C.byref(cin), rs.ctypes.data_as(C.c_void_p), len(rs), C.byref(cs), None, None, None)
     assert rc == loamx.E_CAPACITY and cs.count > 4
+
+
+def test_non_finite_input_is_rejected(small_world):
+    world = small_world
+    """BasicLaserOdometry.cpp:230, :252 / MultiScanRegistration.cpp:187-196: the reference never lets a NaN or Inf coordinate reach this
+    stage; the binned-ring and feature-cloud entry points declare finite input and say so when it is not (LOAMX_E_INVALID) — the
+    rings on the device, inside the curvature pass, the feature clouds on the host."""
+    sw = synth.make_sweep(world, "VLP-16", synth.trajectory(1)[0], synth.trajectory(1)[1], seed=3, az_steps=600)
+    g = loamx.ScanRegistration()
+    ok = g.process(sw.points, sw.ring_sizes)
+    for bad_value, where in ((np.nan, 1234), (np.inf, 0), (-np.inf, len(sw.points) - 1)):
+        pts = sw.points.copy()
+        pts[where, where % 3] = bad_value
+        with pytest.raises(loamx.LoamxError) as e:
+            g.process(pts, sw.ring_sizes)
+        assert e.value.code == loamx.E_INVALID, e.value
+    again = g.process(sw.points, sw.ring_sizes)   # the handle goes on working, results unchanged
+    for name in ("sharp", "less_sharp", "flat", "less_flat"):
+        assert np.array_equal(ok[name], again[name])
+    od = loamx.LaserOdometry()
+    od.process(ok)
+    f = {k: v.copy() for k, v in ok.items() if k in ("sharp", "less_sharp", "flat", "less_flat")}
+    f["flat"][5, 1] = np.nan
+    with pytest.raises(loamx.LoamxError) as e:
+        od.process(f)
+    assert e.value.code == loamx.E_INVALID, e.value

@@ -38,6 +38,8 @@ HANDLES_PER_GPU = 1      # >1: split the streams over several pipeline handles d
 SENSOR = "HDL-64E"
 MAP_POINTS = 1_000_000
 HBM_PEAK_GBS = 8000.0
+HBM_COPY_GBS = 6290.0      # measured float4 copy on MI355X (MI355X_MICROARCH.md): the ceiling a streaming kernel can reach, quoted beside the 8 TB/s peak
+PROFILE_ROUNDS = ("r05", "r04")   # committed rocprofv3 summaries of this command, newest first (profiles/<round>_bench_kernel_stats.csv, <round>_pmc_summary.json)
 
 
 def main():
@@ -50,6 +52,10 @@ def main():
     ap.add_argument("--map-epoch-steps", type=int, default=0,
                     help="E > 0: a new map epoch every E steps inside the timed region — rank 0's map is re-broadcast (RCCL, async), "
                          "indexed in the background and swapped in at the epoch boundary (BASELINE configs[4] double buffering)")
+    ap.add_argument("--epoch-merge", action="store_true",
+                    help="with --map-epoch-steps: the epoch's merge step too — every rank's registered sweeps (re-projected clouds + mapped pose) travel to "
+                         "rank 0 (loamx_dist_gatherv), are inserted into the map accumulator there (loamx_map_insert) and the MERGED map is what the "
+                         "next epoch broadcasts; synchronous on the stepping thread (the accumulator's ~1-2 ms per sweep is rank 0's)")
     ap.add_argument("--sensor", default=SENSOR, choices=["HDL-32", "HDL-64E", "VLP-16"], help="parity / side configurations (BASELINE configs[1], [2])")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU)
     ap.add_argument("--handles", type=int, default=HANDLES_PER_GPU,
@@ -107,10 +113,12 @@ def main():
     M = args.map_points
     n_corner, n_surf = lxdist.split_map(M)
     map_t = torch.empty((M, 4), dtype=torch.float32, device=dev)
+    map_host = None
     if rank == 0:
         cm, sm = world_model.make_map(M)
         assert len(cm) == n_corner and len(sm) == n_surf
         map_t.copy_(torch.from_numpy(np.concatenate([cm, sm], axis=0)))
+        map_host = (cm, sm)
     t_bcast = 0.0
     bcast_via = "none (single rank)"
     ldist = None
@@ -201,6 +209,13 @@ def main():
         map_nexts = [torch.empty_like(map_t), torch.empty_like(map_t)] if E > 0 else None   # ping-pong: a buffer is rewritten only
         # after a registration against the index built from it has been observed complete
         ev_map = torch.cuda.Event() if E > 0 else None
+        # the epoch's merge step (--epoch-merge): rank 0 owns the accumulator, loaded with the first epoch's map
+        acc = None
+        if E > 0 and args.epoch_merge and rank == 0:
+            acc = loamx.LaserMapping(device=local_rank)
+            acc.load_cubes(*map_host)
+        r["merged_sweeps"] = 0
+        sizes = [n_corner, n_surf]   # of the map the NEXT epoch registers against (changes once sweeps are merged)
 
         def snapshot(h, t):
             if collect is not None:
@@ -226,19 +241,40 @@ def main():
                     if k == 0:
                         if p.swap_frozen():
                             r["n_epochs"] += 1
-                        map_next = map_nexts[((t - (1 + W)) // E) % 2]
-                        if rank == 0:
-                            map_next.copy_(map_t, non_blocking=True)   # (the next epoch's map: same content, new buffer)
+                        slot = ((t - (1 + W)) // E) % 2
+                        map_next = map_nexts[slot]
+                        nc_e, ns_e = sizes
+                        if args.epoch_merge and t > 1 + W:
+                            # collective 3: this rank's streams' last sweeps -> rank 0's accumulator -> the merged map
+                            mine = []
+                            for k_ in range(per):
+                                _, _, aft_, st_ = p.get(k_)
+                                if st_["mapped"]:
+                                    lc_, ls_ = p.last_clouds(k_, n_points)
+                                    mine.append((aft_, lc_, ls_))
+                            r["merged_sweeps"] += lxdist.epoch_merge(mine, acc, ldist, rank=rank, root=0)
+                            if rank == 0:
+                                new_c, new_s = acc.cubes("corner"), acc.cubes("surf")
+                                nc_e, ns_e = len(new_c), len(new_s)
+                            if ldist is not None:   # the new sizes reach every rank the way the counts of the other exchanges do
+                                nc_e = int(ldist.allgather_counts(nc_e)[0]); ns_e = int(ldist.allgather_counts(ns_e)[0])
+                            if map_next.shape[0] < nc_e + ns_e:
+                                map_next = map_nexts[slot] = torch.empty((int(1.2 * (nc_e + ns_e)), 4), dtype=torch.float32, device=dev)
+                            if rank == 0:
+                                map_next[:nc_e + ns_e].copy_(torch.from_numpy(np.concatenate([new_c, new_s], axis=0)), non_blocking=False)
+                            sizes[0], sizes[1] = nc_e, ns_e
+                        elif rank == 0:
+                            map_next[:nc_e + ns_e].copy_(map_t[:nc_e + ns_e], non_blocking=True)   # (the next epoch's map: same content, new buffer)
                         if ldist is not None:   # native: the broadcast waits for the copy's event, the index build for the broadcast's
                             ev_map.record()
-                            ev = ldist.broadcast_map(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, root=0, wait_event=ev_map.cuda_event)
+                            ev = ldist.broadcast_map(map_next.data_ptr(), nc_e, map_next.data_ptr() + 16 * nc_e, ns_e, root=0, wait_event=ev_map.cuda_event)
                         else:
                             if dist is not None:
                                 dist.broadcast(map_next, src=0, async_op=True).wait()   # orders torch's stream behind RCCL's, not the host
                             ev_map.record()
                             ev = ev_map.cuda_event
                         # the index build waits for the event on the device; nothing blocks here
-                        p.stage_frozen_device(map_next.data_ptr(), n_corner, map_next.data_ptr() + 16 * n_corner, n_surf, ev)
+                        p.stage_frozen_device(map_next.data_ptr(), nc_e, map_next.data_ptr() + 16 * nc_e, ns_e, ev)
                 # HIP-event timing (stage chains + a pair around every Gauss-Newton launch) on every 4th step only: the event pairs and
                 # their read-back (event synchronise, a statistics download) cost ~4 % of a step
                 sampled = (t - (1 + W)) % period == 0
@@ -286,6 +322,12 @@ def main():
                 r[k] += a[k]
         r["n_sampled"] = racc[0]["n_sampled"]
         r["in_step"] = max(a["in_step"] for a in racc)
+        # the odometry chains' launch pairs (HIP events on the chains' own streams on the sampled steps; totals since the handles were
+        # created, i.e. incl. the warm-up's sampled steps — the same kernels on the same sweeps)
+        r["odom_launch"] = {}
+        for p in pipes:
+            for k_, v_ in p.odom_launch_timing().items():
+                r["odom_launch"][k_] = r["odom_launch"].get(k_, 0) + v_
         r["pipes"] = pipes
         if not keep_open:
             for p in pipes:
@@ -318,11 +360,24 @@ def main():
         try:
             w_ = resident_window()
             per_step = []
-            resident_window(collect=per_step)   # (untimed: the iteration counts of every stream and step)
+            resident_window(collect=per_step)   # (untimed: the poses and iteration counts of every stream and step)
+            sweeps_long = sweeps
         finally:
             sweeps, T, T_all, K = keep
         timed_rows = [r for r in per_step if r[0] >= 1 + W]
+        parity = None
+        try:   # the oracle chain over the long trajectory's stream 0 (~0.1 s per sweep on one core): parity over hundreds of sweeps
+            m_ = map_t.cpu().numpy()
+            chain = oracle_parity_chain(sweeps_long, starts, m_, n_corner, 1 + W + N)
+            parity = pose_error(per_step, chain, stream=0)
+            if parity:
+                parity.pop("odometry_sum_per_sweep_m", None)
+        except Exception as e:
+            parity = {"error": repr(e)[:200]}
+        finally:
+            pass
         return {"value": round(world * ns * N / w_["elapsed"], 2), "unit": "sweeps/s", "steps": N, "ms_per_step": round(w_["elapsed"] / N * 1e3, 4),
+                "pose_err_vs_oracle": parity,
                 "seconds": round(w_["elapsed"], 4),
                 "mean_odom_iterations": round(float(np.mean([r[4] for r in timed_rows])), 2), "mean_map_iterations": round(float(np.mean([r[5] for r in timed_rows])), 2),
                 "note": "same window protocol as `value` over a longer trajectory of its own (40 m circle inside the map; the short window's 115 m "
@@ -456,6 +511,10 @@ def main():
                 "map_broadcast_via": bcast_via,
                 "map_epoch_steps": E,
                 "map_epochs_swapped": n_epochs,
+                "map_epoch_merge": ({"merged_sweeps_on_rank0": win.get("merged_sweeps", 0),
+                                     "note": "every epoch boundary: the ranks' registered sweeps -> loamx_dist_gatherv -> loamx_map_insert on rank 0 -> "
+                                             "the merged map is broadcast and staged for the next epoch (synchronous, inside the timed region)"}
+                                    if args.epoch_merge and E > 0 else None),
                 "numa_node_bound": numa_node,
                 "results_gathered": n_results,
                 # what the RCCL communicator itself reports (ncclCommCount); 0 = a multi-rank run that fell back to torch.distributed for
@@ -465,7 +524,7 @@ def main():
                 "path_hbm_frac": round(float(bytes_per_sweep * value / world / (HBM_PEAK_GBS * 1e9)), 6),
             },
             "pcie_inclusive": pcie,
-            "roofline": {
+            "roofline_gn": {
                 "kernel": "loamx::k_gn_iter",
                 "bound": "hbm",
                 "achieved": round(achieved, 3),
@@ -490,7 +549,12 @@ def main():
             out["pose_err_vs_oracle"] = pose_error(gpu_poses, orc_poses, stream=0)
             if args.long_steps:
                 out["value_long"] = long_window(args.long_steps)
+        # `roofline` = the kernel with the largest total duration in the committed kernel stats of this command (its live figures measured
+        # in THIS run); the Gauss-Newton kernel's block stays beside it
+        out["roofline"] = dominant_roofline(out.pop("roofline_gn"), win.get("odom_launch") or {}, ns)
         out["roofline_kernels"] = roofline_kernels(out["roofline"], ns)
+        out["config"]["env_overrides"] = env_overrides()
+        out["config"]["library_build"] = loamx.build_info()
         print(json.dumps(out), flush=True)
         pe = out.get("pose_err_vs_oracle")
         if pe and not pe.get("within_bar", True):   # a fast path whose poses differ from the reference's is not a result
@@ -523,6 +587,7 @@ def run_live(args):
     stage = np.zeros(3)
     stats = []
     gn_ms, gn_launches, gn_qi, reg_ms, n_timed = 0.0, 0, 0, 0.0, 0
+    gpu_poses = []
     t0 = None
     for t in range(T):
         if t == 1 + W:
@@ -540,6 +605,7 @@ def run_live(args):
         mp.update_odometry(od.transform_sum)
         mp.process(lc, ls, full, inplace=True)   # (full is transform_to_end's own array: registered where it lies, as the C entry point does)
         d = time.perf_counter()
+        gpu_poses.append((t, 0, np.array(od.transform_sum, np.float32), mp.transform("aft"), od.stats()["iterations"], mp.stats()["iterations"]))   # (two 6-float reads: ~2 us)
         if t >= 1 + W:
             stage += [b - a, c - b, d - c]
             stats.append(mp.stats())
@@ -622,8 +688,14 @@ def run_live(args):
                                              "laserOdometry / laserMapping run: throughput is set by the slowest node; final pose bit-identical to the sequential run")
     avg_launch_ms = gn_ms / max(gn_launches, 1)
     achieved = (72.0 * gn_qi / max(gn_launches, 1)) / (avg_launch_ms * 1e-3) / 1e9 if gn_launches else 0.0
+    live_pmc = None
+    try:   # PMC passes of THIS command (scripts/gpu_pmc.sh <tag> --mode live ...), committed per configuration
+        with open(os.path.join(ROOT, "profiles", f"r05_live_{sensor.lower().replace('-', '')}_pmc_summary.json")) as f:
+            live_pmc = json.load(f)["k_gn_iter_full_launch"]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
     out["roofline"] = {"kernel": "loamx::k_gn_iter", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                       "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": live_pmc, "peak_copy_ceiling": HBM_COPY_GBS,
                        "model": "72 B per query-iteration (12 B query + 5 x 12 B neighbours), S = 1 sweep per launch: one sweep's ~5 k queries "
                                 "cannot fill the device — the launch is latency (search ~10 us + fit + 6x6 update step), not bandwidth",
                        "avg_launch_us": round(avg_launch_ms * 1e3, 3), "launches": gn_launches,
@@ -642,9 +714,33 @@ def run_live(args):
             omp.process()
             if t >= 1 + W:
                 per.append(time.perf_counter() - a)
+        # ---- pose parity (BASELINE.json's metric, third part) in the live mode: the same sweeps, FREE RUNNING, through the oracle's parity
+        # build (live map, every sweep inserted) — per sweep the difference of the mapped pose and of the accumulated odometry.  Free
+        # running means a 1e-6-level difference can flip a point across a voxel face of the live map and the two chains then see slightly
+        # different maps: the tests bound that drift at 2e-3 (tests/test_gpu_mapping.py) and check the per-step parity (both sides
+        # started from the same state) at 1e-4; both figures of the run are reported here
+        orc_p = op.Oracle(fast=False)
+        psr, pod, pmp = op.ScanRegistration(orc_p), op.LaserOdometry(orc_p), op.LaserMapping(orc_p)
+        pmp.load_cubes(cm, sm)
+        chain = []
+        for t in range(T):
+            pod.set_features(psr.process(sweeps[t].points, sweeps[t].ring_sizes))
+            pod.process()
+            pmp.set_inputs(pod.last_corner(), pod.last_surf(), pod.full_to_end(), pod.transform_sum)
+            pmp.process()
+            chain.append((t, np.array(pod.transform_sum, np.float32), np.array(pmp.transform("aft"), np.float32), pod.stats()["iterations"], pmp.stats()["iterations"]))
+        pe = pose_error(gpu_poses, chain, stream=0)
+        if pe:
+            pe["bar"] = 1e-4
+            pe["free_running_bar"] = 2e-3
+            pe["within_free_running_bar"] = bool(max(pe["mapped_pose"]["max_m"], pe["mapped_pose"]["max_rad"]) <= 2e-3)
+            pe["note"] = ("free-running chains over %d sweeps with a LIVE map (the map itself depends on every earlier pose); " % len(chain)) + pe["note"]
+        out["pose_err_vs_oracle"] = pe
         out["cpu_baseline"] = {"value": round(1.0 / float(np.median(per)), 4), "unit": "sweeps/s", "cores": 1, "kind": "port",
                                "sample": f"{len(per)} sweeps of the same sequence, same initial map, oracle live-map process() (g++ -O3 -march=native, one thread)",
                                "seconds_per_sweep": _stats(per), "host_cores_available": os.cpu_count()}
+    out["config"]["env_overrides"] = env_overrides()
+    out["config"]["library_build"] = loamx.build_info()
     print(json.dumps(out), flush=True)
 
 
@@ -807,7 +903,19 @@ def pose_error(gpu_poses, orc_poses, stream=0):
     if not rows:
         return None
     a = np.array(rows, float)
+    steps = [t for (t, *_r) in orc_poses if t in g and t >= 1]
+    # where does the accumulated odometry part from the oracle's?  transformSum integrates every sweep's optimised transform, so a
+    # difference that one sweep introduces stays: the per-sweep INCREMENT of the difference names the sweep
+    d_sum = a[:, 2]
+    inc = np.diff(np.concatenate([[0.0], d_sum]))
+    k_big = int(np.argmax(inc))
     return {"stream": stream, "sweeps": len(rows),
+            "odometry_sum_per_sweep_m": [round(float(x), 7) for x in d_sum[:40]],
+            "odometry_sum_largest_step": {"sweep": int(steps[k_big]), "increase_m": round(float(inc[k_big]), 7),
+                                          "odometry_iterations_equal_there": bool(a[k_big, 4]),
+                                          "note": "the sweep after which |transformSum difference| grew most: a difference in ONE sweep's optimised transform "
+                                                  "(float32 sums formed in another order than the oracle's, 1e-5-level) is carried by every later transformSum; "
+                                                  "the mapped pose does not inherit it (the registration re-anchors every sweep)"},
             "mapped_pose": {"max_m": float(a[:, 0].max()), "max_rad": float(a[:, 1].max()), "rmse_m": float(np.sqrt((a[:, 0] ** 2).mean())),
                             "rmse_rad": float(np.sqrt((a[:, 1] ** 2).mean()))},
             "odometry_sum": {"max_m": float(a[:, 2].max()), "max_rad": float(a[:, 3].max()), "rmse_m": float(np.sqrt((a[:, 2] ** 2).mean())),
@@ -818,22 +926,114 @@ def pose_error(gpu_poses, orc_poses, stream=0):
                     "steps) and the oracle chain run by cpu_baseline; the run exits with status 3 above the bar"}
 
 
+def env_overrides():
+    """every LOAMX_* / GPU_MAX_HW_QUEUES / HSA_* variable set in this process: the library reads its tuning and tracing switches from the
+    environment (DESIGN.md section 5 lists them; the result-changing diagnostics only exist in a LOAMX_DIAG build, see library_build)"""
+    keep = {}
+    for k, v in sorted(os.environ.items()):
+        if k.startswith("LOAMX_") or k in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+            keep[k] = v
+    return keep
+
+
+def _committed(name):
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{name}")
+        if os.path.exists(path):
+            return path
+    return None
+
+
+def committed_kernel_stats():
+    """{kernel name: (total ns, calls, average ns)} of the committed rocprofv3 --kernel-trace --stats run of this command"""
+    import csv
+    path = _committed("bench_kernel_stats.csv")
+    out = {}
+    if not path:
+        return out, None
+    try:
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                name = r["Name"].split("(")[0].replace("void ", "").strip()
+                out[name] = (float(r["TotalDurationNs"]), int(r["Calls"]), float(r["AverageNs"]))
+    except (OSError, KeyError, ValueError):
+        pass
+    return out, os.path.relpath(path, ROOT)
+
+
+def dominant_roofline(gn_block, ol, ns):
+    """The bench line's `roofline`: the kernel with the largest TotalDurationNs in the committed kernel stats.  For the
+    odometry's k_odom_lm — a latency chain, not a bandwidth kernel — the HBM fraction is reported as the contract asks AND a latency
+    model beside it: microseconds per Gauss-Newton iteration measured live in this run against a stated floor."""
+    stats, src = committed_kernel_stats()
+    ours = {k: v for k, v in stats.items() if k.startswith("loamx::")}
+    dom = max(ours.items(), key=lambda kv: kv[1][0])[0] if ours else "loamx::k_gn_iter"
+    gn_block = dict(gn_block)
+    gn_block["peak_copy_ceiling"] = HBM_COPY_GBS
+    gn_block["frac_of_copy_ceiling"] = round(gn_block["achieved"] / HBM_COPY_GBS, 6)
+    if not dom.startswith("loamx::k_odom_lm") or not ol.get("lm_launches"):
+        gn_block["dominant_by"] = f"largest TotalDurationNs in {src}" if src else "no committed kernel stats found"
+        return gn_block
+    n_it, n_l = max(ol["lm_iterations"], 1), max(ol["lm_launches"], 1)
+    avg_us = ol["lm_ms"] / n_l * 1e3
+    bytes_per_launch = ol["lm_bytes"] / n_l
+    achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
+    pm = pmc_traffic("k_odom_lm")
+    return {
+        "kernel": dom,
+        "dominant_by": f"largest TotalDurationNs in {src} ({stats[dom][0] / 1e6:.2f} ms over {stats[dom][1]} launches of the profiled run)",
+        "bound": "hbm",
+        "achieved": round(achieved, 3),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 6),
+        "peak_copy_ceiling": HBM_COPY_GBS,
+        "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 6),
+        "traffic": pm,
+        "traffic_note": "bytes of one launch of 4 streams (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of this command, committed "
+                        "under profiles/): several times the algorithmic bytes — the workgroups of a stream poll each other's tagged records",
+        "model": "48 B per feature (12 B query + 3 x 12 B correspondents, SURVEY.md §8d) read ONCE per launch of up to 5 iterations by the streams "
+                 "still iterating; the features then stay in registers — the kernel is a chain of dependent iterations, not a stream of bytes",
+        "avg_launch_us": round(avg_us, 3),
+        "launches": int(ol["lm_launches"]),
+        "launch_sampling": f"HIP-event pairs around every k_odom_lm launch of both odometry chains on every {TIMING_PERIOD}th step (launches over "
+                           "converged streams counted apart)",
+        "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
+        "noop_launches": {"n": int(ol["lm_noop_launches"]), "avg_us": round(ol["lm_noop_ms"] / max(ol["lm_noop_launches"], 1) * 1e3, 3)},
+        "latency_model": {
+            "us_per_iteration": round(ol["lm_ms"] * 1e3 / n_it, 3),
+            "iterations": int(ol["lm_iterations"]),
+            "floor_us": 4.5,
+            "floor_terms_us": {"residual rows (one feature per thread, ~350 dependent VALU instructions)": 0.6,
+                               "28 sums over 256 rows through LDS (two barriers, 32 + 8 dependent double adds)": 0.5,
+                               "exchange between the stream's 9 workgroups (one agent-scope store -> load round trip across XCDs)": 1.0,
+                               "6x6 column-pivoted QR on one wave (~1,100 dependent instructions, bit-identical to the scalar routine)": 2.0,
+                               "update, stop test, next sin/cos (lanes 0-5 of the same wave)": 0.4},
+            "measured_terms_us": "profiles/r05_lm_stamps.md (in-kernel time stamps, -DLOAMX_PROF_LM): rows 1.5, sums 1.0, record stores 0.4, poll 1.0-2.0, "
+                                 "normal equations 0.6, QR 3.0, update 1.1",
+            "source": "us_per_iteration: live, this run (sum of the timed launches' durations / iterations of each launch's slowest stream, "
+                      "launch start-up included); floor: instruction counts of the kernel's serial chain at ~4.5 cycles per dependent wave64 "
+                      "instruction and 2.4 GHz, plus the measured cross-XCD round trip (scripts/micro/atomics.hip)",
+        },
+        "corr_pair": {"kernel": "loamx::k_odom_corr_grid", "avg_launch_us": round(ol["corr_ms"] / max(ol["corr_launches"], 1) * 1e3, 3),
+                      "launches": int(ol["corr_launches"]), "features_per_launch": round(ol["corr_features"] / max(ol["corr_launches"], 1), 1),
+                      "noop_avg_us": round(ol["corr_noop_ms"] / max(ol["corr_noop_launches"], 1) * 1e3, 3)},
+        "k_gn_iter": gn_block,
+    }
+
+
 def roofline_kernels(main, ns):
     """The other kernels on the critical chains next to the dominant one: algorithmic bytes per launch (SURVEY.md §8d models, stated per
     kernel), average launch duration and HBM-side traffic from the COMMITTED rocprofv3 passes of this command (bench.py cannot profile
-    itself: profiles/r04_bench_kernel_stats.csv, profiles/r04_pmc_summary.json; None when a file is missing)."""
-    import csv
-    dur, pmc = {}, {}
+    itself: profiles/<round>_bench_kernel_stats.csv, profiles/<round>_pmc_summary.json, newest round first; None when a file is missing)."""
+    stats, src = committed_kernel_stats()
+    dur = {k: v[2] / 1e3 for k, v in stats.items()}
+    pmc, pmc_src = {}, None
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.csv")) as f:
-            for r in csv.DictReader(f):
-                dur[r["Name"].split("(")[0].replace("void ", "").strip()] = float(r["AverageNs"]) / 1e3
-    except (OSError, KeyError, ValueError):
-        pass
-    try:
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_summary.json")) as f:
+        pmc_src = _committed("pmc_summary.json")
+        with open(pmc_src) as f:
             pmc = json.load(f)
-    except (OSError, ValueError):
+    except (OSError, ValueError, TypeError):
         pass
     feats = 36 * 64
     models = [   # kernel, algorithmic bytes per launch of `ns` sweeps, model
@@ -849,19 +1049,23 @@ def roofline_kernels(main, ns):
         out.append({"kernel": name, "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_us": us,
                     "achieved_gbs": (round(nbytes / (us * 1e-6) / 1e9, 2) if us else None),
                     "frac": (round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 6) if us else None), "traffic": tr, "model": model,
-                    "source": "profiles/r04_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command), profiles/r04_pmc_summary.json"})
+                    "source": f"{src} (rocprofv3 --kernel-trace --stats of this command), {os.path.relpath(pmc_src, ROOT) if pmc_src else None}"})
     return out
 
 
-def pmc_traffic():
-    """HBM bytes per full launch of the dominant kernel from the committed PMC passes of this same command
-    (profiles/r04_pmc_summary.json, else the previous round's: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs, FETCH_SIZE
-    doubled per MI355X_MICROARCH.md).  bench.py cannot run the profiler on itself, so the figure is read, not measured
-    live; None when the file is missing."""
-    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json"):
+def pmc_traffic(kernel="k_gn_iter"):
+    """HBM bytes per full launch of a kernel from the committed PMC passes of this same command (profiles/<round>_pmc_summary.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).  bench.py cannot
+    run the profiler on itself, so the figure is read, not measured live; None when no file has it."""
+    for rnd in PROFILE_ROUNDS + ("r03",):
         try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["k_gn_iter_full_launch"]["traffic_bytes"]
+            with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary.json")) as f:
+                d = json.load(f)
+            if kernel == "k_gn_iter":
+                return d["k_gn_iter_full_launch"]["traffic_bytes"]
+            for k, v in d.items():
+                if isinstance(v, dict) and kernel in k and v.get("traffic_bytes") is not None:
+                    return v["traffic_bytes"]
         except (OSError, KeyError, ValueError):
             continue
     return None
@@ -870,6 +1074,29 @@ def pmc_traffic():
 def _stats(x):
     x = np.asarray(x, float)
     return {"median": round(float(np.median(x)), 5), "p95": round(float(np.percentile(x, 95)), 5), "mean": round(float(x.mean()), 5), "n": int(len(x))}
+
+
+def oracle_parity_chain(sweeps, starts, m, n_corner, T, stream=0):
+    """the parity chain: the SAME sweeps of one stream through the oracle's parity build (liboracle.so: -O2 -ffp-contract=off, the build that
+    is pinned bit for bit against the reference's translation units; the timed build of cpu_baseline is -O3 -march=native and contracts
+    FMAs) -> [(step, transformSum, transformAftMapped, odometry iterations, mapping iterations)]"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as op
+    orc_p = op.Oracle(fast=False)
+    psr, pod, pmp = op.ScanRegistration(orc_p), op.LaserOdometry(orc_p), op.LaserMapping(orc_p)
+    pmp.set_frozen(m[:n_corner], m[n_corner:])
+    pmp.set_transform("aft", starts[stream])
+    out = []
+    for t in range(T):
+        pod.set_features(psr.process(*sweeps[t][stream]))
+        pod.process()
+        if t > 0:
+            pmp.set_transform("sum", pod.transform_sum)
+            pose = pmp.register_frozen(pod.last_corner(), pod.last_surf(), pmp.associate())
+            pmp.set_transform("bef", pod.transform_sum)
+            pmp.set_transform("aft", pose)
+            out.append((t, np.array(pod.transform_sum, np.float32), np.array(pose, np.float32), pod.stats()["iterations"], pmp.stats()["iterations"]))
+    return out
 
 
 def cpu_baseline(sweeps, starts, map_t, n_measure=20, n_warm=3, n_reference=6, poses_out=None):
@@ -909,21 +1136,7 @@ def cpu_baseline(sweeps, starts, map_t, n_measure=20, n_warm=3, n_reference=6, p
         if t > n_warm:
             st["features"].append(b - a); st["odometry"].append(c - b); st["registration"].append(d - c)
     if poses_out is not None:
-        # the parity chain: the SAME sweeps through the oracle's parity build (liboracle.so: -O2 -ffp-contract=off, the build that is pinned
-        # bit for bit against the reference's translation units; the timed build above is -O3 -march=native and contracts FMAs)
-        orc_p = op.Oracle(fast=False)
-        psr, pod, pmp = op.ScanRegistration(orc_p), op.LaserOdometry(orc_p), op.LaserMapping(orc_p)
-        pmp.set_frozen(m[:n_corner], m[n_corner:])
-        pmp.set_transform("aft", starts[0])
-        for t in range(T):
-            pod.set_features(psr.process(*sweeps[t][0]))
-            pod.process()
-            if t > 0:
-                pmp.set_transform("sum", pod.transform_sum)
-                pose = pmp.register_frozen(pod.last_corner(), pod.last_surf(), pmp.associate())
-                pmp.set_transform("bef", pod.transform_sum)
-                pmp.set_transform("aft", pose)
-                poses_out.append((t, np.array(pod.transform_sum, np.float32), np.array(pose, np.float32), pod.stats()["iterations"], pmp.stats()["iterations"]))
+        poses_out.extend(oracle_parity_chain(sweeps, starts, m, n_corner, T))
     per = np.array(st["features"]) + np.array(st["odometry"]) + np.array(st["registration"])
     med = {k: float(np.median(v)) for k, v in st.items()}
     serial = 1.0 / float(np.median(per))

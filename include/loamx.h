@@ -457,6 +457,22 @@ int loamx_dist_shard_of(int rank, int world_size, uint32_t batch, uint32_t* begi
 int loamx_dist_pack_results(const float* poses6, const int* iters_flags2, uint32_t n_local, uint32_t n_pad, float* send8);
 int loamx_dist_unpack_results(const float* recv8, const uint32_t* counts, int world_size, uint32_t n_pad, float* poses6_all,
                               int* iters_flags2_all);
+/* The merge step of a map epoch (BasicLaserMapping.cpp:536-593 is what loamx_map_insert restates): the sweeps a rank has registered —
+ * per stream the re-projected corner / surf clouds of its last step (loamx_pipeline_download_last_clouds) and its transformAftMapped —
+ * travel to the rank that owns the map accumulator as ONE message of 32-bit words per rank:
+ *   'LXCL', n_streams, (n_corner, n_surf) x n_streams | 6 pose floats x n_streams | the points (x y z intensity), corner(0) surf(0) ...
+ * pack / unpack are host-side layout rules (no device, any transport); words == NULL asks for the size only.
+ * loamx_dist_gatherv: variable-size gather to `root` over RCCL — every rank's word count first (all-gather), then the words point to
+ * point inside one group; recv_words (root only) receives the ranks' messages back to back in rank order, counts_all (may be NULL)
+ * every rank's word count.  Every rank calls it, also with n_words = 0. */
+int loamx_dist_pack_clouds(uint32_t n_streams, const loamx_cloud* corner, const loamx_cloud* surf, const float* poses6, uint32_t* words,
+                           uint64_t capacity_words, uint64_t* n_words);
+int loamx_dist_unpack_clouds_header(const uint32_t* words, uint64_t n_words, uint32_t* n_streams, uint32_t* n_corner, uint32_t* n_surf,
+                                    uint32_t capacity_streams);
+int loamx_dist_unpack_clouds_stream(const uint32_t* words, uint64_t n_words, uint32_t stream, float pose6[6], loamx_cloud* corner,
+                                    loamx_cloud* surf);
+int loamx_dist_gatherv(loamx_dist* h, const uint32_t* send_words, uint32_t n_words, int root, uint32_t* recv_words, uint64_t capacity_words,
+                       uint32_t* counts_all);
 int loamx_dist_barrier(loamx_dist* h);
 void* loamx_dist_stream(loamx_dist* h);   /* hipStream_t of the collectives */
 

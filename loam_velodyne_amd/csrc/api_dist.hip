@@ -15,6 +15,7 @@
 // a socket — loam_velodyne_amd/launch.py uses a file).
 #include "common.h"
 #include <memory>
+#include <vector>
 #ifndef LOAMX_NO_RCCL
 #include <rccl/rccl.h>
 
@@ -45,6 +46,8 @@ static inline ncclResult_t ncclGroupEnd() { return 1; }
 static inline ncclResult_t ncclBroadcast(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) { return 1; }
 static inline ncclResult_t ncclAllGather(const void*, void*, size_t, int, ncclComm_t, hipStream_t) { return 1; }
 static inline ncclResult_t ncclAllReduce(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) { return 1; }
+static inline ncclResult_t ncclSend(const void*, size_t, int, int, ncclComm_t, hipStream_t) { return 1; }
+static inline ncclResult_t ncclRecv(void*, size_t, int, int, ncclComm_t, hipStream_t) { return 1; }
 #endif
 
 using namespace loamx;
@@ -58,6 +61,8 @@ struct loamx_dist {
   PinBuf<float> h_send, h_recv;
   DevBuf<uint32_t> d_cnt;
   PinBuf<uint32_t> h_cnt;
+  DevBuf<uint32_t> d_gsend, d_grecv;   // gatherv: this rank's words / (root) every rank's words back to back
+  PinBuf<uint32_t> h_gsend, h_grecv;
   ~loamx_dist() {
     if (comm) (void)ncclCommDestroy(comm);
     if (ev_bcast) (void)hipEventDestroy(ev_bcast);
@@ -223,6 +228,126 @@ int loamx_dist_allgather_results_cap(loamx_dist* h, const float* poses6, const i
 int loamx_dist_allgather_results(loamx_dist* h, const float* poses6, const int* iters_flags2, uint32_t n_local, float* poses6_all,
                                  int* iters_flags2_all, uint32_t* counts_all) {
   return loamx_dist_allgather_results_cap(h, poses6, iters_flags2, n_local, poses6_all, iters_flags2_all, 0xffffffffu, counts_all);
+}
+
+// ---- the epoch's merge step (collective 3): the sweeps a rank has registered travel to the rank that owns the map
+// accumulator.  Layout of one rank's message, in 32-bit words (host side, no device: testable without a GPU, usable over any transport):
+//   [0] magic 'LXCL'  [1] n_streams  [2 + 2 s] n_corner(s)  [3 + 2 s] n_surf(s)  | 6 n_streams pose floats (transformAftMapped) |
+//   the points, x y z intensity each: corner(0), surf(0), corner(1), surf(1), ...
+static constexpr uint32_t LX_CLOUD_MAGIC = 0x4c58434cu;
+int loamx_dist_pack_clouds(uint32_t n_streams, const loamx_cloud* corner, const loamx_cloud* surf, const float* poses6, uint32_t* words,
+                           uint64_t capacity_words, uint64_t* n_words) {
+  return guard([&]() {
+    LX_REQUIRE(n_words && (n_streams == 0 || (corner && surf && poses6)), "NULL argument");
+    uint64_t need = 2 + 2ull * n_streams + 6ull * n_streams;
+    for (uint32_t s = 0; s < n_streams; s++) {
+      check_cloud(&corner[s], false); check_cloud(&surf[s], false);
+      need += 4ull * corner[s].count + 4ull * surf[s].count;
+    }
+    *n_words = need;
+    if (!words) return (int)LOAMX_OK;   // size query
+    if (need > capacity_words) throw Error(LOAMX_E_CAPACITY, "the packed clouds do not fit (n_words holds the size)");
+    words[0] = LX_CLOUD_MAGIC; words[1] = n_streams;
+    for (uint32_t s = 0; s < n_streams; s++) { words[2 + 2 * s] = corner[s].count; words[3 + 2 * s] = surf[s].count; }
+    uint32_t* w = words + 2 + 2 * (size_t)n_streams;
+    memcpy(w, poses6, sizeof(float) * 6 * n_streams);
+    w += 6 * (size_t)n_streams;
+    for (uint32_t s = 0; s < n_streams; s++) {   // (the words are 4-byte aligned: plain float copies, no 16-byte vector stores)
+      const loamx_cloud* two[2] = {&corner[s], &surf[s]};
+      for (const loamx_cloud* c : two) {
+        const char* src = (const char*)c->data;
+        for (uint32_t i = 0; i < c->count; i++) {
+          const char* r = src + (size_t)i * c->stride;
+          memcpy(w, r, 12);
+          memcpy(w + 3, r + c->intensity_offset, 4);
+          w += 4;
+        }
+      }
+    }
+    return (int)LOAMX_OK;
+  });
+}
+int loamx_dist_unpack_clouds_header(const uint32_t* words, uint64_t n_words, uint32_t* n_streams, uint32_t* n_corner, uint32_t* n_surf, uint32_t capacity_streams) {
+  return guard([&]() {
+    LX_REQUIRE(words && n_streams, "NULL argument");
+    LX_REQUIRE(n_words >= 2 && words[0] == LX_CLOUD_MAGIC, "not a packed-cloud message");
+    const uint32_t ns = words[1];
+    *n_streams = ns;
+    uint64_t need = 2 + 8ull * ns;
+    LX_REQUIRE(n_words >= need, "packed-cloud message truncated (header)");
+    for (uint32_t s = 0; s < ns; s++) need += 4ull * words[2 + 2 * s] + 4ull * words[3 + 2 * s];
+    LX_REQUIRE(n_words == need, "packed-cloud message size does not match its header");
+    if (n_corner || n_surf) {
+      if (ns > capacity_streams) throw Error(LOAMX_E_CAPACITY, "more streams in the message than the count arrays hold");
+      for (uint32_t s = 0; s < ns; s++) { if (n_corner) n_corner[s] = words[2 + 2 * s]; if (n_surf) n_surf[s] = words[3 + 2 * s]; }
+    }
+    return (int)LOAMX_OK;
+  });
+}
+int loamx_dist_unpack_clouds_stream(const uint32_t* words, uint64_t n_words, uint32_t stream, float pose6[6], loamx_cloud* corner, loamx_cloud* surf) {
+  return guard([&]() {
+    LX_REQUIRE(words && pose6 && corner && surf, "NULL argument");
+    uint32_t ns = 0;
+    int rc = loamx_dist_unpack_clouds_header(words, n_words, &ns, nullptr, nullptr, 0);
+    if (rc != LOAMX_OK) return rc;
+    LX_REQUIRE(stream < ns, "stream index beyond the message");
+    check_cloud(corner, false); check_cloud(surf, false);
+    memcpy(pose6, words + 2 + 2 * (size_t)ns + 6 * (size_t)stream, 6 * sizeof(float));
+    const uint32_t* w = words + 2 + 8 * (size_t)ns;
+    for (uint32_t s = 0; s < stream; s++) w += 4 * ((size_t)words[2 + 2 * s] + words[3 + 2 * s]);
+    const uint32_t nc = words[2 + 2 * stream], nsf = words[3 + 2 * stream];
+    std::vector<float4> tmp((size_t)std::max(nc, nsf) + 1);
+    memcpy(tmp.data(), w, sizeof(float4) * nc);
+    const int r1 = unpack_cloud(tmp.data(), nc, corner);
+    memcpy(tmp.data(), w + 4 * (size_t)nc, sizeof(float4) * nsf);
+    const int r2 = unpack_cloud(tmp.data(), nsf, surf);
+    return r1 != LOAMX_OK ? r1 : r2;
+  });
+}
+
+// Variable-size gather to one rank: every rank's count first (the all-gather of the result exchange), then the words themselves
+// point to point — RCCL has no gatherv; the root posts one receive per rank, every rank (the root too) one send, in ONE group.
+// recv_words (root only): the ranks' messages back to back in rank order; counts_all (may be NULL): every rank's word count.
+int loamx_dist_gatherv(loamx_dist* h, const uint32_t* send_words, uint32_t n_words, int root, uint32_t* recv_words, uint64_t capacity_words,
+                       uint32_t* counts_all) {
+  return guard([&]() {
+    LX_REQUIRE(h && (send_words || !n_words), "NULL argument");
+    LX_REQUIRE(root >= 0 && root < h->world, "root out of range");
+    LX_HIP(hipSetDevice(h->device));
+    TraceRange trace_range("loamx:dist:gatherv");
+    const int G = h->world;
+    dist_gather_counts(h, n_words);
+    if (counts_all) memcpy(counts_all, h->h_cnt.p, sizeof(uint32_t) * G);
+    unsigned long long total = 0;
+    for (int r = 0; r < G; r++) total += h->h_cnt.p[r];
+    if (!total) return (int)LOAMX_OK;   // (every rank sees the same counts: all of them leave here)
+    h->h_gsend.reserve((size_t)n_words + 1); h->d_gsend.reserve((size_t)n_words + 1);
+    if (n_words) {
+      memcpy(h->h_gsend.p, send_words, sizeof(uint32_t) * n_words);
+      LX_HIP(hipMemcpyAsync(h->d_gsend.p, h->h_gsend.p, sizeof(uint32_t) * n_words, hipMemcpyHostToDevice, h->st));
+    }
+    const bool is_root = h->rank == root;
+    if (is_root) { h->d_grecv.reserve((size_t)total + 1); h->h_grecv.reserve((size_t)total + 1); }
+    LX_NCCL(ncclGroupStart());
+    if (is_root) {
+      size_t off = 0;
+      for (int r = 0; r < G; r++) {
+        if (h->h_cnt.p[r]) LX_NCCL(ncclRecv(h->d_grecv.p + off, h->h_cnt.p[r], ncclUint32, r, h->comm, h->st));
+        off += h->h_cnt.p[r];
+      }
+    }
+    if (n_words) LX_NCCL(ncclSend(h->d_gsend.p, n_words, ncclUint32, root, h->comm, h->st));
+    LX_NCCL(ncclGroupEnd());
+    if (is_root) LX_HIP(hipMemcpyAsync(h->h_grecv.p, h->d_grecv.p, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, h->st));
+    LX_HIP(hipStreamSynchronize(h->st));
+    if (is_root) {
+      // (the capacity is the root's own matter: checked after the exchange, so that a root with too small a buffer fails alone)
+      LX_REQUIRE(recv_words, "NULL receive buffer on the root");
+      if (total > capacity_words) throw Error(LOAMX_E_CAPACITY, "the ranks' words do not fit the receive buffer (counts_all holds the counts)");
+      memcpy(recv_words, h->h_grecv.p, sizeof(uint32_t) * total);
+    }
+    return (int)LOAMX_OK;
+  });
 }
 
 int loamx_dist_comm_count(loamx_dist* h) {   // ranks the RCCL communicator itself reports (a scaling run proves RCCL saw N ranks)

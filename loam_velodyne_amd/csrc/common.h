@@ -113,9 +113,11 @@ inline void pack_cloud(const loamx_cloud* c, float4* dst) {
     if (c->count) memcpy(dst, src, (size_t)c->count * 16);
     return;
   }
+  char* d = (char*)dst;   // (byte copies: the destination is not always 16-byte aligned storage, and the compiler must not assume it is)
   for (uint32_t i = 0; i < c->count; i++) {
-    const float* r = (const float*)(src + (size_t)i * c->stride);
-    dst[i] = make_float4(r[0], r[1], r[2], *(const float*)((const char*)r + c->intensity_offset));
+    const char* r = src + (size_t)i * c->stride;
+    memcpy(d + (size_t)i * 16, r, 12);
+    memcpy(d + (size_t)i * 16 + 12, r + c->intensity_offset, 4);
   }
 }
 // writes min(n, capacity) points; returns LOAMX_E_CAPACITY (after writing what fits) when n > capacity

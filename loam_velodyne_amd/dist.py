@@ -53,3 +53,31 @@ def gather_poses(poses: np.ndarray, dist, device=None) -> np.ndarray:
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return torch.cat(out, 0).cpu().numpy()
+
+
+def epoch_merge(streams, acc, ldist=None, rank: int = 0, root: int = 0):
+    """The merge step of a map epoch (collective 3; BasicLaserMapping.cpp:536-593 is what loamx_map_insert restates).
+
+    streams: this rank's [(pose6 = transformAftMapped, corner_last, surf_last)] — per mapped stream the re-projected clouds of its last
+    step (loamx_pipeline_download_last_clouds).  Every rank packs them into ONE message (loamx_dist_pack_clouds); the messages travel to
+    `root` counts first (ldist.gatherv: RCCL send / recv; ldist = None: a single rank, the message goes through pack / unpack all the
+    same); the root unpacks every rank's streams in rank order and inserts each sweep into the accumulator `acc` (a loamx.LaserMapping
+    loaded with the epoch's map) with ITS pose, as given.  Returns the number of sweeps merged on the root, 0 elsewhere.
+    """
+    from loam_velodyne_amd import loamx
+    words = loamx.dist_pack_clouds([s[1] for s in streams], [s[2] for s in streams], [s[0] for s in streams]) if streams else np.zeros(0, np.uint32)
+    if ldist is None:
+        msgs = [words if len(words) else None]
+    else:
+        msgs, _ = ldist.gatherv(words, root=root)
+    if rank != root or msgs is None:
+        return 0
+    merged = 0
+    for m in msgs:
+        if m is None:
+            continue
+        for pose, corner, surf in loamx.dist_unpack_clouds(m):
+            if len(corner) or len(surf):
+                acc.insert(corner, surf, pose)
+                merged += 1
+    return merged

@@ -58,6 +58,11 @@ def lib():
         L.loamx_last_error.restype = C.c_char_p
         if hasattr(L, "loamx_build_info"):
             L.loamx_build_info.restype = C.c_char_p
+        if hasattr(L, "loamx_dist_pack_clouds"):   # (64-bit sizes and more than six arguments: spelled out rather than left to ctypes' defaults)
+            L.loamx_dist_pack_clouds.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+            L.loamx_dist_unpack_clouds_header.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+            L.loamx_dist_unpack_clouds_stream.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.loamx_dist_gatherv.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         for n in ("loamx_scanreg_create", "loamx_odom_create", "loamx_map_create", "loamx_batch_create",
                   "loamx_batch_stream"):
             if hasattr(L, n):
@@ -752,6 +757,51 @@ def dist_unpack_results(recv, counts, n_pad: int):
     return pa[:tot], fa[:tot]
 
 
+def dist_pack_clouds(corners, surfs, poses6) -> np.ndarray:
+    """one rank's message of the epoch merge step (loamx_dist_pack_clouds): per stream its re-projected corner / surf clouds and its
+    transformAftMapped -> uint32 words"""
+    cs = [as_points(c) for c in corners]
+    ss = [as_points(c) for c in surfs]
+    n = len(cs)
+    assert len(ss) == n
+    p = np.ascontiguousarray(poses6, np.float32).reshape(n, 6) if n else np.zeros((0, 6), np.float32)
+    CA = Cloud * max(n, 1)
+    ca, sa = CA(*[cloud_of(c) for c in cs]), CA(*[cloud_of(c) for c in ss])
+    nw = C.c_uint64(0)
+    _check(lib().loamx_dist_pack_clouds(n, C.addressof(ca), C.addressof(sa), p.ctypes.data, None, 0, C.addressof(nw)))
+    out = np.zeros(int(nw.value), np.uint32)
+    _check(lib().loamx_dist_pack_clouds(n, C.addressof(ca), C.addressof(sa), p.ctypes.data, out.ctypes.data, len(out), C.addressof(nw)))
+    return out
+
+
+def dist_unpack_clouds(words):
+    """inverse of dist_pack_clouds -> [(pose6, corner, surf)] per stream"""
+    w = np.ascontiguousarray(words, np.uint32)
+    ns = C.c_uint32(0)
+    _check(lib().loamx_dist_unpack_clouds_header(w.ctypes.data, len(w), C.addressof(ns), None, None, 0))
+    n = int(ns.value)
+    nc, nsf = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+    _check(lib().loamx_dist_unpack_clouds_header(w.ctypes.data, len(w), C.addressof(ns), nc.ctypes.data, nsf.ctypes.data, max(n, 1)))
+    out = []
+    for s in range(n):
+        pose = np.zeros(6, np.float32)
+        co, so = np.zeros((max(int(nc[s]), 1), 4), np.float32), np.zeros((max(int(nsf[s]), 1), 4), np.float32)
+        cc, sc = cloud_of(co), cloud_of(so)
+        _check(lib().loamx_dist_unpack_clouds_stream(w.ctypes.data, len(w), s, pose.ctypes.data, C.addressof(cc), C.addressof(sc)))
+        out.append((pose, co[:cc.count].copy(), so[:sc.count].copy()))
+    return out
+
+
+def dist_split_messages(words, counts):
+    """the root's receive buffer of a gatherv -> one message per rank (rank order; an empty rank -> None)"""
+    out, o = [], 0
+    for c in counts:
+        c = int(c)
+        out.append(np.ascontiguousarray(words[o:o + c]) if c else None)
+        o += c
+    return out
+
+
 class Dist:
     """loamx_dist_*: the multi-GPU exchanges of the batched mode over RCCL (one process per GPU)."""
     ID_BYTES = 128
@@ -812,6 +862,24 @@ class Dist:
                                                       n, pa.ctypes.data_as(C.c_void_p), fa.ctypes.data_as(C.c_void_p), cap, cnt.ctypes.data_as(C.c_void_p)))
         tot = int(cnt.sum())
         return pa[:tot], fa[:tot], cnt
+
+    def allgather_counts(self, n: int) -> np.ndarray:
+        """every rank's n (loamx_dist_allgather_counts): also the way a root tells the others a size"""
+        cnt = np.zeros(self.world, np.uint32)
+        _check(lib().loamx_dist_allgather_counts(self.h, int(n), cnt.ctypes.data_as(C.c_void_p)))
+        return cnt
+
+    def gatherv(self, words, root: int = 0):
+        """variable-size gather of uint32 words to `root` (loamx_dist_gatherv): returns (messages per rank | None off the root, counts)"""
+        w = np.ascontiguousarray(words if words is not None else np.zeros(0, np.uint32), np.uint32)
+        cnt = np.zeros(self.world, np.uint32)
+        # the root cannot size its buffer before it knows the counts: they are gathered by a first call with nothing to receive into
+        _check(lib().loamx_dist_allgather_counts(self.h, len(w), cnt.ctypes.data_as(C.c_void_p)))
+        tot = int(cnt.sum())
+        recv = np.zeros(max(tot, 1), np.uint32) if self.rank == root else None
+        _check(lib().loamx_dist_gatherv(self.h, w.ctypes.data, len(w), root, recv.ctypes.data if recv is not None else None,
+                                        tot if recv is not None else 0, cnt.ctypes.data))
+        return (dist_split_messages(recv[:tot], cnt) if recv is not None else None), cnt
 
     def comm_count(self) -> int:
         return int(lib().loamx_dist_comm_count(self.h))

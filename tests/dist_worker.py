@@ -68,5 +68,21 @@ else:                                      # more ranks than sweeps: an empty sh
     poses, stats = np.zeros((0, 6), np.float32), np.zeros((0, 4), np.int32)
 allp, allf, counts = d.allgather_results(poses, np.stack([stats[:, 0], stats[:, 1]], 1), batch=B)
 assert int(counts.sum()) == B and d.comm_count() == world
+# the epoch's merge exchange: every rank's (variable-size) cloud message reaches rank 0 intact (loamx_dist_gatherv)
+rngm = np.random.default_rng(7 + rank)
+mine = [(rngm.normal(size=6).astype(np.float32), rngm.normal(size=(30 + 11 * rank + k, 4)).astype(np.float32), rngm.normal(size=(80 + k, 4)).astype(np.float32))
+        for k in range(1 + rank)]
+words = loamx.dist_pack_clouds([m[1] for m in mine], [m[2] for m in mine], [m[0] for m in mine])
+msgs, wcounts = d.gatherv(words, root=0)
+assert int(wcounts[rank]) == len(words)
+if rank == 0:
+    assert len(msgs) == world
+    for r_, m_ in enumerate(msgs):
+        rr = np.random.default_rng(7 + r_)
+        for k, (pose, co, su) in enumerate(loamx.dist_unpack_clouds(m_)):
+            assert np.array_equal(pose, rr.normal(size=6).astype(np.float32))
+            assert np.array_equal(co, rr.normal(size=(30 + 11 * r_ + k, 4)).astype(np.float32)) and np.array_equal(su, rr.normal(size=(80 + k, 4)).astype(np.float32))
+else:
+    assert msgs is None
 d.barrier()
 np.savez(os.path.join(out_dir, f"rank{rank}.npz"), poses=allp, flags=allf, shard=np.array([b0, b1]), map_sum=float(map_t.double().sum().item()))

@@ -42,6 +42,10 @@ class FakeTensor:
     def __len__(self):
         return len(self.a)
 
+    @property
+    def shape(self):
+        return self.a.shape
+
 
 def fake_torch():
     t = types.ModuleType("torch")
@@ -120,6 +124,15 @@ class FakeDist:
     def comm_count(self):
         return self.world
 
+    def allgather_counts(self, n):
+        return np.full(self.world, n, np.uint32)
+
+    def gatherv(self, words, root=0):
+        # every other rank is played by a copy of this rank's message (the layout is the library's own: loamx.dist_pack_clouds is real)
+        w = np.asarray(words, np.uint32)
+        self.gathers = getattr(self, "gathers", 0) + 1
+        return ([w if len(w) else None for _ in range(self.world)] if self.rank == root else None), np.full(self.world, len(w), np.uint32)
+
 
 class FakePipeline:
     """the calls bench.py makes on loamx.Pipeline, with the ordering rules of include/loamx.h asserted"""
@@ -158,6 +171,21 @@ class FakePipeline:
         self.last = t
         return 1 if t == 0 else 0   # the first sweep of a stream only initialises the odometry
 
+    def swap_frozen(self):
+        sw = getattr(self, "staged_maps", 0) > getattr(self, "swapped", 0)
+        self.swapped = getattr(self, "swapped", 0) + (1 if sw else 0)
+        return sw
+
+    def stage_frozen_device(self, d_corner, n_corner, d_surf, n_surf, ev=0):
+        assert d_surf == d_corner + 16 * n_corner and n_corner > 0 and n_surf > 0
+        self.staged_maps = getattr(self, "staged_maps", 0) + 1
+        self.map_sizes = getattr(self, "map_sizes", []) + [(n_corner, n_surf)]
+
+    def last_clouds(self, stream, capacity):
+        assert self.last >= 1 and 0 <= stream < self.ns
+        rng = np.random.default_rng(1000 * self.last + stream)
+        return rng.normal(size=(40, 4)).astype(np.float32), rng.normal(size=(90, 4)).astype(np.float32)
+
     def drain_lookahead(self):
         self.drains = getattr(self, "drains", [])
         self.drains.append(self.last)
@@ -170,6 +198,10 @@ class FakePipeline:
     def timing(self):
         return dict(features_ms=0.2, odometry_ms=0.5, registration_ms=0.4, step_ms=0.4, residual_ms=0.18, residual_launches=3,
                     query_iterations=3 * 1000 * self.ns, queries=1000 * self.ns, run_ms=0.4)
+
+    def odom_launch_timing(self):
+        return dict(lm_ms=0.4, lm_noop_ms=0.02, corr_ms=0.3, corr_noop_ms=0.02, lm_launches=10, lm_noop_launches=4, lm_iterations=44, corr_launches=10,
+                    corr_noop_launches=4, lm_bytes=10 * 48 * 2304 * self.ns, corr_features=10 * 2304 * self.ns)
 
     def get(self, k):
         z = np.zeros(6, np.float32)
@@ -186,9 +218,19 @@ class FakePipeline:
 
 
 class FakeLib:
-    """the two C entry points bench.py calls directly in the PCIe window"""
-    def __init__(self, loamx):
+    """the two C entry points bench.py calls directly in the PCIe window (+ by name, entry points of the real library: host-side layout
+    functions that need no GPU)"""
+    def __init__(self, loamx, real=()):
         self.loamx = loamx
+        if real:
+            import ctypes
+            L = ctypes.CDLL(loamx.LIB_PATH)
+            L.loamx_last_error.restype = ctypes.c_char_p
+            L.loamx_dist_pack_clouds.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+            L.loamx_dist_unpack_clouds_header.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+            L.loamx_dist_unpack_clouds_stream.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            for n in real:
+                setattr(self, n, getattr(L, n))
 
     def _pipe(self, h):
         return next(p for p in FakePipeline.instances if p.h == h)
@@ -209,6 +251,9 @@ class FakeLib:
 
     def loamx_last_error(self):
         return b""
+
+    def loamx_build_info(self):
+        return b"abi=5;diag=0;rccl=1;roctx=1"
 
 
 @pytest.mark.parametrize("argv", [["--steps", "3", "--warmup", "1", "--streams", "2", "--sensor", "VLP-16", "--map-points", "2000", "--no-cpu-baseline",
@@ -235,7 +280,10 @@ def test_bench_main_runs_over_stand_ins(monkeypatch, capsys, argv):
                 "config", "roofline", "value_median", "value_min", "value_max"):
         assert key in out, key
     assert out["steps"] == K and out["warmup"] == W and out["n_gpus"] == 1 and out["config"]["streams_per_gpu"] == ns
-    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "dominant_by", "peak_copy_ceiling"}
+    if out["roofline"]["kernel"].startswith("loamx::k_odom_lm"):   # (the committed kernel stats name the dominant kernel)
+        assert set(out["roofline"]["latency_model"]) >= {"us_per_iteration", "floor_us", "source"} and "k_gn_iter" in out["roofline"]
+    assert "env_overrides" in out["config"] and out["config"]["library_build"]["diag"] == "0"
     assert out["value_repeats"] == 2 and out["config"]["handles_per_gpu"] == H
     if H == 1:
         assert len(out["pcie_inclusive"]["value_windows"]) == 3
@@ -304,3 +352,62 @@ def test_pose_error_and_roofline_kernels_helpers():
     assert {r["kernel"] for r in rows} >= {"loamx::k_odom_corr_grid", "loamx::k_odom_lm<1>", "loamx::k_vb_reduce", "loamx::k_feat_ring"}
     for r in rows:
         assert r["algorithmic_bytes_per_launch"] > 0 and set(r) >= {"avg_launch_us", "frac", "traffic", "model", "source"}
+
+
+class FakeMapping:
+    """loamx.LaserMapping as the epoch's accumulator: counts what is inserted"""
+    made = []
+
+    def __init__(self, **cfg):
+        self.c = self.s = None
+        self.inserted = []
+        FakeMapping.made.append(self)
+
+    def load_cubes(self, cm, sm):
+        self.c, self.s = np.asarray(cm, np.float32).copy(), np.asarray(sm, np.float32).copy()
+
+    def insert(self, corner, surf, pose6):
+        assert corner.shape[1] == 4 and surf.shape[1] == 4 and np.asarray(pose6).shape == (6,)
+        self.inserted.append((len(corner), len(surf)))
+        self.c = np.concatenate([self.c, corner[:3]])   # the merged map grows
+        self.s = np.concatenate([self.s, surf[:5]])
+        return 0
+
+    def cubes(self, which):
+        return self.c if which == "corner" else self.s
+
+
+def test_bench_epoch_merge_as_rank_0_of_eight(monkeypatch, capsys):
+    """bench.py --map-epoch-steps E --epoch-merge as rank 0 of EIGHT: at every epoch boundary the ranks' sweeps are packed with the library's
+    own layout, gathered to rank 0 (the stand-in communicator plays the other seven ranks), inserted into the accumulator, and the merged
+    map — of a new size every epoch — is what is broadcast and staged.  The multi-GPU epoch has never run on hardware: its control flow
+    at least runs here, with the real pack / unpack code under it."""
+    from loam_velodyne_amd import loamx
+    ft = fake_torch()
+    monkeypatch.setitem(sys.modules, "torch", ft)
+    monkeypatch.setitem(sys.modules, "torch.distributed", ft.distributed)
+    monkeypatch.setattr(loamx, "Pipeline", FakePipeline)
+    monkeypatch.setattr(loamx, "Dist", FakeDist)
+    monkeypatch.setattr(loamx, "LaserMapping", FakeMapping)
+    monkeypatch.setattr(loamx, "lib", lambda: FakeLib(loamx, real=("loamx_dist_pack_clouds", "loamx_dist_unpack_clouds_header", "loamx_dist_unpack_clouds_stream")))
+    K, W, ns, E = 6, 1, 2, 2
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", str(K), "--warmup", str(W), "--streams", str(ns), "--sensor", "VLP-16", "--map-points", "2000",
+                                      "--repeat", "1", "--no-pcie", "--map-epoch-steps", str(E), "--epoch-merge"])
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    FakePipeline.instances.clear()
+    FakeDist.made.clear()
+    FakeMapping.made.clear()
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    bench.main()
+    out = json.loads([l for l in capsys.readouterr().out.strip().splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["config"]["rccl_ranks"] == 8 and out["config"]["map_epoch_steps"] == E
+    boundaries = K // E - 1                       # the first epoch has nothing to merge yet
+    merged = out["config"]["map_epoch_merge"]["merged_sweeps_on_rank0"]
+    assert merged == boundaries * 8 * ns, (merged, boundaries)
+    acc = FakeMapping.made[-1]
+    assert len(acc.inserted) == merged and FakeDist.made[0].gathers == boundaries
+    sizes = FakePipeline.instances[-1].map_sizes
+    assert len(sizes) >= K // E and sizes[-1][0] > sizes[0][0] and sizes[-1][1] > sizes[0][1]   # the staged map grew with the merged sweeps

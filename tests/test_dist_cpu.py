@@ -137,3 +137,84 @@ def test_stream_layout_helpers():
     starts = {lxdist.stream_start(g) for g in range(64)}
     assert len(starts) == 64
     assert lxdist.split_map(1_000_000) == (100_000, 900_000)
+
+
+def _cloud_worker(rank, world, port, q):
+    """the epoch's merge step over gloo: every rank packs its streams' clouds + poses with the library's own layout rule
+    (loamx_dist_pack_clouds), the words travel to rank 0 counts first (what loamx_dist_gatherv does with ncclSend / ncclRecv), rank 0
+    splits the buffer by the counts and unpacks (loamx_dist_unpack_clouds_*)"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from loam_velodyne_amd import loamx
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    n_streams = [3, 0, 2][rank % 3]                       # rank 1 holds NO stream: an empty message that still takes part
+    corners = [rng.normal(size=(int(rng.integers(0, 40)), 4)).astype(np.float32) for _ in range(n_streams)]
+    surfs = [rng.normal(size=(int(rng.integers(1, 90)), 4)).astype(np.float32) for _ in range(n_streams)]
+    if n_streams:
+        corners[0] = np.zeros((0, 4), np.float32)        # an empty cloud inside a message
+    poses = rng.normal(size=(n_streams, 6)).astype(np.float32)
+    words = loamx.dist_pack_clouds(corners, surfs, poses) if n_streams else np.zeros(0, np.uint32)
+    cnt = torch.tensor([len(words)], dtype=torch.int64)
+    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(counts, cnt)                           # 1. the counts
+    counts = [int(c.item()) for c in counts]
+    pad = max(max(counts), 1)
+    send = torch.zeros(pad, dtype=torch.int32)
+    send[:len(words)] = torch.from_numpy(words.view(np.int32))
+    recv = [torch.zeros(pad, dtype=torch.int32) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, recv, dst=0)                         # 2. the words (padded here: gloo has no gatherv either)
+    ok = True
+    if rank == 0:
+        buf = np.concatenate([recv[r].numpy().view(np.uint32)[:counts[r]] for r in range(world)])
+        msgs = loamx.dist_split_messages(buf, counts)
+        got = [None if m is None else loamx.dist_unpack_clouds(m) for m in msgs]
+        q.put(("root", counts, [[(p.tolist(), c.tolist(), s.tolist()) for (p, c, s) in g] if g is not None else None for g in got]))
+    q.put((rank, [(poses[s].tolist(), corners[s].tolist(), surfs[s].tolist()) for s in range(n_streams)]))
+    dist.barrier()
+    dist.destroy_process_group()
+    return ok
+
+
+def test_epoch_cloud_messages_world2():
+    """SURVEY.md section 8e, collective 3: variable-size clouds to the accumulator's rank — layout and count-first protocol on CPU"""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cloud_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    items = [q.get(timeout=120) for _ in range(3)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    root = next(i for i in items if i[0] == "root")
+    sent = {i[0]: i[1] for i in items if i[0] != "root"}
+    assert root[1][1] == 0 and root[1][0] > 0                  # rank 1's empty message
+    assert root[2][1] is None
+    assert len(root[2][0]) == 3
+    for s_, (pose, corner, surf) in enumerate(root[2][0]):      # bit for bit what rank 0 packed
+        assert pose == sent[0][s_][0] and corner == sent[0][s_][1] and surf == sent[0][s_][2]
+    assert root[2][0][0][1] == []                               # the empty cloud came through as empty
+
+
+def test_cloud_message_is_validated():
+    from loam_velodyne_amd import loamx
+    w = loamx.dist_pack_clouds([np.ones((3, 4), np.float32)], [np.ones((5, 4), np.float32)], np.zeros((1, 6), np.float32))
+    assert len(w) == 2 + 2 + 6 + 4 * 8
+    assert len(loamx.dist_unpack_clouds(w)) == 1
+    for bad in (w[:-1], np.concatenate([w, w[:1]]), np.concatenate([[1], w[1:]]).astype(np.uint32)):
+        with pytest.raises(loamx.LoamxError):
+            loamx.dist_unpack_clouds(bad)
+    # PCL-layout clouds (32-byte records) pack to the same words
+    a, b = np.arange(12, dtype=np.float32).reshape(3, 4), np.arange(20, dtype=np.float32).reshape(5, 4)
+    w1 = loamx.dist_pack_clouds([a], [b], np.zeros((1, 6), np.float32))
+    w2 = loamx.dist_pack_clouds([loamx.to_pcl_layout(a)], [loamx.to_pcl_layout(b)], np.zeros((1, 6), np.float32))
+    assert np.array_equal(w1, w2)

@@ -540,9 +540,11 @@ def test_map_epoch_with_merge_step(orc, small_world):
     acc = loamx.LaserMapping()                      # the epoch's accumulator starts from the frozen map
     acc.load_cubes(cm, sm)
     n0 = len(acc.cubes("corner")) + len(acc.cubes("surf"))
+    from loam_velodyne_amd import dist as lxdist
     merged = 0
     for t in range(E0):
         p.step(t)
+        mine = []
         for s in range(ns):
             got = p.get(s)
             for i in range(3):
@@ -551,8 +553,10 @@ def test_map_epoch_with_merge_step(orc, small_world):
                 continue
             lc, ls = p.last_clouds(s, len(data[s][t].points))
             assert len(lc) > 50 and len(ls) > 200
-            assert acc.insert(lc, ls, got[2]) == loamx.OK
-            merged += 1
+            mine.append((got[2], lc, ls))
+        # the sweeps reach the accumulator as ONE packed message per rank (loamx_dist_pack_clouds -> unpack -> loamx_map_insert): the
+        # path the ranks' clouds take over RCCL (loamx_dist_gatherv), here with a single rank
+        merged += lxdist.epoch_merge(mine, acc)
     assert merged == ns * (E0 - 1)
     new_c, new_s = acc.cubes("corner"), acc.cubes("surf")
     assert len(new_c) + len(new_s) > n0

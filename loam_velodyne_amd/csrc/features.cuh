@@ -93,9 +93,12 @@ class FeatureExtractor {
   //   kind 0 sharp, 1 less_sharp, 2 flat: compact arrays + per-sweep offsets [nsw+1]
   //   less_flat: voxel-filtered per ring; d_less_flat_ring_off [total_rings+1]; sweep s owns rings [ring_base(s), ring_base(s+1))
   const float4* d_feat(int kind) const { return out_[kind].p; }
-  const uint32_t* d_feat_off(int kind) const { return out_off_[kind].p; }
+  const uint32_t* d_feat_off(int kind) const { return offs_.p + (size_t)kind * off_stride_; }
+  // all four offset tables back to back: [kind][n_sweeps + 1] x 3, then the less-flat ring offsets [total_rings + 1]
+  const uint32_t* d_offsets() const { return offs_.p; }
+  uint32_t n_offsets() const { return 3 * off_stride_ + nring_ + 1; }
   const float4* d_less_flat() const { return lf_out_.p; }
-  const uint32_t* d_less_flat_ring_off() const { return lf_off_.p; }
+  const uint32_t* d_less_flat_ring_off() const { return offs_.p + (size_t)3 * off_stride_; }
   const float4* d_cloud() const { return cloud_.p; }
   uint32_t n_points() const { return n_; }
   uint32_t n_sweeps() const { return nsw_; }
@@ -127,15 +130,15 @@ class FeatureExtractor {
   PinBuf<float4> h_cloud_;
   DevBuf<float4> cloud_;
   DevBuf<uint32_t> ring_off_, ring_sweep_base_;   // ring_off_[nring+1] global point offsets; sweep base offset per ring
-  DevBuf<float> curv_;
-  DevBuf<uint8_t> flags_, gap_, lf_valid_;
+  DevBuf<uint8_t> lf_valid_;   // (curvature, masks and gaps live in k_feat_ring's LDS since round 5)
   DevBuf<float4> slots_[3];       // per-ring fixed-capacity pick slots (sharp / less sharp / flat)
   DevBuf<uint32_t> slot_cnt_[3];  // per-ring counts
-  DevBuf<float4> out_[3];
-  DevBuf<uint32_t> out_off_[3], sweep_ring_base_;
+  DevBuf<float4> out_[3];         // the compact sharp / less-sharp / flat clouds (k_feat_compact)
+  DevBuf<uint32_t> offs_, sweep_ring_base_;   // offs_: [3][nsw + 1] per-sweep offsets | [nring + 1] less-flat ring offsets
+  uint32_t off_stride_ = 1;
+  uint32_t* lf_off_() const { return offs_.p + (size_t)3 * off_stride_; }
   DevBuf<float4> lf_out_, lf_slots_;
   DevBuf<uint32_t> lf_cnt_;
-  DevBuf<uint32_t> lf_off_;
   VoxelPipeline vox_;
   PinBuf<uint32_t> h_off_;
   PinBuf<uint32_t> h_bad_;   // pinned word raised by k_feat_point on a non-finite input coordinate

@@ -1,15 +1,16 @@
 // Feature extraction kernels for gfx950 — reference src/lib/BasicScanRegistration.cpp:155-386.
 //
-//   k_feat_point   per point: curvature stencil (+-curvatureRegion neighbours on the ring, :293-306) and the
-//                  unreliable-point masks of setScanBuffersFor (:321-363).  Streaming, coalesced float4 loads.
-//   k_feat_ring    one wave64 per scan ring.  For each of the ring's feature regions: stable rank sort of the
-//                  curvatures in LDS (:311-317), then the order-dependent greedy picks (:198-235) done
-//                  cooperatively: the 64 lanes test the next 64 candidates in sorted order, a ballot finds the first
-//                  admissible one, and markAsPicked (:367-386) suppresses its neighbours before the next round — the
-//                  sequential semantics are kept exactly, only the skipping of masked candidates is parallel.
-//                  Regions of a ring are processed in order because suppression spills across region borders.
-//   VoxelPipeline  per-ring pcl::VoxelGrid(0.2 m) of the less-flat candidates (:246-252).
-//   k_feat_*       compaction of the per-ring pick slots into the four output clouds (ring order, pick order).
+//   k_feat_ring    one workgroup of six waves per scan ring.  Prologue (rounds 1-4: a kernel of its own): per point the curvature
+//                  stencil (+-curvatureRegion neighbours on the ring, :293-306), the gap test of markAsPicked and the unreliable-point
+//                  masks of setScanBuffersFor (:321-363), straight into LDS.  Then, per feature region, one wave: stable sort of the
+//                  curvatures (:311-317, bitonic network in registers) and the order-dependent greedy picks (:198-235) done
+//                  cooperatively: the 64 lanes test the next 64 candidates in sorted order, a ballot finds the first admissible one,
+//                  and markAsPicked (:367-386) suppresses its neighbours before the next round — the sequential semantics are kept
+//                  exactly.  The regions' picks run side by side with exact settling of the marks that cross a region boundary.
+//   k_feat_compact the per-ring pick slots -> the three compact output clouds + per-sweep offsets, one launch (every workgroup sums the
+//                  counts of the rings before it itself)
+//   k_feat_lf_voxel / k_feat_lf_compact   per-ring pcl::VoxelGrid(0.2 m) of the less-flat candidates (:246-252) and its compaction
+//   VoxelPipeline  the same voxel grid for rings longer than 4096 points.
 #include "features.cuh"
 #include "scan.cuh"
 
@@ -22,63 +23,6 @@ __device__ inline float sqdiff3(const float4& a, const float4& b) {
 __device__ inline float sqdiff3w(const float4& a, const float4& b, float wb) {
   const float dx = a.x - b.x * wb, dy = a.y - b.y * wb, dz = a.z - b.z * wb;
   return dx * dx + dy * dy + dz * dz;
-}
-
-// grid = (ceil(max_ring_len/256), nring)
-__global__ __launch_bounds__(256) void k_feat_point(const float4* __restrict__ cloud, const uint32_t* __restrict__ ring_off, int cr,
-                                                    float* __restrict__ curv, uint8_t* __restrict__ flags, uint8_t* __restrict__ gap,
-                                                    uint32_t* __restrict__ bad_word) {
-  const uint32_t r = blockIdx.y;
-  const uint32_t s0 = ring_off[r], e1 = ring_off[r + 1];
-  const uint32_t len = e1 - s0;
-  const uint32_t i = s0 + blockIdx.x * blockDim.x + threadIdx.x;
-  // Binned rings are finite by contract (the reference drops NaN / Inf points where it bins, MultiScanRegistration.cpp:187-196, and so
-  // does loamx_scanreg_process_raw); a caller that breaks the contract is told (LOAMX_E_INVALID at the call's synchronisation point)
-  // instead of getting a pose that went through NaN arithmetic: every point of every ring is looked at here anyway
-  if (i < e1) {
-    const float4 q = cloud[i];
-    if (!(isfinite(q.x) && isfinite(q.y) && isfinite(q.z))) __hip_atomic_store(bad_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  if (len <= 2u * cr + 1u) return;
-  const uint32_t e0 = e1 - 1;
-  if (i > e0) return;
-  // gap[i]: the step to the next point exceeds markAsPicked's 0.05 m^2 limit (:372, :380) — precomputed so that the
-  // sequential picking loop never waits on global memory
-  if (i < e0) gap[i] = ((double)sqdiff3(cloud[i + 1], cloud[i]) > 0.05) ? 1 : 0;
-  if (i < s0 + cr || i > e0 - cr) return;
-  const float4 p = cloud[i];
-  // curvature (:293-306): diff = -2*cr*p + sum_j (p[i+j] + p[i-j])
-  const float w = (float)(-2 * cr);
-  float dx = w * p.x, dy = w * p.y, dz = w * p.z;
-  for (int j = 1; j <= cr; j++) {
-    const float4 a = cloud[i + j], b = cloud[i - j];
-    dx += a.x + b.x;
-    dy += a.y + b.y;
-    dz += a.z + b.z;
-  }
-  curv[i] = dx * dx + dy * dy + dz * dz;
-  if (i >= e0 - cr) return;   // the mask loop stops one short (:328)
-  // setScanBuffersFor (:329-361); flags are only ever set to 1, so concurrent writers are benign
-  const float4 prev = cloud[i - 1], next = cloud[i + 1];
-  const float diffNext = sqdiff3(next, p);
-  if ((double)diffNext > 0.1) {
-    const float depth1 = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
-    const float depth2 = sqrtf(next.x * next.x + next.y * next.y + next.z * next.z);
-    if (depth1 > depth2) {
-      const float wd = sqrtf(sqdiff3w(next, p, depth2 / depth1)) / depth2;
-      if ((double)wd < 0.1) {
-        for (int k = 0; k <= cr; k++) flags[i - cr + k] = 1;
-        return;   // `continue` in the reference: the parallel-beam test is skipped
-      }
-    } else {
-      const float wd = sqrtf(sqdiff3w(p, next, depth1 / depth2)) / depth1;
-      if ((double)wd < 0.1)
-        for (int k = 0; k <= cr; k++) flags[i + 1 + k] = 1;
-    }
-  }
-  const float diffPrev = sqdiff3(p, prev);
-  const float dis = p.x * p.x + p.y * p.y + p.z * p.z;
-  if ((double)diffNext > 0.0002 * (double)dis && (double)diffPrev > 0.0002 * (double)dis) flags[i] = 1;
 }
 
 struct RingLds {
@@ -279,20 +223,21 @@ constexpr int FEAT_WAVES = 6;   // regions sorted concurrently per ring
 // 5 waves per SIMD (<= 96 VGPRs): three 6-wave workgroups share a CU, and 512 rings on 256 CUs are not dealt two apiece
 __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu(5))) void k_feat_ring(
     const float4* __restrict__ cloud, const uint32_t* __restrict__ ring_off, const uint32_t* __restrict__ ring_sweep_base, FeatParams P,
-    const float* __restrict__ curv, const uint8_t* __restrict__ gflags, const uint8_t* __restrict__ ggap, uint32_t flag_bytes,
-    uint32_t nmax, uint32_t sortP, float4* __restrict__ slotS,
+    uint32_t flag_bytes, uint32_t nmax, uint32_t sortP, float4* __restrict__ slotS,
     float4* __restrict__ slotLS, float4* __restrict__ slotF, uint32_t* __restrict__ cntS, uint32_t* __restrict__ cntLS,
-    uint32_t* __restrict__ cntF, uint8_t* __restrict__ lf_valid, int force_sequential) {
+    uint32_t* __restrict__ cntF, uint8_t* __restrict__ lf_valid, int force_sequential, uint32_t* __restrict__ bad_word) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint8_t* flags = (uint8_t*)smem;
   uint8_t* gaps = flags + flag_bytes;
   uint8_t* fwd = gaps + flag_bytes;   // marks a region's picks leave BEYOND its end (they concern the next region only)
+  uint8_t* flags0 = fwd + flag_bytes; // the masks of setScanBuffersFor as they were before any pick (a region that is made again starts from them)
+  float* curv_all = (float*)(smem + 4 * (size_t)flag_bytes);   // the ring's curvatures (flag_bytes entries)
   // picked point indices (global), region j's in its own slots [j * max, (j + 1) * max) of the three lists, compacted in region order
   // at the end; the points themselves are copied out after that
-  uint32_t* pickS = (uint32_t*)(smem + 3 * (size_t)flag_bytes);
+  uint32_t* pickS = (uint32_t*)(smem + 8 * (size_t)flag_bytes);
   uint32_t* pickLS = pickS + P.max_sharp * P.n_regions;
   uint32_t* pickF = pickLS + P.max_less_sharp * P.n_regions;
-  char* wave_base = smem + ((3 * (size_t)flag_bytes + 4 * (size_t)((P.max_sharp + P.max_less_sharp + P.max_flat) * P.n_regions) + 15) & ~(size_t)15);
+  char* wave_base = smem + ((8 * (size_t)flag_bytes + 4 * (size_t)((P.max_sharp + P.max_less_sharp + P.max_flat) * P.n_regions) + 15) & ~(size_t)15);
   const size_t wave_bytes = (size_t)nmax * 9;
   __shared__ uint32_t reg_n[FEAT_WAVES], reg_gsp[FEAT_WAVES], reg_scan[FEAT_WAVES], npick[3];
   __shared__ uint32_t rcnt[64][3];    // picks per region (n_regions <= 64)
@@ -305,15 +250,67 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu
   const uint32_t capS = P.max_sharp * nreg, capLS = P.max_less_sharp * nreg, capF = P.max_flat * nreg;
   uint32_t nS = 0, nLS = 0, nF = 0;   // maintained by wave 0
   FT_TS(0);
+  if (len <= 2u * cr + 1u) {          // (too short for a curvature stencil: nothing is extracted, but the finite-input contract still holds)
+    for (uint32_t k = tid; k < len; k += blockDim.x) {
+      const float4 p = cloud[s0g + k];
+      if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) __hip_atomic_store(bad_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   if (len > 2u * cr + 1u) {           // block-uniform
     const uint32_t base = ring_sweep_base[r];
     // indices relative to the sweep's cloud, exactly the values the reference's integer region formula sees (:180-183)
     const unsigned long long s0 = s0g - base, e0 = s0 + len - 1;
+    // ---- the per-point pass of the ring (rounds 1-4: a kernel of its own, k_feat_point, with its results — 5 B per point — written to
+    // HBM and read back here): curvature stencil (:293-306), the gap test of markAsPicked (:372, :380) and the unreliable-point masks of
+    // setScanBuffersFor (:321-363), straight into LDS.  The sweep is read ONCE; the +-curvature_region neighbours come from L1.
+    for (uint32_t k = tid; k < len; k += blockDim.x) { flags[k] = 0; fwd[k] = 0; }
+    __syncthreads();
     for (uint32_t k = tid; k < len; k += blockDim.x) {
-      flags[k] = gflags[s0g + k];
-      gaps[k] = k + 1 < len ? ggap[s0g + k] : 1;
-      fwd[k] = 0;
+      const uint32_t i = s0g + k;
+      const float4 p = cloud[i];
+      // (binned rings are finite by contract; a caller that breaks it is told — LOAMX_E_INVALID at the call's synchronisation point)
+      if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) __hip_atomic_store(bad_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // gap: the step to the next point exceeds markAsPicked's 0.05 m^2 limit
+      gaps[k] = k + 1 < len ? (((double)sqdiff3(cloud[i + 1], p) > 0.05) ? 1 : 0) : 1;
+      if (k < (uint32_t)cr || k + (uint32_t)cr > len - 1u) continue;
+      // curvature (:293-306): diff = -2*cr*p + sum_j (p[i+j] + p[i-j])
+      const float w = (float)(-2 * cr);
+      float dx = w * p.x, dy = w * p.y, dz = w * p.z;
+      for (int j = 1; j <= cr; j++) {
+        const float4 a = cloud[i + j], b = cloud[i - j];
+        dx += a.x + b.x;
+        dy += a.y + b.y;
+        dz += a.z + b.z;
+      }
+      curv_all[k] = dx * dx + dy * dy + dz * dz;
+      if (k + (uint32_t)cr >= len - 1u) continue;   // the mask loop stops one short (:328)
+      // setScanBuffersFor (:329-361); flags are only ever set to 1, so concurrent writers are benign
+      const float4 prev = cloud[i - 1], next = cloud[i + 1];
+      const float diffNext = sqdiff3(next, p);
+      bool skip_beam_test = false;
+      if ((double)diffNext > 0.1) {
+        const float depth1 = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+        const float depth2 = sqrtf(next.x * next.x + next.y * next.y + next.z * next.z);
+        if (depth1 > depth2) {
+          const float wd = sqrtf(sqdiff3w(next, p, depth2 / depth1)) / depth2;
+          if ((double)wd < 0.1) {
+            for (int q = 0; q <= cr; q++) flags[k - cr + q] = 1;
+            skip_beam_test = true;   // `continue` in the reference: the parallel-beam test is skipped
+          }
+        } else {
+          const float wd = sqrtf(sqdiff3w(p, next, depth1 / depth2)) / depth1;
+          if ((double)wd < 0.1)
+            for (int q = 0; q <= cr; q++) flags[k + 1 + q] = 1;
+        }
+      }
+      if (!skip_beam_test) {
+        const float diffPrev = sqdiff3(p, prev);
+        const float dis = p.x * p.x + p.y * p.y + p.z * p.z;
+        if ((double)diffNext > 0.0002 * (double)dis && (double)diffPrev > 0.0002 * (double)dis) flags[k] = 1;
+      }
     }
+    __syncthreads();
+    for (uint32_t k = tid; k < len; k += blockDim.x) flags0[k] = flags[k];
     if (tid < 64) { rcnt[tid][0] = 0; rcnt[tid][1] = 0; rcnt[tid][2] = 0; }
     if (tid == 0) {
       // Regions side by side need every region to hold at least curv_region points: a pick's marks then reach into the NEXT region at
@@ -343,7 +340,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu
       }
       if (lane == 0) { reg_n[wid] = n; reg_gsp[wid] = gsp; reg_scan[wid] = scan_sp; }
       for (uint32_t e = lane; e < n; e += 64) {
-        c[e] = curv[gsp + e];
+        c[e] = curv_all[scan_sp + e];
         label[e] = 0;   // SURFACE_LESS_FLAT
       }
       if (lane < 4 && n) c[n + lane] = __builtin_inff();   // padding for the 4-wide reads below (never counted)
@@ -404,7 +401,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu
             const bool hit = lane < cr && (uint32_t)lane < rn2 && fwd[rscan2 + lane] != 0 && rlabel[lane] != 0;
             if (__ballot(hit)) {   // one of its picks was not admissible: again, with the marks of the region before it in place
               for (uint32_t e = lane; e < rn2; e += 64) {
-                flags[rscan2 + e] = gflags[s0g + rscan2 + e] | (e < (uint32_t)cr ? fwd[rscan2 + e] : (uint8_t)0);
+                flags[rscan2 + e] = flags0[rscan2 + e] | (e < (uint32_t)cr ? fwd[rscan2 + e] : (uint8_t)0);
                 rlabel[e] = 0;
               }
               for (uint32_t e = lane; e < (uint32_t)cr; e += 64) fwd[rscan2 + rn2 + e] = 0;   // (its own marks beyond its end: made anew)
@@ -643,74 +640,56 @@ __global__ __launch_bounds__(LFV_THREADS) void k_feat_lf_voxel(const float4* __r
   if (tid == 0) cnt[r] = obase;
 }
 
-// lf_off = exclusive prefix of the per-ring voxel counts (one block)
-__global__ __launch_bounds__(1024) void k_feat_lf_prefix(const uint32_t* __restrict__ cnt, uint32_t nring, uint32_t* __restrict__ off) {
-  __shared__ uint32_t lds[17];
-  uint32_t carry = 0;
-  for (uint32_t b = 0; b < nring; b += 1024) {
-    const uint32_t i = b + threadIdx.x;
-    const uint32_t v = i < nring ? cnt[i] : 0u;
-    uint32_t total;
-    const uint32_t ex = block_excl_scan(v, lds, total);
-    if (i < nring) off[i] = carry + ex;
-    carry += total;
-  }
-  if (threadIdx.x == 0) off[nring] = carry;
+// ---- compaction of the per-ring slots into the output clouds, ONE launch per family (rounds 1-4: a prefix launch, a copy launch and a
+// per-sweep offset launch for the picks; a prefix and a copy launch for the less-flat voxels).  A workgroup finds its ring's place
+// itself: the sum of the counts of the rings before it (<= a few thousand words from L2, one wave-wide reduction) — no workgroup waits
+// for another.  The first ring of a sweep records the sweep's offsets, the last ring the totals.
+__device__ inline uint32_t rings_before(const uint32_t* __restrict__ c, uint32_t r, int lane) {
+  uint32_t part = 0u;
+  for (uint32_t i = (uint32_t)lane; i < r; i += 64u) part += c[i];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d, 64);
+  return part;
 }
-__global__ __launch_bounds__(256) void k_feat_lf_copy(const float4* __restrict__ slots, const uint32_t* __restrict__ ring_off,
-                                                      const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
-                                                      float4* __restrict__ out) {
-  const uint32_t r = blockIdx.x;
-  const uint32_t n = cnt[r], src = ring_off[r], dst = off[r];
-  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) out[dst + k] = slots[src + k];
-}
-
-// exclusive prefix of per-ring counts -> prefix[nring+1]; one block per kind
-__global__ __launch_bounds__(1024) void k_feat_prefix(const uint32_t* __restrict__ c0, const uint32_t* __restrict__ c1,
-                                                      const uint32_t* __restrict__ c2, uint32_t nring, uint32_t* __restrict__ p0,
-                                                      uint32_t* __restrict__ p1, uint32_t* __restrict__ p2) {
-  __shared__ uint32_t lds[17];
-  const uint32_t* cnt = blockIdx.x == 0 ? c0 : (blockIdx.x == 1 ? c1 : c2);
-  uint32_t* pre = blockIdx.x == 0 ? p0 : (blockIdx.x == 1 ? p1 : p2);
-  uint32_t carry = 0;
-  for (uint32_t b = 0; b < nring; b += 1024) {
-    const uint32_t i = b + threadIdx.x;
-    const uint32_t v = i < nring ? cnt[i] : 0u;
-    uint32_t total;
-    const uint32_t ex = block_excl_scan(v, lds, total);
-    if (i < nring) pre[i] = carry + ex;
-    carry += total;
-  }
-  if (threadIdx.x == 0) pre[nring] = carry;
-}
-
-// grid = (nring, 3): copy a ring's slots to its compact position
-__global__ __launch_bounds__(64) void k_feat_copy(const float4* __restrict__ s0, const float4* __restrict__ s1,
-                                                  const float4* __restrict__ s2, const uint32_t* __restrict__ c0,
-                                                  const uint32_t* __restrict__ c1, const uint32_t* __restrict__ c2,
-                                                  const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1,
-                                                  const uint32_t* __restrict__ p2, uint32_t cap0, uint32_t cap1, uint32_t cap2,
-                                                  float4* __restrict__ o0, float4* __restrict__ o1, float4* __restrict__ o2) {
-  const uint32_t r = blockIdx.x, kind = blockIdx.y;
+// grid = (nring, 3), 64 threads
+__global__ __launch_bounds__(64) void k_feat_compact(const float4* __restrict__ s0, const float4* __restrict__ s1, const float4* __restrict__ s2,
+                                                     const uint32_t* __restrict__ c0, const uint32_t* __restrict__ c1, const uint32_t* __restrict__ c2,
+                                                     uint32_t cap0, uint32_t cap1, uint32_t cap2, float4* __restrict__ o0, float4* __restrict__ o1,
+                                                     float4* __restrict__ o2, uint32_t* __restrict__ offs, const uint32_t* __restrict__ sweep_ring_base,
+                                                     uint32_t nsw) {
+  const uint32_t r = blockIdx.x, kind = blockIdx.y, nring = gridDim.x;
+  const int lane = (int)threadIdx.x;
   const float4* s = kind == 0 ? s0 : (kind == 1 ? s1 : s2);
   const uint32_t* c = kind == 0 ? c0 : (kind == 1 ? c1 : c2);
-  const uint32_t* p = kind == 0 ? p0 : (kind == 1 ? p1 : p2);
   const uint32_t cap = kind == 0 ? cap0 : (kind == 1 ? cap1 : cap2);
   float4* o = kind == 0 ? o0 : (kind == 1 ? o1 : o2);
-  const uint32_t n = c[r], dst = p[r];
-  for (uint32_t k = threadIdx.x; k < n; k += 64) o[dst + k] = s[(size_t)r * cap + k];
+  const uint32_t dst = rings_before(c, r, lane), n = c[r];
+  for (uint32_t k = (uint32_t)lane; k < n; k += 64u) o[dst + k] = s[(size_t)r * cap + k];
+  if (lane == 0) {
+    uint32_t* off = offs + (size_t)kind * (nsw + 1);
+    uint32_t lo = 0, hi = nsw + 1;   // first sweep whose first ring is >= r
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sweep_ring_base[mid] < r) lo = mid + 1; else hi = mid; }
+    for (uint32_t sw = lo; sw <= nsw && sweep_ring_base[sw] == r; sw++) off[sw] = dst;
+    if (r + 1 == nring)   // (sweeps that start behind the last ring — the entry [nsw] among them — hold the total)
+      for (uint32_t sw = nsw; sweep_ring_base[sw] >= nring; sw--) { off[sw] = dst + n; if (sw == 0) break; }
+  }
 }
-
-// per-sweep offsets: off[kind][s] = prefix[kind][ring_base[s]]
-__global__ void k_feat_sweep_off(const uint32_t* __restrict__ p0, const uint32_t* __restrict__ p1, const uint32_t* __restrict__ p2,
-                                 const uint32_t* __restrict__ sweep_ring_base, uint32_t nsw, uint32_t* __restrict__ o0,
-                                 uint32_t* __restrict__ o1, uint32_t* __restrict__ o2) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s > nsw) return;
-  const uint32_t rb = sweep_ring_base[s];
-  o0[s] = p0[rb];
-  o1[s] = p1[rb];
-  o2[s] = p2[rb];
+// grid = nring, 256 threads
+__global__ __launch_bounds__(256) void k_feat_lf_compact(const float4* __restrict__ slots, const uint32_t* __restrict__ ring_off,
+                                                         const uint32_t* __restrict__ cnt, uint32_t* __restrict__ lf_off, float4* __restrict__ out) {
+  __shared__ uint32_t s_dst;
+  const uint32_t r = blockIdx.x;
+  if (threadIdx.x < 64) {
+    const uint32_t d = rings_before(cnt, r, (int)threadIdx.x);
+    if (threadIdx.x == 0) {
+      s_dst = d;
+      lf_off[r] = d;
+      if (r + 1 == gridDim.x) lf_off[gridDim.x] = d + cnt[r];
+    }
+  }
+  __syncthreads();
+  const uint32_t n = cnt[r], src = ring_off[r], dst = s_dst;
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) out[dst + k] = slots[src + k];
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -725,6 +704,7 @@ FeatureExtractor::FeatureExtractor(int device, hipStream_t shared_stream) : devi
   vox_.init(st_);
   h_bad_.reserve(16);
   h_bad_.p[0] = 0u;
+  h_bad_.p[1] = 0u;
 }
 
 void FeatureExtractor::check_finite_input() {
@@ -821,24 +801,23 @@ void FeatureExtractor::layout_(uint32_t nsw, const uint32_t* const* ring_size, c
 void FeatureExtractor::allocate_(hipStream_t table_stream) {
   const uint32_t nsw = nsw_;
   cloud_.reserve(n_ + 1);
-  curv_.reserve(n_ + 1);
-  flags_.reserve(n_ + 1);
-  gap_.reserve(n_ + 1);
   lf_valid_.reserve(n_ + 1);
   lf_out_.reserve(n_ + 1);
   lf_slots_.reserve(n_ + 1);
-  lf_cnt_.reserve(nring_ + 2);
   ring_off_.reserve(nring_ + 2);
   ring_sweep_base_.reserve(nring_ + 2);
-  lf_off_.reserve(nring_ + 2);
   sweep_ring_base_.reserve(nsw + 2);
+  // the four offset tables lie back to back — [sharp | less sharp | flat][nsw + 1], then the less-flat cloud's per-ring offsets
+  // [nring + 1] — so that a consumer fetches them with ONE copy (Pipeline::launch_features)
+  offs_.reserve((size_t)3 * (nsw + 1) + nring_ + 2);
+  off_stride_ = nsw + 1;
+  lf_cnt_.reserve(nring_ + 2);
   const uint32_t caps[3] = {(uint32_t)(params.max_sharp * params.n_regions), (uint32_t)(params.max_less_sharp * params.n_regions),
                             (uint32_t)(params.max_flat * params.n_regions)};
   for (int k = 0; k < 3; k++) {
     slots_[k].reserve((size_t)nring_ * caps[k] + 1);
     out_[k].reserve((size_t)nring_ * caps[k] + 1);
-    slot_cnt_[k].reserve(2 * (size_t)nring_ + 4);   // counts [0,nring) + prefix [nring+1 .. 2nring+2)
-    out_off_[k].reserve(nsw + 2);
+    slot_cnt_[k].reserve((size_t)nring_ + 2);
   }
   if (max_ring_len_ > 4096) vox_.reserve(n_ + 1, nring_);
   // the three layout tables travel through pinned memory, so the copies never make the host wait for the stream
@@ -1034,34 +1013,25 @@ void FeatureExtractor::run_async() {
   LX_REQUIRE(nsw_ > 0, "run() before upload()");
   LX_HIP(hipSetDevice(device_));
   const int cr = params.curv_region;
-  LX_HIP(hipMemsetAsync(flags_.p, 0, n_ + 1, st_));
   LX_HIP(hipMemsetAsync(lf_valid_.p, 0, n_ + 1, st_));
-  if (n_ && max_ring_len_) {
-    hipLaunchKernelGGL(k_feat_point, dim3((max_ring_len_ + 255) / 256, nring_), dim3(256), 0, st_, cloud_.p, ring_off_.p, cr, curv_.p,
-                       flags_.p, gap_.p, h_bad_.p);
-  }
+  (void)cr;
   const uint32_t caps[3] = {(uint32_t)(params.max_sharp * params.n_regions), (uint32_t)(params.max_less_sharp * params.n_regions),
                             (uint32_t)(params.max_flat * params.n_regions)};
   const uint32_t flag_bytes = (max_ring_len_ + 15u) & ~15u;
   const uint32_t nmax = (max_ring_len_ / (uint32_t)params.n_regions + 8u + 15u) & ~15u;
   uint32_t sortP = 64;   // bitonic sort size of one region
   while (sortP < nmax) sortP <<= 1;
-  const size_t lds = ((3 * (size_t)flag_bytes + 4 * (size_t)(caps[0] + caps[1] + caps[2]) + 15) & ~(size_t)15) + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) +
+  const size_t lds = ((8 * (size_t)flag_bytes + 4 * (size_t)(caps[0] + caps[1] + caps[2]) + 15) & ~(size_t)15) + (size_t)FEAT_WAVES * nmax * (4 + 4 + 1) +
                      (sortP > 512 ? (size_t)FEAT_WAVES * sortP * 8 : 0) + 16;   // (regions of up to 512 points are sorted in registers)
   LX_REQUIRE(lds <= 160 * 1024, "scan ring too long for the LDS staging of k_feat_ring");
   static const bool force_seq = diag_env("LOAMX_FEAT_SEQUENTIAL") && atoi(diag_env("LOAMX_FEAT_SEQUENTIAL")) != 0;   // (diagnostic: the regions one after the other)
   if (lds > 64 * 1024)
     LX_HIP(hipFuncSetAttribute((const void*)k_feat_ring, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_feat_ring, dim3(nring_), dim3(64 * FEAT_WAVES), lds, st_, cloud_.p, ring_off_.p, ring_sweep_base_.p, params, curv_.p,
-                     flags_.p, gap_.p, flag_bytes, nmax, sortP, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p,
-                     lf_valid_.p, force_seq ? 1 : 0);
-  uint32_t* pre[3] = {slot_cnt_[0].p + nring_ + 1, slot_cnt_[1].p + nring_ + 1, slot_cnt_[2].p + nring_ + 1};
-  hipLaunchKernelGGL(k_feat_prefix, dim3(3), dim3(1024), 0, st_, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p, nring_, pre[0], pre[1],
-                     pre[2]);
-  hipLaunchKernelGGL(k_feat_copy, dim3(nring_, 3), dim3(64), 0, st_, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p,
-                     slot_cnt_[1].p, slot_cnt_[2].p, pre[0], pre[1], pre[2], caps[0], caps[1], caps[2], out_[0].p, out_[1].p, out_[2].p);
-  hipLaunchKernelGGL(k_feat_sweep_off, dim3((nsw_ + 64) / 64), dim3(64), 0, st_, pre[0], pre[1], pre[2], sweep_ring_base_.p, nsw_,
-                     out_off_[0].p, out_off_[1].p, out_off_[2].p);
+  hipLaunchKernelGGL(k_feat_ring, dim3(nring_), dim3(64 * FEAT_WAVES), lds, st_, cloud_.p, ring_off_.p, ring_sweep_base_.p, params, flag_bytes, nmax,
+                     sortP, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p, lf_valid_.p, force_seq ? 1 : 0,
+                     h_bad_.p);
+  hipLaunchKernelGGL(k_feat_compact, dim3(nring_, 3), dim3(64), 0, st_, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p, slot_cnt_[1].p,
+                     slot_cnt_[2].p, caps[0], caps[1], caps[2], out_[0].p, out_[1].p, out_[2].p, offs_.p, sweep_ring_base_.p, nsw_);
   // per-ring voxel grid of the less-flat candidates
   const float inv = 1.0f / params.less_flat_leaf;
   if (max_ring_len_ <= LFV_MAX) {
@@ -1071,11 +1041,10 @@ void FeatureExtractor::run_async() {
       LX_HIP(hipFuncSetAttribute((const void*)k_feat_lf_voxel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)P * 24)));
     hipLaunchKernelGGL(k_feat_lf_voxel, dim3(nring_), dim3(LFV_THREADS), (size_t)P * 24, st_, cloud_.p, ring_off_.p, lf_valid_.p, inv, P,
                        lf_slots_.p, lf_cnt_.p);
-    hipLaunchKernelGGL(k_feat_lf_prefix, dim3(1), dim3(1024), 0, st_, lf_cnt_.p, nring_, lf_off_.p);
-    hipLaunchKernelGGL(k_feat_lf_copy, dim3(nring_), dim3(256), 0, st_, lf_slots_.p, ring_off_.p, lf_cnt_.p, lf_off_.p, lf_out_.p);
+    hipLaunchKernelGGL(k_feat_lf_compact, dim3(nring_), dim3(256), 0, st_, lf_slots_.p, ring_off_.p, lf_cnt_.p, lf_off_(), lf_out_.p);
   } else {   // very long rings: generic segmented pipeline (global radix sort)
     vox_.compute_ijk(cloud_.p, lf_valid_.p, n_, ring_off_.p, nring_, inv, inv);
-    vox_.sort_reduce(cloud_.p, lf_valid_.p, n_, ring_off_.p, nring_, lf_out_.p, lf_off_.p);
+    vox_.sort_reduce(cloud_.p, lf_valid_.p, n_, ring_off_.p, nring_, lf_out_.p, lf_off_());
   }
 #ifdef LOAMX_PROF_FEAT
   {
@@ -1130,7 +1099,7 @@ int FeatureExtractor::download(uint32_t sweep, loamx_cloud* sharp, loamx_cloud* 
   const uint32_t capacity = 4 * n_pts;   // each of the four clouds is a subset of the sweep's points
   h_pack_.reserve((size_t)capacity + 2);
   hipLaunchKernelGGL(k_feat_pack_host, dim3(std::min<uint32_t>((capacity + 1023) / 1024 + 1, 128u)), dim3(256), 0, st_, out_[0].p, out_[1].p, out_[2].p,
-                     lf_out_.p, out_off_[0].p, out_off_[1].p, out_off_[2].p, lf_off_.p, sweep, h_ring_base_[sweep], h_ring_base_[sweep + 1], capacity,
+                     lf_out_.p, d_feat_off(0), d_feat_off(1), d_feat_off(2), lf_off_(), sweep, h_ring_base_[sweep], h_ring_base_[sweep + 1], capacity,
                      h_pack_.p);
   LX_HIP(hipStreamSynchronize(st_));
   vox_.check();

@@ -367,8 +367,10 @@ class Pipeline {
     for (auto& e : evF[t % OR]) if (!e) LX_HIP(hipEventCreate(&e));
     LX_HIP(hipEventRecord(evF[t % OR][0], fstream));
     F.run_async();
-    for (int k = 0; k < 3; k++) LX_HIP(hipMemcpyAsync(ho[k], F.d_feat_off(k), sizeof(uint32_t) * (ns + 1), hipMemcpyDeviceToHost, fstream));
-    LX_HIP(hipMemcpyAsync(hlf, F.d_less_flat_ring_off(), sizeof(uint32_t) * (nring + 1), hipMemcpyDeviceToHost, fstream));
+    // (the four offset tables lie back to back on the device in exactly this host layout: one copy)
+    (void)ho; (void)hlf;
+    LX_REQUIRE(F.n_offsets() == 3 * (ns + 1) + nring + 1, "internal: offset table layout");
+    LX_HIP(hipMemcpyAsync(hb.p, F.d_offsets(), sizeof(uint32_t) * F.n_offsets(), hipMemcpyDeviceToHost, fstream));
     LX_HIP(hipEventRecord(evF[t % OR][1], fstream));
     LA(t) = 1;
   }

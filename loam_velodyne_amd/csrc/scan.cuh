@@ -41,6 +41,50 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* lds /* >= 17 */
   return r;
 }
 
+// ---- decoupled look-back over a chain of workgroups (the chained scan's core; also how the feature extractor's per-ring outputs find
+// their place without prefix / copy launches).  w[b]: workgroup b's 64-bit word = epoch << 34 | flag << 32 | value — flag 1: value = its
+// own count, flag 2: value = the inclusive prefix up to and with it.  Called by the 64 lanes of ONE wave with uniform arguments:
+// publishes `own`, adds up the words of the workgroups before b (64 at a time; stops at the first inclusive prefix), publishes the
+// inclusive prefix and returns the exclusive one in every lane.  The words carry the launch's epoch (30 bits, never 0), so nothing is
+// cleared between launches; everything travels inside the words (relaxed agent-scope atomics, no cache-wide fence).  Workgroups must
+// start in index order; a predecessor that does not show up within ~1 s sets `failed` instead of hanging the device.
+__device__ inline unsigned long long cs_word(unsigned long long epoch, unsigned flag, uint32_t v) { return (epoch << 34) | ((unsigned long long)flag << 32) | v; }
+__device__ inline uint32_t chain_lookback(unsigned long long* __restrict__ w, unsigned long long epoch, uint32_t b, uint32_t own, bool& failed) {
+  const int lane = (int)(threadIdx.x & 63);
+  uint32_t excl = 0u;
+  if (b == 0) {
+    if (lane == 0) __hip_atomic_store(&w[0], cs_word(epoch, 2u, own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0u;
+  }
+  if (lane == 0) __hip_atomic_store(&w[b], cs_word(epoch, 1u, own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int hi = (int)b;   // workgroups [.., hi) are still to be accounted for
+  while (hi > 0 && !failed) {
+    const int j = hi - 1 - lane;   // lane 0 looks at the nearest predecessor
+    unsigned long long x = 0ull;
+    uint32_t spins = 0;
+    for (;;) {
+      x = j >= 0 ? __hip_atomic_load(&w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : cs_word(epoch, 2u, 0u);
+      const bool ok = (x >> 34) == epoch && ((x >> 32) & 3ull) != 0ull;
+      // usable: every lane up to the first inclusive prefix has a word of this epoch
+      const unsigned long long okm = __ballot(ok), incm = __ballot(ok && ((x >> 32) & 3ull) == 2ull);
+      const int first_inc = incm ? __builtin_ctzll(incm) : 64;
+      const unsigned long long need = first_inc >= 63 ? ~0ull : ((2ull << first_inc) - 1ull);
+      if ((okm & need) == need) {   // lanes 0 .. first_inc are all in: add them up
+        uint32_t part = (lane <= first_inc) ? (uint32_t)x : 0u;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d, 64);
+        excl += part;
+        hi = first_inc < 64 ? 0 : hi - 64;   // an inclusive prefix closes the chain
+        break;
+      }
+      if (++spins > (1u << 22)) { failed = true; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  if (lane == 0) __hip_atomic_store(&w[b], cs_word(epoch, 2u, excl + own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
+}
+
 // host launcher.  max_n bounds the launch; the real count is *d_n (<= max_n).  out needs max_n+1 entries and receives
 // out[n] = total; in may alias out.  tile_sums needs 8192 entries.
 void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, const uint32_t* d_n, uint32_t* d_total,

@@ -16,7 +16,6 @@ void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums /
 // state[0]: epoch of the last finished launch (bumped by the last tile to finish), state[1]: tiles finished, state[8 + b]: tile b's word
 //   word = epoch << 34 | flag << 32 | value;  flag 1: value = the tile's own sum, flag 2: value = inclusive prefix up to and with the tile
 constexpr int CS_HDR = 8;
-__device__ inline unsigned long long cs_word(unsigned long long epoch, unsigned flag, uint32_t v) { return (epoch << 34) | ((unsigned long long)flag << 32) | v; }
 
 __global__ __launch_bounds__(256) void k_scan_chained(const uint32_t* in, uint32_t* __restrict__ out, unsigned long long* __restrict__ state,
                                                       const uint32_t* __restrict__ d_n, uint32_t n_host, uint32_t* __restrict__ d_total,
@@ -59,42 +58,10 @@ __global__ __launch_bounds__(256) void k_scan_chained(const uint32_t* in, uint32
   const uint32_t off = block_excl_scan(s, lds, total);
   // ---- the chain: publish the sum, look back (the wave's 64 lanes poll 64 predecessors at a time), publish the inclusive prefix
   if (threadIdx.x < 64) {
-    unsigned long long* w = state + CS_HDR;
-    const int lane = (int)threadIdx.x;
-    uint32_t excl = 0u;
-    if (b == 0) {
-      if (lane == 0) __hip_atomic_store(&w[0], cs_word(epoch, 2u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      if (lane == 0) __hip_atomic_store(&w[b], cs_word(epoch, 1u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int hi = (int)b;   // tiles [.., hi) are still to be accounted for
-      bool failed = false;
-      while (hi > 0 && !failed) {
-        const int j = hi - 1 - lane;   // lane 0 looks at the nearest predecessor
-        unsigned long long x = 0ull;
-        uint32_t spins = 0;
-        for (;;) {
-          x = j >= 0 ? __hip_atomic_load(&w[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : cs_word(epoch, 2u, 0u);
-          const bool ok = (x >> 34) == epoch && ((x >> 32) & 3ull) != 0ull;
-          // usable: every lane up to the first inclusive prefix has a word of this epoch
-          const unsigned long long okm = __ballot(ok), incm = __ballot(ok && ((x >> 32) & 3ull) == 2ull);
-          const int first_inc = incm ? __builtin_ctzll(incm) : 64;
-          const unsigned long long need = first_inc >= 63 ? ~0ull : ((2ull << first_inc) - 1ull);
-          if ((okm & need) == need) {   // lanes 0 .. first_inc are all in: add them up
-            uint32_t part = (lane <= first_inc) ? (uint32_t)x : 0u;
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d, 64);
-            excl += part;
-            hi = first_inc < 64 ? 0 : hi - 64;   // an inclusive prefix closes the chain
-            break;
-          }
-          if (++spins > (1u << 22)) { failed = true; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      if (failed && lane == 0 && err_flag) *err_flag = 1u;
-      if (lane == 0) __hip_atomic_store(&w[b], cs_word(epoch, 2u, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (lane == 0) s_excl = excl;
+    bool failed = false;
+    const uint32_t excl = chain_lookback(state + CS_HDR, epoch, b, total, failed);
+    if (failed && threadIdx.x == 0 && err_flag) *err_flag = 1u;
+    if (threadIdx.x == 0) s_excl = excl;
   }
   __syncthreads();
   const uint32_t base = s_excl + off;

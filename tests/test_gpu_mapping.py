@@ -119,6 +119,47 @@ def test_per_step_parity_hdl64_full_size(orc):
     print(f"HDL-64E live map: worst pose difference {worst:.2e}, worst matched map-point distance {worst_map:.2e}")
 
 
+def test_per_step_parity_hdl32_500k_live_map(orc):
+    """BASELINE configs[2] exactly: HDL-32 sweeps (32 x 2048) against a LIVE map that starts at 500,000 points (the bench's own world,
+    bench.py --mode live --sensor HDL-32 --map-points 500000) — every process() from the oracle's state of the step before:
+    poses within 1e-4, iteration and sub-map counts equal, the updated cubes point for point (BasicLaserMapping.cpp:266-599, :626-926)."""
+    world = synth.World(half_extent=65.0)
+    cm, sm = world.make_map(500_000)
+    n = 5
+    poses = synth.trajectory(n)
+    osr, ood, omp = op.ScanRegistration(orc), op.LaserOdometry(orc), op.LaserMapping(orc)
+    omp.load_cubes(cm, sm)
+    worst, worst_map = 0.0, 0.0
+    for k in range(n):
+        sw = synth.make_sweep(world, "HDL-32", poses[k], poses[k + 1], seed=500 + k)
+        ood.set_features(osr.process(sw.points, sw.ring_sizes))
+        ood.process()
+        full_end, lc, ls, ts = ood.full_to_end(), ood.last_corner(), ood.last_surf(), ood.transform_sum
+        g = loamx.LaserMapping()
+        g.load_cubes(omp.cloud("corner_cubes"), omp.cloud("surf_cubes"))
+        g.set_transform("aft", omp.transform("aft"))
+        g.set_transform("bef", omp.transform("bef"))
+        g.update_odometry(ts)
+        omp.set_inputs(lc, ls, full_end, ts)
+        assert omp.process()
+        rc, gfull = g.process(lc, ls, full_end)
+        assert rc == loamx.OK
+        for which in ("aft", "bef", "tobe"):
+            d = float(np.abs(omp.transform(which) - g.transform(which)).max())
+            worst = max(worst, d)
+            assert d < POSE_TOL, (k, which, d)
+        so, sg = omp.stats(), g.stats()
+        assert so["iterations"] == sg["iterations"] and so["optimized"] == sg["optimized"]
+        assert so["corner_from_map"] == sg["corner_from_map"] and so["surf_from_map"] == sg["surf_from_map"]
+        assert so["corner_from_map"] + so["surf_from_map"] > 150_000          # (the sub-map is the 500 k map's part inside the field of view)
+        assert so["corner_ds"] == sg["corner_ds"] and so["surf_ds"] == sg["surf_ds"]
+        assert np.abs(omp.cloud("full_res") - gfull).max() < 5e-5
+        for name, which in (("corner_cubes", "corner"), ("surf_cubes", "surf")):
+            worst_map = max(worst_map, _assert_same_point_set(g.cubes(which), omp.cloud(name), (k, name), tol=3e-5, max_flips=8))
+        g.close()
+    print(f"HDL-32 / 500 k live map: worst pose difference {worst:.2e}, worst matched map-point distance {worst_map:.2e} over {n} steps")
+
+
 def test_golden_steps(orc):
     g = np.load(os.path.join(GOLDEN, "mapping_seq_vlp16.npz"))
     for t in (3, 4):

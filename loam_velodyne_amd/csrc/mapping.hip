@@ -60,23 +60,57 @@ __global__ __launch_bounds__(256) void k_map_classify(const uint32_t* __restrict
   seg[i] = s;
 }
 
-// order-preserving split: valid -> (sub_pts, sub_seg) ; rest -> (new_pts, new_tags)
+// order-preserving split: valid -> (sub_pts, sub_seg, sub_valid = 1) ; rest -> (new_pts, new_tags).  The sub-map lands where the
+// per-cube re-filtering of the map update reads it (its first n_sub slots: no copy between the two) and its points are folded into the
+// bounds of the sub-map's grid index as they are written (SubMapIndex::d_bounds: one launch less in the index build)
 __global__ __launch_bounds__(256) void k_map_partition(const float4* __restrict__ pts, const uint32_t* __restrict__ tags, uint32_t n,
                                                        const uint32_t* __restrict__ fv, const uint32_t* __restrict__ sv,
                                                        const uint32_t* __restrict__ fr, const uint32_t* __restrict__ sr,
                                                        const uint32_t* __restrict__ seg, float4* __restrict__ sub_pts,
-                                                       uint32_t* __restrict__ sub_seg, float4* __restrict__ new_pts,
-                                                       uint32_t* __restrict__ new_tags) {
+                                                       uint32_t* __restrict__ sub_seg, uint8_t* __restrict__ sub_valid, float4* __restrict__ new_pts,
+                                                       uint32_t* __restrict__ new_tags, uint32_t* __restrict__ bounds) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (fv[i]) {
-    const uint32_t d = sv[i];
-    sub_pts[d] = pts[i];
-    sub_seg[d] = seg[i];
-  } else if (fr[i]) {
-    const uint32_t d = sr[i];
-    new_pts[d] = pts[i];
-    new_tags[d] = tags[i];
+  bool in_sub = false;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n) {
+    if (fv[i]) {
+      const uint32_t d = sv[i];
+      p = pts[i];
+      in_sub = true;
+      sub_pts[d] = p;
+      sub_seg[d] = seg[i];
+      sub_valid[d] = 1;
+    } else if (fr[i]) {
+      const uint32_t d = sr[i];
+      new_pts[d] = pts[i];
+      new_tags[d] = tags[i];
+    }
+  }
+  // bounds of the sub-map: per wave (shuffles), per workgroup (LDS), one atomic per workgroup and word
+  float mn[3] = {in_sub ? p.x : FLT_MAX, in_sub ? p.y : FLT_MAX, in_sub ? p.z : FLT_MAX};
+  float mx[3] = {in_sub ? p.x : -FLT_MAX, in_sub ? p.y : -FLT_MAX, in_sub ? p.z : -FLT_MAX};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], d, 64));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, 64));
+    }
+  }
+  __shared__ float red[4][6];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) { red[wid][a] = mn[a]; red[wid][3 + a] = mx[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    float v = red[0][a];
+    for (int w = 1; w < 4; w++) v = a < 3 ? fminf(v, red[w][a]) : fmaxf(v, red[w][a]);
+    if (a < 3 ? v != FLT_MAX : v != -FLT_MAX) {
+      if (a < 3) atomicMin(&bounds[a], enc_f32(v)); else atomicMax(&bounds[a], enc_f32(v));
+    }
   }
 }
 
@@ -134,8 +168,9 @@ __global__ __launch_bounds__(256) void k_map_append_filtered(const float4* __res
                                                              uint32_t nslots, const uint32_t* __restrict__ slot_tag, uint32_t max_n,
                                                              const uint32_t* __restrict__ d_base0, const uint32_t* __restrict__ d_base1,
                                                              float4* __restrict__ new_pts, uint32_t* __restrict__ new_tags,
-                                                             uint32_t* __restrict__ d_total) {
+                                                             uint32_t* __restrict__ d_total, uint32_t* __restrict__ hist_to_clear) {
   const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t c = v; c < (uint32_t)MCUBES; c += gridDim.x * blockDim.x) hist_to_clear[c] = 0u;   // (k_map_hist runs next on this stream)
   const uint32_t nf = out_off[nslots];
   const uint32_t base = *d_base0 + *d_base1;
   if (v == 0) *d_total = base + nf;
@@ -191,10 +226,6 @@ __global__ __launch_bounds__(256) void k_map_compact(const float4* __restrict__ 
   const uint32_t b = dst_base + (d_dst_base ? *d_dst_base : 0u);
   out[b + scan[i]] = pts[i];
 }
-__global__ void k_map_valid_ones(uint8_t* v, uint32_t n) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) v[i] = 1;
-}
 __global__ void k_map_surround_valid(uint8_t* v, uint32_t max_n, const uint32_t* __restrict__ d_nc, const uint32_t* __restrict__ d_ns) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < max_n) v[i] = i < (*d_nc + *d_ns) ? 1 : 0;
@@ -208,14 +239,13 @@ struct TypeMap {   // one feature type (corner / surf)
   uint32_t n = 0;             // host copy of the point count (exact after every process())
   std::vector<uint32_t> cube_cnt = std::vector<uint32_t>(MCUBES, 0);   // host directory, window coordinates
   // per-sweep work buffers
-  DevBuf<uint32_t> fv, fr, sv, sr, seg, sub_seg, fin_seg, rest_flag, rest_scan, ins_tags, out_off, hist;
-  DevBuf<float4> sub, fin, ins, filt;
+  DevBuf<uint32_t> fv, fr, sv, sr, seg, fin_seg, rest_flag, rest_scan, ins_tags, out_off, hist;
+  DevBuf<float4> fin, ins, filt;   // fin: the per-cube re-filtering's input — the sub-map (written by the partition) followed by the sweep's new features
   DevBuf<uint8_t> fin_valid;
-  DevBuf<uint32_t> counters;   // [0..1] valid scan n/total, [2..3] rest scan n/total, [4..5] insert-rest scan, [6] new total
+  struct { uint32_t* p = nullptr; } counters;   // view into hist (behind the MCUBES bins): [0..1] valid scan n/total, [2..3] rest scan n/total, [4..5] insert-rest scan, [6] new total
   VoxelPipeline vox;
   DevBuf<uint32_t> tile_sums;
-  PinBuf<uint32_t> h_hist;
-  PinBuf<uint32_t> h_counters;
+  PinBuf<uint32_t> h_hist;     // the histogram and the counters behind it
 };
 
 class Mapper {
@@ -304,12 +334,11 @@ Mapper::Mapper(const loamx_map_config& c) : cfg(c), reg(c.device, 1) {
   LX_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
   for (int t = 0; t < 2; t++) {
     tm[t].vox.init(t == 0 ? st2 : reg.stream());
-    tm[t].counters.reserve(16);
+    tm[t].hist.reserve(MCUBES + 16);
+    tm[t].counters.p = tm[t].hist.p + MCUBES;   // (a view: the counters live behind the histogram so that both come down in one copy)
     tm[t].tile_sums.reserve(SCAN_SCRATCH_WORDS);
     LX_HIP(hipMemsetAsync(tm[t].tile_sums.p, 0, sizeof(uint32_t) * tm[t].tile_sums.cap, reg.stream()));
-    tm[t].hist.reserve(MCUBES);
-    tm[t].h_hist.reserve(MCUBES);
-    tm[t].h_counters.reserve(16);
+    tm[t].h_hist.reserve(MCUBES + 16);
     tm[t].out_off.reserve(130);
   }
   sur_vox.init(reg.stream());
@@ -344,7 +373,7 @@ void Mapper::ensure(TypeMap& t, uint32_t n_map_max, uint32_t n_in) {
     t.tags[b].reserve(n_map_max + 1, st, b == t.cur);
   }
   t.fv.reserve(n_map_max + 2); t.fr.reserve(n_map_max + 2); t.sv.reserve(n_map_max + 2); t.sr.reserve(n_map_max + 2);
-  t.seg.reserve(n_map_max + 1); t.sub.reserve(n_map_max + 1); t.sub_seg.reserve(n_map_max + 1);
+  t.seg.reserve(n_map_max + 1);
   t.fin.reserve(n_map_max + 1); t.fin_seg.reserve(n_map_max + 1); t.fin_valid.reserve(n_map_max + 1);
   t.filt.reserve(n_map_max + 1);
   t.rest_flag.reserve(n_in + 2); t.rest_scan.reserve(n_in + 2); t.ins.reserve(n_in + 1); t.ins_tags.reserve(n_in + 1);
@@ -457,13 +486,14 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
       exclusive_scan_u32_n(T.fv.p, T.sv.p, T.tile_sums.p, T.counters.p + 0, T.n, st);
       exclusive_scan_u32_n(T.fr.p, T.sr.p, T.tile_sums.p, T.counters.p + 2, T.n, st);
       hipLaunchKernelGGL(k_map_partition, dim3(nb), dim3(256), 0, st, T.pts[cur].p, T.tags[cur].p, T.n, T.fv.p, T.sv.p, T.fr.p, T.sr.p,
-                         T.seg.p, T.sub.p, T.sub_seg.p, T.pts[nxt].p, T.tags[nxt].p);
+                         T.seg.p, T.fin.p, T.fin_seg.p, T.fin_valid.p, T.pts[nxt].p, T.tags[nxt].p,
+                         (t == 0 ? reg.corner_index : reg.surf_index).d_bounds());
     } else {
       LX_HIP(hipMemsetAsync(T.counters.p, 0, sizeof(uint32_t) * 4, st));
     }
   }
   // ... and their grid indices (the corner sub-map's behind its partition on st2)
-  reg.set_submap_device_split(tm[0].sub.p, n_sub[0], st2, tm[1].sub.p, n_sub[1]);
+  reg.set_submap_device_split(tm[0].fin.p, n_sub[0], st2, tm[1].fin.p, n_sub[1], /*bounds_done=*/true);
   LX_HIP(hipEventRecord(ev_join, st2));
   LX_HIP(hipStreamWaitEvent(reg.stream(), ev_join, 0));
 
@@ -493,11 +523,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     hipStream_t st = t == 0 ? st2 : reg.stream();
     const int nxt = 1 - T.cur;
     const uint32_t n_old = n_sub[t], n_slots = n_in[t], n_fin = n_old + n_slots;
-    if (n_old) {
-      LX_HIP(hipMemcpyAsync(T.fin.p, T.sub.p, sizeof(float4) * n_old, hipMemcpyDeviceToDevice, st));
-      LX_HIP(hipMemcpyAsync(T.fin_seg.p, T.sub_seg.p, sizeof(uint32_t) * n_old, hipMemcpyDeviceToDevice, st));
-      hipLaunchKernelGGL(k_map_valid_ones, dim3((n_old + 255) / 256), dim3(256), 0, st, T.fin_valid.p, n_old);
-    }
+    // (the sub-map's points, cube slots and valid flags are in fin / fin_seg / fin_valid already: the partition wrote them there)
     if (n_slots) {
       const uint32_t nb = (n_slots + 255) / 256;
       hipLaunchKernelGGL(k_map_insert, dim3(nb), dim3(256), 0, st, reg.d_ds_points(), reg.d_ds_offsets(), t, n_slots, reg.d_poses(), w,
@@ -514,12 +540,10 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     T.vox.sort_reduce(T.fin.p, T.fin_valid.p, n_fin, nullptr, nslots, T.filt.p, T.out_off.p, T.fin_seg.p);
     const uint32_t max_f = n_fin ? n_fin : 1;
     hipLaunchKernelGGL(k_map_append_filtered, dim3((max_f + 255) / 256), dim3(256), 0, st, T.filt.p, T.out_off.p, nslots, slot_tag_v,
-                       max_f, T.counters.p + 3, T.counters.p + 5, T.pts[nxt].p, T.tags[nxt].p, T.counters.p + 6);
-    LX_HIP(hipMemsetAsync(T.hist.p, 0, sizeof(uint32_t) * MCUBES, st));
+                       max_f, T.counters.p + 3, T.counters.p + 5, T.pts[nxt].p, T.tags[nxt].p, T.counters.p + 6, T.hist.p);
     const uint32_t max_new = T.n + n_slots + 1;
     hipLaunchKernelGGL(k_map_hist, dim3(std::min<uint32_t>((max_new + 2047) / 2048, 256u)), dim3(256), 0, st, T.tags[nxt].p, T.counters.p + 6, max_new, w, T.hist.p);
-    LX_HIP(hipMemcpyAsync(T.h_hist.p, T.hist.p, sizeof(uint32_t) * MCUBES, hipMemcpyDeviceToHost, st));
-    LX_HIP(hipMemcpyAsync(T.h_counters.p, T.counters.p, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost, st));
+    LX_HIP(hipMemcpyAsync(T.h_hist.p, T.hist.p, sizeof(uint32_t) * (MCUBES + 16), hipMemcpyDeviceToHost, st));   // (histogram + the counters behind it: one copy)
   }
   LX_HIP(hipEventRecord(ev_join, st2));
   LX_HIP(hipStreamWaitEvent(reg.stream(), ev_join, 0));
@@ -533,9 +557,9 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   LX_HIP(hipGetLastError());
   for (int t = 0; t < 2; t++) {
     TypeMap& T = tm[t];
-    LX_REQUIRE(T.n == 0 || T.h_counters.p[1] == n_sub[t], "internal: sub-map size differs from the host cube directory");
+    LX_REQUIRE(T.n == 0 || T.h_hist.p[MCUBES + 1] == n_sub[t], "internal: sub-map size differs from the host cube directory");
     T.cur = 1 - T.cur;
-    T.n = T.h_counters.p[6];
+    T.n = T.h_hist.p[MCUBES + 6];
     for (int idx = 0; idx < MCUBES; idx++) T.cube_cnt[idx] = T.h_hist.p[idx];
   }
   SweepStats ss;

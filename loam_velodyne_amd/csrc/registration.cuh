@@ -25,7 +25,10 @@ class SubMapIndex {
  public:
   void init(hipStream_t st);
   // (re)build over n device points (packed float4; .w ignored).  Asynchronous on the stream.
-  void build(const float4* d_pts, uint32_t n);
+  // bounds_done: the kernel that produced d_pts has folded every point into d_bounds() as it wrote it (enc_f32 atomicMin / atomicMax on
+  // words 0-2 / 3-5; the accumulators are left reset by every build) — the bounding-box launch is skipped
+  void build(const float4* d_pts, uint32_t n, bool bounds_done = false);
+  uint32_t* d_bounds() const { return scratch_.p; }
   // exchange contents with another index (buffers, sizes and the streams they are bound to stay with the contents' owner)
   void swap(SubMapIndex& o);
   void bind(hipStream_t st) { st_ = st; }
@@ -38,7 +41,7 @@ class SubMapIndex {
   hipStream_t st_ = nullptr;
   uint32_t n_ = 0;
   DevBuf<float4> sorted_;
-  DevBuf<uint32_t> cell_of_, cell_start_, cursor_, tile_sums_, scratch_;   // scratch_: bbox enc[6], ncell+1, total
+  DevBuf<uint32_t> cell_of_, rank_of_, cell_start_, cursor_, tile_sums_, scratch_;   // scratch_: bbox enc[6], ncell+1, total; cursor_: the cell counters (empty between builds)
   DevBuf<GridDesc> d_desc_;
 };
 
@@ -226,7 +229,7 @@ class Registrar {
   void download_stats(SweepStats* out);
   int download_full_res(uint32_t sweep, loamx_cloud* out);
   void download_full_res_async(uint32_t sweep);
-  void set_submap_device_split(const float4* d_corner, uint32_t nc, hipStream_t corner_stream, const float4* d_surf, uint32_t ns);
+  void set_submap_device_split(const float4* d_corner, uint32_t nc, hipStream_t corner_stream, const float4* d_surf, uint32_t ns, bool bounds_done = false);
   // down-sampled query clouds of a sweep (device pointers valid until the next run); counts need a sync'd download
   void download_ds(uint32_t sweep, std::vector<float4>& corner_ds, std::vector<float4>& surf_ds);
   // registered (final-pose) DS clouds, for map insertion: device array + offsets

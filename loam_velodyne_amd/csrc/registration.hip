@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void k_bbox(const float4* __restrict__ pts, ui
   }
 }
 
-__global__ void k_grid_setup(uint32_t* __restrict__ scratch, GridDesc* __restrict__ desc, uint32_t max_cells) {
+// grid descriptor from the bounds (k_bbox, or the producer of the points through SubMapIndex::d_bounds()): the cell edge starts at
+// 1.05 m and grows by 1.25x while the table would not fit (a coarser grid is still exact: the 27-cell neighbourhood only grows)
+__device__ inline GridDesc grid_from_bounds(const uint32_t* __restrict__ scratch, uint32_t max_cells) {
   float mn[3], mx[3];
   for (int a = 0; a < 3; a++) { mn[a] = dec_f32(scratch[a]); mx[a] = dec_f32(scratch[3 + a]); }
   float h = 1.05f;
@@ -82,42 +84,65 @@ __global__ void k_grid_setup(uint32_t* __restrict__ scratch, GridDesc* __restric
     g.nz = (int)floorf((mx[2] - mn[2]) * g.inv_h) + 1;
     unsigned long long nc = (unsigned long long)g.nx * g.ny * g.nz;
     if (nc <= max_cells) { g.ncell = (uint32_t)nc; break; }
-    h *= 1.25f;   // a coarser grid is still exact (the 27-cell neighbourhood only grows)
+    h *= 1.25f;
   }
-  *desc = g;
-  scratch[6] = g.ncell + 1;
-  scratch[8] = g.ncell;
+  return g;
 }
 
-
-__global__ __launch_bounds__(256) void k_cell_count(const float4* __restrict__ pts, uint32_t n, const GridDesc* __restrict__ desc,
-                                                    uint32_t* __restrict__ cell_of, uint32_t* __restrict__ counts) {
-  const GridDesc g = *desc;
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float4 p = pts[i];
-  int cx, cy, cz;
-  cell_coords(g, p.x, p.y, p.z, cx, cy, cz);
-  uint32_t c = ((uint32_t)cz * g.ny + cy) * g.nx + cx;
-  cell_of[i] = c;
-  atomicAdd(&counts[c], 1u);
+// count: every workgroup derives the descriptor itself (the same arithmetic everywhere; workgroup 0 records it and the scan's count);
+// a point's rank inside its cell is the counter's value before its run's bump, so the scatter needs no atomics and the counters can
+// be cleared behind the scan (rounds 1-4: k_init_bbox, k_grid_setup and k_zero_u32_dn were three launches of their own)
+__global__ __launch_bounds__(256) void k_cell_count(const float4* __restrict__ pts, uint32_t n, uint32_t* __restrict__ scratch, GridDesc* __restrict__ desc,
+                                                    uint32_t max_cells, uint32_t* __restrict__ cell_of, uint32_t* __restrict__ counts,
+                                                    uint32_t* __restrict__ rank_of) {
+  __shared__ GridDesc s_g;
+  if (threadIdx.x == 0) {
+    s_g = grid_from_bounds(scratch, max_cells);
+    if (blockIdx.x == 0) {
+      *desc = s_g;
+      scratch[6] = s_g.ncell + 1;
+      scratch[8] = s_g.ncell;
+    }
+  }
+  __syncthreads();
+  const GridDesc g = s_g;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < n;
+  uint32_t c = 0;
+  if (active) {
+    const float4 p = pts[i];
+    int cx, cy, cz;
+    cell_coords(g, p.x, p.y, p.z, cx, cy, cz);
+    c = ((uint32_t)cz * g.ny + cy) * g.nx + cx;
+    cell_of[i] = c;
+  }
+  int head, len;
+  wave_runs(c, active, head, len);
+  uint32_t base = 0;
+  if (active && head == (int)__lane_id()) base = atomicAdd(&counts[c], (uint32_t)len);
+  base = __shfl(base, head, 64);
+  if (active) rank_of[i] = base + (uint32_t)((int)__lane_id() - head);
 }
 
-
-__global__ __launch_bounds__(256) void k_cell_scatter(const float4* __restrict__ pts, uint32_t n,
-                                                      const uint32_t* __restrict__ cell_of, uint32_t* __restrict__ cursor,
-                                                      float4* __restrict__ sorted) {
+// scatter; its first thread leaves the bounds accumulators reset for the next build
+__global__ __launch_bounds__(256) void k_cell_scatter(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ cell_of,
+                                                      const uint32_t* __restrict__ rank_of, const uint32_t* __restrict__ cell_start,
+                                                      float4* __restrict__ sorted, uint32_t* __restrict__ scratch) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) {
+#pragma unroll
+    for (int a = 0; a < 6; a++) scratch[a] = a < 3 ? 0xffffffffu : 0u;
+  }
   if (i >= n) return;
   float4 p = pts[i];
-  uint32_t pos = atomicAdd(&cursor[cell_of[i]], 1u);
   p.w = __uint_as_float(i);   // original index: kNN ties are broken on it, so the slot order inside a cell is irrelevant
-  sorted[pos] = p;
+  sorted[cell_start[cell_of[i]] + rank_of[i]] = p;
 }
 
 void SubMapIndex::init(hipStream_t st) {
   st_ = st;
   scratch_.reserve(16);
+  hipLaunchKernelGGL(k_init_bbox, dim3(1), dim3(16), 0, st, scratch_.p);   // (once: every build's scatter leaves the bounds reset)
   d_desc_.reserve(1);
   tile_sums_.reserve(SCAN_SCRATCH_WORDS);
   LX_HIP(hipMemsetAsync(tile_sums_.p, 0, sizeof(uint32_t) * tile_sums_.cap, st));
@@ -126,25 +151,28 @@ void SubMapIndex::init(hipStream_t st) {
 void SubMapIndex::swap(SubMapIndex& o) {
   std::swap(n_, o.n_);
   auto sw = [](auto& a, auto& b) { std::swap(a.p, b.p); std::swap(a.cap, b.cap); };
-  sw(sorted_, o.sorted_); sw(cell_of_, o.cell_of_); sw(cell_start_, o.cell_start_); sw(cursor_, o.cursor_);
+  sw(sorted_, o.sorted_); sw(cell_of_, o.cell_of_); sw(rank_of_, o.rank_of_); sw(cell_start_, o.cell_start_); sw(cursor_, o.cursor_);
   sw(tile_sums_, o.tile_sums_); sw(scratch_, o.scratch_); sw(d_desc_, o.d_desc_);
 }
 
-void SubMapIndex::build(const float4* d_pts, uint32_t n) {
+void SubMapIndex::build(const float4* d_pts, uint32_t n, bool bounds_done) {
   n_ = n;
   if (n == 0) return;
   sorted_.reserve(n);
   cell_of_.reserve(n);
+  rank_of_.reserve(n);
   cell_start_.reserve((size_t)LX_MAX_CELLS + 2);
-  cursor_.reserve((size_t)LX_MAX_CELLS + 2);
-  hipLaunchKernelGGL(k_init_bbox, dim3(1), dim3(16), 0, st_, scratch_.p);
+  if (!cursor_.p) {   // the cell counters: cleared once, kept clear by every build (the scan clears them behind itself)
+    cursor_.reserve((size_t)LX_MAX_CELLS + 2);
+    LX_HIP(hipMemsetAsync(cursor_.p, 0, sizeof(uint32_t) * cursor_.cap, st_));
+  }
   const uint32_t nb = (n + 255) / 256;
-  hipLaunchKernelGGL(k_bbox, dim3(nb < 128 ? nb : 128), dim3(256), 0, st_, d_pts, n, scratch_.p);
-  hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(1), 0, st_, scratch_.p, d_desc_.p, LX_MAX_CELLS);
-  hipLaunchKernelGGL(k_zero_u32_dn, dim3(2048), dim3(256), 0, st_, cursor_.p, scratch_.p + 6);
-  hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st_, d_pts, n, d_desc_.p, cell_of_.p, cursor_.p);
-  exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 8, scratch_.p + 7, LX_MAX_CELLS, st_, cursor_.p);
-  hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(256), 0, st_, d_pts, n, cell_of_.p, cursor_.p, sorted_.p);
+  // bounds (unless the kernel that produced the points folded them into d_bounds() as it wrote them) -> count (+ grid set-up) -> scan
+  // (+ counters cleared) -> scatter (+ bounds reset): 3 - 4 launches (rounds 1-4: 7)
+  if (!bounds_done) hipLaunchKernelGGL(k_bbox, dim3(nb < 128 ? nb : 128), dim3(256), 0, st_, d_pts, n, scratch_.p);
+  hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, st_, d_pts, n, scratch_.p, d_desc_.p, LX_MAX_CELLS, cell_of_.p, cursor_.p, rank_of_.p);
+  exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 8, scratch_.p + 7, LX_MAX_CELLS, st_, nullptr, cursor_.p);
+  hipLaunchKernelGGL(k_cell_scatter, dim3(nb), dim3(256), 0, st_, d_pts, n, cell_of_.p, rank_of_.p, cell_start_.p, sorted_.p, scratch_.p);
   LX_HIP(hipGetLastError());
 }
 
@@ -1017,12 +1045,12 @@ void Registrar::set_submap_device(const float4* d_corner, uint32_t nc, const flo
 
 // the two indices built side by side: the corner index on a stream of the caller's (ordered by the caller: the registration's stream
 // has to wait for what this enqueues there before run_async()), the surf index on the registration's stream
-void Registrar::set_submap_device_split(const float4* d_corner, uint32_t nc, hipStream_t corner_stream, const float4* d_surf, uint32_t ns) {
+void Registrar::set_submap_device_split(const float4* d_corner, uint32_t nc, hipStream_t corner_stream, const float4* d_surf, uint32_t ns, bool bounds_done) {
   LX_HIP(hipSetDevice(device_));
   corner_index.bind(corner_stream);
-  corner_index.build(d_corner, nc);
+  corner_index.build(d_corner, nc, bounds_done);
   corner_index.bind(st_);
-  surf_index.build(d_surf, ns);
+  surf_index.build(d_surf, ns, bounds_done);
 }
 
 void Registrar::stage_submap_device(const float4* d_corner, uint32_t nc, const float4* d_surf, uint32_t ns, hipEvent_t wait_for) {

@@ -41,54 +41,72 @@ struct MapWindow {
   int cen[3];
 };
 
-// cls: 0 dropped (outside the window), 1 rest, 2 valid (slot in seg)
-__global__ __launch_bounds__(256) void k_map_classify(const uint32_t* __restrict__ tags, uint32_t n, MapWindow w,
-                                                      const short* __restrict__ slot_lut, uint32_t* __restrict__ fv,
-                                                      uint32_t* __restrict__ fr, uint32_t* __restrict__ seg) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  int ia, ja, ka;
-  unpack_tag(tags[i], ia, ja, ka);
-  const int I = ia + w.cen[0], J = ja + w.cen[1], K = ka + w.cen[2];
-  uint32_t v = 0, r = 0, s = 0;
-  if (I >= 0 && I < MW && J >= 0 && J < MH && K >= 0 && K < MD) {
-    const int slot = slot_lut[I + MW * J + MW * MH * K];
-    if (slot >= 0) { v = 1; s = (uint32_t)slot; } else r = 1;
+// ---- the map's split of one sweep (:300-509 without the pointer grid): every map point is valid (its cube is in the field of view:
+// it joins the sub-map), rest (inside the window, not visible) or dropped (its cube left the window).  ONE launch (rounds 1-4:
+// classify, two device-wide scans, partition): a workgroup classifies its tile of 2048 points, scans the two flags inside the tile,
+// finds the tile's two offsets by a decoupled look-back over the tiles before it (scan.cuh: chain_lookback) and moves its points —
+// order preserved in both outputs.  valid -> (sub_pts, sub_seg, sub_valid = 1): where the per-cube re-filtering of the map update reads
+// the sub-map (its first n_sub slots), folded into the bounds of the sub-map's grid index on the way (SubMapIndex::d_bounds);
+// rest -> (new_pts, new_tags).  The last tile records the totals: counters[1] = valid, counters[3] = rest.
+constexpr int MS_TILE = 2048;
+__global__ __launch_bounds__(256) void k_map_split(const float4* __restrict__ pts, const uint32_t* __restrict__ tags, uint32_t n, MapWindow w,
+                                                   const short* __restrict__ slot_lut, float4* __restrict__ sub_pts, uint32_t* __restrict__ sub_seg,
+                                                   uint8_t* __restrict__ sub_valid, float4* __restrict__ new_pts, uint32_t* __restrict__ new_tags,
+                                                   uint32_t* __restrict__ bounds, unsigned long long* __restrict__ chain_v,
+                                                   unsigned long long* __restrict__ chain_r, unsigned long long epoch, uint32_t* __restrict__ counters,
+                                                   uint32_t* __restrict__ err_word) {
+  __shared__ uint32_t lds[17];
+  __shared__ uint32_t s_base[2];
+  __shared__ float red[4][6];
+  const uint32_t b = blockIdx.x, i0 = b * MS_TILE + threadIdx.x * 8u;
+  uint32_t cls[8], slot[8], tg[8];   // cls: 0 dropped, 1 rest, 2 valid
+  uint32_t nv = 0, nr = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t i = i0 + k;
+    cls[k] = 0; slot[k] = 0; tg[k] = 0;
+    if (i < n) {
+      tg[k] = tags[i];
+      int ia, ja, ka;
+      unpack_tag(tg[k], ia, ja, ka);
+      const int I = ia + w.cen[0], J = ja + w.cen[1], K = ka + w.cen[2];
+      if (I >= 0 && I < MW && J >= 0 && J < MH && K >= 0 && K < MD) {
+        const int sl = slot_lut[I + MW * J + MW * MH * K];
+        if (sl >= 0) { cls[k] = 2; slot[k] = (uint32_t)sl; nv++; } else { cls[k] = 1; nr++; }
+      }
+    }
   }
-  fv[i] = v;
-  fr[i] = r;
-  seg[i] = s;
-}
-
-// order-preserving split: valid -> (sub_pts, sub_seg, sub_valid = 1) ; rest -> (new_pts, new_tags).  The sub-map lands where the
-// per-cube re-filtering of the map update reads it (its first n_sub slots: no copy between the two) and its points are folded into the
-// bounds of the sub-map's grid index as they are written (SubMapIndex::d_bounds: one launch less in the index build)
-__global__ __launch_bounds__(256) void k_map_partition(const float4* __restrict__ pts, const uint32_t* __restrict__ tags, uint32_t n,
-                                                       const uint32_t* __restrict__ fv, const uint32_t* __restrict__ sv,
-                                                       const uint32_t* __restrict__ fr, const uint32_t* __restrict__ sr,
-                                                       const uint32_t* __restrict__ seg, float4* __restrict__ sub_pts,
-                                                       uint32_t* __restrict__ sub_seg, uint8_t* __restrict__ sub_valid, float4* __restrict__ new_pts,
-                                                       uint32_t* __restrict__ new_tags, uint32_t* __restrict__ bounds) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool in_sub = false;
-  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i < n) {
-    if (fv[i]) {
-      const uint32_t d = sv[i];
-      p = pts[i];
-      in_sub = true;
-      sub_pts[d] = p;
-      sub_seg[d] = seg[i];
-      sub_valid[d] = 1;
-    } else if (fr[i]) {
-      const uint32_t d = sr[i];
-      new_pts[d] = pts[i];
-      new_tags[d] = tags[i];
+  uint32_t tv, tr;
+  const uint32_t ov = block_excl_scan(nv, lds, tv);
+  const uint32_t orr = block_excl_scan(nr, lds, tr);
+  if (threadIdx.x < 64) {
+    bool failed = false;
+    const uint32_t ev = chain_lookback(chain_v, epoch, b, tv, failed);
+    const uint32_t er = chain_lookback(chain_r, epoch, b, tr, failed);
+    if (threadIdx.x == 0) {
+      s_base[0] = ev; s_base[1] = er;
+      if (b + 1 == gridDim.x) { counters[0] = n; counters[1] = ev + tv; counters[2] = n; counters[3] = er + tr; }
+      if (failed && err_word) __hip_atomic_store(err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  uint32_t dv = s_base[0] + ov, dr = s_base[1] + orr;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (cls[k] == 2) {
+      const float4 p = pts[i0 + k];
+      sub_pts[dv] = p; sub_seg[dv] = slot[k]; sub_valid[dv] = 1;
+      dv++;
+      mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+      mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+      mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+    } else if (cls[k] == 1) {
+      new_pts[dr] = pts[i0 + k]; new_tags[dr] = tg[k];
+      dr++;
     }
   }
   // bounds of the sub-map: per wave (shuffles), per workgroup (LDS), one atomic per workgroup and word
-  float mn[3] = {in_sub ? p.x : FLT_MAX, in_sub ? p.y : FLT_MAX, in_sub ? p.z : FLT_MAX};
-  float mx[3] = {in_sub ? p.x : -FLT_MAX, in_sub ? p.y : -FLT_MAX, in_sub ? p.z : -FLT_MAX};
 #pragma unroll
   for (int a = 0; a < 3; a++) {
 #pragma unroll
@@ -97,7 +115,6 @@ __global__ __launch_bounds__(256) void k_map_partition(const float4* __restrict_
       mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, 64));
     }
   }
-  __shared__ float red[4][6];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (lane == 0) {
 #pragma unroll
@@ -107,30 +124,35 @@ __global__ __launch_bounds__(256) void k_map_partition(const float4* __restrict_
   if (threadIdx.x < 6) {
     const int a = threadIdx.x;
     float v = red[0][a];
-    for (int w = 1; w < 4; w++) v = a < 3 ? fminf(v, red[w][a]) : fmaxf(v, red[w][a]);
+    for (int q = 1; q < 4; q++) v = a < 3 ? fminf(v, red[q][a]) : fmaxf(v, red[q][a]);
     if (a < 3 ? v != FLT_MAX : v != -FLT_MAX) {
       if (a < 3) atomicMin(&bounds[a], enc_f32(v)); else atomicMax(&bounds[a], enc_f32(v));
     }
   }
 }
 
-// re-project the down-sampled features of one type with the final pose and bucket them (:536-577).
-// Filter-input slot (n_old + j) receives feature j when its cube is valid; features in other in-window cubes are
-// flagged for the rest list; the remainder (outside the window) is dropped as in the reference.
+// re-project the down-sampled features of one type with the final pose and bucket them (:536-577), ONE launch (rounds 1-4: insert,
+// a device-wide scan, append).  Filter-input slot (n_old + j) receives feature j when its cube is valid; features in other in-window
+// cubes go behind the rest points carried over by the split (*d_base = counters[3]), in feature order — their place by a scan inside
+// the tile and a look-back over the tiles before it; the remainder (outside the window) is dropped as in the reference.
+// The last tile records how many were appended (counters[5]).
 __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ ds_pts, const uint32_t* __restrict__ ds_off, int type,
                                                     uint32_t n_slots, const Pose* __restrict__ pose, MapWindow w,
                                                     const short* __restrict__ slot_lut, uint32_t n_old, float4* __restrict__ fin_pts,
                                                     uint32_t* __restrict__ fin_seg, uint8_t* __restrict__ fin_valid,
-                                                    uint32_t* __restrict__ rest_flag, float4* __restrict__ ins_pts,
-                                                    uint32_t* __restrict__ ins_tags) {
+                                                    const uint32_t* __restrict__ d_base, float4* __restrict__ new_pts, uint32_t* __restrict__ new_tags,
+                                                    unsigned long long* __restrict__ chain, unsigned long long epoch, uint32_t* __restrict__ counters,
+                                                    uint32_t* __restrict__ err_word) {
+  __shared__ uint32_t lds[17];
+  __shared__ uint32_t s_base;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_slots) return;
   const uint32_t a = ds_off[type], b = ds_off[type + 1];
   uint8_t valid = 0;
-  uint32_t rest = 0;
-  if (j < b - a) {
+  uint32_t rest = 0, tag = 0;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (j < n_slots && j < b - a) {
     const Pose T = *pose;
-    float4 p = ds_pts[a + j];
+    p = ds_pts[a + j];
     to_map(T, p.x, p.y, p.z);
     const int ia = cube_abs(p.x), ja = cube_abs(p.y), ka = cube_abs(p.z);
     const int I = ia + w.cen[0], J = ja + w.cen[1], K = ka + w.cen[2];
@@ -142,25 +164,28 @@ __global__ __launch_bounds__(256) void k_map_insert(const float4* __restrict__ d
         fin_seg[n_old + j] = (uint32_t)slot;
       } else {
         rest = 1;
-        ins_pts[j] = p;
-        ins_tags[j] = pack_tag(ia, ja, ka);
+        tag = pack_tag(ia, ja, ka);
       }
     }
   }
-  fin_valid[n_old + j] = valid;
-  rest_flag[j] = rest;
-}
-
-// cnt[0] = number of rest points carried over (from the partition scan); appends flagged insertions after them
-__global__ __launch_bounds__(256) void k_map_append_rest(const float4* __restrict__ ins_pts, const uint32_t* __restrict__ ins_tags,
-                                                         const uint32_t* __restrict__ flag, const uint32_t* __restrict__ scan,
-                                                         uint32_t n, const uint32_t* __restrict__ d_base, float4* __restrict__ new_pts,
-                                                         uint32_t* __restrict__ new_tags) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n || !flag[j]) return;
-  const uint32_t d = *d_base + scan[j];
-  new_pts[d] = ins_pts[j];
-  new_tags[d] = ins_tags[j];
+  if (j < n_slots) fin_valid[n_old + j] = valid;
+  uint32_t total;
+  const uint32_t off = block_excl_scan(rest, lds, total);
+  if (threadIdx.x < 64) {
+    bool failed = false;
+    const uint32_t ex = chain_lookback(chain, epoch, blockIdx.x, total, failed);
+    if (threadIdx.x == 0) {
+      s_base = ex;
+      if (blockIdx.x + 1 == gridDim.x) { counters[4] = n_slots; counters[5] = ex + total; }
+      if (failed && err_word) __hip_atomic_store(err_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  if (rest) {
+    const uint32_t d = *d_base + s_base + off;
+    new_pts[d] = p;
+    new_tags[d] = tag;
+  }
 }
 
 // filtered voxels (segment-ordered) go behind rest + inserted; base = d_base0 + d_base1
@@ -239,13 +264,16 @@ struct TypeMap {   // one feature type (corner / surf)
   uint32_t n = 0;             // host copy of the point count (exact after every process())
   std::vector<uint32_t> cube_cnt = std::vector<uint32_t>(MCUBES, 0);   // host directory, window coordinates
   // per-sweep work buffers
-  DevBuf<uint32_t> fv, fr, sv, sr, seg, fin_seg, rest_flag, rest_scan, ins_tags, out_off, hist;
-  DevBuf<float4> fin, ins, filt;   // fin: the per-cube re-filtering's input — the sub-map (written by the partition) followed by the sweep's new features
+  DevBuf<uint32_t> fin_seg, out_off, hist;
+  DevBuf<float4> fin, filt;   // fin: the per-cube re-filtering's input — the sub-map (written by the partition) followed by the sweep's new features
   DevBuf<uint8_t> fin_valid;
   struct { uint32_t* p = nullptr; } counters;   // view into hist (behind the MCUBES bins): [0..1] valid scan n/total, [2..3] rest scan n/total, [4..5] insert-rest scan, [6] new total
   VoxelPipeline vox;
-  DevBuf<uint32_t> tile_sums;
   PinBuf<uint32_t> h_hist;     // the histogram and the counters behind it
+  // look-back words of the fused kernels' chains (k_map_split: valid, rest; k_map_insert: rest), tagged with a per-launch epoch
+  DevBuf<unsigned long long> chain;
+  size_t chain_stride = 0;
+  uint32_t chain_epoch = 0;
 };
 
 class Mapper {
@@ -296,6 +324,7 @@ class Mapper {
   DevBuf<uint8_t> sur_valid;
   VoxelPipeline sur_vox;
   uint32_t n_surround = 0;
+  PinBuf<uint32_t> h_err;                            // raised by a fused kernel whose look-back gave up (checked behind process()'s synchronisation)
   hipStream_t st2 = nullptr;                        // the corner map's update (the surf map's runs on the registration's stream)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   ~Mapper() {
@@ -329,6 +358,8 @@ Mapper::Mapper(const loamx_map_config& c) : cfg(c), reg(c.device, 1) {
   reg.params.surf_leaf = c.surf_filter_size;
   // the two feature types' map updates are independent: the corner map's runs on a stream of its own next to the surf map's
   // (process(): forked behind the registration, joined before the results are read)
+  h_err.reserve(16);
+  *h_err.p = 0u;
   st2 = create_stream(0);
   LX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
   LX_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
@@ -336,8 +367,6 @@ Mapper::Mapper(const loamx_map_config& c) : cfg(c), reg(c.device, 1) {
     tm[t].vox.init(t == 0 ? st2 : reg.stream());
     tm[t].hist.reserve(MCUBES + 16);
     tm[t].counters.p = tm[t].hist.p + MCUBES;   // (a view: the counters live behind the histogram so that both come down in one copy)
-    tm[t].tile_sums.reserve(SCAN_SCRATCH_WORDS);
-    LX_HIP(hipMemsetAsync(tm[t].tile_sums.p, 0, sizeof(uint32_t) * tm[t].tile_sums.cap, reg.stream()));
     tm[t].h_hist.reserve(MCUBES + 16);
     tm[t].out_off.reserve(130);
   }
@@ -372,11 +401,17 @@ void Mapper::ensure(TypeMap& t, uint32_t n_map_max, uint32_t n_in) {
     t.pts[b].reserve(n_map_max + 1, st, b == t.cur);
     t.tags[b].reserve(n_map_max + 1, st, b == t.cur);
   }
-  t.fv.reserve(n_map_max + 2); t.fr.reserve(n_map_max + 2); t.sv.reserve(n_map_max + 2); t.sr.reserve(n_map_max + 2);
-  t.seg.reserve(n_map_max + 1);
+  {   // chains of the fused split / insert kernels: one word per tile, cleared when the buffer (re)appears
+    const size_t need = std::max<size_t>(n_map_max / MS_TILE, n_in / 256) + 4;
+    if (need > t.chain_stride) {
+      t.chain_stride = need + need / 2;
+      t.chain.reserve(3 * t.chain_stride);
+      LX_HIP(hipMemsetAsync(t.chain.p, 0, sizeof(unsigned long long) * t.chain.cap, st));
+      t.chain_epoch = 0;
+    }
+  }
   t.fin.reserve(n_map_max + 1); t.fin_seg.reserve(n_map_max + 1); t.fin_valid.reserve(n_map_max + 1);
   t.filt.reserve(n_map_max + 1);
-  t.rest_flag.reserve(n_in + 2); t.rest_scan.reserve(n_in + 2); t.ins.reserve(n_in + 1); t.ins_tags.reserve(n_in + 1);
   t.vox.reserve(n_map_max + 1, 126);
 }
 
@@ -482,12 +517,14 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     const int cur = T.cur, nxt = 1 - cur;
     if (T.n) {
       const uint32_t nb = (T.n + 255) / 256;
-      hipLaunchKernelGGL(k_map_classify, dim3(nb), dim3(256), 0, st, T.tags[cur].p, T.n, w, slot_lut_v, T.fv.p, T.fr.p, T.seg.p);
-      exclusive_scan_u32_n(T.fv.p, T.sv.p, T.tile_sums.p, T.counters.p + 0, T.n, st);
-      exclusive_scan_u32_n(T.fr.p, T.sr.p, T.tile_sums.p, T.counters.p + 2, T.n, st);
-      hipLaunchKernelGGL(k_map_partition, dim3(nb), dim3(256), 0, st, T.pts[cur].p, T.tags[cur].p, T.n, T.fv.p, T.sv.p, T.fr.p, T.sr.p,
-                         T.seg.p, T.fin.p, T.fin_seg.p, T.fin_valid.p, T.pts[nxt].p, T.tags[nxt].p,
-                         (t == 0 ? reg.corner_index : reg.surf_index).d_bounds());
+      (void)nb;
+      if (++T.chain_epoch >= (1u << 30) - 2u) {   // (the chains' words carry a 30-bit epoch: cleared on the stream before it comes round)
+        LX_HIP(hipMemsetAsync(T.chain.p, 0, sizeof(unsigned long long) * T.chain.cap, st));
+        T.chain_epoch = 1;
+      }
+      hipLaunchKernelGGL(k_map_split, dim3((T.n + MS_TILE - 1) / MS_TILE), dim3(256), 0, st, T.pts[cur].p, T.tags[cur].p, T.n, w, slot_lut_v, T.fin.p,
+                         T.fin_seg.p, T.fin_valid.p, T.pts[nxt].p, T.tags[nxt].p, (t == 0 ? reg.corner_index : reg.surf_index).d_bounds(),
+                         T.chain.p, T.chain.p + T.chain_stride, (unsigned long long)T.chain_epoch, T.counters.p, h_err.p);
     } else {
       LX_HIP(hipMemsetAsync(T.counters.p, 0, sizeof(uint32_t) * 4, st));
     }
@@ -526,11 +563,13 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     // (the sub-map's points, cube slots and valid flags are in fin / fin_seg / fin_valid already: the partition wrote them there)
     if (n_slots) {
       const uint32_t nb = (n_slots + 255) / 256;
+      if (++T.chain_epoch >= (1u << 30) - 2u) {
+        LX_HIP(hipMemsetAsync(T.chain.p, 0, sizeof(unsigned long long) * T.chain.cap, st));
+        T.chain_epoch = 1;
+      }
       hipLaunchKernelGGL(k_map_insert, dim3(nb), dim3(256), 0, st, reg.d_ds_points(), reg.d_ds_offsets(), t, n_slots, reg.d_poses(), w,
-                         slot_lut_v, n_old, T.fin.p, T.fin_seg.p, T.fin_valid.p, T.rest_flag.p, T.ins.p, T.ins_tags.p);
-      exclusive_scan_u32_n(T.rest_flag.p, T.rest_scan.p, T.tile_sums.p, T.counters.p + 4, n_slots, st);
-      hipLaunchKernelGGL(k_map_append_rest, dim3(nb), dim3(256), 0, st, T.ins.p, T.ins_tags.p, T.rest_flag.p, T.rest_scan.p, n_slots,
-                         T.counters.p + 3, T.pts[nxt].p, T.tags[nxt].p);
+                         slot_lut_v, n_old, T.fin.p, T.fin_seg.p, T.fin_valid.p, T.counters.p + 3, T.pts[nxt].p, T.tags[nxt].p,
+                         T.chain.p + 2 * T.chain_stride, (unsigned long long)T.chain_epoch, T.counters.p, h_err.p);
     } else {
       LX_HIP(hipMemsetAsync(T.counters.p + 4, 0, sizeof(uint32_t) * 2, st));
     }
@@ -553,6 +592,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   int stats4[4];
   reg.sync();   // the histogram / counter copies above
   for (int t = 0; t < 2; t++) tm[t].vox.check();   // (a timed-out wait inside the per-cube voxel kernel must not corrupt the map silently)
+  if (*(volatile uint32_t*)h_err.p) { *h_err.p = 0u; throw Error(LOAMX_E_HIP, "map update: a tile's look-back gave up waiting for the tiles before it"); }
   reg.download(pose6, stats4);
   LX_HIP(hipGetLastError());
   for (int t = 0; t < 2; t++) {

@@ -105,6 +105,8 @@ class VoxelPipeline {
   size_t zero_words_ = 0, status_words_ = 0;
   PinBuf<uint32_t> h_err_;
   uint32_t slots_ = 0, slots_seg_ = 0;
+  bool zero_ready_ = false;   // compute_ijk has cleared zero_ for the general kernel of the same (n, nseg)
+  uint32_t zero_ready_n_ = 0, zero_ready_nseg_ = 0;
 };
 
 }  // namespace loamx

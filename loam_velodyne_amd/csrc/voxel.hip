@@ -9,6 +9,13 @@ __global__ void k_vox_init_minmax(int* mm, uint32_t nseg) {
   if (i < 6 * nseg) mm[i] = (i % 6) < 3 ? 2147483647 : (-2147483647 - 1);
 }
 
+// the bounds' initial values and k_vox_ds's cleared block (counters, histograms, tile status) in one launch
+__global__ __launch_bounds__(256) void k_vox_prepare(int* __restrict__ mm, uint32_t nseg, uint4* __restrict__ zero, uint32_t nquads) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 6 * nseg) mm[i] = (i % 6) < 3 ? 2147483647 : (-2147483647 - 1);
+  for (uint32_t q = i; q < nquads; q += gridDim.x * blockDim.x) zero[q] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // seg_ids given (scattered segment ids: the map's cube slots): the bounds of up to VIJK_LDS_SEGS segments are reduced in LDS per
 // workgroup and flushed with one global atomic per touched bound — per-lane global atomics on a few dozen segments' six words
 // serialise (measured: up to 2 ms per launch on a 166 k-point sub-map).
@@ -796,7 +803,7 @@ void VoxelPipeline::reserve(uint32_t n, uint32_t nseg) {
   const uint32_t passes = (31u + seg_bits + 7u) / 8u;   // upper bound of the kernel's pass count (31 bits of voxel index + the segment)
   status_words_ = (size_t)passes * ntiles * VDS_ROW;
   zero_words_ = 64 + 8 * 256 + status_words_ + ntiles;   // TileSync counters | gh | status | tile head counts
-  zero_.reserve(zero_words_ + ntiles);                                       // + the tile lists (not cleared)
+  zero_.reserve(zero_words_ + ntiles + 4);                                     // + the tile lists (not cleared)
   if (!h_err_.p) { h_err_.reserve(1); *h_err_.p = 0u; }
 }
 
@@ -806,8 +813,17 @@ void VoxelPipeline::reset_minmax(uint32_t nseg) {
 
 void VoxelPipeline::compute_ijk(const float4* pts, const uint8_t* valid, uint32_t n, const uint32_t* d_seg_off, uint32_t nseg,
                                 float inv_even, float inv_odd, const uint32_t* d_seg_ids) {
-  reset_minmax(nseg);
-  if (n == 0) return;
+  zero_ready_ = false;
+  if (n == 0) { reset_minmax(nseg); return; }
+  if (d_seg_ids) {   // the general kernel follows (sort_reduce): clear its block here instead of with a memset of its own
+    reserve(n, nseg);
+    const uint32_t nquads = (uint32_t)((zero_words_ + 3) / 4);   // (the tile lists behind the cleared block may be overwritten: they are not read before they are written)
+    const uint32_t blocks = std::max<uint32_t>((6 * nseg + 255) / 256, std::min<uint32_t>((nquads + 255) / 256, 1024u));
+    hipLaunchKernelGGL(k_vox_prepare, dim3(blocks), dim3(256), 0, st_, seg_minmax_.p, nseg, reinterpret_cast<uint4*>(zero_.p), nquads);
+    zero_ready_ = true; zero_ready_n_ = n; zero_ready_nseg_ = nseg;
+  } else {
+    reset_minmax(nseg);
+  }
   hipLaunchKernelGGL(k_vox_ijk, dim3((n + 255) / 256), dim3(256), 0, st_, pts, valid, n, d_seg_off, d_seg_ids, nseg, inv_even, inv_odd, ijk_.p,
                      seg_minmax_.p);
 }
@@ -892,7 +908,9 @@ void VoxelPipeline::sort_reduce(const float4* pts, const uint8_t* valid, uint32_
   a.barrier = zero_.p; a.gh = zero_.p + 64; a.status = zero_.p + 64 + 8 * 256;
   a.tile_cnt = a.status + status_words_;
   a.link = zero_.p + zero_words_;
-  LX_HIP(hipMemsetAsync(zero_.p, 0, sizeof(uint32_t) * zero_words_, st_));   // one block: barrier counter, digit histograms, tile status
+  if (!(zero_ready_ && zero_ready_n_ == n && zero_ready_nseg_ == nseg))
+    LX_HIP(hipMemsetAsync(zero_.p, 0, sizeof(uint32_t) * zero_words_, st_));   // one block: barrier counter, digit histograms, tile status
+  zero_ready_ = false;
   uint32_t G = std::max<uint32_t>(1u, std::min<uint32_t>(a.ntiles, slots_));   // tiles are claimed: residency is not a correctness condition
   if (const char* e = getenv("LOAMX_VDS_WGS")) { const int v = atoi(e); if (v >= 1) G = std::min<uint32_t>(G, (uint32_t)v); }
   hipLaunchKernelGGL(k_vox_ds, dim3(G), dim3(256), 0, st_, a);

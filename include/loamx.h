@@ -69,7 +69,7 @@ const char* loamx_last_error(void);
 /* number of visible HIP devices (0 if none / HIP unavailable); never fails */
 int loamx_device_count(void);
 /* ABI version of this header */
-#define LOAMX_ABI_VERSION 5
+#define LOAMX_ABI_VERSION 6
 int loamx_abi_version(void);
 /* How this library was built, as "key=value;..." (static storage): abi=<n>; diag=0|1 (1: made with EXTRA=-DLOAMX_DIAG — the only kind of
  * build that reads the diagnostic LOAMX_* environment switches, some of which change results; a product library ignores them);
@@ -172,6 +172,28 @@ int loamx_odom_transform_to_end(loamx_odom* h, loamx_cloud* cloud);
 int loamx_odom_get_stats(loamx_odom* h, int stats[4]);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Linked nodes (ABI version 6): the reference's three nodes exchange a sweep's clouds as ROS messages — host memory
+ * (ScanRegistration.cpp:186-208 -> LaserOdometry.cpp:141-233 -> LaserMapping.cpp:155-230).  A process that hosts the three
+ * handles on ONE device can hand the clouds from node to node in HBM instead: same data flow, same results bit for bit
+ * (tests/test_gpu_linked.py), without the five round trips over PCIe per sweep.
+ *   loamx_scanreg_process_linked   the sweep goes up and the extraction is enqueued; returns without waiting.  The feature
+ *                                  clouds and the sweep stay in the handle's device buffers.
+ *   loamx_odom_process_linked      waits for `sr`'s extraction (and reports what loamx_scanreg_process would: LOAMX_E_INVALID
+ *                                  for non-finite input, ...), runs process() on its clouds and re-projects the sweep's
+ *                                  full-resolution cloud to the sweep end (transformToEnd of LaserOdometry.cpp:326) into a
+ *                                  device buffer of `od`.  Returns with the pose (LOAMX_SKIPPED for the initialising sweep); the
+ *                                  tail goes on behind it.  `sr`'s buffers are read until loamx_odom_link_wait(od) or
+ *                                  loamx_map_process_linked has returned: start `sr`'s next sweep only then.
+ *   loamx_map_process_linked       updateOdometry(od's transformSum) + process() on od's last corner / surface clouds and the
+ *                                  re-projected full-resolution cloud, ordered behind od's tail on the device.
+ *                                  full_res_registered (may be NULL): receives the registered full-resolution cloud
+ *                                  (count = capacity in, points out).  `od` may start its next sweep when this has returned.
+ * The host-cloud getters (loamx_odom_get_last_clouds, ...) keep working after the linked calls. */
+int loamx_scanreg_process_linked(loamx_scanreg* h, const loamx_cloud* cloud, const uint32_t* ring_size, uint32_t n_rings);
+int loamx_odom_process_linked(loamx_odom* h, loamx_scanreg* sr);
+int loamx_odom_link_wait(loamx_odom* h);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Scan-to-map registration  (BasicLaserMapping)
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct loamx_map loamx_map;
@@ -193,6 +215,8 @@ void loamx_map_destroy(loamx_map* h);
 int loamx_map_update_odometry(loamx_map* h, const float transform_sum[6]);
 /* process(): corner_last / surf_last in, full_res registered in place (transformFullResToMap). */
 int loamx_map_process(loamx_map* h, const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res);
+/* see "Linked nodes" above */
+int loamx_map_process_linked(loamx_map* h, loamx_odom* od, loamx_cloud* full_res_registered);
 /* The map side of process() alone — the merge step of a map epoch (collective 3): a sweep that was registered elsewhere
  * (the batched pipeline, against a frozen copy of this map) is stacked, down-sized, inserted into the cubes with the GIVEN pose
  * (rx, ry, rz, tx, ty, tz = its transformAftMapped) and the touched cubes are re-filtered, exactly as process() does after its

@@ -1,12 +1,7 @@
 // C-ABI: sweep-to-sweep odometry (loamx_odom_*) — shim over loamx::Odometry.
-#include "odometry.cuh"
+#include "api_handles.h"
 
 using namespace loamx;
-
-struct loamx_odom {
-  OdometryBatch od;
-  explicit loamx_odom(int device) : od(device, 1) {}
-};
 
 extern "C" {
 
@@ -51,6 +46,23 @@ int loamx_odom_process(loamx_odom* h, const loamx_cloud* sharp, const loamx_clou
   return guard([&]() {
     LX_REQUIRE(h && sharp && less_sharp && flat && less_flat, "NULL argument");
     return h->od.process_host(sharp, less_sharp, flat, less_flat);
+  });
+}
+int loamx_odom_process_linked(loamx_odom* h, loamx_scanreg* sr) {
+  return guard([&]() {
+    LX_REQUIRE(h && sr, "NULL argument");
+    LX_REQUIRE(sr->fx.device() == h->od.device(), "linked handles must live on one device");
+    const float4* p[4];
+    uint32_t n[4];
+    sr->fx.device_results(0, p, n);   // (waits for the extraction; the clouds stay where they are)
+    return h->od.process_linked(p, n, sr->fx.d_cloud() + sr->fx.point_base(0), sr->fx.point_base(1) - sr->fx.point_base(0));
+  });
+}
+int loamx_odom_link_wait(loamx_odom* h) {
+  return guard([&]() {
+    LX_REQUIRE(h, "NULL handle");
+    if (h->od.link_ready()) LX_HIP(hipEventSynchronize(h->od.link_ready()));
+    return LOAMX_OK;
   });
 }
 int loamx_odom_get_transform(loamx_odom* h, float t[6]) {

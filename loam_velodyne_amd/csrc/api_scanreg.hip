@@ -1,14 +1,9 @@
 // C-ABI: feature extraction (loamx_scanreg_*) — shim over loamx::FeatureExtractor.
-#include "features.cuh"
+#include "api_handles.h"
 #include <algorithm>
 #include <string>
 
 using namespace loamx;
-
-struct loamx_scanreg {
-  FeatureExtractor fx;
-  explicit loamx_scanreg(int device) : fx(device) {}
-};
 
 extern "C" {
 
@@ -82,6 +77,17 @@ int loamx_scanreg_process(loamx_scanreg* h, const loamx_cloud* cloud, const uint
     h->fx.upload(1, cloud, rs, &n_rings);
     h->fx.run_async();
     return h->fx.download(0, sharp, less_sharp, flat, less_flat);   // (one wait, behind the launch that packs the clouds into pinned memory)
+  });
+}
+
+int loamx_scanreg_process_linked(loamx_scanreg* h, const loamx_cloud* cloud, const uint32_t* ring_size, uint32_t n_rings) {
+  return guard([&]() {
+    LX_REQUIRE(h && cloud && ring_size && n_rings > 0, "NULL / empty argument");
+    const uint32_t* rs[1] = {ring_size};
+    h->fx.begin_sweep();
+    h->fx.upload(1, cloud, rs, &n_rings);   // (the caller's cloud has been copied out when this returns)
+    h->fx.run_async();                      // no wait: loamx_odom_process_linked waits for (and checks) the extraction
+    return LOAMX_OK;
   });
 }
 

@@ -89,6 +89,10 @@ class FeatureExtractor {
   // host copies of one sweep's outputs (after sync); any pointer may be NULL
   int download(uint32_t sweep, loamx_cloud* sharp, loamx_cloud* less_sharp, loamx_cloud* flat, loamx_cloud* less_flat);
 
+  // the same clouds left where they are: waits for the run (and raises what download() would raise), then hands out the device views
+  // and sizes of one sweep's sharp / less sharp / flat / less flat clouds (valid until the next upload)
+  void device_results(uint32_t sweep, const float4* ptr[4], uint32_t count[4]);
+
   // device-side results for chaining (valid after run_async on the same stream):
   //   kind 0 sharp, 1 less_sharp, 2 flat: compact arrays + per-sweep offsets [nsw+1]
   //   less_flat: voxel-filtered per ring; d_less_flat_ring_off [total_rings+1]; sweep s owns rings [ring_base(s), ring_base(s+1))
@@ -140,7 +144,7 @@ class FeatureExtractor {
   DevBuf<float4> lf_out_, lf_slots_;
   DevBuf<uint32_t> lf_cnt_;
   VoxelPipeline vox_;
-  PinBuf<uint32_t> h_off_;
+  PinBuf<uint32_t> h_off_, h_link_off_;
   PinBuf<uint32_t> h_bad_;   // pinned word raised by k_feat_point on a non-finite input coordinate
   PinBuf<float4> h_pack_;   // download(): [header | sharp | less sharp | flat | less flat] of one sweep, written by k_feat_pack_host
 };

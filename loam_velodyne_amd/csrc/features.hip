@@ -844,12 +844,12 @@ void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uin
     for (uint32_t r = 0; r < n_rings[s]; r++) sum += ring_size[s][r];
     LX_REQUIRE(sum == clouds[s].count, "ring sizes do not add up to the cloud size");
   }
+  LX_HIP(hipStreamSynchronize(st_));   // (the staging block and the tables of the previous sweep are free: nothing to wait for unless the caller skipped its results)
   layout_(nsw, ring_size, n_rings);
   h_cloud_.reserve(n_ + 1);
   for (uint32_t s = 0; s < nsw; s++) pack_cloud(&clouds[s], h_cloud_.p + h_pt_base_[s]);
   allocate_();
-  if (n_) LX_HIP(hipMemcpyAsync(cloud_.p, h_cloud_.p, sizeof(float4) * n_, hipMemcpyHostToDevice, st_));
-  LX_HIP(hipStreamSynchronize(st_));
+  if (n_) LX_HIP(hipMemcpyAsync(cloud_.p, h_cloud_.p, sizeof(float4) * n_, hipMemcpyHostToDevice, st_));   // (no wait: the kernels follow on the same stream)
 }
 
 // One raw revolution (MultiScanRegistration::process, src/lib/MultiScanRegistration.cpp:160-238): records with x, y, z
@@ -1089,6 +1089,25 @@ __global__ __launch_bounds__(256) void k_feat_pack_host(const float4* __restrict
     else v = lf[a3 + (i - n0 - n1 - n2)];
     dst[1 + i] = v;
   }
+}
+
+void FeatureExtractor::device_results(uint32_t sweep, const float4* ptr[4], uint32_t count[4]) {
+  LX_REQUIRE(sweep < nsw_, "sweep index out of range");
+  h_link_off_.reserve(n_offsets());
+  LX_HIP(hipMemcpyAsync(h_link_off_.p, offs_.p, sizeof(uint32_t) * n_offsets(), hipMemcpyDeviceToHost, st_));
+  LX_HIP(hipStreamSynchronize(st_));
+  vox_.check();
+  check_finite_input();
+  const uint32_t* o = h_link_off_.p;
+  for (int k = 0; k < 3; k++) {
+    const uint32_t a = o[(size_t)k * off_stride_ + sweep], b = o[(size_t)k * off_stride_ + sweep + 1];
+    ptr[k] = out_[k].p + a;
+    count[k] = b - a;
+  }
+  const uint32_t* lf = o + (size_t)3 * off_stride_;
+  const uint32_t a = lf[h_ring_base_[sweep]], b = lf[h_ring_base_[sweep + 1]];
+  ptr[3] = lf_out_.p + a;
+  count[3] = b - a;
 }
 
 int FeatureExtractor::download(uint32_t sweep, loamx_cloud* sharp, loamx_cloud* less_sharp, loamx_cloud* flat, loamx_cloud* less_flat) {

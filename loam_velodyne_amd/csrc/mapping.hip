@@ -11,6 +11,7 @@
 //   k_map_append / k_map_hist                   next map = rest ++ filtered; per-cube counts for the host directory
 // Host: closed-form pose prediction (:103-167), cube window + field-of-view selection (:300-500), transformUpdate.
 #include "registration.cuh"
+#include "api_handles.h"
 #include <algorithm>
 #include <deque>
 #include "host_math.h"
@@ -333,7 +334,15 @@ class Mapper {
     if (ev_join) (void)hipEventDestroy(ev_join);
   }
 
-  int process(const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res);
+  // the sweep's clouds already in HBM (the linked entry point): packed float4 arrays of this device, read behind `ready` (may be NULL)
+  struct DeviceInput {
+    const float4* corner; uint32_t n_corner;
+    const float4* surf; uint32_t n_surf;
+    const float4* full; uint32_t n_full;
+    hipEvent_t ready;
+  };
+  // dev given: corner_last / surf_last are ignored (may be NULL), full_res (may be NULL) only receives the registered cloud
+  int process(const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res, const DeviceInput* dev = nullptr);
   // The map side of process() alone, for a sweep that has been registered elsewhere (the batched pipeline against a frozen map): stack,
   // down-size, insert into the cubes with the GIVEN pose and re-filter the touched cubes (BasicLaserMapping.cpp:512-593) — the
   // optimisation (:628-923) does not run, the pose is taken as transformTobeMapped.  The merge step of a map epoch.
@@ -415,10 +424,12 @@ void Mapper::ensure(TypeMap& t, uint32_t n_map_max, uint32_t n_in) {
   t.vox.reserve(n_map_max + 1, 126);
 }
 
-int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res) {
+int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res, const DeviceInput* dev) {
   TraceRange trace_range("loamx:mapping:process");
-  check_cloud(corner_last, false);
-  check_cloud(surf_last, false);
+  if (!dev) {
+    check_cloud(corner_last, false);
+    check_cloud(surf_last, false);
+  }
   if (full_res) check_cloud(full_res, false);
   LX_HIP(hipSetDevice(cfg.device));
   hipStream_t st = reg.stream();
@@ -497,14 +508,23 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
 
   MapWindow w;
   for (int a = 0; a < 3; a++) w.cen[a] = cen[a];
-  const uint32_t n_in[2] = {corner_last->count, surf_last->count};
+  const uint32_t n_in[2] = {dev ? dev->n_corner : corner_last->count, dev ? dev->n_surf : surf_last->count};
+  const bool want_full = dev ? dev->n_full != 0 : (full_res && full_res->count);
 
   // the sweep's clouds and the guess go up first: the copies run while this thread is still enqueuing the partition (the chain
   // of short launches below is bound by the host's launch rate, not by the device)
   {
     float g6[6];
     tobe.get(g6);
-    reg.upload(1, corner_last, surf_last, full_res, g6, false);
+    if (dev) {
+      if (dev->ready) LX_HIP(hipStreamWaitEvent(reg.stream(), dev->ready, 0));
+      const float4* c[1] = {dev->corner};
+      const float4* sf[1] = {dev->surf};
+      const float4* fl[1] = {dev->full};
+      reg.upload_device(1, c, &dev->n_corner, sf, &dev->n_surf, dev->n_full ? fl : nullptr, &dev->n_full, g6);
+    } else {
+      reg.upload(1, corner_last, surf_last, full_res, g6, false);
+    }
   }
 
   // ---- partition the map: sub-map | rest | dropped (the two types side by side, as in the update below)
@@ -550,7 +570,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     reg.finish_with_poses(p6);
   }
 
-  if (full_res && full_res->count) reg.download_full_res_async(0);   // (lands while the map is updated)
+  if (want_full && full_res) reg.download_full_res_async(0);   // (lands while the map is updated)
 
   // ---- map insertion + per-cube re-filtering: corners on st2, surfs on the registration's stream, side by side
   LX_HIP(hipEventRecord(ev_fork, reg.stream()));
@@ -612,7 +632,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     bef = sum;
     aft = tobe;
   }
-  if (full_res && full_res->count) {
+  if (want_full && full_res) {
     int r = reg.download_full_res(0, full_res);
     if (r != LOAMX_OK) rc = r;
   }
@@ -859,6 +879,20 @@ int loamx_map_process(loamx_map* h, const loamx_cloud* corner_last, const loamx_
   return guard([&]() {
     LX_REQUIRE(h && corner_last && surf_last, "NULL argument");
     return h->m.process(corner_last, surf_last, full_res);
+  });
+}
+int loamx_map_process_linked(loamx_map* h, loamx_odom* od, loamx_cloud* full_res_registered) {
+  return guard([&]() {
+    LX_REQUIRE(h && od, "NULL argument");
+    OdometryBatch& ob = od->od;
+    LX_REQUIRE(ob.device() == h->m.cfg.device, "linked handles must live on one device");
+    LX_REQUIRE(ob.link_valid(), "loamx_odom_process_linked has not handed a sweep on");
+    float sum6[6];
+    ob.stream_state(0).transform_sum.get(sum6);
+    h->m.sum.set(sum6);   // updateOdometry (:607-611)
+    Mapper::DeviceInput in{ob.d_last_corner(0), ob.stream_state(0).n_last_corner, ob.d_last_surf(0), ob.stream_state(0).n_last_surf,
+                           ob.d_link_full(), ob.n_link_full(), ob.link_ready()};
+    return h->m.process(nullptr, nullptr, full_res_registered, &in);
   });
 }
 int loamx_map_get_transform(loamx_map* h, int which, float t[6]) {

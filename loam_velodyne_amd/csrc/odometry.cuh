@@ -97,6 +97,15 @@ class OdometryBatch {
   void set_keep(int n) { keep_ = n < 2 ? 2 : (n > MAX_KEEP ? MAX_KEEP : n); }
   // host-cloud convenience (single-stream handles)
   int process_host(const loamx_cloud* sharp, const loamx_cloud* less_sharp, const loamx_cloud* flat, const loamx_cloud* less_flat);
+  // the same sweep from DEVICE clouds (the feature extractor's own buffers, read until this call returns), plus the sweep's
+  // full-resolution cloud: re-projected to the sweep end (LaserOdometry.cpp:326) into a buffer of this object behind the tail.
+  // link_ready() is recorded behind everything a consumer on another stream reads: d_last_corner / d_last_surf / d_link_full
+  int process_linked(const float4* const feat[4], const uint32_t n_feat[4], const float4* d_full, uint32_t n_full);
+  hipEvent_t link_ready() const { return ev_link_; }
+  const float4* d_link_full() const { return link_full_.p; }
+  uint32_t n_link_full() const { return n_link_full_; }
+  bool link_valid() const { return link_valid_; }
+  int device() const { return device_; }
   int get_last_clouds(uint32_t s, loamx_cloud* corner, loamx_cloud* surf);
   int transform_to_end_host(uint32_t s, loamx_cloud* cloud);
   // in place on device points with stream s's current transform (async on the stream)
@@ -151,7 +160,10 @@ class OdometryBatch {
   PinBuf<float4> h_stage_;
   PinBuf<float4> h_last_dl_;     // process_host(): the clouds get_last_clouds() hands out, copied behind the tail
   bool last_dl_valid_ = false;
-  DevBuf<float4> up_[4], tmp_cloud_;
+  DevBuf<float4> up_[4], tmp_cloud_, link_full_;
+  uint32_t n_link_full_ = 0;
+  bool link_valid_ = false;
+  hipEvent_t ev_link_ = nullptr;
   uint32_t lm_slots_[2] = {0, 0};   // workgroups of k_odom_lm<1> / <2> the device holds at once (occupancy x CUs)
   hipEvent_t ev_tail_ = nullptr, ev_pose_ = nullptr, ev_up_ = nullptr;
   bool tail_pending_ = false, up_pending_ = false;

@@ -821,6 +821,11 @@ __device__ inline float4 to_end_point(float4 p, const ToEndParams& P) {
   rot_y(x, z, P.c_end[1], -P.s_end[1]); rot_x(y, z, P.c_end[0], -P.s_end[0]); rot_z(x, y, P.c_end[2], -P.s_end[2]);
   return make_float4(x, y, z, (float)(int)p.w);
 }
+__global__ __launch_bounds__(256) void k_transform_to_end_copy(float4* __restrict__ dst, const float4* __restrict__ src, uint32_t n, ToEndParams P) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  dst[i] = to_end_point(src[i], P);
+}
 __global__ __launch_bounds__(256) void k_transform_to_end(float4* __restrict__ pts, uint32_t n, ToEndParams P) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -1324,6 +1329,24 @@ int OdometryBatch::process_host(const loamx_cloud* sharp, const loamx_cloud* les
   h_last_dl_.reserve((size_t)n + 1);
   if (n) LX_HIP(hipMemcpyAsync(h_last_dl_.p, d_last_corner(0), sizeof(float4) * n, hipMemcpyDeviceToHost, st_));
   last_dl_valid_ = d_last_surf(0) == d_last_corner(0) + S.n_last_corner;
+  return rc;
+}
+
+int OdometryBatch::process_linked(const float4* const feat[4], const uint32_t n_feat[4], const float4* d_full, uint32_t n_full) {
+  LX_REQUIRE(n_streams() == 1, "process_linked is a single-stream entry point");
+  LX_HIP(hipSetDevice(device_));
+  OdomInput in{feat[0], n_feat[0], feat[1], n_feat[1], feat[2], n_feat[2], feat[3], n_feat[3]};
+  int rc = LOAMX_OK;
+  last_dl_valid_ = false;
+  link_valid_ = false;
+  process(&in, &rc, /*defer_tail=*/true);
+  link_full_.reserve((size_t)n_full + 1);
+  if (n_full)
+    hipLaunchKernelGGL(k_transform_to_end_copy, dim3((n_full + 255) / 256), dim3(256), 0, st_, link_full_.p, d_full, n_full, to_end_params(0, true));
+  n_link_full_ = n_full;
+  if (!ev_link_) LX_HIP(hipEventCreateWithFlags(&ev_link_, hipEventDisableTiming));
+  LX_HIP(hipEventRecord(ev_link_, st_));
+  link_valid_ = true;
   return rc;
 }
 

@@ -330,6 +330,14 @@ class ScanRegistration:
         # (LaserMapping.process(inplace=True)) rewrites the caller's sweep — pass a copy where the sweep is needed again
         return res
 
+    def process_linked(self, points, ring_sizes):
+        """loamx_scanreg_process_linked: enqueue the extraction and leave the clouds in HBM for LaserOdometry.process_linked"""
+        pts = as_points(points)
+        rs = np.ascontiguousarray(ring_sizes, np.uint32)
+        cin = cloud_of(pts)
+        self._linked_n = len(pts)
+        return _check(lib().loamx_scanreg_process_linked(self.h, C.byref(cin), rs.ctypes.data_as(C.c_void_p), len(rs)))
+
     def update_imu(self, stamp, roll, pitch, yaw, acc):
         """loamx_scanreg_update_imu (updateIMUData); stamp in seconds"""
         a = np.ascontiguousarray(acc, np.float32)
@@ -394,6 +402,15 @@ class LaserOdometry:
         rc = _check(lib().loamx_odom_process(self.h, C.byref(cl[0]), C.byref(cl[1]), C.byref(cl[2]), C.byref(cl[3])))
         self._sizes = (len(arrs[1]), len(arrs[3]))
         return rc
+
+    def process_linked(self, scanreg):
+        """loamx_odom_process_linked: the sweep `scanreg` has just extracted, taken from its device buffers"""
+        rc = _check(lib().loamx_odom_process_linked(self.h, scanreg.h))
+        self._sizes = (scanreg._linked_n, scanreg._linked_n)   # (capacities for last_clouds(): each cloud is a subset of the sweep)
+        return rc
+
+    def link_wait(self):
+        return _check(lib().loamx_odom_link_wait(self.h))
 
     def _t(self, fn):
         t = np.zeros(6, np.float32)
@@ -474,6 +491,15 @@ class LaserMapping:
             return rc, f
         rc = _check(lib().loamx_map_process(self.h, C.byref(cc), C.byref(sc), None))
         return rc, None
+
+    def process_linked(self, odometry, full_out=None):
+        """loamx_map_process_linked: the sweep `odometry` has just handed on (device to device); full_out: an (n, 4) / (n, 8) float32
+        array with room for the sweep — receives the registered full-resolution cloud (returned trimmed, a view)"""
+        if full_out is None:
+            return _check(lib().loamx_map_process_linked(self.h, odometry.h, None)), None
+        fc = cloud_of(full_out)
+        rc = _check(lib().loamx_map_process_linked(self.h, odometry.h, C.byref(fc)))
+        return rc, full_out[:fc.count]
 
     def insert(self, corner_last, surf_last, pose6):
         """loamx_map_insert: the epoch merge step — stack, down-size and insert a sweep registered elsewhere with the given pose"""

@@ -23,10 +23,10 @@ def test_exports_every_declared_symbol():
     assert len(names) >= 50
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, f"declared in include/loamx.h but not exported: {missing}"
-    assert L.loamx_abi_version() == 5
+    assert L.loamx_abi_version() == 6
     L.loamx_build_info.restype = __import__("ctypes").c_char_p
     info = dict(kv.split("=") for kv in L.loamx_build_info().decode().split(";"))
-    assert info["abi"] == "5" and info["diag"] == "0", info   # the shipped library is not a diagnostic build
+    assert info["abi"] == "6" and info["diag"] == "0", info   # the shipped library is not a diagnostic build
 
 
 def test_no_oracle_in_product():

@@ -253,7 +253,7 @@ class FakeLib:
         return b""
 
     def loamx_build_info(self):
-        return b"abi=5;diag=0;rccl=1;roctx=1"
+        return b"abi=6;diag=0;rccl=1;roctx=1"
 
 
 @pytest.mark.parametrize("argv", [["--steps", "3", "--warmup", "1", "--streams", "2", "--sensor", "VLP-16", "--map-points", "2000", "--no-cpu-baseline",

@@ -1,0 +1,96 @@
+"""GPU: the linked entry points (loamx_scanreg_process_linked -> loamx_odom_process_linked -> loamx_map_process_linked: a sweep handed
+from node to node in HBM) against the host-message entry points on the same sweeps — the data flow is the same, so everything the
+two chains produce must be equal bit for bit: odometry transforms, the clouds handed on, mapped poses, the registered cloud, the map."""
+import numpy as np
+import pytest
+
+from loam_velodyne_amd import loamx, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _chains(world, sensor, n, map_points, az_steps=None):
+    cm, sm = world.make_map(map_points)
+    poses = synth.trajectory(n)
+    kw = {} if az_steps is None else {"az_steps": az_steps}
+    sweeps = [synth.make_sweep(world, sensor, poses[t], poses[t + 1], seed=900 + t, **kw) for t in range(n)]
+    return cm, sm, sweeps
+
+
+@pytest.mark.parametrize("sensor,map_points", [("VLP-16", 60_000), ("HDL-32", 150_000)])
+def test_linked_chain_equals_host_message_chain(sensor, map_points):
+    world = synth.World(half_extent=65.0)
+    n = 9   # (the surround cloud is due on the 1st, 6th, ... processed frame: both branches of process() are covered)
+    cm, sm, sweeps = _chains(world, sensor, n, map_points)
+    sr_a, od_a, mp_a = loamx.ScanRegistration(), loamx.LaserOdometry(), loamx.LaserMapping()
+    sr_b, od_b, mp_b = loamx.ScanRegistration(), loamx.LaserOdometry(), loamx.LaserMapping()
+    mp_a.load_cubes(cm, sm)
+    mp_b.load_cubes(cm, sm)
+    landing = np.zeros((max(len(s.points) for s in sweeps), 4), np.float32)
+    for t, sw in enumerate(sweeps):
+        # host messages
+        f = sr_a.process(sw.points.copy(), sw.ring_sizes)
+        rc_a = od_a.process(f)
+        lc, ls = od_a.last_clouds()
+        full = od_a.transform_to_end(f["full"])
+        mp_a.update_odometry(od_a.transform_sum)
+        rcm_a, reg_a = mp_a.process(lc, ls, full)
+        # linked
+        sr_b.process_linked(sw.points.copy(), sw.ring_sizes)
+        rc_b = od_b.process_linked(sr_b)
+        rcm_b, reg_b = mp_b.process_linked(od_b, landing)
+        assert rc_a == rc_b and rcm_a == rcm_b, (t, rc_a, rc_b, rcm_a, rcm_b)
+        assert rc_b == (loamx.SKIPPED if t == 0 else loamx.OK)
+        assert np.array_equal(od_a.transform, od_b.transform), t
+        assert np.array_equal(od_a.transform_sum, od_b.transform_sum), t
+        assert od_a.stats() == od_b.stats(), t
+        lc_b, ls_b = od_b.last_clouds()   # (the host getters keep working behind a linked call)
+        assert np.array_equal(lc, lc_b) and np.array_equal(ls, ls_b), t
+        for which in ("aft", "bef", "tobe", "sum"):
+            assert np.array_equal(mp_a.transform(which), mp_b.transform(which)), (t, which)
+        assert mp_a.stats() == mp_b.stats(), t
+        assert reg_a.shape == reg_b.shape and np.array_equal(reg_a, reg_b), t
+        assert mp_a.has_fresh_map() == mp_b.has_fresh_map(), t
+        if mp_a.has_fresh_map():
+            assert np.array_equal(mp_a.surround(), mp_b.surround()), t
+    for which in (0, 1):
+        assert np.array_equal(mp_a.cubes(which), mp_b.cubes(which)), which
+    assert mp_a.stats()["iterations"] >= 1
+
+
+def test_linked_chain_without_registered_cloud_and_errors():
+    world = synth.World(half_extent=65.0)
+    cm, sm, sweeps = _chains(world, "VLP-16", 3, 40_000)
+    sr, od, mp = loamx.ScanRegistration(), loamx.LaserOdometry(), loamx.LaserMapping()
+    mp.load_cubes(cm, sm)
+    # nothing handed on yet
+    with pytest.raises(loamx.LoamxError) as e:
+        mp.process_linked(od)
+    assert e.value.code == loamx.E_INVALID
+    ref_sr, ref_od, ref_mp = loamx.ScanRegistration(), loamx.LaserOdometry(), loamx.LaserMapping()
+    ref_mp.load_cubes(cm, sm)
+    for sw in sweeps:
+        sr.process_linked(sw.points, sw.ring_sizes)
+        od.process_linked(sr)
+        od.link_wait()
+        rc, reg = mp.process_linked(od)      # no landing area: the registered cloud is not asked for
+        assert reg is None
+        f = ref_sr.process(sw.points.copy(), sw.ring_sizes)
+        ref_od.process(f)
+        lc, ls = ref_od.last_clouds()
+        ref_mp.update_odometry(ref_od.transform_sum)
+        ref_mp.process(lc, ls, ref_od.transform_to_end(f["full"]))
+        assert np.array_equal(mp.transform("aft"), ref_mp.transform("aft"))
+    # a landing area that is too small is reported, not overrun
+    sr.process_linked(sweeps[0].points, sweeps[0].ring_sizes)
+    od.process_linked(sr)
+    small = np.zeros((16, 4), np.float32)
+    with pytest.raises(loamx.LoamxError):
+        mp.process_linked(od, small)
+    # non-finite input: told at the node that waits for the extraction
+    bad = sweeps[1].points.copy()
+    bad[len(bad) // 2, 1] = np.nan
+    sr.process_linked(bad, sweeps[1].ring_sizes)
+    with pytest.raises(loamx.LoamxError) as e:
+        od.process_linked(sr)
+    assert e.value.code == loamx.E_INVALID

@@ -213,7 +213,12 @@ void loamx_map_default_config(loamx_map_config* cfg);
 loamx_map* loamx_map_create(const loamx_map_config* cfg);
 void loamx_map_destroy(loamx_map* h);
 int loamx_map_update_odometry(loamx_map* h, const float transform_sum[6]);
-/* process(): corner_last / surf_last in, full_res registered in place (transformFullResToMap). */
+/* process(): corner_last / surf_last in, full_res registered in place (transformFullResToMap).
+ * Returns with the sweep's results — the transforms, the statistics, the registered cloud.  The map update that ends the reference's
+ * process() (insertion into the cubes and their re-filtering, BasicLaserMapping.cpp:535-593) is enqueued behind the registration on
+ * the device and may still be running then: every later call that reads or changes the map (the next process / insert, get_cubes,
+ * save_snapshot, ...) waits for it first, so the map any call sees is the reference's.  A failure inside the deferred update is
+ * reported by that later call.  Every fifth processed frame (the surround cloud is cut from the updated map, :242-264) waits itself. */
 int loamx_map_process(loamx_map* h, const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res);
 /* see "Linked nodes" above */
 int loamx_map_process_linked(loamx_map* h, loamx_odom* od, loamx_cloud* full_res_registered);

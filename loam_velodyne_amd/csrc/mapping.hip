@@ -326,10 +326,17 @@ class Mapper {
   VoxelPipeline sur_vox;
   uint32_t n_surround = 0;
   PinBuf<uint32_t> h_err;                            // raised by a fused kernel whose look-back gave up (checked behind process()'s synchronisation)
-  hipStream_t st2 = nullptr;                        // the corner map's update (the surf map's runs on the registration's stream)
+  hipStream_t st2 = nullptr, st3 = nullptr;         // the corner / surf map's update (the sub-map partition: st2 and the registration's stream)
+  // The map update of a sweep (insertion, per-cube re-filtering, the new cube directory) is enqueued behind the registration but NOT waited
+  // for: process() returns with the pose and the registered cloud while the update runs on st2 / st3; whoever needs the map next — the
+  // next process(), the getters, a snapshot — finishes it first (finish_update: a wait that is normally over long before).
+  bool upd_pending = false;
+  uint32_t upd_n_sub[2] = {0, 0};
+  void finish_update();
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   ~Mapper() {
     if (st2) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); }
+    if (st3) { (void)hipStreamSynchronize(st3); (void)hipStreamDestroy(st3); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
   }
@@ -370,10 +377,11 @@ Mapper::Mapper(const loamx_map_config& c) : cfg(c), reg(c.device, 1) {
   h_err.reserve(16);
   *h_err.p = 0u;
   st2 = create_stream(0);
+  st3 = create_stream(0);
   LX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
   LX_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
   for (int t = 0; t < 2; t++) {
-    tm[t].vox.init(t == 0 ? st2 : reg.stream());
+    tm[t].vox.init(t == 0 ? st2 : st3);
     tm[t].hist.reserve(MCUBES + 16);
     tm[t].counters.p = tm[t].hist.p + MCUBES;   // (a view: the counters live behind the histogram so that both come down in one copy)
     tm[t].h_hist.reserve(MCUBES + 16);
@@ -432,6 +440,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   }
   if (full_res) check_cloud(full_res, false);
   LX_HIP(hipSetDevice(cfg.device));
+  finish_update();
   hipStream_t st = reg.stream();
   frame_count++;
   if (frame_count < 1) return LOAMX_SKIPPED;   // _stackFrameNum = 1 (:269-274)
@@ -570,14 +579,15 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     reg.finish_with_poses(p6);
   }
 
-  if (want_full && full_res) reg.download_full_res_async(0);   // (lands while the map is updated)
-
-  // ---- map insertion + per-cube re-filtering: corners on st2, surfs on the registration's stream, side by side
+  // ---- map insertion + per-cube re-filtering: corners on st2, surfs on st3, side by side behind the registration — and NOT in front of
+  // its results (see upd_pending)
   LX_HIP(hipEventRecord(ev_fork, reg.stream()));
+  if (want_full && full_res) reg.download_full_res_async(0);   // (lands while the map is updated)
   LX_HIP(hipStreamWaitEvent(st2, ev_fork, 0));
+  LX_HIP(hipStreamWaitEvent(st3, ev_fork, 0));
   for (int t = 1; t >= 0; t--) {   // (the surf map first: its chain is the longer one, and the host needs ~80 us to enqueue either)
     TypeMap& T = tm[t];
-    hipStream_t st = t == 0 ? st2 : reg.stream();
+    hipStream_t st = t == 0 ? st2 : st3;
     const int nxt = 1 - T.cur;
     const uint32_t n_old = n_sub[t], n_slots = n_in[t], n_fin = n_old + n_slots;
     // (the sub-map's points, cube slots and valid flags are in fin / fin_seg / fin_valid already: the partition wrote them there)
@@ -603,25 +613,16 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     const uint32_t max_new = T.n + n_slots + 1;
     hipLaunchKernelGGL(k_map_hist, dim3(std::min<uint32_t>((max_new + 2047) / 2048, 256u)), dim3(256), 0, st, T.tags[nxt].p, T.counters.p + 6, max_new, w, T.hist.p);
     LX_HIP(hipMemcpyAsync(T.h_hist.p, T.hist.p, sizeof(uint32_t) * (MCUBES + 16), hipMemcpyDeviceToHost, st));   // (histogram + the counters behind it: one copy)
+    upd_n_sub[t] = n_sub[t];
   }
-  LX_HIP(hipEventRecord(ev_join, st2));
-  LX_HIP(hipStreamWaitEvent(reg.stream(), ev_join, 0));
+  upd_pending = true;
 
-  // ---- results
+  // ---- results (the registration's stream: poses, statistics, the registered cloud's copy — not the map update)
   float pose6[6];
   int stats4[4];
-  reg.sync();   // the histogram / counter copies above
-  for (int t = 0; t < 2; t++) tm[t].vox.check();   // (a timed-out wait inside the per-cube voxel kernel must not corrupt the map silently)
-  if (*(volatile uint32_t*)h_err.p) { *h_err.p = 0u; throw Error(LOAMX_E_HIP, "map update: a tile's look-back gave up waiting for the tiles before it"); }
+  reg.sync();
   reg.download(pose6, stats4);
   LX_HIP(hipGetLastError());
-  for (int t = 0; t < 2; t++) {
-    TypeMap& T = tm[t];
-    LX_REQUIRE(T.n == 0 || T.h_hist.p[MCUBES + 1] == n_sub[t], "internal: sub-map size differs from the host cube directory");
-    T.cur = 1 - T.cur;
-    T.n = T.h_hist.p[MCUBES + 6];
-    for (int idx = 0; idx < MCUBES; idx++) T.cube_cnt[idx] = T.h_hist.p[idx];
-  }
   SweepStats ss;
   reg.download_stats(&ss);
   last_stats = ss;
@@ -642,6 +643,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   fresh_map = false;
   if (map_frame_count >= 5) {
     map_frame_count = 0;
+    finish_update();   // (the surround cloud is cut from the UPDATED map)
     const uint32_t nc = tm[0].n, nsf = tm[1].n, ntot = nc + nsf;
     sur_in.reserve(ntot + 1);
     sur_out.reserve(ntot + 1);
@@ -684,6 +686,23 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   return rc;
 }
 
+void Mapper::finish_update() {
+  if (!upd_pending) return;
+  upd_pending = false;
+  LX_HIP(hipSetDevice(cfg.device));
+  LX_HIP(hipStreamSynchronize(st2));
+  LX_HIP(hipStreamSynchronize(st3));   // (the histogram / counter copies are the last thing on either stream)
+  for (int t = 0; t < 2; t++) tm[t].vox.check();   // (a timed-out wait inside the per-cube voxel kernel must not corrupt the map silently)
+  if (*(volatile uint32_t*)h_err.p) { *h_err.p = 0u; throw Error(LOAMX_E_HIP, "map update: a tile's look-back gave up waiting for the tiles before it"); }
+  for (int t = 0; t < 2; t++) {
+    TypeMap& T = tm[t];
+    LX_REQUIRE(T.n == 0 || T.h_hist.p[MCUBES + 1] == upd_n_sub[t], "internal: sub-map size differs from the host cube directory");
+    T.cur = 1 - T.cur;
+    T.n = T.h_hist.p[MCUBES + 6];
+    for (int idx = 0; idx < MCUBES; idx++) T.cube_cnt[idx] = T.h_hist.p[idx];
+  }
+}
+
 int Mapper::insert(const loamx_cloud* corner_last, const loamx_cloud* surf_last, const float pose6[6]) {
   // process() with zero Gauss-Newton launches and a forced pose: the map side alone (:512-593).  Everything of the handle that is NOT
   // the map is put back when the call ends, also when it throws: the iteration limit, the frame counter (an insertion is not a
@@ -702,6 +721,7 @@ int Mapper::insert(const loamx_cloud* corner_last, const loamx_cloud* surf_last,
 }
 
 void Mapper::load_cubes(const loamx_cloud* corner, const loamx_cloud* surf) {
+  finish_update();
   LX_HIP(hipSetDevice(cfg.device));
   hipStream_t st = reg.stream();
   const loamx_cloud* cl[2] = {corner, surf};
@@ -732,6 +752,7 @@ void Mapper::load_cubes(const loamx_cloud* corner, const loamx_cloud* surf) {
 }
 
 int Mapper::get_cubes(int which, loamx_cloud* out) {
+  finish_update();
   LX_REQUIRE(which == 0 || which == 1, "which must be 0 (corner) or 1 (surf)");
   check_cloud(out, false);
   LX_HIP(hipSetDevice(cfg.device));
@@ -759,6 +780,7 @@ struct SnapshotHeader {
 }  // namespace
 
 void Mapper::save_snapshot(const char* path) {
+  finish_update();
   LX_REQUIRE(path && *path, "NULL path");
   LX_HIP(hipSetDevice(cfg.device));
   LX_HIP(hipStreamSynchronize(reg.stream()));
@@ -786,6 +808,7 @@ void Mapper::save_snapshot(const char* path) {
 }
 
 void Mapper::load_snapshot(const char* path) {
+  finish_update();
   LX_REQUIRE(path && *path, "NULL path");
   FILE* f = fopen(path, "rb");
   if (!f) throw Error(LOAMX_E_INVALID, std::string("cannot open ") + path);

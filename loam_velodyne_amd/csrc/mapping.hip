@@ -13,7 +13,13 @@
 #include "registration.cuh"
 #include "api_handles.h"
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <deque>
+#include <exception>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include "host_math.h"
 #include "scan.cuh"
 
@@ -330,11 +336,27 @@ class Mapper {
   // The map update of a sweep (insertion, per-cube re-filtering, the new cube directory) is enqueued behind the registration but NOT waited
   // for: process() returns with the pose and the registered cloud while the update runs on st2 / st3; whoever needs the map next — the
   // next process(), the getters, a snapshot — finishes it first (finish_update: a wait that is normally over long before).
+  // Its ~14 launches and copies cost the host ~60 us: a helper thread of this object enqueues them (behind an event of the
+  // registration's stream) while the calling thread fetches the results.
   bool upd_pending = false;
   uint32_t upd_n_sub[2] = {0, 0};
-  void finish_update();
+  void finish_update();     // the calling thread: the helper has run its job; the update's result is in the host's cube directory
+  void complete_update();   // the wait + the bookkeeping themselves (either thread, behind the helper's enqueue)
+  void compute_surround(const MapWindow& w);
+  struct Helper {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool busy = false, quit = false;
+    std::exception_ptr err;
+    void post(std::function<void()> f);
+    void wait();          // returns when the posted job has run; rethrows what it threw
+    ~Helper();
+  } helper;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   ~Mapper() {
+    try { helper.wait(); } catch (...) {}
     if (st2) { (void)hipStreamSynchronize(st2); (void)hipStreamDestroy(st2); }
     if (st3) { (void)hipStreamSynchronize(st3); (void)hipStreamDestroy(st3); }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -387,7 +409,7 @@ Mapper::Mapper(const loamx_map_config& c) : cfg(c), reg(c.device, 1) {
     tm[t].h_hist.reserve(MCUBES + 16);
     tm[t].out_off.reserve(130);
   }
-  sur_vox.init(reg.stream());
+  sur_vox.init(st3);
   sur_off.reserve(4);
   sur_cnt.reserve(16);
   sur_tiles.reserve(SCAN_SCRATCH_WORDS);
@@ -432,8 +454,32 @@ void Mapper::ensure(TypeMap& t, uint32_t n_map_max, uint32_t n_in) {
   t.vox.reserve(n_map_max + 1, 126);
 }
 
+namespace {
+// LOAMX_MAP_TRACE: host-side stamps of process() (us since entry), printed for every 16th call — where the host's share of a sweep goes
+struct MapTrace {
+  bool on;
+  int n = 0;
+  double t0 = 0;
+  const char* name[16];
+  double at[16];
+  static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  MapTrace() : on(getenv("LOAMX_MAP_TRACE") != nullptr) {}
+  void begin() { if (on) { n = 0; t0 = now(); } }
+  void mark(const char* what) { if (on && n < 16) { name[n] = what; at[n++] = now() - t0; } }
+  void end() {
+    static int calls = 0;
+    if (!on || (calls++ & 15)) return;
+    fprintf(stderr, "[map trace]");
+    for (int k = 0; k < n; k++) fprintf(stderr, " %s %.1f", name[k], at[k]);
+    fprintf(stderr, "\n");
+  }
+};
+}  // namespace
+
 int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res, const DeviceInput* dev) {
   TraceRange trace_range("loamx:mapping:process");
+  static thread_local MapTrace tr;
+  tr.begin();
   if (!dev) {
     check_cloud(corner_last, false);
     check_cloud(surf_last, false);
@@ -441,6 +487,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   if (full_res) check_cloud(full_res, false);
   LX_HIP(hipSetDevice(cfg.device));
   finish_update();
+  tr.mark("finished_update");
   hipStream_t st = reg.stream();
   frame_count++;
   if (frame_count < 1) return LOAMX_SKIPPED;   // _stackFrameNum = 1 (:269-274)
@@ -515,6 +562,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     slot_tag_v = (const uint32_t*)(d_tables.p + o_tag);
   }
 
+  tr.mark("tables");
   MapWindow w;
   for (int a = 0; a < 3; a++) w.cen[a] = cen[a];
   const uint32_t n_in[2] = {dev ? dev->n_corner : corner_last->count, dev ? dev->n_surf : surf_last->count};
@@ -536,6 +584,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     }
   }
 
+  tr.mark("uploaded");
   // ---- partition the map: sub-map | rest | dropped (the two types side by side, as in the update below)
   for (int t = 0; t < 2; t++) ensure(tm[t], tm[t].n + n_in[t] + 64, n_in[t]);
   LX_HIP(hipEventRecord(ev_fork, reg.stream()));   // (behind the look-up tables' copy)
@@ -564,6 +613,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   LX_HIP(hipStreamWaitEvent(reg.stream(), ev_join, 0));
 
   // ---- registration against the sub-map (guard + iterations inside Registrar::run_async)
+  tr.mark("split+index");
   reg.early_exit = true;   // process() is blocking
   // (insert(): the caller's pose goes into the map verbatim — a pipeline pose has had its IMU blend already)
   const bool imu_blend = !imu_history.empty() && !forced_pose;
@@ -579,10 +629,22 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     reg.finish_with_poses(p6);
   }
 
+  tr.mark("registered");
   // ---- map insertion + per-cube re-filtering: corners on st2, surfs on st3, side by side behind the registration — and NOT in front of
   // its results (see upd_pending)
   LX_HIP(hipEventRecord(ev_fork, reg.stream()));
   if (want_full && full_res) reg.download_full_res_async(0);   // (lands while the map is updated)
+  for (int t = 0; t < 2; t++) upd_n_sub[t] = n_sub[t];
+  const uint32_t n_sub0 = n_sub[0], n_sub1 = n_sub[1], n_in0 = n_in[0], n_in1 = n_in[1];
+  // createDownsizedMap (:242-264) is due on every 5th processed frame: the helper goes on to finish the update and cut the surround cloud
+  if (!forced_pose) map_frame_count++;   // (insert() is not a processed frame: no surround cloud is due)
+  fresh_map = false;
+  const bool surround_due = map_frame_count >= 5;
+  if (surround_due) { map_frame_count = 0; fresh_map = true; }
+  upd_pending = true;
+  helper.post([this, n_sub0, n_sub1, n_in0, n_in1, nvalid, w, surround_due]() {
+  LX_HIP(hipSetDevice(cfg.device));
+  const uint32_t n_sub[2] = {n_sub0, n_sub1}, n_in[2] = {n_in0, n_in1};
   LX_HIP(hipStreamWaitEvent(st2, ev_fork, 0));
   LX_HIP(hipStreamWaitEvent(st3, ev_fork, 0));
   for (int t = 1; t >= 0; t--) {   // (the surf map first: its chain is the longer one, and the host needs ~80 us to enqueue either)
@@ -613,14 +675,19 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     const uint32_t max_new = T.n + n_slots + 1;
     hipLaunchKernelGGL(k_map_hist, dim3(std::min<uint32_t>((max_new + 2047) / 2048, 256u)), dim3(256), 0, st, T.tags[nxt].p, T.counters.p + 6, max_new, w, T.hist.p);
     LX_HIP(hipMemcpyAsync(T.h_hist.p, T.hist.p, sizeof(uint32_t) * (MCUBES + 16), hipMemcpyDeviceToHost, st));   // (histogram + the counters behind it: one copy)
-    upd_n_sub[t] = n_sub[t];
   }
-  upd_pending = true;
+  if (surround_due) {
+    complete_update();
+    compute_surround(w);
+  }
+  });
+  tr.mark("update_posted");
 
   // ---- results (the registration's stream: poses, statistics, the registered cloud's copy — not the map update)
   float pose6[6];
   int stats4[4];
   reg.sync();
+  tr.mark("synced");
   reg.download(pose6, stats4);
   LX_HIP(hipGetLastError());
   SweepStats ss;
@@ -638,55 +705,99 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     if (r != LOAMX_OK) rc = r;
   }
 
-  // ---- createDownsizedMap (:242-264): every 5th processed frame
-  if (!forced_pose) map_frame_count++;   // (insert() is not a processed frame: no surround cloud is due)
-  fresh_map = false;
-  if (map_frame_count >= 5) {
-    map_frame_count = 0;
-    finish_update();   // (the surround cloud is cut from the UPDATED map)
-    const uint32_t nc = tm[0].n, nsf = tm[1].n, ntot = nc + nsf;
-    sur_in.reserve(ntot + 1);
-    sur_out.reserve(ntot + 1);
-    sur_flag.reserve(std::max(nc, nsf) + 2);
-    sur_scan.reserve(std::max(nc, nsf) + 2);
-    sur_valid.reserve(ntot + 1);
-    sur_vox.reserve(ntot + 1, 2);
-    for (int t = 0; t < 2; t++) {
-      TypeMap& T = tm[t];
-      const uint32_t n = T.n;
-      uint32_t* cnt = sur_cnt.p + 4 * t;   // [n, total]
-      if (n) {
-        const uint32_t nb = (n + 255) / 256;
-        hipLaunchKernelGGL(k_map_surround_flags, dim3(nb), dim3(256), 0, st, T.tags[T.cur].p, T.counters.p + 6, n, w, sur_lut_v, sur_flag.p);
-        exclusive_scan_u32_n(sur_flag.p, sur_scan.p, sur_tiles.p, cnt, n, st);
-        hipLaunchKernelGGL(k_map_compact, dim3(nb), dim3(256), 0, st, T.pts[T.cur].p, sur_flag.p, sur_scan.p, n, 0u,
-                           t == 0 ? (const uint32_t*)nullptr : (const uint32_t*)(sur_cnt.p + 1), sur_in.p);
-      } else {
-        LX_HIP(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2, st));
-      }
-    }
-    if (ntot) {
-      hipLaunchKernelGGL(k_map_surround_valid, dim3((ntot + 255) / 256), dim3(256), 0, st, sur_valid.p, ntot, sur_cnt.p + 1, sur_cnt.p + 5);
-      const float inv = 1.0f / cfg.corner_filter_size;   // the corner filter, not the map filter (:261)
-      uint32_t zero_off[2] = {0, ntot};
-      LX_HIP(hipMemcpyAsync(sur_off.p, zero_off, sizeof(zero_off), hipMemcpyHostToDevice, st));
-      LX_HIP(hipStreamSynchronize(st));
-      sur_vox.compute_ijk(sur_in.p, sur_valid.p, ntot, sur_off.p, 1, inv, inv);
-      sur_vox.sort_reduce(sur_in.p, sur_valid.p, ntot, sur_off.p, 1, sur_out.p, sur_off.p + 2);
-      uint32_t off[2] = {0, 0};
-      LX_HIP(hipMemcpyAsync(off, sur_off.p + 2, sizeof(off), hipMemcpyDeviceToHost, st));
-      LX_HIP(hipStreamSynchronize(st));
-      sur_vox.check();
-      n_surround = off[1];
-    } else {
-      n_surround = 0;
-    }
-    fresh_map = true;
-  }
+  tr.mark("results");
+  tr.end();
   return rc;
 }
 
+// createDownsizedMap (:242-264): the surround cloud, cut from the UPDATED map.  Runs on the helper thread behind the update (st3; the
+// two host waits in here are why: they would sit in front of the caller's next sweep otherwise)
+void Mapper::compute_surround(const MapWindow& w) {
+  hipStream_t st = st3;
+  const uint32_t nc = tm[0].n, nsf = tm[1].n, ntot = nc + nsf;
+  sur_in.reserve(ntot + 1);
+  sur_out.reserve(ntot + 1);
+  sur_flag.reserve(std::max(nc, nsf) + 2);
+  sur_scan.reserve(std::max(nc, nsf) + 2);
+  sur_valid.reserve(ntot + 1);
+  sur_vox.reserve(ntot + 1, 2);
+  for (int t = 0; t < 2; t++) {
+    TypeMap& T = tm[t];
+    const uint32_t n = T.n;
+    uint32_t* cnt = sur_cnt.p + 4 * t;   // [n, total]
+    if (n) {
+      const uint32_t nb = (n + 255) / 256;
+      hipLaunchKernelGGL(k_map_surround_flags, dim3(nb), dim3(256), 0, st, T.tags[T.cur].p, T.counters.p + 6, n, w, sur_lut_v, sur_flag.p);
+      exclusive_scan_u32_n(sur_flag.p, sur_scan.p, sur_tiles.p, cnt, n, st);
+      hipLaunchKernelGGL(k_map_compact, dim3(nb), dim3(256), 0, st, T.pts[T.cur].p, sur_flag.p, sur_scan.p, n, 0u,
+                         t == 0 ? (const uint32_t*)nullptr : (const uint32_t*)(sur_cnt.p + 1), sur_in.p);
+    } else {
+      LX_HIP(hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 2, st));
+    }
+  }
+  if (ntot) {
+    hipLaunchKernelGGL(k_map_surround_valid, dim3((ntot + 255) / 256), dim3(256), 0, st, sur_valid.p, ntot, sur_cnt.p + 1, sur_cnt.p + 5);
+    const float inv = 1.0f / cfg.corner_filter_size;   // the corner filter, not the map filter (:261)
+    uint32_t zero_off[2] = {0, ntot};
+    LX_HIP(hipMemcpyAsync(sur_off.p, zero_off, sizeof(zero_off), hipMemcpyHostToDevice, st));
+    LX_HIP(hipStreamSynchronize(st));
+    sur_vox.compute_ijk(sur_in.p, sur_valid.p, ntot, sur_off.p, 1, inv, inv);
+    sur_vox.sort_reduce(sur_in.p, sur_valid.p, ntot, sur_off.p, 1, sur_out.p, sur_off.p + 2);
+    uint32_t off[2] = {0, 0};
+    LX_HIP(hipMemcpyAsync(off, sur_off.p + 2, sizeof(off), hipMemcpyDeviceToHost, st));
+    LX_HIP(hipStreamSynchronize(st));
+    sur_vox.check();
+    n_surround = off[1];
+  } else {
+    n_surround = 0;
+  }
+}
+
+void Mapper::Helper::post(std::function<void()> f) {
+  std::unique_lock<std::mutex> lk(mu);
+  if (!th.joinable())
+    th = std::thread([this]() {
+      std::unique_lock<std::mutex> l(mu);
+      for (;;) {
+        cv.wait(l, [this]() { return quit || (busy && job); });
+        if (quit) return;
+        std::function<void()> j = std::move(job);
+        job = nullptr;
+        l.unlock();
+        std::exception_ptr e;
+        try { j(); } catch (...) { e = std::current_exception(); }
+        l.lock();
+        err = e;
+        busy = false;
+        cv.notify_all();
+      }
+    });
+  cv.wait(lk, [this]() { return !busy; });
+  job = std::move(f);
+  busy = true;
+  cv.notify_all();
+}
+void Mapper::Helper::wait() {
+  std::unique_lock<std::mutex> lk(mu);
+  cv.wait(lk, [this]() { return !busy; });
+  if (err) { std::exception_ptr e = err; err = nullptr; std::rethrow_exception(e); }
+}
+Mapper::Helper::~Helper() {
+  {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this]() { return !busy; });
+    quit = true;
+    cv.notify_all();
+  }
+  if (th.joinable()) th.join();
+}
+
 void Mapper::finish_update() {
+  helper.wait();   // (the launches are enqueued by the helper thread; on a surround frame it has completed the update as well)
+  complete_update();
+}
+
+void Mapper::complete_update() {
   if (!upd_pending) return;
   upd_pending = false;
   LX_HIP(hipSetDevice(cfg.device));
@@ -851,6 +962,7 @@ void Mapper::load_snapshot(const char* path) {
 }
 
 int Mapper::get_surround(loamx_cloud* out) {
+  finish_update();
   check_cloud(out, false);
   LX_HIP(hipSetDevice(cfg.device));
   std::vector<float4> tmp(n_surround);

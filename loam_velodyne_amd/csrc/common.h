@@ -67,6 +67,7 @@ template <class T> struct DevBuf {
     if (n <= cap) return;
     size_t ncap = n + n / 4 + 64;
     T* np = nullptr;
+    if (getenv("LOAMX_ALLOC_TRACE")) fprintf(stderr, "[alloc] device buffer %zu -> %zu bytes%s\n", cap * sizeof(T), ncap * sizeof(T), keep ? " (contents kept)" : "");
     LX_HIP(hipMalloc((void**)&np, ncap * sizeof(T)));
     if (keep && p && cap) {
       LX_HIP(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st));

@@ -269,6 +269,7 @@ struct TypeMap {   // one feature type (corner / surf)
   DevBuf<uint32_t> tags[2];
   int cur = 0;
   uint32_t n = 0;             // host copy of the point count (exact after every process())
+  uint32_t room = 0;          // points every buffer of this type has room for (ensure())
   std::vector<uint32_t> cube_cnt = std::vector<uint32_t>(MCUBES, 0);   // host directory, window coordinates
   // per-sweep work buffers
   DevBuf<uint32_t> fin_seg, out_off, hist;
@@ -331,6 +332,7 @@ class Mapper {
   DevBuf<uint8_t> sur_valid;
   VoxelPipeline sur_vox;
   uint32_t n_surround = 0;
+  PinBuf<uint32_t> h_sur;
   PinBuf<uint32_t> h_err;                            // raised by a fused kernel whose look-back gave up (checked behind process()'s synchronisation)
   hipStream_t st2 = nullptr, st3 = nullptr;         // the corner / surf map's update (the sub-map partition: st2 and the registration's stream)
   // The map update of a sweep (insertion, per-cube re-filtering, the new cube directory) is enqueued behind the registration but NOT waited
@@ -436,12 +438,18 @@ void Mapper::shift_counts(int axis, int dir) {
 
 void Mapper::ensure(TypeMap& t, uint32_t n_map_max, uint32_t n_in) {
   hipStream_t st = reg.stream();
+  // A rolling map grows with every sweep that sees something new, and growing a device buffer is a hipFree + hipMalloc: 1.5-2 ms with the
+  // device drained, in front of a 0.3 ms call (measured: four such stalls in 110 sweeps of the live bench with 25 % head room).  Room
+  // is taken in large steps instead — a million points to start with (~100 MB per feature type over all its buffers), doubled when a
+  // map outgrows it — the sub-map's index and the surround cloud's buffers included.
+  if (n_map_max + 1 > t.room) t.room = std::max<uint32_t>(2u * (n_map_max + 1), 1u << 20);
+  const uint32_t room = t.room;
   for (int b = 0; b < 2; b++) {
-    t.pts[b].reserve(n_map_max + 1, st, b == t.cur);
-    t.tags[b].reserve(n_map_max + 1, st, b == t.cur);
+    t.pts[b].reserve(room, st, b == t.cur);
+    t.tags[b].reserve(room, st, b == t.cur);
   }
   {   // chains of the fused split / insert kernels: one word per tile, cleared when the buffer (re)appears
-    const size_t need = std::max<size_t>(n_map_max / MS_TILE, n_in / 256) + 4;
+    const size_t need = std::max<size_t>(room / MS_TILE, n_in / 256) + 4;
     if (need > t.chain_stride) {
       t.chain_stride = need + need / 2;
       t.chain.reserve(3 * t.chain_stride);
@@ -449,29 +457,38 @@ void Mapper::ensure(TypeMap& t, uint32_t n_map_max, uint32_t n_in) {
       t.chain_epoch = 0;
     }
   }
-  t.fin.reserve(n_map_max + 1); t.fin_seg.reserve(n_map_max + 1); t.fin_valid.reserve(n_map_max + 1);
-  t.filt.reserve(n_map_max + 1);
-  t.vox.reserve(n_map_max + 1, 126);
+  t.fin.reserve(room); t.fin_seg.reserve(room); t.fin_valid.reserve(room);
+  t.filt.reserve(room);
+  t.vox.reserve(room, 126);
+  (&t == &tm[0] ? reg.corner_index : reg.surf_index).reserve_points(room);
 }
 
 namespace {
-// LOAMX_MAP_TRACE: host-side stamps of process() (us since entry), printed for every 16th call — where the host's share of a sweep goes
+// LOAMX_MAP_TRACE: host-side stamps of process() (us since entry), averaged over 50 calls and printed — where the host's share of a sweep goes
 struct MapTrace {
   bool on;
-  int n = 0;
+  int n = 0, calls = 0;
   double t0 = 0;
   const char* name[16];
-  double at[16];
+  double at[16], sum[16] = {}, worst = 0;
   static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   MapTrace() : on(getenv("LOAMX_MAP_TRACE") != nullptr) {}
   void begin() { if (on) { n = 0; t0 = now(); } }
   void mark(const char* what) { if (on && n < 16) { name[n] = what; at[n++] = now() - t0; } }
   void end() {
-    static int calls = 0;
-    if (!on || (calls++ & 15)) return;
-    fprintf(stderr, "[map trace]");
-    for (int k = 0; k < n; k++) fprintf(stderr, " %s %.1f", name[k], at[k]);
-    fprintf(stderr, "\n");
+    if (!on) return;
+    for (int k = 0; k < n; k++) sum[k] += at[k];
+    if (n) worst = std::max(worst, at[n - 1]);
+    if (n && at[n - 1] > 700.0) {
+      fprintf(stderr, "[map trace, slow call]");
+      for (int k = 0; k < n; k++) fprintf(stderr, " %s %.1f", name[k], at[k]);
+      fprintf(stderr, "\n");
+    }
+    if (++calls < 50) return;
+    fprintf(stderr, "[map trace, mean of %d calls]", calls);
+    for (int k = 0; k < n; k++) { fprintf(stderr, " %s %.1f", name[k], sum[k] / calls); sum[k] = 0; }
+    fprintf(stderr, " (slowest call %.1f)\n", worst);
+    calls = 0; worst = 0;
   }
 };
 }  // namespace
@@ -587,6 +604,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   tr.mark("uploaded");
   // ---- partition the map: sub-map | rest | dropped (the two types side by side, as in the update below)
   for (int t = 0; t < 2; t++) ensure(tm[t], tm[t].n + n_in[t] + 64, n_in[t]);
+  tr.mark("ensured");
   LX_HIP(hipEventRecord(ev_fork, reg.stream()));   // (behind the look-up tables' copy)
   LX_HIP(hipStreamWaitEvent(st2, ev_fork, 0));
   for (int t = 0; t < 2; t++) {
@@ -607,6 +625,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
       LX_HIP(hipMemsetAsync(T.counters.p, 0, sizeof(uint32_t) * 4, st));
     }
   }
+  tr.mark("split");
   // ... and their grid indices (the corner sub-map's behind its partition on st2)
   reg.set_submap_device_split(tm[0].fin.p, n_sub[0], st2, tm[1].fin.p, n_sub[1], /*bounds_done=*/true);
   LX_HIP(hipEventRecord(ev_join, st2));
@@ -677,8 +696,12 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     LX_HIP(hipMemcpyAsync(T.h_hist.p, T.hist.p, sizeof(uint32_t) * (MCUBES + 16), hipMemcpyDeviceToHost, st));   // (histogram + the counters behind it: one copy)
   }
   if (surround_due) {
+    static const bool trace = getenv("LOAMX_MAP_TRACE") != nullptr;
+    const double t0 = trace ? MapTrace::now() : 0.0;
     complete_update();
+    const double t1 = trace ? MapTrace::now() : 0.0;
     compute_surround(w);
+    if (trace) fprintf(stderr, "[map trace, helper] update completed %.1f us after its enqueue, surround cloud %.1f us\n", t1 - t0, MapTrace::now() - t1);
   }
   });
   tr.mark("update_posted");
@@ -715,12 +738,16 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
 void Mapper::compute_surround(const MapWindow& w) {
   hipStream_t st = st3;
   const uint32_t nc = tm[0].n, nsf = tm[1].n, ntot = nc + nsf;
-  sur_in.reserve(ntot + 1);
-  sur_out.reserve(ntot + 1);
-  sur_flag.reserve(std::max(nc, nsf) + 2);
-  sur_scan.reserve(std::max(nc, nsf) + 2);
-  sur_valid.reserve(ntot + 1);
-  sur_vox.reserve(ntot + 1, 2);
+  const uint32_t room2 = std::max(tm[0].room + tm[1].room, ntot + 2), room1 = std::max(std::max(tm[0].room, tm[1].room), std::max(nc, nsf) + 2);   // (ensure(): room in large steps)
+  sur_in.reserve(room2);
+  sur_out.reserve(room2);
+  sur_flag.reserve(room1);
+  sur_scan.reserve(room1);
+  sur_valid.reserve(room2);
+  sur_vox.reserve(room2, 2);
+  static const bool trace = getenv("LOAMX_MAP_TRACE") != nullptr;
+  const double tq0 = trace ? MapTrace::now() : 0.0;
+  double tq1 = 0;
   for (int t = 0; t < 2; t++) {
     TypeMap& T = tm[t];
     const uint32_t n = T.n;
@@ -738,16 +765,18 @@ void Mapper::compute_surround(const MapWindow& w) {
   if (ntot) {
     hipLaunchKernelGGL(k_map_surround_valid, dim3((ntot + 255) / 256), dim3(256), 0, st, sur_valid.p, ntot, sur_cnt.p + 1, sur_cnt.p + 5);
     const float inv = 1.0f / cfg.corner_filter_size;   // the corner filter, not the map filter (:261)
-    uint32_t zero_off[2] = {0, ntot};
-    LX_HIP(hipMemcpyAsync(sur_off.p, zero_off, sizeof(zero_off), hipMemcpyHostToDevice, st));
-    LX_HIP(hipStreamSynchronize(st));
+    // (offsets up and the result's size down through pinned words of this object: true asynchronous copies, one wait)
+    h_sur.reserve(8);
+    h_sur.p[0] = 0u; h_sur.p[1] = ntot;
+    LX_HIP(hipMemcpyAsync(sur_off.p, h_sur.p, sizeof(uint32_t) * 2, hipMemcpyHostToDevice, st));
     sur_vox.compute_ijk(sur_in.p, sur_valid.p, ntot, sur_off.p, 1, inv, inv);
     sur_vox.sort_reduce(sur_in.p, sur_valid.p, ntot, sur_off.p, 1, sur_out.p, sur_off.p + 2);
-    uint32_t off[2] = {0, 0};
-    LX_HIP(hipMemcpyAsync(off, sur_off.p + 2, sizeof(off), hipMemcpyDeviceToHost, st));
+    LX_HIP(hipMemcpyAsync(h_sur.p + 2, sur_off.p + 2, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, st));
+    if (trace) tq1 = MapTrace::now();
     LX_HIP(hipStreamSynchronize(st));
+    if (trace && MapTrace::now() - tq0 > 600.0) fprintf(stderr, "[map trace, surround] enqueue %.1f us, wait %.1f us (%u points)\n", tq1 - tq0, MapTrace::now() - tq1, ntot);
     sur_vox.check();
-    n_surround = off[1];
+    n_surround = h_sur.p[3];
   } else {
     n_surround = 0;
   }

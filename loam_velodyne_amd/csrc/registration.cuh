@@ -28,6 +28,8 @@ class SubMapIndex {
   // bounds_done: the kernel that produced d_pts has folded every point into d_bounds() as it wrote it (enc_f32 atomicMin / atomicMax on
   // words 0-2 / 3-5; the accumulators are left reset by every build) — the bounding-box launch is skipped
   void build(const float4* d_pts, uint32_t n, bool bounds_done = false);
+  // room for sub-maps of up to n points without another allocation (a live map grows: Mapper::ensure)
+  void reserve_points(uint32_t n) { sorted_.reserve(n); cell_of_.reserve(n); rank_of_.reserve(n); }
   uint32_t* d_bounds() const { return scratch_.p; }
   // exchange contents with another index (buffers, sizes and the streams they are bound to stay with the contents' owner)
   void swap(SubMapIndex& o);

@@ -4,7 +4,7 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 qcol = 'Stream_Id' if 'Stream_Id' in rows[0] and len({r['Stream_Id'] for r in rows}) > 1 else 'Queue_Id'
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), re.sub(r'\(.*', '', r['Kernel_Name'])[-40:], r[qcol]) for r in rows)
-key = sys.argv[3] if len(sys.argv) > 3 else 'k_feat_point'
+key = sys.argv[3] if len(sys.argv) > 3 else 'k_feat_ring'
 idx = [i for i, e in enumerate(ev) if key in e[2]]
 a, b = idx[-4], idx[-3]
 t0, t1 = ev[a][0], ev[b][0]

@@ -3,9 +3,9 @@ import csv, re, sys
 from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), re.sub(r'\(.*', '', r['Kernel_Name'])[-44:]) for r in rows)
-idx = [i for i, e in enumerate(ev) if 'k_feat_point' in e[2]]
+idx = [i for i, e in enumerate(ev) if 'k_feat_ring' in e[2]]
 ev = ev[idx[len(idx) // 2]:]          # second half of the run
-nstep = len([e for e in ev if 'k_feat_point' in e[2]])
+nstep = len([e for e in ev if 'k_feat_ring' in e[2]])
 d = defaultdict(list)
 for e in ev: d[e[2]].append((e[1] - e[0]) / 1e3)
 print('steps', nstep)

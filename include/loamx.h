@@ -75,6 +75,12 @@ int loamx_abi_version(void);
  * build that reads the diagnostic LOAMX_* environment switches, some of which change results; a product library ignores them);
  * rccl=0|1; roctx=0|1.  A harness records it next to its measurements. */
 const char* loamx_build_info(void);
+/* Host memory pinned by the HIP runtime this library runs on (hipHostMalloc / hipHostFree; NULL when there is no device or no
+ * memory): sweeps of packed {stride 16, intensity at 12} records handed over from such memory, and landing areas of that kind for
+ * registered clouds, are copied by DMA from / to where they lie instead of through the handles' staging blocks.  Memory pinned by other
+ * means through the same runtime (hipHostRegister, a framework's pinned allocator) is recognised as well; anything else works as before. */
+void* loamx_host_alloc(size_t bytes);
+void loamx_host_free(void* p);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Feature extraction  (BasicScanRegistration, IMU-less path)
@@ -177,7 +183,10 @@ int loamx_odom_get_stats(loamx_odom* h, int stats[4]);
  * handles on ONE device can hand the clouds from node to node in HBM instead: same data flow, same results bit for bit
  * (tests/test_gpu_linked.py), without the five round trips over PCIe per sweep.
  *   loamx_scanreg_process_linked   the sweep goes up and the extraction is enqueued; returns without waiting.  The feature
- *                                  clouds and the sweep stay in the handle's device buffers.
+ *                                  clouds and the sweep stay in the handle's device buffers.  A sweep of packed {stride 16,
+ *                                  intensity at 12} records in memory the HIP runtime has pinned (hipHostMalloc / hipHostRegister)
+ *                                  is copied by DMA from where it lies and must stay unchanged until loamx_odom_process_linked
+ *                                  has returned; any other cloud has been copied out when this call returns.
  *   loamx_odom_process_linked      waits for `sr`'s extraction (and reports what loamx_scanreg_process would: LOAMX_E_INVALID
  *                                  for non-finite input, ...), runs process() on its clouds and re-projects the sweep's
  *                                  full-resolution cloud to the sweep end (transformToEnd of LaserOdometry.cpp:326) into a
@@ -187,7 +196,8 @@ int loamx_odom_get_stats(loamx_odom* h, int stats[4]);
  *   loamx_map_process_linked       updateOdometry(od's transformSum) + process() on od's last corner / surface clouds and the
  *                                  re-projected full-resolution cloud, ordered behind od's tail on the device.
  *                                  full_res_registered (may be NULL): receives the registered full-resolution cloud
- *                                  (count = capacity in, points out).  `od` may start its next sweep when this has returned.
+ *                                  (count = capacity in, points out; packed records in pinned memory receive it by DMA directly —
+ *                                  loamx_map_process's full_res likewise).  `od` may start its next sweep when this has returned.
  * The host-cloud getters (loamx_odom_get_last_clouds, ...) keep working after the linked calls. */
 int loamx_scanreg_process_linked(loamx_scanreg* h, const loamx_cloud* cloud, const uint32_t* ring_size, uint32_t n_rings);
 int loamx_odom_process_linked(loamx_odom* h, loamx_scanreg* sr);

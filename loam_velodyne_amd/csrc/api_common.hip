@@ -24,6 +24,14 @@ int loamx_device_count(void) {
   return n;
 }
 int loamx_abi_version(void) { return LOAMX_ABI_VERSION; }
+void* loamx_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+void loamx_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
 #define LX_STR2(x) #x
 #define LX_STR(x) LX_STR2(x)
 const char* loamx_build_info(void) {

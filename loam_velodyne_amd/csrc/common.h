@@ -108,6 +108,17 @@ inline bool packed_all_finite(const float4* p, size_t n) {
   for (size_t i = 0; i < n; i++) acc += p[i].x * 0.f + p[i].y * 0.f + p[i].z * 0.f;
   return acc == 0.f;
 }
+// true when [p, p + bytes) is host memory the HIP runtime has pinned (hipHostMalloc, hipHostRegister; torch's pin_memory()): an
+// asynchronous copy from / to it is a DMA straight from / to the caller's buffer — no staging copy by this library or by the runtime
+inline bool host_pinned(const void* p, size_t bytes) {
+  if (!p || !bytes) return false;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (a.type != hipMemoryTypeHost) return false;
+  if (hipPointerGetAttributes(&a, (const char*)p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+inline bool packed_layout(const loamx_cloud* c) { return c->stride == 16 && c->intensity_offset == 12; }
 inline void pack_cloud(const loamx_cloud* c, float4* dst) {
   const char* src = (const char*)c->data;
   if (c->stride == 16 && c->intensity_offset == 12) {   // x y z intensity records: the device layout itself

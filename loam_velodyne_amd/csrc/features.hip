@@ -846,10 +846,15 @@ void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uin
   }
   LX_HIP(hipStreamSynchronize(st_));   // (the staging block and the tables of the previous sweep are free: nothing to wait for unless the caller skipped its results)
   layout_(nsw, ring_size, n_rings);
-  h_cloud_.reserve(n_ + 1);
-  for (uint32_t s = 0; s < nsw; s++) pack_cloud(&clouds[s], h_cloud_.p + h_pt_base_[s]);
+  // one sweep of packed x y z intensity records in memory the runtime has pinned goes up straight from where it lies (the caller
+  // keeps it unchanged until the results of this sweep have been taken); anything else through this object's pinned staging block
+  const bool direct = nsw == 1 && n_ && packed_layout(&clouds[0]) && host_pinned(clouds[0].data, sizeof(float4) * n_);
+  if (!direct) {
+    h_cloud_.reserve(n_ + 1);
+    for (uint32_t s = 0; s < nsw; s++) pack_cloud(&clouds[s], h_cloud_.p + h_pt_base_[s]);
+  }
   allocate_();
-  if (n_) LX_HIP(hipMemcpyAsync(cloud_.p, h_cloud_.p, sizeof(float4) * n_, hipMemcpyHostToDevice, st_));   // (no wait: the kernels follow on the same stream)
+  if (n_) LX_HIP(hipMemcpyAsync(cloud_.p, direct ? clouds[0].data : (const void*)h_cloud_.p, sizeof(float4) * n_, hipMemcpyHostToDevice, st_));   // (no wait: the kernels follow on the same stream)
 }
 
 // One raw revolution (MultiScanRegistration::process, src/lib/MultiScanRegistration.cpp:160-238): records with x, y, z

@@ -652,7 +652,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   // ---- map insertion + per-cube re-filtering: corners on st2, surfs on st3, side by side behind the registration — and NOT in front of
   // its results (see upd_pending)
   LX_HIP(hipEventRecord(ev_fork, reg.stream()));
-  if (want_full && full_res) reg.download_full_res_async(0);   // (lands while the map is updated)
+  if (want_full && full_res) reg.download_full_res_async(0, full_res);   // (lands while the map is updated)
   for (int t = 0; t < 2; t++) upd_n_sub[t] = n_sub[t];
   const uint32_t n_sub0 = n_sub[0], n_sub1 = n_sub[1], n_in0 = n_in[0], n_in1 = n_in[1];
   // createDownsizedMap (:242-264) is due on every 5th processed frame: the helper goes on to finish the update and cut the surround cloud

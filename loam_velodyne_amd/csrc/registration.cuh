@@ -230,7 +230,7 @@ class Registrar {
   void download(float* poses6, int* stats4);
   void download_stats(SweepStats* out);
   int download_full_res(uint32_t sweep, loamx_cloud* out);
-  void download_full_res_async(uint32_t sweep);
+  void download_full_res_async(uint32_t sweep, const loamx_cloud* into = nullptr);   // into: the cloud download_full_res() will be given (a pinned one takes the copy directly)
   void set_submap_device_split(const float4* d_corner, uint32_t nc, hipStream_t corner_stream, const float4* d_surf, uint32_t ns, bool bounds_done = false);
   // down-sampled query clouds of a sweep (device pointers valid until the next run); counts need a sync'd download
   void download_ds(uint32_t sweep, std::vector<float4>& corner_ds, std::vector<float4>& surf_ds);
@@ -271,6 +271,7 @@ class Registrar {
   std::vector<uint32_t> next_full_off_;
   hipEvent_t ev_look_ = nullptr;
   PinBuf<float4> h_full_dl_;      // download_full_res(): pinned landing area of one sweep's registered cloud
+  void* full_dl_direct_ = nullptr;   // download_full_res_async() copied straight into this caller memory
   int full_dl_sweep_ = -1;       // the sweep whose copy download_full_res_async() has enqueued since the clouds were registered (-1: none)
   VoxelPipeline vox_;
   // the stack clouds' voxel grid normally takes the bucketed path (voxbucket.cuh); a run that gives up is repeated through the

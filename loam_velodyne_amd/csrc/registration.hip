@@ -1657,11 +1657,19 @@ void Registrar::download(float* poses6, int* stats4) {
 // The registered full-resolution cloud of one sweep, asked for ahead of time: the copy into pinned memory is enqueued behind the
 // registration's last launch and overlaps whatever the caller enqueues next (Mapper: the map update); download_full_res() of the same
 // sweep then only waits for the stream and unpacks.
-void Registrar::download_full_res_async(uint32_t sweep) {
+void Registrar::download_full_res_async(uint32_t sweep, const loamx_cloud* into) {
   LX_REQUIRE(sweep < n_sweeps_, "sweep index out of range");
   const uint32_t a = h_full_off_[sweep], b = h_full_off_[sweep + 1];
-  h_full_dl_.reserve((size_t)(b - a) + 1);
-  if (b > a) LX_HIP(hipMemcpyAsync(h_full_dl_.p, full_.p + a, sizeof(float4) * (b - a), hipMemcpyDeviceToHost, st_));
+  // a landing area of packed records in runtime-pinned memory with room for the cloud takes the copy itself (download_full_res() then
+  // only waits); anything else goes through this object's pinned block and is unpacked there
+  full_dl_direct_ = nullptr;
+  if (into && b > a && into->count >= b - a && packed_layout(into) && host_pinned(into->data, sizeof(float4) * (b - a))) {
+    LX_HIP(hipMemcpyAsync(into->data, full_.p + a, sizeof(float4) * (b - a), hipMemcpyDeviceToHost, st_));
+    full_dl_direct_ = into->data;
+  } else {
+    h_full_dl_.reserve((size_t)(b - a) + 1);
+    if (b > a) LX_HIP(hipMemcpyAsync(h_full_dl_.p, full_.p + a, sizeof(float4) * (b - a), hipMemcpyDeviceToHost, st_));
+  }
   full_dl_sweep_ = (int)sweep;
 }
 
@@ -1670,12 +1678,15 @@ int Registrar::download_full_res(uint32_t sweep, loamx_cloud* out) {
   check_cloud(out, false);
   fetch_results();
   const uint32_t a = h_full_off_[sweep], b = h_full_off_[sweep + 1];
-  if (full_dl_sweep_ != (int)sweep) {   // not asked for ahead of time (or the clouds were registered again since): copy now
+  const bool landed = full_dl_sweep_ == (int)sweep && full_dl_direct_ && full_dl_direct_ == out->data;   // the copy went straight into `out`
+  if (full_dl_sweep_ != (int)sweep || (full_dl_direct_ && !landed)) {   // not asked for ahead of time (or the clouds were registered again since, or into other memory): copy now
     h_full_dl_.reserve((size_t)(b - a) + 1);   // (pinned: a copy into pageable memory is staged by the runtime)
     if (b > a) LX_HIP(hipMemcpyAsync(h_full_dl_.p, full_.p + a, sizeof(float4) * (b - a), hipMemcpyDeviceToHost, st_));
   }
   full_dl_sweep_ = -1;
+  full_dl_direct_ = nullptr;
   LX_HIP(hipStreamSynchronize(st_));
+  if (landed) { out->count = b - a; return LOAMX_OK; }
   return unpack_cloud(h_full_dl_.p, b - a, out);
 }
 

@@ -81,6 +81,30 @@ def device_count() -> int:
     return int(lib().loamx_device_count())
 
 
+def pinned_empty(shape, dtype=np.float32):
+    """numpy array in host memory pinned by the library's HIP runtime (loamx_host_alloc): the entry points copy straight from / to such
+    arrays (DMA) instead of through their staging blocks.  Freed when the array and every view of it are gone."""
+    import weakref
+    L = lib()
+    L.loamx_host_alloc.restype = C.c_void_p
+    L.loamx_host_alloc.argtypes = [C.c_size_t]
+    L.loamx_host_free.argtypes = [C.c_void_p]
+    shape = tuple(int(x) for x in (shape if hasattr(shape, "__len__") else (shape,)))
+    nbytes = max(int(np.prod(shape)) * np.dtype(dtype).itemsize, 1)
+    ptr = L.loamx_host_alloc(nbytes)
+    if not ptr:
+        raise LoamxError(E_HIP, "loamx_host_alloc failed")
+    buf = (C.c_char * nbytes).from_address(ptr)
+    weakref.finalize(buf, L.loamx_host_free, C.c_void_p(ptr))
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+def pinned_copy(a, dtype=np.float32):
+    out = pinned_empty(np.shape(a), dtype)
+    out[...] = a
+    return out
+
+
 def build_info() -> dict:
     """loamx_build_info() as a dict: abi, diag (1: a diagnostic build that reads the result-changing LOAMX_* switches), rccl, roctx."""
     return dict(kv.split("=", 1) for kv in lib().loamx_build_info().decode().split(";") if kv)

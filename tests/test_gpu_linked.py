@@ -94,3 +94,41 @@ def test_linked_chain_without_registered_cloud_and_errors():
     with pytest.raises(loamx.LoamxError) as e:
         od.process_linked(sr)
     assert e.value.code == loamx.E_INVALID
+
+
+def test_pinned_caller_memory_is_copied_from_and_to_directly():
+    """sweeps and landing areas in memory the runtime has pinned (loamx_host_alloc) take the direct-DMA path of the upload and of
+    the registered cloud's download: same results as pageable memory through the library's staging blocks, for both kinds of entry point"""
+    world = synth.World(half_extent=65.0)
+    cm, sm, sweeps = _chains(world, "VLP-16", 4, 40_000)
+    pin = loamx.pinned_copy
+
+    results = []
+    for pinned in (False, True):
+        sr, od, mp = loamx.ScanRegistration(), loamx.LaserOdometry(), loamx.LaserMapping()
+        sr2, od2, mp2 = loamx.ScanRegistration(), loamx.LaserOdometry(), loamx.LaserMapping()
+        mp.load_cubes(cm, sm)
+        mp2.load_cubes(cm, sm)
+        n_max = max(len(s.points) for s in sweeps)
+        landing = pin(np.zeros((n_max, 4), np.float32)) if pinned else np.zeros((n_max, 4), np.float32)
+        out = []
+        for sw in sweeps:
+            p = pin(sw.points) if pinned else sw.points.copy()
+            before = p.copy()
+            sr.process_linked(p, sw.ring_sizes)
+            od.process_linked(sr)
+            rc, reg = mp.process_linked(od, landing)
+            assert np.array_equal(p, before)            # the caller's sweep is only read
+            # host-message entry points with the same kind of memory; the registration in place in a pinned copy of the re-projected cloud
+            f = sr2.process(p, sw.ring_sizes)
+            od2.process(f)
+            lc, ls = od2.last_clouds()
+            full = od2.transform_to_end(f["full"])
+            full = pin(full) if pinned else full
+            mp2.update_odometry(od2.transform_sum)
+            rc2, reg2 = mp2.process(lc, ls, full, inplace=True)
+            assert rc == rc2 and np.array_equal(reg, reg2)
+            out.append((np.array(od.transform_sum), mp.transform("aft"), reg.copy()))
+        results.append(out)
+    for a, b in zip(*results):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])

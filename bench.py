@@ -310,10 +310,14 @@ def main():
             for p in pipes:
                 p.swap_frozen()
             sync_all()
+        import gc
+        gc.collect()
+        gc.disable()   # (as timeit does: a collection over this process's heap — torch is loaded — pauses the harness for tens of ms, a 9 ms window cannot absorb that)
         t0 = time.perf_counter()
         on_all(timed)
         sync_all()
         r["elapsed"] = lxdist.max_over_ranks(time.perf_counter() - t0, dist, dev)
+        gc.enable()
         if pool is not None:
             pool.shutdown()
         for a in racc:   # stage times: mean over the handles (they run side by side); counts: summed
@@ -871,9 +875,12 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
         stage(t)
     assert p.lookahead_depth() == AHEAD - 1, "the streaming ring's look-ahead depth changed: adapt AHEAD"
     stager = ThreadPoolExecutor(max_workers=1)   # stage_step(t + AHEAD) runs beside step(t)
+    import gc
     t0 = None
     mapped_pts = 0
     host = np.zeros(3)
+    gc.collect()
+    gc.disable()   # (see the resident window)
     for t in range(T):
         if t == 1 + W:   # steady state: the pipeline is NOT emptied here (steps t .. t+6 are staged, the look-ahead has run as far as it
             p.drain_lookahead()   # may, copies may be in flight — as in production); the window ends the same way plus everything landed,
@@ -901,6 +908,7 @@ def pcie_inclusive_run(torch, loamx, local_rank, map_t, n_corner, n_surf, sweeps
     p.wait_downloads()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     elapsed_local = elapsed
     elapsed = lxdist.max_over_ranks(elapsed, dist, dev)
     n_direct, n_hip = p.download_counts()

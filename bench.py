@@ -639,6 +639,7 @@ def run_live(args):
         r["elapsed"] = time.perf_counter() - t0
         gc.enable()
         r["aft"] = mp.transform("aft")
+        r["speculation"] = mp.speculation()
         return r
 
     host = run_chain(False)
@@ -658,6 +659,9 @@ def run_live(args):
                                "the timed region), the clouds between the three handles handed on in HBM (loamx_*_process_linked)",
                    "stage_ms_per_sweep": {"features_enqueue": round(stage[0] / K * 1e3, 4), "features_wait_and_odometry": round(stage[1] / K * 1e3, 4), "mapping": round(stage[2] / K * 1e3, 4),
                                           "harness_between_calls": round(run["other"] / K * 1e3, 4)},
+                   "partition_prepared_ahead": {"adopted": run["speculation"][0], "redone": run["speculation"][1],
+                                                "what": "sweeps (warm-up included) whose map partition + sub-map index had been built behind the previous sweep's "
+                                                        "update for the predicted pose and were adopted because the true pose's plan was identical / sweeps that partitioned afresh"},
                    "host_message_chain": {"sweeps_per_s": round(K / host["elapsed"], 2), "ms_per_step": round(host["elapsed"] / K * 1e3, 4),
                                           "stage_ms_per_sweep": {"features": round(host["stage"][0] / K * 1e3, 4), "odometry": round(host["stage"][1] / K * 1e3, 4),
                                                                  "mapping": round(host["stage"][2] / K * 1e3, 4), "harness_between_calls": round(host["other"] / K * 1e3, 4)},

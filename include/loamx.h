@@ -232,6 +232,11 @@ int loamx_map_update_odometry(loamx_map* h, const float transform_sum[6]);
 int loamx_map_process(loamx_map* h, const loamx_cloud* corner_last, const loamx_cloud* surf_last, loamx_cloud* full_res);
 /* see "Linked nodes" above */
 int loamx_map_process_linked(loamx_map* h, loamx_odom* od, loamx_cloud* full_res_registered);
+/* Behind a sweep's map update the handle prepares the NEXT sweep's map partition and sub-map index for the pose it predicts (constant
+ * odometry velocity); the next process() adopts that work when the plan of the true pose — cube window, valid cubes, their order and
+ * sizes — equals the predicted one entry by entry, and partitions afresh otherwise: results never depend on it.  counts[0] = sweeps
+ * that adopted a prepared partition, counts[1] = sweeps whose prediction missed.  LOAMX_MAP_NO_SPECULATION=1 switches it off. */
+int loamx_map_get_speculation(loamx_map* h, uint64_t counts[2]);
 /* The map side of process() alone — the merge step of a map epoch (collective 3): a sweep that was registered elsewhere
  * (the batched pipeline, against a frozen copy of this map) is stacked, down-sized, inserted into the cubes with the GIVEN pose
  * (rx, ry, rz, tx, ty, tz = its transformAftMapped) and the touched cubes are re-filtered, exactly as process() does after its

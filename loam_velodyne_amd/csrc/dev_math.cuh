@@ -558,7 +558,9 @@ typedef unsigned xrec_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void xrec_store(xrec_t* p, double v, unsigned tag) {
   xrec_t r;
   r.x = tag; r.y = (unsigned)__double2loint(v); r.z = (unsigned)__double2hiint(v); r.w = tag;
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
+  // (s_nop 1: a store of more than 64 bits must not be followed at once by a write to its data registers — the compiler pads its own
+  // stores, it cannot see into this statement)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
 }
 __device__ __forceinline__ xrec_t xrec_load(const xrec_t* p) {
   xrec_t r;

@@ -321,8 +321,42 @@ class Mapper {
   }
   uint32_t last_sub[2] = {0, 0};
   TypeMap tm[2];
-  DevBuf<char> d_tables;      // slot look-up table (short[MCUBES]) | surround flags (uint8[MCUBES]) | cube tags of the valid slots
-  PinBuf<char> h_tables;
+  // slot look-up table (short[MCUBES]) | surround flags (uint8[MCUBES]) | cube tags of the valid slots — two sets: the one the current
+  // sweep's kernels read and the one a speculative partition (below) was given
+  DevBuf<char> d_tables[2];
+  PinBuf<char> h_tables[2];
+  int tab_cur = 0;
+  // What a sweep's pose decides about the map before anything is registered: the cube window, the valid cubes of the 5x5x5
+  // neighbourhood in the reference's order (:443-500), their slots, the sub-map's size.
+  struct Plan {
+    int cen[3] = {0, 0, 0};
+    int nvalid = 0;
+    std::vector<short> lut;
+    std::vector<uint8_t> slut;
+    std::vector<uint32_t> stag;
+    uint32_t n_sub[2] = {0, 0};
+    bool same_as(const Plan& o) const {
+      return cen[0] == o.cen[0] && cen[1] == o.cen[1] && cen[2] == o.cen[2] && nvalid == o.nvalid && n_sub[0] == o.n_sub[0] &&
+             n_sub[1] == o.n_sub[1] && lut == o.lut && slut == o.slut && stag == o.stag;
+    }
+  };
+  // may_shift = false: give up (return false) when the cube window would have to move first
+  bool make_plan(const HTwist& pose, bool may_shift, Plan& out);
+  // tables up (set `set`), partition of both feature types, their grid indices: everything of a sweep that depends on the plan alone
+  void enqueue_partition(const Plan& plan, int set, const uint32_t n_in_room[2]);
+  // SPECULATION: the partition and the index build of the NEXT sweep depend only on the map as this sweep's update leaves it and on the
+  // valid-cube list of the next pose — discrete outputs of a pose that moves by centimetres per sweep.  The helper thread predicts the
+  // next transformTobeMapped (constant-velocity odometry through transformAssociateToMap), plans for it and enqueues partition + index
+  // behind the update, while the caller is busy with the next sweep's extraction and odometry; the next process() plans for the TRUE pose
+  // and adopts the prepared work when — and only when — the two plans are equal in every entry (the prepared buffers are then exactly
+  // what it would have produced); otherwise it partitions as before.  ~60 us of host enqueue + ~40 us of device work off the sweep's path.
+  Plan spec_plan;
+  bool spec_valid = false;
+  bool spec_enabled = getenv("LOAMX_MAP_NO_SPECULATION") == nullptr;   // (read when the handle is made; result-neutral: a prepared partition is only ever adopted when it is the one the sweep would build)
+  uint64_t spec_hits = 0, spec_misses = 0;
+  float sum_prev6[6] = {0, 0, 0, 0, 0, 0};   // transformSum of the previous processed sweep (the prediction's velocity)
+  bool have_sum_prev = false;
+  struct SpecInputs { float sum6[6], sum_prev6[6]; HTwist bef, aft; bool ok = false, ready = false; uint32_t n_in_room[2] = {0, 0}; } spec_in;   // (guarded by helper.mu)
   const short* slot_lut_v = nullptr;
   const uint8_t* sur_lut_v = nullptr;
   const uint32_t* slot_tag_v = nullptr;
@@ -505,85 +539,30 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   LX_HIP(hipSetDevice(cfg.device));
   finish_update();
   tr.mark("finished_update");
-  hipStream_t st = reg.stream();
   frame_count++;
   if (frame_count < 1) return LOAMX_SKIPPED;   // _stackFrameNum = 1 (:269-274)
   frame_count = 0;
 
   if (forced_pose) tobe.set(forced_pose);
   else transform_associate_to_map(sum, bef, aft, incre, tobe);
-  const Pose guess = tobe.pose();
-
-  // pointOnYAxis (:294-298)
-  float py[3] = {0.f, 10.f, 0.f};
-  to_map(guess, py[0], py[1], py[2]);
-
-  int cc[3] = {cube_abs(tobe.pos.x) + cen[0], cube_abs(tobe.pos.y) + cen[1], cube_abs(tobe.pos.z) + cen[2]};
-  const int dims[3] = {MW, MH, MD};
-  for (int a = 0; a < 3; a++) {
-    while (cc[a] < 3) { shift_counts(a, +1); cc[a]++; cen[a]++; }
-    while (cc[a] >= dims[a] - 3) { shift_counts(a, -1); cc[a]--; cen[a]--; }
-  }
-
-  // 5x5x5 neighbourhood, FOV test on the cube corners (:443-500); valid list in the reference's i->j->k order
-  std::vector<short> lut(MCUBES, -1);
-  std::vector<uint8_t> slut(MCUBES, 0);
-  std::vector<uint32_t> stag;
-  int nvalid = 0;
-  for (int i = cc[0] - 2; i <= cc[0] + 2; i++)
-    for (int j = cc[1] - 2; j <= cc[1] + 2; j++)
-      for (int k = cc[2] - 2; k <= cc[2] + 2; k++) {
-        if (i < 0 || i >= MW || j < 0 || j >= MH || k < 0 || k >= MD) continue;
-        const float centerX = 50.0f * (i - cen[0]), centerY = 50.0f * (j - cen[1]), centerZ = 50.0f * (k - cen[2]);
-        bool in_fov = false;
-        for (int ii = -1; ii <= 1; ii += 2)
-          for (int jj = -1; jj <= 1; jj += 2)
-            for (int kk = -1; kk <= 1; kk += 2) {
-              const float cx = centerX + 25.0f * ii, cy = centerY + 25.0f * jj, cz = centerZ + 25.0f * kk;
-              const float ax = tobe.pos.x - cx, ay = tobe.pos.y - cy, az = tobe.pos.z - cz;
-              const float s1 = ax * ax + ay * ay + az * az;
-              const float bx = py[0] - cx, by = py[1] - cy, bz = py[2] - cz;
-              const float s2 = bx * bx + by * by + bz * bz;
-              const float check1 = 100.0f + s1 - s2 - 10.0f * std::sqrt(3.0f) * std::sqrt(s1);
-              const float check2 = 100.0f + s1 - s2 + 10.0f * std::sqrt(3.0f) * std::sqrt(s1);
-              if (check1 < 0 && check2 > 0) in_fov = true;
-            }
-        const int idx = i + MW * j + MW * MH * k;
-        if (in_fov) {
-          lut[idx] = (short)nvalid++;
-          stag.push_back(pack_tag(i - cen[0], j - cen[1], k - cen[2]));
-        }
-        slut[idx] = 1;
-      }
-  if (stag.empty()) stag.push_back(0);
-  uint32_t n_sub[2] = {0, 0};
-  for (int t = 0; t < 2; t++)
-    for (int idx = 0; idx < MCUBES; idx++)
-      if (lut[idx] >= 0) n_sub[t] += tm[t].cube_cnt[idx];
+  Plan plan;
+  make_plan(tobe, /*may_shift=*/true, plan);
+  const int nvalid = plan.nvalid;
+  uint32_t n_sub[2] = {plan.n_sub[0], plan.n_sub[1]};
   last_sub[0] = n_sub[0];
   last_sub[1] = n_sub[1];
-
-  // the three tables travel as one block through pinned memory owned by this object (the previous call's copy has completed: every
-  // process() ends synchronised) — no host wait here
-  {
-    const size_t o_sur = sizeof(short) * MCUBES, o_tag = (o_sur + MCUBES + 3) & ~(size_t)3, bytes = o_tag + sizeof(uint32_t) * 128;
-    h_tables.reserve(bytes);
-    d_tables.reserve(bytes);
-    LX_REQUIRE(stag.size() <= 128, "internal: more than 125 valid cubes");
-    memcpy(h_tables.p, lut.data(), sizeof(short) * MCUBES);
-    memcpy(h_tables.p + o_sur, slut.data(), MCUBES);
-    memcpy(h_tables.p + o_tag, stag.data(), sizeof(uint32_t) * stag.size());
-    LX_HIP(hipMemcpyAsync(d_tables.p, h_tables.p, bytes, hipMemcpyHostToDevice, st));
-    slot_lut_v = (const short*)d_tables.p;
-    sur_lut_v = (const uint8_t*)(d_tables.p + o_sur);
-    slot_tag_v = (const uint32_t*)(d_tables.p + o_tag);
-  }
-
-  tr.mark("tables");
+  tr.mark("planned");
   MapWindow w;
   for (int a = 0; a < 3; a++) w.cen[a] = cen[a];
   const uint32_t n_in[2] = {dev ? dev->n_corner : corner_last->count, dev ? dev->n_surf : surf_last->count};
   const bool want_full = dev ? dev->n_full != 0 : (full_res && full_res->count);
+
+  // a partition prepared for the predicted pose is this sweep's own if the plans agree entry by entry (and the sweep fits the room the
+  // buffers were given: ensure() must not move them)
+  const bool adopt = spec_valid && plan.same_as(spec_plan) && tm[0].n + n_in[0] + 65 <= tm[0].room && tm[1].n + n_in[1] + 65 <= tm[1].room;
+  if (spec_valid) (adopt ? spec_hits : spec_misses)++;
+  spec_valid = false;
+  if (adopt) tab_cur ^= 1;   // (the prepared tables are the current ones now; slot_lut_v / sur_lut_v / slot_tag_v point into them already)
 
   // the sweep's clouds and the guess go up first: the copies run while this thread is still enqueuing the partition (the chain
   // of short launches below is bound by the host's launch rate, not by the device)
@@ -600,39 +579,11 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
       reg.upload(1, corner_last, surf_last, full_res, g6, false);
     }
   }
-
   tr.mark("uploaded");
-  // ---- partition the map: sub-map | rest | dropped (the two types side by side, as in the update below)
-  for (int t = 0; t < 2; t++) ensure(tm[t], tm[t].n + n_in[t] + 64, n_in[t]);
-  tr.mark("ensured");
-  LX_HIP(hipEventRecord(ev_fork, reg.stream()));   // (behind the look-up tables' copy)
-  LX_HIP(hipStreamWaitEvent(st2, ev_fork, 0));
-  for (int t = 0; t < 2; t++) {
-    TypeMap& T = tm[t];
-    hipStream_t st = t == 0 ? st2 : reg.stream();
-    const int cur = T.cur, nxt = 1 - cur;
-    if (T.n) {
-      const uint32_t nb = (T.n + 255) / 256;
-      (void)nb;
-      if (++T.chain_epoch >= (1u << 30) - 2u) {   // (the chains' words carry a 30-bit epoch: cleared on the stream before it comes round)
-        LX_HIP(hipMemsetAsync(T.chain.p, 0, sizeof(unsigned long long) * T.chain.cap, st));
-        T.chain_epoch = 1;
-      }
-      hipLaunchKernelGGL(k_map_split, dim3((T.n + MS_TILE - 1) / MS_TILE), dim3(256), 0, st, T.pts[cur].p, T.tags[cur].p, T.n, w, slot_lut_v, T.fin.p,
-                         T.fin_seg.p, T.fin_valid.p, T.pts[nxt].p, T.tags[nxt].p, (t == 0 ? reg.corner_index : reg.surf_index).d_bounds(),
-                         T.chain.p, T.chain.p + T.chain_stride, (unsigned long long)T.chain_epoch, T.counters.p, h_err.p);
-    } else {
-      LX_HIP(hipMemsetAsync(T.counters.p, 0, sizeof(uint32_t) * 4, st));
-    }
-  }
-  tr.mark("split");
-  // ... and their grid indices (the corner sub-map's behind its partition on st2)
-  reg.set_submap_device_split(tm[0].fin.p, n_sub[0], st2, tm[1].fin.p, n_sub[1], /*bounds_done=*/true);
-  LX_HIP(hipEventRecord(ev_join, st2));
-  LX_HIP(hipStreamWaitEvent(reg.stream(), ev_join, 0));
+  if (!adopt) enqueue_partition(plan, tab_cur, n_in);
+  tr.mark(adopt ? "partition_adopted" : "partition+index");
 
   // ---- registration against the sub-map (guard + iterations inside Registrar::run_async)
-  tr.mark("split+index");
   reg.early_exit = true;   // process() is blocking
   // (insert(): the caller's pose goes into the map verbatim — a pipeline pose has had its IMU blend already)
   const bool imu_blend = !imu_history.empty() && !forced_pose;
@@ -661,7 +612,21 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   const bool surround_due = map_frame_count >= 5;
   if (surround_due) { map_frame_count = 0; fresh_map = true; }
   upd_pending = true;
-  helper.post([this, n_sub0, n_sub1, n_in0, n_in1, nvalid, w, surround_due]() {
+  const bool speculate = !forced_pose && spec_enabled;
+  {
+    std::lock_guard<std::mutex> lk(helper.mu);
+    spec_in.ready = false;
+    spec_in.ok = false;
+  }
+  struct SpecRelease {   // whatever happens below, the helper must not wait for this sweep's results for ever
+    Mapper* m;
+    ~SpecRelease() {
+      std::lock_guard<std::mutex> lk(m->helper.mu);
+      m->spec_in.ready = true;
+      m->helper.cv.notify_all();
+    }
+  } spec_release{this};
+  helper.post([this, n_sub0, n_sub1, n_in0, n_in1, nvalid, w, surround_due, speculate]() {
   LX_HIP(hipSetDevice(cfg.device));
   const uint32_t n_sub[2] = {n_sub0, n_sub1}, n_in[2] = {n_in0, n_in1};
   LX_HIP(hipStreamWaitEvent(st2, ev_fork, 0));
@@ -703,6 +668,28 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     compute_surround(w);
     if (trace) fprintf(stderr, "[map trace, helper] update completed %.1f us after its enqueue, surround cloud %.1f us\n", t1 - t0, MapTrace::now() - t1);
   }
+  if (speculate) {   // the next sweep's partition + index for the predicted pose (see spec_plan)
+    complete_update();
+    SpecInputs in;
+    {
+      std::unique_lock<std::mutex> lk(helper.mu);
+      helper.cv.wait(lk, [this]() { return spec_in.ready; });
+      in = spec_in;
+    }
+    if (in.ok) {
+      float p6[6];
+      for (int k = 0; k < 6; k++) p6[k] = in.sum6[k] + (in.sum6[k] - in.sum_prev6[k]);
+      HTwist sum_pred, incre_tmp, tobe_pred;
+      sum_pred.set(p6);
+      transform_associate_to_map(sum_pred, in.bef, in.aft, incre_tmp, tobe_pred);
+      Plan sp;
+      if (make_plan(tobe_pred, /*may_shift=*/false, sp)) {
+        enqueue_partition(sp, tab_cur ^ 1, in.n_in_room);
+        spec_plan = std::move(sp);
+        spec_valid = true;
+      }
+    }
+  }
   });
   tr.mark("update_posted");
 
@@ -723,6 +710,17 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     bef = sum;
     aft = tobe;
   }
+  if (speculate) {   // what the prediction needs of this sweep (the helper waits for it behind the update)
+    std::lock_guard<std::mutex> lk(helper.mu);
+    sum.get(spec_in.sum6);
+    for (int k = 0; k < 6; k++) spec_in.sum_prev6[k] = have_sum_prev ? sum_prev6[k] : spec_in.sum6[k];
+    spec_in.bef = bef;
+    spec_in.aft = aft;
+    spec_in.n_in_room[0] = 2 * n_in[0] + 1024;
+    spec_in.n_in_room[1] = 2 * n_in[1] + 1024;
+    spec_in.ok = true;
+  }
+  if (!forced_pose) { sum.get(sum_prev6); have_sum_prev = true; }
   if (want_full && full_res) {
     int r = reg.download_full_res(0, full_res);
     if (r != LOAMX_OK) rc = r;
@@ -731,6 +729,106 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   tr.mark("results");
   tr.end();
   return rc;
+}
+
+bool Mapper::make_plan(const HTwist& pose_tw, bool may_shift, Plan& out) {
+  const Pose guess = pose_tw.pose();
+  // pointOnYAxis (:294-298)
+  float py[3] = {0.f, 10.f, 0.f};
+  to_map(guess, py[0], py[1], py[2]);
+
+  int cc[3] = {cube_abs(pose_tw.pos.x) + cen[0], cube_abs(pose_tw.pos.y) + cen[1], cube_abs(pose_tw.pos.z) + cen[2]};
+  const int dims[3] = {MW, MH, MD};
+  for (int a = 0; a < 3; a++) {
+    if (!may_shift && (cc[a] < 3 || cc[a] >= dims[a] - 3)) return false;
+    while (cc[a] < 3) { shift_counts(a, +1); cc[a]++; cen[a]++; }
+    while (cc[a] >= dims[a] - 3) { shift_counts(a, -1); cc[a]--; cen[a]--; }
+  }
+  for (int a = 0; a < 3; a++) out.cen[a] = cen[a];
+
+  // 5x5x5 neighbourhood, FOV test on the cube corners (:443-500); valid list in the reference's i->j->k order
+  out.lut.assign(MCUBES, -1);
+  out.slut.assign(MCUBES, 0);
+  out.stag.clear();
+  int nvalid = 0;
+  for (int i = cc[0] - 2; i <= cc[0] + 2; i++)
+    for (int j = cc[1] - 2; j <= cc[1] + 2; j++)
+      for (int k = cc[2] - 2; k <= cc[2] + 2; k++) {
+        if (i < 0 || i >= MW || j < 0 || j >= MH || k < 0 || k >= MD) continue;
+        const float centerX = 50.0f * (i - cen[0]), centerY = 50.0f * (j - cen[1]), centerZ = 50.0f * (k - cen[2]);
+        bool in_fov = false;
+        for (int ii = -1; ii <= 1; ii += 2)
+          for (int jj = -1; jj <= 1; jj += 2)
+            for (int kk = -1; kk <= 1; kk += 2) {
+              const float cx = centerX + 25.0f * ii, cy = centerY + 25.0f * jj, cz = centerZ + 25.0f * kk;
+              const float ax = pose_tw.pos.x - cx, ay = pose_tw.pos.y - cy, az = pose_tw.pos.z - cz;
+              const float s1 = ax * ax + ay * ay + az * az;
+              const float bx = py[0] - cx, by = py[1] - cy, bz = py[2] - cz;
+              const float s2 = bx * bx + by * by + bz * bz;
+              const float check1 = 100.0f + s1 - s2 - 10.0f * std::sqrt(3.0f) * std::sqrt(s1);
+              const float check2 = 100.0f + s1 - s2 + 10.0f * std::sqrt(3.0f) * std::sqrt(s1);
+              if (check1 < 0 && check2 > 0) in_fov = true;
+            }
+        const int idx = i + MW * j + MW * MH * k;
+        if (in_fov) {
+          out.lut[idx] = (short)nvalid++;
+          out.stag.push_back(pack_tag(i - cen[0], j - cen[1], k - cen[2]));
+        }
+        out.slut[idx] = 1;
+      }
+  if (out.stag.empty()) out.stag.push_back(0);
+  LX_REQUIRE(out.stag.size() <= 128, "internal: more than 125 valid cubes");
+  out.nvalid = nvalid;
+  for (int t = 0; t < 2; t++) {
+    out.n_sub[t] = 0;
+    for (int idx = 0; idx < MCUBES; idx++)
+      if (out.lut[idx] >= 0) out.n_sub[t] += tm[t].cube_cnt[idx];
+  }
+  return true;
+}
+
+void Mapper::enqueue_partition(const Plan& plan, int set, const uint32_t n_in_room[2]) {
+  hipStream_t st = reg.stream();
+  // the three tables travel as one block through pinned memory owned by this object (its previous copy from this set has completed:
+  // a whole sweep with its waits lies in between) — no host wait here
+  {
+    const size_t o_sur = sizeof(short) * MCUBES, o_tag = (o_sur + MCUBES + 3) & ~(size_t)3, bytes = o_tag + sizeof(uint32_t) * 128;
+    h_tables[set].reserve(bytes);
+    d_tables[set].reserve(bytes);
+    memcpy(h_tables[set].p, plan.lut.data(), sizeof(short) * MCUBES);
+    memcpy(h_tables[set].p + o_sur, plan.slut.data(), MCUBES);
+    memcpy(h_tables[set].p + o_tag, plan.stag.data(), sizeof(uint32_t) * plan.stag.size());
+    LX_HIP(hipMemcpyAsync(d_tables[set].p, h_tables[set].p, bytes, hipMemcpyHostToDevice, st));
+    slot_lut_v = (const short*)d_tables[set].p;
+    sur_lut_v = (const uint8_t*)(d_tables[set].p + o_sur);
+    slot_tag_v = (const uint32_t*)(d_tables[set].p + o_tag);
+  }
+  MapWindow w;
+  for (int a = 0; a < 3; a++) w.cen[a] = plan.cen[a];
+  // ---- partition the map: sub-map | rest | dropped (the two types side by side, as in the update)
+  for (int t = 0; t < 2; t++) ensure(tm[t], tm[t].n + n_in_room[t] + 64, n_in_room[t]);
+  LX_HIP(hipEventRecord(ev_fork, reg.stream()));   // (behind the look-up tables' copy)
+  LX_HIP(hipStreamWaitEvent(st2, ev_fork, 0));
+  for (int t = 0; t < 2; t++) {
+    TypeMap& T = tm[t];
+    hipStream_t stt = t == 0 ? st2 : reg.stream();
+    const int cur = T.cur, nxt = 1 - cur;
+    if (T.n) {
+      if (++T.chain_epoch >= (1u << 30) - 2u) {   // (the chains' words carry a 30-bit epoch: cleared on the stream before it comes round)
+        LX_HIP(hipMemsetAsync(T.chain.p, 0, sizeof(unsigned long long) * T.chain.cap, stt));
+        T.chain_epoch = 1;
+      }
+      hipLaunchKernelGGL(k_map_split, dim3((T.n + MS_TILE - 1) / MS_TILE), dim3(256), 0, stt, T.pts[cur].p, T.tags[cur].p, T.n, w, slot_lut_v, T.fin.p,
+                         T.fin_seg.p, T.fin_valid.p, T.pts[nxt].p, T.tags[nxt].p, (t == 0 ? reg.corner_index : reg.surf_index).d_bounds(),
+                         T.chain.p, T.chain.p + T.chain_stride, (unsigned long long)T.chain_epoch, T.counters.p, h_err.p);
+    } else {
+      LX_HIP(hipMemsetAsync(T.counters.p, 0, sizeof(uint32_t) * 4, stt));
+    }
+  }
+  // ... and their grid indices (the corner sub-map's behind its partition on st2)
+  reg.set_submap_device_split(tm[0].fin.p, plan.n_sub[0], st2, tm[1].fin.p, plan.n_sub[1], /*bounds_done=*/true);
+  LX_HIP(hipEventRecord(ev_join, st2));
+  LX_HIP(hipStreamWaitEvent(reg.stream(), ev_join, 0));
 }
 
 // createDownsizedMap (:242-264): the surround cloud, cut from the UPDATED map.  Runs on the helper thread behind the update (st3; the
@@ -862,6 +960,7 @@ int Mapper::insert(const loamx_cloud* corner_last, const loamx_cloud* surf_last,
 
 void Mapper::load_cubes(const loamx_cloud* corner, const loamx_cloud* surf) {
   finish_update();
+  spec_valid = false;   // (a partition prepared for the old map is of no use)
   LX_HIP(hipSetDevice(cfg.device));
   hipStream_t st = reg.stream();
   const loamx_cloud* cl[2] = {corner, surf};
@@ -949,6 +1048,7 @@ void Mapper::save_snapshot(const char* path) {
 
 void Mapper::load_snapshot(const char* path) {
   finish_update();
+  spec_valid = false;   // (a partition prepared for the old map is of no use)
   LX_REQUIRE(path && *path, "NULL path");
   FILE* f = fopen(path, "rb");
   if (!f) throw Error(LOAMX_E_INVALID, std::string("cannot open ") + path);
@@ -1057,6 +1157,15 @@ int loamx_map_process_linked(loamx_map* h, loamx_odom* od, loamx_cloud* full_res
     Mapper::DeviceInput in{ob.d_last_corner(0), ob.stream_state(0).n_last_corner, ob.d_last_surf(0), ob.stream_state(0).n_last_surf,
                            ob.d_link_full(), ob.n_link_full(), ob.link_ready()};
     return h->m.process(nullptr, nullptr, full_res_registered, &in);
+  });
+}
+int loamx_map_get_speculation(loamx_map* h, uint64_t counts[2]) {
+  return guard([&]() {
+    LX_REQUIRE(h && counts, "NULL argument");
+    h->m.finish_update();
+    counts[0] = h->m.spec_hits;
+    counts[1] = h->m.spec_misses;
+    return LOAMX_OK;
   });
 }
 int loamx_map_get_transform(loamx_map* h, int which, float t[6]) {

@@ -525,6 +525,12 @@ class LaserMapping:
         rc = _check(lib().loamx_map_process_linked(self.h, odometry.h, C.byref(fc)))
         return rc, full_out[:fc.count]
 
+    def speculation(self):
+        """(sweeps that adopted the partition prepared for the predicted pose, sweeps whose prediction missed)"""
+        c = (C.c_uint64 * 2)()
+        _check(lib().loamx_map_get_speculation(self.h, c))
+        return int(c[0]), int(c[1])
+
     def insert(self, corner_last, surf_last, pose6):
         """loamx_map_insert: the epoch merge step — stack, down-size and insert a sweep registered elsewhere with the given pose"""
         c, s = as_points(corner_last), as_points(surf_last)

@@ -132,3 +132,38 @@ def test_pinned_caller_memory_is_copied_from_and_to_directly():
         results.append(out)
     for a, b in zip(*results):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_prepared_partition_is_adopted_and_changes_nothing(monkeypatch):
+    """the next sweep's map partition + sub-map index are prepared behind the update for the predicted pose and adopted when the true
+    pose's plan is identical: on a smooth trajectory that is nearly every sweep, and a handle that never speculates produces the same
+    poses, registered clouds and map bit for bit"""
+    world = synth.World(half_extent=65.0)
+    cm, sm, sweeps = _chains(world, "VLP-16", 12, 60_000)
+    chains = []
+    for spec in (True, False):
+        if spec:
+            monkeypatch.delenv("LOAMX_MAP_NO_SPECULATION", raising=False)
+        else:
+            monkeypatch.setenv("LOAMX_MAP_NO_SPECULATION", "1")
+        sr, od, mp = loamx.ScanRegistration(), loamx.LaserOdometry(), loamx.LaserMapping()
+        mp.load_cubes(cm, sm)
+        landing = np.zeros((max(len(s.points) for s in sweeps), 4), np.float32)
+        out = []
+        for t, sw in enumerate(sweeps):
+            sr.process_linked(sw.points, sw.ring_sizes)
+            od.process_linked(sr)
+            rc, reg = mp.process_linked(od, landing)
+            out.append((mp.transform("aft"), mp.transform("tobe"), reg.copy(), mp.stats()))
+            if t == 5:
+                assert len(mp.cubes(0)) > 0      # a getter between two sweeps leaves the prepared partition usable
+        hits, misses = mp.speculation()
+        if spec:
+            assert hits + misses == len(sweeps) - 1 and hits >= len(sweeps) - 4, (hits, misses)
+        else:
+            assert hits == 0 and misses == 0
+        chains.append((out, mp.cubes(0), mp.cubes(1), mp.surround()))
+    (a, ac, asf, asur), (b, bc, bsf, bsur) = chains
+    for x, y in zip(a, b):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) and x[3] == y[3]
+    assert np.array_equal(ac, bc) and np.array_equal(asf, bsf) and np.array_equal(asur, bsur)

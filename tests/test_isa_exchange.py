@@ -56,3 +56,19 @@ def test_no_instruction_touches_a_pending_exchange_load(tmp_path):
             assert not (_regs(ins) & pending), f"{func}: '{ins}' touches a register of an exchange load that is still in flight"
             assert not op.startswith("s_cbranch") and op not in ("s_branch", "s_endpgm", "s_setpc_b64"), f"{func}: control flow between exchange loads and their wait: {ins}"
     assert batches >= 1 and worst >= 8, (batches, worst)   # the batch exists and is a batch (k_gn_iter's solve_sweep: 18 loads in flight)
+
+
+@pytest.mark.skipif(not (os.path.exists(HIPCC) and os.path.exists(OBJDUMP)), reason="needs hipcc and llvm-objdump")
+def test_inline_16_byte_exchange_store_is_followed_by_its_wait_states(tmp_path):
+    """xrec_store (dev_math.cuh) is a 16-byte agent-scope store issued through inline asm: the instruction behind it must be the
+    `s_nop` of the same statement (a store of more than 64 bits followed at once by a write to its data registers is a hazard the
+    compiler only pads for stores it emitted itself)"""
+    co = str(tmp_path / "odometry.co")
+    subprocess.run([HIPCC, *FLAGS, "-c", os.path.join(CSRC, "odometry.hip"), "-o", co], check=True, capture_output=True)
+    dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+    lines = [ln.strip().split("//")[0].strip() for ln in dis.splitlines()]
+    lines = [ln for ln in lines if ln and not re.match(r"^[0-9a-f]+ <", ln)]
+    stores = [i for i, ln in enumerate(lines) if ln.startswith("global_store_dwordx4") and ln.rstrip().endswith("sc1")]
+    assert stores, "no agent-scope 16-byte store found in odometry.hip's kernels"
+    for i in stores:
+        assert lines[i + 1].startswith("s_nop"), (lines[i], lines[i + 1])

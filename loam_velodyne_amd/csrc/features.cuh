@@ -133,12 +133,17 @@ class FeatureExtractor {
   std::vector<uint32_t> h_ring_off_, h_ring_base_, h_pt_base_, h_ring_sweep_base_;
   PinBuf<float4> h_cloud_;
   DevBuf<float4> cloud_;
-  DevBuf<uint32_t> ring_off_, ring_sweep_base_;   // ring_off_[nring+1] global point offsets; sweep base offset per ring
+  // the layout tables: ring_off_[nring+1] global point offsets | sweep base offset per ring | first ring of every sweep — views into ONE
+  // device block (tab_dev_), uploaded in one copy and only when the layout differs from the one the block holds (tab_last_)
+  struct TabView { uint32_t* p = nullptr; };
+  TabView ring_off_, ring_sweep_base_, sweep_ring_base_;
+  DevBuf<uint32_t> tab_dev_;
+  std::vector<uint32_t> tab_last_;
   DevBuf<uint8_t> lf_valid_;   // (curvature, masks and gaps live in k_feat_ring's LDS since round 5)
   DevBuf<float4> slots_[3];       // per-ring fixed-capacity pick slots (sharp / less sharp / flat)
   DevBuf<uint32_t> slot_cnt_[3];  // per-ring counts
   DevBuf<float4> out_[3];         // the compact sharp / less-sharp / flat clouds (k_feat_compact)
-  DevBuf<uint32_t> offs_, sweep_ring_base_;   // offs_: [3][nsw + 1] per-sweep offsets | [nring + 1] less-flat ring offsets
+  DevBuf<uint32_t> offs_;   // offs_: [3][nsw + 1] per-sweep offsets | [nring + 1] less-flat ring offsets
   uint32_t off_stride_ = 1;
   uint32_t* lf_off_() const { return offs_.p + (size_t)3 * off_stride_; }
   DevBuf<float4> lf_out_, lf_slots_;

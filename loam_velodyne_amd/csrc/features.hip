@@ -12,6 +12,7 @@
 //   k_feat_lf_voxel / k_feat_lf_compact   per-ring pcl::VoxelGrid(0.2 m) of the less-flat candidates (:246-252) and its compaction
 //   VoxelPipeline  the same voxel grid for rings longer than 4096 points.
 #include "features.cuh"
+#include "pinned_copy.cuh"
 #include "scan.cuh"
 
 namespace loamx {
@@ -250,6 +251,9 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu
   const uint32_t capS = P.max_sharp * nreg, capLS = P.max_less_sharp * nreg, capF = P.max_flat * nreg;
   uint32_t nS = 0, nLS = 0, nF = 0;   // maintained by wave 0
   FT_TS(0);
+  // the less-flat marks of the ring start from zero: the regions below write theirs (points outside every region — the first and last
+  // curv_region of a ring, a region of one point — keep the zero); ordered before those writes by the prologue's barriers
+  for (uint32_t k = tid; k < len; k += blockDim.x) lf_valid[s0g + k] = 0;
   if (len <= 2u * cr + 1u) {          // (too short for a curvature stencil: nothing is extracted, but the finite-input contract still holds)
     for (uint32_t k = tid; k < len; k += blockDim.x) {
       const float4 p = cloud[s0g + k];
@@ -804,9 +808,6 @@ void FeatureExtractor::allocate_(hipStream_t table_stream) {
   lf_valid_.reserve(n_ + 1);
   lf_out_.reserve(n_ + 1);
   lf_slots_.reserve(n_ + 1);
-  ring_off_.reserve(nring_ + 2);
-  ring_sweep_base_.reserve(nring_ + 2);
-  sweep_ring_base_.reserve(nsw + 2);
   // the four offset tables lie back to back — [sharp | less sharp | flat][nsw + 1], then the less-flat cloud's per-ring offsets
   // [nring + 1] — so that a consumer fetches them with ONE copy (Pipeline::launch_features)
   offs_.reserve((size_t)3 * (nsw + 1) + nring_ + 2);
@@ -820,18 +821,25 @@ void FeatureExtractor::allocate_(hipStream_t table_stream) {
     slot_cnt_[k].reserve((size_t)nring_ + 2);
   }
   if (max_ring_len_ > 4096) vox_.reserve(n_ + 1, nring_);
-  // the three layout tables travel through pinned memory, so the copies never make the host wait for the stream
+  // the three layout tables lie back to back in one device block and travel through pinned memory in ONE copy — and only when the
+  // layout changed: a sensor's sweeps usually repeat their ring sizes, and the block on the device is then already the right one
   hipStream_t ts = table_stream ? table_stream : st_;
-  h_tab_.reserve((size_t)2 * nring_ + nsw + 8);
-  uint32_t* t0 = h_tab_.p;
-  uint32_t* t1 = t0 + nring_ + 1;
-  uint32_t* t2 = t1 + nring_;
-  memcpy(t0, h_ring_off_.data(), sizeof(uint32_t) * (nring_ + 1));
-  memcpy(t1, h_ring_sweep_base_.data(), sizeof(uint32_t) * nring_);
-  memcpy(t2, h_ring_base_.data(), sizeof(uint32_t) * (nsw + 1));
-  LX_HIP(hipMemcpyAsync(ring_off_.p, t0, sizeof(uint32_t) * (nring_ + 1), hipMemcpyHostToDevice, ts));
-  LX_HIP(hipMemcpyAsync(ring_sweep_base_.p, t1, sizeof(uint32_t) * nring_, hipMemcpyHostToDevice, ts));
-  LX_HIP(hipMemcpyAsync(sweep_ring_base_.p, t2, sizeof(uint32_t) * (nsw + 1), hipMemcpyHostToDevice, ts));
+  const size_t words = (size_t)2 * nring_ + nsw + 2;
+  std::vector<uint32_t> tab(words);
+  memcpy(tab.data(), h_ring_off_.data(), sizeof(uint32_t) * (nring_ + 1));
+  memcpy(tab.data() + nring_ + 1, h_ring_sweep_base_.data(), sizeof(uint32_t) * nring_);
+  memcpy(tab.data() + 2 * (size_t)nring_ + 1, h_ring_base_.data(), sizeof(uint32_t) * (nsw + 1));
+  const bool same = tab_dev_.p && tab_dev_.cap >= words + 8 && tab == tab_last_;
+  if (!same) {
+    tab_dev_.reserve(words + 8);
+    h_tab_.reserve(words + 8);
+    memcpy(h_tab_.p, tab.data(), sizeof(uint32_t) * words);
+    LX_HIP(hipMemcpyAsync(tab_dev_.p, h_tab_.p, sizeof(uint32_t) * words, hipMemcpyHostToDevice, ts));
+    tab_last_.swap(tab);
+  }
+  ring_off_.p = tab_dev_.p;
+  ring_sweep_base_.p = tab_dev_.p + nring_ + 1;
+  sweep_ring_base_.p = tab_dev_.p + 2 * (size_t)nring_ + 1;
 }
 
 void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
@@ -854,7 +862,9 @@ void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uin
     for (uint32_t s = 0; s < nsw; s++) pack_cloud(&clouds[s], h_cloud_.p + h_pt_base_[s]);
   }
   allocate_();
-  if (n_) LX_HIP(hipMemcpyAsync(cloud_.p, direct ? clouds[0].data : (const void*)h_cloud_.p, sizeof(float4) * n_, hipMemcpyHostToDevice, st_));   // (no wait: the kernels follow on the same stream)
+  // (by a kernel that reads the pinned block: no copy engine in front of the extraction — pinned_copy.cuh; no wait: the kernels follow
+  // on the same stream)
+  fetch_from_pinned(cloud_.p, direct ? clouds[0].data : (const void*)h_cloud_.p, n_, st_);
 }
 
 // One raw revolution (MultiScanRegistration::process, src/lib/MultiScanRegistration.cpp:160-238): records with x, y, z
@@ -1018,8 +1028,7 @@ void FeatureExtractor::run_async() {
   LX_REQUIRE(nsw_ > 0, "run() before upload()");
   LX_HIP(hipSetDevice(device_));
   const int cr = params.curv_region;
-  LX_HIP(hipMemsetAsync(lf_valid_.p, 0, n_ + 1, st_));
-  (void)cr;
+  (void)cr;   // (lf_valid_ is cleared ring by ring in k_feat_ring's prologue: no memset)
   const uint32_t caps[3] = {(uint32_t)(params.max_sharp * params.n_regions), (uint32_t)(params.max_less_sharp * params.n_regions),
                             (uint32_t)(params.max_flat * params.n_regions)};
   const uint32_t flag_bytes = (max_ring_len_ + 15u) & ~15u;

@@ -14,6 +14,7 @@
 //                  the de-skew chain rule, J^T J / J^T r reduced with wave shuffles (double accumulators), thread 0:
 //                  6x6 pivoted QR solve, degeneracy projector, update, convergence test.
 #include "odometry.cuh"
+#include "pinned_copy.cuh"
 #include <type_traits>
 
 namespace loamx {
@@ -1317,7 +1318,7 @@ int OdometryBatch::process_host(const loamx_cloud* sharp, const loamx_cloud* les
   // feature clouds are finite by contract (BasicLaserOdometry.cpp:230, :252 strip NaN points as a safeguard; the registration stage
   // never produces them): a caller that hands over NaN / Inf coordinates is told instead of getting a pose through NaN arithmetic
   if (!packed_all_finite(h_stage_.p, off[4])) throw Error(LOAMX_E_INVALID, "a feature cloud holds non-finite coordinates");
-  if (off[4]) LX_HIP(hipMemcpyAsync(up_[0].p, h_stage_.p, sizeof(float4) * off[4], hipMemcpyHostToDevice, st_));
+  fetch_from_pinned(up_[0].p, h_stage_.p, off[4], st_);   // (by kernel: pinned_copy.cuh)
   OdomInput in{up_[0].p, sharp->count, up_[0].p + off[1], less_sharp->count, up_[0].p + off[2], flat->count, up_[0].p + off[3], less_flat->count};
   int rc = LOAMX_OK;
   last_dl_valid_ = false;
@@ -1392,7 +1393,7 @@ int OdometryBatch::transform_to_end_host(uint32_t s, loamx_cloud* cloud) {
   h_stage_.reserve(n + 1);
   tmp_cloud_.reserve(n + 1);
   pack_cloud(cloud, h_stage_.p);
-  if (n) LX_HIP(hipMemcpyAsync(tmp_cloud_.p, h_stage_.p, sizeof(float4) * n, hipMemcpyHostToDevice, st_));
+  fetch_from_pinned(tmp_cloud_.p, h_stage_.p, n, st_);
   to_end_device(s, tmp_cloud_.p, n);
   if (n) LX_HIP(hipMemcpyAsync(h_stage_.p, tmp_cloud_.p, sizeof(float4) * n, hipMemcpyDeviceToHost, st_));
   LX_HIP(hipStreamSynchronize(st_));

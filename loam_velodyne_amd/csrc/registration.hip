@@ -13,6 +13,7 @@
 // HBM-bound gather work: no MFMA (the only dense contraction is 6x6).  Points are packed float4 so a neighbour is one
 // 16-byte load; queries are processed in voxel order, so the lanes of a wave walk the same few grid cells.
 #include "registration.cuh"
+#include "pinned_copy.cuh"
 #include <atomic>
 #include <chrono>
 #include "scan.cuh"
@@ -1138,12 +1139,12 @@ void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const 
   }
   // (the feature clouds of the registration are finite by contract, as the odometry's: common.h packed_all_finite)
   if (!packed_all_finite(h_in_.p, n_in_)) throw Error(LOAMX_E_INVALID, "a feature cloud holds non-finite coordinates");
-  LX_HIP(hipMemcpyAsync(in_.p, h_in_.p, sizeof(float4) * n_in_, hipMemcpyHostToDevice, st_));
+  fetch_from_pinned(in_.p, h_in_.p, n_in_, st_);   // (single-sweep sizes by kernel, a batch's MiB by the copy engine: pinned_copy.cuh)
   if (n_full_) {
     h_full_.reserve(n_full_);
     full_.reserve(n_full_);
     for (uint32_t s = 0; s < n_sweeps; s++) pack_cloud(&full_res[s], h_full_.p + h_full_off_[s]);
-    LX_HIP(hipMemcpyAsync(full_.p, h_full_.p, sizeof(float4) * n_full_, hipMemcpyHostToDevice, st_));
+    fetch_from_pinned(full_.p, h_full_.p, n_full_, st_);
   }
   {   // guesses / offsets travel as ONE block through pinned memory owned by this object (as in upload_device; copies from the
       // pageable vectors were staged by the runtime, one wait each)
@@ -1664,6 +1665,7 @@ void Registrar::download_full_res_async(uint32_t sweep, const loamx_cloud* into)
   // only waits); anything else goes through this object's pinned block and is unpacked there
   full_dl_direct_ = nullptr;
   if (into && b > a && into->count >= b - a && packed_layout(into) && host_pinned(into->data, sizeof(float4) * (b - a))) {
+    // (a kernel storing to the pinned block instead of this copy was measured: 8 us slower per sweep — profiles/r05_ab.md section 6)
     LX_HIP(hipMemcpyAsync(into->data, full_.p + a, sizeof(float4) * (b - a), hipMemcpyDeviceToHost, st_));
     full_dl_direct_ = into->data;
   } else {

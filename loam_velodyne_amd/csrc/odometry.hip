@@ -1159,7 +1159,11 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
         }
         hipLaunchKernelGGL(k_odom_corr_grid, dim3(8 * (((max_sharp + 7) / 8 + (max_flat + 7) / 8 + 3) / 4), na), dim3(256), 0, st_, prob_.p, params);
         if (lk >= 0) LX_HIP(hipEventRecord(lt->ev[3 * lk + 1], st_));
+#ifdef OD_LM_HALF_WGS   // (measurement: half as many workgroups per stream, two features per thread — profiles/r05_ab.md section 2)
+        const uint32_t nb = std::min<uint32_t>(16u, std::max<uint32_t>(1u, (max_feat + 2 * OD_THREADS - 1) / (2 * OD_THREADS)));
+#else
         const uint32_t nb = std::min<uint32_t>(16u, (max_feat + OD_THREADS - 1) / OD_THREADS);
+#endif
         // k_odom_lm's workgroups of one stream spin on each other: everything a launch puts on the device must be resident
         // at once.  The launch is cut into chunks of streams that fill at most half of what the device can hold (occupancy x
         // CUs, queried once) — the registration and feature kernels of the other HIP streams share the CUs.

@@ -167,3 +167,43 @@ def test_prepared_partition_is_adopted_and_changes_nothing(monkeypatch):
     for x, y in zip(a, b):
         assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) and x[3] == y[3]
     assert np.array_equal(ac, bc) and np.array_equal(asf, bsf) and np.array_equal(asur, bsur)
+
+
+def test_a_missed_prediction_is_redone_and_changes_nothing(monkeypatch):
+    """replay recorded odometry messages into two mapping handles, one preparing the next partition ahead and one not, with jumps in
+    the odometry pose that the constant-velocity prediction cannot follow (a turn of 0.6 rad, a leap of 60 m that moves the cube window):
+    the prepared work is discarded on those sweeps and everything the two handles produce stays equal bit for bit"""
+    world = synth.World(half_extent=65.0)
+    cm, sm, sweeps = _chains(world, "VLP-16", 10, 60_000)
+    sr, od = loamx.ScanRegistration(), loamx.LaserOdometry()
+    msgs = []
+    for sw in sweeps:
+        f = sr.process(sw.points.copy(), sw.ring_sizes)
+        od.process(f)
+        lc, ls = od.last_clouds()
+        msgs.append((lc, ls, od.transform_to_end(f["full"]), np.array(od.transform_sum, np.float32)))
+    jump = {4: np.array([0, 0.6, 0, 0, 0, 0], np.float32), 7: np.array([0, 0, 0, 60.0, 0, 0], np.float32)}
+    outs = []
+    for spec in (True, False):
+        if spec:
+            monkeypatch.delenv("LOAMX_MAP_NO_SPECULATION", raising=False)
+        else:
+            monkeypatch.setenv("LOAMX_MAP_NO_SPECULATION", "1")
+        mp = loamx.LaserMapping()
+        mp.load_cubes(cm, sm)
+        offset = np.zeros(6, np.float32)
+        out = []
+        for t, (lc, ls, full, s6) in enumerate(msgs):
+            offset = offset + jump.get(t, 0)
+            mp.update_odometry(s6 + offset)
+            rc, reg = mp.process(lc, ls, full)
+            out.append((rc, mp.transform("aft"), mp.transform("tobe"), reg, mp.stats()))
+        hits, misses = mp.speculation()
+        if spec:
+            assert misses >= 2 and hits >= 4, (hits, misses)
+        out.append((mp.cubes(0), mp.cubes(1)))
+        outs.append(out)
+    a, b = outs
+    for x, y in zip(a[:-1], b[:-1]):
+        assert x[0] == y[0] and np.array_equal(x[1], y[1]) and np.array_equal(x[2], y[2]) and np.array_equal(x[3], y[3]) and x[4] == y[4]
+    assert np.array_equal(a[-1][0], b[-1][0]) and np.array_equal(a[-1][1], b[-1][1])

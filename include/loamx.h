@@ -406,7 +406,7 @@ int loamx_pipeline_update_imu(loamx_pipeline* h, uint32_t stream, double stamp_s
  * buffers so the next step does not wait for the copy.  wait_downloads blocks until every started copy has landed.
  * When the destination is pinned memory of the ROCm runtime's own (hipHostMalloc, torch's pinned tensors) the copy is handed to
  * the GPU's SDMA engine directly; other host memory goes through hipMemcpyAsync on a copy stream (whose choice of engine may
- * disturb kernels that write to host memory, see csrc/hostlink.cuh).  download_counts: [0] downloads issued the first way,
+ * disturb kernels that write to host memory, see csrc/hostlink.hpp).  download_counts: [0] downloads issued the first way,
  * [1] the second. */
 int loamx_pipeline_enable_async_downloads(loamx_pipeline* h);
 int loamx_pipeline_download_step_async(loamx_pipeline* h, loamx_cloud* out, uint32_t n_out);

@@ -1,5 +1,5 @@
 // C-ABI: batched-sweep registration (loamx_batch_*) — thin shim over loamx::Registrar.
-#include "registration.cuh"
+#include "registration.hpp"
 
 using namespace loamx;
 

@@ -11,9 +11,9 @@
 //                  counts of the rings before it itself)
 //   k_feat_lf_voxel / k_feat_lf_compact   per-ring pcl::VoxelGrid(0.2 m) of the less-flat candidates (:246-252) and its compaction
 //   VoxelPipeline  the same voxel grid for rings longer than 4096 points.
-#include "features.cuh"
-#include "pinned_copy.cuh"
-#include "scan.cuh"
+#include "features.hpp"
+#include "pinned_copy.hpp"
+#include "scan.hpp"
 
 namespace loamx {
 
@@ -862,7 +862,7 @@ void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uin
     for (uint32_t s = 0; s < nsw; s++) pack_cloud(&clouds[s], h_cloud_.p + h_pt_base_[s]);
   }
   allocate_();
-  // (by a kernel that reads the pinned block: no copy engine in front of the extraction — pinned_copy.cuh; no wait: the kernels follow
+  // (by a kernel that reads the pinned block: no copy engine in front of the extraction — pinned_copy.hpp; no wait: the kernels follow
   // on the same stream)
   fetch_from_pinned(cloud_.p, direct ? clouds[0].data : (const void*)h_cloud_.p, n_, st_);
 }

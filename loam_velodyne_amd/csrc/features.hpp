@@ -2,9 +2,9 @@
 #pragma once
 #include "common.h"
 #include "host_math.h"
-#include "ingest.cuh"
+#include "ingest.hpp"
 #include <deque>
-#include "voxel.cuh"
+#include "voxel.hpp"
 
 namespace loamx {
 
@@ -22,7 +22,7 @@ struct FeatParams {
 // The IMU state machine of BasicScanRegistration for ONE sensor stream, on the host (src/lib/BasicScanRegistration.cpp:55-152,
 // :258-281): history with accumulated position / velocity (updateIMUData :82-98), interpolation (interpolateIMUStateFor
 // :133-147), reset(scanTime) :55-79 and updateIMUTransform :258-281.  The per-point projection (projectPointToStartOfSweep
-// :101-131) runs on the device from a table this class fills (ingest.cuh ImuTable); the state the projection loop leaves behind
+// :101-131) runs on the device from a table this class fills (ingest.hpp ImuTable); the state the projection loop leaves behind
 // comes back as ImuLast.  Used by FeatureExtractor (single-sweep entry points) and, one per stream, by the batched pipeline.
 class ImuTracker {
  public:

@@ -6,7 +6,7 @@
 //   transform_associate_to_map <-> src/lib/BasicLaserMapping.cpp:103-167
 #pragma once
 #include <cmath>
-#include "dev_math.cuh"
+#include "dev_math.hpp"
 
 namespace loamx {
 

@@ -1,9 +1,9 @@
-// Raw-sweep ingestion for gfx950 — see ingest.cuh.  The reference walks the points once, sequentially; the only
+// Raw-sweep ingestion for gfx950 — see ingest.hpp.  The reference walks the points once, sequentially; the only
 // order-dependent pieces are (a) the halfPassed flag — it flips at the FIRST kept point whose unwrapped azimuth is more
 // than pi past the start and stays set, so it is "index > j*" with j* a min-reduction — and (b) the per-ring push_back,
 // i.e. a stable split by ring id: per-workgroup ring histograms, a column scan over the workgroups, and a stable rank
 // inside the workgroup (wave ballots per distinct ring + wave-order prefix).
-#include "ingest.cuh"
+#include "ingest.hpp"
 
 namespace loamx {
 

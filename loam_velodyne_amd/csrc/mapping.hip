@@ -10,7 +10,7 @@
 //   VoxelPipeline (segments = valid cubes)      per-cube pcl::VoxelGrid re-filtering (:580-593)
 //   k_map_append / k_map_hist                   next map = rest ++ filtered; per-cube counts for the host directory
 // Host: closed-form pose prediction (:103-167), cube window + field-of-view selection (:300-500), transformUpdate.
-#include "registration.cuh"
+#include "registration.hpp"
 #include "api_handles.h"
 #include <algorithm>
 #include <chrono>
@@ -21,7 +21,7 @@
 #include <mutex>
 #include <thread>
 #include "host_math.h"
-#include "scan.cuh"
+#include "scan.hpp"
 
 namespace loamx {
 
@@ -51,7 +51,7 @@ struct MapWindow {
 // ---- the map's split of one sweep (:300-509 without the pointer grid): every map point is valid (its cube is in the field of view:
 // it joins the sub-map), rest (inside the window, not visible) or dropped (its cube left the window).  ONE launch (rounds 1-4:
 // classify, two device-wide scans, partition): a workgroup classifies its tile of 2048 points, scans the two flags inside the tile,
-// finds the tile's two offsets by a decoupled look-back over the tiles before it (scan.cuh: chain_lookback) and moves its points —
+// finds the tile's two offsets by a decoupled look-back over the tiles before it (scan.hpp: chain_lookback) and moves its points —
 // order preserved in both outputs.  valid -> (sub_pts, sub_seg, sub_valid = 1): where the per-cube re-filtering of the map update reads
 // the sub-map (its first n_sub slots), folded into the bounds of the sub-map's grid index on the way (SubMapIndex::d_bounds);
 // rest -> (new_pts, new_tags).  The last tile records the totals: counters[1] = valid, counters[3] = rest.

@@ -13,8 +13,8 @@
 //                  kernel boundary: thread per feature point-to-line / point-to-plane coefficients and Jacobian row with
 //                  the de-skew chain rule, J^T J / J^T r reduced with wave shuffles (double accumulators), thread 0:
 //                  6x6 pivoted QR solve, degeneracy projector, update, convergence test.
-#include "odometry.cuh"
-#include "pinned_copy.cuh"
+#include "odometry.hpp"
+#include "pinned_copy.hpp"
 #include <type_traits>
 
 namespace loamx {
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(OD_THREADS) OD_LM_ATTR void k_odom_lm(OdomProblem* 
 #pragma unroll
       for (int w = 0; w < 8; w++) xs += red[w][tid];
       if (NB > 1) {
-        // one tagged 16-byte record per sum, fire and forget: no wait for the store, no arrival counter (dev_math.cuh: xrec_store)
+        // one tagged 16-byte record per sum, fire and forget: no wait for the store, no arrival counter (dev_math.hpp: xrec_store)
         xrec_store(reinterpret_cast<xrec_t*>(pb.part) + (((unsigned)iter & 1u) * 16u + blockIdx.x) * LX_NSUM + tid, xs, xtag | (unsigned)(iter + 1));
       }
     }
@@ -1322,7 +1322,7 @@ int OdometryBatch::process_host(const loamx_cloud* sharp, const loamx_cloud* les
   // feature clouds are finite by contract (BasicLaserOdometry.cpp:230, :252 strip NaN points as a safeguard; the registration stage
   // never produces them): a caller that hands over NaN / Inf coordinates is told instead of getting a pose through NaN arithmetic
   if (!packed_all_finite(h_stage_.p, off[4])) throw Error(LOAMX_E_INVALID, "a feature cloud holds non-finite coordinates");
-  fetch_from_pinned(up_[0].p, h_stage_.p, off[4], st_);   // (by kernel: pinned_copy.cuh)
+  fetch_from_pinned(up_[0].p, h_stage_.p, off[4], st_);   // (by kernel: pinned_copy.hpp)
   OdomInput in{up_[0].p, sharp->count, up_[0].p + off[1], less_sharp->count, up_[0].p + off[2], flat->count, up_[0].p + off[3], less_flat->count};
   int rc = LOAMX_OK;
   last_dl_valid_ = false;

@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 #include "host_math.h"
-#include "registration.cuh"
+#include "registration.hpp"
 #include <atomic>
 #include <condition_variable>
 #include <functional>

@@ -2,7 +2,7 @@
 // Measured (profiles/r05_ab.md section 6): on these latency-bound chains a lone hipMemcpyAsync of a few hundred KB goes to an SDMA
 // engine, and the hand-overs between that queue and the compute queue cost far more than the copy — ~180 us per VLP-16 sweep in front
 // of the feature extraction; a kernel on the same stream costs ~10 us and needs no hand-over.  Blocks of many MiB (the batched
-// pipeline's staging) stay on the copy engines (hostlink.cuh).
+// pipeline's staging) stay on the copy engines (hostlink.hpp).
 #pragma once
 #include "common.h"
 

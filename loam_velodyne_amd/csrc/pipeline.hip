@@ -5,10 +5,10 @@
 // across GPUs; every stream keeps the reference's sequential semantics (its odometry state, its
 // transformBefMapped / transformAftMapped), only the map is frozen for the epoch.  All device work of a step runs on one
 // HIP stream with inputs resident in HBM; the host touches only offsets and 6-float poses between the stages.
-#include "features.cuh"
-#include "odometry.cuh"
-#include "registration.cuh"
-#include "hostlink.cuh"
+#include "features.hpp"
+#include "odometry.hpp"
+#include "registration.hpp"
+#include "hostlink.hpp"
 #include <atomic>
 #include <deque>
 #include <functional>
@@ -124,7 +124,7 @@ class Pipeline {
   hipEvent_t ev_reg_done = nullptr, ev_d2h[2] = {nullptr, nullptr};
   bool d2h_pending[2] = {false, false};
   uint64_t downloads_direct = 0, downloads_hip = 0;      // asynchronous downloads issued to the SDMA engine directly / through hipMemcpyAsync
-  HostLinkDma hostlink;                                   // the same downloads on the SDMA engine directly (hostlink.cuh)
+  HostLinkDma hostlink;                                   // the same downloads on the SDMA engine directly (hostlink.hpp)
   HostLinkUp uplink;                                      // ... and the staging copies of stage_step (slot = t % RING); LOAMX_H2D_DIRECT=0: through HIP
   uint32_t up_runs[RING] = {};                            // block copies of the slot's step handed to uplink (0: none, the HIP copy stream carried them)
   std::atomic<long> last_step{-1};                        // the last step that has run (-1: none yet)
@@ -445,7 +445,7 @@ class Pipeline {
     if (t > 0) finalize_raw(t - 1);
     rawslot[t % RING].raw = false;
     rawslot[t % RING].finalized = true;
-    // The sweeps' block copies go to ROCr directly when source and destination are the runtime's own allocations (hostlink.cuh: a copy
+    // The sweeps' block copies go to ROCr directly when source and destination are the runtime's own allocations (hostlink.hpp: a copy
     // stream of the HIP runtime would be a fifth busy HIP stream): the blocks are counted first (the group's size must be known when
     // it begins), then issued; launch_features() waits for the slot's signal on the host — a whole step later.
     static const bool direct = !(getenv("LOAMX_H2D_DIRECT") && atoi(getenv("LOAMX_H2D_DIRECT")) == 0);
@@ -627,7 +627,7 @@ class Pipeline {
       if (cnt) runs.push_back(Run{base, (const char*)(reg.d_full_res() + last_full_off[k]), sizeof(float4) * cnt});
       k = e;
     }
-    // The copies go to the SDMA engine directly (hostlink.cuh: the HIP runtime may pick its blit kernel for them, which stalls
+    // The copies go to the SDMA engine directly (hostlink.hpp: the HIP runtime may pick its blit kernel for them, which stalls
     // every kernel that writes to host memory meanwhile) when source and destination are ROCr allocations; else through HIP.
     static const bool via_hip = getenv("LOAMX_D2H_HIP") != nullptr;   // diagnostic: always hipMemcpyAsync
     bool direct = !via_hip && !runs.empty();

@@ -12,12 +12,12 @@
 //   k_transform_full transformFullResToMap                                                         (:235-240)
 // HBM-bound gather work: no MFMA (the only dense contraction is 6x6).  Points are packed float4 so a neighbour is one
 // 16-byte load; queries are processed in voxel order, so the lanes of a wave walk the same few grid cells.
-#include "registration.cuh"
-#include "pinned_copy.cuh"
+#include "registration.hpp"
+#include "pinned_copy.hpp"
 #include <atomic>
 #include <chrono>
-#include "scan.cuh"
-#include "voxel.cuh"
+#include "scan.hpp"
+#include "voxel.hpp"
 
 namespace loamx {
 
@@ -484,7 +484,7 @@ struct Row {
 };
 
 // corner query: BasicLaserMapping.cpp:667-751.  JACOBI: the 3x3 eigen-decomposition by the cyclic Jacobi iteration the oracle uses
-// for Eigen's solver (instruction for instruction) instead of the closed form (dev_math.cuh)
+// for Eigen's solver (instruction for instruction) instead of the closed form (dev_math.hpp)
 template <bool JACOBI>
 __device__ __forceinline__ void corner_row(const Pose& T, const float4 po, const float4* __restrict__ pts, const uint32_t (&bp)[5], float& cx_,
                                   float& cy_, float& cz_, float& ci_, bool& sel) {
@@ -604,7 +604,7 @@ __device__ __forceinline__ void solve_sweep(uint32_t s, const uint32_t* __restri
   if (tid < LX_SOLVE_GROUPS * LX_NSUM) {
     const uint32_t g = (uint32_t)tid / LX_NSUM, t = (uint32_t)tid % LX_NSUM;
     double x = 0.0;
-    // LX_SOLVE_MLP agent-scope loads in flight (the partials come from the other XCDs' workgroups; see dev_math.cuh "exchange"), added
+    // LX_SOLVE_MLP agent-scope loads in flight (the partials come from the other XCDs' workgroups; see dev_math.hpp "exchange"), added
     // in tile order.  Unconditional loads with a clamped tile index: the conditional ones of round 3 were compiled into one branch +
     // wait per load — 34 dependent round trips, 9-12 of solve_sweep's ~20 us (in-kernel time stamps)
     for (uint32_t b0 = g; b0 < nact; b0 += LX_SOLVE_MLP * LX_SOLVE_GROUPS) {
@@ -1139,7 +1139,7 @@ void Registrar::upload(uint32_t n_sweeps, const loamx_cloud* corner_last, const 
   }
   // (the feature clouds of the registration are finite by contract, as the odometry's: common.h packed_all_finite)
   if (!packed_all_finite(h_in_.p, n_in_)) throw Error(LOAMX_E_INVALID, "a feature cloud holds non-finite coordinates");
-  fetch_from_pinned(in_.p, h_in_.p, n_in_, st_);   // (single-sweep sizes by kernel, a batch's MiB by the copy engine: pinned_copy.cuh)
+  fetch_from_pinned(in_.p, h_in_.p, n_in_, st_);   // (single-sweep sizes by kernel, a batch's MiB by the copy engine: pinned_copy.hpp)
   if (n_full_) {
     h_full_.reserve(n_full_);
     full_.reserve(n_full_);
@@ -1564,7 +1564,7 @@ void Registrar::qr6_probe(const float* ata, const float* atb, uint32_t n, float*
   LX_HIP(hipStreamSynchronize(st_));
 }
 
-// Stress probe of the exchange primitive k_odom_lm rests on (dev_math.cuh: xrec_store / xrec_load).  The assumption: an aligned 16-byte
+// Stress probe of the exchange primitive k_odom_lm rests on (dev_math.hpp: xrec_store / xrec_load).  The assumption: an aligned 16-byte
 // agent-scope store is observed whole or split at 8 bytes, never finer, so a record read with BOTH tags equal to k holds both halves
 // of value k.  Workgroup pairs (2 p, 2 p + 1) — consecutive workgroups run on different XCDs — hammer shared records: thread t of the
 // producer writes versions 1 .. rounds of record (p, t) back to back, thread t of the consumer reads the record as fast as it can until

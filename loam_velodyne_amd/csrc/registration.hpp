@@ -3,9 +3,9 @@
 #pragma once
 #include <functional>
 #include "common.h"
-#include "dev_math.cuh"
-#include "voxel.cuh"
-#include "voxbucket.cuh"
+#include "dev_math.hpp"
+#include "voxel.hpp"
+#include "voxbucket.hpp"
 
 namespace loamx {
 
@@ -17,7 +17,7 @@ struct GridDesc {
   uint32_t ncell;
 };
 
-constexpr uint32_t LX_MAX_CELLS = 16u * 1024 * 1024 - 2048;   // scan limit (scan.cuh)
+constexpr uint32_t LX_MAX_CELLS = 16u * 1024 * 1024 - 2048;   // scan limit (scan.hpp)
 constexpr int LX_RES_THREADS = 256;
 constexpr int LX_NSUM = 28;   // 21 upper-triangular AtA + 6 AtB + row count
 
@@ -274,7 +274,7 @@ class Registrar {
   void* full_dl_direct_ = nullptr;   // download_full_res_async() copied straight into this caller memory
   int full_dl_sweep_ = -1;       // the sweep whose copy download_full_res_async() has enqueued since the clouds were registered (-1: none)
   VoxelPipeline vox_;
-  // the stack clouds' voxel grid normally takes the bucketed path (voxbucket.cuh); a run that gives up is repeated through the
+  // the stack clouds' voxel grid normally takes the bucketed path (voxbucket.hpp); a run that gives up is repeated through the
   // general kernel as soon as the host has synchronised with it (LOAMX_VOX_LEGACY=1 forces the general kernel)
   VoxBucket vb_;
   bool vb_disabled_ = false;   // LOAMX_VOX_LEGACY

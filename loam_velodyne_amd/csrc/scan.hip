@@ -1,5 +1,5 @@
-// Device-wide exclusive scan kernels (see scan.cuh).
-#include "scan.cuh"
+// Device-wide exclusive scan kernels (see scan.hpp).
+#include "scan.hpp"
 #include "common.h"
 #include <mutex>
 #include <unordered_map>
@@ -12,7 +12,7 @@ void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums /
   exclusive_scan_u32_chained(in, out, (unsigned long long*)tile_sums, d_n, d_total, max_n, st, out2, zero_in);
 }
 
-// ---- one-launch variant (see scan.cuh) ---------------------------------------------------------------------------------------------
+// ---- one-launch variant (see scan.hpp) ---------------------------------------------------------------------------------------------
 // state[0]: epoch of the last finished launch (bumped by the last tile to finish), state[1]: tiles finished, state[8 + b]: tile b's word
 //   word = epoch << 34 | flag << 32 | value;  flag 1: value = the tile's own sum, flag 2: value = inclusive prefix up to and with the tile
 constexpr int CS_HDR = 8;

@@ -95,7 +95,7 @@ void exclusive_scan_u32(const uint32_t* in, uint32_t* out, uint32_t* tile_sums, 
 // before it, publishes its own inclusive prefix and writes its slice.  The words carry the launch's epoch, so nothing is cleared between
 // launches; `state` (chained_scan_state_words() uint64 words) is zero-filled ONCE by its owner and may be shared by all scans of one HIP
 // stream.  Everything a tile needs from another one travels INSIDE those words: relaxed agent-scope atomics, no cache-wide fence
-// (dev_math.cuh "exchange").  Workgroups start in index order (as everywhere in this library where a workgroup waits for a
+// (dev_math.hpp "exchange").  Workgroups start in index order (as everywhere in this library where a workgroup waits for a
 // lower-numbered one); a predecessor that does not show up within ~1 s raises the process-wide error word (scan_check_errors()) instead
 // of hanging the device.  n_host != UINT32_MAX: the element count is this value and d_n is ignored (no k_scan_set_n launch).
 constexpr uint32_t CHAINED_SCAN_MAX_TILES = 8192;

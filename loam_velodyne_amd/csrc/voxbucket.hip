@@ -1,7 +1,7 @@
-// Bucketed voxel grid of the registration's stack clouds (see voxbucket.cuh).  gfx950, wave64.
-#include "voxbucket.cuh"
-#include "scan.cuh"
-#include "voxel.cuh"
+// Bucketed voxel grid of the registration's stack clouds (see voxbucket.hpp).  gfx950, wave64.
+#include "voxbucket.hpp"
+#include "scan.hpp"
+#include "voxel.hpp"
 
 namespace loamx {
 
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(VB_THREADS) void k_vb_reduce(const VbArgs A) {
   uint32_t tot;
   const uint32_t ex = block_excl_scan(nh, s_scan, tot);
   if (tid == 0) {
-    xchg_stores_done();   // the box atomics above (this wave's lanes 0-5) have been performed before the count is published; no cache-wide fence (dev_math.cuh)
+    xchg_stores_done();   // the box atomics above (this wave's lanes 0-5) have been performed before the count is published; no cache-wide fence (dev_math.hpp)
     __hip_atomic_store(&A.heads[b], tot + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   uint32_t part = 0u;

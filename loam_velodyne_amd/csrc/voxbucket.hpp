@@ -15,7 +15,7 @@
 // (k_vox_ds_seg).  Output is bit-identical to that kernel's (same voxel order, same summation order).
 #pragma once
 #include "common.h"
-#include "dev_math.cuh"
+#include "dev_math.hpp"
 
 namespace loamx {
 

@@ -1,5 +1,5 @@
-// Segmented voxel-grid down-sampling kernels (see voxel.cuh).
-#include "voxel.cuh"
+// Segmented voxel-grid down-sampling kernels (see voxel.hpp).
+#include "voxel.hpp"
 #include <vector>
 
 namespace loamx {

@@ -9,7 +9,7 @@
 #pragma once
 #include <algorithm>
 #include "common.h"
-#include "scan.cuh"
+#include "scan.hpp"
 
 namespace loamx {
 

@@ -36,7 +36,7 @@ def test_no_oracle_in_product():
     assert "oracle" not in out
     for dirpath, _, files in os.walk(os.path.join(ROOT, "loam_velodyne_amd")):
         for fn in files:
-            if fn.endswith((".py", ".hip", ".cuh", ".h", ".cpp")):
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "oracle_py" not in txt and "liboracle" not in txt and '#include "oracle' not in txt, fn
                 assert "oracle_mock" not in txt and "mock_loamx" not in txt, fn     # the C-ABI test double belongs to tests only

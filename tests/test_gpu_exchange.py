@@ -1,7 +1,7 @@
 """GPU: the exchange between the workgroups of one odometry stream (k_odom_lm, BasicLaserOdometry.cpp:484-622 is ONE loop there) rests on
 a property of the memory system that no document promises: an aligned 16-byte agent-scope store is observed whole, or split at 8 bytes —
 never finer — so a tagged record {tag, value lo, value hi, tag} read with both tags equal to k holds both halves of value k
-(csrc/dev_math.cuh: xrec_store / xrec_load).  The poses would drift silently if a ROCm or firmware update broke that; this probe would
+(csrc/dev_math.hpp: xrec_store / xrec_load).  The poses would drift silently if a ROCm or firmware update broke that; this probe would
 not be silent: producer / consumer workgroup pairs on different XCDs hammer shared records and every ACCEPTED read is checked against the
 value its tag names."""
 import pytest

@@ -276,7 +276,7 @@ def test_bench_scale_8_streams_vs_oracle():
 
 @pytest.mark.parametrize("ahead,pinned", [(3, False), (8, False), (7, True)])
 def test_streaming_io_equals_staged_run(orc, small_world, ahead, pinned):
-    """(pinned: the destinations are pinned memory of the runtime's own, the downloads go to the SDMA engine directly — csrc/hostlink.cuh;
+    """(pinned: the destinations are pinned memory of the runtime's own, the downloads go to the SDMA engine directly — csrc/hostlink.hpp;
     ahead = 8: the header's contract to the letter — eight steps in flight, stage_step(t) right after step(t - 8))
     loamx_pipeline_stage_step / download_step_async (the PCIe-inclusive mode): one step handed over at a time, at most eight
     in flight, registered clouds copied out asynchronously from alternating device buffers — bit-identical to the run that

@@ -1,4 +1,4 @@
-"""Static check of the exchange loads (no GPU): `xchg_load_nowait` (dev_math.cuh) issues an agent-scope load WITHOUT its wait so that a
+"""Static check of the exchange loads (no GPU): `xchg_load_nowait` (dev_math.hpp) issues an agent-scope load WITHOUT its wait so that a
 batch of them is in flight at once; nothing may touch a destination register before the batch's `s_waitcnt vmcnt(0)` — the hardware
 does not interlock on a pending load, and the compiler does not know the register is pending.  The call site's
 discipline is checked here in the ISA of the product build's flags, so a compiler that starts moving or spilling those registers
@@ -60,7 +60,7 @@ def test_no_instruction_touches_a_pending_exchange_load(tmp_path):
 
 @pytest.mark.skipif(not (os.path.exists(HIPCC) and os.path.exists(OBJDUMP)), reason="needs hipcc and llvm-objdump")
 def test_inline_16_byte_exchange_store_is_followed_by_its_wait_states(tmp_path):
-    """xrec_store (dev_math.cuh) is a 16-byte agent-scope store issued through inline asm: the instruction behind it must be the
+    """xrec_store (dev_math.hpp) is a 16-byte agent-scope store issued through inline asm: the instruction behind it must be the
     `s_nop` of the same statement (a store of more than 64 bits followed at once by a write to its data registers is a hazard the
     compiler only pads for stores it emitted itself)"""
     co = str(tmp_path / "odometry.co")

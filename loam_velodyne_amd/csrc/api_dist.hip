@@ -52,6 +52,15 @@ static inline ncclResult_t ncclRecv(void*, size_t, int, int, ncclComm_t, hipStre
 
 using namespace loamx;
 
+// ncclGroupStart ... ncclGroupEnd with the end guaranteed: a throw between the two (LX_NCCL on a failed send / recv) would otherwise leave
+// the thread's group open and every later collective of the process queued inside it
+struct NcclGroup {
+  bool open = false;
+  NcclGroup() { LX_NCCL(ncclGroupStart()); open = true; }
+  void end() { open = false; LX_NCCL(ncclGroupEnd()); }
+  ~NcclGroup() { if (open) (void)ncclGroupEnd(); }
+};
+
 struct loamx_dist {
   int rank = 0, world = 1, device = 0;
   ncclComm_t comm = nullptr;
@@ -121,10 +130,12 @@ int loamx_dist_broadcast_map(loamx_dist* h, void* d_corner_xyzi, uint32_t n_corn
     LX_HIP(hipSetDevice(h->device));
     TraceRange trace_range("loamx:dist:broadcast_map");
     if (wait_event) LX_HIP(hipStreamWaitEvent(h->st, (hipEvent_t)wait_event, 0));   // whatever filled the root's buffers
-    LX_NCCL(ncclGroupStart());
-    if (n_corner) LX_NCCL(ncclBroadcast(d_corner_xyzi, d_corner_xyzi, (size_t)4 * n_corner, ncclFloat, root, h->comm, h->st));
-    if (n_surf) LX_NCCL(ncclBroadcast(d_surf_xyzi, d_surf_xyzi, (size_t)4 * n_surf, ncclFloat, root, h->comm, h->st));
-    LX_NCCL(ncclGroupEnd());
+    {
+      NcclGroup grp;
+      if (n_corner) LX_NCCL(ncclBroadcast(d_corner_xyzi, d_corner_xyzi, (size_t)4 * n_corner, ncclFloat, root, h->comm, h->st));
+      if (n_surf) LX_NCCL(ncclBroadcast(d_surf_xyzi, d_surf_xyzi, (size_t)4 * n_surf, ncclFloat, root, h->comm, h->st));
+      grp.end();
+    }
     LX_HIP(hipEventRecord(h->ev_bcast, h->st));
     if (done_event) *done_event = (void*)h->ev_bcast;
     return LOAMX_OK;
@@ -328,16 +339,18 @@ int loamx_dist_gatherv(loamx_dist* h, const uint32_t* send_words, uint32_t n_wor
     }
     const bool is_root = h->rank == root;
     if (is_root) { h->d_grecv.reserve((size_t)total + 1); h->h_grecv.reserve((size_t)total + 1); }
-    LX_NCCL(ncclGroupStart());
-    if (is_root) {
-      size_t off = 0;
-      for (int r = 0; r < G; r++) {
-        if (h->h_cnt.p[r]) LX_NCCL(ncclRecv(h->d_grecv.p + off, h->h_cnt.p[r], ncclUint32, r, h->comm, h->st));
-        off += h->h_cnt.p[r];
+    {
+      NcclGroup grp;
+      if (is_root) {
+        size_t off = 0;
+        for (int r = 0; r < G; r++) {
+          if (h->h_cnt.p[r]) LX_NCCL(ncclRecv(h->d_grecv.p + off, h->h_cnt.p[r], ncclUint32, r, h->comm, h->st));
+          off += h->h_cnt.p[r];
+        }
       }
+      if (n_words) LX_NCCL(ncclSend(h->d_gsend.p, n_words, ncclUint32, root, h->comm, h->st));
+      grp.end();
     }
-    if (n_words) LX_NCCL(ncclSend(h->d_gsend.p, n_words, ncclUint32, root, h->comm, h->st));
-    LX_NCCL(ncclGroupEnd());
     if (is_root) LX_HIP(hipMemcpyAsync(h->h_grecv.p, h->d_grecv.p, sizeof(uint32_t) * total, hipMemcpyDeviceToHost, h->st));
     LX_HIP(hipStreamSynchronize(h->st));
     if (is_root) {

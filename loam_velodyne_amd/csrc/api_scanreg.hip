@@ -74,7 +74,7 @@ int loamx_scanreg_process(loamx_scanreg* h, const loamx_cloud* cloud, const uint
     LX_REQUIRE(h && cloud && ring_size && n_rings > 0, "NULL / empty argument");
     const uint32_t* rs[1] = {ring_size};
     h->fx.begin_sweep();   // reset(scanTime) / updateIMUTransform() of processScanlines (identities without IMU data)
-    h->fx.upload(1, cloud, rs, &n_rings);
+    h->fx.upload(1, cloud, rs, &n_rings, /*allow_direct=*/true);   // (download() below waits for the sweep: the cloud is free when this returns)
     h->fx.run_async();
     return h->fx.download(0, sharp, less_sharp, flat, less_flat);   // (one wait, behind the launch that packs the clouds into pinned memory)
   });
@@ -85,7 +85,10 @@ int loamx_scanreg_process_linked(loamx_scanreg* h, const loamx_cloud* cloud, con
     LX_REQUIRE(h && cloud && ring_size && n_rings > 0, "NULL / empty argument");
     const uint32_t* rs[1] = {ring_size};
     h->fx.begin_sweep();
-    h->fx.upload(1, cloud, rs, &n_rings);   // (the caller's cloud has been copied out when this returns)
+    // a packed cloud in runtime-pinned memory is NOT copied out when this returns: a kernel of the extraction fetches it from where it
+    // lies, so it must stay unchanged until loamx_odom_process_linked has returned for this sweep (include/loamx.h); any other cloud
+    // has been packed into the handle's own staging block by now
+    h->fx.upload(1, cloud, rs, &n_rings, /*allow_direct=*/true);
     h->fx.run_async();                      // no wait: loamx_odom_process_linked waits for (and checks) the extraction
     return LOAMX_OK;
   });

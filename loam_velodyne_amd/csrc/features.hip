@@ -842,7 +842,7 @@ void FeatureExtractor::allocate_(hipStream_t table_stream) {
   sweep_ring_base_.p = tab_dev_.p + 2 * (size_t)nring_ + 1;
 }
 
-void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
+void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings, bool allow_direct) {
   LX_REQUIRE(nsw >= 1 && clouds && ring_size && n_rings, "invalid sweep batch");
   check_params_();
   LX_HIP(hipSetDevice(device_));
@@ -854,9 +854,11 @@ void FeatureExtractor::upload(uint32_t nsw, const loamx_cloud* clouds, const uin
   }
   LX_HIP(hipStreamSynchronize(st_));   // (the staging block and the tables of the previous sweep are free: nothing to wait for unless the caller skipped its results)
   layout_(nsw, ring_size, n_rings);
-  // one sweep of packed x y z intensity records in memory the runtime has pinned goes up straight from where it lies (the caller
-  // keeps it unchanged until the results of this sweep have been taken); anything else through this object's pinned staging block
-  const bool direct = nsw == 1 && n_ && packed_layout(&clouds[0]) && host_pinned(clouds[0].data, sizeof(float4) * n_);
+  // one sweep of packed x y z intensity records in memory the runtime has pinned goes up straight from where it lies — only for the
+  // callers that ask for it (allow_direct): the fetch kernel reads the CALLER's block after this function has returned, so the entry
+  // point must either wait for the sweep's results itself (loamx_scanreg_process) or state the lifetime in its contract
+  // (loamx_scanreg_process_linked).  Anything else goes through this object's own pinned staging block, packed before this returns.
+  const bool direct = allow_direct && nsw == 1 && n_ && packed_layout(&clouds[0]) && host_pinned(clouds[0].data, sizeof(float4) * n_);
   if (!direct) {
     h_cloud_.reserve(n_ + 1);
     for (uint32_t s = 0; s < nsw; s++) pack_cloud(&clouds[s], h_cloud_.p + h_pt_base_[s]);

@@ -60,7 +60,7 @@ class FeatureExtractor {
   int device() const { return device_; }
 
   // stage nsw sweeps: cloud[s] = rings concatenated, ring_size[s][0..n_rings[s])
-  void upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings);
+  void upload(uint32_t nsw, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings, bool allow_direct = false);
   // the same without blocking: every copy goes to `copy_stream` (packed float4 clouds straight from the caller's memory —
   // pinned memory makes that a true DMA — other layouts through this object's pinned staging), `done` is recorded behind
   // them; run_async() must be ordered behind `done`.  The caller's buffers are read until `done` has completed.

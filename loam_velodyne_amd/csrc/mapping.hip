@@ -357,6 +357,7 @@ class Mapper {
   float sum_prev6[6] = {0, 0, 0, 0, 0, 0};   // transformSum of the previous processed sweep (the prediction's velocity)
   bool have_sum_prev = false;
   struct SpecInputs { float sum6[6], sum_prev6[6]; HTwist bef, aft; bool ok = false, ready = false; uint32_t n_in_room[2] = {0, 0}; } spec_in;   // (guarded by helper.mu)
+  uint32_t spec_room[2] = {0, 0};   // n_in_room of the partition that was prepared (valid with spec_valid; written by the helper before it posts)
   const short* slot_lut_v = nullptr;
   const uint8_t* sur_lut_v = nullptr;
   const uint32_t* slot_tag_v = nullptr;
@@ -474,9 +475,9 @@ void Mapper::ensure(TypeMap& t, uint32_t n_map_max, uint32_t n_in) {
   hipStream_t st = reg.stream();
   // A rolling map grows with every sweep that sees something new, and growing a device buffer is a hipFree + hipMalloc: 1.5-2 ms with the
   // device drained, in front of a 0.3 ms call (measured: four such stalls in 110 sweeps of the live bench with 25 % head room).  Room
-  // is taken in large steps instead — a million points to start with (~100 MB per feature type over all its buffers), doubled when a
-  // map outgrows it — the sub-map's index and the surround cloud's buffers included.
-  if (n_map_max + 1 > t.room) t.room = std::max<uint32_t>(2u * (n_map_max + 1), 1u << 20);
+  // is taken in large steps instead — twice what the map needs when a buffer has to move (at least 128 k points), so a map that grows
+  // steadily moves its buffers O(log) times — the sub-map's index and the surround cloud's buffers included.
+  if (n_map_max + 1 > t.room) t.room = std::max<uint32_t>(2u * (n_map_max + 1), 1u << 17);   // (a small handle stays small: ~13 MB per feature type at the floor)
   const uint32_t room = t.room;
   for (int b = 0; b < 2; b++) {
     t.pts[b].reserve(room, st, b == t.cur);
@@ -559,7 +560,9 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
 
   // a partition prepared for the predicted pose is this sweep's own if the plans agree entry by entry (and the sweep fits the room the
   // buffers were given: ensure() must not move them)
-  const bool adopt = spec_valid && plan.same_as(spec_plan) && tm[0].n + n_in[0] + 65 <= tm[0].room && tm[1].n + n_in[1] + 65 <= tm[1].room;
+  // ... nor grow a look-back chain: the prepared side sized them for sweeps of at most spec_room points
+  const bool adopt = spec_valid && plan.same_as(spec_plan) && tm[0].n + n_in[0] + 65 <= tm[0].room && tm[1].n + n_in[1] + 65 <= tm[1].room &&
+                     n_in[0] <= spec_room[0] && n_in[1] <= spec_room[1];
   if (spec_valid) (adopt ? spec_hits : spec_misses)++;
   spec_valid = false;
   if (adopt) tab_cur ^= 1;   // (the prepared tables are the current ones now; slot_lut_v / sur_lut_v / slot_tag_v point into them already)
@@ -685,6 +688,8 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
       Plan sp;
       if (make_plan(tobe_pred, /*may_shift=*/false, sp)) {
         enqueue_partition(sp, tab_cur ^ 1, in.n_in_room);
+        spec_room[0] = in.n_in_room[0];   // (the look-back chains of k_map_insert were sized for sweeps of at most this many points)
+        spec_room[1] = in.n_in_room[1];
         spec_plan = std::move(sp);
         spec_valid = true;
       }
@@ -698,6 +703,9 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   int stats4[4];
   reg.sync();
   tr.mark("synced");
+  // the partition this registration read was split by a fused kernel with a look-back: had a tile given up, the sub-map would be
+  // incomplete — fail THIS sweep, not the next call (the word is host-visible; the split precedes the registration on its stream)
+  if (*(volatile uint32_t*)h_err.p) { *h_err.p = 0u; throw Error(LOAMX_E_HIP, "map partition: a tile's look-back gave up waiting for the tiles before it"); }
   reg.download(pose6, stats4);
   LX_HIP(hipGetLastError());
   SweepStats ss;

@@ -15,6 +15,8 @@
 //                  6x6 pivoted QR solve, degeneracy projector, update, convergence test.
 #include "odometry.hpp"
 #include "pinned_copy.hpp"
+#include <chrono>
+#include <cstring>
 #include <type_traits>
 
 namespace loamx {
@@ -1150,7 +1152,18 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   }
   if (na) {
     if (max_feat) {
-      for (int it0 = 0; it0 < params.max_iterations; it0 += 5) {
+      // Launch pairs (correspondences + up to five iterations).  The reference leaves its loop when the stop test fires
+      // (BasicLaserOdometry.cpp:613-620); a pair enqueued behind a sweep that has converged costs ~20 us of empty launches, so pairs
+      // are enqueued as they turn out to be needed, one pair behind the device: while pair k runs, the host reads from the pinned
+      // mirror (k_odom_lm writes a stream's state there at the end of every launch) whether pair k - 1 left any stream unconverged,
+      // and only then enqueues pair k + 1 — the queue never runs dry and at most ONE pair is wasted (round 5: 1.6 on average).
+      // Result-neutral by construction: a pair that is not enqueued would have returned at its first instruction (pb.done / the
+      // iteration bound).  LOAMX_ODOM_PAIRS=all restores the fixed five pairs, =exact waits for the LAST pair instead (no wasted pair,
+      // one host round trip in front of the tail).
+      const int pair_mode = [] { const char* e = getenv("LOAMX_ODOM_PAIRS"); return !e ? 1 : !strcmp(e, "all") ? 0 : !strcmp(e, "exact") ? 2 : 1; }();
+      const int maxp = (params.max_iterations + 4) / 5;
+      for (uint32_t a = 0; a < na; a++) { h_mirror_.p[a].done = 0; h_mirror_.p[a].stats.iterations = 0; }   // (the previous sweep's launches finished before its poses were read)
+      auto enqueue_pair = [&](int it0) {
         const int nit = std::min(5, params.max_iterations - it0);
         const int lk = lt && lt->pairs < LT_MAXP ? lt->pairs : -1;
         if (lk >= 0) {
@@ -1183,7 +1196,36 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
           else hipLaunchKernelGGL(k_odom_lm<1>, dim3(nb, nc), dim3(OD_THREADS), 0, st_, prob_.p + a0, params, it0, nit);
         }
         if (lk >= 0) { LX_HIP(hipEventRecord(lt->ev[3 * lk + 2], st_)); lt->pairs = lk + 1; }
+      };
+      const volatile OdomProblem* hm = h_mirror_.p;
+      auto settled = [&](int k) {     // every stream is through launch pair k (or had converged before it)
+        const int want = std::min(5 * (k + 1), params.max_iterations);
+        for (uint32_t a = 0; a < na; a++) if (hm[a].done == 0 && hm[a].stats.iterations < want) return false;
+        return true;
+      };
+      auto converged = [&]() {        // no stream has anything left to iterate
+        for (uint32_t a = 0; a < na; a++) if (hm[a].done == 0 && hm[a].stats.iterations < params.max_iterations) return false;
+        return true;
+      };
+      int enq = 0;
+      const int first = pair_mode == 0 ? maxp : std::min(maxp, pair_mode == 2 ? std::max(1, pred_pairs_) : 2);
+      for (; enq < first; enq++) enqueue_pair(5 * enq);
+      bool blind = false;             // the mirror did not answer in time: enqueue the rest unconditionally (always correct)
+      while (enq < maxp) {
+        const int watch = pair_mode == 2 ? enq - 1 : enq - 2;
+        if (!blind && watch >= 0) {
+          const auto t_in = std::chrono::steady_clock::now();
+          for (unsigned spins = 0; !settled(watch);) {
+            if ((++spins & 255u) == 0u && std::chrono::steady_clock::now() - t_in > std::chrono::milliseconds(20)) { blind = true; break; }
+            __builtin_ia32_pause();
+          }
+          if (!blind && converged()) break;
+        }
+        enqueue_pair(5 * enq);
+        enq++;
       }
+      pairs_enqueued_ += (uint64_t)enq;
+      pair_calls_++;
     }
     if (!max_feat) LX_HIP(hipMemcpyAsync(h_mirror_.p, prob_.p, sizeof(OdomProblem) * na, hipMemcpyDeviceToHost, st_));   // (no launch wrote the mirror)
     if (!ev_pose_) LX_HIP(hipEventCreateWithFlags(&ev_pose_, hipEventDisableTiming));
@@ -1240,6 +1282,11 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       fprintf(stderr, "\n");
     }
 #endif
+    {
+      int need = 1;
+      for (uint32_t a = 0; a < na; a++) need = std::max(need, (h_mirror_.p[a].stats.iterations + 4) / 5);
+      pred_pairs_ = need;   // (LOAMX_ODOM_PAIRS=exact: a stream that needs every iteration needs them for several sweeps in a row)
+    }
     for (uint32_t a = 0; a < na; a++) {
       OdomStream& S = *streams_[active[a]];
       // _transform.rot_* = rad + x re-derives the cached sin/cos (:599-601)

@@ -164,6 +164,8 @@ class OdometryBatch {
   uint32_t n_link_full_ = 0;
   bool link_valid_ = false;
   hipEvent_t ev_link_ = nullptr;
+  int pred_pairs_ = 5;               // launch pairs the slowest stream of the previous sweep needed (LOAMX_ODOM_PAIRS=exact)
+  uint64_t pairs_enqueued_ = 0, pair_calls_ = 0;   // launch pairs enqueued / sweeps with iterations, since creation
   uint32_t lm_slots_[2] = {0, 0};   // workgroups of k_odom_lm<1> / <2> the device holds at once (occupancy x CUs)
   hipEvent_t ev_tail_ = nullptr, ev_pose_ = nullptr, ev_up_ = nullptr;
   bool tail_pending_ = false, up_pending_ = false;

@@ -910,13 +910,15 @@ class Dist:
         # disagreed would hang in mismatched collectives); `batch` is only checked against them
         _check(lib().loamx_dist_allgather_counts(self.h, n, cnt.ctypes.data_as(C.c_void_p)))
         cap = int(cnt.sum())
-        if batch is not None and int(batch) != cap:
-            raise ValueError(f"allgather_results: batch = {batch} but the ranks hold {cap} records")
+        # (a `batch` that disagrees is reported AFTER the results collective: a rank that left the protocol between the two collectives
+        # would leave the others blocked inside the second one)
         pa = np.zeros((max(cap, 1), 6), np.float32)
         fa = np.zeros((max(cap, 1), 2), np.int32)
         _check(lib().loamx_dist_allgather_results_cap(self.h, p.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p) if f is not None else None,
                                                       n, pa.ctypes.data_as(C.c_void_p), fa.ctypes.data_as(C.c_void_p), cap, cnt.ctypes.data_as(C.c_void_p)))
         tot = int(cnt.sum())
+        if batch is not None and int(batch) != cap:
+            raise ValueError(f"allgather_results: batch = {batch} but the ranks hold {cap} records")
         return pa[:tot], fa[:tot], cnt
 
     def allgather_counts(self, n: int) -> np.ndarray:

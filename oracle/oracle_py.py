@@ -430,11 +430,12 @@ class RefLaserOdometry:
     against oracle/ref_stubs — see oracle/ref_odometry_shim.cpp for what is and is not the reference's code).  Same surface as
     LaserOdometry above.  `available()` is False when oracle/_ref/libref_odometry.so is not built."""
     _L = None
+    _SO = "libref_odometry.so"
 
     @classmethod
     def available(cls):
         if cls._L is None:
-            path = os.path.join(_HERE, "_ref", "libref_odometry.so")
+            path = os.path.join(_HERE, "_ref", cls._SO)
             if not os.path.exists(path):
                 return False
             cls._L = C.CDLL(path)
@@ -712,6 +713,13 @@ class RefNodes:
             self.L.nodes_cloud_get(self.h, which, i, a.ctypes.data_as(C.c_void_p), n)
             out.append(a[:n].reshape(-1, 4).copy())
         return out
+
+
+class RefLaserOdometryAlt(RefLaserOdometry):
+    """the reference's BasicLaserOdometry over the ALTERNATIVE third-party arithmetic (-DREF_STUB_ALT_ARITH): products accumulated in double,
+    the 6x6 solve by elimination in double — a sensitivity probe (what the unpinned Eigen operations could change), not a pin"""
+    _L = None
+    _SO = "libref_odometry_alt.so"
 
 
 class RefLaserMappingAlt(RefLaserMapping):

@@ -205,7 +205,7 @@ class FakePipeline:
 
     def get(self, k):
         z = np.zeros(6, np.float32)
-        return z, z, z, dict(map_iterations=3, mapped=1, odom_iterations=7, odom_sel=100, map_sel=500, corner_q=100, surf_q=900, degenerate=0)
+        return z, z, z, dict(map_iterations=3, mapped=1, odom_iterations=7, odom_sel=100, map_sel=500, corner_ds=100, surf_ds=900, degenerate=0)
 
     def wait_downloads(self):
         pass
@@ -257,9 +257,9 @@ class FakeLib:
 
 
 @pytest.mark.parametrize("argv", [["--steps", "3", "--warmup", "1", "--streams", "2", "--sensor", "VLP-16", "--map-points", "2000", "--no-cpu-baseline",
-                                   "--repeat", "2"],
+                                   "--repeat", "2", "--no-side-configs"],
                                   ["--steps", "3", "--warmup", "1", "--streams", "2", "--sensor", "VLP-16", "--map-points", "2000", "--no-cpu-baseline",
-                                   "--repeat", "2", "--handles", "2"]])
+                                   "--repeat", "2", "--handles", "2", "--no-side-configs"]])
 def test_bench_main_runs_over_stand_ins(monkeypatch, capsys, argv):
     H = int(argv[argv.index("--handles") + 1]) if "--handles" in argv else 1
     from loam_velodyne_amd import loamx
@@ -411,3 +411,107 @@ def test_bench_epoch_merge_as_rank_0_of_eight(monkeypatch, capsys):
     assert len(acc.inserted) == merged and FakeDist.made[0].gathers == boundaries
     sizes = FakePipeline.instances[-1].map_sizes
     assert len(sizes) >= K // E and sizes[-1][0] > sizes[0][0] and sizes[-1][1] > sizes[0][1]   # the staged map grew with the merged sweeps
+
+
+def _canned_live(sensor, M, K, W, cpu=True, nodes=True, within=True):
+    """what bench.live_block returns, as far as the line's assembly reads it"""
+    return {"metric": f"sweeps/sec (sequential SLAM: {sensor})", "value": 1500.0, "unit": "sweeps/s", "ms_per_step": 0.66, "steps": K, "warmup": W,
+            "config": {"workload": sensor}, "roofline": {"kernel": "loamx::k_gn_iter", "frac": 0.003},
+            "cpu_baseline": {"value": 25.0, "unit": "sweeps/s", "cores": 1, "kind": "port"},
+            "pose_err_vs_oracle": {"mapped_pose": {"max_m": 4e-4, "max_rad": 1e-6, "rmse_m": 1e-4}, "bar_free_running": 1.4e-3, "within_bar": within}}
+
+
+@pytest.mark.parametrize("within", [True, False])
+def test_default_line_carries_every_single_gpu_configuration(monkeypatch, capsys, within):
+    """the driver runs `bench.py --gpus 1` only: the line must carry BASELINE configs[1], [2] and configs[4]'s one-GPU point as blocks, their
+    headline figures flat in `config` and once more in the line's LAST key — and the run must exit with status 3 when any block's parity is
+    outside its bar (after the line has been printed)"""
+    from loam_velodyne_amd import loamx
+    monkeypatch.setitem(sys.modules, "torch", fake_torch())
+    monkeypatch.setattr(loamx, "Pipeline", FakePipeline)
+    monkeypatch.setattr(loamx, "lib", lambda: FakeLib(loamx))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3", "--warmup", "1", "--streams", "2", "--sensor", "VLP-16", "--map-points", "2000", "--map2-points", "4000",
+                                      "--no-cpu-baseline", "--repeat", "1", "--no-pcie"])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    FakePipeline.instances.clear()
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(bench, "live_block", lambda *a, **kw: _canned_live(*a, **kw, within=within))
+    if within:
+        bench.main()
+    else:
+        with pytest.raises(SystemExit) as e:
+            bench.main()
+        assert e.value.code == 3
+    line = [l for l in capsys.readouterr().out.strip().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert list(out)[-1] == "summary"
+    for key in ("map_2m", "live_vlp16", "live_hdl32"):
+        assert key in out and "error" not in out[key], out.get(key)
+    assert out["map_2m"]["workload"].startswith("BASELINE configs[4]") and "4000-pt" in out["map_2m"]["workload"]
+    for k in ("live_vlp16_sweeps_per_s", "live_vlp16_ms_per_sweep", "live_vlp16_pose_max_m", "live_vlp16_within_bar", "live_hdl32_sweeps_per_s",
+              "map_2m_sweeps_per_s", "map_2m_ms_per_step", "all_within_bar"):
+        assert k in out["summary"] and out["config"][k] == out["summary"][k], k
+    assert out["summary"]["all_within_bar"] is within
+    # the 2 M block ran its windows against its own map and put the first map back
+    assert out["config"]["map_points"] == 2000
+
+
+def _rows(n, d_at=None, counts_at=None):
+    """(gpu rows, oracle rows): identical chains except a mapped-pose difference d at sweep index d_at (and other counts there)"""
+    g, o = [], []
+    for t in range(1, n + 1):
+        ts = np.full(6, 0.01 * t, np.float32)
+        aft = np.full(6, 0.02 * t, np.float32)
+        cnt = (1800, 11000, 1300, 12000)
+        ag, cg = aft.copy(), cnt
+        if d_at is not None and t == d_at[0]:
+            ag[3] += np.float32(d_at[1])
+            if counts_at:
+                cg = (1800, 10999, 1299, 12000)
+        g.append((t, 0, ts, ag, 6, 3, cg))
+        o.append((t, ts, aft, 6, 3, cnt))
+    return g, o
+
+
+def test_parity_gate_rules():
+    """bench.pose_error's bar: flat 1e-4 without an envelope; with one, max(1e-4, envelope) — and a sweep beyond that only as an explained
+    threshold flip (per step from identical state <= 1e-6 there and a discrete count differing), the distribution not above the envelope's"""
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    g, o = _rows(50)
+    assert bench.pose_error(g, o)["within_bar"] is True
+    g, o = _rows(50, d_at=(20, 3e-4))
+    pe = bench.pose_error(g, o)
+    assert pe["within_bar"] is False and pe["mapped_pose"]["max_at"]["sweep"] == 20 and pe["mapped_pose"]["max_at"]["component"] == "x"
+    env = {"max_m": 1.7e-4, "max_rad": 1e-5, "rmse_m": 5e-5, "p99_m": 2e-4, "sweeps_above_1e-4": 3, "odometry_sum_max_m": 5e-4, "pairs": {}}
+    ps_ok = {"max_m": 7e-5, "max_rad": 1e-6, "by_sweep": {t: 1e-8 for t in range(1, 51)}}
+    # beyond the envelope, per step fine, but no count differs: not explained
+    assert bench.pose_error(g, o, envelope=env, per_step=ps_ok)["within_bar"] is False
+    # ... with a differing count at that sweep: an explained flip
+    g, o = _rows(50, d_at=(20, 3e-4), counts_at=True)
+    pe = bench.pose_error(g, o, envelope=env, per_step=ps_ok)
+    assert pe["within_bar"] is True and pe["sweeps_outside_bar_free_running"][0]["explained_as_threshold_flip"] is True and pe["bar_free_running"] == pytest.approx(1.7e-4)
+    assert pe["counts_equal"]["map_sel"] == 49 and pe["counts_equal"]["odom_sel"] == 50
+    # the same flip, but the device differs from the oracle on identical inputs at that sweep: not a flip of the chain, a difference of the arithmetic
+    ps_bad = dict(ps_ok, by_sweep={**ps_ok["by_sweep"], 20: 5e-5})
+    assert bench.pose_error(g, o, envelope=env, per_step=ps_bad)["within_bar"] is False
+    # per step from identical state above 1e-4 anywhere fails whatever the envelope says
+    assert bench.pose_error(*_rows(50), envelope=env, per_step=dict(ps_ok, max_m=2e-4))["within_bar"] is False
+    # inside the envelope: fine without any explanation
+    g, o = _rows(50, d_at=(20, 1.5e-4))
+    assert bench.pose_error(g, o, envelope=env, per_step=ps_ok)["within_bar"] is True
+
+
+def test_reference_envelope_block():
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    base = np.zeros((30, 13)); base[:, 0] = np.arange(1, 31)
+    fast = base.copy(); fast[7, 10] += 1.2e-4
+    ref = base.copy()
+    alt = base.copy(); alt[9, 12] -= 2.0e-4; alt[3, 8] += 3e-6
+    env = bench.reference_envelope({"oracle_fast": fast, "ref": ref, "ref_map_alt": alt}, base)
+    assert env["pairs"]["ref"]["mapped_max_m"] == 0.0                      # the pin: reported, not part of the envelope
+    assert env["max_m"] == pytest.approx(2.0e-4) and env["pairs"]["ref_map_alt"]["mapped_max_at_sweep"] == 10
+    assert env["sweeps_above_1e-4"] == 1 and env["max_rad"] == pytest.approx(3e-6)

@@ -56,6 +56,10 @@ def main():
                     help="with --map-epoch-steps: the epoch's merge step too — every rank's registered sweeps (re-projected clouds + mapped pose) travel to "
                          "rank 0 (loamx_dist_gatherv), are inserted into the map accumulator there (loamx_map_insert) and the MERGED map is what the "
                          "next epoch broadcasts; synchronous on the stepping thread (the accumulator's ~1-2 ms per sweep is rank 0's)")
+    ap.add_argument("--epoch-merge-async", action="store_true",
+                    help="with --map-epoch-steps: the merge step OFF the stepping thread — the accumulator (gather, loamx_map_insert, cubes download, upload + broadcast "
+                         "of the merged map) runs on a worker thread with a communicator of its own (loam_velodyne_amd.dist.AsyncEpochMerger); the stepping thread hands "
+                         "over its streams' latest sweeps whenever the worker is idle and stages a merged map when one has arrived (swapped in at the next boundary)")
     ap.add_argument("--sensor", default=SENSOR, choices=["HDL-32", "HDL-64E", "VLP-16"], help="parity / side configurations (BASELINE configs[1], [2])")
     ap.add_argument("--streams", type=int, default=STREAMS_PER_GPU)
     ap.add_argument("--handles", type=int, default=HANDLES_PER_GPU,
@@ -151,6 +155,15 @@ def main():
             t_bcast = time.perf_counter() - t0
             bcast_via = "torch.distributed broadcast (native path failed: %s)" % repr(e)[:160]
 
+    # the asynchronous epoch merge's worker thread talks over a communicator of its own (an RCCL communicator serves one thread at a time)
+    ldist_merge = None
+    if dist is not None and ldist is not None and args.epoch_merge_async and args.map_epoch_steps > 0:
+        uid2 = torch.zeros(loamx.Dist.ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid2.copy_(torch.frombuffer(bytearray(loamx.Dist.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid2, src=0)
+        ldist_merge = loamx.Dist(bytes(uid2.cpu().numpy().tobytes()), rank, world, local_rank)
+
     # ---- this rank's streams and staged sweeps (distinct trajectories per rank and stream)
     sweeps = [[None] * ns for _ in range(T_all)]
     starts = []
@@ -163,7 +176,7 @@ def main():
             jobs.append((t, s, (125.0, args.sensor, poses[t], poses[t + 1], 1000 * gs + t)))
     # ray casting is ~0.5 s per HDL-64E sweep on one core and the GPU box is leased by the minute: the (seeded, order-independent)
     # sweeps are generated by worker processes — spawned, not forked: the HIP runtime is already up in this one
-    n_workers = max(1, min(int(os.environ.get("LOAMX_BENCH_WORKERS", "32")), (os.cpu_count() or 1) // max(world, 1), len(jobs)))
+    n_workers = max(1, min(int(os.environ.get("LOAMX_BENCH_WORKERS", "96")), len(os.sched_getaffinity(0)) // max(world, 1), len(jobs)))
     if n_workers > 1:
         import multiprocessing as mp
         from concurrent.futures import ProcessPoolExecutor
@@ -215,10 +228,35 @@ def main():
         ev_map = torch.cuda.Event() if E > 0 else None
         # the epoch's merge step (--epoch-merge): rank 0 owns the accumulator, loaded with the first epoch's map
         acc = None
-        if E > 0 and args.epoch_merge and rank == 0:
+        if E > 0 and (args.epoch_merge or args.epoch_merge_async) and rank == 0:
             acc = loamx.LaserMapping(device=local_rank)
             acc.load_cubes(*map_host)
         r["merged_sweeps"] = 0
+        merger = None
+        if E > 0 and args.epoch_merge_async:
+            # three device buffers in rotation: the map being registered against, the one staged behind it, the one being filled
+            bufs = [torch.empty((int(1.3 * M) + 65536, 4), dtype=torch.float32, device=dev) for _ in range(3)]
+            turn = [0]
+            ev_pub = [torch.cuda.Event() for _ in range(3)]
+
+            def publish(corner, surf):   # (worker thread)
+                b = turn[0] % 3
+                turn[0] += 1
+                nc_e, ns_e = (len(corner), len(surf)) if corner is not None else (0, 0)
+                if ldist_merge is not None:   # the new sizes reach every rank the way the counts of the other exchanges do
+                    nc_e = int(ldist_merge.allgather_counts(nc_e)[0]); ns_e = int(ldist_merge.allgather_counts(ns_e)[0])
+                if bufs[b].shape[0] < nc_e + ns_e:
+                    bufs[b] = torch.empty((int(1.2 * (nc_e + ns_e)), 4), dtype=torch.float32, device=dev)
+                if corner is not None:
+                    bufs[b][:nc_e + ns_e].copy_(torch.from_numpy(np.concatenate([corner, surf], axis=0)))
+                ev_pub[b].record()
+                ev = ev_pub[b].cuda_event
+                if ldist_merge is not None:
+                    ev = ldist_merge.broadcast_map(bufs[b].data_ptr(), nc_e, bufs[b].data_ptr() + 16 * nc_e, ns_e, root=0, wait_event=ev)
+                return (bufs[b].data_ptr(), nc_e, bufs[b].data_ptr() + 16 * nc_e, ns_e, ev)
+
+            merger = lxdist.AsyncEpochMerger(acc, ldist_merge, rank, 0, publish, before_job=lambda: torch.cuda.set_device(local_rank))
+        r["merge_jobs"] = 0
         sizes = [n_corner, n_surf]   # of the map the NEXT epoch registers against (changes once sweeps are merged)
 
         def snapshot(h, t):
@@ -249,6 +287,19 @@ def main():
                         slot = ((t - (1 + W)) // E) % 2
                         map_next = map_nexts[slot]
                         nc_e, ns_e = sizes
+                        if merger is not None:
+                            # the accumulator runs beside the steps: hand it this rank's latest sweeps whenever it is idle, nothing else
+                            # happens at a boundary (a merged map that has arrived was staged between two steps, below)
+                            if t > 1 + W and merger.idle():
+                                mine = []
+                                for k_ in range(per):
+                                    _, _, aft_, st_ = p.get(k_)
+                                    if st_["mapped"]:
+                                        lc_, ls_ = p.last_clouds(k_, n_points)
+                                        mine.append((aft_, lc_, ls_))
+                                merger.submit(mine)
+                            k = -1   # (skip the synchronous staging below)
+                    if k == 0:
                         if args.epoch_merge and t > 1 + W:
                             # collective 3: this rank's streams' last sweeps -> rank 0's accumulator -> the merged map
                             mine = []
@@ -280,6 +331,10 @@ def main():
                             ev = ev_map.cuda_event
                         # the index build waits for the event on the device; nothing blocks here
                         p.stage_frozen_device(map_next.data_ptr(), nc_e, map_next.data_ptr() + 16 * nc_e, ns_e, ev)
+                if merger is not None:
+                    tok = merger.take_ready()
+                    if tok is not None:   # a merged map has arrived: index it in the background now, swap it in at the next boundary
+                        p.stage_frozen_device(*tok)
                 # HIP-event timing (stage chains + a pair around every Gauss-Newton launch) on every 4th step only: the event pairs and
                 # their read-back (event synchronise, a statistics download) cost ~4 % of a step
                 sampled = (t - (1 + W)) % period == 0
@@ -323,6 +378,10 @@ def main():
         sync_all()
         r["elapsed"] = lxdist.max_over_ranks(time.perf_counter() - t0, dist, dev)
         gc.enable()
+        if merger is not None:   # (the job in flight when the window closed finishes outside it)
+            r["merge_jobs"], r["merged_sweeps"] = merger.jobs_done, merger.merged_sweeps
+            r["merge_job_seconds"] = [round(x, 4) for x in merger.job_seconds]
+            merger.close()
         if pool is not None:
             pool.shutdown()
         for a in racc:   # stage times: mean over the handles (they run side by side); counts: summed
@@ -586,7 +645,14 @@ def main():
                 "map_epoch_merge": ({"merged_sweeps_on_rank0": win.get("merged_sweeps", 0),
                                      "note": "every epoch boundary: the ranks' registered sweeps -> loamx_dist_gatherv -> loamx_map_insert on rank 0 -> "
                                              "the merged map is broadcast and staged for the next epoch (synchronous, inside the timed region)"}
-                                    if args.epoch_merge and E > 0 else None),
+                                    if args.epoch_merge and E > 0 else
+                                    {"mode": "asynchronous (loam_velodyne_amd.dist.AsyncEpochMerger)", "merge_jobs_completed_in_window": win.get("merge_jobs", 0),
+                                     "merged_sweeps_on_rank0": win.get("merged_sweeps", 0), "job_seconds": win.get("merge_job_seconds"),
+                                     "merged_maps_swapped_in": n_epochs,
+                                     "note": "the accumulator runs on a worker thread beside the steps: it takes the ranks' latest sweeps whenever it is idle "
+                                             "(gatherv -> loamx_map_insert on rank 0 -> cubes -> upload + broadcast on its own communicator); a merged map that has "
+                                             "arrived is staged between two steps and swapped in at the next epoch boundary"}
+                                    if args.epoch_merge_async and E > 0 else None),
                 "numa_node_bound": numa_node,
                 "results_gathered": n_results,
                 # what the RCCL communicator itself reports (ncclCommCount); 0 = a multi-rank run that fell back to torch.distributed for
@@ -624,18 +690,10 @@ def main():
             phases[name] = round(now - t_phase, 1)
             t_phase = now
 
-        long_blk, env_jobs = None, None
-        if world == 1 and not args.no_cpu_baseline:
-            orc_poses = []
-            out["cpu_baseline"] = cpu_baseline(sweeps, starts, map_t, poses_out=orc_poses)
-            out["pose_err_vs_oracle"] = pose_error(gpu_poses, orc_poses, stream=0)
-            phase("cpu_baseline")
-            if args.long_steps:
-                long_blk, env_jobs = long_window(args.long_steps)
-                out["value_long"] = long_blk
-                phase("long_window")
         # ---- the other single-GPU configurations of BASELINE.json, each a block of this line (the driver runs this command only):
-        # configs[4]'s one-GPU point (2 M-point map), configs[1] and configs[2] (sequential SLAM over a live map)
+        # configs[4]'s one-GPU point (2 M-point map), configs[1] and configs[2] (sequential SLAM over a live map).  They run BEFORE the
+        # CPU legs below: the long window's envelope chains occupy five cores for ~100 s, and the sequential-SLAM mode is bound by the
+        # host's launch latency (measured with them beside it: VLP-16 1,290 instead of 1,470-1,500 sweeps/s)
         if world == 1 and not args.no_side_configs:
             try:
                 out["map_2m"] = map_2m_block()
@@ -648,6 +706,16 @@ def main():
                 except Exception as e:   # noqa: BLE001
                     out[key] = {"error": repr(e)[:300]}
                 phase(key)
+        long_blk, env_jobs = None, None
+        if world == 1 and not args.no_cpu_baseline:
+            orc_poses = []
+            out["cpu_baseline"] = cpu_baseline(sweeps, starts, map_t, poses_out=orc_poses)
+            out["pose_err_vs_oracle"] = pose_error(gpu_poses, orc_poses, stream=0)
+            phase("cpu_baseline")
+            if args.long_steps:
+                long_blk, env_jobs = long_window(args.long_steps)
+                out["value_long"] = long_blk
+                phase("long_window")
         if long_blk is not None:
             finish_long(long_blk, env_jobs)
             phase("envelope_wait")

@@ -481,12 +481,17 @@ __global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr_grid(OdomProblem
 #else
 #define LM_TS(k) do { } while (0)
 #endif
-// 4 waves per SIMD (<= 128 VGPRs) and 36 KB of LDS: the persistent workgroups of a stream have to find room next to the wide
-// registration / feature kernels of the other HIP streams — at 226 VGPRs + 61 KB they waited for half-empty CUs
+// 3 waves per SIMD (<= 168 VGPRs) and 36 KB of LDS: the persistent workgroups of a stream have to find room next to the wide
+// registration / feature kernels of the other HIP streams — at 226 VGPRs + 61 KB they waited for half-empty CUs.  Round 6: the
+// 128-VGPR build (4 waves) spilled 41 VGPRs = 160 B of scratch per thread, 1.2 MB of scratch writes per launch in the counters for
+// the same speed (16,467 / 16,582 against 16,245 / 16,558 sweeps/s, interleaved on one box, profiles/r06_ab.md): no spills now.
 #ifndef OD_LM_WAVES
-#define OD_LM_WAVES 4
+#define OD_LM_WAVES 3
 #endif
-#define OD_LM_ATTR __attribute__((amdgpu_waves_per_eu(OD_LM_WAVES, OD_LM_WAVES)))
+#ifndef OD_LM_WAVES_MIN
+#define OD_LM_WAVES_MIN 1   // (the compiler may take more registers than OD_LM_WAVES waves would leave it: <1> then needs 230 VGPRs and nothing spills)
+#endif
+#define OD_LM_ATTR __attribute__((amdgpu_waves_per_eu(OD_LM_WAVES_MIN, OD_LM_WAVES)))
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wpass-failed"   // (the two-features-per-thread variant keeps 64 KB of LDS and cannot reach that occupancy)
 template <int OD_FPT>

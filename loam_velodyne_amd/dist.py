@@ -81,3 +81,92 @@ def epoch_merge(streams, acc, ldist=None, rank: int = 0, root: int = 0):
                 acc.insert(corner, surf, pose)
                 merged += 1
     return merged
+
+
+class AsyncEpochMerger:
+    """Collective 3 off the stepping thread: the accumulator — gather of the ranks' sweeps, insertion into the
+    map (loamx_map_insert: BasicLaserMapping.cpp:536-593 restated), download of the merged cubes, upload + broadcast of the new epoch's
+    map — runs on a worker thread of its own with a communicator of its own, while the stepping thread goes on registering against the
+    map it has.  The stepping thread only
+      * hands over its streams' latest sweeps when the worker is idle (submit), and
+      * asks between two steps whether a merged map has arrived (take_ready) — then stages it (loamx_pipeline_stage_frozen_device: the
+        index is built in the background) and swaps it in at the next epoch boundary.
+    Which step adopts which merged map therefore depends on timing; the synchronous protocol (epoch_merge on the stepping thread at every
+    boundary) is the deterministic one, and the one the tests pin.  Every rank runs one merger; their workers meet in the collectives
+    (gatherv, counts, broadcast), so job i is the same job on every rank.
+
+    publish(corner, surf) -> token: called on the worker thread after the merge; on the root with the merged cubes (elsewhere None, None):
+    must make the new map resident on every rank (sizes exchange + broadcast on the WORKER's communicator) and return whatever the stepping
+    thread needs to stage it (device pointers, sizes, the event to wait for)."""
+
+    def __init__(self, acc, ldist, rank, root, publish, before_job=None):
+        import queue
+        import threading
+        self.acc, self.ldist, self.rank, self.root, self.publish = acc, ldist, rank, root, publish
+        self.before_job = before_job
+        self.q = queue.Queue()
+        self.lock = threading.Lock()
+        self.ready = []
+        self.busy = False
+        self.error = None
+        self.jobs_done = 0
+        self.merged_sweeps = 0
+        self.job_seconds = []
+        self.th = threading.Thread(target=self._run, name="loamx-epoch-merger", daemon=True)
+        self.th.start()
+
+    def _run(self):
+        import time
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            try:
+                t0 = time.perf_counter()
+                if self.before_job is not None:
+                    self.before_job()
+                merged = epoch_merge(job, self.acc, self.ldist, rank=self.rank, root=self.root)
+                corner = surf = None
+                if self.rank == self.root:
+                    corner, surf = self.acc.cubes("corner"), self.acc.cubes("surf")
+                token = self.publish(corner, surf)
+                with self.lock:
+                    self.ready.append(token)
+                    self.jobs_done += 1
+                    self.merged_sweeps += merged
+                    self.job_seconds.append(time.perf_counter() - t0)
+                    self.busy = False
+            except BaseException as e:   # noqa: BLE001 (reported by the stepping thread)
+                with self.lock:
+                    self.error = e
+                    self.busy = False
+                return
+
+    def idle(self) -> bool:
+        with self.lock:
+            if self.error is not None:
+                raise self.error
+            return not self.busy
+
+    def submit(self, streams):
+        with self.lock:
+            self.busy = True
+        self.q.put(streams)
+
+    def take_ready(self):
+        """the newest merged map that has arrived since the last call (older ones that were never staged are dropped), or None"""
+        with self.lock:
+            if self.error is not None:
+                raise self.error
+            if not self.ready:
+                return None
+            tok = self.ready[-1]
+            self.ready.clear()
+            return tok
+
+    def close(self, wait=True):
+        self.q.put(None)
+        if wait:
+            self.th.join(timeout=120)
+        if self.error is not None:
+            raise self.error

@@ -413,6 +413,49 @@ def test_bench_epoch_merge_as_rank_0_of_eight(monkeypatch, capsys):
     assert len(sizes) >= K // E and sizes[-1][0] > sizes[0][0] and sizes[-1][1] > sizes[0][1]   # the staged map grew with the merged sweeps
 
 
+def test_bench_async_epoch_merge_as_rank_0_of_two(monkeypatch, capsys):
+    """bench.py --map-epoch-steps E --epoch-merge-async as rank 0 of two: the accumulator on a worker thread with a communicator of its own;
+    the stepping thread only hands sweeps over when the worker is idle and stages a merged map once one has arrived.  With the stand-ins the
+    worker is quick, so merged maps do arrive inside the window: they were staged (sizes growing) and swapped in at epoch boundaries."""
+    from loam_velodyne_amd import loamx
+    ft = fake_torch()
+    ft.cuda.Event.cuda_event = 0
+    monkeypatch.setitem(sys.modules, "torch", ft)
+    monkeypatch.setitem(sys.modules, "torch.distributed", ft.distributed)
+    monkeypatch.setattr(loamx, "Pipeline", FakePipeline)
+    monkeypatch.setattr(loamx, "Dist", FakeDist)
+    monkeypatch.setattr(loamx, "LaserMapping", FakeMapping)
+    monkeypatch.setattr(loamx, "lib", lambda: FakeLib(loamx, real=("loamx_dist_pack_clouds", "loamx_dist_unpack_clouds_header", "loamx_dist_unpack_clouds_stream")))
+    K, W, ns, E = 12, 1, 2, 2
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", str(K), "--warmup", str(W), "--streams", str(ns), "--sensor", "VLP-16", "--map-points", "2000",
+                                      "--repeat", "1", "--no-pcie", "--map-epoch-steps", str(E), "--epoch-merge-async"])
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    FakePipeline.instances.clear()
+    FakeDist.made.clear()
+    FakeMapping.made.clear()
+    orig_step = FakePipeline.step
+
+    def slow_step(self, t):   # (give the worker thread a chance between two steps, as a real step's 0.4 ms does)
+        import time
+        time.sleep(0.01)
+        return orig_step(self, t)
+    monkeypatch.setattr(FakePipeline, "step", slow_step)
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    bench.main()
+    out = json.loads([l for l in capsys.readouterr().out.strip().splitlines() if l.startswith("{")][-1])
+    em = out["config"]["map_epoch_merge"]
+    assert em["mode"].startswith("asynchronous") and em["merge_jobs_completed_in_window"] >= 1 and em["merged_sweeps_on_rank0"] >= 2 * ns
+    assert len(FakeDist.made) == 2                      # the stepping thread's communicator and the worker's own
+    assert FakeDist.made[1].gathers == em["merge_jobs_completed_in_window"] or FakeDist.made[1].gathers == em["merge_jobs_completed_in_window"] + 1
+    assert getattr(FakeDist.made[0], "gathers", 0) == 0  # nothing of the merge on the stepping thread's communicator
+    sizes = FakePipeline.instances[-1].map_sizes
+    assert len(sizes) >= 2 and sizes[-1][0] > sizes[0][0]   # (the untimed first stage, then merged maps of growing size)
+    assert em["merged_maps_swapped_in"] >= 1
+
+
 def _canned_live(sensor, M, K, W, cpu=True, nodes=True, within=True):
     """what bench.live_block returns, as far as the line's assembly reads it"""
     return {"metric": f"sweeps/sec (sequential SLAM: {sensor})", "value": 1500.0, "unit": "sweeps/s", "ms_per_step": 0.66, "steps": K, "warmup": W,

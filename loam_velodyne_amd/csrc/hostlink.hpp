@@ -124,7 +124,7 @@ template <int SLOTS> class HostLinkT {
   // direction other than ENGINE_0, else ENGINE_1.  LOAMX_D2H_ENGINE=<mask bit> overrides (0: ROCr's own choice per copy).
   uint32_t engine_(hsa_agent_t cpu, hsa_agent_t gpu) {
     if (engine_mask_ == ~0u) {
-      if (const char* e = getenv("LOAMX_D2H_ENGINE")) engine_mask_ = (uint32_t)strtoul(e, nullptr, 0);
+      if (const char* e = diag_env("LOAMX_D2H_ENGINE")) engine_mask_ = (uint32_t)strtoul(e, nullptr, 0);
       else {
         uint32_t rec = 0;
         if (hsa_amd_memory_get_preferred_copy_engine(cpu, gpu, &rec) != HSA_STATUS_SUCCESS) rec = 0;

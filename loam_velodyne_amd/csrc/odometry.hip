@@ -482,14 +482,15 @@ __global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr_grid(OdomProblem
 #define LM_TS(k) do { } while (0)
 #endif
 // 3 waves per SIMD (<= 168 VGPRs) and 36 KB of LDS: the persistent workgroups of a stream have to find room next to the wide
-// registration / feature kernels of the other HIP streams — at 226 VGPRs + 61 KB they waited for half-empty CUs.  Round 6: the
-// 128-VGPR build (4 waves) spilled 41 VGPRs = 160 B of scratch per thread, 1.2 MB of scratch writes per launch in the counters for
-// the same speed (16,467 / 16,582 against 16,245 / 16,558 sweeps/s, interleaved on one box, profiles/r06_ab.md): no spills now.
+// registration / feature kernels of the other HIP streams — at 226 VGPRs + 61 KB they waited for half-empty CUs.  Round 6, one box,
+// three interleaved rounds (profiles/r06_ab.md): 128 VGPRs / 41 spilled (160 B of scratch per thread, 1.2 MB of scratch writes per
+// launch in the counters) 16,828 / 16,805 / 16,725 sweeps/s; 168 VGPRs / 5 spilled (24 B) 16,576 / 16,708 / 17,002; 230 VGPRs / none
+// (2 waves) 16,658 / 16,540 / 16,511 — the middle one: a sixth of the scratch at the speed of the first.
 #ifndef OD_LM_WAVES
 #define OD_LM_WAVES 3
 #endif
 #ifndef OD_LM_WAVES_MIN
-#define OD_LM_WAVES_MIN 1   // (the compiler may take more registers than OD_LM_WAVES waves would leave it: <1> then needs 230 VGPRs and nothing spills)
+#define OD_LM_WAVES_MIN 3
 #endif
 #define OD_LM_ATTR __attribute__((amdgpu_waves_per_eu(OD_LM_WAVES_MIN, OD_LM_WAVES)))
 #pragma clang diagnostic push
@@ -932,7 +933,7 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
   for (uint32_t s = 0; s < n_streams; s++) streams_.push_back(new OdomStream());
   // nn1_wave is exact for any cell size; coarser cells than the map index keep the cell tables (rebuilt every sweep) small
   index_.cell_size = 2.1f;
-  if (const char* e = getenv("LOAMX_ODOM_CELL")) { const float v = (float)atof(e); if (v >= 0.25f && v <= 16.f) index_.cell_size = v; }
+  if (const char* e = diag_env("LOAMX_ODOM_CELL")) { const float v = (float)atof(e); if (v >= 0.25f && v <= 16.f) index_.cell_size = v; }
   index_.pack_ring = true;   // k_odom_corr_grid filters a cell's points by ring
   index_.init(st_);
   h_mirror_.reserve(n_streams);

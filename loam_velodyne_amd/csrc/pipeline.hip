@@ -58,7 +58,7 @@ class Pipeline {
     op.delta_r_abort = oc.delta_r_abort;
     {
       int g = (int)std::min<uint32_t>(n_streams, 2);
-      if (const char* e = getenv("LOAMX_ODOM_GROUPS")) g = atoi(e);
+      if (const char* e = diag_env("LOAMX_ODOM_GROUPS")) g = atoi(e);
       n_groups = (uint32_t)std::max(1, std::min(g, (int)std::min<uint32_t>(n_streams, MAX_GROUPS)));
     }
     for (uint32_t g = 0; g < n_groups; g++) {
@@ -216,7 +216,7 @@ class Pipeline {
   // sweeps in a row (a chain then takes ~570 us per step against the registration's ~430): on average the chains keep up, and a deeper
   // look-ahead lets them build the lead that such a run eats (depth 2: 15.6 k sweeps/s, 4: 16.6 k, 6: 16.9 k, 8 - 12: 16.4 - 16.6 k;
   // profiles/r04_ab.md).  The streaming ring holds RING = 8 slots: the same six steps.
-  int ahead_depth = std::max(1, std::min(getenv("LOAMX_ODOM_AHEAD") ? atoi(getenv("LOAMX_ODOM_AHEAD")) : 6, OR - 2));
+  int ahead_depth = std::max(1, std::min(diag_env("LOAMX_ODOM_AHEAD") ? atoi(diag_env("LOAMX_ODOM_AHEAD")) : 6, OR - 2));
   int depth() const { return !prefetch ? 0 : (streaming ? std::min(ahead_depth, (int)RING - 2) : ahead_depth); }
   float last_ms[4] = {0, 0, 0, 0};
   std::atomic<bool> timing{false};
@@ -448,7 +448,7 @@ class Pipeline {
     // The sweeps' block copies go to ROCr directly when source and destination are the runtime's own allocations (hostlink.hpp: a copy
     // stream of the HIP runtime would be a fifth busy HIP stream): the blocks are counted first (the group's size must be known when
     // it begins), then issued; launch_features() waits for the slot's signal on the host — a whole step later.
-    static const bool direct = !(getenv("LOAMX_H2D_DIRECT") && atoi(getenv("LOAMX_H2D_DIRECT")) == 0);
+    static const bool direct = !(diag_env("LOAMX_H2D_DIRECT") && atoi(diag_env("LOAMX_H2D_DIRECT")) == 0);
     const int slot = (int)(t % RING);
     up_runs[slot] = 0;
     uint32_t n_blocks = 0;
@@ -629,7 +629,7 @@ class Pipeline {
     }
     // The copies go to the SDMA engine directly (hostlink.hpp: the HIP runtime may pick its blit kernel for them, which stalls
     // every kernel that writes to host memory meanwhile) when source and destination are ROCr allocations; else through HIP.
-    static const bool via_hip = getenv("LOAMX_D2H_HIP") != nullptr;   // diagnostic: always hipMemcpyAsync
+    static const bool via_hip = diag_env("LOAMX_D2H_HIP") != nullptr;   // diagnostic: always hipMemcpyAsync
     bool direct = !via_hip && !runs.empty();
     for (const Run& r : runs) direct = direct && hostlink.can_copy(r.dst, r.src, r.bytes);
     wait_download(par);   // (a caller that downloads the same step twice)

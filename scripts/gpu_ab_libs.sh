@@ -18,7 +18,7 @@ for r in $(seq 1 $rounds); do
   for l in "$@"; do
     name=$(basename $l .so)
     if [ "$l" = "-" ]; then unset LOAMX_LIB; name=product; else export LOAMX_LIB=$root/$l; fi
-    timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pcie --repeat 3 --long-steps 0 ${AB_ARGS:-} > $out/bench_${name}_$r.json 2> $out/err_${name}_$r.txt
+    timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-configs --no-pcie --repeat 3 --long-steps 0 ${AB_ARGS:-} > $out/bench_${name}_$r.json 2> $out/err_${name}_$r.txt
     python - <<PY
 import json
 try:

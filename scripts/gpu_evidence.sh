@@ -14,15 +14,15 @@ scripts/gpu_pmc.sh ${tag}_pmc > $out/pmc.log 2>&1; cp gpurun_out/${tag}_pmc/pmc_
 LOAMX_NO_LOOKAHEAD=1 scripts/gpu_trace_raw.sh ${tag}_seq > /dev/null 2>&1; cp gpurun_out/${tag}_seq/summary.txt $out/sequential_summary.txt 2>/dev/null
 scripts/gpu_live_profile.sh ${tag}_live1 > $out/live_vlp16.log 2>&1; tail -c 300 gpurun_out/${tag}_live1/bench.json; echo
 scripts/gpu_live_profile.sh ${tag}_live2 --sensor HDL-32 --map-points 500000 > $out/live_hdl32.log 2>&1; tail -c 300 gpurun_out/${tag}_live2/bench.json; echo
-scripts/gpu_pmc.sh ${tag}_pmc_live1 --mode live --steps 8 --warmup 2 --no-cpu-baseline --no-live-nodes > $out/pmc_live_vlp16.log 2>&1; cp gpurun_out/${tag}_pmc_live1/pmc_summary.json $out/live_vlp16_pmc_summary.json 2>/dev/null
-scripts/gpu_pmc.sh ${tag}_pmc_live2 --mode live --sensor HDL-32 --map-points 500000 --steps 8 --warmup 2 --no-cpu-baseline --no-live-nodes > $out/pmc_live_hdl32.log 2>&1; cp gpurun_out/${tag}_pmc_live2/pmc_summary.json $out/live_hdl32_pmc_summary.json 2>/dev/null
+scripts/gpu_pmc.sh ${tag}_pmc_live1 --mode live --steps 8 --warmup 2 --no-cpu-baseline --no-side-configs --no-live-nodes > $out/pmc_live_vlp16.log 2>&1; cp gpurun_out/${tag}_pmc_live1/pmc_summary.json $out/live_vlp16_pmc_summary.json 2>/dev/null
+scripts/gpu_pmc.sh ${tag}_pmc_live2 --mode live --sensor HDL-32 --map-points 500000 --steps 8 --warmup 2 --no-cpu-baseline --no-side-configs --no-live-nodes > $out/pmc_live_hdl32.log 2>&1; cp gpurun_out/${tag}_pmc_live2/pmc_summary.json $out/live_hdl32_pmc_summary.json 2>/dev/null
 scripts/gpu_trace_session.sh ${tag}_trace - > $out/pipe_trace.log 2>&1; cp gpurun_out/${tag}_trace/summary.txt $out/pipe_trace_summary.txt 2>/dev/null
 for S in 1 4 16 32; do
-  timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pcie --repeat 2 --streams $S > $out/streams_$S.json 2> $out/streams_$S.err
+  timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-configs --no-pcie --repeat 2 --streams $S > $out/streams_$S.json 2> $out/streams_$S.err
   python -c "import json,sys; d=json.loads(open('$out/streams_$S.json').read().strip().splitlines()[-1]); print('streams', $S, d['value'], d['value_median'], d['ms_per_step'])"
 done
 cd /tmp; rm -rf /tmp/prof_copy
-LOAMX_PIPE_TRACE=1 timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/prof_copy -- python $root/bench.py --steps 8 --warmup 3 --no-cpu-baseline --repeat 1 > $out/pcie_traced.json 2> $out/pcie_traced.err
+LOAMX_PIPE_TRACE=1 timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/prof_copy -- python $root/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-side-configs --repeat 1 > $out/pcie_traced.json 2> $out/pcie_traced.err
 mc=$(find /tmp/prof_copy -name '*memory_copy_trace.csv' | head -1)
 python - "$mc" > $out/pcie_copies.txt 2>&1 <<'PY'
 import csv, sys, collections

@@ -5,7 +5,7 @@ tag=$1; shift
 root=$(pwd); out=$root/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp; rm -rf /tmp/prof_$tag
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python $root/bench.py --mode live --steps 20 --warmup 3 --no-cpu-baseline "$@" > $out/bench_profiled.json 2> $out/prof.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python $root/bench.py --mode live --steps 20 --warmup 3 --no-cpu-baseline --no-side-configs "$@" > $out/bench_profiled.json 2> $out/prof.err
 ks=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
 kt=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
 cp "$ks" $out/kernel_stats.csv 2>/dev/null

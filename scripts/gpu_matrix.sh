@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 k=0
 for v in "$@"; do
   k=$((k+1))
-  env $v timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-pcie > $out/m$k.json 2> $out/m$k.err
+  env $v timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-side-configs --no-pcie > $out/m$k.json 2> $out/m$k.err
   python - "$out/m$k.json" "$v" <<'PY'
 import json, sys
 try:

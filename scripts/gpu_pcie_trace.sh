@@ -5,7 +5,7 @@ tag=$1; shift
 root=$(pwd); out=$root/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp; rm -rf /tmp/prof_$tag
-timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/prof_$tag -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pcie --repeat 1 --ab-pcie "$1" > $out/bench.json 2> $out/bench.err
+timeout 600 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/prof_$tag -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-configs --no-pcie --repeat 1 --ab-pcie "$1" > $out/bench.json 2> $out/bench.err
 grep "ab-pcie" $out/bench.err
 kt=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1); mc=$(find /tmp/prof_$tag -name '*memory_copy_trace.csv' | head -1)
 python - "$kt" "$mc" <<'PY'

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Run on the MI355X box: three SEPARATE rocprofv3 --pmc passes of the bench command (FETCH_SIZE | WRITE_SIZE | TCC hit/miss), each with
 # --kernel-trace only (never combined with other trace domains), then scripts/pmc_summary.py.
-# usage: scripts/gpu_pmc.sh <tag> [bench args]     (default: the driver's workload, 4 steps; e.g. "--mode live --steps 8 --warmup 2 --no-cpu-baseline --no-live-nodes")
+# usage: scripts/gpu_pmc.sh <tag> [bench args]     (default: the driver's workload, 4 steps; e.g. "--mode live --steps 8 --warmup 2 --no-cpu-baseline --no-side-configs --no-live-nodes")
 set -u
 tag=$1; shift
-if [ $# -eq 0 ]; then set -- --steps 4 --warmup 1 --no-cpu-baseline --no-pcie --repeat 1; fi
+if [ $# -eq 0 ]; then set -- --steps 4 --warmup 1 --no-cpu-baseline --no-side-configs --no-pcie --repeat 1; fi
 root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p $out

@@ -10,7 +10,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 cd /tmp
 rm -rf /tmp/prof_$tag
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pcie --repeat 1 "$@" > $out/bench_profiled.json 2> $out/prof.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-configs --no-pcie --repeat 1 "$@" > $out/bench_profiled.json 2> $out/prof.err
 kt=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
 ks=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
 cp "$ks" $out/kernel_stats.csv 2>/dev/null

@@ -20,7 +20,7 @@ except Exception as e:
 PY
 for v in "$@"; do
   name=$(echo "$v" | tr '= ' '__')
-  env $v timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pcie > $out/bench_$name.json 2> $out/bench_$name.err
+  env $v timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-configs --no-pcie > $out/bench_$name.json 2> $out/bench_$name.err
   python - "$out/bench_$name.json" "$v" <<'PY'
 import json, sys
 try:

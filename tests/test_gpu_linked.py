@@ -1,10 +1,16 @@
 """GPU: the linked entry points (loamx_scanreg_process_linked -> loamx_odom_process_linked -> loamx_map_process_linked: a sweep handed
 from node to node in HBM) against the host-message entry points on the same sweeps — the data flow is the same, so everything the
 two chains produce must be equal bit for bit: odometry transforms, the clouds handed on, mapped poses, the registered cloud, the map."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
-from loam_velodyne_amd import loamx, synth
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import oracle_py as op  # noqa: E402
+
+from loam_velodyne_amd import loamx, synth  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +33,17 @@ def test_linked_chain_equals_host_message_chain(sensor, map_points):
     mp_a.load_cubes(cm, sm)
     mp_b.load_cubes(cm, sm)
     landing = np.zeros((max(len(s.points) for s in sweeps), 4), np.float32)
+    # the linked chain also meets the ORACLE directly (it used to be compared with the product's own host-message chain
+    # only): the same sweeps, free running over its own live map, through the CPU restatement of the reference
+    orc = op.Oracle()
+    osr, ood, omp = op.ScanRegistration(orc), op.LaserOdometry(orc), op.LaserMapping(orc)
+    omp.load_cubes(cm, sm)
+    worst_odom = worst_map = 0.0
     for t, sw in enumerate(sweeps):
+        ood.set_features(osr.process(sw.points, sw.ring_sizes))
+        ood.process()
+        omp.set_inputs(ood.last_corner(), ood.last_surf(), ood.full_to_end(), ood.transform_sum)
+        omp.process()
         # host messages
         f = sr_a.process(sw.points.copy(), sw.ring_sizes)
         rc_a = od_a.process(f)
@@ -53,6 +69,14 @@ def test_linked_chain_equals_host_message_chain(sensor, map_points):
         assert mp_a.has_fresh_map() == mp_b.has_fresh_map(), t
         if mp_a.has_fresh_map():
             assert np.array_equal(mp_a.surround(), mp_b.surround()), t
+        # against the oracle: the odometry's accumulated transform within 1e-4, the mapped pose within the free-running bound of a LIVE map
+        # (2e-3, tests/test_gpu_mapping.py: both chains insert their own registered sweeps, so a difference feeds back through the map)
+        d_odom = float(np.abs(np.asarray(od_b.transform_sum) - ood.transform_sum).max())
+        d_map = float(np.abs(mp_b.transform("aft") - omp.transform("aft")).max())
+        worst_odom, worst_map = max(worst_odom, d_odom), max(worst_map, d_map)
+        assert d_odom < 1e-4 and d_map < 2e-3, (t, d_odom, d_map)
+        assert od_b.stats()["iterations"] == ood.stats()["iterations"], t
+    print(f"linked chain vs oracle ({sensor}): accumulated odometry max {worst_odom:.2e}, mapped pose max {worst_map:.2e}")
     for which in (0, 1):
         assert np.array_equal(mp_a.cubes(which), mp_b.cubes(which)), which
     assert mp_a.stats()["iterations"] >= 1

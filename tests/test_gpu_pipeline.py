@@ -92,6 +92,54 @@ def test_lookahead_is_transparent(small_world):
             assert np.array_equal(tra, trb) and np.array_equal(tsa, tsb) and np.array_equal(afa, afb) and sta == stb
 
 
+def test_launch_pairs_as_needed_change_nothing(small_world, monkeypatch):
+    """Round 6: the odometry's launch pairs (correspondences + five iterations) are enqueued as they turn out to be needed — one pair behind
+    the device, decided from the pinned mirror — instead of all five up front (the reference leaves its loop when the stop test fires,
+    BasicLaserOdometry.cpp:613-620).  A pair that is not enqueued would have returned at its first instruction, so LOAMX_ODOM_PAIRS = all
+    (the fixed five), lag (default) and exact (wait for the last pair, none wasted) must give bit-identical transforms, iteration counts
+    and mapped poses — in the batched pipeline and through the single-stream odometry handle."""
+    cm, sm = small_world.make_map(40000)
+    T, ns = 7, 3
+    data = []
+    for s in range(ns):
+        poses = synth.trajectory(T, start=(1.0 * s, 0.0, 2.0 * s))
+        data.append([synth.make_sweep(small_world, "VLP-16", poses[t], poses[t + 1], seed=40 * s + t, az_steps=800) for t in range(T)])
+
+    def run(mode):
+        if mode is None:
+            monkeypatch.delenv("LOAMX_ODOM_PAIRS", raising=False)
+        else:
+            monkeypatch.setenv("LOAMX_ODOM_PAIRS", mode)
+        p = loamx.Pipeline(ns)
+        p.set_frozen(cm, sm)
+        for s in range(ns):
+            p.set_state(s, aft=np.array([0, 0, 0, 1.0 * s, 0, 2.0 * s], np.float32))
+        p.upload([[(data[s][t].points, data[s][t].ring_sizes) for s in range(ns)] for t in range(T)])
+        out = []
+        for t in range(T):
+            rc = p.step(t)
+            out.append((rc, [p.get(s) for s in range(ns)]))
+        p.close()
+        # the single-stream handle (the sequential-SLAM entry points) on stream 0's sweeps
+        sr, od = loamx.ScanRegistration(), loamx.LaserOdometry()
+        single = []
+        for t in range(T):
+            od.process(sr.process(data[0][t].points, data[0][t].ring_sizes))
+            single.append((np.array(od.transform), np.array(od.transform_sum), od.stats()))
+        sr.close(); od.close()
+        return out, single
+    ref_out, ref_single = run("all")
+    assert max(st["odom_iterations"] for _, g in ref_out for (_, _, _, st) in g) > 5   # (more than one pair was needed somewhere)
+    for mode in (None, "lag", "exact"):
+        out, single = run(mode)
+        for (rca, ga), (rcb, gb) in zip(ref_out, out):
+            assert rca == rcb
+            for (tra, tsa, afa, sta), (trb, tsb, afb, stb) in zip(ga, gb):
+                assert np.array_equal(tra, trb) and np.array_equal(tsa, tsb) and np.array_equal(afa, afb) and sta == stb, mode
+        for (ta, sa, xa), (tb, sb, xb) in zip(ref_single, single):
+            assert np.array_equal(ta, tb) and np.array_equal(sa, sb) and xa == xb, mode
+
+
 def test_lookahead_toggled_and_state_set_mid_run(small_world):
     """ADVICE.md (round 3): loamx_pipeline_set_lookahead(0) and loamx_pipeline_set_state in the MIDDLE of a run, right after step() has
     returned and while the look-ahead is still working on the next steps, must leave the odometry chain where it really is — the old

@@ -1495,6 +1495,24 @@ def dominant_roofline(gn_block, ol, ns):
     gn_block = dict(gn_block)
     gn_block["peak_copy_ceiling"] = HBM_COPY_GBS
     gn_block["frac_of_copy_ceiling"] = round(gn_block["achieved"] / HBM_COPY_GBS, 6)
+    if dom.startswith("loamx::k_odom_corr_grid") and ol.get("corr_launches"):
+        # the correspondence kernel leads the committed stats: its block from THIS run's HIP events, the iteration kernel's beside it
+        n_l = max(ol["corr_launches"], 1)
+        avg_us = ol["corr_ms"] / n_l * 1e3
+        bytes_per_launch = ol["corr_features"] / n_l * (12 + 16 * 64)
+        achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
+        return {"kernel": dom, "dominant_by": f"largest TotalDurationNs in {src} ({stats[dom][0] / 1e6:.2f} ms over {stats[dom][1]} launches of the profiled run)",
+                "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                "peak_copy_ceiling": HBM_COPY_GBS, "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 6), "traffic": pmc_traffic("k_odom_corr_grid"),
+                "traffic_note": f"bytes of one launch of {max(ns // 2, 1)} streams (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of this command, {pmc_source()})",
+                "model": "per feature 12 B query + ~64 candidate points x 16 B (the 27-cell block or the ring window), one wave per feature (SURVEY.md §8d): a chain of "
+                         "~10 dependent memory round trips per wave, latency not bandwidth",
+                "avg_launch_us": round(avg_us, 3), "launches": int(ol["corr_launches"]), "algorithmic_bytes_per_launch": round(bytes_per_launch, 1),
+                "launch_sampling": f"HIP-event pairs around every launch of both odometry chains on every {TIMING_PERIOD}th step (launches over converged streams counted apart)",
+                "noop_launches": {"n": int(ol["corr_noop_launches"]), "avg_us": round(ol["corr_noop_ms"] / max(ol["corr_noop_launches"], 1) * 1e3, 3)},
+                "lm_pair": {"kernel": "loamx::k_odom_lm<1>", "avg_launch_us": round(ol["lm_ms"] / max(ol["lm_launches"], 1) * 1e3, 3), "launches": int(ol["lm_launches"]),
+                            "us_per_iteration": round(ol["lm_ms"] * 1e3 / max(ol["lm_iterations"], 1), 3)},
+                "k_gn_iter": gn_block}
     if not dom.startswith("loamx::k_odom_lm") or not ol.get("lm_launches"):
         gn_block["dominant_by"] = f"largest TotalDurationNs in {src}" if src else "no committed kernel stats found"
         return gn_block
@@ -1514,8 +1532,8 @@ def dominant_roofline(gn_block, ol, ns):
         "peak_copy_ceiling": HBM_COPY_GBS,
         "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 6),
         "traffic": pm,
-        "traffic_note": "bytes of one launch of 4 streams (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of this command, committed "
-                        "under profiles/): several times the algorithmic bytes — the workgroups of a stream poll each other's tagged records",
+        "traffic_note": f"bytes of one launch of {max(ns // 2, 1)} streams (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes of this command, {pmc_source()}): "
+                        "several times the algorithmic bytes — the workgroups of a stream poll each other's tagged records",
         "model": "48 B per feature (12 B query + 3 x 12 B correspondents, SURVEY.md §8d) read ONCE per launch of up to 5 iterations by the streams "
                  "still iterating; the features then stay in registers — the kernel is a chain of dependent iterations, not a stream of bytes",
         "avg_launch_us": round(avg_us, 3),
@@ -1533,7 +1551,7 @@ def dominant_roofline(gn_block, ol, ns):
                                "exchange between the stream's 9 workgroups (one agent-scope store -> load round trip across XCDs)": 1.0,
                                "6x6 column-pivoted QR on one wave (~1,100 dependent instructions, bit-identical to the scalar routine)": 2.0,
                                "update, stop test, next sin/cos (lanes 0-5 of the same wave)": 0.4},
-            "measured_terms_us": "profiles/r05_lm_stamps.md (in-kernel time stamps, -DLOAMX_PROF_LM): rows 1.5, sums 1.0, record stores 0.4, poll 1.0-2.0, "
+            "measured_terms_us": "profiles/r05_lm_stamps.md (in-kernel time stamps, -DLOAMX_PROF_LM; the iteration is unchanged since): rows 1.5, sums 1.0, record stores 0.4, poll 1.0-2.0, "
                                  "normal equations 0.6, QR 3.0, update 1.1",
             "source": "us_per_iteration: live, this run (sum of the timed launches' durations / iterations of each launch's slowest stream, "
                       "launch start-up included); floor: instruction counts of the kernel's serial chain at ~4.5 cycles per dependent wave64 "
@@ -1568,6 +1586,8 @@ def roofline_kernels(main, ns):
     ]
     out = []
     for name, nbytes, model in models:
+        if main and str(main.get("kernel", "")).startswith(name):
+            continue   # (one fraction per kernel per line: the dominant kernel's is `roofline`'s, measured live)
         us = next((v for k, v in dur.items() if k.startswith(name)), None)
         tr = next((v.get("traffic_bytes") for k, v in pmc.items() if isinstance(v, dict) and name.split("::")[-1].split("<")[0] in k), None)
         out.append({"kernel": name, "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_us": us,

@@ -268,20 +268,39 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu
     // HBM and read back here): curvature stencil (:293-306), the gap test of markAsPicked (:372, :380) and the unreliable-point masks of
     // setScanBuffersFor (:321-363), straight into LDS.  The sweep is read ONCE; the +-curvature_region neighbours come from L1.
     for (uint32_t k = tid; k < len; k += blockDim.x) { flags[k] = 0; fwd[k] = 0; }
-    __syncthreads();
-    for (uint32_t k = tid; k < len; k += blockDim.x) {
-      const uint32_t i = s0g + k;
-      const float4 p = cloud[i];
+    // Round 6: the ring's points go through LDS in chunks (each point is needed by 2 * curv_region + 3 points of the stencil and mask
+    // tests: 13 loads per point through the L1 became one coalesced load + LDS reads; in-kernel stamps: this pass was 17-20 of a ring's
+    // 41 us).  The chunks live in the per-wave sort buffers, which nothing touches before the prologue is over.  Same values, same
+    // operations in the same order: bit-identical.
+    float4* stg = (float4*)wave_base;
+    const uint32_t stg_cap = (uint32_t)((FEAT_WAVES * wave_bytes) / sizeof(float4));
+    const uint32_t halo = (uint32_t)(cr > 1 ? cr : 1);
+    const bool staged = stg_cap >= 2u * halo + 64u;          // (block-uniform; otherwise — a huge curvature region — straight from memory)
+    const uint32_t chunk = staged ? stg_cap - 2u * halo : len;
+    for (uint32_t c0 = 0; c0 < len; c0 += chunk) {
+    const uint32_t lo = c0 >= halo ? c0 - halo : 0u;
+    const uint32_t c1 = c0 + chunk < len ? c0 + chunk : len;
+    const uint32_t hi = c1 + halo < len ? c1 + halo : len;
+    __syncthreads();                                         // (the flags above are cleared / the previous chunk has been read)
+    if (staged) {
+      for (uint32_t k = lo + tid; k < hi; k += blockDim.x) stg[k - lo] = cloud[s0g + k];
+      __syncthreads();
+    }
+    // (two instantiations of the pass: LDS reads stay ds_read, not flat loads; point k of the ring is src[k - off])
+    auto point_pass = [&](const auto* __restrict__ src_, const uint32_t off) {
+    auto src = [&](uint32_t kk) -> float4 { return src_[kk - off]; };
+    for (uint32_t k = c0 + tid; k < c1; k += blockDim.x) {
+      const float4 p = src(k);
       // (binned rings are finite by contract; a caller that breaks it is told — LOAMX_E_INVALID at the call's synchronisation point)
       if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) __hip_atomic_store(bad_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       // gap: the step to the next point exceeds markAsPicked's 0.05 m^2 limit
-      gaps[k] = k + 1 < len ? (((double)sqdiff3(cloud[i + 1], p) > 0.05) ? 1 : 0) : 1;
+      gaps[k] = k + 1 < len ? (((double)sqdiff3(src(k + 1), p) > 0.05) ? 1 : 0) : 1;
       if (k < (uint32_t)cr || k + (uint32_t)cr > len - 1u) continue;
       // curvature (:293-306): diff = -2*cr*p + sum_j (p[i+j] + p[i-j])
       const float w = (float)(-2 * cr);
       float dx = w * p.x, dy = w * p.y, dz = w * p.z;
       for (int j = 1; j <= cr; j++) {
-        const float4 a = cloud[i + j], b = cloud[i - j];
+        const float4 a = src(k + j), b = src(k - j);
         dx += a.x + b.x;
         dy += a.y + b.y;
         dz += a.z + b.z;
@@ -289,7 +308,7 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu
       curv_all[k] = dx * dx + dy * dy + dz * dz;
       if (k + (uint32_t)cr >= len - 1u) continue;   // the mask loop stops one short (:328)
       // setScanBuffersFor (:329-361); flags are only ever set to 1, so concurrent writers are benign
-      const float4 prev = cloud[i - 1], next = cloud[i + 1];
+      const float4 prev = src(k - 1), next = src(k + 1);
       const float diffNext = sqdiff3(next, p);
       bool skip_beam_test = false;
       if ((double)diffNext > 0.1) {
@@ -312,6 +331,9 @@ __global__ __launch_bounds__(64 * FEAT_WAVES) __attribute__((amdgpu_waves_per_eu
         const float dis = p.x * p.x + p.y * p.y + p.z * p.z;
         if ((double)diffNext > 0.0002 * (double)dis && (double)diffPrev > 0.0002 * (double)dis) flags[k] = 1;
       }
+    }
+    };
+    if (staged) point_pass((const float4*)stg, lo); else point_pass(cloud + s0g, 0u);
     }
     __syncthreads();
     for (uint32_t k = tid; k < len; k += blockDim.x) flags0[k] = flags[k];

@@ -598,6 +598,26 @@ def test_third_party_arithmetic_sensitivity_frozen_map(orc, small_world):
     assert worst < 1e-5
 
 
+@pytest.mark.skipif(not (op.RefLaserOdometry.available() and op.RefLaserOdometryAlt.available()), reason="oracle/_ref/libref_odometry_alt.so not built")
+def test_third_party_arithmetic_sensitivity_odometry(orc, small_world):
+    """the odometry's unit of work (one sweep against the previous one): under the alternative third-party arithmetic (products accumulated
+    in double, the 6x6 solve by elimination) the optimised transform of a sweep moves (3e-7 on these small VLP-16 sweeps, up to 4e-5 on HDL-64E ones) — the kind of difference between
+    the device (double row sums) and the oracle (float, row by row) that the long-chain envelope of bench.py is about (round 6)"""
+    poses = synth.trajectory(6)
+    plain, alt = op.RefLaserOdometry(), op.RefLaserOdometryAlt()
+    sr = op.ScanRegistration(orc)
+    worst = 0.0
+    for k in range(6):
+        sw = synth.make_sweep(small_world, "VLP-16", poses[k], poses[k + 1], seed=300 + k, az_steps=900)
+        f = sr.process(sw.points, sw.ring_sizes)
+        for o in (plain, alt):
+            o.set_features(f)
+            o.process()
+        worst = max(worst, float(np.abs(plain.transform - alt.transform).max()))
+    print(f"odometry, per-sweep transform change under the alternative third-party arithmetic: {worst:.2e}")
+    assert 0.0 < worst < 1e-4
+
+
 @needs_alt
 def test_third_party_arithmetic_sensitivity_node_graph(small_world):
     """the four-node pipeline: the odometry stays within 1e-4; the LIVE-MAP poses are reported, not bounded tightly — the rolling

@@ -101,7 +101,7 @@ def main():
         torch.cuda.set_device(local_rank)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
-    numa_node = bind_near_gpu(torch, local_rank)
+    numa_node = None if os.environ.get("LOAMX_BENCH_NO_BIND") else bind_near_gpu(torch, local_rank)   # (LOAMX_BENCH_NO_BIND: diagnostic)
 
     from loam_velodyne_amd import loamx, synth
     from loam_velodyne_amd import dist as lxdist
@@ -176,7 +176,8 @@ def main():
             jobs.append((t, s, (125.0, args.sensor, poses[t], poses[t + 1], 1000 * gs + t)))
     # ray casting is ~0.5 s per HDL-64E sweep on one core and the GPU box is leased by the minute: the (seeded, order-independent)
     # sweeps are generated by worker processes — spawned, not forked: the HIP runtime is already up in this one
-    n_workers = max(1, min(int(os.environ.get("LOAMX_BENCH_WORKERS", "96")), len(os.sched_getaffinity(0)) // max(world, 1), len(jobs)))
+    # (32: measured on the pool's 256-thread hosts — 96 workers took four times as long for the long window's 3,296 sweeps as 32 did)
+    n_workers = max(1, min(int(os.environ.get("LOAMX_BENCH_WORKERS", "32")), len(os.sched_getaffinity(0)) // max(world, 1), len(jobs)))
     if n_workers > 1:
         import multiprocessing as mp
         from concurrent.futures import ProcessPoolExecutor
@@ -411,6 +412,8 @@ def main():
         sweeps cheaper or dearer than the short window's."""
         nonlocal sweeps, T, T_all, K
         T_l = 1 + W + N + LOOK
+        t_l0 = time.perf_counter()
+        secs = {}
         jobs_l = []
         for s_, gs in enumerate(lxdist.stream_ids(rank, world, ns)):
             poses = synth.trajectory(T_l, yaw_step_deg=1.43, start=lxdist.stream_start(gs))
@@ -420,6 +423,7 @@ def main():
         from concurrent.futures import ProcessPoolExecutor
         with ProcessPoolExecutor(max_workers=n_workers, mp_context=mp.get_context("spawn")) as ex:
             made_l = list(ex.map(synth.make_sweep_job, [j[2] for j in jobs_l], chunksize=max(1, len(jobs_l) // (4 * n_workers))))
+        secs["sweeps_generated"] = round(time.perf_counter() - t_l0, 1)
         keep = (sweeps, T, T_all, K)
         sweeps = [[None] * ns for _ in range(T_l)]
         for (t, s_, _), (pts, rs) in zip(jobs_l, made_l):
@@ -430,6 +434,7 @@ def main():
             per_step = []
             resident_window(collect=per_step)   # (untimed: the poses and iteration counts of every stream and step)
             sweeps_long = sweeps
+            secs["two_windows"] = round(time.perf_counter() - t_l0 - secs["sweeps_generated"], 1)
         finally:
             sweeps, T, T_all, K = keep
         timed_rows = [r for r in per_step if r[0] >= 1 + W]
@@ -448,6 +453,7 @@ def main():
                     print("bench.py: envelope chains not started: %r" % e, file=sys.stderr, flush=True)
             inputs = []
             chain = oracle_parity_chain(sweeps_long, starts, m_, n_corner, 1 + W + N, inputs=inputs)
+            secs["oracle_chain"] = round(time.perf_counter() - t_l0 - secs["sweeps_generated"] - secs.get("two_windows", 0), 1)
             ps = per_step_check(loamx, m_[:n_corner], m_[n_corner:], inputs, chain)
             del inputs
             parity = ("pending", per_step, chain, ps)   # (completed by finish_long once the envelope chains are in)
@@ -455,7 +461,7 @@ def main():
             parity = {"error": repr(e)[:200]}
         blk = {"value": round(world * ns * N / w_["elapsed"], 2), "unit": "sweeps/s", "steps": N, "ms_per_step": round(w_["elapsed"] / N * 1e3, 4),
                "pose_err_vs_oracle": parity,
-               "seconds": round(w_["elapsed"], 4),
+               "seconds": round(w_["elapsed"], 4), "host_seconds": secs,
                "mean_odom_iterations": round(float(np.mean([r[4] for r in timed_rows])), 2), "mean_map_iterations": round(float(np.mean([r[5] for r in timed_rows])), 2),
                "note": "same window protocol as `value` over a longer trajectory of its own (40 m circle inside the map; the short window's 115 m "
                        "circle leaves the synthetic world after ~100 sweeps)"}
@@ -785,14 +791,6 @@ def live_block(sensor, M, K, W, cpu=True, nodes=True):
     pts = [loamx.pinned_copy(sw.points) for sw in sweeps]
     landing = loamx.pinned_empty((max(len(sw.points) for sw in sweeps), 4))
     env_pool, env_future, env_paths = None, None, []
-    if cpu and all(len(sw.points) == len(sweeps[0].points) for sw in sweeps):   # the envelope chain runs in a process of its own beside the device chains
-        import multiprocessing as mp_
-        from concurrent.futures import ProcessPoolExecutor
-        env_paths = [f"/dev/shm/loamx_bench_{os.getpid()}_live_{sensor}_sweeps.npy", f"/dev/shm/loamx_bench_{os.getpid()}_live_{sensor}_map.npy"]
-        np.save(env_paths[0], np.stack([sw.points for sw in sweeps]))
-        np.save(env_paths[1], np.concatenate([cm, sm], axis=0))
-        env_pool = ProcessPoolExecutor(max_workers=1, mp_context=mp_.get_context("spawn"))
-        env_future = env_pool.submit(chain_worker, ("oracle_fast", "live", env_paths[0], np.asarray(sweeps[0].ring_sizes), env_paths[1], len(cm), None, T))
 
     def run_chain(linked):
         """one sweep in flight through the three handles; linked: the sweep's clouds go from handle to handle in HBM (loamx_*_process_linked)
@@ -957,6 +955,14 @@ def live_block(sensor, M, K, W, cpu=True, nodes=True):
                        "avg_launch_us": round(avg_launch_ms * 1e3, 3), "launches": gn_launches,
                        "algorithmic_bytes_per_launch": round(72.0 * gn_qi / max(gn_launches, 1), 1)}
     if not args.no_cpu_baseline:
+        if all(len(sw.points) == len(sweeps[0].points) for sw in sweeps):   # the envelope chain: a process of its own beside the CPU legs below (after the timed device chains)
+            import multiprocessing as mp_
+            from concurrent.futures import ProcessPoolExecutor
+            env_paths = [f"/dev/shm/loamx_bench_{os.getpid()}_live_{sensor}_sweeps.npy", f"/dev/shm/loamx_bench_{os.getpid()}_live_{sensor}_map.npy"]
+            np.save(env_paths[0], np.stack([sw.points for sw in sweeps]))
+            np.save(env_paths[1], np.concatenate([cm, sm], axis=0))
+            env_pool = ProcessPoolExecutor(max_workers=1, mp_context=mp_.get_context("spawn"))
+            env_future = env_pool.submit(chain_worker, ("oracle_fast", "live", env_paths[0], np.asarray(sweeps[0].ring_sizes), env_paths[1], len(cm), None, T))
         import oracle_py as op
         orc = op.Oracle(fast=True)
         osr, ood, omp = op.ScanRegistration(orc), op.LaserOdometry(orc), op.LaserMapping(orc)

@@ -42,6 +42,16 @@ HBM_COPY_GBS = 6290.0      # measured float4 copy on MI355X (MI355X_MICROARCH.md
 PROFILE_ROUNDS = ("r06", "r05", "r04")   # committed rocprofv3 summaries of this command, newest first (profiles/<round>_bench_kernel_stats.csv, <round>_pmc_summary.json)
 
 
+def unbind_worker():
+    """initializer of the sweep-generating worker processes: bench.py binds itself (and the pinned memory it first-touches) to the NUMA node of
+    its GPU, and children inherit the mask — but ray casting is memory-bound numpy, and 32 workers on one socket's memory controllers took
+    96 s for the long window's 3,296 sweeps (0.5 s per sweep on an idle core)"""
+    try:
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))
+    except OSError:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,7 +191,7 @@ def main():
     if n_workers > 1:
         import multiprocessing as mp
         from concurrent.futures import ProcessPoolExecutor
-        with ProcessPoolExecutor(max_workers=n_workers, mp_context=mp.get_context("spawn")) as ex:
+        with ProcessPoolExecutor(max_workers=n_workers, mp_context=mp.get_context("spawn"), initializer=unbind_worker) as ex:
             made = list(ex.map(synth.make_sweep_job, [j[2] for j in jobs], chunksize=max(1, len(jobs) // (4 * n_workers))))
     else:
         made = [synth.make_sweep_job(j[2]) for j in jobs]
@@ -421,8 +431,24 @@ def main():
                 jobs_l.append((t, s_, (125.0, args.sensor, poses[t], poses[t + 1], 1000 * gs + t)))
         import multiprocessing as mp
         from concurrent.futures import ProcessPoolExecutor
-        with ProcessPoolExecutor(max_workers=n_workers, mp_context=mp.get_context("spawn")) as ex:
-            made_l = list(ex.map(synth.make_sweep_job, [j[2] for j in jobs_l], chunksize=max(1, len(jobs_l) // (4 * n_workers))))
+        jobs_l.sort(key=lambda j: (j[1] != 0, j[1], j[0]))   # stream 0 first: its sweeps are all the envelope chains need
+        n0 = sum(1 for j in jobs_l if j[1] == 0)
+        env_jobs = None
+        m_ = map_t.cpu().numpy()
+        with ProcessPoolExecutor(max_workers=n_workers, mp_context=mp.get_context("spawn"), initializer=unbind_worker) as ex:
+            made_l = list(ex.map(synth.make_sweep_job, [j[2] for j in jobs_l[:n0]], chunksize=max(1, n0 // (4 * n_workers))))
+            # the reference's own envelope over stream 0's sweeps: five worker processes, ~100 s — started NOW, beside the generation of the
+            # other streams' sweeps (CPU work anyway), stopped (SIGSTOP) while the device windows below are timed, collected when the line
+            # is assembled
+            if not args.no_envelope and not args.no_cpu_baseline:
+                try:
+                    env_jobs = EnvelopeJobs("long", "frozen", np.stack([made_l[t][0] for t in range(1 + W + N)]), made_l[0][1],
+                                            m_[:n_corner], m_[n_corner:], starts[0], 1 + W + N,
+                                            ["oracle_fast", "ref", "ref_map_alt", "ref_odom_alt", "ref_both_alt"])
+                except Exception as e:   # noqa: BLE001
+                    env_jobs = None
+                    print("bench.py: envelope chains not started: %r" % e, file=sys.stderr, flush=True)
+            made_l += list(ex.map(synth.make_sweep_job, [j[2] for j in jobs_l[n0:]], chunksize=max(1, (len(jobs_l) - n0) // (4 * n_workers))))
         secs["sweeps_generated"] = round(time.perf_counter() - t_l0, 1)
         keep = (sweeps, T, T_all, K)
         sweeps = [[None] * ns for _ in range(T_l)]
@@ -430,27 +456,20 @@ def main():
             sweeps[t][s_] = (pts, rs)
         T, T_all, K = 1 + W + N, T_l, N
         try:
+            if env_jobs is not None:
+                env_jobs.pause()
             w_ = resident_window()
             per_step = []
             resident_window(collect=per_step)   # (untimed: the poses and iteration counts of every stream and step)
             sweeps_long = sweeps
             secs["two_windows"] = round(time.perf_counter() - t_l0 - secs["sweeps_generated"], 1)
         finally:
+            if env_jobs is not None:
+                env_jobs.resume()
             sweeps, T, T_all, K = keep
         timed_rows = [r for r in per_step if r[0] >= 1 + W]
         parity = None
-        env_jobs = None
         try:   # the oracle chain over the long trajectory's stream 0 (~0.1 s per sweep on one core): parity over hundreds of sweeps
-            m_ = map_t.cpu().numpy()
-            # the reference's own envelope over the same sweeps: worker processes, started now, collected when the line is assembled
-            if not args.no_envelope:
-                try:
-                    env_jobs = EnvelopeJobs("long", "frozen", np.stack([sweeps_long[t][0][0] for t in range(1 + W + N)]), sweeps_long[0][0][1],
-                                            m_[:n_corner], m_[n_corner:], starts[0], 1 + W + N,
-                                            ["oracle_fast", "ref", "ref_map_alt", "ref_odom_alt", "ref_both_alt"])
-                except Exception as e:   # noqa: BLE001
-                    env_jobs = None
-                    print("bench.py: envelope chains not started: %r" % e, file=sys.stderr, flush=True)
             inputs = []
             chain = oracle_parity_chain(sweeps_long, starts, m_, n_corner, 1 + W + N, inputs=inputs)
             secs["oracle_chain"] = round(time.perf_counter() - t_l0 - secs["sweeps_generated"] - secs.get("two_windows", 0), 1)
@@ -780,7 +799,7 @@ def live_block(sensor, M, K, W, cpu=True, nodes=True):
     if nw > 1:
         import multiprocessing as mp_
         from concurrent.futures import ProcessPoolExecutor
-        with ProcessPoolExecutor(max_workers=nw, mp_context=mp_.get_context("spawn")) as ex:
+        with ProcessPoolExecutor(max_workers=nw, mp_context=mp_.get_context("spawn"), initializer=unbind_worker) as ex:
             made = list(ex.map(synth.make_sweep_job, jobs, chunksize=max(1, T // (4 * nw))))
     else:
         made = [synth.make_sweep_job(j) for j in jobs]
@@ -1252,7 +1271,23 @@ class EnvelopeJobs:
         self.t0 = time.perf_counter()
         self.futs = [self.ex.submit(chain_worker, (k, mode, self.paths[0], np.asarray(rings), self.paths[1], len(cm), start, T)) for k in kinds]
 
+    def _signal(self, sig):
+        import signal
+        for pid in list(getattr(self.ex, "_processes", {}) or {}):
+            try:
+                os.kill(pid, getattr(signal, sig))
+            except OSError:
+                pass
+
+    def pause(self):
+        """stop the worker processes while a device window is timed (the batched pipeline's host threads are latency-sensitive)"""
+        self._signal("SIGSTOP")
+
+    def resume(self):
+        self._signal("SIGCONT")
+
     def collect(self):
+        self.resume()
         out = {}
         try:
             for f in self.futs:
@@ -1414,7 +1449,15 @@ def flat_summary(out):
     def pe_of(blk):
         return blk.get("pose_err_vs_oracle") if isinstance(blk, dict) and isinstance(blk.get("pose_err_vs_oracle"), dict) else None
 
-    sm["value_sweeps_per_s"] = out.get("value")
+    sm["value_sweeps_per_s"] = out.get("value"); sm["ms_per_step"] = out.get("ms_per_step"); sm["value_median_of_windows"] = out.get("value_median")
+    if isinstance(out.get("pcie_inclusive"), dict):
+        sm["pcie_inclusive_sweeps_per_s"] = out["pcie_inclusive"].get("value")
+    if isinstance(out.get("roofline"), dict):
+        sm["roofline_kernel"] = out["roofline"].get("kernel"); sm["roofline_frac"] = out["roofline"].get("frac")
+    if isinstance(out.get("config"), dict):
+        sm["path_hbm_frac"] = out["config"].get("path_hbm_frac")
+    if isinstance(out.get("cpu_baseline"), dict):
+        sm["cpu_sweeps_per_s_one_core"] = out["cpu_baseline"].get("value")
     pe = pe_of(out)
     if pe:
         sm["pose_max_m"] = pe["mapped_pose"]["max_m"]; sm["pose_max_rad"] = pe["mapped_pose"]["max_rad"]; sm["pose_within_bar"] = pe["within_bar"]

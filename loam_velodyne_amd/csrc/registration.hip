@@ -218,6 +218,30 @@ __global__ __launch_bounds__(256) void k_bb_bbox(const float4* __restrict__ pts,
     if (a < 3) atomicMin(&enc[bb_word(c, a)], enc_f32(v)); else atomicMax(&enc[bb_word(c, a)], enc_f32(v));
   }
 }
+// grid descriptor of cloud c from its accumulated bounds, within the per-cloud cell budget (cell_base is the caller's scan)
+__device__ inline GridDescB bb_make_desc(const uint32_t* __restrict__ enc, const uint32_t* __restrict__ off, uint32_t c, uint32_t budget, float cell0) {
+  GridDescB d;
+  d.g.ox = d.g.oy = d.g.oz = 0.f; d.g.inv_h = 1.f; d.g.nx = d.g.ny = d.g.nz = 1;
+  d.pt_base = off[c];
+  d.cell_base = 0;
+  d.g.ncell = 1;   // an empty cloud: a 1-cell grid
+  if (off[c + 1] != off[c]) {
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; a++) { mn[a] = dec_f32(enc[bb_word(c, a)]); mx[a] = dec_f32(enc[bb_word(c, 3 + a)]); }
+    float h = cell0;
+    for (;;) {
+      d.g.inv_h = 1.0f / h;
+      d.g.ox = mn[0]; d.g.oy = mn[1]; d.g.oz = mn[2];
+      d.g.nx = (int)floorf((mx[0] - mn[0]) * d.g.inv_h) + 1;
+      d.g.ny = (int)floorf((mx[1] - mn[1]) * d.g.inv_h) + 1;
+      d.g.nz = (int)floorf((mx[2] - mn[2]) * d.g.inv_h) + 1;
+      const unsigned long long nc = (unsigned long long)d.g.nx * d.g.ny * d.g.nz;
+      if (nc <= budget) { d.g.ncell = (uint32_t)nc; break; }
+      h *= 1.25f;
+    }
+  }
+  return d;
+}
 // one thread per cloud (one workgroup, K <= 4096 in rounds of 1024): grid descriptors within the per-cloud cell budget, table bases by a scan
 // (leaves the bounds accumulators reset for the next build: k_bb_init runs only when K grows)
 __global__ __launch_bounds__(1024) void k_bb_setup(uint32_t* __restrict__ enc, const uint32_t* __restrict__ off, uint32_t K, GridDescB* __restrict__ desc,
@@ -231,23 +255,7 @@ __global__ __launch_bounds__(1024) void k_bb_setup(uint32_t* __restrict__ enc, c
     d.g.ox = d.g.oy = d.g.oz = 0.f; d.g.inv_h = 1.f; d.g.nx = d.g.ny = d.g.nz = 1; d.g.ncell = 0;
     d.pt_base = 0; d.cell_base = 0;
     if (c < K) {
-      d.pt_base = off[c];
-      d.g.ncell = 1;   // an empty cloud: a 1-cell grid
-      if (off[c + 1] != off[c]) {
-        float mn[3], mx[3];
-        for (int a = 0; a < 3; a++) { mn[a] = dec_f32(enc[bb_word(c, a)]); mx[a] = dec_f32(enc[bb_word(c, 3 + a)]); }
-        float h = cell0;
-        for (;;) {
-          d.g.inv_h = 1.0f / h;
-          d.g.ox = mn[0]; d.g.oy = mn[1]; d.g.oz = mn[2];
-          d.g.nx = (int)floorf((mx[0] - mn[0]) * d.g.inv_h) + 1;
-          d.g.ny = (int)floorf((mx[1] - mn[1]) * d.g.inv_h) + 1;
-          d.g.nz = (int)floorf((mx[2] - mn[2]) * d.g.inv_h) + 1;
-          const unsigned long long nc = (unsigned long long)d.g.nx * d.g.ny * d.g.nz;
-          if (nc <= budget) { d.g.ncell = (uint32_t)nc; break; }
-          h *= 1.25f;
-        }
-      }
+      d = bb_make_desc(enc, off, c, budget, cell0);
 #pragma unroll
       for (int a = 0; a < 6; a++) enc[bb_word(c, a)] = a < 3 ? 0xffffffffu : 0u;
     }
@@ -264,9 +272,33 @@ __global__ __launch_bounds__(1024) void k_bb_setup(uint32_t* __restrict__ enc, c
     scratch[2] = carry;
   }
 }
+// Round 6: for a handful of clouds (K <= BB_FUSE_MAXK: the odometry's 2 x streams of a chain) the set-up above is folded into the count —
+// every workgroup derives the K descriptors from the bounds itself (a few dependent loads, in parallel over the workgroups), workgroup 0
+// publishes them and the table size; the bounds accumulators are reset by the scatter, the build's last kernel.  One launch (and one
+// dependent-launch gap) less in the tail of every odometry pass.
+constexpr uint32_t BB_FUSE_MAXK = 64;
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k_bb_count(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off, uint32_t K,
-                                                  const GridDescB* __restrict__ desc, uint32_t* __restrict__ cell_of,
-                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ rank_of) {
+                                                  GridDescB* __restrict__ desc, uint32_t* __restrict__ cell_of,
+                                                  uint32_t* __restrict__ counts, uint32_t* __restrict__ rank_of, const uint32_t* __restrict__ enc,
+                                                  uint32_t* __restrict__ scratch, uint32_t max_cells_total, float cell0) {
+  __shared__ GridDescB s_desc[FUSED ? BB_FUSE_MAXK : 1];
+  if (FUSED) {
+    __shared__ uint32_t lds[17];
+    const uint32_t cc = threadIdx.x;
+    GridDescB d;
+    d.g.ncell = 0;
+    if (cc < K) d = bb_make_desc(enc, off, cc, max_cells_total / (K ? K : 1), cell0);
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(cc < K ? d.g.ncell : 0u, lds, tot);
+    if (cc < K) {
+      d.cell_base = ex;
+      s_desc[cc] = d;
+      if (blockIdx.x == 0) desc[cc] = d;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scratch[0] = tot + 1; scratch[2] = tot; }
+    __syncthreads();
+  }
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < n;
   uint32_t c = 0;
@@ -276,7 +308,7 @@ __global__ __launch_bounds__(256) void k_bb_count(const float4* __restrict__ pts
       const uint32_t mid = (lo + hi) >> 1;
       if (off[mid] <= i) lo = mid; else hi = mid;
     }
-    const GridDescB d = desc[lo];
+    const GridDescB d = FUSED ? s_desc[lo] : desc[lo];
     const float4 p = pts[i];
     int cx, cy, cz;
     cell_coords(d.g, p.x, p.y, p.z, cx, cy, cz);
@@ -294,7 +326,12 @@ __global__ __launch_bounds__(256) void k_bb_count(const float4* __restrict__ pts
 
 __global__ __launch_bounds__(256) void k_bb_scatter(const float4* __restrict__ pts, uint32_t n, const uint32_t* __restrict__ off, uint32_t K,
                                                     const uint32_t* __restrict__ cell_of, const uint32_t* __restrict__ rank_of,
-                                                    const uint32_t* __restrict__ cell_start, float4* __restrict__ sorted, int pack_ring) {
+                                                    const uint32_t* __restrict__ cell_start, float4* __restrict__ sorted, int pack_ring,
+                                                    uint32_t* __restrict__ enc_reset) {
+  if (enc_reset && blockIdx.x == 0 && threadIdx.x < K) {   // (the fused set-up: every workgroup of the count has read the bounds by now)
+#pragma unroll
+    for (int a = 0; a < 6; a++) enc_reset[bb_word(threadIdx.x, a)] = a < 3 ? 0xffffffffu : 0u;
+  }
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t lo = 0, hi = K;
@@ -362,11 +399,18 @@ void SubMapIndexBatch::build(const float4* d_pts, const uint32_t* h_off, uint32_
   for (uint32_t c = 0; c < K; c++) max_len = std::max(max_len, h_off[c + 1] - h_off[c]);
   const uint32_t nbx = std::min<uint32_t>(std::max<uint32_t>((max_len + 255) / 256, 1u), 32u);
   if (!bounds_done) hipLaunchKernelGGL(k_bb_bbox, dim3(nbx, K), dim3(256), 0, st_, d_pts, d_off, enc_.p);
-  hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1024), 0, st_, enc_.p, d_off, K, d_desc_.p, scratch_.p, LX_MAX_CELLS, cell_size);
-  if (n) hipLaunchKernelGGL(k_bb_count, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, d_desc_.p, cell_of_.p, cursor_.p, rank_of_.p);
+  const bool fused = n > 0 && K <= BB_FUSE_MAXK;   // (see k_bb_count: set-up folded into the count, bounds reset by the scatter)
+  if (!fused) hipLaunchKernelGGL(k_bb_setup, dim3(1), dim3(1024), 0, st_, enc_.p, d_off, K, d_desc_.p, scratch_.p, LX_MAX_CELLS, cell_size);
+  if (n) {
+    if (fused) hipLaunchKernelGGL(k_bb_count<true>, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, d_desc_.p, cell_of_.p, cursor_.p, rank_of_.p,
+                                  enc_.p, scratch_.p, LX_MAX_CELLS, cell_size);
+    else hipLaunchKernelGGL(k_bb_count<false>, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, d_desc_.p, cell_of_.p, cursor_.p, rank_of_.p,
+                            enc_.p, scratch_.p, LX_MAX_CELLS, cell_size);
+  }
   // (the cell counters are cleared behind the scan: they are empty again when the next build starts)
   exclusive_scan_u32(cursor_.p, cell_start_.p, tile_sums_.p, scratch_.p + 2, scratch_.p + 1, LX_MAX_CELLS, st_, nullptr, cursor_.p);
-  if (n) hipLaunchKernelGGL(k_bb_scatter, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, cell_of_.p, rank_of_.p, cell_start_.p, sorted_.p, pack_ring ? 1 : 0);
+  if (n) hipLaunchKernelGGL(k_bb_scatter, dim3((n + 255) / 256), dim3(256), 0, st_, d_pts, n, d_off, K, cell_of_.p, rank_of_.p, cell_start_.p, sorted_.p, pack_ring ? 1 : 0,
+                            fused ? enc_.p : nullptr);
   LX_HIP(hipGetLastError());
 }
 

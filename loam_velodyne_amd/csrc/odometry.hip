@@ -1160,25 +1160,29 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   if (na) {
     if (max_feat) {
       // Launch pairs (correspondences + up to five iterations).  The reference leaves its loop when the stop test fires
-      // (BasicLaserOdometry.cpp:613-620); a pair enqueued behind a sweep that has converged costs ~20 us of empty launches, so pairs
-      // are enqueued as they turn out to be needed, one pair behind the device: while pair k runs, the host reads from the pinned
-      // mirror (k_odom_lm writes a stream's state there at the end of every launch) whether pair k - 1 left any stream unconverged,
-      // and only then enqueues pair k + 1 — the queue never runs dry and at most ONE pair is wasted (round 5: 1.6 on average).
-      // Result-neutral by construction: a pair that is not enqueued would have returned at its first instruction (pb.done / the
-      // iteration bound).  LOAMX_ODOM_PAIRS=all restores the fixed five pairs, =exact waits for the LAST pair instead (no wasted pair,
-      // one host round trip in front of the tail).
-      const int pair_mode = [] { const char* e = getenv("LOAMX_ODOM_PAIRS"); return !e ? 1 : !strcmp(e, "all") ? 0 : !strcmp(e, "exact") ? 2 : 1; }();
+      // (BasicLaserOdometry.cpp:613-620); launches enqueued behind a sweep that has converged cost ~10 us each, so they are enqueued as
+      // they turn out to be needed: the host reads from the pinned mirror (k_odom_lm writes a stream's state there at the end of every
+      // launch) whether a pair left any stream unconverged.  Round 5 enqueued all five pairs up front (1.6 empty pairs per pass on
+      // average).  Result-neutral by construction: a launch that is not enqueued would have returned at its first instruction (pb.done /
+      // the iteration bound).  LOAMX_ODOM_PAIRS: `lag` (default) speculates on ONE launch (the next pair's correspondences), `lag2` on one
+      // PAIR (round 6's first form), `exact` on nothing (a host round trip in front of every further pair and of the tail), `all` = round 5.
+      const int pair_mode = [] { const char* e = getenv("LOAMX_ODOM_PAIRS"); return !e ? 1 : !strcmp(e, "all") ? 0 : !strcmp(e, "exact") ? 2 : !strcmp(e, "lag2") ? 3 : 1; }();
       const int maxp = (params.max_iterations + 4) / 5;
       for (uint32_t a = 0; a < na; a++) { h_mirror_.p[a].done = 0; h_mirror_.p[a].stats.iterations = 0; }   // (the previous sweep's launches finished before its poses were read)
-      auto enqueue_pair = [&](int it0) {
-        const int nit = std::min(5, params.max_iterations - it0);
-        const int lk = lt && lt->pairs < LT_MAXP ? lt->pairs : -1;
+      // the two halves of a pair, enqueued apart: `lag` speculates on the correspondence launch only
+      auto enqueue_corr = [&](int k) {
+        const int lk = lt && k < LT_MAXP ? k : -1;
         if (lk >= 0) {
           for (int e = 0; e < 3; e++) if (!lt->ev[3 * lk + e]) LX_HIP(hipEventCreate(&lt->ev[3 * lk + e]));
           LX_HIP(hipEventRecord(lt->ev[3 * lk], st_));
         }
         hipLaunchKernelGGL(k_odom_corr_grid, dim3(8 * (((max_sharp + 7) / 8 + (max_flat + 7) / 8 + 3) / 4), na), dim3(256), 0, st_, prob_.p, params);
         if (lk >= 0) LX_HIP(hipEventRecord(lt->ev[3 * lk + 1], st_));
+      };
+      auto enqueue_lm = [&](int k) {
+        const int it0 = 5 * k;
+        const int nit = std::min(5, params.max_iterations - it0);
+        const int lk = lt && k < LT_MAXP ? k : -1;
 #ifdef OD_LM_HALF_WGS   // (measurement: half as many workgroups per stream, two features per thread — profiles/r05_ab.md section 2)
         const uint32_t nb = std::min<uint32_t>(16u, std::max<uint32_t>(1u, (max_feat + 2 * OD_THREADS - 1) / (2 * OD_THREADS)));
 #else
@@ -1204,6 +1208,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
         }
         if (lk >= 0) { LX_HIP(hipEventRecord(lt->ev[3 * lk + 2], st_)); lt->pairs = lk + 1; }
       };
+      auto enqueue_pair = [&](int it0) { enqueue_corr(it0 / 5); enqueue_lm(it0 / 5); };
       const volatile OdomProblem* hm = h_mirror_.p;
       auto settled = [&](int k) {     // every stream is through launch pair k (or had converged before it)
         const int want = std::min(5 * (k + 1), params.max_iterations);
@@ -1214,22 +1219,47 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
         for (uint32_t a = 0; a < na; a++) if (hm[a].done == 0 && hm[a].stats.iterations < params.max_iterations) return false;
         return true;
       };
-      int enq = 0;
+      auto wait_settled = [&](int k) {   // false: the mirror did not answer in time (the caller then enqueues the rest unconditionally)
+        const auto t_in = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; !settled(k);) {
+          if ((++spins & 255u) == 0u && std::chrono::steady_clock::now() - t_in > std::chrono::milliseconds(20)) return false;
+          __builtin_ia32_pause();
+        }
+        return true;
+      };
+      int enq = 0;                    // launch pairs whose iterations have been enqueued
+      if (pair_mode == 1) {
+        // `lag` (default): pair 0, then only the NEXT pair's correspondence launch ahead of need.  When pair k's iterations have ended the
+        // host knows whether pair k + 1 is needed: if so it enqueues its iterations (and the correspondence launch of pair k + 2) while
+        // the correspondence launch of k + 1 runs — the queue never runs dry; if not, that one launch is the pass's only empty one.
+        enqueue_corr(0);
+        enqueue_lm(0);
+        enq = 1;
+        if (maxp > 1) enqueue_corr(1);
+        while (enq < maxp) {
+          if (!wait_settled(enq - 1)) {   // blind: everything that is left, unconditionally (always correct)
+            enqueue_lm(enq);
+            for (enq++; enq < maxp; enq++) enqueue_pair(5 * enq);
+            break;
+          }
+          if (converged()) break;
+          enqueue_lm(enq);
+          enq++;
+          if (enq < maxp) enqueue_corr(enq);
+        }
+      } else {
       const int first = pair_mode == 0 ? maxp : std::min(maxp, pair_mode == 2 ? std::max(1, pred_pairs_) : 2);
       for (; enq < first; enq++) enqueue_pair(5 * enq);
       bool blind = false;             // the mirror did not answer in time: enqueue the rest unconditionally (always correct)
       while (enq < maxp) {
         const int watch = pair_mode == 2 ? enq - 1 : enq - 2;
         if (!blind && watch >= 0) {
-          const auto t_in = std::chrono::steady_clock::now();
-          for (unsigned spins = 0; !settled(watch);) {
-            if ((++spins & 255u) == 0u && std::chrono::steady_clock::now() - t_in > std::chrono::milliseconds(20)) { blind = true; break; }
-            __builtin_ia32_pause();
-          }
+          if (!wait_settled(watch)) blind = true;
           if (!blind && converged()) break;
         }
         enqueue_pair(5 * enq);
         enq++;
+      }
       }
       pairs_enqueued_ += (uint64_t)enq;
       pair_calls_++;

@@ -96,7 +96,7 @@ def test_launch_pairs_as_needed_change_nothing(small_world, monkeypatch):
     """Round 6: the odometry's launch pairs (correspondences + five iterations) are enqueued as they turn out to be needed — one pair behind
     the device, decided from the pinned mirror — instead of all five up front (the reference leaves its loop when the stop test fires,
     BasicLaserOdometry.cpp:613-620).  A pair that is not enqueued would have returned at its first instruction, so LOAMX_ODOM_PAIRS = all
-    (the fixed five), lag (default) and exact (wait for the last pair, none wasted) must give bit-identical transforms, iteration counts
+    (the fixed five), lag (default: one launch ahead of need), lag2 (one pair ahead) and exact (none) must give bit-identical transforms, iteration counts
     and mapped poses — in the batched pipeline and through the single-stream odometry handle."""
     cm, sm = small_world.make_map(40000)
     T, ns = 7, 3
@@ -130,7 +130,7 @@ def test_launch_pairs_as_needed_change_nothing(small_world, monkeypatch):
         return out, single
     ref_out, ref_single = run("all")
     assert max(st["odom_iterations"] for _, g in ref_out for (_, _, _, st) in g) > 5   # (more than one pair was needed somewhere)
-    for mode in (None, "lag", "exact"):
+    for mode in (None, "lag", "lag2", "exact"):
         out, single = run(mode)
         for (rca, ga), (rcb, gb) in zip(ref_out, out):
             assert rca == rcb

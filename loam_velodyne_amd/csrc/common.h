@@ -1,6 +1,7 @@
 // Shared host/device definitions of libloamx (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -176,6 +177,33 @@ inline const char* diag_env(const char* name) { return getenv(name); }
 #else
 inline const char* diag_env(const char*) { return nullptr; }
 #endif
+
+// Wait for a stream by polling (hipStreamQuery) for up to `spin_ms` before falling back to hipStreamSynchronize.  The runtime's blocking
+// wait sleeps on an interrupt after a short spin; on the sequential-SLAM path — a wait every ~0.3 ms — one wake-up in a few hundred
+// arrived ~10 ms late on some hosts (one such call in a window of 100 sweeps is 15 % of the window: profiles/r06_ab.md section 8).
+inline void spin_sync(hipStream_t st, int spin_ms = 4) {
+  const auto t_in = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; spins++) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) { LX_HIP(e); }
+    if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t_in > std::chrono::milliseconds(spin_ms)) break;
+    __builtin_ia32_pause();
+  }
+  LX_HIP(hipStreamSynchronize(st));
+}
+
+inline void spin_event(hipEvent_t ev, int spin_ms = 4) {   // the same for an event
+  const auto t_in = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; spins++) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) { LX_HIP(e); }
+    if ((spins & 63u) == 63u && std::chrono::steady_clock::now() - t_in > std::chrono::milliseconds(spin_ms)) break;
+    __builtin_ia32_pause();
+  }
+  LX_HIP(hipEventSynchronize(ev));
+}
 
 // HIP stream with a relative priority: +1 = highest the device offers, 0 = default, -1 = lowest.  The stages of the
 // pipeline run on streams of their own; the latency-critical ones (registration, odometry) outrank feature extraction,

@@ -386,6 +386,8 @@ class Mapper {
     std::condition_variable cv;
     std::function<void()> job;
     bool busy = false, quit = false;
+    std::atomic<uint32_t> posted{0};   // bumped by post(): the helper spins on it for a while before it sleeps on cv
+    std::atomic<bool> running{false};  // mirror of `busy` for wait()'s spin phase
     std::exception_ptr err;
     void post(std::function<void()> f);
     void wait();          // returns when the posted job has run; rethrows what it threw
@@ -894,6 +896,19 @@ void Mapper::Helper::post(std::function<void()> f) {
     th = std::thread([this]() {
       std::unique_lock<std::mutex> l(mu);
       for (;;) {
+        // a job arrives every ~0.7 ms while sweeps flow: waking from a condition variable costs tens of microseconds as a rule and ~10 ms
+        // when the thread has lost its time slice (measured: one such call per ~100 sweeps on some hosts, profiles/r06_ab.md section 8),
+        // so the helper spins for up to 2 ms on the post counter before it goes to sleep — an idle handle costs nothing after that
+        if (!(quit || (busy && job))) {
+          const uint32_t seen = posted.load(std::memory_order_acquire);
+          l.unlock();
+          const auto t_in = std::chrono::steady_clock::now();
+          for (unsigned spins = 0; posted.load(std::memory_order_acquire) == seen;) {
+            if ((++spins & 255u) == 0u && std::chrono::steady_clock::now() - t_in > std::chrono::milliseconds(2)) break;
+            __builtin_ia32_pause();
+          }
+          l.lock();
+        }
         cv.wait(l, [this]() { return quit || (busy && job); });
         if (quit) return;
         std::function<void()> j = std::move(job);
@@ -904,15 +919,25 @@ void Mapper::Helper::post(std::function<void()> f) {
         l.lock();
         err = e;
         busy = false;
+        running.store(false, std::memory_order_release);
         cv.notify_all();
       }
     });
   cv.wait(lk, [this]() { return !busy; });
   job = std::move(f);
   busy = true;
+  running.store(true, std::memory_order_release);
+  posted.fetch_add(1, std::memory_order_release);
   cv.notify_all();
 }
 void Mapper::Helper::wait() {
+  {   // (the job is a few hundred microseconds of enqueueing as a rule: spin for it before sleeping on the condition variable)
+    const auto t_in = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; running.load(std::memory_order_acquire);) {
+      if ((++spins & 255u) == 0u && std::chrono::steady_clock::now() - t_in > std::chrono::milliseconds(2)) break;
+      __builtin_ia32_pause();
+    }
+  }
   std::unique_lock<std::mutex> lk(mu);
   cv.wait(lk, [this]() { return !busy; });
   if (err) { std::exception_ptr e = err; err = nullptr; std::rethrow_exception(e); }
@@ -922,6 +947,7 @@ Mapper::Helper::~Helper() {
     std::unique_lock<std::mutex> lk(mu);
     cv.wait(lk, [this]() { return !busy; });
     quit = true;
+    posted.fetch_add(1, std::memory_order_release);
     cv.notify_all();
   }
   if (th.joinable()) th.join();
@@ -936,8 +962,8 @@ void Mapper::complete_update() {
   if (!upd_pending) return;
   upd_pending = false;
   LX_HIP(hipSetDevice(cfg.device));
-  LX_HIP(hipStreamSynchronize(st2));
-  LX_HIP(hipStreamSynchronize(st3));   // (the histogram / counter copies are the last thing on either stream)
+  spin_sync(st2);   // (polling, not the runtime's blocking wait: common.h)
+  spin_sync(st3);   // (the histogram / counter copies are the last thing on either stream)
   for (int t = 0; t < 2; t++) tm[t].vox.check();   // (a timed-out wait inside the per-cube voxel kernel must not corrupt the map silently)
   if (*(volatile uint32_t*)h_err.p) { *h_err.p = 0u; throw Error(LOAMX_E_HIP, "map update: a tile's look-back gave up waiting for the tiles before it"); }
   for (int t = 0; t < 2; t++) {

@@ -727,7 +727,7 @@ def main():
             phase("map_2m")
             for key, sensor_, m_pts in (("live_vlp16", "VLP-16", 200_000), ("live_hdl32", "HDL-32", 500_000)):
                 try:
-                    out[key] = live_block(sensor_, m_pts, args.live_steps, 10, cpu=not args.no_cpu_baseline, nodes=not args.no_live_nodes)
+                    out[key] = side_live(sensor_, m_pts, args.live_steps, 10, cpu=not args.no_cpu_baseline, nodes=not args.no_live_nodes)
                 except Exception as e:   # noqa: BLE001
                     out[key] = {"error": repr(e)[:300]}
                 phase(key)
@@ -779,6 +779,30 @@ def run_live(args):
     if pe and not pe.get("within_bar", True):
         print("bench.py: live-mode pose error outside its bar: %r" % pe, file=sys.stderr, flush=True)
         sys.exit(3)
+
+
+def side_live(sensor, M, K, W, cpu=True, nodes=True):
+    """A sequential-SLAM block of the default line, measured in a process of its own (`bench.py --mode live ...` as a child, its line
+    embedded): inside the parent — after the batched windows have created and destroyed a few dozen HIP streams — the same chain ran
+    1,230-1,353 sweeps/s (VLP-16) where a fresh process runs 1,440-1,510 (profiles/r06_ab.md section 8: the extraction + odometry wait is
+    45 us longer, whatever the queue count or the NUMA binding).  LOAMX_BENCH_LIVE_INPROCESS=1 measures it inside the parent instead."""
+    if os.environ.get("LOAMX_BENCH_LIVE_INPROCESS"):
+        return live_block(sensor, M, K, W, cpu=cpu, nodes=nodes)
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "live", "--sensor", sensor, "--map-points", str(M), "--steps", str(K), "--warmup", str(W)]
+    if not cpu:
+        cmd.append("--no-cpu-baseline")
+    if not nodes:
+        cmd.append("--no-live-nodes")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}   # (the child is exactly `bench.py --mode live`: the runtime's default queues)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    if not lines:
+        raise RuntimeError("live child produced no line (rc %d): %s" % (r.returncode, r.stderr[-300:]))
+    blk = json.loads(lines[-1])
+    blk["measured_in"] = "a child process: " + " ".join(cmd[1:])
+    blk["child_rc"] = r.returncode   # (3: the child's own parity gate)
+    return blk
 
 
 def live_block(sensor, M, K, W, cpu=True, nodes=True):

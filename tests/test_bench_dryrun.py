@@ -480,7 +480,7 @@ def test_default_line_carries_every_single_gpu_configuration(monkeypatch, capsys
     FakePipeline.instances.clear()
     sys.path.insert(0, ROOT)
     bench = importlib.import_module("bench")
-    monkeypatch.setattr(bench, "live_block", lambda *a, **kw: _canned_live(*a, **kw, within=within))
+    monkeypatch.setattr(bench, "side_live", lambda *a, **kw: _canned_live(*a, **kw, within=within))
     if within:
         bench.main()
     else:

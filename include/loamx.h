@@ -188,7 +188,9 @@ int loamx_odom_get_stats(loamx_odom* h, int stats[4]);
  *                                  is copied by DMA from where it lies and must stay unchanged until loamx_odom_process_linked
  *                                  has returned; any other cloud has been copied out when this call returns.
  *   loamx_odom_process_linked      waits for `sr`'s extraction (and reports what loamx_scanreg_process would: LOAMX_E_INVALID
- *                                  for non-finite input, ...), runs process() on its clouds and re-projects the sweep's
+ *                                  for non-finite input, ...) — in two steps: the iterations start on the sharp / less-sharp / flat
+ *                                  clouds, the less-flat cloud (its voxel grid still running) is taken when the sweep's tail
+ *                                  needs it — runs process() on its clouds and re-projects the sweep's
  *                                  full-resolution cloud to the sweep end (transformToEnd of LaserOdometry.cpp:326) into a
  *                                  device buffer of `od`.  Returns with the pose (LOAMX_SKIPPED for the initialising sweep); the
  *                                  tail goes on behind it.  `sr`'s buffers are read until loamx_odom_link_wait(od) or

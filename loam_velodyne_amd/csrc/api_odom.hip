@@ -52,10 +52,18 @@ int loamx_odom_process_linked(loamx_odom* h, loamx_scanreg* sr) {
   return guard([&]() {
     LX_REQUIRE(h && sr, "NULL argument");
     LX_REQUIRE(sr->fx.device() == h->od.device(), "linked handles must live on one device");
-    const float4* p[4];
-    uint32_t n[4];
+    const float4* p[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t n[4] = {0, 0, 0, 0};
+    const float4* full = sr->fx.d_cloud() + sr->fx.point_base(0);
+    const uint32_t n_full = sr->fx.point_base(1) - sr->fx.point_base(0);
+    if (sr->fx.split_results()) {
+      // the iterations start as soon as the sharp / less-sharp / flat clouds are compacted; the less-flat cloud (its per-ring voxel
+      // grid runs on the extraction's stream meanwhile) is fetched when the sweep's tail is about to be enqueued
+      sr->fx.device_results_front(0, p, n);
+      return h->od.process_linked(p, n, full, n_full, [sr](const float4*& q, uint32_t& c) { sr->fx.device_results_lf(0, q, c); });
+    }
     sr->fx.device_results(0, p, n);   // (waits for the extraction; the clouds stay where they are)
-    return h->od.process_linked(p, n, sr->fx.d_cloud() + sr->fx.point_base(0), sr->fx.point_base(1) - sr->fx.point_base(0));
+    return h->od.process_linked(p, n, full, n_full);
   });
 }
 int loamx_odom_link_wait(loamx_odom* h) {

@@ -89,7 +89,10 @@ int loamx_scanreg_process_linked(loamx_scanreg* h, const loamx_cloud* cloud, con
     // lies, so it must stay unchanged until loamx_odom_process_linked has returned for this sweep (include/loamx.h); any other cloud
     // has been packed into the handle's own staging block by now
     h->fx.upload(1, cloud, rs, &n_rings, /*allow_direct=*/true);
-    h->fx.run_async();                      // no wait: loamx_odom_process_linked waits for (and checks) the extraction
+    // no wait: loamx_odom_process_linked waits for (and checks) the extraction — in two steps, the less-flat cloud behind the odometry's
+    // first launches (LOAMX_LINK_NO_SPLIT=1: in one step, as before round 6; same results — tests/test_gpu_linked.py)
+    const bool no_split = getenv("LOAMX_LINK_NO_SPLIT") != nullptr;   // (read per call: a test toggles it)
+    h->fx.run_async(/*mirror_offsets=*/!no_split);
     return LOAMX_OK;
   });
 }

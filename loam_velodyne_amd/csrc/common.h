@@ -216,7 +216,22 @@ inline int env_priority(const char* name, int dflt) {
   return v > 0 ? 1 : (v < 0 ? -1 : 0);
 }
 // cu_stride > 1 (diagnostic, LOAMX_FEAT_CU_STRIDE): a stream whose kernels only run on every cu_stride-th compute unit
-inline hipStream_t create_stream(int rel_priority, int cu_stride = 0) {
+// cu_split (diagnostic, LOAMX_CU_SPLIT=n): the device's compute units in two sets — mask bits [0, n) for the streams created with part 0
+// (the odometry chains), the rest for those created with part 1 (registration, features): do the chains' persistent workgroups run
+// their iterations faster when nothing else shares their compute units?  (a masked stream has no priority: the runtime offers no call for both)
+inline hipStream_t create_stream(int rel_priority, int cu_stride = 0, int part = -1) {
+  if (part >= 0 && diag_env("LOAMX_CU_SPLIT") && atoi(diag_env("LOAMX_CU_SPLIT")) > 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    LX_HIP(hipGetDevice(&dev));
+    LX_HIP(hipGetDeviceProperties(&prop, dev));
+    const int ncu = prop.multiProcessorCount, n = std::min(atoi(diag_env("LOAMX_CU_SPLIT")), ncu - 8);
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int i = (part == 0 ? 0 : n); i < (part == 0 ? n : ncu); i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+    hipStream_t st = nullptr;
+    LX_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    return st;
+  }
   if (cu_stride > 1) {
     hipDeviceProp_t prop;
     int dev = 0;

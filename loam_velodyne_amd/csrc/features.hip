@@ -682,7 +682,7 @@ __global__ __launch_bounds__(64) void k_feat_compact(const float4* __restrict__ 
                                                      const uint32_t* __restrict__ c0, const uint32_t* __restrict__ c1, const uint32_t* __restrict__ c2,
                                                      uint32_t cap0, uint32_t cap1, uint32_t cap2, float4* __restrict__ o0, float4* __restrict__ o1,
                                                      float4* __restrict__ o2, uint32_t* __restrict__ offs, const uint32_t* __restrict__ sweep_ring_base,
-                                                     uint32_t nsw) {
+                                                     uint32_t nsw, uint32_t* __restrict__ host_offs) {
   const uint32_t r = blockIdx.x, kind = blockIdx.y, nring = gridDim.x;
   const int lane = (int)threadIdx.x;
   const float4* s = kind == 0 ? s0 : (kind == 1 ? s1 : s2);
@@ -693,16 +693,20 @@ __global__ __launch_bounds__(64) void k_feat_compact(const float4* __restrict__ 
   for (uint32_t k = (uint32_t)lane; k < n; k += 64u) o[dst + k] = s[(size_t)r * cap + k];
   if (lane == 0) {
     uint32_t* off = offs + (size_t)kind * (nsw + 1);
+    // host_offs (linked single-sweep handles): the same table in pinned host memory — the host reads the three sizes behind an event
+    // recorded right after this launch, while the less-flat voxel grid is still running (FeatureExtractor::device_results_front)
+    uint32_t* hoff = host_offs ? host_offs + (size_t)kind * (nsw + 1) : nullptr;
     uint32_t lo = 0, hi = nsw + 1;   // first sweep whose first ring is >= r
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sweep_ring_base[mid] < r) lo = mid + 1; else hi = mid; }
-    for (uint32_t sw = lo; sw <= nsw && sweep_ring_base[sw] == r; sw++) off[sw] = dst;
+    for (uint32_t sw = lo; sw <= nsw && sweep_ring_base[sw] == r; sw++) { off[sw] = dst; if (hoff) hoff[sw] = dst; }
     if (r + 1 == nring)   // (sweeps that start behind the last ring — the entry [nsw] among them — hold the total)
-      for (uint32_t sw = nsw; sweep_ring_base[sw] >= nring; sw--) { off[sw] = dst + n; if (sw == 0) break; }
+      for (uint32_t sw = nsw; sweep_ring_base[sw] >= nring; sw--) { off[sw] = dst + n; if (hoff) hoff[sw] = dst + n; if (sw == 0) break; }
   }
 }
 // grid = nring, 256 threads
 __global__ __launch_bounds__(256) void k_feat_lf_compact(const float4* __restrict__ slots, const uint32_t* __restrict__ ring_off,
-                                                         const uint32_t* __restrict__ cnt, uint32_t* __restrict__ lf_off, float4* __restrict__ out) {
+                                                         const uint32_t* __restrict__ cnt, uint32_t* __restrict__ lf_off, float4* __restrict__ out,
+                                                         uint32_t* __restrict__ host_lf_off) {
   __shared__ uint32_t s_dst;
   const uint32_t r = blockIdx.x;
   if (threadIdx.x < 64) {
@@ -711,6 +715,10 @@ __global__ __launch_bounds__(256) void k_feat_lf_compact(const float4* __restric
       s_dst = d;
       lf_off[r] = d;
       if (r + 1 == gridDim.x) lf_off[gridDim.x] = d + cnt[r];
+      if (host_lf_off) {   // (pinned host mirror: FeatureExtractor::device_results_lf)
+        host_lf_off[r] = d;
+        if (r + 1 == gridDim.x) host_lf_off[gridDim.x] = d + cnt[r];
+      }
     }
   }
   __syncthreads();
@@ -741,6 +749,8 @@ void FeatureExtractor::check_finite_input() {
 }
 
 FeatureExtractor::~FeatureExtractor() {
+  if (ev_front_) (void)hipEventDestroy(ev_front_);
+  if (ev_lf_) (void)hipEventDestroy(ev_lf_);
   if (own_stream_ && st_) (void)hipStreamDestroy(st_);
 }
 
@@ -1047,10 +1057,20 @@ int FeatureExtractor::download_cloud(uint32_t sweep, loamx_cloud* full, uint32_t
   return unpack_cloud(h_pack_.p, b - a, full);
 }
 
-void FeatureExtractor::run_async() {
+void FeatureExtractor::run_async(bool mirror_offsets) {
   TraceRange trace_range("loamx:features:extract");
   LX_REQUIRE(nsw_ > 0, "run() before upload()");
   LX_HIP(hipSetDevice(device_));
+  // mirror_offsets (the linked single-sweep chain): the compaction kernels write their offset tables into pinned host memory as well,
+  // and an event is recorded behind each — the consumer reads the sharp / less-sharp / flat sizes ~50 us before the less-flat voxel grid
+  // has finished (device_results_front / device_results_lf) and starts the odometry's iterations, which do not need that cloud
+  split_ = mirror_offsets && max_ring_len_ <= LFV_MAX;
+  uint32_t* hmir = nullptr;
+  if (split_) {
+    h_mirror_off_.reserve(n_offsets());
+    hmir = h_mirror_off_.p;
+    if (!ev_front_) { LX_HIP(hipEventCreateWithFlags(&ev_front_, hipEventDisableTiming)); LX_HIP(hipEventCreateWithFlags(&ev_lf_, hipEventDisableTiming)); }
+  }
   const int cr = params.curv_region;
   (void)cr;   // (lf_valid_ is cleared ring by ring in k_feat_ring's prologue: no memset)
   const uint32_t caps[3] = {(uint32_t)(params.max_sharp * params.n_regions), (uint32_t)(params.max_less_sharp * params.n_regions),
@@ -1069,7 +1089,8 @@ void FeatureExtractor::run_async() {
                      sortP, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p, slot_cnt_[1].p, slot_cnt_[2].p, lf_valid_.p, force_seq ? 1 : 0,
                      h_bad_.p);
   hipLaunchKernelGGL(k_feat_compact, dim3(nring_, 3), dim3(64), 0, st_, slots_[0].p, slots_[1].p, slots_[2].p, slot_cnt_[0].p, slot_cnt_[1].p,
-                     slot_cnt_[2].p, caps[0], caps[1], caps[2], out_[0].p, out_[1].p, out_[2].p, offs_.p, sweep_ring_base_.p, nsw_);
+                     slot_cnt_[2].p, caps[0], caps[1], caps[2], out_[0].p, out_[1].p, out_[2].p, offs_.p, sweep_ring_base_.p, nsw_, hmir);
+  if (split_) LX_HIP(hipEventRecord(ev_front_, st_));
   // per-ring voxel grid of the less-flat candidates
   const float inv = 1.0f / params.less_flat_leaf;
   if (max_ring_len_ <= LFV_MAX) {
@@ -1079,7 +1100,9 @@ void FeatureExtractor::run_async() {
       LX_HIP(hipFuncSetAttribute((const void*)k_feat_lf_voxel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)P * 24)));
     hipLaunchKernelGGL(k_feat_lf_voxel, dim3(nring_), dim3(LFV_THREADS), (size_t)P * 24, st_, cloud_.p, ring_off_.p, lf_valid_.p, inv, P,
                        lf_slots_.p, lf_cnt_.p);
-    hipLaunchKernelGGL(k_feat_lf_compact, dim3(nring_), dim3(256), 0, st_, lf_slots_.p, ring_off_.p, lf_cnt_.p, lf_off_(), lf_out_.p);
+    hipLaunchKernelGGL(k_feat_lf_compact, dim3(nring_), dim3(256), 0, st_, lf_slots_.p, ring_off_.p, lf_cnt_.p, lf_off_(), lf_out_.p,
+                       hmir ? hmir + (size_t)3 * off_stride_ : nullptr);
+    if (split_) LX_HIP(hipEventRecord(ev_lf_, st_));
   } else {   // very long rings: generic segmented pipeline (global radix sort)
     vox_.compute_ijk(cloud_.p, lf_valid_.p, n_, ring_off_.p, nring_, inv, inv);
     vox_.sort_reduce(cloud_.p, lf_valid_.p, n_, ring_off_.p, nring_, lf_out_.p, lf_off_());
@@ -1146,6 +1169,31 @@ void FeatureExtractor::device_results(uint32_t sweep, const float4* ptr[4], uint
   const uint32_t a = lf[h_ring_base_[sweep]], b = lf[h_ring_base_[sweep + 1]];
   ptr[3] = lf_out_.p + a;
   count[3] = b - a;
+}
+
+// The two halves of device_results() for a run_async(true): the sharp / less-sharp / flat clouds as soon as k_feat_compact has finished
+// (input check included: k_feat_ring raises the non-finite mark) ...
+void FeatureExtractor::device_results_front(uint32_t sweep, const float4* ptr[3], uint32_t count[3]) {
+  LX_REQUIRE(sweep < nsw_, "sweep index out of range");
+  LX_REQUIRE(split_, "internal: device_results_front() without run_async(true)");
+  spin_event(ev_front_);
+  check_finite_input();
+  const uint32_t* o = h_mirror_off_.p;
+  for (int k = 0; k < 3; k++) {
+    const uint32_t a = o[(size_t)k * off_stride_ + sweep], b = o[(size_t)k * off_stride_ + sweep + 1];
+    ptr[k] = out_[k].p + a;
+    count[k] = b - a;
+  }
+}
+// ... and the less-flat cloud once its per-ring voxel grid has been compacted
+void FeatureExtractor::device_results_lf(uint32_t sweep, const float4*& ptr, uint32_t& count) {
+  LX_REQUIRE(sweep < nsw_, "sweep index out of range");
+  LX_REQUIRE(split_, "internal: device_results_lf() without run_async(true)");
+  spin_event(ev_lf_);
+  const uint32_t* lf = h_mirror_off_.p + (size_t)3 * off_stride_;
+  const uint32_t a = lf[h_ring_base_[sweep]], b = lf[h_ring_base_[sweep + 1]];
+  ptr = lf_out_.p + a;
+  count = b - a;
 }
 
 int FeatureExtractor::download(uint32_t sweep, loamx_cloud* sharp, loamx_cloud* less_sharp, loamx_cloud* flat, loamx_cloud* less_flat) {

@@ -82,7 +82,8 @@ class FeatureExtractor {
   const float* imu_trans() const { return imu_.imu_trans(); }   // imuTransform(): 4 x (x, y, z)
   int imu_history_size = 200;                               // RegistrationParams::imuHistorySize
   int download_cloud(uint32_t sweep, loamx_cloud* full, uint32_t* ring_size_out);
-  void run_async();
+  // mirror_offsets: the offset tables also go to pinned host memory, with an event behind each compaction (device_results_front / _lf)
+  void run_async(bool mirror_offsets = false);
   void sync();
   // after a synchronisation point behind run_async(): throws LOAMX_E_INVALID when k_feat_point met a non-finite coordinate (and clears the mark)
   void check_finite_input();
@@ -92,6 +93,12 @@ class FeatureExtractor {
   // the same clouds left where they are: waits for the run (and raises what download() would raise), then hands out the device views
   // and sizes of one sweep's sharp / less sharp / flat / less flat clouds (valid until the next upload)
   void device_results(uint32_t sweep, const float4* ptr[4], uint32_t count[4]);
+  // the same in two steps behind a run_async(true) whose rings fit the LDS voxel grid (split_results()): sharp / less sharp / flat as soon
+  // as they are compacted (raises what device_results() would raise about the input), the less-flat cloud when its voxel grid is done —
+  // the odometry's iterations run in between (OdometryBatch::process_linked)
+  bool split_results() const { return split_; }
+  void device_results_front(uint32_t sweep, const float4* ptr[3], uint32_t count[3]);
+  void device_results_lf(uint32_t sweep, const float4*& ptr, uint32_t& count);
 
   // device-side results for chaining (valid after run_async on the same stream):
   //   kind 0 sharp, 1 less_sharp, 2 flat: compact arrays + per-sweep offsets [nsw+1]
@@ -150,6 +157,9 @@ class FeatureExtractor {
   DevBuf<uint32_t> lf_cnt_;
   VoxelPipeline vox_;
   PinBuf<uint32_t> h_off_, h_link_off_;
+  PinBuf<uint32_t> h_mirror_off_;   // run_async(true): the offset tables as the compaction kernels wrote them (layout of offs_)
+  hipEvent_t ev_front_ = nullptr, ev_lf_ = nullptr;   // behind k_feat_compact / behind k_feat_lf_compact
+  bool split_ = false;
   PinBuf<uint32_t> h_bad_;   // pinned word raised by k_feat_point on a non-finite input coordinate
   PinBuf<float4> h_pack_;   // download(): [header | sharp | less sharp | flat | less flat] of one sweep, written by k_feat_pack_host
 };

@@ -18,6 +18,7 @@
 #include <deque>
 #include <exception>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include "host_math.h"
@@ -378,8 +379,12 @@ class Mapper {
   bool upd_pending = false;
   uint32_t upd_n_sub[2] = {0, 0};
   void finish_update();     // the calling thread: the helper has run its job; the update's result is in the host's cube directory
+  // the same for the next process() call only: the helper's job is through the update and the prepared partition — on every fifth frame it
+  // is still cutting the surround cloud then (createDownsizedMap: ~0.2 ms on a stream of its own, reading the updated map, which the next
+  // sweep's partition only reads as well); everything else that touches the handle waits for the whole job (finish_update)
+  void finish_update_front();
   void complete_update();   // the wait + the bookkeeping themselves (either thread, behind the helper's enqueue)
-  void compute_surround(const MapWindow& w);
+  void compute_surround(const MapWindow& w, const uint8_t* sur_lut);
   struct Helper {
     std::thread th;
     std::mutex mu;
@@ -388,6 +393,8 @@ class Mapper {
     bool busy = false, quit = false;
     std::atomic<uint32_t> posted{0};   // bumped by post(): the helper spins on it for a while before it sleeps on cv
     std::atomic<bool> running{false};  // mirror of `busy` for wait()'s spin phase
+    std::atomic<bool> front_done{true};   // the running job has left its front part (update + prepared partition) behind: finish_update_front()
+    std::atomic<bool> front_failed{false};   // ... by an exception (wait() rethrows it)
     std::exception_ptr err;
     void post(std::function<void()> f);
     void wait();          // returns when the posted job has run; rethrows what it threw
@@ -540,7 +547,7 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   }
   if (full_res) check_cloud(full_res, false);
   LX_HIP(hipSetDevice(cfg.device));
-  finish_update();
+  finish_update_front();
   tr.mark("finished_update");
   frame_count++;
   if (frame_count < 1) return LOAMX_SKIPPED;   // _stackFrameNum = 1 (:269-274)
@@ -585,7 +592,10 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     }
   }
   tr.mark("uploaded");
-  if (!adopt) enqueue_partition(plan, tab_cur, n_in);
+  if (!adopt) {
+    helper.wait();   // (a surround cloud still being cut reads the look-up tables the partition is about to rewrite; ensure() may move the map)
+    enqueue_partition(plan, tab_cur, n_in);
+  }
   tr.mark(adopt ? "partition_adopted" : "partition+index");
 
   // ---- registration against the sub-map (guard + iterations inside Registrar::run_async)
@@ -632,6 +642,14 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     }
   } spec_release{this};
   helper.post([this, n_sub0, n_sub1, n_in0, n_in1, nvalid, w, surround_due, speculate]() {
+  struct FrontDone {   // (also when the front part throws: the caller's next wait must end — it goes on to Helper::wait(), which rethrows)
+    Helper& h;
+    ~FrontDone() {
+      if (std::uncaught_exceptions() > 0) h.front_failed.store(true, std::memory_order_release);
+      h.front_done.store(true, std::memory_order_release);
+    }
+  };
+  std::unique_ptr<FrontDone> front(new FrontDone{helper});
   LX_HIP(hipSetDevice(cfg.device));
   const uint32_t n_sub[2] = {n_sub0, n_sub1}, n_in[2] = {n_in0, n_in1};
   LX_HIP(hipStreamWaitEvent(st2, ev_fork, 0));
@@ -665,14 +683,13 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     hipLaunchKernelGGL(k_map_hist, dim3(std::min<uint32_t>((max_new + 2047) / 2048, 256u)), dim3(256), 0, st, T.tags[nxt].p, T.counters.p + 6, max_new, w, T.hist.p);
     LX_HIP(hipMemcpyAsync(T.h_hist.p, T.hist.p, sizeof(uint32_t) * (MCUBES + 16), hipMemcpyDeviceToHost, st));   // (histogram + the counters behind it: one copy)
   }
-  if (surround_due) {
-    static const bool trace = getenv("LOAMX_MAP_TRACE") != nullptr;
-    const double t0 = trace ? MapTrace::now() : 0.0;
-    complete_update();
-    const double t1 = trace ? MapTrace::now() : 0.0;
-    compute_surround(w);
-    if (trace) fprintf(stderr, "[map trace, helper] update completed %.1f us after its enqueue, surround cloud %.1f us\n", t1 - t0, MapTrace::now() - t1);
-  }
+  static const bool trace = getenv("LOAMX_MAP_TRACE") != nullptr;
+  const double t0 = trace ? MapTrace::now() : 0.0;
+  if (surround_due) complete_update();
+  const double t1 = trace ? MapTrace::now() : 0.0;
+  // (the surround cloud is cut LAST, behind the prepared partition: the next sweep waits for the partition, not for the cloud — round 6; the
+  // cloud is cut with THIS sweep's look-up table, the preparation below points sur_lut_v at the next one's)
+  const uint8_t* sur_lut_now = sur_lut_v;
   if (speculate) {   // the next sweep's partition + index for the predicted pose (see spec_plan)
     complete_update();
     SpecInputs in;
@@ -696,6 +713,12 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
         spec_valid = true;
       }
     }
+  }
+  front.reset();   // the next process() call may start
+  if (surround_due) {
+    const double t2 = trace ? MapTrace::now() : 0.0;
+    compute_surround(w, sur_lut_now);
+    if (trace) fprintf(stderr, "[map trace, helper] update completed %.1f us after its enqueue, surround cloud %.1f us\n", t1 - t0, MapTrace::now() - t2);
   }
   });
   tr.mark("update_posted");
@@ -843,7 +866,7 @@ void Mapper::enqueue_partition(const Plan& plan, int set, const uint32_t n_in_ro
 
 // createDownsizedMap (:242-264): the surround cloud, cut from the UPDATED map.  Runs on the helper thread behind the update (st3; the
 // two host waits in here are why: they would sit in front of the caller's next sweep otherwise)
-void Mapper::compute_surround(const MapWindow& w) {
+void Mapper::compute_surround(const MapWindow& w, const uint8_t* sur_lut) {
   hipStream_t st = st3;
   const uint32_t nc = tm[0].n, nsf = tm[1].n, ntot = nc + nsf;
   const uint32_t room2 = std::max(tm[0].room + tm[1].room, ntot + 2), room1 = std::max(std::max(tm[0].room, tm[1].room), std::max(nc, nsf) + 2);   // (ensure(): room in large steps)
@@ -862,7 +885,7 @@ void Mapper::compute_surround(const MapWindow& w) {
     uint32_t* cnt = sur_cnt.p + 4 * t;   // [n, total]
     if (n) {
       const uint32_t nb = (n + 255) / 256;
-      hipLaunchKernelGGL(k_map_surround_flags, dim3(nb), dim3(256), 0, st, T.tags[T.cur].p, T.counters.p + 6, n, w, sur_lut_v, sur_flag.p);
+      hipLaunchKernelGGL(k_map_surround_flags, dim3(nb), dim3(256), 0, st, T.tags[T.cur].p, T.counters.p + 6, n, w, sur_lut, sur_flag.p);
       exclusive_scan_u32_n(sur_flag.p, sur_scan.p, sur_tiles.p, cnt, n, st);
       hipLaunchKernelGGL(k_map_compact, dim3(nb), dim3(256), 0, st, T.pts[T.cur].p, sur_flag.p, sur_scan.p, n, 0u,
                          t == 0 ? (const uint32_t*)nullptr : (const uint32_t*)(sur_cnt.p + 1), sur_in.p);
@@ -926,6 +949,8 @@ void Mapper::Helper::post(std::function<void()> f) {
   cv.wait(lk, [this]() { return !busy; });
   job = std::move(f);
   busy = true;
+  front_failed.store(false, std::memory_order_release);
+  front_done.store(false, std::memory_order_release);
   running.store(true, std::memory_order_release);
   posted.fetch_add(1, std::memory_order_release);
   cv.notify_all();
@@ -951,6 +976,17 @@ Mapper::Helper::~Helper() {
     cv.notify_all();
   }
   if (th.joinable()) th.join();
+}
+
+void Mapper::finish_update_front() {
+  const auto t_in = std::chrono::steady_clock::now();
+  for (unsigned spins = 0; !helper.front_done.load(std::memory_order_acquire);) {
+    if ((++spins & 255u) == 0u && std::chrono::steady_clock::now() - t_in > std::chrono::milliseconds(2)) { helper.wait(); break; }
+    __builtin_ia32_pause();
+  }
+  // (a job that has ended or whose front part threw: take what it threw — no wait in the first case, the job's unwinding in the second)
+  if (!helper.running.load(std::memory_order_acquire) || helper.front_failed.load(std::memory_order_acquire)) helper.wait();
+  complete_update();   // (a job that neither cut a surround cloud nor prepared a partition has only enqueued the update)
 }
 
 void Mapper::finish_update() {

@@ -927,7 +927,7 @@ OdometryBatch::OdometryBatch(int device, uint32_t n_streams, hipStream_t shared_
   if (shared_stream) {
     st_ = shared_stream;
   } else {
-    st_ = create_stream(env_priority("LOAMX_PRIO_ODOM", +1));
+    st_ = create_stream(env_priority("LOAMX_PRIO_ODOM", +1), 0, /*part=*/0);
     own_stream_ = true;
   }
   for (uint32_t s = 0; s < n_streams; s++) streams_.push_back(new OdomStream());
@@ -1050,6 +1050,18 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
     LX_HIP(hipEventSynchronize(ev_up_));   // they precede its iterations); the device-side tail of that call needs no waiting for — same stream
     up_pending_ = false;
   }
+  // A single-stream caller may hand the less-flat cloud over LATE (late_less_flat, process_linked): the iterations read the sharp / flat
+  // features and the previous sweep's clouds only; the less-flat cloud of THIS sweep is first read by the tail (re-projection, index of
+  // the "last" clouds).  Its producer — the per-ring voxel grid of the extraction, ~50 us on a stream of its own — then runs beside the
+  // first launch pair instead of in front of it.  The callback is called once, before the tail is enqueued, and blocks until the cloud
+  // and its size are known; until then the cloud counts as empty (offsets, staging) and the buffers are sized with late_bound.
+  const bool late = ns == 1 && (bool)late_less_flat;
+  std::vector<OdomInput> in_late;
+  if (late) {
+    in_late.assign(in, in + ns);
+    in_late[0].less_flat = nullptr; in_late[0].n_less_flat = 0;
+    in = in_late.data();
+  }
   // ---- stage the current less-sharp / less-flat clouds of all streams (they are re-projected in place later)
   for (uint32_t s = 0; s < ns; s++) {
     h_cur_off_[s + 1] = h_cur_off_[s] + in[s].n_less_sharp;
@@ -1057,8 +1069,9 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
                           "less_sharp clouds of the streams must be contiguous");
   }
   for (uint32_t s = 0; s < ns; s++) h_cur_off_[ns + s + 1] = h_cur_off_[ns + s] + in[s].n_less_flat;
-  const uint32_t n_corner_all = h_cur_off_[ns], n_all = h_cur_off_[K];
-  cur_.reserve((size_t)n_all + 1);
+  const uint32_t n_corner_all = h_cur_off_[ns];
+  uint32_t n_all = h_cur_off_[K];   // (late: without the less-flat cloud until resolve_late())
+  cur_.reserve((size_t)n_all + (late ? late_bound : 0u) + 1);
   // per-type bulk copies when the inputs are contiguous, else per stream
   bool contig_c = true, contig_s = true;
   for (uint32_t s = 1; s < ns; s++) {
@@ -1069,6 +1082,23 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   const bool fused_stage = contig_c && contig_s;
   const float4* src_c = fused_stage ? in[0].less_sharp : nullptr;
   const float4* src_s = fused_stage ? in[0].less_flat : nullptr;
+  bool late_pending = late;
+  auto resolve_late = [&]() {
+    if (!late_pending) return;
+    late_pending = false;
+    const float4* p = nullptr;
+    uint32_t n = 0;
+    late_less_flat(p, n);
+    LX_REQUIRE(n <= late_bound, "internal: the late less-flat cloud is larger than its announced bound");
+    in_late[0].less_flat = p; in_late[0].n_less_flat = n;
+    h_cur_off_[ns + 1] = h_cur_off_[ns] + n;
+    n_all = h_cur_off_[K];
+    src_s = p;   // (ns == 1: contiguous by construction, the re-projection reads the cloud where it lies)
+    h_off_late_.reserve(K + 1);
+    memcpy(h_off_late_.p, h_cur_off_.data(), sizeof(uint32_t) * (K + 1));
+    LX_HIP(hipMemcpyAsync(d_cur_off_.p, h_off_late_.p, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st_));   // the offsets again, now complete
+    LX_HIP(hipEventRecord(ev_up_, st_));   // (the next call waits for this copy too before it rewrites the pinned blocks)
+  };
   if (fused_stage) {
   } else if (contig_c) {
     if (n_corner_all) LX_HIP(hipMemcpyAsync(cur_.p, in[0].less_sharp, sizeof(float4) * n_corner_all, hipMemcpyDeviceToDevice, st_));
@@ -1236,6 +1266,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
         enqueue_lm(0);
         enq = 1;
         if (maxp > 1) enqueue_corr(1);
+        resolve_late();   // (the device has a launch pair and a half in its queue: the wait for the less-flat cloud costs the chain nothing)
         while (enq < maxp) {
           if (!wait_settled(enq - 1)) {   // blind: everything that is left, unconditionally (always correct)
             enqueue_lm(enq);
@@ -1250,6 +1281,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
       } else {
       const int first = pair_mode == 0 ? maxp : std::min(maxp, pair_mode == 2 ? std::max(1, pred_pairs_) : 2);
       for (; enq < first; enq++) enqueue_pair(5 * enq);
+      resolve_late();
       bool blind = false;             // the mirror did not answer in time: enqueue the rest unconditionally (always correct)
       while (enq < maxp) {
         const int watch = pair_mode == 2 ? enq - 1 : enq - 2;
@@ -1272,6 +1304,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   // ---- re-project to the sweep end (:651-652), hand over as "last" clouds and rebuild their index (:654-664): enqueued
   // right behind the iterations; the host only waits for the poses
   static const bool fuse_bounds = !(diag_env("LOAMX_BB_FUSED") && atoi(diag_env("LOAMX_BB_FUSED")) == 0);   // diagnostic: 0 = separate k_bb_bbox launch
+  resolve_late();   // (a sweep without iterations: the tail is the first reader)
   if (n_all)
   {
     if (++rf_epoch_ > 255u) rf_epoch_ = 1u;   // entries of this re-projection carry the new epoch; the problems of the NEXT call name it
@@ -1421,13 +1454,19 @@ int OdometryBatch::process_host(const loamx_cloud* sharp, const loamx_cloud* les
   return rc;
 }
 
-int OdometryBatch::process_linked(const float4* const feat[4], const uint32_t n_feat[4], const float4* d_full, uint32_t n_full) {
+int OdometryBatch::process_linked(const float4* const feat[4], const uint32_t n_feat[4], const float4* d_full, uint32_t n_full,
+                                  const std::function<void(const float4*&, uint32_t&)>& less_flat_late) {
   LX_REQUIRE(n_streams() == 1, "process_linked is a single-stream entry point");
   LX_HIP(hipSetDevice(device_));
   OdomInput in{feat[0], n_feat[0], feat[1], n_feat[1], feat[2], n_feat[2], feat[3], n_feat[3]};
   int rc = LOAMX_OK;
   last_dl_valid_ = false;
   link_valid_ = false;
+  struct Late {   // feat[3] / n_feat[3] are ignored when the cloud comes late (a subset of the sweep: at most n_full points)
+    OdometryBatch& o;
+    ~Late() { o.late_less_flat = nullptr; o.late_bound = 0; }
+  } late_guard{*this};
+  if (less_flat_late) { late_less_flat = less_flat_late; late_bound = n_full; }
   process(&in, &rc, /*defer_tail=*/true);
   link_full_.reserve((size_t)n_full + 1);
   if (n_full)

@@ -100,7 +100,10 @@ class OdometryBatch {
   // the same sweep from DEVICE clouds (the feature extractor's own buffers, read until this call returns), plus the sweep's
   // full-resolution cloud: re-projected to the sweep end (LaserOdometry.cpp:326) into a buffer of this object behind the tail.
   // link_ready() is recorded behind everything a consumer on another stream reads: d_last_corner / d_last_surf / d_link_full
-  int process_linked(const float4* const feat[4], const uint32_t n_feat[4], const float4* d_full, uint32_t n_full);
+  // less_flat_late (optional): the less-flat cloud is asked for only when the tail needs it — the callback blocks until it exists and
+  // returns its device view and size (a subset of the sweep); the iterations start without it (process(): late_less_flat)
+  int process_linked(const float4* const feat[4], const uint32_t n_feat[4], const float4* d_full, uint32_t n_full,
+                     const std::function<void(const float4*&, uint32_t&)>& less_flat_late = nullptr);
   hipEvent_t link_ready() const { return ev_link_; }
   const float4* d_link_full() const { return link_full_.p; }
   uint32_t n_link_full() const { return n_link_full_; }
@@ -157,6 +160,9 @@ class OdometryBatch {
   View<OdomProblem> prob_, h_prob_;
   View<ToEndParams> te_, h_te_;
   View<uint32_t> d_cur_off_, h_off_pin_;
+  PinBuf<uint32_t> h_off_late_;      // the cloud offsets once more, uploaded when a late less-flat cloud has arrived
+  std::function<void(const float4*&, uint32_t&)> late_less_flat;   // single-stream process() only; set and cleared by process_linked
+  uint32_t late_bound = 0;           // upper bound of that cloud's size
   PinBuf<float4> h_stage_;
   PinBuf<float4> h_last_dl_;     // process_host(): the clouds get_last_clouds() hands out, copied behind the tail
   bool last_dl_valid_ = false;

@@ -378,7 +378,7 @@ class Pipeline {
   void upload(uint32_t n_steps, const loamx_cloud* clouds, const uint32_t* const* ring_size, const uint32_t* n_rings) {
     LX_REQUIRE(n_steps >= 1 && clouds && ring_size && n_rings, "invalid argument");
     LX_HIP(hipSetDevice(device));
-    if (!fstream) fstream = create_stream(env_priority("LOAMX_PRIO_FEAT", -1), diag_env("LOAMX_FEAT_CU_STRIDE") ? atoi(diag_env("LOAMX_FEAT_CU_STRIDE")) : 0);
+    if (!fstream) fstream = create_stream(env_priority("LOAMX_PRIO_FEAT", -1), diag_env("LOAMX_FEAT_CU_STRIDE") ? atoi(diag_env("LOAMX_FEAT_CU_STRIDE")) : 0, /*part=*/1);
     LX_HIP(hipStreamSynchronize(fstream));
     fx.clear();
     streaming = false;
@@ -406,7 +406,7 @@ class Pipeline {
   void ensure_streaming_(uint32_t t) {
     if (!streaming) {   // first use: switch to the ring of slots
       LX_REQUIRE(t == 0, "streaming input starts at step 0");
-      if (!fstream) fstream = create_stream(env_priority("LOAMX_PRIO_FEAT", -1), diag_env("LOAMX_FEAT_CU_STRIDE") ? atoi(diag_env("LOAMX_FEAT_CU_STRIDE")) : 0);
+      if (!fstream) fstream = create_stream(env_priority("LOAMX_PRIO_FEAT", -1), diag_env("LOAMX_FEAT_CU_STRIDE") ? atoi(diag_env("LOAMX_FEAT_CU_STRIDE")) : 0, /*part=*/1);
       LX_HIP(hipStreamSynchronize(fstream));
       fx.clear();
       for (uint32_t k = 0; k < RING; k++) {

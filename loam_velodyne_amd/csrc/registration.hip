@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_gather_segments(float4* __restrict__ ds
 // ----------------------------------------------------------------------------------------------------------------
 Registrar::Registrar(int device, uint32_t max_sweeps) : device_(device), max_sweeps_(max_sweeps) {
   select_device(device);
-  st_ = create_stream(env_priority("LOAMX_PRIO_REG", +1));
+  st_ = create_stream(env_priority("LOAMX_PRIO_REG", +1), 0, /*part=*/1);
   corner_index.init(st_);
   surf_index.init(st_);
   poses_.reserve(max_sweeps);

@@ -158,6 +158,40 @@ def test_pinned_caller_memory_is_copied_from_and_to_directly():
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
 
 
+@pytest.mark.parametrize("max_iterations", [25, 4])
+def test_late_less_flat_cloud_changes_nothing(monkeypatch, max_iterations):
+    """the linked odometry starts its iterations as soon as the sharp / less-sharp / flat clouds are compacted and takes the less-flat
+    cloud when the sweep's tail needs it (the per-ring voxel grid runs beside the first launches); LOAMX_LINK_NO_SPLIT=1 waits for the
+    whole extraction first, as before: everything either chain produces is equal bit for bit — also when one launch pair is all a
+    sweep may use (max_iterations 4: no second correspondence launch in front of the late hand-over)"""
+    world = synth.World(half_extent=65.0)
+    cm, sm, sweeps = _chains(world, "VLP-16", 7, 60_000)
+    chains = []
+    for split in (True, False):
+        if split:
+            monkeypatch.delenv("LOAMX_LINK_NO_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("LOAMX_LINK_NO_SPLIT", "1")
+        sr, od, mp = loamx.ScanRegistration(), loamx.LaserOdometry(max_iterations=max_iterations), loamx.LaserMapping()
+        mp.load_cubes(cm, sm)
+        landing = np.zeros((max(len(s.points) for s in sweeps), 4), np.float32)
+        out = []
+        for sw in sweeps:
+            sr.process_linked(sw.points, sw.ring_sizes)
+            rc = od.process_linked(sr)
+            lc, ls = od.last_clouds()
+            rcm, reg = mp.process_linked(od, landing)
+            out.append((rc, np.array(od.transform), np.array(od.transform_sum), od.stats(), lc, ls, rcm, mp.transform("aft"), reg.copy(), mp.stats()))
+        chains.append((out, mp.cubes(0), mp.cubes(1)))
+    (a, ac, asf), (b, bc, bsf) = chains
+    for t, (x, y) in enumerate(zip(a, b)):
+        assert x[0] == y[0] and x[3] == y[3] and x[6] == y[6] and x[9] == y[9], t
+        for k in (1, 2, 4, 5, 7, 8):
+            assert np.array_equal(x[k], y[k]), (t, k)
+    assert len(a[-1][5]) > 100 and a[-1][3]["iterations"] >= 1
+    assert np.array_equal(ac, bc) and np.array_equal(asf, bsf)
+
+
 def test_prepared_partition_is_adopted_and_changes_nothing(monkeypatch):
     """the next sweep's map partition + sub-map index are prepared behind the update for the predicted pose and adopted when the true
     pose's plan is identical: on a smooth trajectory that is nearly every sweep, and a handle that never speculates produces the same

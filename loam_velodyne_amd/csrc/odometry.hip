@@ -269,7 +269,10 @@ __device__ unsigned long long g_corr_ts[3][16];   // [corner feature / flat mid 
 #else
 #define OC_TS(k) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr_grid(OdomProblem* __restrict__ probs, OdomParams P) {
+// patch_dst / patch (optional): three words this launch writes for the kernels BEHIND it on the stream — the cloud offsets of a
+// single-stream sweep whose less-flat cloud arrived late (OdometryBatch::process, resolve_late): no copy command between two launches
+__global__ __launch_bounds__(256) OD_CORR_ATTR void k_odom_corr_grid(OdomProblem* __restrict__ probs, OdomParams P, uint32_t* __restrict__ patch_dst, uint4 patch) {
+  if (patch_dst && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { patch_dst[0] = patch.x; patch_dst[1] = patch.y; patch_dst[2] = patch.z; }
   OdomProblem& pb = probs[blockIdx.y];
   if (pb.done) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -1082,7 +1085,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   const bool fused_stage = contig_c && contig_s;
   const float4* src_c = fused_stage ? in[0].less_sharp : nullptr;
   const float4* src_s = fused_stage ? in[0].less_flat : nullptr;
-  bool late_pending = late;
+  bool late_pending = late, patch_pending = false;
   auto resolve_late = [&]() {
     if (!late_pending) return;
     late_pending = false;
@@ -1094,9 +1097,14 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
     h_cur_off_[ns + 1] = h_cur_off_[ns] + n;
     n_all = h_cur_off_[K];
     src_s = p;   // (ns == 1: contiguous by construction, the re-projection reads the cloud where it lies)
+    patch_pending = true;   // the offsets again, now complete: with the next correspondence launch, or by a copy in front of the tail
+  };
+  auto flush_patch = [&]() {
+    if (!patch_pending) return;
+    patch_pending = false;
     h_off_late_.reserve(K + 1);
     memcpy(h_off_late_.p, h_cur_off_.data(), sizeof(uint32_t) * (K + 1));
-    LX_HIP(hipMemcpyAsync(d_cur_off_.p, h_off_late_.p, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st_));   // the offsets again, now complete
+    LX_HIP(hipMemcpyAsync(d_cur_off_.p, h_off_late_.p, sizeof(uint32_t) * (K + 1), hipMemcpyHostToDevice, st_));
     LX_HIP(hipEventRecord(ev_up_, st_));   // (the next call waits for this copy too before it rewrites the pinned blocks)
   };
   if (fused_stage) {
@@ -1206,7 +1214,10 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
           for (int e = 0; e < 3; e++) if (!lt->ev[3 * lk + e]) LX_HIP(hipEventCreate(&lt->ev[3 * lk + e]));
           LX_HIP(hipEventRecord(lt->ev[3 * lk], st_));
         }
-        hipLaunchKernelGGL(k_odom_corr_grid, dim3(8 * (((max_sharp + 7) / 8 + (max_flat + 7) / 8 + 3) / 4), na), dim3(256), 0, st_, prob_.p, params);
+        uint32_t* pd = nullptr;
+        uint4 pv = make_uint4(0u, 0u, 0u, 0u);
+        if (patch_pending) { patch_pending = false; pd = d_cur_off_.p; pv = make_uint4(h_cur_off_[0], h_cur_off_[1], h_cur_off_[2], 0u); }   // (ns == 1: K + 1 = 3 words)
+        hipLaunchKernelGGL(k_odom_corr_grid, dim3(8 * (((max_sharp + 7) / 8 + (max_flat + 7) / 8 + 3) / 4), na), dim3(256), 0, st_, prob_.p, params, pd, pv);
         if (lk >= 0) LX_HIP(hipEventRecord(lt->ev[3 * lk + 1], st_));
       };
       auto enqueue_lm = [&](int k) {
@@ -1305,6 +1316,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   // right behind the iterations; the host only waits for the poses
   static const bool fuse_bounds = !(diag_env("LOAMX_BB_FUSED") && atoi(diag_env("LOAMX_BB_FUSED")) == 0);   // diagnostic: 0 = separate k_bb_bbox launch
   resolve_late();   // (a sweep without iterations: the tail is the first reader)
+  flush_patch();    // (no correspondence launch took the completed offsets along)
   if (n_all)
   {
     if (++rf_epoch_ > 255u) rf_epoch_ = 1u;   // entries of this re-projection carry the new epoch; the problems of the NEXT call name it

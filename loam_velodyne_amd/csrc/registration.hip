@@ -1419,7 +1419,10 @@ bool Registrar::run_iterations(bool trace, double& th2, double& th3) {
   bool waited = false, spec_full = false, all_done = false;
   const int maxit = params.max_iterations;
   const bool want_full = n_full_ && !defer_full;
-  int chunk = early_exit ? std::min(std::max(pred_iters_ + 1, 2), maxit) : maxit;
+  // (LOAMX_GN_AHEAD, diagnostic: launches enqueued beyond the previous call's need — 1 by default; a launch over converged sweeps costs ~4 us
+  // of the stream, a host round trip for a launch that turns out to be missing ~20)
+  static const int ahead = diag_env("LOAMX_GN_AHEAD") ? std::max(0, atoi(diag_env("LOAMX_GN_AHEAD"))) : 1;
+  int chunk = early_exit ? std::min(std::max(pred_iters_ + ahead, 2), maxit) : maxit;
   while (it < maxit) {
     const int end = std::min(maxit, it + chunk);
     for (; it < end; it++) {

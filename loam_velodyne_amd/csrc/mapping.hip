@@ -12,6 +12,7 @@
 // Host: closed-form pose prediction (:103-167), cube window + field-of-view selection (:300-500), transformUpdate.
 #include "registration.hpp"
 #include "api_handles.h"
+#include "pinned_copy.hpp"
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -650,10 +651,18 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     }
   };
   std::unique_ptr<FrontDone> front(new FrontDone{helper});
+  static const bool htrace = getenv("LOAMX_MAP_TRACE") != nullptr;   // (helper-side stamps: a job slower than 1 ms says where it spent its time)
+  double hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hs[0] = htrace ? MapTrace::now() : 0.0;
   LX_HIP(hipSetDevice(cfg.device));
   const uint32_t n_sub[2] = {n_sub0, n_sub1}, n_in[2] = {n_in0, n_in1};
+  // (trace only: which call of the update's enqueue took longest — a job that needs milliseconds to ENQUEUE is a call that blocked)
+  double ht_prev = hs[0], ht_worst = 0;
+  const char* ht_what = "";
+  auto HT = [&](const char* what) { if (htrace) { const double n = MapTrace::now(); if (n - ht_prev > ht_worst) { ht_worst = n - ht_prev; ht_what = what; } ht_prev = n; } };
   LX_HIP(hipStreamWaitEvent(st2, ev_fork, 0));
   LX_HIP(hipStreamWaitEvent(st3, ev_fork, 0));
+  HT("stream waits");
   for (int t = 1; t >= 0; t--) {   // (the surf map first: its chain is the longer one, and the host needs ~80 us to enqueue either)
     TypeMap& T = tm[t];
     hipStream_t st = t == 0 ? st2 : st3;
@@ -672,19 +681,25 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
     } else {
       LX_HIP(hipMemsetAsync(T.counters.p + 4, 0, sizeof(uint32_t) * 2, st));
     }
+    HT("k_map_insert");
     const uint32_t nslots = (uint32_t)std::max(nvalid, 1);
     const float inv = 1.0f / (t == 0 ? cfg.corner_filter_size : cfg.surf_filter_size);
     T.vox.compute_ijk(T.fin.p, T.fin_valid.p, n_fin, nullptr, nslots, inv, inv, T.fin_seg.p);
+    HT("compute_ijk");
     T.vox.sort_reduce(T.fin.p, T.fin_valid.p, n_fin, nullptr, nslots, T.filt.p, T.out_off.p, T.fin_seg.p);
+    HT("sort_reduce");
     const uint32_t max_f = n_fin ? n_fin : 1;
     hipLaunchKernelGGL(k_map_append_filtered, dim3((max_f + 255) / 256), dim3(256), 0, st, T.filt.p, T.out_off.p, nslots, slot_tag_v,
                        max_f, T.counters.p + 3, T.counters.p + 5, T.pts[nxt].p, T.tags[nxt].p, T.counters.p + 6, T.hist.p);
     const uint32_t max_new = T.n + n_slots + 1;
     hipLaunchKernelGGL(k_map_hist, dim3(std::min<uint32_t>((max_new + 2047) / 2048, 256u)), dim3(256), 0, st, T.tags[nxt].p, T.counters.p + 6, max_new, w, T.hist.p);
-    LX_HIP(hipMemcpyAsync(T.h_hist.p, T.hist.p, sizeof(uint32_t) * (MCUBES + 16), hipMemcpyDeviceToHost, st));   // (histogram + the counters behind it: one copy)
+    HT("append + hist");
+    store_to_pinned_u32(T.h_hist.p, T.hist.p, MCUBES + 16, st);   // (histogram + the counters behind it, by a kernel: pinned_copy.hpp — the copy call blocked for milliseconds now and then)
+    HT("histogram copy");
   }
   static const bool trace = getenv("LOAMX_MAP_TRACE") != nullptr;
   const double t0 = trace ? MapTrace::now() : 0.0;
+  hs[1] = t0;   // update enqueued
   if (surround_due) complete_update();
   const double t1 = trace ? MapTrace::now() : 0.0;
   // (the surround cloud is cut LAST, behind the prepared partition: the next sweep waits for the partition, not for the cloud — round 6; the
@@ -692,12 +707,14 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
   const uint8_t* sur_lut_now = sur_lut_v;
   if (speculate) {   // the next sweep's partition + index for the predicted pose (see spec_plan)
     complete_update();
+    hs[2] = htrace ? MapTrace::now() : 0.0;   // update complete
     SpecInputs in;
     {
       std::unique_lock<std::mutex> lk(helper.mu);
       helper.cv.wait(lk, [this]() { return spec_in.ready; });
       in = spec_in;
     }
+    hs[3] = htrace ? MapTrace::now() : 0.0;   // the caller's results are in
     if (in.ok) {
       float p6[6];
       for (int k = 0; k < 6; k++) p6[k] = in.sum6[k] + (in.sum6[k] - in.sum_prev6[k]);
@@ -714,6 +731,10 @@ int Mapper::process(const loamx_cloud* corner_last, const loamx_cloud* surf_last
       }
     }
   }
+  hs[4] = htrace ? MapTrace::now() : 0.0;     // partition prepared (enqueued)
+  if (htrace && hs[4] - hs[0] > 1000.0)
+    fprintf(stderr, "[map trace, slow helper job] update enqueued %.0f us (longest call: %s, %.0f us), update complete %.0f, caller's results in %.0f, partition prepared %.0f\n",
+            hs[1] - hs[0], ht_what, ht_worst, hs[2] ? hs[2] - hs[0] : -1.0, hs[3] ? hs[3] - hs[0] : -1.0, hs[4] - hs[0]);
   front.reset();   // the next process() call may start
   if (surround_due) {
     const double t2 = trace ? MapTrace::now() : 0.0;
@@ -902,7 +923,7 @@ void Mapper::compute_surround(const MapWindow& w, const uint8_t* sur_lut) {
     LX_HIP(hipMemcpyAsync(sur_off.p, h_sur.p, sizeof(uint32_t) * 2, hipMemcpyHostToDevice, st));
     sur_vox.compute_ijk(sur_in.p, sur_valid.p, ntot, sur_off.p, 1, inv, inv);
     sur_vox.sort_reduce(sur_in.p, sur_valid.p, ntot, sur_off.p, 1, sur_out.p, sur_off.p + 2);
-    LX_HIP(hipMemcpyAsync(h_sur.p + 2, sur_off.p + 2, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, st));
+    store_to_pinned_u32(h_sur.p + 2, sur_off.p + 2, 2, st);
     if (trace) tq1 = MapTrace::now();
     LX_HIP(hipStreamSynchronize(st));
     if (trace && MapTrace::now() - tq0 > 600.0) fprintf(stderr, "[map trace, surround] enqueue %.1f us, wait %.1f us (%u points)\n", tq1 - tq0, MapTrace::now() - tq1, ntot);

@@ -26,4 +26,23 @@ inline void fetch_from_pinned(float4* dst, const void* host_src, size_t n, hipSt
   LX_HIP(hipMemcpyAsync(dst, host_src, sizeof(float4) * n, hipMemcpyHostToDevice, st));
 }
 
+// Device -> host of a few KB of 32-bit words by a kernel that stores into the pinned block (visible to the host once the stream has passed
+// the launch).  Round 6: the sequential-SLAM chain's 19 KB cube histogram went down by hipMemcpyAsync, and that call BLOCKED the calling
+// thread for 6.5-9 ms once at the start of every process and again every few hundred sweeps (LOAMX_MAP_TRACE, profiles/r06_ab.md
+// section 16) — the "slow window" of the sequential figures.
+__global__ __launch_bounds__(256) static void k_store_pinned_u32(uint32_t* __restrict__ host_dst, const uint32_t* __restrict__ src, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) host_dst[i] = src[i];
+}
+inline void store_to_pinned_u32(uint32_t* host_dst, const uint32_t* src, size_t n, hipStream_t st) {
+  if (!n) return;
+  void* d = nullptr;
+  if (n <= ((size_t)1 << 20) && hipHostGetDevicePointer(&d, host_dst, 0) == hipSuccess && d) {
+    hipLaunchKernelGGL(k_store_pinned_u32, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (uint32_t*)d, src, (uint32_t)n);
+    return;
+  }
+  (void)hipGetLastError();
+  LX_HIP(hipMemcpyAsync(host_dst, src, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
+}
+
 }  // namespace loamx

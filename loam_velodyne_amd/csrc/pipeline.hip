@@ -5,6 +5,7 @@
 // across GPUs; every stream keeps the reference's sequential semantics (its odometry state, its
 // transformBefMapped / transformAftMapped), only the map is frozen for the epoch.  All device work of a step runs on one
 // HIP stream with inputs resident in HBM; the host touches only offsets and 6-float poses between the stages.
+#include "pinned_copy.hpp"
 #include "features.hpp"
 #include "odometry.hpp"
 #include "registration.hpp"
@@ -370,7 +371,7 @@ class Pipeline {
     // (the four offset tables lie back to back on the device in exactly this host layout: one copy)
     (void)ho; (void)hlf;
     LX_REQUIRE(F.n_offsets() == 3 * (ns + 1) + nring + 1, "internal: offset table layout");
-    LX_HIP(hipMemcpyAsync(hb.p, F.d_offsets(), sizeof(uint32_t) * F.n_offsets(), hipMemcpyDeviceToHost, fstream));
+    store_to_pinned_u32(hb.p, F.d_offsets(), F.n_offsets(), fstream);   // (by a kernel: a small device-to-host hipMemcpyAsync blocks its caller for milliseconds now and then — pinned_copy.hpp)
     LX_HIP(hipEventRecord(evF[t % OR][1], fstream));
     LA(t) = 1;
   }

@@ -23,8 +23,27 @@ struct Error : std::runtime_error {
   int code;
   Error(int c, const std::string& s) : std::runtime_error(s), code(c) {}
 };
+// -DLOAMX_API_TRACE (diagnostic build): every runtime call made through LX_HIP and every kernel launch is timed on the host; one that
+// takes longer than 300 us — and is not a wait by its name — is reported on stderr with its place.  How round 6 found the copies that
+// blocked their callers for milliseconds (profiles/r06_ab.md section 16).
+#ifdef LOAMX_API_TRACE
+struct ApiTimer {
+  const char* what; const char* file; int line;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  ApiTimer(const char* w, const char* f, int l) : what(w), file(f), line(l) {}
+  ~ApiTimer() {
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (us > 300.0 && !strstr(what, "Synchronize") && !strstr(what, "Malloc") && !strstr(what, "Free") && !strstr(what, "hipGetDeviceProperties") && !strstr(what, "Occupancy"))
+      fprintf(stderr, "[api trace] %.0f us in %.80s (%s:%d)\n", us, what, file, line);
+  }
+};
+#define LX_API_TIMER(what) ::loamx::ApiTimer api_timer_(what, __FILE__, __LINE__)
+#else
+#define LX_API_TIMER(what) do { } while (0)
+#endif
 #define LX_HIP(expr)                                                                                         \
   do {                                                                                                       \
+    LX_API_TIMER(#expr);                                                                                     \
     hipError_t e_ = (expr);                                                                                  \
     if (e_ != hipSuccess)                                                                                    \
       throw ::loamx::Error(LOAMX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + \
@@ -253,3 +272,12 @@ inline hipStream_t create_stream(int rel_priority, int cu_stride = 0, int part =
 }
 
 }  // namespace loamx
+
+#ifdef LOAMX_API_TRACE
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                 \
+  do {                                                      \
+    LX_API_TIMER(#kernelName);                              \
+    hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);  \
+  } while (0)
+#endif

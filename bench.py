@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 STREAMS_PER_GPU = 8
-TIMING_PERIOD = 4         # every 4th step of the timed region carries the HIP-event timing (stage chains, k_gn_iter launches)
+TIMING_PERIOD = 10        # every 10th step of the timed region carries the HIP-event timing (stage chains, k_gn_iter / odometry launches); every 4th cost 2.4 % of the window, every 10th nothing measurable (profiles/r06_ab.md section 17)
 HANDLES_PER_GPU = 1      # >1: split the streams over several pipeline handles driven from host threads (measured: no gain)
 SENSOR = "HDL-64E"
 MAP_POINTS = 1_000_000
@@ -346,8 +346,8 @@ def main():
                     tok = merger.take_ready()
                     if tok is not None:   # a merged map has arrived: index it in the background now, swap it in at the next boundary
                         p.stage_frozen_device(*tok)
-                # HIP-event timing (stage chains + a pair around every Gauss-Newton launch) on every 4th step only: the event pairs and
-                # their read-back (event synchronise, a statistics download) cost ~4 % of a step
+                # HIP-event timing (stage chains + a pair around every Gauss-Newton / odometry launch) on every TIMING_PERIOD-th step only:
+                # a sampled step is ~10 % slower (event records between dependent launches, their read-back)
                 sampled = (t - (1 + W)) % period == 0
                 p.set_timing(sampled)
                 tc0 = time.perf_counter()
@@ -702,7 +702,7 @@ def main():
                          "forms the 28 normal-equation sums and runs the 6x6 update step",
                 "avg_launch_us": round(avg_launch_ms * 1e3, 3),
                 "launches": res_launches,
-                "launch_sampling": f"HIP-event pairs around every k_gn_iter launch on every {TIMING_PERIOD}th step of the timed region (the pairs and their read-back cost ~4 % of a step)",
+                "launch_sampling": f"HIP-event pairs around every k_gn_iter launch on every {TIMING_PERIOD}th step of the timed region (a sampled step is ~10 % slower: event records between dependent launches)",
                 "algorithmic_bytes_per_launch": round(72.0 * q_iters_timed / max(res_launches, 1), 1),
             },
         }
@@ -850,7 +850,7 @@ def live_block(sensor, M, K, W, cpu=True, nodes=True):
             if t == 1 + W:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-            sampled = t >= 1 + W and (t - (1 + W)) % TIMING_PERIOD == 0   # HIP-event pairs around the registration's launches on every 4th sweep only (as in the batched mode)
+            sampled = t >= 1 + W and (t - (1 + W)) % TIMING_PERIOD == 0   # HIP-event pairs around the registration's launches on every TIMING_PERIOD-th sweep only (as in the batched mode)
             top = time.perf_counter()
             mp.set_timing(sampled)
             a = time.perf_counter()

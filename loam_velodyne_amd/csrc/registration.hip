@@ -1025,6 +1025,17 @@ __global__ __launch_bounds__(256) void k_gather_segments(float4* __restrict__ ds
   dst[i] = src[k][i - off[k]];
 }
 
+// One sweep (the sequential entry points): its full-resolution cloud is ONE range, and the parameter block of the call (guess, offsets,
+// source pointers: 72 bytes) fits the kernel's arguments — thread 0..17 of the first workgroup write it for the kernels behind this one,
+// the launch replaces the block's copy command AND k_gather_segments (one dependent launch less at the head of every sweep's mapping)
+struct ParamBlock1 { uint32_t w[18]; };
+__global__ __launch_bounds__(256) void k_gather_one(float4* __restrict__ dst, const float4* __restrict__ src, uint32_t n, ParamBlock1 blk,
+                                                    uint32_t* __restrict__ blk_dst) {
+  if (blockIdx.x == 0 && threadIdx.x < 18) blk_dst[threadIdx.x] = blk.w[threadIdx.x];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // Registrar (host)
 // ----------------------------------------------------------------------------------------------------------------
@@ -1290,14 +1301,18 @@ void Registrar::upload_device(uint32_t n_sweeps, const float4* const* corner_las
   const float4** hsrc = (const float4**)(h_blob_.p + o_src);
   for (uint32_t s = 0; s < n_sweeps; s++) { hsrc[2 * s] = corner_last[s]; hsrc[2 * s + 1] = surf_last[s]; }
   for (uint32_t s = 0; s < n_sweeps; s++) hsrc[nseg + s] = full_res ? full_res[s] : nullptr;
-  LX_HIP(hipMemcpyAsync(blob_.p, h_blob_.p, bytes, hipMemcpyHostToDevice, st_));
   d_guess_ = (const float*)blob_.p;
   d_seg_off_ = (const uint32_t*)(blob_.p + o_off);
   d_full_off_ = (const uint32_t*)(blob_.p + o_full);
   d_src_ = (const float4* const*)(blob_.p + o_src);
-  if (n_full_) {
-    full_.reserve(n_full_);
-    if (!staged)
+  if (n_full_) full_.reserve(n_full_);
+  if (n_sweeps == 1 && n_full_ && !staged && bytes == sizeof(ParamBlock1)) {   // the block travels in the gather's arguments (k_gather_one)
+    ParamBlock1 pb1;
+    memcpy(pb1.w, h_blob_.p, sizeof(pb1));
+    hipLaunchKernelGGL(k_gather_one, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, full_res[0], n_full_, pb1, (uint32_t*)blob_.p);
+  } else {
+    LX_HIP(hipMemcpyAsync(blob_.p, h_blob_.p, bytes, hipMemcpyHostToDevice, st_));
+    if (n_full_ && !staged)
       hipLaunchKernelGGL(k_gather_segments, dim3((n_full_ + 255) / 256), dim3(256), 0, st_, full_.p, d_full_off_, n_sweeps, d_src_ + nseg,
                          n_full_);
   }

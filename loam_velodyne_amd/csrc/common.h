@@ -224,6 +224,13 @@ inline void spin_event(hipEvent_t ev, int spin_ms = 4) {   // the same for an ev
   LX_HIP(hipEventSynchronize(ev));
 }
 
+// The steady-state waits of the chains (the odometry's pose event, the features' event in front of a pass, the registration's results):
+// polling for up to 4 ms before they block (spin_event / spin_sync) — +1-1.5 % on the sequential chain, neutral on the batched one;
+// LOAMX_WAIT_SPIN=0: the runtime's blocking waits (profiles/r06_ab.md section 20)
+inline bool wait_spins() { static const bool on = !(getenv("LOAMX_WAIT_SPIN") != nullptr && atoi(getenv("LOAMX_WAIT_SPIN")) == 0); return on; }
+inline void wait_event(hipEvent_t ev) { if (wait_spins()) spin_event(ev); else LX_HIP(hipEventSynchronize(ev)); }
+inline void wait_stream(hipStream_t st) { if (wait_spins()) spin_sync(st); else LX_HIP(hipStreamSynchronize(st)); }
+
 // HIP stream with a relative priority: +1 = highest the device offers, 0 = default, -1 = lowest.  The stages of the
 // pipeline run on streams of their own; the latency-critical ones (registration, odometry) outrank feature extraction,
 // whose wide kernels would otherwise delay their short dependent launches.

@@ -1339,7 +1339,7 @@ void OdometryBatch::process(const OdomInput* in, int* rc, bool defer_tail) {
   LX_HIP(hipEventRecord(ev_tail_, st_));
   tail_pending_ = true;
   if (na) {
-    LX_HIP(hipEventSynchronize(ev_pose_));
+    wait_event(ev_pose_);
     if (*(volatile uint32_t*)h_err_.p) {   // k_odom_lm's exchange timed out (its workgroups were not all resident)
       *h_err_.p = 0u;
       throw Error(LOAMX_E_HIP, "odometry: the exchange between a stream's k_odom_lm workgroups timed out (not all of them resident)");

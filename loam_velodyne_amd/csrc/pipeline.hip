@@ -674,7 +674,7 @@ class Pipeline {
     uint32_t* hb = h_off3[t % OR].p;
     uint32_t* ho[3] = {hb, hb + (ns + 1), hb + 2 * (ns + 1)};
     uint32_t* hlf = hb + 3 * (ns + 1);
-    LX_HIP(hipEventSynchronize(evF[t % OR][1]));
+    wait_event(evF[t % OR][1]);
     F.check_finite_input();   // (LOAMX_E_INVALID out of step(): a staged sweep with NaN / Inf coordinates)
     c.tr[1] = tr_us();
     const bool timed = timing.load(std::memory_order_relaxed);   // latched: the caller flips the flag while this chain runs steps ahead

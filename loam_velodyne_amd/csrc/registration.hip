@@ -1676,7 +1676,7 @@ void Registrar::xrec_stress(uint32_t pairs, uint32_t rounds, unsigned long long 
   LX_HIP(hipStreamSynchronize(st_));
 }
 
-void Registrar::sync() { LX_HIP(hipStreamSynchronize(st_)); }
+void Registrar::sync() { wait_stream(st_); }
 
 // final poses / statistics on the host: an early-exit run that saw every sweep converge already holds them (the update
 // step mirrors them into pinned memory), anything else is copied
@@ -1749,7 +1749,7 @@ int Registrar::download_full_res(uint32_t sweep, loamx_cloud* out) {
   }
   full_dl_sweep_ = -1;
   full_dl_direct_ = nullptr;
-  LX_HIP(hipStreamSynchronize(st_));
+  wait_stream(st_);
   if (landed) { out->count = b - a; return LOAMX_OK; }
   return unpack_cloud(h_full_dl_.p, b - a, out);
 }

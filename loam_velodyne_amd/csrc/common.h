@@ -225,9 +225,10 @@ inline void spin_event(hipEvent_t ev, int spin_ms = 4) {   // the same for an ev
 }
 
 // The steady-state waits of the chains (the odometry's pose event, the features' event in front of a pass, the registration's results):
-// polling for up to 4 ms before they block (spin_event / spin_sync) — +1-1.5 % on the sequential chain, neutral on the batched one;
-// LOAMX_WAIT_SPIN=0: the runtime's blocking waits (profiles/r06_ab.md section 20)
-inline bool wait_spins() { static const bool on = !(getenv("LOAMX_WAIT_SPIN") != nullptr && atoi(getenv("LOAMX_WAIT_SPIN")) == 0); return on; }
+// the runtime's blocking waits by default; LOAMX_WAIT_SPIN=1: polling for up to 4 ms before they block (spin_event / spin_sync) — +1-1.5 %
+// on the sequential chain in a process of its own, neutral on the batched one, but -3 % on the HDL-32 chain beside busy host cores (the
+// bench's child processes): profiles/r06_ab.md section 20
+inline bool wait_spins() { static const bool on = getenv("LOAMX_WAIT_SPIN") != nullptr && atoi(getenv("LOAMX_WAIT_SPIN")) != 0; return on; }
 inline void wait_event(hipEvent_t ev) { if (wait_spins()) spin_event(ev); else LX_HIP(hipEventSynchronize(ev)); }
 inline void wait_stream(hipStream_t st) { if (wait_spins()) spin_sync(st); else LX_HIP(hipStreamSynchronize(st)); }
 
